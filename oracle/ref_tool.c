@@ -1,0 +1,394 @@
+/*
+ * oracle/ref_tool.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A small driver of OUR OWN that calls the genuine reference (femto-dev/femto v1.3.0,
+ * compiled by oracle/Makefile from /root/reference where it lies) through its own API:
+ *
+ *   build   : init_prepared_text / count_file / append_file_mem (src/main/bwt_prepare.c:115,192,227)
+ *             -> save_prepared_bwt (src/main/bwt_creator.c:36, Larsson qsufsort test sorter)
+ *             -> bwt_reader_open -> index_documents(map=NULL) (src/main/construct.c:572)
+ *   dump    : open_header_block / open_data_block, header_occs_request, block_request
+ *             (src/main/index.h:366-394) for every row: L[row], Occ(L[row],row), mark offset
+ *   count   : parallel_count  (src/main/femto.c:275)
+ *   locate  : parallel_locate (src/main/femto.c:331)
+ *   bench   : the same two calls, timed (wall clock of the batch call only)
+ *   bseq    : bseq_construct_forcetype (src/main/wtree.c:365) -> encoded image
+ *   flatten : flatten_index (src/main/index.c:2260)
+ *
+ * Nothing here is part of the product; the product never links or executes this file.
+ *
+ * Pattern file ("FPAT", native little-endian): u32 magic 0x54415046, u32 npats,
+ * i32 len[npats], then sum(len) alpha_t (u16 = byte+5) codes.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include <time.h>
+#include <sys/stat.h>
+
+#include "index.h"
+#include "femto_internal.h"
+#include "construct.h"
+#include "bwt_prepare.h"
+#include "bwt_creator.h"
+#include "bwt_reader.h"
+#include "server.h"
+#include "timing.h"
+#include "wtree_funcs.h"
+
+#define FPAT_MAGIC 0x54415046u
+
+static double now_s(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+static void die(const char* what, error_t err)
+{
+  fprintf(stderr, "ref_tool: %s failed", what);
+  if (err) fprintf(stderr, ": %s", err_string(err));
+  fprintf(stderr, "\n");
+  exit(2);
+}
+
+static unsigned char* slurp(const char* path, int64_t* len)
+{
+  FILE* f = fopen(path, "rb");
+  if (!f) { perror(path); exit(2); }
+  fseek(f, 0, SEEK_END);
+  *len = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  unsigned char* d = malloc(*len ? *len : 1);
+  if (*len && fread(d, 1, *len, f) != (size_t)*len) { perror("fread"); exit(2); }
+  fclose(f);
+  return d;
+}
+
+typedef struct {
+  int npats;
+  int* plen;
+  alpha_t** pats;
+  alpha_t* storage;
+} patset_t;
+
+static patset_t read_patterns(const char* path)
+{
+  patset_t ps;
+  int64_t len;
+  unsigned char* d = slurp(path, &len);
+  uint32_t* w = (uint32_t*)d;
+  if (len < 8 || w[0] != FPAT_MAGIC) { fprintf(stderr, "bad pattern file %s\n", path); exit(2); }
+  ps.npats = (int)w[1];
+  ps.plen = malloc(sizeof(int) * (ps.npats + 1));
+  ps.pats = malloc(sizeof(alpha_t*) * (ps.npats + 1));
+  memcpy(ps.plen, d + 8, sizeof(int) * ps.npats);
+  ps.storage = (alpha_t*)(d + 8 + 4 * (size_t)ps.npats);
+  size_t off = 0;
+  for (int i = 0; i < ps.npats; i++) {
+    ps.pats[i] = ps.storage + off;
+    off += ps.plen[i];
+  }
+  return ps;
+}
+
+/* build <index_dir> <params|-> <doc files...>   (params e.g. "block_size=65536,bucket_size=8192,mark_period=20") */
+static int cmd_build(int argc, char** argv)
+{
+  if (argc < 3) { fprintf(stderr, "build <index_dir> <params|-> <doc>...\n"); return 2; }
+  const char* index_dir = argv[0];
+  const char* params = argv[1];
+  int ndocs = argc - 2;
+  error_t err;
+  index_block_param_t param;
+  prepared_text_t p;
+  char info_path[4096];
+  char bwt_path[4096];
+
+  set_default_param(&param);
+  if (strcmp(params, "-") != 0) {
+    err = parse_param(&param, params);
+    if (err) die("parse_param", err);
+  }
+  mkdir(index_dir, 0777);
+  snprintf(info_path, sizeof info_path, "%s/_build_info.tmp", index_dir);
+  snprintf(bwt_path, sizeof bwt_path, "%s/_build_bwt.tmp", index_dir);
+
+  err = init_prepared_text(&p, info_path);
+  if (err) die("init_prepared_text", err);
+
+  unsigned char** docs = malloc(sizeof(char*) * ndocs);
+  int64_t* lens = malloc(sizeof(int64_t) * ndocs);
+  for (int i = 0; i < ndocs; i++) {
+    docs[i] = slurp(argv[2 + i], &lens[i]);
+    err = count_file(&p, lens[i], 0, NULL, strlen(argv[2 + i]), (unsigned char*)argv[2 + i]);
+    if (err) die("count_file", err);
+  }
+  for (int i = 0; i < ndocs; i++) {
+    err = append_file_mem(&p, lens[i], docs[i], 0, NULL, NULL,
+                          strlen(argv[2 + i]), (unsigned char*)argv[2 + i]);
+    if (err) die("append_file_mem", err);
+  }
+
+  double t0 = now_s();
+  FILE* bf = fopen(bwt_path, "w+");
+  if (!bf) { perror(bwt_path); return 2; }
+  start_clock(); /* save_prepared_bwt stops one clock more than it starts (bwt_creator.c:128) */
+  err = save_prepared_bwt(&p, param.mark_period, bf, 0, NULL, 0);
+  if (err) die("save_prepared_bwt", err);
+  double t1 = now_s();
+  rewind(bf);
+
+  bwt_reader_t bwt;
+  err = bwt_reader_open(&bwt, bf);
+  if (err) die("bwt_reader_open", err);
+  err = index_documents(&bwt, NULL, &p.info_reader, &param, index_dir, NULL);
+  if (err) die("index_documents", err);
+  bwt_reader_close(&bwt);
+  double t2 = now_s();
+  free_prepared_text(&p);
+  remove(info_path);
+  remove(bwt_path);
+  printf("{\"bwt_s\": %.3f, \"index_s\": %.3f}\n", t1 - t0, t2 - t1);
+  return 0;
+}
+
+/* dump <index> <out.bin>: i64 total_length, i64 nblocks, i64 C[262], i64 block_occs[261*nblocks],
+   then per row: u16 L, i32 occ_in_block(L[row],row) , i64 offset   (packed arrays, one after another) */
+static int cmd_dump(int argc, char** argv)
+{
+  if (argc < 2) return 2;
+  error_t err;
+  path_translator_t pt;
+  index_locator_t loc;
+  header_block_t hb;
+  memset(&pt, 0, sizeof pt);
+  err = path_translator_init(&pt);
+  if (err) die("path_translator_init", err);
+  err = path_translator_id_for_path(&pt, argv[0], &loc);
+  if (err) die("id_for_path", err);
+  err = open_header_block(&hb, &pt, loc);
+  if (err) die("open_header_block", err);
+
+  int64_t n = hb.hdr.total_length, nblocks = hb.hdr.number_of_blocks;
+  FILE* out = fopen(argv[1], "wb");
+  fwrite(&n, 8, 1, out);
+  fwrite(&nblocks, 8, 1, out);
+  for (int ch = 0; ch <= ALPHA_SIZE; ch++) {
+    header_occs_request_t r; memset(&r, 0, sizeof r);
+    r.ch = ch;
+    err = header_occs_request(&hb, HDR_REQUEST_C, &r);
+    if (err) die("HDR_REQUEST_C", err);
+    fwrite(&r.occs, 8, 1, out);
+  }
+  for (int ch = 0; ch < ALPHA_SIZE; ch++)
+    for (int64_t b = 0; b < nblocks; b++) {
+      header_occs_request_t r; memset(&r, 0, sizeof r);
+      r.ch = ch; r.block_num = b;
+      err = header_occs_request(&hb, HDR_REQUEST_BLOCK_OCCS, &r);
+      if (err) die("HDR_REQUEST_BLOCK_OCCS", err);
+      fwrite(&r.occs, 8, 1, out);
+    }
+  uint16_t* L = malloc(2 * n);
+  int32_t* occ = malloc(4 * n);
+  int64_t* off = malloc(8 * n);
+  int64_t row = 0;
+  for (int64_t b = 0; b < nblocks; b++) {
+    data_block_t blk;
+    err = open_data_block(&blk, &pt, loc, b, 4);
+    if (err) die("open_data_block", err);
+    for (int r = 0; r < blk.hdr.size; r++, row++) {
+      block_request_t q; memset(&q, 0, sizeof q);
+      q.row_in_block = r; q.ch = INVALID_ALPHA;
+      err = block_request(&blk, BLOCK_REQUEST_CHAR | BLOCK_REQUEST_OCCS | BLOCK_REQUEST_LOCATION, &q);
+      if (err) die("block_request", err);
+      L[row] = q.ch; occ[row] = q.occs_in_block; off[row] = q.offset;
+    }
+    close_data_block(&blk);
+  }
+  fwrite(L, 2, n, out); fwrite(occ, 4, n, out); fwrite(off, 8, n, out);
+  fclose(out);
+  close_header_block(&hb);
+  return 0;
+}
+
+/* occs <index> <ch> <out.bin>: i32 Occ-in-block(ch,row) for every row (BLOCK_REQUEST_OCCS) */
+static int cmd_occs(int argc, char** argv)
+{
+  if (argc < 3) return 2;
+  error_t err;
+  path_translator_t pt;
+  index_locator_t loc;
+  header_block_t hb;
+  int ch = atoi(argv[1]);
+  memset(&pt, 0, sizeof pt);
+  err = path_translator_init(&pt);
+  if (err) die("path_translator_init", err);
+  err = path_translator_id_for_path(&pt, argv[0], &loc);
+  if (err) die("id_for_path", err);
+  err = open_header_block(&hb, &pt, loc);
+  if (err) die("open_header_block", err);
+  int64_t nblocks = hb.hdr.number_of_blocks;
+  FILE* out = fopen(argv[2], "wb");
+  for (int64_t b = 0; b < nblocks; b++) {
+    data_block_t blk;
+    err = open_data_block(&blk, &pt, loc, b, 4);
+    if (err) die("open_data_block", err);
+    for (int r = 0; r < blk.hdr.size; r++) {
+      block_request_t q; memset(&q, 0, sizeof q);
+      q.row_in_block = r; q.ch = ch;
+      err = block_request(&blk, BLOCK_REQUEST_OCCS, &q);
+      if (err) die("block_request", err);
+      int32_t v = q.occs_in_block;
+      fwrite(&v, 4, 1, out);
+    }
+    close_data_block(&blk);
+  }
+  fclose(out);
+  return 0;
+}
+
+static femto_server_t start_srv(int threads)
+{
+  femto_server_t srv;
+  server_settings_t settings;
+  error_t err = set_default_server_settings(&settings);
+  if (err) die("set_default_server_settings", err);
+  if (threads > 0) settings.num_threads = threads;  /* default is the reference's hard-wired 1 (server.c:3597) */
+  err = start_server(&srv.state, &settings);
+  if (err) die("start_server", err);
+  return srv;
+}
+
+/* count <index> <patfile> <out.bin>: i64 first[n], i64 last[n] */
+static int cmd_count(int argc, char** argv)
+{
+  if (argc < 3) return 2;
+  femto_server_t srv = start_srv(0);
+  index_locator_t loc;
+  error_t err = femto_loc_for_path_err(&srv, argv[0], &loc);
+  if (err) die("femto_loc_for_path_err", err);
+  patset_t ps = read_patterns(argv[1]);
+  int64_t* first = calloc(ps.npats + 1, 8);
+  int64_t* last = calloc(ps.npats + 1, 8);
+  err = parallel_count(&srv, loc, ps.npats, ps.plen, ps.pats, first, last);
+  if (err) die("parallel_count", err);
+  FILE* out = fopen(argv[2], "wb");
+  fwrite(first, 8, ps.npats, out);
+  fwrite(last, 8, ps.npats, out);
+  fclose(out);
+  femto_stop_server(&srv);
+  return 0;
+}
+
+/* locate <index> <patfile> <max_occs> <out.bin>: i32 noccs[n], then all offsets i64 concatenated */
+static int cmd_locate(int argc, char** argv)
+{
+  if (argc < 4) return 2;
+  femto_server_t srv = start_srv(0);
+  index_locator_t loc;
+  error_t err = femto_loc_for_path_err(&srv, argv[0], &loc);
+  if (err) die("femto_loc_for_path_err", err);
+  patset_t ps = read_patterns(argv[1]);
+  int max_occs = atoi(argv[2]);
+  int* noccs = calloc(ps.npats + 1, sizeof(int));
+  int64_t** offsets = calloc(ps.npats + 1, sizeof(int64_t*));
+  err = parallel_locate(&srv, loc, ps.npats, ps.plen, ps.pats, max_occs, noccs, offsets);
+  if (err) die("parallel_locate", err);
+  FILE* out = fopen(argv[3], "wb");
+  fwrite(noccs, 4, ps.npats, out);
+  for (int i = 0; i < ps.npats; i++)
+    if (noccs[i] > 0) fwrite(offsets[i], 8, noccs[i], out);
+  fclose(out);
+  femto_stop_server(&srv);
+  return 0;
+}
+
+/* bench <index> <patfile> <count|locate> <max_occs> <threads> <reps> */
+static int cmd_bench(int argc, char** argv)
+{
+  if (argc < 6) return 2;
+  int locate = strcmp(argv[2], "locate") == 0;
+  int max_occs = atoi(argv[3]);
+  int threads = atoi(argv[4]);
+  int reps = atoi(argv[5]);
+  femto_server_t srv = start_srv(threads);
+  index_locator_t loc;
+  error_t err = femto_loc_for_path_err(&srv, argv[0], &loc);
+  if (err) die("femto_loc_for_path_err", err);
+  patset_t ps = read_patterns(argv[1]);
+  int64_t* first = calloc(ps.npats + 1, 8);
+  int64_t* last = calloc(ps.npats + 1, 8);
+  int* noccs = calloc(ps.npats + 1, sizeof(int));
+  int64_t** offsets = calloc(ps.npats + 1, sizeof(int64_t*));
+  double best = 1e30, tot = 0;
+  int64_t results = 0;
+  /* one untimed warm-up pass pages the index in */
+  for (int rep = -1; rep < reps; rep++) {
+    double t0 = now_s();
+    if (locate) err = parallel_locate(&srv, loc, ps.npats, ps.plen, ps.pats, max_occs, noccs, offsets);
+    else err = parallel_count(&srv, loc, ps.npats, ps.plen, ps.pats, first, last);
+    double dt = now_s() - t0;
+    if (err) die("batch call", err);
+    if (locate) {
+      results = 0;
+      for (int i = 0; i < ps.npats; i++) { results += noccs[i]; free(offsets[i]); offsets[i] = NULL; }
+    } else {
+      results = 0;
+      for (int i = 0; i < ps.npats; i++) if (last[i] >= first[i]) results += last[i] - first[i] + 1;
+    }
+    if (rep >= 0) { tot += dt; if (dt < best) best = dt; }
+  }
+  printf("{\"mode\": \"%s\", \"npats\": %d, \"threads\": %d, \"reps\": %d, \"best_s\": %.6f, \"mean_s\": %.6f, "
+         "\"results\": %lld, \"patterns_per_s\": %.1f}\n",
+         locate ? "locate" : "count", ps.npats, threads > 0 ? threads : 1, reps, best, tot / reps,
+         (long long)results, ps.npats / best);
+  femto_stop_server(&srv);
+  return 0;
+}
+
+/* bseq <rawbits-file> <bitlen> <type -1|0|1> <out>: bseq_construct_forcetype (src/main/wtree.c:365) image */
+static int cmd_bseq(int argc, char** argv)
+{
+  if (argc < 4) return 2;
+  int64_t len;
+  unsigned char* raw = slurp(argv[0], &len);
+  int bitlen = atoi(argv[1]), type = atoi(argv[2]);
+  int zlen = 0; unsigned char* z = NULL;
+  error_t err = bseq_construct_forcetype(&zlen, &z, bitlen, raw, NULL, type);
+  if (err) die("bseq_construct_forcetype", err);
+  FILE* out = fopen(argv[3], "wb");
+  fwrite(z, 1, zlen, out);
+  fclose(out);
+  return 0;
+}
+
+/* flatten <index_dir> <out_file>: flatten_index (src/main/index.c:2260) */
+static int cmd_flatten(int argc, char** argv)
+{
+  if (argc < 2) return 2;
+  error_t err = flatten_index(argv[0], argv[1]);
+  if (err) die("flatten_index", err);
+  return 0;
+}
+
+int main(int argc, char** argv)
+{
+  if (argc < 2) {
+    fprintf(stderr, "usage: ref_tool build|dump|occs|count|locate|bench ...\n");
+    return 2;
+  }
+  const char* c = argv[1];
+  if (!strcmp(c, "build")) return cmd_build(argc - 2, argv + 2);
+  if (!strcmp(c, "dump")) return cmd_dump(argc - 2, argv + 2);
+  if (!strcmp(c, "occs")) return cmd_occs(argc - 2, argv + 2);
+  if (!strcmp(c, "count")) return cmd_count(argc - 2, argv + 2);
+  if (!strcmp(c, "locate")) return cmd_locate(argc - 2, argv + 2);
+  if (!strcmp(c, "bench")) return cmd_bench(argc - 2, argv + 2);
+  if (!strcmp(c, "bseq")) return cmd_bseq(argc - 2, argv + 2);
+  if (!strcmp(c, "flatten")) return cmd_flatten(argc - 2, argv + 2);
+  fprintf(stderr, "unknown command %s\n", c);
+  return 2;
+}
