@@ -145,6 +145,16 @@ void fo_bseq_rank(const unsigned char* z, int index1, int occs[2], int* bit_out,
   occs[0] = (int)o0; occs[1] = (int)o1; *bit_out = bit;
 }
 
+/* test helper: rank at every index 1..nbits -> out[3*i] = {occs0, occs1, bit} */
+void fo_bseq_rank_all(const unsigned char* z, int nbits, int64_t* out)
+{
+  for (int i = 0; i < nbits; i++) {
+    int occs[2], bit;
+    fo_bseq_rank(z, i + 1, occs, &bit, NULL);
+    out[3 * (size_t)i] = occs[0]; out[3 * (size_t)i + 1] = occs[1]; out[3 * (size_t)i + 2] = bit;
+  }
+}
+
 /* wtree_bseq + stored_num_for_node_num, src/main/wtree_funcs.h:584-626 */
 static const unsigned char* wtree_node(const unsigned char* wt, unsigned int node)
 {

@@ -54,6 +54,7 @@ int  fo_param(const fo_index_t* ix, int which); /* 0 block_size 1 b_size 2 mark_
 
 /* L1: src/main/wtree.c */
 void fo_bseq_rank(const unsigned char* z, int index, int occs[2], int* bit, fo_counters_t* c);
+void fo_bseq_rank_all(const unsigned char* z, int nbits, int64_t* out);
 int  fo_wtree_occs(const unsigned char* wt, int leaf, int index, fo_counters_t* c);
 void fo_wtree_rank(const unsigned char* wt, int index, int* leaf, int* count, fo_counters_t* c);
 int  fo_decode_gamma(uint64_t word, unsigned int* out);

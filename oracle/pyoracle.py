@@ -67,6 +67,7 @@ def lib():
                                C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.fo_locate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.fo_bseq_rank_all.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.fo_decode_gamma.argtypes = [C.c_uint64, C.POINTER(C.c_uint)]
         L.fo_decode_varbyte.argtypes = [C.c_char_p, C.POINTER(C.c_uint)]
         L.fo_resolve_location.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
@@ -168,13 +169,8 @@ def bseq_rank(image, index):
 
 def bseq_rank_all(image, nbits):
     buf = (C.c_ubyte * (len(image) + 64)).from_buffer_copy(bytes(image) + b"\0" * 64)
-    occs = (C.c_int * 2)()
-    bit = C.c_int()
     out = np.zeros((nbits, 3), dtype=np.int64)
-    f = lib().fo_bseq_rank
-    for i in range(nbits):
-        f(buf, i + 1, occs, C.byref(bit), None)
-        out[i] = (occs[0], occs[1], bit.value)
+    lib().fo_bseq_rank_all(buf, nbits, C.c_void_p(out.ctypes.data))
     return out
 
 
