@@ -1,0 +1,230 @@
+"""femto_amd -- MI355X-native FM-index query engine reading femto (femto-dev/femto) index files.
+
+This package is a thin ctypes binding over the C ABI in include/femto_amd.h (the product is the
+shared library femto_amd/libfemto_amd.so: C++ host + hand-written HIP kernels for gfx950).  There
+is NO CPU fallback: without the built library or without a HIP device every query call raises.
+
+Host-side mirror of the reference's batch interface (src/main/femto_internal.h):
+    Index.count(...)   <-> parallel_count   (src/main/femto.c:275)
+    Index.locate(...)  <-> parallel_locate  (src/main/femto.c:331)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+__all__ = ["Index", "FemtoAmdError", "lib", "ALPHA_SIZE", "CHARACTER_OFFSET", "Info"]
+
+ALPHA_SIZE = 261
+CHARACTER_OFFSET = 5
+ERR_NAMES = {0: "NOERR", 1: "MEM", 2: "IO", 3: "PARAM", 4: "FORMAT", 5: "BZ_DATA", 6: "INVALID",
+             8: "MISSING", 12: "UNKNOWN"}
+
+
+class FemtoAmdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"femto_amd error {code} ({ERR_NAMES.get(code, '?')}): {msg}")
+        self.code = code
+
+
+class Info(C.Structure):
+    _fields_ = [("total_length", C.c_int64), ("number_of_blocks", C.c_int64), ("number_of_documents", C.c_int64),
+                ("block_size", C.c_int32), ("bucket_size", C.c_int32), ("mark_period", C.c_int32),
+                ("chunk_size", C.c_int32), ("text_size_bits", C.c_int32), ("total_buckets", C.c_int64),
+                ("image_bytes", C.c_int64), ("table_bytes", C.c_int64)]
+
+
+_lib = None
+
+
+def lib():
+    """Load (never silently substitute) the HIP extension."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_build.LIB):
+            raise ImportError(f"{_build.LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback)")
+        L = C.CDLL(_build.LIB)
+        vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+        L.femto_amd_open.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+        L.femto_amd_close.argtypes = [vp]
+        L.femto_amd_close.restype = None
+        L.femto_amd_last_error.restype = C.c_char_p
+        L.femto_amd_info.argtypes = [vp, C.POINTER(Info)]
+        L.femto_amd_count_flat.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+        L.femto_amd_count_bytes.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+        L.femto_amd_locate_flat.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, vp, i64, C.POINTER(i64)]
+        L.femto_amd_parallel_count.argtypes = [vp, i32, vp, vp, vp, vp]
+        L.femto_amd_parallel_locate.argtypes = [vp, i32, vp, vp, i32, vp, vp]
+        L.femto_amd_resolve_location.argtypes = [vp, i64, C.POINTER(i64), C.POINTER(i64)]
+        L.femto_amd_count_device.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
+        L.femto_amd_locate_plan_device.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, vp, vp, vp]
+        L.femto_amd_locate_walk_device.argtypes = [vp, i64, vp, vp, i64, vp, vp]
+        L.femto_amd_block_requests.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+        L.femto_amd_kernel_time_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]
+        L.femto_amd_kernel_time_reset.argtypes = [vp]
+        L.femto_amd_kernel_time_reset.restype = None
+        L.femto_amd_kernel_time_enable.argtypes = [vp, i32]
+        L.femto_amd_kernel_time_enable.restype = None
+        L.femto_amd_build_index.argtypes = [C.c_char_p, i32, vp, vp, vp, C.c_char_p, i32]
+        L.femto_amd_build_index_from_sa.argtypes = [C.c_char_p, i32, vp, vp, vp, C.c_char_p, vp]
+        L.femto_amd_bseq_encode.argtypes = [vp, i64, i32, vp, i64, C.POINTER(i64)]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc:
+        raise FemtoAmdError(rc, lib().femto_amd_last_error().decode(errors="replace"))
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else None
+
+
+def flatten(patterns):
+    """list of uint16 alpha arrays -> (plen int32[n], flat uint16[sum], starts int64[n])"""
+    plen = np.array([len(p) for p in patterns], dtype=np.int32)
+    starts = np.zeros(len(patterns), dtype=np.int64)
+    if len(patterns):
+        starts[1:] = np.cumsum(plen[:-1], dtype=np.int64)
+    flat = (np.concatenate([np.asarray(p, dtype=np.uint16) for p in patterns])
+            if len(patterns) and plen.sum() else np.zeros(1, dtype=np.uint16))
+    return plen, np.ascontiguousarray(flat), starts
+
+
+class Index:
+    """A femto index resident in the HBM of one GPU.  device=-1 parses only (host logic tests)."""
+
+    def __init__(self, path, device=0):
+        self._h = C.c_void_p()
+        _check(lib().femto_amd_open(os.fsencode(path), device, C.byref(self._h)))
+        self.device = device
+        self.info = Info()
+        _check(lib().femto_amd_info(self._h, C.byref(self.info)))
+
+    def close(self):
+        if self._h:
+            lib().femto_amd_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    # ---- host-array API (numpy in, numpy out)
+    def count_flat(self, plen, flat, starts):
+        n = len(plen)
+        plen = np.ascontiguousarray(plen, dtype=np.int32)
+        flat = np.ascontiguousarray(flat, dtype=np.uint16)
+        starts = np.ascontiguousarray(starts, dtype=np.int64)
+        first = np.zeros(n, dtype=np.int64)
+        last = np.zeros(n, dtype=np.int64)
+        _check(lib().femto_amd_count_flat(self._h, n, _ptr(plen), _ptr(flat), _ptr(starts), _ptr(first), _ptr(last)))
+        return first, last
+
+    def count(self, patterns):
+        return self.count_flat(*flatten(patterns))
+
+    def locate_flat(self, plen, flat, starts, max_occs):
+        n = len(plen)
+        plen = np.ascontiguousarray(plen, dtype=np.int32)
+        flat = np.ascontiguousarray(flat, dtype=np.uint16)
+        starts = np.ascontiguousarray(starts, dtype=np.int64)
+        noccs = np.zeros(n, dtype=np.int32)
+        ostarts = np.zeros(n + 1, dtype=np.int64)
+        total = C.c_int64(0)
+        _check(lib().femto_amd_locate_flat(self._h, n, _ptr(plen), _ptr(flat), _ptr(starts), max_occs, _ptr(noccs),
+                                           _ptr(ostarts), None, 0, C.byref(total)))
+        offs = np.zeros(max(1, total.value), dtype=np.int64)
+        if total.value:
+            _check(lib().femto_amd_locate_flat(self._h, n, _ptr(plen), _ptr(flat), _ptr(starts), max_occs,
+                                               _ptr(noccs), _ptr(ostarts), _ptr(offs), total.value, C.byref(total)))
+        return noccs, offs[:total.value]
+
+    def locate(self, patterns, max_occs):
+        return self.locate_flat(*flatten(patterns), max_occs)
+
+    def block_requests(self, rows, ch_in=None):
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        n = len(rows)
+        ch = np.zeros(n, dtype=np.uint16)
+        occ = np.zeros(n, dtype=np.int32)
+        off = np.zeros(n, dtype=np.int64)
+        chin = np.ascontiguousarray(ch_in, dtype=np.uint16) if ch_in is not None else None
+        _check(lib().femto_amd_block_requests(self._h, n, _ptr(rows), _ptr(chin), _ptr(ch), _ptr(occ), _ptr(off)))
+        return ch, occ, off
+
+    def resolve_location(self, offset):
+        d, o = C.c_int64(), C.c_int64()
+        _check(lib().femto_amd_resolve_location(self._h, offset, C.byref(d), C.byref(o)))
+        return d.value, o.value
+
+    # ---- device-pointer API (raw pointers, e.g. torch tensors' data_ptr())
+    def count_device(self, npats, d_plen, d_pats, d_starts, d_first, d_last, stream=0):
+        _check(lib().femto_amd_count_device(self._h, npats, d_plen, d_pats, d_starts, d_first, d_last or None,
+                                            stream or None))
+
+    def locate_plan_device(self, npats, d_plen, d_pats, d_starts, max_occs, d_first, d_last, d_noccs, d_out_starts,
+                           stream=0):
+        _check(lib().femto_amd_locate_plan_device(self._h, npats, d_plen, d_pats, d_starts, max_occs, d_first, d_last,
+                                                  d_noccs, d_out_starts, stream or None))
+
+    def locate_walk_device(self, npats, d_first, d_out_starts, total, d_offsets, stream=0):
+        _check(lib().femto_amd_locate_walk_device(self._h, npats, d_first, d_out_starts, total, d_offsets,
+                                                  stream or None))
+
+    def kernel_time(self, name):
+        ms, n = C.c_double(), C.c_int64()
+        _check(lib().femto_amd_kernel_time_ms(self._h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def kernel_time_enable(self, on=True):
+        lib().femto_amd_kernel_time_enable(self._h, 1 if on else 0)
+
+    def kernel_time_reset(self):
+        lib().femto_amd_kernel_time_reset(self._h)
+
+
+def bseq_encode(raw_bytes, bitlen, force_type=0):
+    """bseq_construct_forcetype-compatible encoding of a bit string (MSB-first bytes)."""
+    raw = np.frombuffer(bytes(raw_bytes) + b"\0", dtype=np.uint8)
+    n = C.c_int64(0)
+    _check(lib().femto_amd_bseq_encode(_ptr(raw), bitlen, force_type, None, 0, C.byref(n)))
+    out = np.zeros(n.value, dtype=np.uint8)
+    _check(lib().femto_amd_bseq_encode(_ptr(raw), bitlen, force_type, _ptr(out), n.value, C.byref(n)))
+    return out
+
+
+def _doc_args(docs, infos):
+    docs = [np.ascontiguousarray(np.frombuffer(bytes(d), dtype=np.uint8) if not isinstance(d, np.ndarray) else d,
+                                 dtype=np.uint8) for d in docs]
+    n = len(docs)
+    ptrs = (C.c_void_p * n)(*[d.ctypes.data if len(d) else None for d in docs])
+    lens = np.array([len(d) for d in docs], dtype=np.int64)
+    infos = infos or [""] * n
+    iarr = (C.c_char_p * n)(*[i.encode() if isinstance(i, str) else bytes(i) for i in infos])
+    return docs, n, ptrs, lens, iarr
+
+
+def build_index(out_dir, docs, params=None, infos=None, device=0):
+    """GPU suffix sort + femto block-file writer (femto_amd_build_index)."""
+    keep, n, ptrs, lens, iarr = _doc_args(docs, infos)
+    _check(lib().femto_amd_build_index(os.fsencode(out_dir), n, ptrs, _ptr(lens), iarr,
+                                       params.encode() if params else None, device))
+
+
+def build_index_from_sa(out_dir, docs, sa, params=None, infos=None):
+    """femto block-file writer from a caller-supplied suffix array of the prepared text."""
+    keep, n, ptrs, lens, iarr = _doc_args(docs, infos)
+    sa = np.ascontiguousarray(sa, dtype=np.int64)
+    _check(lib().femto_amd_build_index_from_sa(os.fsencode(out_dir), n, ptrs, _ptr(lens), iarr,
+                                               params.encode() if params else None, _ptr(sa)))

@@ -1,0 +1,38 @@
+"""Build the in-tree HIP extension (femto_amd/libfemto_amd.so) with hipcc for gfx950."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libfemto_amd.so")
+SOURCES = ["femto_amd_api.hip", "host_index.cpp", "index_builder.cpp", "suffix_sort.hip"]
+HEADERS = ["device_tables.h", "host_index.hpp", "kernels.hip.hpp", "index_builder.hpp",
+           os.path.join("..", "..", "include", "femto_amd.h")]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    for f in SOURCES + HEADERS:
+        p = os.path.join(CSRC, f)
+        if os.path.exists(p) and os.path.getmtime(p) > t:
+            return True
+    return False
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return LIB
+    srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
+           "-Wno-unused-result", "-o", LIB] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force=True, verbose=True)

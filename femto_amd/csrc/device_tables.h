@@ -1,0 +1,70 @@
+// device_tables.h -- layout of the HBM-resident index (shared by the host loader and the kernels).
+//
+// The femto block files are uploaded UNCHANGED (big-endian, 8-byte aligned) into one device
+// buffer `image`; the loader adds small derived side tables so that no kernel has to parse a
+// bucket's mapping/Huffman header or search a wavelet-tree directory:
+//
+//   image        : [data block 0 | data block 1 | ...], each block start 256-byte aligned
+//   nodes[]      : one DevNode per internal wavelet-tree node, bucket after bucket, in the order
+//                  of the bucket's own (sorted) node directory; local index 0 is the root
+//   buckets[]    : one DevBucket per global bucket gb = row / b_size
+//   occ_base[]   : int64 [gb][261]  = C[ch] + block_occs[ch][block] + bucket_occs[ch][bucket]
+//                  (the three additive terms of Occ outside the wavelet tree; reference
+//                  src/main/index.c:1538-1569, :1828-1843, combined as HDR_BACK does, :1740-1746)
+//   leaf_code[]  : uint32 [gb][261] = Huffman leaf number (code with leading 1,
+//                  src/main/index.c:290-300) of ch in that bucket, 0 if ch does not occur
+//   seqs[]       : one DevSeq per in-use character per bucket: its alpha code, its mark table
+//                  (a bseq) and its mark array
+#pragma once
+#include <stdint.h>
+
+namespace femto_amd {
+
+constexpr int kAlphaSize = 261;        // ALPHA_SIZE, src/main/index_types.h:66
+constexpr int kSEOF = 2;               // ESCAPE_CODE_SEOF
+constexpr int kGroupSize = 31;         // GROUP_SIZE, src/main/wtree.c:48
+constexpr int kSegmentWords = 8;       // SEGMENT_WORDS, src/main/wtree_funcs.h:34
+
+struct DevBseq {            // one encoded binary sequence (src/main/wtree_funcs.h:294-358)
+  uint64_t off;             // absolute byte offset of the bseq header inside `image`
+  uint32_t num_groups;      // NUM_GROUPS
+  uint32_t d_off;           // D_OFFSET (relative to off)
+  uint32_t total_words;     // TOTAL_SEGMENT_WORDS
+  uint32_t pad;
+};
+
+struct DevNode {            // 32 bytes
+  DevBseq bs;
+  int32_t child[2];         // >= 0: local index of the internal child; < 0: leaf, seq = -1 - child
+};
+
+struct DevSeq {             // 40 bytes
+  DevBseq mark_table;       // bseq over this character's occurrences in the bucket (1 = marked)
+  uint64_t mark_array;      // absolute byte offset of this character's mark records
+  uint32_t ch;              // alpha code (0..260); kAlphaSize for the end-of-bucket symbol
+  uint32_t pad;
+};
+
+struct DevBucket {          // 16 bytes
+  uint32_t node_base;       // first DevNode of this bucket
+  uint32_t seq_base;        // first DevSeq of this bucket
+  uint32_t n_internal;
+  uint32_t n_in_use;
+};
+
+struct DevIndex {           // passed by value to kernels
+  const uint8_t* image;
+  const DevNode* nodes;
+  const DevBucket* buckets;
+  const DevSeq* seqs;
+  const int64_t* occ_base;  // [gb*261 + ch]
+  const uint32_t* leaf_code;// [gb*261 + ch]
+  const int64_t* C;         // [262]; C[261] == total_length (get_C, src/main/index.c:1545)
+  int64_t total_length;
+  int64_t total_buckets;
+  int32_t b_size;
+  int32_t b_shift;          // log2(b_size) when b_size is a power of two, else -1
+  int32_t text_size_bits;
+};
+
+}  // namespace femto_amd

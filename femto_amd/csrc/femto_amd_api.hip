@@ -1,0 +1,631 @@
+// femto_amd_api.hip -- the C ABI (include/femto_amd.h) over the HIP kernels.  C++ host code that
+// owns device memory, streams and launch configuration; no compute happens on the host.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/femto_amd.h"
+#include "host_index.hpp"
+#include "index_builder.hpp"
+#include "kernels.hip.hpp"
+
+using namespace femto_amd;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int set_err(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return set_err(e_ == hipErrorOutOfMemory ? FEMTO_AMD_ERR_MEM : FEMTO_AMD_ERR_INVALID,        \
+                     std::string(#expr) + ": " + hipGetErrorString(e_));                           \
+  } while (0)
+
+constexpr int kGroupW = 32;          // lanes per rank group; a count query uses one wavefront
+constexpr int kBlockThreads = 256;
+
+struct DeviceBuffer {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return set_err(FEMTO_AMD_ERR_MEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    cap = want;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+struct KernelTimer {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  double total_ms = 0;
+  int64_t launches = 0;
+  void drain() {
+    for (auto& pr : events) {
+      float ms = 0;
+      if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+        total_ms += ms;
+        launches++;
+      }
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
+    events.clear();
+  }
+};
+
+}  // namespace
+
+struct femto_amd_index {
+  HostIndex host;
+  int device = -1;
+  std::recursive_mutex mu;
+  // device-resident index
+  uint8_t* d_image = nullptr;
+  DevNode* d_nodes = nullptr;
+  DevBucket* d_buckets = nullptr;
+  DevSeq* d_seqs = nullptr;
+  int64_t* d_occ_base = nullptr;
+  uint32_t* d_leaf_code = nullptr;
+  int64_t* d_C = nullptr;
+  int* d_err = nullptr;
+  DevIndex dev{};
+  int64_t table_bytes = 0;
+  // scratch for the host-pointer API and the locate plan
+  DeviceBuffer s_plen, s_pats, s_starts, s_first, s_last, s_noccs, s_noccs64, s_out_starts, s_offsets, s_scan[3];
+  DeviceBuffer s_rows, s_ch, s_occ, s_off;
+  bool timing = false;
+  KernelTimer t_count, t_locate;
+};
+
+namespace {
+
+template <class T>
+int upload(T** dst, const std::vector<T>& src, int64_t* bytes) {
+  size_t n = src.size() * sizeof(T);
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(dst), n ? n : 16));
+  if (n) HIP_TRY(hipMemcpy(*dst, src.data(), n, hipMemcpyHostToDevice));
+  if (bytes) *bytes += int64_t(n);
+  return 0;
+}
+
+int ensure_device(femto_amd_index* ix) {
+  if (ix->device < 0) return set_err(FEMTO_AMD_ERR_INVALID, "index was opened without a device (parse-only handle)");
+  HIP_TRY(hipSetDevice(ix->device));
+  return 0;
+}
+
+int check_err_flag(femto_amd_index* ix, hipStream_t stream) {
+  int flag = 0;
+  HIP_TRY(hipMemcpyAsync(&flag, ix->d_err, sizeof(int), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  if (flag) {
+    HIP_TRY(hipMemsetAsync(ix->d_err, 0, sizeof(int), stream));
+    return set_err(FEMTO_AMD_ERR_PARAM, "pattern contains a character code >= ALPHA_SIZE (261)");
+  }
+  return 0;
+}
+
+int launch_count(femto_amd_index* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
+                 const int64_t* d_starts, int64_t* d_first, int64_t* d_last, hipStream_t stream) {
+  if (npats <= 0) return 0;
+  constexpr int lanes_per_query = 2 * kGroupW;
+  const int64_t threads = npats * lanes_per_query;
+  const int64_t blocks = (threads + kBlockThreads - 1) / kBlockThreads;
+  if (blocks > 0x7fffffffLL) return set_err(FEMTO_AMD_ERR_PARAM, "batch too large for one launch");
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ix->timing) {
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, stream));
+  }
+  hipLaunchKernelGGL((count_kernel<kGroupW>), dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats,
+                     d_plen, d_pats, d_starts, d_first, d_last, ix->d_err);
+  HIP_TRY(hipGetLastError());
+  if (ix->timing) {
+    HIP_TRY(hipEventRecord(e1, stream));
+    ix->t_count.events.emplace_back(e0, e1);
+  }
+  return 0;
+}
+
+int device_scan(femto_amd_index* ix, int64_t n, const int64_t* in, int64_t* out /* n+1 */, int level, hipStream_t stream) {
+  if (n <= 0) {
+    HIP_TRY(hipMemsetAsync(out, 0, sizeof(int64_t), stream));
+    return 0;
+  }
+  const int64_t tiles = (n + kScanTile - 1) / kScanTile;
+  if (level >= 3) return set_err(FEMTO_AMD_ERR_PARAM, "scan too deep");
+  int rc = ix->s_scan[level].reserve(size_t(2 * (tiles + 1)) * sizeof(int64_t));
+  if (rc) return rc;
+  int64_t* tile_sums = ix->s_scan[level].as<int64_t>();
+  int64_t* tile_offs = tile_sums + tiles + 1;
+  hipLaunchKernelGGL(scan_tile_kernel, dim3(uint32_t(tiles)), dim3(kScanBlock), 0, stream, n, in, out, tile_sums);
+  if (tiles > 1) {
+    rc = device_scan(ix, tiles, tile_sums, tile_offs, level + 1, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(scan_add_kernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, stream, n, out, tile_offs);
+  }
+  hipLaunchKernelGGL(set_total_kernel, dim3(1), dim3(64), 0, stream, n, out, in, out + n);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_locate(femto_amd_index* ix, int64_t npats, const int64_t* d_first, const int64_t* d_out_starts,
+                  int64_t total, int64_t* d_offsets, hipStream_t stream) {
+  if (total <= 0) return 0;
+  const int64_t threads = total * kGroupW;
+  const int64_t blocks = (threads + kBlockThreads - 1) / kBlockThreads;
+  if (blocks > 0x7fffffffLL) return set_err(FEMTO_AMD_ERR_PARAM, "too many rows to locate in one launch");
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ix->timing) {
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, stream));
+  }
+  hipLaunchKernelGGL((locate_kernel<kGroupW>), dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats,
+                     d_first, d_out_starts, total, d_offsets);
+  HIP_TRY(hipGetLastError());
+  if (ix->timing) {
+    HIP_TRY(hipEventRecord(e1, stream));
+    ix->t_locate.events.emplace_back(e0, e1);
+  }
+  return 0;
+}
+
+int validate_patterns(int64_t npats, const int32_t* plen, const int64_t* starts) {
+  if (npats < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative pattern count");
+  if (npats && (!plen || !starts)) return set_err(FEMTO_AMD_ERR_PARAM, "null pattern arrays");
+  for (int64_t i = 0; i < npats; i++)
+    if (plen[i] < 0 || starts[i] < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative pattern length/start");
+  return 0;
+}
+
+// copies a flat host pattern set to device scratch; returns total symbols
+int stage_patterns(femto_amd_index* ix, int64_t npats, const int32_t* plen, const uint16_t* pats, const int64_t* starts) {
+  int rc = validate_patterns(npats, plen, starts);
+  if (rc) return rc;
+  int64_t total = 0;
+  for (int64_t i = 0; i < npats; i++) total = std::max<int64_t>(total, starts[i] + plen[i]);
+  if ((rc = ix->s_plen.reserve(size_t(npats + 1) * 4))) return rc;
+  if ((rc = ix->s_starts.reserve(size_t(npats + 1) * 8))) return rc;
+  if ((rc = ix->s_pats.reserve(size_t(total + 1) * 2))) return rc;
+  if (npats) {
+    HIP_TRY(hipMemcpy(ix->s_plen.p, plen, size_t(npats) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ix->s_starts.p, starts, size_t(npats) * 8, hipMemcpyHostToDevice));
+  }
+  if (total) HIP_TRY(hipMemcpy(ix->s_pats.p, pats, size_t(total) * 2, hipMemcpyHostToDevice));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* femto_amd_last_error(void) { return g_last_error.c_str(); }
+
+int femto_amd_open(const char* index_path, int device, femto_amd_index_t** out) {
+  if (!index_path || !out) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  *out = nullptr;
+  femto_amd_index* ix = new (std::nothrow) femto_amd_index();
+  if (!ix) return set_err(FEMTO_AMD_ERR_MEM, "out of memory");
+  Error err{0, ""};
+  int rc = ix->host.load(index_path, &err);
+  if (rc) {
+    delete ix;
+    return set_err(rc, err.msg);
+  }
+  ix->device = device;
+  if (device >= 0) {
+    int ndev = 0;
+    hipError_t he = hipGetDeviceCount(&ndev);
+    if (he != hipSuccess || device >= ndev) {
+      delete ix;
+      return set_err(FEMTO_AMD_ERR_INVALID, "no usable HIP device " + std::to_string(device) +
+                                                " (this library has no CPU fallback)");
+    }
+    auto up = [&]() -> int {
+      HIP_TRY(hipSetDevice(device));
+      HostIndex& h = ix->host;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_image), h.image.size()));
+      HIP_TRY(hipMemcpy(ix->d_image, h.image.data(), h.image.size(), hipMemcpyHostToDevice));
+      int r;
+      if ((r = upload(&ix->d_nodes, h.nodes, &ix->table_bytes))) return r;
+      if ((r = upload(&ix->d_buckets, h.buckets, &ix->table_bytes))) return r;
+      if ((r = upload(&ix->d_seqs, h.seqs, &ix->table_bytes))) return r;
+      if ((r = upload(&ix->d_occ_base, h.occ_base, &ix->table_bytes))) return r;
+      if ((r = upload(&ix->d_leaf_code, h.leaf_code, &ix->table_bytes))) return r;
+      if ((r = upload(&ix->d_C, h.C, &ix->table_bytes))) return r;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_err), sizeof(int)));
+      HIP_TRY(hipMemset(ix->d_err, 0, sizeof(int)));
+      DevIndex& d = ix->dev;
+      d.image = ix->d_image;
+      d.nodes = ix->d_nodes;
+      d.buckets = ix->d_buckets;
+      d.seqs = ix->d_seqs;
+      d.occ_base = ix->d_occ_base;
+      d.leaf_code = ix->d_leaf_code;
+      d.C = ix->d_C;
+      d.total_length = h.total_length;
+      d.total_buckets = h.total_buckets;
+      d.b_size = h.b_size;
+      d.b_shift = (h.b_size & (h.b_size - 1)) == 0 ? __builtin_ctz(unsigned(h.b_size)) : -1;
+      d.text_size_bits = h.text_size_bits;
+      return 0;
+    };
+    rc = up();
+    if (rc) {
+      femto_amd_close(ix);
+      return rc;
+    }
+  }
+  *out = ix;
+  return FEMTO_AMD_OK;
+}
+
+void femto_amd_close(femto_amd_index_t* ix) {
+  if (!ix) return;
+  if (ix->device >= 0) {
+    (void)hipSetDevice(ix->device);
+    ix->t_count.drain();
+    ix->t_locate.drain();
+    (void)hipFree(ix->d_image);
+    (void)hipFree(ix->d_nodes);
+    (void)hipFree(ix->d_buckets);
+    (void)hipFree(ix->d_seqs);
+    (void)hipFree(ix->d_occ_base);
+    (void)hipFree(ix->d_leaf_code);
+    (void)hipFree(ix->d_C);
+    (void)hipFree(ix->d_err);
+    for (DeviceBuffer* b : {&ix->s_plen, &ix->s_pats, &ix->s_starts, &ix->s_first, &ix->s_last, &ix->s_noccs,
+                            &ix->s_noccs64, &ix->s_out_starts, &ix->s_offsets, &ix->s_scan[0], &ix->s_scan[1],
+                            &ix->s_scan[2], &ix->s_rows, &ix->s_ch, &ix->s_occ, &ix->s_off})
+      b->release();
+  }
+  delete ix;
+}
+
+int femto_amd_info(const femto_amd_index_t* ix, femto_amd_info_t* out) {
+  if (!ix || !out) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  const HostIndex& h = ix->host;
+  out->total_length = h.total_length;
+  out->number_of_blocks = h.number_of_blocks;
+  out->number_of_documents = h.number_of_documents;
+  out->block_size = h.block_size;
+  out->bucket_size = h.b_size;
+  out->mark_period = h.mark_period;
+  out->chunk_size = h.chunk_size;
+  out->text_size_bits = h.text_size_bits;
+  out->total_buckets = h.total_buckets;
+  out->image_bytes = int64_t(h.image.size());
+  out->table_bytes = int64_t(h.nodes.size() * sizeof(DevNode) + h.buckets.size() * sizeof(DevBucket) +
+                             h.seqs.size() * sizeof(DevSeq) + h.occ_base.size() * 8 + h.leaf_code.size() * 4 +
+                             h.C.size() * 8);
+  return FEMTO_AMD_OK;
+}
+
+int femto_amd_resolve_location(const femto_amd_index_t* ix, int64_t offset, int64_t* doc, int64_t* doc_offset) {
+  if (!ix || !doc || !doc_offset) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  return ix->host.resolve_location(offset, doc, doc_offset);
+}
+
+int femto_amd_count_device(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
+                           const int64_t* d_starts, int64_t* d_first, int64_t* d_last, void* stream) {
+  if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
+  int rc = ensure_device(ix);
+  if (rc) return rc;
+  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  return launch_count(ix, npats, d_plen, d_pats, d_starts, d_first, d_last, static_cast<hipStream_t>(stream));
+}
+
+int femto_amd_count_flat(femto_amd_index_t* ix, int64_t npats, const int32_t* plen, const uint16_t* pats,
+                         const int64_t* starts, int64_t* first, int64_t* last) {
+  if (!ix || (npats && !first)) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  int rc = ensure_device(ix);
+  if (rc) return rc;
+  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  if ((rc = stage_patterns(ix, npats, plen, pats, starts))) return rc;
+  if ((rc = ix->s_first.reserve(size_t(npats + 1) * 8))) return rc;
+  if ((rc = ix->s_last.reserve(size_t(npats + 1) * 8))) return rc;
+  rc = launch_count(ix, npats, ix->s_plen.as<int32_t>(), ix->s_pats.as<uint16_t>(), ix->s_starts.as<int64_t>(),
+                    ix->s_first.as<int64_t>(), last ? ix->s_last.as<int64_t>() : nullptr, nullptr);
+  if (rc) return rc;
+  if ((rc = check_err_flag(ix, nullptr))) return rc;
+  if (npats) {
+    HIP_TRY(hipMemcpy(first, ix->s_first.p, size_t(npats) * 8, hipMemcpyDeviceToHost));
+    if (last) HIP_TRY(hipMemcpy(last, ix->s_last.p, size_t(npats) * 8, hipMemcpyDeviceToHost));
+  }
+  return FEMTO_AMD_OK;
+}
+
+int femto_amd_count_bytes(femto_amd_index_t* ix, int64_t npats, const int32_t* plen, const uint8_t* bytes,
+                          const int64_t* starts, int64_t* first, int64_t* last) {
+  int rc = validate_patterns(npats, plen, starts);
+  if (rc) return rc;
+  int64_t total = 0;
+  for (int64_t i = 0; i < npats; i++) total = std::max<int64_t>(total, starts[i] + plen[i]);
+  std::vector<uint16_t> codes(size_t(total) + 1);
+  for (int64_t i = 0; i < total; i++) codes[size_t(i)] = uint16_t(bytes[i]) + FEMTO_AMD_CHARACTER_OFFSET;
+  return femto_amd_count_flat(ix, npats, plen, codes.data(), starts, first, last);
+}
+
+int femto_amd_parallel_count(femto_amd_index_t* ix, int npats, const int* plen, const uint16_t* const* pats,
+                             int64_t* first, int64_t* last) {
+  if (npats < 0 || (npats && (!plen || !pats))) return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
+  std::vector<int64_t> starts(size_t(npats) + 1, 0);
+  for (int i = 0; i < npats; i++) {
+    if (plen[i] < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative pattern length");
+    starts[size_t(i) + 1] = starts[size_t(i)] + plen[i];
+  }
+  std::vector<uint16_t> flat(size_t(starts[size_t(npats)]) + 1);
+  for (int i = 0; i < npats; i++)  // patterns are copied, as setup_string_query does (src/main/server.c:691-695)
+    if (plen[i]) memcpy(flat.data() + starts[size_t(i)], pats[i], size_t(plen[i]) * 2);
+  return femto_amd_count_flat(ix, npats, plen, flat.data(), starts.data(), first, last);
+}
+
+int femto_amd_locate_plan_device(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
+                                 const int64_t* d_starts, int max_occs_each, int64_t* d_first, int64_t* d_last,
+                                 int32_t* d_noccs, int64_t* d_out_starts, void* stream_) {
+  if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
+  if (max_occs_each < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative max_occs_each");
+  int rc = ensure_device(ix);
+  if (rc) return rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  if ((rc = launch_count(ix, npats, d_plen, d_pats, d_starts, d_first, d_last, stream))) return rc;
+  if ((rc = ix->s_noccs64.reserve(size_t(npats + 1) * 8))) return rc;
+  if (npats) {
+    hipLaunchKernelGGL(clamp_kernel, dim3(uint32_t((npats + 255) / 256)), dim3(256), 0, stream, npats, d_first, d_last,
+                       max_occs_each, d_noccs, ix->s_noccs64.as<int64_t>());
+    HIP_TRY(hipGetLastError());
+  }
+  return device_scan(ix, npats, ix->s_noccs64.as<int64_t>(), d_out_starts, 0, stream);
+}
+
+int femto_amd_locate_walk_device(femto_amd_index_t* ix, int64_t npats, const int64_t* d_first,
+                                 const int64_t* d_out_starts, int64_t total, int64_t* d_offsets, void* stream) {
+  if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
+  int rc = ensure_device(ix);
+  if (rc) return rc;
+  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  return launch_locate(ix, npats, d_first, d_out_starts, total, d_offsets, static_cast<hipStream_t>(stream));
+}
+
+int femto_amd_locate_flat(femto_amd_index_t* ix, int64_t npats, const int32_t* plen, const uint16_t* pats,
+                          const int64_t* starts, int max_occs_each, int32_t* noccs, int64_t* out_starts,
+                          int64_t* offsets, int64_t offsets_capacity, int64_t* total_out) {
+  if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
+  if (max_occs_each < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative max_occs_each");
+  int rc = ensure_device(ix);
+  if (rc) return rc;
+  int64_t total = 0;
+  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  if ((rc = stage_patterns(ix, npats, plen, pats, starts))) return rc;
+  if ((rc = ix->s_first.reserve(size_t(npats + 1) * 8))) return rc;
+  if ((rc = ix->s_last.reserve(size_t(npats + 1) * 8))) return rc;
+  if ((rc = ix->s_noccs.reserve(size_t(npats + 1) * 4))) return rc;
+  if ((rc = ix->s_out_starts.reserve(size_t(npats + 2) * 8))) return rc;
+  rc = femto_amd_locate_plan_device(ix, npats, ix->s_plen.as<int32_t>(), ix->s_pats.as<uint16_t>(),
+                                    ix->s_starts.as<int64_t>(), max_occs_each, ix->s_first.as<int64_t>(),
+                                    ix->s_last.as<int64_t>(), ix->s_noccs.as<int32_t>(),
+                                    ix->s_out_starts.as<int64_t>(), nullptr);
+  if (rc) return rc;
+  if ((rc = check_err_flag(ix, nullptr))) return rc;
+  HIP_TRY(hipMemcpy(&total, ix->s_out_starts.as<int64_t>() + npats, 8, hipMemcpyDeviceToHost));
+  if (total_out) *total_out = total;
+  if (noccs && npats) HIP_TRY(hipMemcpy(noccs, ix->s_noccs.p, size_t(npats) * 4, hipMemcpyDeviceToHost));
+  if (out_starts) HIP_TRY(hipMemcpy(out_starts, ix->s_out_starts.p, size_t(npats + 1) * 8, hipMemcpyDeviceToHost));
+  if (!offsets) return FEMTO_AMD_OK;
+  if (offsets_capacity < total) return set_err(FEMTO_AMD_ERR_PARAM, "offsets buffer too small");
+  if (total == 0) return FEMTO_AMD_OK;
+  if ((rc = ix->s_offsets.reserve(size_t(total) * 8))) return rc;
+  rc = femto_amd_locate_walk_device(ix, npats, ix->s_first.as<int64_t>(), ix->s_out_starts.as<int64_t>(), total,
+                                    ix->s_offsets.as<int64_t>(), nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(offsets, ix->s_offsets.p, size_t(total) * 8, hipMemcpyDeviceToHost));
+  return FEMTO_AMD_OK;
+}
+
+int femto_amd_parallel_locate(femto_amd_index_t* ix, int npats, const int* plen, const uint16_t* const* pats,
+                              int max_occs_each, int* noccs, int64_t** offsets) {
+  if (npats < 0 || (npats && (!plen || !pats || !noccs || !offsets))) return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
+  std::vector<int64_t> starts(size_t(npats) + 1, 0);
+  for (int i = 0; i < npats; i++) {
+    if (plen[i] < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative pattern length");
+    starts[size_t(i) + 1] = starts[size_t(i)] + plen[i];
+  }
+  std::vector<uint16_t> flat(size_t(starts[size_t(npats)]) + 1);
+  for (int i = 0; i < npats; i++)
+    if (plen[i]) memcpy(flat.data() + starts[size_t(i)], pats[i], size_t(plen[i]) * 2);
+  std::vector<int32_t> n32(size_t(npats) + 1);
+  std::vector<int64_t> ostarts(size_t(npats) + 2);
+  int64_t total = 0;
+  int rc = femto_amd_locate_flat(ix, npats, plen, flat.data(), starts.data(), max_occs_each, n32.data(), ostarts.data(),
+                                 nullptr, 0, &total);
+  if (rc) return rc;
+  std::vector<int64_t> all(size_t(total) + 1);
+  if (total) {
+    // second call re-runs the (cheap) plan; keeps the flat entry point stateless
+    rc = femto_amd_locate_flat(ix, npats, plen, flat.data(), starts.data(), max_occs_each, n32.data(), ostarts.data(),
+                               all.data(), total, &total);
+    if (rc) return rc;
+  }
+  for (int i = 0; i < npats; i++) {  // femto.c:372-386
+    noccs[i] = n32[size_t(i)];
+    offsets[i] = nullptr;
+    if (noccs[i] > 0) {
+      offsets[i] = static_cast<int64_t*>(malloc(sizeof(int64_t) * size_t(noccs[i])));
+      if (!offsets[i]) {
+        for (int j = 0; j < i; j++) { free(offsets[j]); offsets[j] = nullptr; }
+        return set_err(FEMTO_AMD_ERR_MEM, "malloc failed");
+      }
+      memcpy(offsets[i], all.data() + ostarts[size_t(i)], sizeof(int64_t) * size_t(noccs[i]));
+    }
+  }
+  return FEMTO_AMD_OK;
+}
+
+int femto_amd_block_requests(femto_amd_index_t* ix, int64_t n, const int64_t* rows, const uint16_t* ch_in,
+                             uint16_t* ch_out, int32_t* occ_out, int64_t* off_out) {
+  if (!ix || (n && !rows)) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  int rc = ensure_device(ix);
+  if (rc) return rc;
+  const HostIndex& h = ix->host;
+  for (int64_t i = 0; i < n; i++) {
+    if (rows[i] < 0 || rows[i] >= h.total_length) return set_err(FEMTO_AMD_ERR_PARAM, "row out of range");
+    if (ch_in && ch_in[i] >= kAlphaSize) return set_err(FEMTO_AMD_ERR_PARAM, "character out of range");
+  }
+  if (n == 0) return FEMTO_AMD_OK;
+  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  if ((rc = ix->s_rows.reserve(size_t(n) * 8))) return rc;
+  if ((rc = ix->s_ch.reserve(size_t(n) * 4))) return rc;
+  if ((rc = ix->s_occ.reserve(size_t(n) * 8))) return rc;
+  if ((rc = ix->s_off.reserve(size_t(n) * 8))) return rc;
+  HIP_TRY(hipMemcpy(ix->s_rows.p, rows, size_t(n) * 8, hipMemcpyHostToDevice));
+  uint16_t* d_chin = nullptr;
+  uint16_t* d_chout = ix->s_ch.as<uint16_t>();
+  if (ch_in) {
+    d_chin = ix->s_ch.as<uint16_t>() + n;
+    HIP_TRY(hipMemcpy(d_chin, ch_in, size_t(n) * 2, hipMemcpyHostToDevice));
+  }
+  const int64_t blocks = (n * kGroupW + kBlockThreads - 1) / kBlockThreads;
+  hipLaunchKernelGGL((block_request_kernel<kGroupW>), dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, nullptr, ix->dev, n,
+                     ix->s_rows.as<int64_t>(), d_chin, d_chout, ix->s_occ.as<int64_t>(), ix->s_off.as<int64_t>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<uint16_t> chs((size_t(n)));
+  std::vector<int64_t> occ((size_t(n)));
+  HIP_TRY(hipMemcpy(chs.data(), d_chout, size_t(n) * 2, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(occ.data(), ix->s_occ.p, size_t(n) * 8, hipMemcpyDeviceToHost));
+  if (off_out) HIP_TRY(hipMemcpy(off_out, ix->s_off.p, size_t(n) * 8, hipMemcpyDeviceToHost));
+  if (ch_out) memcpy(ch_out, chs.data(), size_t(n) * 2);
+  if (occ_out) {
+    // occs_in_block = Occ - (C[ch] + block_occs[ch][block])   (HDR_BACK sum, src/main/index.c:1740-1746)
+    const size_t bo_off = 88 + 8 * size_t(kAlphaSize);
+    for (int64_t i = 0; i < n; i++) {
+      const int ch = ch_in ? ch_in[i] : chs[size_t(i)];
+      const int64_t blk = rows[i] / h.block_size;
+      const uint8_t* p = h.header.data() + bo_off + 8 * (size_t(ch) * size_t(h.number_of_blocks) + size_t(blk));
+      uint64_t v = 0;
+      for (int k = 0; k < 8; k++) v = (v << 8) | p[k];
+      occ_out[i] = int32_t(occ[size_t(i)] - h.C[size_t(ch)] - int64_t(v));
+    }
+  }
+  return FEMTO_AMD_OK;
+}
+
+void femto_amd_kernel_time_enable(femto_amd_index_t* ix, int on) {
+  if (ix) ix->timing = on != 0;
+}
+
+void femto_amd_kernel_time_reset(femto_amd_index_t* ix) {
+  if (!ix) return;
+  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  ix->t_count.drain();
+  ix->t_locate.drain();
+  ix->t_count.total_ms = ix->t_locate.total_ms = 0;
+  ix->t_count.launches = ix->t_locate.launches = 0;
+}
+
+int femto_amd_kernel_time_ms(femto_amd_index_t* ix, const char* kernel, double* avg_ms, int64_t* n_launches) {
+  if (!ix || !kernel) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  KernelTimer* t = nullptr;
+  if (!strcmp(kernel, "count")) t = &ix->t_count;
+  else if (!strcmp(kernel, "locate")) t = &ix->t_locate;
+  else return set_err(FEMTO_AMD_ERR_PARAM, "unknown kernel name");
+  t->drain();
+  if (avg_ms) *avg_ms = t->launches ? t->total_ms / double(t->launches) : 0.0;
+  if (n_launches) *n_launches = t->launches;
+  return FEMTO_AMD_OK;
+}
+
+
+namespace {
+int collect_docs(int ndocs, const uint8_t* const* docs, const int64_t* doc_lens, const char* const* doc_infos,
+                 std::vector<Document>* out) {
+  if (ndocs <= 0 || !docs || !doc_lens) return set_err(FEMTO_AMD_ERR_PARAM, "an index needs at least one document");
+  for (int i = 0; i < ndocs; i++) {
+    if (doc_lens[i] < 0 || (doc_lens[i] && !docs[i])) return set_err(FEMTO_AMD_ERR_PARAM, "bad document");
+    out->push_back(Document{docs[i], doc_lens[i], (doc_infos && doc_infos[i]) ? std::string(doc_infos[i]) : std::string()});
+  }
+  return 0;
+}
+int host_threads() {
+  unsigned n = std::thread::hardware_concurrency();
+  return n ? int(n) : 4;
+}
+}  // namespace
+
+int femto_amd_build_index_from_sa(const char* out_dir, int ndocs, const uint8_t* const* docs, const int64_t* doc_lens,
+                                  const char* const* doc_infos, const char* params, const int64_t* sa) {
+  if (!out_dir || !sa) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  std::vector<Document> d;
+  int rc = collect_docs(ndocs, docs, doc_lens, doc_infos, &d);
+  if (rc) return rc;
+  BuildParams bp;
+  Error e{0, ""};
+  if ((rc = parse_build_params(params, &bp, &e))) return set_err(rc, e.msg);
+  if ((rc = build_index_from_sa(out_dir, d, bp, sa, host_threads(), &e))) return set_err(rc, e.msg);
+  return FEMTO_AMD_OK;
+}
+
+int femto_amd_build_index(const char* out_dir, int ndocs, const uint8_t* const* docs, const int64_t* doc_lens,
+                          const char* const* doc_infos, const char* params, int device) {
+  if (!out_dir) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  std::vector<Document> d;
+  int rc = collect_docs(ndocs, docs, doc_lens, doc_infos, &d);
+  if (rc) return rc;
+  BuildParams bp;
+  Error e{0, ""};
+  if ((rc = parse_build_params(params, &bp, &e))) return set_err(rc, e.msg);
+  std::vector<uint16_t> text;
+  std::vector<int64_t> doc_ends, sa;
+  prepare_text(d, &text, &doc_ends);
+  if ((rc = gpu_suffix_sort(text, device, &sa, &e))) return set_err(rc, e.msg);
+  text.clear();
+  text.shrink_to_fit();
+  if ((rc = build_index_from_sa(out_dir, d, bp, sa.data(), host_threads(), &e))) return set_err(rc, e.msg);
+  return FEMTO_AMD_OK;
+}
+
+/* test hook: bseq_construct_forcetype-compatible encoder (src/main/wtree.c:365) */
+int femto_amd_bseq_encode(const uint8_t* bits_msb_first, int64_t bitlen, int force_type, uint8_t* out, int64_t cap,
+                          int64_t* out_len) {
+  if (!bits_msb_first || bitlen <= 0 || !out_len) return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
+  std::vector<uint8_t> z;
+  bseq_encode(bits_msb_first, bitlen, force_type, &z);
+  *out_len = int64_t(z.size());
+  if (out) {
+    if (cap < int64_t(z.size())) return set_err(FEMTO_AMD_ERR_PARAM, "output buffer too small");
+    memcpy(out, z.data(), z.size());
+  }
+  return FEMTO_AMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,45 @@
+// host_index.hpp -- host-side loader of a femto index (directory or flattened file).
+// Parses what the reference parses lazily in b_fault()/read_block_header()
+// (src/main/index.c:1222-1404) once, up front, into the flat tables of device_tables.h.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "device_tables.h"
+
+namespace femto_amd {
+
+struct Error {
+  int code;
+  std::string msg;
+};
+
+struct HostIndex {
+  // block header facts
+  int64_t total_length = 0, number_of_blocks = 0, number_of_documents = 0;
+  int32_t block_size = 0, b_size = 0, mark_period = 0, chunk_size = 0, text_size_bits = 0;
+  int32_t buckets_per_block = 0;
+  int64_t total_buckets = 0;
+
+  // raw images
+  std::vector<uint8_t> header;          // header block bytes
+  std::vector<uint8_t> image;           // all data blocks, each start 256-byte aligned (+ tail pad)
+  std::vector<uint64_t> block_off;      // offset of data block b inside image
+  std::vector<uint64_t> block_len;
+
+  // derived tables
+  std::vector<DevNode> nodes;
+  std::vector<DevBucket> buckets;
+  std::vector<DevSeq> seqs;
+  std::vector<int64_t> occ_base;        // [gb*261+ch]
+  std::vector<uint32_t> leaf_code;      // [gb*261+ch]
+  std::vector<int64_t> C;               // 262 entries
+  std::vector<int64_t> doc_ends;
+
+  // Returns 0 or an err_code_t value; fills err.msg.
+  int load(const std::string& path, Error* err);
+  int resolve_location(int64_t offset, int64_t* doc, int64_t* doc_offset) const;
+};
+
+}  // namespace femto_amd

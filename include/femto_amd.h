@@ -1,0 +1,163 @@
+/*
+ * femto_amd.h -- C ABI of the MI355X-native FM-index query engine (drop-in for femto's batched
+ * count/locate path).  Plain pointers and sizes only; no C++/torch/HIP types in any signature.
+ *
+ * The reference (femto-dev/femto v1.3.0) exposes no plugin ABI; its batch entry points are the C
+ * functions of src/main/femto_internal.h.  Each entry point below names the reference interface it
+ * replaces (paths relative to the reference tree).  INTEGRATION.md shows the shim a femto
+ * maintainer would add so that parallel_count()/parallel_locate() call into this library.
+ *
+ * Conventions kept from the reference:
+ *   - patterns are arrays of alpha_t (uint16_t) = byte + 5 (src/main/index_types.h:61-69);
+ *   - every function returns an err_code_t value (src/utils/error.h:25-39), 0 = OK;
+ *   - calls are blocking; a handle may be used from several host threads (calls on one handle are
+ *     serialised internally);
+ *   - results are bit-exact with parallel_count / parallel_locate on the same index files.
+ *
+ * All compute runs in hand-written HIP kernels on the GPU; there is NO CPU fallback: if no HIP
+ * device is usable, femto_amd_open fails with FEMTO_AMD_ERR_INVALID.
+ */
+#ifndef FEMTO_AMD_H
+#define FEMTO_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* err_code_t of src/utils/error.h:25-39 (same numeric values) */
+enum {
+  FEMTO_AMD_OK = 0,
+  FEMTO_AMD_ERR_MEM = 1,
+  FEMTO_AMD_ERR_IO = 2,
+  FEMTO_AMD_ERR_PARAM = 3,
+  FEMTO_AMD_ERR_FORMAT = 4,
+  FEMTO_AMD_ERR_BZ_DATA = 5,
+  FEMTO_AMD_ERR_INVALID = 6,
+  FEMTO_AMD_ERR_MISSING = 8,
+  FEMTO_AMD_ERR_UNKNOWN = 12
+};
+
+#define FEMTO_AMD_ALPHA_SIZE 261       /* src/main/index_types.h:64-66 */
+#define FEMTO_AMD_CHARACTER_OFFSET 5
+
+typedef struct femto_amd_index femto_amd_index_t;   /* opaque; owns the device-resident index */
+
+/* Replaces femto_start_server_err + femto_loc_for_path_err (src/main/femto.c:54,269) and the lazy
+ * block faults of open_header_block/open_data_block (src/main/index.c:1482,1419): reads a femto
+ * index (directory "<dir>/00","<dir>/01".. per src/main/block_storage.c:257-263, or a flattened
+ * single file per src/main/index.c:2260), validates every block header (src/main/index.c:1348),
+ * uploads the block images unchanged to HBM of HIP device `device` and builds the small side tables
+ * (per-bucket Huffman leaf codes, wavelet-node directory, Occ bases). */
+int femto_amd_open(const char* index_path, int device, femto_amd_index_t** out);
+void femto_amd_close(femto_amd_index_t* ix);
+
+/* like err_string() of src/utils/error.h:72; thread-local message of the last failing call */
+const char* femto_amd_last_error(void);
+
+/* index facts (block header fields, src/main/index.c:817-868) */
+typedef struct {
+  int64_t total_length;       /* rows of L == prepared text length */
+  int64_t number_of_blocks;
+  int64_t number_of_documents;
+  int32_t block_size, bucket_size, mark_period, chunk_size;
+  int32_t text_size_bits;     /* bits per mark-array record */
+  int64_t total_buckets;
+  int64_t image_bytes;        /* bytes of femto block images resident in HBM */
+  int64_t table_bytes;        /* bytes of derived side tables resident in HBM */
+} femto_amd_info_t;
+int femto_amd_info(const femto_amd_index_t* ix, femto_amd_info_t* out);
+
+/* ---- host-pointer batch API ------------------------------------------------------------- */
+
+/* Replaces parallel_count (src/main/femto.c:275; do_string_query src/main/server.c:713):
+ * for pattern i, [first[i], last[i]] is the inclusive row range of the backward search (first>last
+ * when there is no match; the empty pattern gives [0, total_length-1]).  If last==NULL, first[i]
+ * receives the match count last-first+1 (src/main/femto.c:313-318). */
+int femto_amd_parallel_count(femto_amd_index_t* ix, int npats, const int* plen,
+                             const uint16_t* const* pats, int64_t* first, int64_t* last);
+
+/* Replaces parallel_locate (src/main/femto.c:331; do_locate_query src/main/server.c:4373):
+ * noccs[i] rows are located per pattern, clamped as the reference does (when last-first >
+ * max_occs_each only max_occs_each rows are located -- i.e. a range of exactly max_occs_each+1 rows
+ * is returned whole, src/main/server.c:4411); offsets[i] is malloc()ed by the callee (NULL when
+ * noccs[i]==0) and free()d by the caller; offsets[i][j] = SA[first[i]+j], row order. */
+int femto_amd_parallel_locate(femto_amd_index_t* ix, int npats, const int* plen,
+                              const uint16_t* const* pats, int max_occs_each,
+                              int* noccs, int64_t** offsets);
+
+/* Flat forms of the two calls above (no per-pattern pointers): pattern i is
+ * pats[starts[i] .. starts[i]+plen[i]).  locate_flat writes out_starts[npats+1] (exclusive prefix
+ * sum of noccs) and at most offsets_capacity offsets; *total_out receives sum(noccs) -- call with
+ * offsets==NULL to size the buffer. */
+int femto_amd_count_flat(femto_amd_index_t* ix, int64_t npats, const int32_t* plen,
+                         const uint16_t* pats, const int64_t* starts, int64_t* first, int64_t* last);
+int femto_amd_locate_flat(femto_amd_index_t* ix, int64_t npats, const int32_t* plen,
+                          const uint16_t* pats, const int64_t* starts, int max_occs_each,
+                          int32_t* noccs, int64_t* out_starts, int64_t* offsets,
+                          int64_t offsets_capacity, int64_t* total_out);
+
+/* Raw-byte convenience form: patterns given as bytes (each +5 -> alpha_t), as femto_search does
+ * for literal patterns. */
+int femto_amd_count_bytes(femto_amd_index_t* ix, int64_t npats, const int32_t* plen,
+                          const uint8_t* bytes, const int64_t* starts, int64_t* first, int64_t* last);
+
+/* Offset -> (document, offset in document): resolve_location (src/main/index.c:1587). */
+int femto_amd_resolve_location(const femto_amd_index_t* ix, int64_t offset, int64_t* doc, int64_t* doc_offset);
+
+/* ---- device-pointer batch API (inputs and outputs already resident in HBM) ---------------- */
+/* All pointers are device pointers on the index's device; `stream` is a hipStream_t passed as
+ * void* (NULL = default stream).  Calls only enqueue work and return; the caller synchronises. */
+int femto_amd_count_device(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen,
+                           const uint16_t* d_pats, const int64_t* d_starts,
+                           int64_t* d_first, int64_t* d_last, void* stream);
+
+/* Locate on device: phase 1 (count + clamp + prefix sum) writes d_noccs[npats] and
+ * d_out_starts[npats+1]; the caller reads d_out_starts[npats] (= total) to size d_offsets, then
+ * phase 2 walks every row.  d_first must hold the ranges' first rows (phase 1 fills it). */
+int femto_amd_locate_plan_device(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen,
+                                 const uint16_t* d_pats, const int64_t* d_starts, int max_occs_each,
+                                 int64_t* d_first, int64_t* d_last, int32_t* d_noccs,
+                                 int64_t* d_out_starts, void* stream);
+int femto_amd_locate_walk_device(femto_amd_index_t* ix, int64_t npats, const int64_t* d_first,
+                                 const int64_t* d_out_starts, int64_t total, int64_t* d_offsets,
+                                 void* stream);
+
+/* ---- leaf requests (the reference's block_request interface, src/main/index.h:300-394) ---- */
+/* For rows[i] (global row numbers, host memory): ch_out = L[row] (BLOCK_REQUEST_CHAR),
+ * occ_out = Occ-in-block(L[row] or ch_in[i], row) (BLOCK_REQUEST_OCCS; ch_in==NULL -> use L[row]),
+ * off_out = mark offset or -1 (BLOCK_REQUEST_LOCATION).  Any output pointer may be NULL. */
+int femto_amd_block_requests(femto_amd_index_t* ix, int64_t n, const int64_t* rows, const uint16_t* ch_in,
+                             uint16_t* ch_out, int32_t* occ_out, int64_t* off_out);
+
+/* ---- profiling hooks ---------------------------------------------------------------------- */
+/* Average duration (ms) of the launches of the named kernel ("count", "locate") since the last
+ * reset, measured with HIP events on the stream the kernel was launched on; n_launches out. */
+int femto_amd_kernel_time_ms(femto_amd_index_t* ix, const char* kernel, double* avg_ms, int64_t* n_launches);
+void femto_amd_kernel_time_reset(femto_amd_index_t* ix);
+void femto_amd_kernel_time_enable(femto_amd_index_t* ix, int on);
+
+/* ---- index construction (femto block-file writer) ------------------------- */
+/* Builds a femto index directory (byte-identical to index_documents(map=NULL),
+ * src/main/construct.c:572) from `ndocs` documents given as raw bytes.  The suffix array of the
+ * prepared text (bytes+5, one SEOF per document; src/main/bwt_prepare.c:227-311, ordered as the
+ * reference's test sorter orders it, src/main/bwt_qsufsort.c:176-240) is computed on the GPU.
+ * params: "block_size=..,bucket_size=..,mark_period=.." (src/main/index.c:185-219) or NULL. */
+int femto_amd_build_index(const char* out_dir, int ndocs, const uint8_t* const* docs, const int64_t* doc_lens,
+                          const char* const* doc_infos, const char* params, int device);
+/* Same, from a caller-supplied suffix array of the prepared text (host arrays); no GPU needed. */
+int femto_amd_build_index_from_sa(const char* out_dir, int ndocs, const uint8_t* const* docs,
+                                  const int64_t* doc_lens, const char* const* doc_infos,
+                                  const char* params, const int64_t* sa);
+
+/* Test hook: encodes one binary sequence exactly as bseq_construct_forcetype does
+ * (src/main/wtree.c:365; force_type -1 literal only, 0 automatic, 1 RLE only).  out may be NULL to size. */
+int femto_amd_bseq_encode(const uint8_t* bits_msb_first, int64_t bitlen, int force_type, uint8_t* out,
+                          int64_t cap, int64_t* out_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
