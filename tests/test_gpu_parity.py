@@ -1,0 +1,179 @@
+"""`-m gpu` parity tests: the HIP path (through the C ABI, femto_amd/libfemto_amd.so) against the
+oracle and the committed golden vectors of the genuine reference.  Bit-exact (integer work)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import femto_amd
+from conftest import INDEX_FIXTURES
+from femto_amd import textgen as tg
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu_ok():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return True
+
+
+@pytest.mark.parametrize("name", INDEX_FIXTURES)
+def test_leaf_requests_match_reference(fixtures, gpu_ok, name):
+    """block_request CHAR|OCCS|LOCATION for every row (index_test.c:60-476 checks the same leaves)."""
+    fx = fixtures(name)
+    g = fx.gold
+    ix = femto_amd.Index(fx.index, device=0)
+    n = ix.info.total_length
+    rows = np.arange(n, dtype=np.int64)
+    ch, occ, off = ix.block_requests(rows)
+    assert np.array_equal(ch, g["L"])
+    assert np.array_equal(occ, g["occ"])
+    assert np.array_equal(off, g["off"])
+    for key in g.files:
+        if key.startswith("occs_ch"):
+            c = int(key[7:])
+            _, occ_c, _ = ix.block_requests(rows, np.full(n, c, dtype=np.uint16))
+            assert np.array_equal(occ_c, g[key]), c
+    ix.close()
+
+
+@pytest.mark.parametrize("name", INDEX_FIXTURES)
+def test_count_locate_match_reference_goldens(fixtures, gpu_ok, name):
+    fx = fixtures(name)
+    ix = femto_amd.Index(fx.index, device=0)
+    plen, flat, starts = fx.patterns
+    first, last = ix.count_flat(plen, flat, starts)
+    assert np.array_equal(first, fx.gold["count_first"])
+    assert np.array_equal(last, fx.gold["count_last"])
+    for mo, noccs, offs in fx.locate_cases():
+        n, got = ix.locate_flat(plen, flat, starts, mo)
+        assert np.array_equal(n, noccs), mo
+        assert np.array_equal(got, offs), mo
+    ix.close()
+
+
+def test_flattened_index(fixtures, gpu_ok):
+    fx = fixtures("acgt48k")
+    a = femto_amd.Index(fx.index, device=0)
+    b = femto_amd.Index(fx.flat, device=0)
+    plen, flat, starts = fx.patterns
+    for x, y in zip(a.count_flat(plen, flat, starts), b.count_flat(plen, flat, starts)):
+        assert np.array_equal(x, y)
+    for x, y in zip(a.locate_flat(plen, flat, starts, 9), b.locate_flat(plen, flat, starts, 9)):
+        assert np.array_equal(x, y)
+
+
+def test_pointer_array_forms(fixtures, gpu_ok):
+    """femto_amd_parallel_count / femto_amd_parallel_locate: the reference's own calling convention
+    (alpha_t** patterns, callee-malloc'd offsets[i], femto.c:275-400)."""
+    fx = fixtures("eng2doc")
+    ix = femto_amd.Index(fx.index, device=0)
+    plen, flat, starts = fx.patterns
+    n = len(plen)
+    L = femto_amd.lib()
+    pats = [np.ascontiguousarray(flat[starts[i]:starts[i] + plen[i]]) for i in range(n)]
+    parr = (C.c_void_p * n)(*[p.ctypes.data if len(p) else None for p in pats])
+    pl = plen.astype(np.int32)
+    first = np.zeros(n, dtype=np.int64)
+    last = np.zeros(n, dtype=np.int64)
+    assert L.femto_amd_parallel_count(ix.handle, n, pl.ctypes.data, parr, first.ctypes.data, last.ctypes.data) == 0
+    assert np.array_equal(first, fx.gold["count_first"]) and np.array_equal(last, fx.gold["count_last"])
+    cnt = np.zeros(n, dtype=np.int64)   # last == NULL -> counts (femto.c:313-318)
+    assert L.femto_amd_parallel_count(ix.handle, n, pl.ctypes.data, parr, cnt.ctypes.data, None) == 0
+    assert np.array_equal(cnt, last - first + 1)
+    noccs = np.zeros(n, dtype=np.int32)
+    offs = (C.POINTER(C.c_int64) * n)()
+    assert L.femto_amd_parallel_locate(ix.handle, n, pl.ctypes.data, parr, 7, noccs.ctypes.data, offs) == 0
+    assert np.array_equal(noccs, fx.gold["loc7_noccs"])
+    got = []
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    for i in range(n):
+        if noccs[i]:
+            got.extend(offs[i][j] for j in range(noccs[i]))
+            libc.free(offs[i])
+        else:
+            assert not offs[i]
+    assert np.array_equal(np.array(got, dtype=np.int64), fx.gold["loc7_offs"])
+
+
+def test_invalid_pattern_character_is_param_error(fixtures, gpu_ok):
+    fx = fixtures("acgt48k")
+    ix = femto_amd.Index(fx.index, device=0)
+    with pytest.raises(femto_amd.FemtoAmdError) as ei:
+        ix.count([np.array([70, 300], dtype=np.uint16)])
+    assert ei.value.code == 3
+    # the handle stays usable
+    f, l = ix.count([np.array([70], dtype=np.uint16)])
+    assert l[0] >= f[0]
+
+
+def _random_index(tmp_path, text, params, name):
+    out = str(tmp_path / name)
+    femto_amd.build_index(out, [text], params=params, infos=[name], device=0)
+    return out
+
+
+def test_gpu_built_index_vs_oracle_medium(tmp_path, gpu_ok):
+    """4 MiB random ACGT with the reference's DEFAULT parameters (bucket 2^20 rows): the GPU
+    suffix sorter + writer build the index, the HIP query path is compared with the oracle on
+    100 k patterns (BASELINE config 1 shape, scaled), plus size-independent properties."""
+    text = tg.t_acgt(1 << 22, 2024)
+    path = _random_index(tmp_path, text, None, "acgt4m")
+    ix = femto_amd.Index(path, device=0)
+    o = po.Oracle(path)
+    assert ix.info.total_length == o.total_length == len(text) + 1
+    plen_r, flat_r = tg.p_rand(20, 50000, 7)
+    plen_h, flat_h = tg.p_hit(20, 20, 50000, 8, text)
+    plen = np.concatenate([plen_r, plen_h])
+    flat = np.concatenate([flat_r, flat_h])
+    starts = tg.starts_of(plen)
+    first, last = ix.count_flat(plen, flat, starts)
+    of, ol = o.count_flat(plen, flat, starts, threads=8)
+    assert np.array_equal(first, of) and np.array_equal(last, ol)
+    assert ((last - first + 1)[50000:] >= 1).all()          # sampled substrings always occur
+    noccs, offs = ix.locate_flat(plen, flat, starts, 50)
+    on, oo = o.locate_flat(plen, flat, starts, 50, threads=8)
+    assert np.array_equal(noccs, on) and np.array_equal(offs, oo)
+    # located offsets really are occurrences of the pattern in the text
+    pos = np.concatenate([[0], np.cumsum(noccs)])
+    for i in list(range(0, 200)) + list(range(50000, 50200)):
+        p = (flat[starts[i]:starts[i] + plen[i]] - 5).astype(np.uint8)
+        for off in offs[pos[i]:pos[i + 1]]:
+            assert np.array_equal(text[off:off + len(p)], p)
+
+
+def test_gpu_built_english_like_vs_oracle(tmp_path, gpu_ok):
+    """sigma ~ 96 text (RLE-heavy wavelet nodes, deep Huffman codes), mixed-length patterns 8..64
+    (BASELINE config 3 shape, scaled)."""
+    text = tg.t_eng(3 << 20, 99)
+    path = _random_index(tmp_path, text, "block_size=2097152,bucket_size=262144,mark_period=20", "eng3m")
+    ix = femto_amd.Index(path, device=0)
+    o = po.Oracle(path)
+    plen, flat = tg.p_hit(8, 64, 40000, 5, text)
+    starts = tg.starts_of(plen)
+    first, last = ix.count_flat(plen, flat, starts)
+    of, ol = o.count_flat(plen, flat, starts, threads=8)
+    assert np.array_equal(first, of) and np.array_equal(last, ol)
+    noccs, offs = ix.locate_flat(plen, flat, starts, 20)
+    on, oo = o.locate_flat(plen, flat, starts, 20, threads=8)
+    assert np.array_equal(noccs, on) and np.array_equal(offs, oo)
+
+
+def test_full_text_lf_walk_recovers_every_offset(tmp_path, gpu_ok):
+    """Size-independent property: locating the range of the EMPTY pattern (all rows) returns a
+    permutation of 0..n-1, i.e. the whole suffix array, and L[row] == text[SA[row]-1]."""
+    text = tg.t_acgt(300000, 5)
+    path = _random_index(tmp_path, text, "block_size=131072,bucket_size=16384,mark_period=32", "perm")
+    ix = femto_amd.Index(path, device=0)
+    n = ix.info.total_length
+    noccs, offs = ix.locate([np.zeros(0, dtype=np.uint16)], n)
+    assert noccs[0] == n
+    assert np.array_equal(np.sort(offs), np.arange(n))
+    ch, _, _ = ix.block_requests(np.arange(n, dtype=np.int64))
+    prepared = np.concatenate([text.astype(np.uint16) + 5, [2]])
+    assert np.array_equal(ch, prepared[offs - 1])           # SA[row]==0 wraps to the final SEOF
