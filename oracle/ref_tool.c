@@ -306,7 +306,9 @@ static int cmd_locate(int argc, char** argv)
   return 0;
 }
 
-/* bench <index> <patfile> <count|locate> <max_occs> <threads> <reps> */
+/* bench <index> <patfile> <count|locate> <max_occs> <threads> <reps> [out.bin]
+   (out.bin, count mode: i64 first[n], i64 last[n] of the last repetition -- lets the caller check
+   the very results that were timed) */
 static int cmd_bench(int argc, char** argv)
 {
   if (argc < 6) return 2;
@@ -340,6 +342,12 @@ static int cmd_bench(int argc, char** argv)
       for (int i = 0; i < ps.npats; i++) if (last[i] >= first[i]) results += last[i] - first[i] + 1;
     }
     if (rep >= 0) { tot += dt; if (dt < best) best = dt; }
+  }
+  if (argc >= 7 && !locate) {
+    FILE* out = fopen(argv[6], "wb");
+    fwrite(first, 8, ps.npats, out);
+    fwrite(last, 8, ps.npats, out);
+    fclose(out);
   }
   printf("{\"mode\": \"%s\", \"npats\": %d, \"threads\": %d, \"reps\": %d, \"best_s\": %.6f, \"mean_s\": %.6f, "
          "\"results\": %lld, \"patterns_per_s\": %.1f}\n",
