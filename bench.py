@@ -201,7 +201,7 @@ def main():
                 traffic = None
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "count_kernel<32>", "kernel_ms": kern_ms, "launches_timed": kern_n,
+                "kernel": "count_kernel_lane" if ix.rank_mode == 1 else "count_kernel<32>", "kernel_ms": kern_ms, "launches_timed": kern_n,
                 "algorithmic_bytes_per_launch": alg_launch,
                 "per_pattern": {"bseq_rank": c["n_rank"] / sample, "occ": c["n_occ"] / sample,
                                 "S_bytes_per_rank": c["s_bytes"] / max(1, c["n_rank"]),

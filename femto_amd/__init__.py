@@ -70,6 +70,8 @@ def lib():
         L.femto_amd_kernel_time_enable.restype = None
         L.femto_amd_build_index.argtypes = [C.c_char_p, i32, vp, vp, vp, C.c_char_p, i32]
         L.femto_amd_build_index_from_sa.argtypes = [C.c_char_p, i32, vp, vp, vp, C.c_char_p, vp]
+        L.femto_amd_set_rank_mode.argtypes = [vp, i32]
+        L.femto_amd_get_rank_mode.argtypes = [vp]
         L.femto_amd_bseq_encode.argtypes = [vp, i64, i32, vp, i64, C.POINTER(i64)]
         _lib = L
     return _lib
@@ -181,6 +183,14 @@ class Index:
     def locate_walk_device(self, npats, d_first, d_out_starts, total, d_offsets, stream=0):
         _check(lib().femto_amd_locate_walk_device(self._h, npats, d_first, d_out_starts, total, d_offsets,
                                                   stream or None))
+
+    def set_rank_mode(self, mode):
+        """1 = lane-per-query over the block directory (default), 0 = wavefront-per-query raw walk"""
+        _check(lib().femto_amd_set_rank_mode(self._h, mode))
+
+    @property
+    def rank_mode(self):
+        return lib().femto_amd_get_rank_mode(self._h)
 
     def kernel_time(self, name):
         ms, n = C.c_double(), C.c_int64()

@@ -93,7 +93,9 @@ struct femto_amd_index {
   int64_t* d_occ_base = nullptr;
   uint32_t* d_leaf_code = nullptr;
   int64_t* d_C = nullptr;
+  DirEntry* d_dir = nullptr;
   int* d_err = nullptr;
+  int mode = 1;  // 1: lane-per-item kernels over the block directory; 0: wavefront-cooperative raw A/S/D walk
   DevIndex dev{};
   int64_t table_bytes = 0;
   // scratch for the host-pointer API and the locate plan
@@ -144,8 +146,14 @@ int launch_count(femto_amd_index* ix, int64_t npats, const int32_t* d_plen, cons
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, stream));
   }
-  hipLaunchKernelGGL((count_kernel<kGroupW>), dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats,
-                     d_plen, d_pats, d_starts, d_first, d_last, ix->d_err);
+  if (ix->mode == 1) {
+    const int64_t lblocks = (npats + kBlockThreads - 1) / kBlockThreads;
+    hipLaunchKernelGGL(count_kernel_lane, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
+                       d_pats, d_starts, d_first, d_last, ix->d_err);
+  } else {
+    hipLaunchKernelGGL((count_kernel<kGroupW>), dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats,
+                       d_plen, d_pats, d_starts, d_first, d_last, ix->d_err);
+  }
   HIP_TRY(hipGetLastError());
   if (ix->timing) {
     HIP_TRY(hipEventRecord(e1, stream));
@@ -188,8 +196,14 @@ int launch_locate(femto_amd_index* ix, int64_t npats, const int64_t* d_first, co
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, stream));
   }
-  hipLaunchKernelGGL((locate_kernel<kGroupW>), dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats,
-                     d_first, d_out_starts, total, d_offsets);
+  if (ix->mode == 1) {
+    const int64_t lblocks = (total + kBlockThreads - 1) / kBlockThreads;
+    hipLaunchKernelGGL(locate_kernel_lane, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_first,
+                       d_out_starts, total, d_offsets);
+  } else {
+    hipLaunchKernelGGL((locate_kernel<kGroupW>), dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats,
+                       d_first, d_out_starts, total, d_offsets);
+  }
   HIP_TRY(hipGetLastError());
   if (ix->timing) {
     HIP_TRY(hipEventRecord(e1, stream));
@@ -261,6 +275,7 @@ int femto_amd_open(const char* index_path, int device, femto_amd_index_t** out) 
       if ((r = upload(&ix->d_occ_base, h.occ_base, &ix->table_bytes))) return r;
       if ((r = upload(&ix->d_leaf_code, h.leaf_code, &ix->table_bytes))) return r;
       if ((r = upload(&ix->d_C, h.C, &ix->table_bytes))) return r;
+      if ((r = upload(&ix->d_dir, h.dir, &ix->table_bytes))) return r;
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_err), sizeof(int)));
       HIP_TRY(hipMemset(ix->d_err, 0, sizeof(int)));
       DevIndex& d = ix->dev;
@@ -271,11 +286,17 @@ int femto_amd_open(const char* index_path, int device, femto_amd_index_t** out) 
       d.occ_base = ix->d_occ_base;
       d.leaf_code = ix->d_leaf_code;
       d.C = ix->d_C;
+      d.dir = ix->d_dir;
       d.total_length = h.total_length;
       d.total_buckets = h.total_buckets;
       d.b_size = h.b_size;
       d.b_shift = (h.b_size & (h.b_size - 1)) == 0 ? __builtin_ctz(unsigned(h.b_size)) : -1;
       d.text_size_bits = h.text_size_bits;
+      ix->mode = h.dir_regular ? 1 : 0;
+      if (const char* m = getenv("FEMTO_AMD_RANK_MODE")) {
+        if (!strcmp(m, "raw")) ix->mode = 0;
+        else if (!strcmp(m, "dir") && h.dir_regular) ix->mode = 1;
+      }
       return 0;
     };
     rc = up();
@@ -301,6 +322,7 @@ void femto_amd_close(femto_amd_index_t* ix) {
     (void)hipFree(ix->d_occ_base);
     (void)hipFree(ix->d_leaf_code);
     (void)hipFree(ix->d_C);
+    (void)hipFree(ix->d_dir);
     (void)hipFree(ix->d_err);
     for (DeviceBuffer* b : {&ix->s_plen, &ix->s_pats, &ix->s_starts, &ix->s_first, &ix->s_last, &ix->s_noccs,
                             &ix->s_noccs64, &ix->s_out_starts, &ix->s_offsets, &ix->s_scan[0], &ix->s_scan[1],
@@ -325,7 +347,7 @@ int femto_amd_info(const femto_amd_index_t* ix, femto_amd_info_t* out) {
   out->image_bytes = int64_t(h.image.size());
   out->table_bytes = int64_t(h.nodes.size() * sizeof(DevNode) + h.buckets.size() * sizeof(DevBucket) +
                              h.seqs.size() * sizeof(DevSeq) + h.occ_base.size() * 8 + h.leaf_code.size() * 4 +
-                             h.C.size() * 8);
+                             h.C.size() * 8 + h.dir.size() * sizeof(DirEntry));
   return FEMTO_AMD_OK;
 }
 
@@ -514,8 +536,13 @@ int femto_amd_block_requests(femto_amd_index_t* ix, int64_t n, const int64_t* ro
     HIP_TRY(hipMemcpy(d_chin, ch_in, size_t(n) * 2, hipMemcpyHostToDevice));
   }
   const int64_t blocks = (n * kGroupW + kBlockThreads - 1) / kBlockThreads;
-  hipLaunchKernelGGL((block_request_kernel<kGroupW>), dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, nullptr, ix->dev, n,
-                     ix->s_rows.as<int64_t>(), d_chin, d_chout, ix->s_occ.as<int64_t>(), ix->s_off.as<int64_t>());
+  if (ix->mode == 1)
+    hipLaunchKernelGGL(block_request_kernel_lane, dim3(uint32_t((n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads),
+                       0, nullptr, ix->dev, n, ix->s_rows.as<int64_t>(), d_chin, d_chout, ix->s_occ.as<int64_t>(),
+                       ix->s_off.as<int64_t>());
+  else
+    hipLaunchKernelGGL((block_request_kernel<kGroupW>), dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, nullptr, ix->dev, n,
+                       ix->s_rows.as<int64_t>(), d_chin, d_chout, ix->s_occ.as<int64_t>(), ix->s_off.as<int64_t>());
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   std::vector<uint16_t> chs((size_t(n)));
@@ -538,6 +565,17 @@ int femto_amd_block_requests(femto_amd_index_t* ix, int64_t n, const int64_t* ro
   }
   return FEMTO_AMD_OK;
 }
+
+int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode) {
+  if (!ix || (mode != 0 && mode != 1)) return set_err(FEMTO_AMD_ERR_PARAM, "bad rank mode");
+  if (mode == 1 && !ix->host.dir_regular)
+    return set_err(FEMTO_AMD_ERR_INVALID, "this index has a short non-final segment: only the raw walk (mode 0) applies");
+  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  ix->mode = mode;
+  return FEMTO_AMD_OK;
+}
+
+int femto_amd_get_rank_mode(const femto_amd_index_t* ix) { return ix ? ix->mode : -1; }
 
 void femto_amd_kernel_time_enable(femto_amd_index_t* ix, int on) {
   if (ix) ix->timing = on != 0;

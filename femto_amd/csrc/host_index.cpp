@@ -98,6 +98,54 @@ struct BitReader {  // MSB-first, like bsR24 (src/utils/buffer_funcs.h:136)
   }
 };
 
+// Re-expresses one sequence's A0/A1/AP + varbyte S tables (src/main/wtree_funcs.h:294-358) as a
+// block directory: for every 512-bit block the segment holding its first bit, with the
+// cumulative and in-segment (zeros, ones).
+int build_directory(const std::vector<uint8_t>& img, DevBseq* bs, std::vector<DirEntry>* dir, bool* regular, Error* e) {
+  bs->dir_base = uint32_t(dir->size());
+  if (dir->size() > 0xfff00000ull) return fail(e, ERR_MEM, "block directory too large");
+  const uint8_t* z = img.data() + bs->off;
+  const uint32_t G = bs->num_groups;
+  const uint8_t* A0 = z + 16;
+  const uint8_t* A1 = A0 + 4ull * G;
+  const uint8_t* AP = A1 + 4ull * G;
+  const uint8_t* S = AP + 4ull * G;
+  const uint8_t* Send = z + bs->d_off;
+  const uint64_t nseg = (uint64_t(bs->total_words) + kSegmentWords - 1) / kSegmentWords;
+  uint64_t pos = 0, next_block = 0;
+  uint64_t seg = 0;
+  for (uint32_t g = 0; g < G && seg < nseg; g++) {
+    uint32_t o0 = be32(A0 + 4ull * g), o1 = be32(A1 + 4ull * g);
+    if (uint64_t(o0) + o1 != pos) return fail(e, ERR_FORMAT, "bseq group table disagrees with segment sums");
+    const uint8_t* sp = S + be32(AP + 4ull * g);
+    for (int j = 0; j < kGroupSize && seg < nseg; j++, seg++) {
+      uint32_t v[2];
+      for (int k = 0; k < 2; k++) {
+        uint32_t val = 0;
+        int i = 0;
+        for (;;) {
+          if (sp >= Send || i > 4) return fail(e, ERR_FORMAT, "bseq segment sums run past the S section");
+          const uint8_t w = *sp++;
+          val |= uint32_t(w & 0x7f) << (7 * i++);
+          if (w & 0x80) break;
+        }
+        v[k] = val;
+      }
+      const uint64_t len = uint64_t(v[0]) + v[1];
+      if (len < 511 && seg + 1 < nseg) *regular = false;
+      while (next_block * 512 < pos + len) {
+        dir->push_back(DirEntry{o0, o1, v[0], v[1], uint32_t(seg), 0});
+        next_block++;
+      }
+      pos += len;
+      o0 += v[0];
+      o1 += v[1];
+    }
+  }
+  if (seg != nseg) return fail(e, ERR_FORMAT, "bseq has fewer segment sums than segments");
+  return OK;
+}
+
 int parse_bseq(const std::vector<uint8_t>& img, uint64_t abs, uint64_t limit, DevBseq* out, Error* e) {
   if (abs + 16 > limit) return fail(e, ERR_FORMAT, "bseq header out of range");
   const uint8_t* z = img.data() + abs;
@@ -105,7 +153,7 @@ int parse_bseq(const std::vector<uint8_t>& img, uint64_t abs, uint64_t limit, De
   out->num_groups = be32(z + 4);
   out->total_words = be32(z + 8);
   out->d_off = be32(z + 12);
-  out->pad = 0;
+  out->dir_base = 0;
   if (be32(z) != 0) return fail(e, ERR_FORMAT, "bseq header word 0 not zero");
   uint64_t need_dir = 16 + 12ull * out->num_groups;
   if (out->d_off < need_dir || abs + out->d_off + 8ull * out->total_words > limit)
@@ -320,6 +368,8 @@ int HostIndex::load(const std::string& path, Error* e) {
         } else {
           rc = parse_bseq(image, boff + wt_off + off, blimit, &nd.bs, e);
           if (rc) return rc;
+          rc = build_directory(image, &nd.bs, &dir, &dir_regular, e);
+          if (rc) return rc;
         }
         for (int bit = 0; bit < 2; bit++) {
           uint32_t childnum = node_num[i] * 2 + uint32_t(bit);
@@ -345,6 +395,8 @@ int HostIndex::load(const std::string& path, Error* e) {
         uint32_t toff = be32(d + mt_off + 4 * size_t(s));
         if (toff & 7) return fail(e, ERR_FORMAT, "misaligned mark table");
         rc = parse_bseq(image, boff + mt_off + toff, blimit, &sq.mark_table, e);
+        if (rc) return rc;
+        rc = build_directory(image, &sq.mark_table, &dir, &dir_regular, e);
         if (rc) return rc;
         uint32_t aoff = be32(d + ma_off + 4 * size_t(s));
         sq.mark_array = boff + ma_off + aoff;

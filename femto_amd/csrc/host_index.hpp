@@ -32,6 +32,8 @@ struct HostIndex {
   std::vector<DevNode> nodes;
   std::vector<DevBucket> buckets;
   std::vector<DevSeq> seqs;
+  std::vector<DirEntry> dir;            // block directories (see device_tables.h)
+  bool dir_regular = true;              // false: some non-final segment holds < 511 bits -> raw A/S walk only
   std::vector<int64_t> occ_base;        // [gb*261+ch]
   std::vector<uint32_t> leaf_code;      // [gb*261+ch]
   std::vector<int64_t> C;               // 262 entries

@@ -471,4 +471,259 @@ __global__ __launch_bounds__(256) void block_request_kernel(const DevIndex ix, c
   }
 }
 
+
+// =====================================================================================
+// Lane-per-item kernels over the block directory (device_tables.h: DirEntry).
+//
+// Measured on MI355X (profiles/r01_v1_*): the wavefront-cooperative walk above spends ~190 VALU
+// wave-instructions per rank (cross-lane scans/shuffles) and is VALU-issue + latency bound at 5 %
+// of the HBM roofline.  Here every LANE owns a whole query: a rank is ONE 24-byte directory load
+// (which segment, and the zeros/ones before it) plus the 64-byte segment itself, ~1 instruction per
+// rank per lane once amortised over the 64 lanes of a wavefront, so the kernel is limited by the
+// memory system (random 64-byte segment reads), which is what the roofline prices.
+// =====================================================================================
+
+__device__ __forceinline__ uint64_t sel8(const uint64_t (&w)[kSegmentWords], int i) {
+  const uint64_t a = (i & 1) ? w[1] : w[0];
+  const uint64_t b = (i & 1) ? w[3] : w[2];
+  const uint64_t c = (i & 1) ? w[5] : w[4];
+  const uint64_t d = (i & 1) ? w[7] : w[6];
+  const uint64_t ab = (i & 2) ? b : a;
+  const uint64_t cd = (i & 2) ? d : c;
+  const uint64_t r = (i & 4) ? cd : ab;
+  return (i & ~7) ? 0 : r;
+}
+
+// bseq_rank (src/main/wtree.c:635-763) by ONE lane: directory entry -> segment -> popcount / gamma runs.
+__device__ __forceinline__ RankResult bseq_rank_lane(const DevIndex& ix, const DevBseq bs, uint32_t index1) {
+  const uint32_t t = index1 - 1;
+  const uint64_t* de = reinterpret_cast<const uint64_t*>(ix.dir + (uint64_t(bs.dir_base) + (t >> 9)));
+  const uint64_t e0 = de[0], e1 = de[1], e2 = de[2];
+  uint32_t o0 = uint32_t(e0), o1 = uint32_t(e0 >> 32);
+  const uint32_t s0 = uint32_t(e1), s1 = uint32_t(e1 >> 32);
+  uint32_t seg = uint32_t(e2);
+  if (t >= o0 + o1 + s0 + s1) {  // the block's second segment
+    o0 += s0;
+    o1 += s1;
+    seg++;
+  }
+  const uint8_t* D = ix.image + bs.off + bs.d_off;
+  const uint32_t wbase = kSegmentWords * seg;
+  uint64_t w[kSegmentWords];
+#pragma unroll
+  for (int k = 0; k < kSegmentWords; k++)
+    w[k] = (wbase + uint32_t(k) < bs.total_words) ? ld_be64(D + 8ull * (wbase + uint32_t(k))) : 0;  // bseq_segment zero fill
+
+  RankResult r;
+  if (w[0] >> 63) {
+    // RLE segment (wtree.c:690-712)
+    uint32_t bit = uint32_t(w[0] >> 62) & 1u;
+    int p = 2;
+    uint64_t win = 0;
+    int avail = 0;
+    for (int it = 0; it < 512; it++) {
+      int k = win ? __clzll(win) : 64;
+      if (2 * k + 1 > avail) {
+        const int wi = p >> 6, sh = p & 63;
+        const uint64_t a = sel8(w, wi);
+        const uint64_t c = sel8(w, wi + 1);
+        win = (a << sh) | (sh ? (c >> (64 - sh)) : 0);
+        avail = 64;
+        k = win ? __clzll(win) : 64;
+        if (k >= 32) break;  // corrupt data guard
+      }
+      const int nb = 2 * k + 1;
+      const uint32_t v = uint32_t(win >> (64 - nb));
+      win = nb < 64 ? (win << nb) : 0;
+      avail -= nb;
+      p += nb;
+      const uint32_t tot = o0 + o1;
+      if (tot + v <= t) {
+        if (bit) o1 += v; else o0 += v;
+        bit ^= 1u;
+      } else {
+        const uint32_t rem = t + 1 - tot;
+        if (bit) o1 += rem; else o0 += rem;
+        break;
+      }
+    }
+    r.bit = bit;
+  } else {
+    // literal segment (wtree.c:713-759): count ones in segment bits 1..nb
+    const uint32_t nb = 1 + t - o0 - o1;
+    uint32_t ones = 0;
+    uint64_t bw = 0;
+#pragma unroll
+    for (int k = 0; k < kSegmentWords; k++) {
+      const uint32_t lo = 64u * uint32_t(k);
+      uint64_t m = 0;
+      if (nb >= lo) m = (nb - lo >= 63) ? ~0ull : (~0ull << (63 - (nb - lo)));
+      ones += uint32_t(__popcll(w[k] & m));
+      if ((nb >> 6) == uint32_t(k)) bw = w[k];
+    }
+    o1 += ones;
+    o0 += nb - ones;
+    r.bit = uint32_t(bw >> (63 - (nb & 63))) & 1u;
+  }
+  r.o0 = o0;
+  r.o1 = o1;
+  return r;
+}
+
+// wtree_occs (src/main/wtree.c:1081-1115), one lane
+__device__ __forceinline__ uint32_t wt_occs_lane(const DevIndex& ix, const uint32_t node_base, uint32_t code, uint32_t idx) {
+  const int len = 31 - __clz(int(code));
+  int cur = 0;
+  for (int i = 1; i <= len; i++) {
+    const DevNode nd = ix.nodes[node_base + uint32_t(cur)];
+    const RankResult r = bseq_rank_lane(ix, nd.bs, idx);
+    const uint32_t b = (code >> (len - i)) & 1u;
+    idx -= b ? r.o0 : r.o1;
+    if (idx == 0) break;
+    cur = b ? nd.child[1] : nd.child[0];
+    if (cur < 0) break;
+  }
+  return idx;
+}
+
+// wtree_rank (src/main/wtree.c:1117-1148), one lane
+__device__ __forceinline__ void wt_rank_lane(const DevIndex& ix, const uint32_t node_base, uint32_t idx, int* seq_out, uint32_t* cnt_out) {
+  int cur = 0, seq = -1;
+  for (int depth = 0; depth < 32; depth++) {
+    const DevNode nd = ix.nodes[node_base + uint32_t(cur)];
+    const RankResult r = bseq_rank_lane(ix, nd.bs, idx);
+    idx -= r.bit ? r.o0 : r.o1;
+    const int c = r.bit ? nd.child[1] : nd.child[0];
+    if (c < 0) { seq = -1 - c; break; }
+    cur = c;
+  }
+  *seq_out = seq;
+  *cnt_out = idx;
+}
+
+// C[ch] + Occ(ch,row): header + block + bucket bases and the wavelet walk, one lane
+__device__ __forceinline__ int64_t c_plus_occ_lane(const DevIndex& ix, uint32_t ch, int64_t row) {
+  uint32_t idx1;
+  const int64_t gb = bucket_of(ix, row, &idx1);
+  const int64_t base = ix.occ_base[gb * kAlphaSize + ch];
+  const uint32_t code = ix.leaf_code[gb * kAlphaSize + ch];
+  uint32_t occ = 0;
+  if (code) occ = wt_occs_lane(ix, ix.buckets[gb].node_base, code, idx1);
+  return base + int64_t(occ);
+}
+
+// do_string_query (src/main/server.c:713-946): one LANE per pattern
+__global__ __launch_bounds__(256) void count_kernel_lane(const DevIndex ix, const int64_t npats,
+                                                         const int32_t* __restrict__ plen,
+                                                         const uint16_t* __restrict__ pats,
+                                                         const int64_t* __restrict__ starts,
+                                                         int64_t* __restrict__ first_out,
+                                                         int64_t* __restrict__ last_out, int* __restrict__ err_flag) {
+  const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (q >= npats) return;
+  const int len = plen[q];
+  const uint16_t* pat = pats + starts[q];
+  int64_t first, last;
+  if (len == 0) {
+    first = 0;
+    last = ix.total_length - 1;
+  } else {
+    int i = len - 1;
+    uint32_t ch = pat[i];
+    if (ch >= uint32_t(kAlphaSize)) {
+      atomicOr(err_flag, 1);
+      first = 0;
+      last = -1;
+    } else {
+      first = ix.C[ch];
+      last = ix.C[ch + 1] - 1;
+      while (first <= last && i > 0) {
+        ch = pat[i - 1];
+        if (ch >= uint32_t(kAlphaSize)) {
+          atomicOr(err_flag, 1);
+          first = 0;
+          last = -1;
+          break;
+        }
+        const int64_t nf = first == 0 ? ix.C[ch] : c_plus_occ_lane(ix, ch, first - 1);
+        const int64_t nl = c_plus_occ_lane(ix, ch, last);
+        first = nf;
+        last = nl - 1;
+        i--;
+      }
+    }
+  }
+  first_out[q] = first;
+  if (last_out) last_out[q] = last;
+  else first_out[q] = last - first + 1;
+}
+
+// locate walk (do_back_query / do_context_query), one LANE per located row
+__global__ __launch_bounds__(256) void locate_kernel_lane(const DevIndex ix, const int64_t npats,
+                                                          const int64_t* __restrict__ first,
+                                                          const int64_t* __restrict__ out_starts, const int64_t total,
+                                                          int64_t* __restrict__ offsets) {
+  const int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (item >= total) return;
+  int64_t lo = 0, hi = npats;
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (out_starts[mid] <= item) lo = mid; else hi = mid;
+  }
+  int64_t row = first[lo] + (item - out_starts[lo]);
+  int64_t steps = 0, result = -1;
+  while (row >= 0) {
+    uint32_t idx1;
+    const int64_t gb = bucket_of(ix, row, &idx1);
+    const DevBucket bk = ix.buckets[gb];
+    int seq;
+    uint32_t cnt;
+    wt_rank_lane(ix, bk.node_base, idx1, &seq, &cnt);
+    if (seq < 0 || uint32_t(seq) >= bk.n_in_use) break;
+    const DevSeq sq = ix.seqs[bk.seq_base + uint32_t(seq)];
+    const RankResult m = bseq_rank_lane(ix, sq.mark_table, cnt);
+    if (m.bit) {
+      const uint64_t rec = uint64_t(m.o1) - 1;
+      result = int64_t(read_bits(ix.image, sq.mark_array * 8 + rec * uint64_t(ix.text_size_bits), ix.text_size_bits)) + steps;
+      break;
+    }
+    if (sq.ch <= uint32_t(kSEOF)) break;
+    row = ix.occ_base[gb * kAlphaSize + sq.ch] + int64_t(cnt) - 1;
+    steps++;
+  }
+  offsets[item] = result;
+}
+
+__global__ __launch_bounds__(256) void block_request_kernel_lane(const DevIndex ix, const int64_t n,
+                                                                 const int64_t* __restrict__ rows,
+                                                                 const uint16_t* __restrict__ ch_in,
+                                                                 uint16_t* __restrict__ ch_out,
+                                                                 int64_t* __restrict__ occ_out,
+                                                                 int64_t* __restrict__ off_out) {
+  const int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (item >= n) return;
+  const int64_t row = rows[item];
+  uint32_t idx1;
+  const int64_t gb = bucket_of(ix, row, &idx1);
+  const DevBucket bk = ix.buckets[gb];
+  int seq;
+  uint32_t cnt;
+  wt_rank_lane(ix, bk.node_base, idx1, &seq, &cnt);
+  const DevSeq sq = ix.seqs[bk.seq_base + uint32_t(seq)];
+  int64_t off = -1;
+  const RankResult m = bseq_rank_lane(ix, sq.mark_table, cnt);
+  if (m.bit) off = int64_t(read_bits(ix.image, sq.mark_array * 8 + (uint64_t(m.o1) - 1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
+  int64_t occ;
+  uint32_t ch = sq.ch;
+  if (ch_in) {
+    ch = ch_in[item];
+    occ = c_plus_occ_lane(ix, ch, row);
+  } else {
+    occ = ix.occ_base[gb * kAlphaSize + ch] + int64_t(cnt);
+  }
+  if (ch_out) ch_out[item] = uint16_t(sq.ch);
+  if (occ_out) occ_out[item] = occ;
+  if (off_out) off_out[item] = off;
+}
+
 }  // namespace femto_amd

@@ -132,6 +132,14 @@ int femto_amd_locate_walk_device(femto_amd_index_t* ix, int64_t npats, const int
 int femto_amd_block_requests(femto_amd_index_t* ix, int64_t n, const int64_t* rows, const uint16_t* ch_in,
                              uint16_t* ch_out, int32_t* occ_out, int64_t* off_out);
 
+/* ---- kernel family ---------------------------------------------------------------------------- */
+/* mode 1 (default): one LANE per query over the derived 24-byte block directory (one directory load
+ * + one 64-byte segment per rank).  mode 0: one WAVEFRONT per query walking femto's own A0/A1/AP
+ * group tables and varbyte S sums with __ballot/ds_bpermute (no derived rank tables).  Both are
+ * bit-exact; FEMTO_AMD_RANK_MODE=raw|dir selects the default at open. */
+int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode);
+int femto_amd_get_rank_mode(const femto_amd_index_t* ix);
+
 /* ---- profiling hooks ---------------------------------------------------------------------- */
 /* Average duration (ms) of the launches of the named kernel ("count", "locate") since the last
  * reset, measured with HIP events on the stream the kernel was launched on; n_launches out. */

@@ -21,12 +21,17 @@ def gpu_ok():
     return True
 
 
+MODES = [1, 0]   # 1: lane-per-query over the block directory (default); 0: wavefront-per-query raw A/S/D walk
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name", INDEX_FIXTURES)
-def test_leaf_requests_match_reference(fixtures, gpu_ok, name):
+def test_leaf_requests_match_reference(fixtures, gpu_ok, name, mode):
     """block_request CHAR|OCCS|LOCATION for every row (index_test.c:60-476 checks the same leaves)."""
     fx = fixtures(name)
     g = fx.gold
     ix = femto_amd.Index(fx.index, device=0)
+    ix.set_rank_mode(mode)
     n = ix.info.total_length
     rows = np.arange(n, dtype=np.int64)
     ch, occ, off = ix.block_requests(rows)
@@ -41,10 +46,13 @@ def test_leaf_requests_match_reference(fixtures, gpu_ok, name):
     ix.close()
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name", INDEX_FIXTURES)
-def test_count_locate_match_reference_goldens(fixtures, gpu_ok, name):
+def test_count_locate_match_reference_goldens(fixtures, gpu_ok, name, mode):
     fx = fixtures(name)
     ix = femto_amd.Index(fx.index, device=0)
+    ix.set_rank_mode(mode)
+    assert ix.rank_mode == mode
     plen, flat, starts = fx.patterns
     first, last = ix.count_flat(plen, flat, starts)
     assert np.array_equal(first, fx.gold["count_first"])
@@ -118,13 +126,15 @@ def _random_index(tmp_path, text, params, name):
     return out
 
 
-def test_gpu_built_index_vs_oracle_medium(tmp_path, gpu_ok):
+@pytest.mark.parametrize("mode", MODES)
+def test_gpu_built_index_vs_oracle_medium(tmp_path, gpu_ok, mode):
     """4 MiB random ACGT with the reference's DEFAULT parameters (bucket 2^20 rows): the GPU
     suffix sorter + writer build the index, the HIP query path is compared with the oracle on
     100 k patterns (BASELINE config 1 shape, scaled), plus size-independent properties."""
     text = tg.t_acgt(1 << 22, 2024)
     path = _random_index(tmp_path, text, None, "acgt4m")
     ix = femto_amd.Index(path, device=0)
+    ix.set_rank_mode(mode)
     o = po.Oracle(path)
     assert ix.info.total_length == o.total_length == len(text) + 1
     plen_r, flat_r = tg.p_rand(20, 50000, 7)
@@ -147,12 +157,14 @@ def test_gpu_built_index_vs_oracle_medium(tmp_path, gpu_ok):
             assert np.array_equal(text[off:off + len(p)], p)
 
 
-def test_gpu_built_english_like_vs_oracle(tmp_path, gpu_ok):
+@pytest.mark.parametrize("mode", MODES)
+def test_gpu_built_english_like_vs_oracle(tmp_path, gpu_ok, mode):
     """sigma ~ 96 text (RLE-heavy wavelet nodes, deep Huffman codes), mixed-length patterns 8..64
     (BASELINE config 3 shape, scaled)."""
     text = tg.t_eng(3 << 20, 99)
     path = _random_index(tmp_path, text, "block_size=2097152,bucket_size=262144,mark_period=20", "eng3m")
     ix = femto_amd.Index(path, device=0)
+    ix.set_rank_mode(mode)
     o = po.Oracle(path)
     plen, flat = tg.p_hit(8, 64, 40000, 5, text)
     starts = tg.starts_of(plen)
