@@ -48,6 +48,40 @@ struct DirEntry {           // 24 bytes
   uint32_t pad;
 };
 
+// ---- lane-kernel view of a binary sequence (derived at load time) --------------------------
+// segs  : every sequence's D words copied into 64-byte-ALIGNED segment slots (native-endian
+//         u64, most significant bit first; the last slot zero padded), so one rank reads exactly
+//         one 64-byte sector instead of an 8-byte-aligned run straddling two;
+// cum   : per segment the zeros/ones BEFORE it (the varbyte S sums and A0/A1 group tables,
+//         prefix-summed), plus one terminal entry per sequence;
+// hint  : per 512-bit block the segment holding the block's first bit.  Every segment but a
+//         sequence's last stores >= 511 bits (save_run, src/main/wtree.c:240-290), so bit t lies in
+//         segment hint[t>>9] or the next one.  Sequences whose segments all hold exactly 511 bits
+//         (all-literal: random ACGT) need no hint: segment = t / 511.
+struct CumEntry { uint32_t o0, o1; };
+constexpr uint32_t kNoHint = 0xffffffffu;
+struct LaneBseq {           // 16 bytes
+  uint64_t seg_base;        // first 64-byte slot of this sequence in DevIndex::segs
+  uint32_t cum_base;        // first CumEntry
+  uint32_t hint_base;       // first hint entry, or kNoHint for uniform 511-bit segments
+};
+struct LaneNode {           // 32 bytes
+  LaneBseq bs;
+  int32_t child[2];
+  uint32_t pad[2];
+};
+struct LaneSeq {            // 32 bytes
+  LaneBseq mark_table;
+  uint64_t mark_array;      // absolute byte offset in `image`
+  uint32_t ch;
+  uint32_t pad;
+};
+struct OccEntry {           // 16 bytes, [gb*261 + ch]
+  int64_t base;             // C[ch] + block_occs + bucket_occs
+  uint32_t code;            // Huffman leaf number (0: ch absent from the bucket)
+  uint32_t node_base;       // first LaneNode of the bucket
+};
+
 struct DevNode {            // 32 bytes
   DevBseq bs;
   int32_t child[2];         // >= 0: local index of the internal child; < 0: leaf, seq = -1 - child
@@ -75,7 +109,13 @@ struct DevIndex {           // passed by value to kernels
   const int64_t* occ_base;  // [gb*261 + ch]
   const uint32_t* leaf_code;// [gb*261 + ch]
   const int64_t* C;         // [262]; C[261] == total_length (get_C, src/main/index.c:1545)
-  const DirEntry* dir;      // block directories of all sequences
+  const DirEntry* dir;      // block directories of all sequences (unused by the current kernels)
+  const uint64_t* segs;     // 64-byte aligned native-endian segment slots (8 words each)
+  const CumEntry* cum;
+  const uint32_t* hint;
+  const LaneNode* lnodes;   // parallel to nodes[]
+  const LaneSeq* lseqs;     // parallel to seqs[]
+  const OccEntry* occ;      // [gb*261 + ch]
   int64_t total_length;
   int64_t total_buckets;
   int32_t b_size;

@@ -93,7 +93,12 @@ struct femto_amd_index {
   int64_t* d_occ_base = nullptr;
   uint32_t* d_leaf_code = nullptr;
   int64_t* d_C = nullptr;
-  DirEntry* d_dir = nullptr;
+  uint64_t* d_segs = nullptr;
+  CumEntry* d_cum = nullptr;
+  uint32_t* d_hint = nullptr;
+  LaneNode* d_lnodes = nullptr;
+  LaneSeq* d_lseqs = nullptr;
+  OccEntry* d_occ = nullptr;
   int* d_err = nullptr;
   int mode = 1;  // 1: lane-per-item kernels over the block directory; 0: wavefront-cooperative raw A/S/D walk
   DevIndex dev{};
@@ -275,7 +280,12 @@ int femto_amd_open(const char* index_path, int device, femto_amd_index_t** out) 
       if ((r = upload(&ix->d_occ_base, h.occ_base, &ix->table_bytes))) return r;
       if ((r = upload(&ix->d_leaf_code, h.leaf_code, &ix->table_bytes))) return r;
       if ((r = upload(&ix->d_C, h.C, &ix->table_bytes))) return r;
-      if ((r = upload(&ix->d_dir, h.dir, &ix->table_bytes))) return r;
+      if ((r = upload(&ix->d_segs, h.segs, &ix->table_bytes))) return r;
+      if ((r = upload(&ix->d_cum, h.cum, &ix->table_bytes))) return r;
+      if ((r = upload(&ix->d_hint, h.hint, &ix->table_bytes))) return r;
+      if ((r = upload(&ix->d_lnodes, h.lnodes, &ix->table_bytes))) return r;
+      if ((r = upload(&ix->d_lseqs, h.lseqs, &ix->table_bytes))) return r;
+      if ((r = upload(&ix->d_occ, h.occ, &ix->table_bytes))) return r;
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_err), sizeof(int)));
       HIP_TRY(hipMemset(ix->d_err, 0, sizeof(int)));
       DevIndex& d = ix->dev;
@@ -286,7 +296,13 @@ int femto_amd_open(const char* index_path, int device, femto_amd_index_t** out) 
       d.occ_base = ix->d_occ_base;
       d.leaf_code = ix->d_leaf_code;
       d.C = ix->d_C;
-      d.dir = ix->d_dir;
+      d.dir = nullptr;
+      d.segs = ix->d_segs;
+      d.cum = ix->d_cum;
+      d.hint = ix->d_hint;
+      d.lnodes = ix->d_lnodes;
+      d.lseqs = ix->d_lseqs;
+      d.occ = ix->d_occ;
       d.total_length = h.total_length;
       d.total_buckets = h.total_buckets;
       d.b_size = h.b_size;
@@ -322,7 +338,12 @@ void femto_amd_close(femto_amd_index_t* ix) {
     (void)hipFree(ix->d_occ_base);
     (void)hipFree(ix->d_leaf_code);
     (void)hipFree(ix->d_C);
-    (void)hipFree(ix->d_dir);
+    (void)hipFree(ix->d_segs);
+    (void)hipFree(ix->d_cum);
+    (void)hipFree(ix->d_hint);
+    (void)hipFree(ix->d_lnodes);
+    (void)hipFree(ix->d_lseqs);
+    (void)hipFree(ix->d_occ);
     (void)hipFree(ix->d_err);
     for (DeviceBuffer* b : {&ix->s_plen, &ix->s_pats, &ix->s_starts, &ix->s_first, &ix->s_last, &ix->s_noccs,
                             &ix->s_noccs64, &ix->s_out_starts, &ix->s_offsets, &ix->s_scan[0], &ix->s_scan[1],
@@ -347,7 +368,9 @@ int femto_amd_info(const femto_amd_index_t* ix, femto_amd_info_t* out) {
   out->image_bytes = int64_t(h.image.size());
   out->table_bytes = int64_t(h.nodes.size() * sizeof(DevNode) + h.buckets.size() * sizeof(DevBucket) +
                              h.seqs.size() * sizeof(DevSeq) + h.occ_base.size() * 8 + h.leaf_code.size() * 4 +
-                             h.C.size() * 8 + h.dir.size() * sizeof(DirEntry));
+                             h.C.size() * 8 + h.segs.size() * 8 + h.cum.size() * sizeof(CumEntry) + h.hint.size() * 4 +
+                             h.lnodes.size() * sizeof(LaneNode) + h.lseqs.size() * sizeof(LaneSeq) +
+                             h.occ.size() * sizeof(OccEntry));
   return FEMTO_AMD_OK;
 }
 

@@ -101,9 +101,30 @@ struct BitReader {  // MSB-first, like bsR24 (src/utils/buffer_funcs.h:136)
 // Re-expresses one sequence's A0/A1/AP + varbyte S tables (src/main/wtree_funcs.h:294-358) as a
 // block directory: for every 512-bit block the segment holding its first bit, with the
 // cumulative and in-segment (zeros, ones).
-int build_directory(const std::vector<uint8_t>& img, DevBseq* bs, std::vector<DirEntry>* dir, bool* regular, Error* e) {
-  bs->dir_base = uint32_t(dir->size());
-  if (dir->size() > 0xfff00000ull) return fail(e, ERR_MEM, "block directory too large");
+struct LaneTables {
+  std::vector<uint64_t>* segs;
+  std::vector<CumEntry>* cum;
+  std::vector<uint32_t>* hint;
+};
+
+int build_directory(const std::vector<uint8_t>& img, DevBseq* bs, std::vector<DirEntry>* dir, bool* regular, Error* e,
+                    LaneTables* lt = nullptr, LaneBseq* lane = nullptr) {
+  bs->dir_base = 0;
+  (void)dir;
+  const size_t cum0 = lt ? lt->cum->size() : 0;
+  const size_t hint0 = lt ? lt->hint->size() : 0;
+  bool uniform = true;
+  if (lt) {
+    if (lt->cum->size() > 0xfff00000ull || lt->hint->size() > 0xfff00000ull) return fail(e, ERR_MEM, "lane tables too large");
+    lane->seg_base = lt->segs->size() / kSegmentWords;
+    lane->cum_base = uint32_t(cum0);
+    // copy the D words into aligned native-endian slots (bseq_segment's zero fill included)
+    const uint8_t* Dsrc = img.data() + bs->off + bs->d_off;
+    const uint64_t ns = (uint64_t(bs->total_words) + kSegmentWords - 1) / kSegmentWords;
+    const size_t at = lt->segs->size();
+    lt->segs->resize(at + size_t(ns) * kSegmentWords, 0);
+    for (uint32_t wdx = 0; wdx < bs->total_words; wdx++) (*lt->segs)[at + wdx] = be64(Dsrc + 8ull * wdx);
+  }
   const uint8_t* z = img.data() + bs->off;
   const uint32_t G = bs->num_groups;
   const uint8_t* A0 = z + 16;
@@ -114,6 +135,7 @@ int build_directory(const std::vector<uint8_t>& img, DevBseq* bs, std::vector<Di
   const uint64_t nseg = (uint64_t(bs->total_words) + kSegmentWords - 1) / kSegmentWords;
   uint64_t pos = 0, next_block = 0;
   uint64_t seg = 0;
+  uint32_t tot0 = 0, tot1 = 0;
   for (uint32_t g = 0; g < G && seg < nseg; g++) {
     uint32_t o0 = be32(A0 + 4ull * g), o1 = be32(A1 + 4ull * g);
     if (uint64_t(o0) + o1 != pos) return fail(e, ERR_FORMAT, "bseq group table disagrees with segment sums");
@@ -133,16 +155,31 @@ int build_directory(const std::vector<uint8_t>& img, DevBseq* bs, std::vector<Di
       }
       const uint64_t len = uint64_t(v[0]) + v[1];
       if (len < 511 && seg + 1 < nseg) *regular = false;
+      if (seg + 1 < nseg ? len != 511 : len > 511) uniform = false;
+      if (lt) lt->cum->push_back(CumEntry{o0, o1});
       while (next_block * 512 < pos + len) {
-        dir->push_back(DirEntry{o0, o1, v[0], v[1], uint32_t(seg), 0});
+        if (lt) lt->hint->push_back(uint32_t(seg));
         next_block++;
       }
       pos += len;
       o0 += v[0];
       o1 += v[1];
+      tot0 = o0;
+      tot1 = o1;
     }
   }
   if (seg != nseg) return fail(e, ERR_FORMAT, "bseq has fewer segment sums than segments");
+  if (lt) {
+    // terminal entry: totals after the last segment (the two-candidate test reads cum[seg+1])
+    const uint32_t t0 = tot0, t1 = tot1;
+    lt->cum->push_back(CumEntry{t0, t1});
+    if (uniform) {
+      lt->hint->resize(hint0);
+      lane->hint_base = kNoHint;
+    } else {
+      lane->hint_base = uint32_t(hint0);
+    }
+  }
   return OK;
 }
 
@@ -362,13 +399,16 @@ int HostIndex::load(const std::string& path, Error* e) {
       for (uint32_t i = 0; i < n_internal; i++) {
         DevNode nd;
         memset(&nd, 0, sizeof nd);
+        LaneNode ln;
+        memset(&ln, 0, sizeof ln);
         uint32_t off = be32(wt + 4 + 8 * size_t(i) + 4);
         if (off == 0) {  // "0 indicates no data" (src/main/wtree.c:1048): never ranked
           nd.bs.off = boff + wt_off; nd.bs.num_groups = 0; nd.bs.d_off = 0; nd.bs.total_words = 0;
         } else {
           rc = parse_bseq(image, boff + wt_off + off, blimit, &nd.bs, e);
           if (rc) return rc;
-          rc = build_directory(image, &nd.bs, &dir, &dir_regular, e);
+          LaneTables lt{&segs, &cum, &hint};
+          rc = build_directory(image, &nd.bs, &dir, &dir_regular, e, &lt, &ln.bs);
           if (rc) return rc;
         }
         for (int bit = 0; bit < 2; bit++) {
@@ -382,7 +422,10 @@ int HostIndex::load(const std::string& path, Error* e) {
             nd.child[bit] = -1 - seq;
           }
         }
+        ln.child[0] = nd.child[0];
+        ln.child[1] = nd.child[1];
         nodes.push_back(nd);
+        lnodes.push_back(ln);
       }
 
       // mark tables and arrays (index.c:645-720): nInUse u32 offsets each
@@ -396,23 +439,41 @@ int HostIndex::load(const std::string& path, Error* e) {
         if (toff & 7) return fail(e, ERR_FORMAT, "misaligned mark table");
         rc = parse_bseq(image, boff + mt_off + toff, blimit, &sq.mark_table, e);
         if (rc) return rc;
-        rc = build_directory(image, &sq.mark_table, &dir, &dir_regular, e);
+        LaneSeq lsq;
+        memset(&lsq, 0, sizeof lsq);
+        LaneTables lt{&segs, &cum, &hint};
+        rc = build_directory(image, &sq.mark_table, &dir, &dir_regular, e, &lt, &lsq.mark_table);
         if (rc) return rc;
         uint32_t aoff = be32(d + ma_off + 4 * size_t(s));
         sq.mark_array = boff + ma_off + aoff;
         if (sq.mark_array > blimit) return fail(e, ERR_FORMAT, "mark array out of range");
         sq.ch = seqToUnseq[s];
         seqs.push_back(sq);
+        lsq.mark_array = sq.mark_array;
+        lsq.ch = sq.ch;
+        lseqs.push_back(lsq);
       }
       {  // end-of-bucket pseudo symbol (never occurs in L)
         DevSeq sq;
         memset(&sq, 0, sizeof sq);
         sq.ch = kAlphaSize;
         seqs.push_back(sq);
+        LaneSeq lsq;
+        memset(&lsq, 0, sizeof lsq);
+        lsq.ch = kAlphaSize;
+        lseqs.push_back(lsq);
       }
     }
   }
   if (gb != total_buckets) return fail(e, ERR_FORMAT, "bucket count mismatch");
+  occ.resize(size_t(total_buckets) * kAlphaSize);
+  for (int64_t g = 0; g < total_buckets; g++)
+    for (int ch = 0; ch < kAlphaSize; ch++) {
+      OccEntry& oe = occ[size_t(g) * kAlphaSize + size_t(ch)];
+      oe.base = occ_base[size_t(g) * kAlphaSize + size_t(ch)];
+      oe.code = leaf_code[size_t(g) * kAlphaSize + size_t(ch)];
+      oe.node_base = buckets[size_t(g)].node_base;
+    }
   return OK;
 }
 

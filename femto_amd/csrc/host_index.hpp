@@ -33,6 +33,12 @@ struct HostIndex {
   std::vector<DevBucket> buckets;
   std::vector<DevSeq> seqs;
   std::vector<DirEntry> dir;            // block directories (see device_tables.h)
+  std::vector<uint64_t> segs;           // 64-byte aligned native-endian segment slots
+  std::vector<CumEntry> cum;
+  std::vector<uint32_t> hint;
+  std::vector<LaneNode> lnodes;
+  std::vector<LaneSeq> lseqs;
+  std::vector<OccEntry> occ;
   bool dir_regular = true;              // false: some non-final segment holds < 511 bits -> raw A/S walk only
   std::vector<int64_t> occ_base;        // [gb*261+ch]
   std::vector<uint32_t> leaf_code;      // [gb*261+ch]

@@ -494,25 +494,39 @@ __device__ __forceinline__ uint64_t sel8(const uint64_t (&w)[kSegmentWords], int
   return (i & ~7) ? 0 : r;
 }
 
-// bseq_rank (src/main/wtree.c:635-763) by ONE lane: directory entry -> segment -> popcount / gamma runs.
-__device__ __forceinline__ RankResult bseq_rank_lane(const DevIndex& ix, const DevBseq bs, uint32_t index1) {
+// bseq_rank (src/main/wtree.c:635-763) by ONE lane: which segment (cum/hint tables) -> the aligned
+// 64-byte segment -> popcount / gamma runs.
+__device__ __forceinline__ RankResult bseq_rank_lane(const DevIndex& ix, const LaneBseq bs, uint32_t index1) {
   const uint32_t t = index1 - 1;
-  const uint64_t* de = reinterpret_cast<const uint64_t*>(ix.dir + (uint64_t(bs.dir_base) + (t >> 9)));
-  const uint64_t e0 = de[0], e1 = de[1], e2 = de[2];
-  uint32_t o0 = uint32_t(e0), o1 = uint32_t(e0 >> 32);
-  const uint32_t s0 = uint32_t(e1), s1 = uint32_t(e1 >> 32);
-  uint32_t seg = uint32_t(e2);
-  if (t >= o0 + o1 + s0 + s1) {  // the block's second segment
-    o0 += s0;
-    o1 += s1;
-    seg++;
+  uint32_t seg, o0, o1;
+  if (bs.hint_base == kNoHint) {
+    seg = t / 511u;  // all segments literal and full: 511 data bits each
+    const uint64_t c = *reinterpret_cast<const uint64_t*>(ix.cum + (uint64_t(bs.cum_base) + seg));
+    o0 = uint32_t(c);
+    o1 = uint32_t(c >> 32);
+  } else {
+    seg = ix.hint[uint64_t(bs.hint_base) + (t >> 9)];
+    const uint64_t* cp = reinterpret_cast<const uint64_t*>(ix.cum + (uint64_t(bs.cum_base) + seg));
+    const uint64_t c0 = cp[0], c1 = cp[1];
+    o0 = uint32_t(c0);
+    o1 = uint32_t(c0 >> 32);
+    const uint32_t n0 = uint32_t(c1), n1 = uint32_t(c1 >> 32);
+    if (t >= n0 + n1) {  // the block's second segment
+      o0 = n0;
+      o1 = n1;
+      seg++;
+    }
   }
-  const uint8_t* D = ix.image + bs.off + bs.d_off;
-  const uint32_t wbase = kSegmentWords * seg;
   uint64_t w[kSegmentWords];
+  {
+    const ulonglong2* sp = reinterpret_cast<const ulonglong2*>(ix.segs + (bs.seg_base + seg) * kSegmentWords);
 #pragma unroll
-  for (int k = 0; k < kSegmentWords; k++)
-    w[k] = (wbase + uint32_t(k) < bs.total_words) ? ld_be64(D + 8ull * (wbase + uint32_t(k))) : 0;  // bseq_segment zero fill
+    for (int k = 0; k < kSegmentWords / 2; k++) {
+      const ulonglong2 v = sp[k];
+      w[2 * k] = v.x;
+      w[2 * k + 1] = v.y;
+    }
+  }
 
   RankResult r;
   if (w[0] >> 63) {
@@ -575,7 +589,7 @@ __device__ __forceinline__ uint32_t wt_occs_lane(const DevIndex& ix, const uint3
   const int len = 31 - __clz(int(code));
   int cur = 0;
   for (int i = 1; i <= len; i++) {
-    const DevNode nd = ix.nodes[node_base + uint32_t(cur)];
+    const LaneNode nd = ix.lnodes[node_base + uint32_t(cur)];
     const RankResult r = bseq_rank_lane(ix, nd.bs, idx);
     const uint32_t b = (code >> (len - i)) & 1u;
     idx -= b ? r.o0 : r.o1;
@@ -590,7 +604,7 @@ __device__ __forceinline__ uint32_t wt_occs_lane(const DevIndex& ix, const uint3
 __device__ __forceinline__ void wt_rank_lane(const DevIndex& ix, const uint32_t node_base, uint32_t idx, int* seq_out, uint32_t* cnt_out) {
   int cur = 0, seq = -1;
   for (int depth = 0; depth < 32; depth++) {
-    const DevNode nd = ix.nodes[node_base + uint32_t(cur)];
+    const LaneNode nd = ix.lnodes[node_base + uint32_t(cur)];
     const RankResult r = bseq_rank_lane(ix, nd.bs, idx);
     idx -= r.bit ? r.o0 : r.o1;
     const int c = r.bit ? nd.child[1] : nd.child[0];
@@ -605,11 +619,10 @@ __device__ __forceinline__ void wt_rank_lane(const DevIndex& ix, const uint32_t 
 __device__ __forceinline__ int64_t c_plus_occ_lane(const DevIndex& ix, uint32_t ch, int64_t row) {
   uint32_t idx1;
   const int64_t gb = bucket_of(ix, row, &idx1);
-  const int64_t base = ix.occ_base[gb * kAlphaSize + ch];
-  const uint32_t code = ix.leaf_code[gb * kAlphaSize + ch];
+  const OccEntry oe = ix.occ[gb * kAlphaSize + ch];
   uint32_t occ = 0;
-  if (code) occ = wt_occs_lane(ix, ix.buckets[gb].node_base, code, idx1);
-  return base + int64_t(occ);
+  if (oe.code) occ = wt_occs_lane(ix, oe.node_base, oe.code, idx1);
+  return oe.base + int64_t(occ);
 }
 
 // do_string_query (src/main/server.c:713-946): one LANE per pattern
@@ -680,7 +693,7 @@ __global__ __launch_bounds__(256) void locate_kernel_lane(const DevIndex ix, con
     uint32_t cnt;
     wt_rank_lane(ix, bk.node_base, idx1, &seq, &cnt);
     if (seq < 0 || uint32_t(seq) >= bk.n_in_use) break;
-    const DevSeq sq = ix.seqs[bk.seq_base + uint32_t(seq)];
+    const LaneSeq sq = ix.lseqs[bk.seq_base + uint32_t(seq)];
     const RankResult m = bseq_rank_lane(ix, sq.mark_table, cnt);
     if (m.bit) {
       const uint64_t rec = uint64_t(m.o1) - 1;
@@ -709,7 +722,7 @@ __global__ __launch_bounds__(256) void block_request_kernel_lane(const DevIndex 
   int seq;
   uint32_t cnt;
   wt_rank_lane(ix, bk.node_base, idx1, &seq, &cnt);
-  const DevSeq sq = ix.seqs[bk.seq_base + uint32_t(seq)];
+  const LaneSeq sq = ix.lseqs[bk.seq_base + uint32_t(seq)];
   int64_t off = -1;
   const RankResult m = bseq_rank_lane(ix, sq.mark_table, cnt);
   if (m.bit) off = int64_t(read_bits(ix.image, sq.mark_array * 8 + (uint64_t(m.o1) - 1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
