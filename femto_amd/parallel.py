@@ -1,0 +1,95 @@
+"""Multi-GPU query sharding: one process per GPU (torch.distributed, backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" in the CPU tests).  Queries are independent (the reference's
+do_parallel_query just fans out, src/main/server.c:3969-4001), so the index is replicated, the
+pattern batch is split contiguously, and the ONLY collective on the path is the final gather of
+results to rank 0 (16 bytes per pattern for count; sizes then payload for locate)."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n, rank, world):
+    """Contiguous shard [lo, hi) of n items owned by `rank`."""
+    lo = n * rank // world
+    hi = n * (rank + 1) // world
+    return lo, hi
+
+
+def gather_fixed(t, dst=0):
+    """Gather equal-shape tensors to `dst`; returns the list on dst, None elsewhere."""
+    world = dist.get_world_size()
+    rank = dist.get_rank()
+    if world == 1:
+        return [t]
+    out = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
+    dist.gather(t, out, dst=dst)
+    return out
+
+
+def gather_varlen(t, dst=0):
+    """Gather 1-D tensors of different lengths to `dst` (two phases: sizes, then payload padded to
+    the maximum so that a single gather moves it); returns the concatenation on dst."""
+    world = dist.get_world_size()
+    rank = dist.get_rank()
+    if world == 1:
+        return t
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(sizes + [1])
+    pad = torch.zeros(m, dtype=t.dtype, device=t.device)
+    pad[:t.numel()] = t
+    out = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, out, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([o[:s] for o, s in zip(out, sizes)])
+
+
+def sharded_count(count_fn, plen, flat, starts, device="cpu", dst=0):
+    """Run count_fn(plen, flat, starts) -> (first, last) numpy int64 on this rank's contiguous shard
+    of the batch and gather (first, last) for the WHOLE batch on rank dst."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    n = len(plen)
+    lo, hi = shard_range(n, rank, world)
+    s = starts[lo:hi] - (starts[lo] if hi > lo else 0)
+    f0 = int(starts[lo]) if hi > lo else 0
+    f1 = int(starts[hi - 1] + plen[hi - 1]) if hi > lo else 0
+    first, last = count_fn(plen[lo:hi], flat[f0:f1] if f1 > f0 else flat[:0], s)
+    res = torch.from_numpy(np.stack([first, last]).reshape(-1)).to(device)
+    if world == 1:
+        return first, last
+    allres = gather_varlen(res, dst=dst)
+    if rank != dst:
+        return None
+    out_f, out_l = [], []
+    pos = 0
+    allres = allres.cpu().numpy()
+    for r in range(world):
+        a, b = shard_range(n, r, world)
+        k = b - a
+        out_f.append(allres[pos:pos + k])
+        out_l.append(allres[pos + k:pos + 2 * k])
+        pos += 2 * k
+    return np.concatenate(out_f), np.concatenate(out_l)
+
+
+def sharded_locate(locate_fn, plen, flat, starts, max_occs, device="cpu", dst=0):
+    """locate_fn(plen, flat, starts, max_occs) -> (noccs int32, offsets int64); gathers both."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    n = len(plen)
+    lo, hi = shard_range(n, rank, world)
+    s = starts[lo:hi] - (starts[lo] if hi > lo else 0)
+    f0 = int(starts[lo]) if hi > lo else 0
+    f1 = int(starts[hi - 1] + plen[hi - 1]) if hi > lo else 0
+    noccs, offs = locate_fn(plen[lo:hi], flat[f0:f1] if f1 > f0 else flat[:0], s, max_occs)
+    if world == 1:
+        return noccs, offs
+    gn = gather_varlen(torch.from_numpy(noccs.astype(np.int64)).to(device), dst=dst)
+    go = gather_varlen(torch.from_numpy(offs.astype(np.int64)).to(device), dst=dst)
+    if rank != dst:
+        return None
+    return gn.cpu().numpy().astype(np.int32), go.cpu().numpy()

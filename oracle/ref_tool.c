@@ -132,21 +132,35 @@ static int cmd_build(int argc, char** argv)
     if (err) die("append_file_mem", err);
   }
 
+  /* FEMTO_REF_WITH_MAP=1: also write the document map so that buckets carry document chunks
+     (the production layout).  Only safe with one bucket per block (index_documents overruns
+     chunks[] otherwise, construct.c:667). */
+  int with_map = getenv("FEMTO_REF_WITH_MAP") != NULL;
+  char map_path[4096];
+  snprintf(map_path, sizeof map_path, "%s/_build_map.tmp", index_dir);
   double t0 = now_s();
   FILE* bf = fopen(bwt_path, "w+");
   if (!bf) { perror(bwt_path); return 2; }
+  FILE* mf = with_map ? fopen(map_path, "w+") : NULL;
   start_clock(); /* save_prepared_bwt stops one clock more than it starts (bwt_creator.c:128) */
-  err = save_prepared_bwt(&p, param.mark_period, bf, 0, NULL, 0);
+  err = save_prepared_bwt(&p, param.mark_period, bf, param.chunk_size, mf, 0);
   if (err) die("save_prepared_bwt", err);
   double t1 = now_s();
   rewind(bf);
 
   bwt_reader_t bwt;
+  bwt_document_map_reader_t map;
   err = bwt_reader_open(&bwt, bf);
   if (err) die("bwt_reader_open", err);
-  err = index_documents(&bwt, NULL, &p.info_reader, &param, index_dir, NULL);
+  if (with_map) {
+    rewind(mf);
+    err = bwt_document_map_reader_open(&map, mf);
+    if (err) die("bwt_document_map_reader_open", err);
+  }
+  err = index_documents(&bwt, with_map ? &map : NULL, &p.info_reader, &param, index_dir, NULL);
   if (err) die("index_documents", err);
   bwt_reader_close(&bwt);
+  if (with_map) { bwt_document_map_reader_close(&map); remove(map_path); }
   double t2 = now_s();
   free_prepared_text(&p);
   remove(info_path);

@@ -10,7 +10,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-INDEX_FIXTURES = ["acgt48k", "eng2doc", "counter400_small", "counter400_default", "runs3doc", "construct_kat"]
+# built by the reference with index_documents(map=NULL): our writer reproduces them byte for byte
+WRITER_FIXTURES = ["acgt48k", "eng2doc", "counter400_small", "counter400_default", "runs3doc", "construct_kat"]
+# + one built WITH a document map (buckets carry document chunks, the production femto_index layout)
+INDEX_FIXTURES = WRITER_FIXTURES + ["chunks2doc"]
 
 
 def pytest_configure(config):

@@ -60,7 +60,7 @@ def patterns_for(docs, seed, n_hit=150, n_rand=100, kmax=24, alphabet=None):
     return pats
 
 
-def make_index_fixture(name, docs, params, seed, flatten=False, occ_chars=(), max_occs=(1, 3, 7, 1000)):
+def make_index_fixture(name, docs, params, seed, flatten=False, occ_chars=(), max_occs=(1, 3, 7, 1000), with_map=False):
     print("fixture", name)
     with tempfile.TemporaryDirectory() as td:
         docnames = []
@@ -71,7 +71,10 @@ def make_index_fixture(name, docs, params, seed, flatten=False, occ_chars=(), ma
         cwd = os.getcwd()
         os.chdir(td)
         try:
+            if with_map:   # document chunks in every bucket (the production femto_index layout)
+                os.environ["FEMTO_REF_WITH_MAP"] = "1"
             po.ref_build("index", params, docnames)
+            os.environ.pop("FEMTO_REF_WITH_MAP", None)
             if flatten:
                 po.ref_tool("flatten", "index", "index.flat")
         finally:
@@ -170,6 +173,10 @@ def main():
     make_index_fixture("construct_kat", [np.frombuffer(b"test_one;", dtype=np.uint8),
                                          np.frombuffer(b"test_two_fun;", dtype=np.uint8)],
                        "mark_period=100", seed=106, occ_chars=(5 + ord("t"), 5 + ord("n"), 5 + ord("e")))
+    rng2 = np.random.Generator(np.random.PCG64(78))
+    cd = [rng2.choice(np.frombuffer(b"abcdefgh \n", dtype=np.uint8), k).astype(np.uint8) for k in (3000, 2500)]
+    make_index_fixture("chunks2doc", cd, "block_size=2048,bucket_size=2048,chunk_size=256,mark_period=10", seed=107,
+                       occ_chars=(5 + ord("a"),), with_map=True)
     make_bseq_kat()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden dir bytes:", tot)

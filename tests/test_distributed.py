@@ -1,0 +1,68 @@
+"""N > 1 path on CPU: world_size 2, gloo backend, 127.0.0.1 rendezvous.  Each rank runs its shard
+(here through the oracle, which is test infrastructure; on the GPU box the same code path runs the
+HIP kernels) and rank 0 must end up with exactly the single-process result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN, ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, index_path, npz, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from femto_amd import parallel as par
+    from oracle import pyoracle as po
+    g = np.load(npz)
+    plen = g["pat_len"].astype(np.int32)
+    flat = g["pat_flat"].astype(np.uint16)
+    starts = np.zeros(len(plen), dtype=np.int64)
+    starts[1:] = np.cumsum(plen[:-1])
+    o = po.Oracle(index_path)
+    res = par.sharded_count(lambda a, b, c: o.count_flat(a, b, c), plen, flat, starts)
+    loc = par.sharded_locate(lambda a, b, c, m: o.locate_flat(a, b, c, m), plen, flat, starts, 7)
+    if rank == 0:
+        ok = (np.array_equal(res[0], g["count_first"]) and np.array_equal(res[1], g["count_last"])
+              and np.array_equal(loc[0], g["loc7_noccs"]) and np.array_equal(loc[1], g["loc7_offs"]))
+        q.put(bool(ok))
+    else:
+        assert res is None and loc is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_count_and_locate_world2_gloo(fixtures):
+    fx = fixtures("eng2doc")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, fx.index, os.path.join(GOLDEN, "eng2doc.npz"), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_shard_range_partitions():
+    from femto_amd.parallel import shard_range
+    for n in (0, 1, 7, 10_000_001):
+        for w in (1, 2, 3, 8):
+            cover = [shard_range(n, r, w) for r in range(w)]
+            assert cover[0][0] == 0 and cover[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(cover, cover[1:]))

@@ -1,0 +1,133 @@
+"""CPU (`-m "not gpu"`) tests of the product's host side: C-ABI surface, index loader, index writer."""
+import ctypes as C
+import filecmp
+import os
+import re
+import shutil
+
+import numpy as np
+import pytest
+
+import femto_amd
+from conftest import GOLDEN, INDEX_FIXTURES, ROOT, WRITER_FIXTURES
+from sa_util import suffix_array
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "femto_amd.h")).read()
+    names = sorted(set(re.findall(r"\b(femto_amd_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 20
+    lib = femto_amd.lib()
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+@pytest.mark.parametrize("name", INDEX_FIXTURES)
+def test_loader_parses_reference_built_indexes(fixtures, name):
+    fx = fixtures(name)
+    ix = femto_amd.Index(fx.index, device=-1)      # parse + validate only: no GPU here
+    g = fx.gold
+    assert ix.info.total_length == len(g["L"])
+    assert ix.info.number_of_blocks == g["block_occs"].shape[1]
+    assert ix.info.number_of_documents == len(fx.docs)
+    assert ix.info.text_size_bits == max(1, int(ix.info.total_length).bit_length())
+    assert ix.info.total_buckets == -(-ix.info.total_length // ix.info.bucket_size)
+    if name in WRITER_FIXTURES:
+        assert ix.info.chunk_size == -1            # index_documents(map=NULL), construct.c:604
+    else:
+        assert ix.info.chunk_size == 256
+    # resolve_location (index.c:1587): doc_ends are cumulative doc_len+1
+    ends = np.cumsum([len(d) + 1 for d in fx.docs])
+    for off in [0, int(ends[0]) - 1, int(ends[-1]) - 1] + ([int(ends[0])] if len(ends) > 1 else []):
+        d = int(np.searchsorted(ends, off, side="right"))
+        assert ix.resolve_location(off) == (d, off - (int(ends[d - 1]) if d else 0))
+
+
+def test_flattened_and_directory_forms_parse_alike(fixtures):
+    fx = fixtures("acgt48k")
+    a = femto_amd.Index(fx.index, device=-1)
+    b = femto_amd.Index(fx.flat, device=-1)
+    for f, _ in femto_amd.Info._fields_:
+        if f != "image_bytes":
+            assert getattr(a.info, f) == getattr(b.info, f), f
+
+
+def test_loader_error_behaviour(fixtures, tmp_path):
+    fx = fixtures("counter400_default")
+    with pytest.raises(femto_amd.FemtoAmdError) as e:
+        femto_amd.Index(str(tmp_path / "nope"), device=-1)
+    assert e.value.code == 2                        # ERR_IO
+    bad = tmp_path / "bad"
+    shutil.copytree(fx.index, bad)
+    raw = bytearray(open(bad / "01", "rb").read())
+    raw[0] ^= 0xFF                                  # DATA_BLOCK_START magic
+    open(bad / "01", "wb").write(raw)
+    with pytest.raises(femto_amd.FemtoAmdError) as e:
+        femto_amd.Index(str(bad), device=-1)
+    assert e.value.code == 4 and "block start" in str(e.value)   # ERR_FORMAT "Invalid block start" (index.c:1361)
+    bad2 = tmp_path / "bad2"
+    shutil.copytree(fx.index, bad2)
+    raw = bytearray(open(bad2 / "00", "rb").read())
+    raw[79] ^= 1                                    # wavelet settings number
+    open(bad2 / "00", "wb").write(raw)
+    with pytest.raises(femto_amd.FemtoAmdError) as e:
+        femto_amd.Index(str(bad2), device=-1)
+    assert e.value.code == 4
+    bad3 = tmp_path / "bad3"
+    shutil.copytree(fx.index, bad3)
+    raw = open(bad3 / "01", "rb").read()
+    open(bad3 / "01", "wb").write(raw[: len(raw) // 2])       # truncated data block
+    with pytest.raises(femto_amd.FemtoAmdError):
+        femto_amd.Index(str(bad3), device=-1)
+
+
+def test_no_cpu_fallback(fixtures):
+    """The product must fail loudly without a GPU: no silent host path exists."""
+    import torch
+    fx = fixtures("acgt48k")
+    ix = femto_amd.Index(fx.index, device=-1)
+    with pytest.raises(femto_amd.FemtoAmdError) as e:
+        ix.count([np.array([70, 72], dtype=np.uint16)])
+    assert e.value.code == 6
+    with pytest.raises(femto_amd.FemtoAmdError):
+        ix.locate([np.array([70], dtype=np.uint16)], 3)
+    if not torch.cuda.is_available():
+        with pytest.raises(femto_amd.FemtoAmdError) as e:
+            femto_amd.Index(fx.index, device=0)
+        assert e.value.code == 6 and "no CPU fallback" in str(e.value)
+        with pytest.raises(femto_amd.FemtoAmdError):
+            femto_amd.build_index(str(fx.dir) + "/x", [b"ACGT"], device=0)
+
+
+def test_bseq_encoder_is_byte_identical_to_reference():
+    """The 12 sequences x 3 segment-type modes of wtree_test.c:440-580, images captured from the
+    reference's bseq_construct_forcetype."""
+    kat = np.load(os.path.join(GOLDEN, "bseq_kat.npz"))
+    for i in range(int(kat["nseq"])):
+        raw, nbits = kat[f"s{i}_raw"], int(kat[f"s{i}_nbits"])
+        for t in range(3):
+            z = femto_amd.bseq_encode(raw.tobytes(), nbits, t - 1)
+            assert np.array_equal(z, kat[f"s{i}_t{t}_z"]), (i, t)
+
+
+@pytest.mark.parametrize("name", WRITER_FIXTURES)
+def test_index_writer_is_byte_identical_to_reference(fixtures, tmp_path, name):
+    """same documents + parameters -> the same bytes as index_documents(map=NULL)."""
+    fx = fixtures(name)
+    sa = suffix_array(fx.prepared_text())
+    out = str(tmp_path / "mine")
+    infos = [os.path.basename(p) for p in fx.doc_paths]
+    femto_amd.build_index_from_sa(out, fx.docs, sa, params=None if fx.params == "-" else fx.params, infos=infos)
+    ref_files = sorted(f for f in os.listdir(fx.index) if f != "_femto_index")
+    my_files = sorted(f for f in os.listdir(out) if f != "_femto_index")
+    assert ref_files == my_files
+    for f in ref_files:
+        assert filecmp.cmp(os.path.join(fx.index, f), os.path.join(out, f), shallow=False), f
+
+
+def test_builder_parameter_validation(tmp_path):
+    docs = [np.frombuffer(b"ACGTACGT", dtype=np.uint8)]
+    sa = suffix_array(np.concatenate([docs[0].astype(np.uint16) + 5, [2]]))
+    for bad in ("block_size=10,bucket_size=4", "bucket_size=0", "bogus=1", "mark_period=0"):
+        with pytest.raises(femto_amd.FemtoAmdError):
+            femto_amd.build_index_from_sa(str(tmp_path / "x"), docs, sa, params=bad)

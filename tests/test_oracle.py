@@ -122,6 +122,12 @@ def test_count_locate_brute_force(fixtures, name):
         cnt = max(0, last[i] - first[i] + 1)
         if len(p) == 0:
             assert cnt == len(text)
+        elif (p[:-1] == 2).any():
+            # a pattern that CONTINUES past a SEOF: the reference's LF mapping of SEOF rows follows
+            # the circular convention L[suffix 0] = SEOF (bwt_qsufsort.c:62-83), so which document
+            # start it lands on is "indeterminate" (server.c:2336-2342); parity with the reference is
+            # what the golden tests check, brute force over the concatenation does not apply.
+            pass
         else:
             w = np.lib.stride_tricks.sliding_window_view(text, len(p)) if len(text) >= len(p) else np.zeros((0, len(p)))
             hits = np.nonzero((w == p).all(axis=1))[0]
