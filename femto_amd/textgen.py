@@ -36,10 +36,7 @@ def _vocabulary(rng, nwords):
     return words
 
 
-def t_eng(n, seed, nwords=20000):
-    """T_eng(N, seed): deterministic English-like text, sigma ~ 96 printable ASCII + newline:
-    Zipfian synthetic vocabulary, sentence capitalisation, digits, punctuation, newlines."""
-    rng = np.random.Generator(np.random.PCG64(seed))
+def _eng_tables(rng, nwords):
     words = _vocabulary(rng, nwords)
     seps = [b" "] * 70 + [b", "] * 8 + [b". "] * 7 + [b".\n"] * 3 + [b"; "] + [b": "] + [b"? "] + [b"! "] + \
            [b" - "] + [b" (", b") ", b" \"", b"\" ", b"'s "] + [b"\n\n"] + [b"/", b"_", b"=", b"+", b"*", b"&", b"%",
@@ -73,6 +70,18 @@ def t_eng(n, seed, nwords=20000):
     sep_start = np.zeros(len(seps), dtype=np.int64)
     sep_start[1:] = np.cumsum(sep_len[:-1])
     sep_pool = np.frombuffer(b"".join(seps), dtype=np.uint8)
+    return dict(cdf=cdf, ntok=ntok, tok_len=tok_len, tok_start=tok_start, tok_pool=tok_pool,
+                sep_len=sep_len, sep_start=sep_start, sep_pool=sep_pool, nseps=len(seps))
+
+
+def t_eng(n, seed, nwords=20000):
+    """T_eng(N, seed): deterministic English-like text, sigma ~ 96 printable ASCII + newline:
+    Zipfian synthetic vocabulary, sentence capitalisation, digits, punctuation, newlines."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    T = _eng_tables(rng, nwords)
+    cdf, ntok, tok_len, tok_start, tok_pool = T["cdf"], T["ntok"], T["tok_len"], T["tok_start"], T["tok_pool"]
+    sep_len, sep_start, sep_pool = T["sep_len"], T["sep_start"], T["sep_pool"]
+    seps = range(T["nseps"])
 
     out = np.empty(n, dtype=np.uint8)
     pos = 0
@@ -96,6 +105,40 @@ def t_eng(n, seed, nwords=20000):
         out[pos:pos + m] = piece[:m]
         pos += m
     return out
+
+
+def t_eng_torch(n, seed, device, nwords=20000):
+    """Same token tables and distribution as t_eng, sampled with torch on `device` (seconds instead of
+    minutes for 1 GiB).  Deterministic for a given (seed, device type); NOT byte-identical to t_eng."""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(seed))
+    T = _eng_tables(rng, nwords)
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    cdf = torch.from_numpy(T["cdf"]).to(dev)
+    tok_len = torch.from_numpy(T["tok_len"]).to(dev)
+    tok_start = torch.from_numpy(T["tok_start"]).to(dev)
+    npool = len(T["tok_pool"])
+    sep_len = torch.from_numpy(T["sep_len"]).to(dev)
+    sep_start = torch.from_numpy(T["sep_start"]).to(dev) + npool
+    pool = torch.from_numpy(np.concatenate([T["tok_pool"], T["sep_pool"]])).to(dev)
+    out = torch.empty(n, dtype=torch.uint8, device=dev)
+    pos = 0
+    chunk = 1 << 22
+    while pos < n:
+        ids = torch.searchsorted(cdf, torch.rand(chunk, generator=g, device=dev, dtype=torch.float64), right=True).clamp_(0, T["ntok"] - 1)
+        sids = torch.randint(0, T["nseps"], (chunk,), generator=g, device=dev)
+        lens = torch.stack([tok_len[ids], sep_len[sids]], dim=1).reshape(-1)
+        starts = torch.stack([tok_start[ids], sep_start[sids]], dim=1).reshape(-1)
+        ends = torch.cumsum(lens, 0)
+        total = int(ends[-1].item())
+        dst0 = ends - lens
+        src = torch.repeat_interleave(starts - dst0, lens) + torch.arange(total, device=dev)
+        m = min(total, n - pos)
+        out[pos:pos + m] = pool[src[:m]]
+        pos += m
+    return out.cpu().numpy()
 
 
 def t_counter(n):
