@@ -254,7 +254,7 @@ def main():
                 traffic = None
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": ("count_kernel_lane" if ix.rank_mode == 1 else "count_kernel<32>") + ("+locate_kernel_lane" if locate else ""),
+                "kernel": {1: "count_kernel_lane", 2: "count_kernel_flat", 0: "count_kernel<32>"}[ix.rank_mode] + ("+locate kernel" if locate else ""),
                 "kernel_ms": kern_ms, "locate_kernel_ms": loc_ms if locate else None, "launches_timed": kern_n,
                 "algorithmic_bytes_per_launch": alg_launch,
                 "per_pattern": {"bseq_rank": c["n_rank"] / sample, "occ": c["n_occ"] / sample,

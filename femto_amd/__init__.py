@@ -185,7 +185,7 @@ class Index:
                                                   stream or None))
 
     def set_rank_mode(self, mode):
-        """1 = lane-per-query over the block directory (default), 0 = wavefront-per-query raw walk"""
+        """1 = lane per query (default), 2 = flattened persistent lanes, 0 = wavefront-per-query raw walk"""
         _check(lib().femto_amd_set_rank_mode(self._h, mode))
 
     @property

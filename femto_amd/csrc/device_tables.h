@@ -58,6 +58,13 @@ struct DirEntry {           // 24 bytes
 //         sequence's last stores >= 511 bits (save_run, src/main/wtree.c:240-290), so bit t lies in
 //         segment hint[t>>9] or the next one.  Sequences whose segments all hold exactly 511 bits
 //         (all-literal: random ACGT) need no hint: segment = t / 511.
+// Sequences that need a hint (some segment is RLE) use TWO 64-byte slots per segment: the segment
+// and, for RLE segments, a skip table so that a rank decodes at most the gamma codes of one 64-bit
+// word instead of half the segment (a sigma~96 text averages 67 codes per RLE rank):
+//   aux word 0      : p_1..p_7, 9 bits each (p_k in the low bits ... p_7 highest): bit position of the
+//                     first gamma code that starts at or after bit 64*k of the segment
+//   aux word k (1-7): low 32 bits = data bits covered by the codes before p_k (0xffffffff: no such
+//                     code), high 32 bits = ones among them | (value of the run starting at p_k) << 31
 struct CumEntry { uint32_t o0, o1; };
 constexpr uint32_t kNoHint = 0xffffffffu;
 struct LaneBseq {           // 16 bytes

@@ -100,7 +100,10 @@ struct femto_amd_index {
   LaneSeq* d_lseqs = nullptr;
   OccEntry* d_occ = nullptr;
   int* d_err = nullptr;
-  int mode = 1;  // 1: lane-per-item kernels over the block directory; 0: wavefront-cooperative raw A/S/D walk
+  int mode = 1;  // 1: lane-per-query kernels (default); 2: flattened persistent-lane kernels; 0: wavefront-cooperative raw A/S/D walk
+  int num_cus = 256;
+  int blocks_per_cu_override = 0;
+  int queries_per_lane = 1;
   DevIndex dev{};
   int64_t table_bytes = 0;
   // scratch for the host-pointer API and the locate plan
@@ -151,7 +154,25 @@ int launch_count(femto_amd_index* ix, int64_t npats, const int32_t* d_plen, cons
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, stream));
   }
-  if (ix->mode == 1) {
+  if (ix->mode == 2) {
+    int64_t lblocks = (npats + kBlockThreads - 1) / kBlockThreads;
+    {  // persistent grid: exactly the resident blocks, lanes stride over the batch
+      int per_cu = 0;
+      hipError_t oe = ix->queries_per_lane >= 2
+                          ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, count_kernel_flat<2>, kBlockThreads, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, count_kernel_flat<1>, kBlockThreads, 0);
+      if (oe != hipSuccess || per_cu < 1) per_cu = 1;
+      int64_t cap = int64_t(ix->num_cus) * per_cu;
+      if (ix->blocks_per_cu_override > 0) cap = int64_t(ix->num_cus) * ix->blocks_per_cu_override;
+      if (lblocks > cap) lblocks = cap;
+    }
+    if (ix->queries_per_lane >= 2)
+      hipLaunchKernelGGL((count_kernel_flat<2>), dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats,
+                         d_plen, d_pats, d_starts, d_first, d_last, ix->d_err);
+    else
+      hipLaunchKernelGGL((count_kernel_flat<1>), dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats,
+                         d_plen, d_pats, d_starts, d_first, d_last, ix->d_err);
+  } else if (ix->mode == 1) {
     const int64_t lblocks = (npats + kBlockThreads - 1) / kBlockThreads;
     hipLaunchKernelGGL(count_kernel_lane, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
                        d_pats, d_starts, d_first, d_last, ix->d_err);
@@ -201,7 +222,18 @@ int launch_locate(femto_amd_index* ix, int64_t npats, const int64_t* d_first, co
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, stream));
   }
-  if (ix->mode == 1) {
+  if (ix->mode == 2) {
+    int64_t lblocks = (total + kBlockThreads - 1) / kBlockThreads;
+    {
+      int per_cu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, locate_kernel_flat, kBlockThreads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+      int64_t cap = int64_t(ix->num_cus) * per_cu;
+      if (ix->blocks_per_cu_override > 0) cap = int64_t(ix->num_cus) * ix->blocks_per_cu_override;
+      if (lblocks > cap) lblocks = cap;
+    }
+    hipLaunchKernelGGL(locate_kernel_flat, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_first,
+                       d_out_starts, total, d_offsets);
+  } else if (ix->mode == 1) {
     const int64_t lblocks = (total + kBlockThreads - 1) / kBlockThreads;
     hipLaunchKernelGGL(locate_kernel_lane, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_first,
                        d_out_starts, total, d_offsets);
@@ -308,10 +340,18 @@ int femto_amd_open(const char* index_path, int device, femto_amd_index_t** out) 
       d.b_size = h.b_size;
       d.b_shift = (h.b_size & (h.b_size - 1)) == 0 ? __builtin_ctz(unsigned(h.b_size)) : -1;
       d.text_size_bits = h.text_size_bits;
+      {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        ix->num_cus = prop.multiProcessorCount;
+        if (const char* ql = getenv("FEMTO_AMD_QUERIES_PER_LANE")) ix->queries_per_lane = atoi(ql);
+        if (const char* pb = getenv("FEMTO_AMD_BLOCKS_PER_CU")) ix->blocks_per_cu_override = atoi(pb);
+      }
       ix->mode = h.dir_regular ? 1 : 0;
       if (const char* m = getenv("FEMTO_AMD_RANK_MODE")) {
         if (!strcmp(m, "raw")) ix->mode = 0;
-        else if (!strcmp(m, "dir") && h.dir_regular) ix->mode = 1;
+        else if (!strcmp(m, "lane") && h.dir_regular) ix->mode = 1;
+        else if (!strcmp(m, "flat") && h.dir_regular) ix->mode = 2;
       }
       return 0;
     };
@@ -559,7 +599,7 @@ int femto_amd_block_requests(femto_amd_index_t* ix, int64_t n, const int64_t* ro
     HIP_TRY(hipMemcpy(d_chin, ch_in, size_t(n) * 2, hipMemcpyHostToDevice));
   }
   const int64_t blocks = (n * kGroupW + kBlockThreads - 1) / kBlockThreads;
-  if (ix->mode == 1)
+  if (ix->mode >= 1)
     hipLaunchKernelGGL(block_request_kernel_lane, dim3(uint32_t((n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads),
                        0, nullptr, ix->dev, n, ix->s_rows.as<int64_t>(), d_chin, d_chout, ix->s_occ.as<int64_t>(),
                        ix->s_off.as<int64_t>());
@@ -590,8 +630,8 @@ int femto_amd_block_requests(femto_amd_index_t* ix, int64_t n, const int64_t* ro
 }
 
 int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode) {
-  if (!ix || (mode != 0 && mode != 1)) return set_err(FEMTO_AMD_ERR_PARAM, "bad rank mode");
-  if (mode == 1 && !ix->host.dir_regular)
+  if (!ix || mode < 0 || mode > 2) return set_err(FEMTO_AMD_ERR_PARAM, "bad rank mode");
+  if (mode >= 1 && !ix->host.dir_regular)
     return set_err(FEMTO_AMD_ERR_INVALID, "this index has a short non-final segment: only the raw walk (mode 0) applies");
   std::lock_guard<std::recursive_mutex> lk(ix->mu);
   ix->mode = mode;

@@ -118,12 +118,6 @@ int build_directory(const std::vector<uint8_t>& img, DevBseq* bs, std::vector<Di
     if (lt->cum->size() > 0xfff00000ull || lt->hint->size() > 0xfff00000ull) return fail(e, ERR_MEM, "lane tables too large");
     lane->seg_base = lt->segs->size() / kSegmentWords;
     lane->cum_base = uint32_t(cum0);
-    // copy the D words into aligned native-endian slots (bseq_segment's zero fill included)
-    const uint8_t* Dsrc = img.data() + bs->off + bs->d_off;
-    const uint64_t ns = (uint64_t(bs->total_words) + kSegmentWords - 1) / kSegmentWords;
-    const size_t at = lt->segs->size();
-    lt->segs->resize(at + size_t(ns) * kSegmentWords, 0);
-    for (uint32_t wdx = 0; wdx < bs->total_words; wdx++) (*lt->segs)[at + wdx] = be64(Dsrc + 8ull * wdx);
   }
   const uint8_t* z = img.data() + bs->off;
   const uint32_t G = bs->num_groups;
@@ -178,6 +172,53 @@ int build_directory(const std::vector<uint8_t>& img, DevBseq* bs, std::vector<Di
       lane->hint_base = kNoHint;
     } else {
       lane->hint_base = uint32_t(hint0);
+    }
+    // copy the D words into 64-byte aligned native-endian slots (bseq_segment's zero fill included);
+    // non-uniform sequences get a second slot per segment holding the RLE skip table
+    const int stride = uniform ? 1 : 2;
+    const uint8_t* Dsrc = img.data() + bs->off + bs->d_off;
+    const size_t at = lt->segs->size();
+    lt->segs->resize(at + size_t(nseg) * kSegmentWords * size_t(stride), 0);
+    for (uint64_t sg = 0; sg < nseg; sg++) {
+      uint64_t w[kSegmentWords];
+      for (int k = 0; k < kSegmentWords; k++) {
+        const uint64_t wi = sg * kSegmentWords + uint64_t(k);
+        w[k] = wi < bs->total_words ? be64(Dsrc + 8ull * wi) : 0;
+      }
+      uint64_t* dst = lt->segs->data() + at + size_t(sg) * kSegmentWords * size_t(stride);
+      memcpy(dst, w, sizeof w);
+      if (stride == 2 && (w[0] >> 63)) {
+        // decode the whole RLE segment once (wtree.c:690-712) and record the state at each 64-bit boundary
+        uint64_t* aux = dst + kSegmentWords;
+        for (int k = 1; k < kSegmentWords; k++) aux[k] = 0xffffffffull;
+        auto window = [&](int p) -> uint64_t {
+          const int wi = p >> 6, sh = p & 63;
+          uint64_t v = wi < kSegmentWords ? w[wi] << sh : 0;
+          if (sh && wi + 1 < kSegmentWords) v |= w[wi + 1] >> (64 - sh);
+          return v;
+        };
+        uint32_t bit = uint32_t(w[0] >> 62) & 1u, total = 0, ones = 0;
+        int p = 2, next_k = 1;
+        uint64_t pk = 0;
+        while (p < kSegmentWords * 64) {
+          const uint64_t win = window(p);
+          if (win == 0) break;
+          while (next_k < kSegmentWords && p >= 64 * next_k) {
+            aux[next_k] = uint64_t(total) | (uint64_t(ones | (bit << 31)) << 32);
+            pk |= uint64_t(p) << (9 * (next_k - 1));
+            next_k++;
+          }
+          const int kz = __builtin_clzll(win);
+          if (kz >= 32) break;
+          const int nb = 2 * kz + 1;
+          const uint32_t v = uint32_t(win >> (64 - nb));
+          total += v;
+          if (bit) ones += v;
+          bit ^= 1u;
+          p += nb;
+        }
+        aux[0] = pk;
+      }
     }
   }
   return OK;

@@ -477,10 +477,12 @@ __global__ __launch_bounds__(256) void block_request_kernel(const DevIndex ix, c
 //
 // Measured on MI355X (profiles/r01_v1_*): the wavefront-cooperative walk above spends ~190 VALU
 // wave-instructions per rank (cross-lane scans/shuffles) and is VALU-issue + latency bound at 5 %
-// of the HBM roofline.  Here every LANE owns a whole query: a rank is ONE 24-byte directory load
-// (which segment, and the zeros/ones before it) plus the 64-byte segment itself, ~1 instruction per
-// rank per lane once amortised over the 64 lanes of a wavefront, so the kernel is limited by the
-// memory system (random 64-byte segment reads), which is what the roofline prices.
+// of the HBM roofline.  Here every LANE owns a whole query: a rank is one 8-byte cumulative-count
+// load (which segment, zeros/ones before it) plus the 64-byte aligned segment slot itself, a few
+// instructions per rank per lane once amortised over the 64 lanes of a wavefront, so the kernel is
+// limited by the memory system (random 64-byte segment reads), which is what the roofline prices.
+// Lanes of a wavefront start their patterns together, so the early backward-search steps (few
+// distinct ranges) hit the same cache lines; measured, this beats the flattened variant below.
 // =====================================================================================
 
 __device__ __forceinline__ uint64_t sel8(const uint64_t (&w)[kSegmentWords], int i) {
@@ -492,6 +494,32 @@ __device__ __forceinline__ uint64_t sel8(const uint64_t (&w)[kSegmentWords], int
   const uint64_t cd = (i & 2) ? d : c;
   const uint64_t r = (i & 4) ? cd : ab;
   return (i & ~7) ? 0 : r;
+}
+
+// RLE skip table (device_tables.h): jump to the last 64-bit boundary of the gamma stream whose
+// preceding runs all lie before the target bit `rel` (bits of this segment before the target).
+__device__ __forceinline__ void rle_skip(const uint64_t* __restrict__ aux, uint32_t rel, uint32_t& o0, uint32_t& o1,
+                                         uint32_t& bit, int& p) {
+  const ulonglong2* ap = reinterpret_cast<const ulonglong2*>(aux);
+  const ulonglong2 a01 = ap[0], a23 = ap[1], a45 = ap[2], a67 = ap[3];
+  const uint64_t e[7] = {a01.y, a23.x, a23.y, a45.x, a45.y, a67.x, a67.y};
+  uint64_t best = 0;
+  int k = 0;
+#pragma unroll
+  for (int j = 0; j < 7; j++) {
+    if (uint32_t(e[j]) <= rel) {  // totals are non-decreasing; 0xffffffff marks "no code starts here"
+      best = e[j];
+      k = j + 1;
+    }
+  }
+  if (k) {
+    const uint32_t total = uint32_t(best), hi = uint32_t(best >> 32);
+    const uint32_t ones = hi & 0x7fffffffu;
+    o0 += total - ones;
+    o1 += ones;
+    bit = hi >> 31;
+    p = int((a01.x >> (9 * (k - 1))) & 0x1ffu);
+  }
 }
 
 // bseq_rank (src/main/wtree.c:635-763) by ONE lane: which segment (cum/hint tables) -> the aligned
@@ -519,7 +547,8 @@ __device__ __forceinline__ RankResult bseq_rank_lane(const DevIndex& ix, const L
   }
   uint64_t w[kSegmentWords];
   {
-    const ulonglong2* sp = reinterpret_cast<const ulonglong2*>(ix.segs + (bs.seg_base + seg) * kSegmentWords);
+    const uint64_t slot = bs.hint_base == kNoHint ? bs.seg_base + seg : bs.seg_base + 2ull * seg;
+    const ulonglong2* sp = reinterpret_cast<const ulonglong2*>(ix.segs + slot * kSegmentWords);
 #pragma unroll
     for (int k = 0; k < kSegmentWords / 2; k++) {
       const ulonglong2 v = sp[k];
@@ -533,6 +562,8 @@ __device__ __forceinline__ RankResult bseq_rank_lane(const DevIndex& ix, const L
     // RLE segment (wtree.c:690-712)
     uint32_t bit = uint32_t(w[0] >> 62) & 1u;
     int p = 2;
+    if (bs.hint_base != kNoHint)
+      rle_skip(ix.segs + ((bs.seg_base + 2ull * seg) + 1) * kSegmentWords, t - o0 - o1, o0, o1, bit, p);
     uint64_t win = 0;
     int avail = 0;
     for (int it = 0; it < 512; it++) {
@@ -737,6 +768,358 @@ __global__ __launch_bounds__(256) void block_request_kernel_lane(const DevIndex 
   if (ch_out) ch_out[item] = uint16_t(sq.ch);
   if (occ_out) occ_out[item] = occ;
   if (off_out) off_out[item] = off;
+}
+
+
+// =====================================================================================
+// Flattened persistent-lane kernels (mode 2, selectable).
+//
+// The nested loops of the lane kernels above (pattern steps x two rows x wavelet levels x gamma
+// codes) diverge multiplicatively inside a wavefront: on a sigma~96 index (code lengths 1..20,
+// 74 % RLE ranks, ~67 gamma codes each) rocprofv3 showed 1.4e11 VALU wave-instructions per 2 M
+// patterns, ~10 % lane utilisation.  Here every lane runs ONE flat loop whose body performs exactly
+// one bseq_rank for whatever (query, row, level) the lane is at, then advances a small state
+// machine; finished lanes pull their next query (grid-stride), so a wavefront's 64 lanes always
+// rank together and only the rank itself (literal popcount vs gamma runs) can diverge.
+// =====================================================================================
+
+// ---- staged rank: the loads of several independent ranks are issued stage by stage so that one
+// lane keeps several 64-byte segment reads in flight (the walk of row first-1, the walk of row
+// last, and the same for a second query).
+struct RankJob {
+  uint32_t t;          // 0-based bit position
+  uint32_t seg, o0, o1;
+  uint64_t slot;       // segment slot index in DevIndex::segs
+  bool has_aux;        // the next slot holds the RLE skip table
+};
+
+__device__ __forceinline__ void rank_locate_segment(const DevIndex& ix, const LaneBseq bs, uint32_t index1, RankJob& j) {
+  j.t = index1 - 1;
+  if (bs.hint_base == kNoHint) {
+    j.seg = j.t / 511u;
+    const uint64_t c = *reinterpret_cast<const uint64_t*>(ix.cum + (uint64_t(bs.cum_base) + j.seg));
+    j.o0 = uint32_t(c);
+    j.o1 = uint32_t(c >> 32);
+  } else {
+    j.seg = ix.hint[uint64_t(bs.hint_base) + (j.t >> 9)];
+    const uint64_t* cp = reinterpret_cast<const uint64_t*>(ix.cum + (uint64_t(bs.cum_base) + j.seg));
+    const uint64_t c0 = cp[0], c1 = cp[1];
+    j.o0 = uint32_t(c0);
+    j.o1 = uint32_t(c0 >> 32);
+    const uint32_t n0 = uint32_t(c1), n1 = uint32_t(c1 >> 32);
+    if (j.t >= n0 + n1) {
+      j.o0 = n0;
+      j.o1 = n1;
+      j.seg++;
+    }
+  }
+  j.slot = bs.hint_base == kNoHint ? bs.seg_base + j.seg : bs.seg_base + 2ull * j.seg;
+  j.has_aux = bs.hint_base != kNoHint;
+}
+
+__device__ __forceinline__ void rank_load_segment(const DevIndex& ix, const RankJob& j, uint64_t (&w)[kSegmentWords]) {
+  const ulonglong2* sp = reinterpret_cast<const ulonglong2*>(ix.segs + j.slot * kSegmentWords);
+#pragma unroll
+  for (int k = 0; k < kSegmentWords / 2; k++) {
+    const ulonglong2 v = sp[k];
+    w[2 * k] = v.x;
+    w[2 * k + 1] = v.y;
+  }
+}
+
+__device__ __forceinline__ RankResult rank_finish(const DevIndex& ix, const RankJob& j, const uint64_t (&w)[kSegmentWords]) {
+  uint32_t o0 = j.o0, o1 = j.o1;
+  const uint32_t t = j.t;
+  RankResult r;
+  if (w[0] >> 63) {  // RLE segment (wtree.c:690-712)
+    uint32_t bit = uint32_t(w[0] >> 62) & 1u;
+    int p = 2;
+    if (j.has_aux) rle_skip(ix.segs + (j.slot + 1) * kSegmentWords, t - o0 - o1, o0, o1, bit, p);
+    uint64_t win = 0;
+    int avail = 0;
+    for (int it = 0; it < 512; it++) {
+      int k = win ? __clzll(win) : 64;
+      if (2 * k + 1 > avail) {
+        const int wi = p >> 6, sh = p & 63;
+        const uint64_t a = sel8(w, wi);
+        const uint64_t c = sel8(w, wi + 1);
+        win = (a << sh) | (sh ? (c >> (64 - sh)) : 0);
+        avail = 64;
+        k = win ? __clzll(win) : 64;
+        if (k >= 32) break;
+      }
+      const int nb = 2 * k + 1;
+      const uint32_t v = uint32_t(win >> (64 - nb));
+      win = nb < 64 ? (win << nb) : 0;
+      avail -= nb;
+      p += nb;
+      const uint32_t tot = o0 + o1;
+      if (tot + v <= t) {
+        if (bit) o1 += v; else o0 += v;
+        bit ^= 1u;
+      } else {
+        const uint32_t rem = t + 1 - tot;
+        if (bit) o1 += rem; else o0 += rem;
+        break;
+      }
+    }
+    r.bit = bit;
+  } else {  // literal segment (wtree.c:713-759)
+    const uint32_t nb = 1 + t - o0 - o1;
+    uint32_t ones = 0;
+    uint64_t bw = 0;
+#pragma unroll
+    for (int k = 0; k < kSegmentWords; k++) {
+      const uint32_t lo = 64u * uint32_t(k);
+      uint64_t m = 0;
+      if (nb >= lo) m = (nb - lo >= 63) ? ~0ull : (~0ull << (63 - (nb - lo)));
+      ones += uint32_t(__popcll(w[k] & m));
+      if ((nb >> 6) == uint32_t(k)) bw = w[k];
+    }
+    o1 += ones;
+    o0 += nb - ones;
+    r.bit = uint32_t(bw >> (63 - (nb & 63))) & 1u;
+  }
+  r.o0 = o0;
+  r.o1 = o1;
+  return r;
+}
+
+enum : int { ST_QUERY = 0, ST_STEP = 1, ST_WALK = 2, ST_DONE = 3 };
+
+// do_string_query (src/main/server.c:713-946), flattened: every lane owns NQ patterns at a time and
+// advances the two walks (rows first-1 and last) of each by ONE wavelet level per loop iteration.
+template <int NQ>
+__global__ __launch_bounds__(256) void count_kernel_flat(const DevIndex ix, const int64_t npats,
+                                                         const int32_t* __restrict__ plen,
+                                                         const uint16_t* __restrict__ pats,
+                                                         const int64_t* __restrict__ starts,
+                                                         int64_t* __restrict__ first_out,
+                                                         int64_t* __restrict__ last_out, int* __restrict__ err_flag) {
+  constexpr int NW = 2 * NQ;  // walks per lane
+  const int64_t T = int64_t(gridDim.x) * blockDim.x;
+  const int64_t tid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  int64_t q[NQ];
+  int st[NQ];
+  const uint16_t* pat[NQ];
+  int i[NQ];
+  int64_t first[NQ], last[NQ];
+  // per walk (w = 2*slot + side)
+  bool walking[NW];
+  int64_t base[NW];
+  uint32_t code[NW], idx[NW], nodei[NW], node_base[NW];
+  int rem[NW];
+#pragma unroll
+  for (int s = 0; s < NQ; s++) {
+    q[s] = tid + int64_t(s) * T;
+    st[s] = ST_QUERY;
+    pat[s] = nullptr;
+    i[s] = 0;
+    first[s] = 0;
+    last[s] = -1;
+  }
+#pragma unroll
+  for (int w = 0; w < NW; w++) {
+    walking[w] = false;
+    base[w] = 0;
+    code[w] = idx[w] = nodei[w] = node_base[w] = 0;
+    rem[w] = 0;
+  }
+
+  for (;;) {
+    // ---- transitions (cheap, divergent): make every live slot either walking or finished
+    bool any_live = false;
+#pragma unroll
+    for (int s = 0; s < NQ; s++) {
+      if (st[s] == ST_QUERY) {
+        if (q[s] >= npats) {
+          st[s] = ST_DONE;
+        } else {
+          const int len = plen[q[s]];
+          pat[s] = pats + starts[q[s]];
+          st[s] = ST_STEP;
+          if (len == 0) {  // server.c:782-808
+            first[s] = 0;
+            last[s] = ix.total_length - 1;
+            i[s] = 0;
+          } else {
+            i[s] = len - 1;
+            const uint32_t c0 = pat[s][i[s]];
+            if (c0 >= uint32_t(kAlphaSize)) {
+              atomicOr(err_flag, 1);
+              first[s] = 0;
+              last[s] = -1;
+            } else {
+              first[s] = ix.C[c0];       // server.c:795-829
+              last[s] = ix.C[c0 + 1] - 1;
+            }
+          }
+        }
+      }
+      if (st[s] == ST_STEP) {
+        if (first[s] > last[s] || i[s] == 0) {  // server.c:832
+          first_out[q[s]] = last_out ? first[s] : last[s] - first[s] + 1;
+          if (last_out) last_out[q[s]] = last[s];
+          q[s] += int64_t(NQ) * T;
+          st[s] = ST_QUERY;  // refilled at the top of the next iteration
+        } else {
+          const uint32_t ch = pat[s][i[s] - 1];
+          if (ch >= uint32_t(kAlphaSize)) {
+            atomicOr(err_flag, 1);
+            first[s] = 0;
+            last[s] = -1;
+          } else {
+            // both rows of the step: first-1 (skipped when first == 0: only C[ch], server.c:838-843) and last
+            uint32_t ia = 1, ib;
+            const int64_t ga = first[s] > 0 ? bucket_of(ix, first[s] - 1, &ia) : 0;
+            const int64_t gbk = bucket_of(ix, last[s], &ib);
+            const OccEntry ea = ix.occ[ga * kAlphaSize + ch];
+            const OccEntry eb = ix.occ[gbk * kAlphaSize + ch];
+            const int wa = 2 * s, wb = 2 * s + 1;
+            if (first[s] == 0) {
+              base[wa] = ix.C[ch];
+              idx[wa] = 0;
+              walking[wa] = false;
+            } else {
+              base[wa] = ea.base;
+              idx[wa] = ea.code ? ia : 0;   // absent character: Occ adds 0 (index.c:2080-2089)
+              walking[wa] = ea.code != 0;
+              code[wa] = ea.code;
+              rem[wa] = 31 - __clz(int(ea.code | 1u));
+              node_base[wa] = ea.node_base;
+              nodei[wa] = ea.node_base;
+            }
+            base[wb] = eb.base;
+            idx[wb] = eb.code ? ib : 0;
+            walking[wb] = eb.code != 0;
+            code[wb] = eb.code;
+            rem[wb] = 31 - __clz(int(eb.code | 1u));
+            node_base[wb] = eb.node_base;
+            nodei[wb] = eb.node_base;
+            st[s] = ST_WALK;
+          }
+        }
+      }
+      if (st[s] == ST_WALK && !walking[2 * s] && !walking[2 * s + 1]) {
+        // first = C+Occ(ch, first-1); last = C+Occ(ch, last) - 1 (server.c:909-936)
+        first[s] = base[2 * s] + int64_t(idx[2 * s]);
+        last[s] = base[2 * s + 1] + int64_t(idx[2 * s + 1]) - 1;
+        i[s]--;
+        st[s] = ST_STEP;
+      }
+      any_live = any_live || st[s] != ST_DONE;
+    }
+    if (!any_live) break;
+
+    // ---- one wavelet level for every active walk, loads issued stage by stage
+    LaneNode nd[NW];
+    RankJob job[NW];
+    uint64_t words[NW][kSegmentWords];
+#pragma unroll
+    for (int w = 0; w < NW; w++)
+      if (walking[w]) nd[w] = ix.lnodes[nodei[w]];
+#pragma unroll
+    for (int w = 0; w < NW; w++)
+      if (walking[w]) rank_locate_segment(ix, nd[w].bs, idx[w], job[w]);
+#pragma unroll
+    for (int w = 0; w < NW; w++)
+      if (walking[w]) rank_load_segment(ix, job[w], words[w]);
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      if (walking[w]) {  // one level of wtree_occs (src/main/wtree.c:1081-1115)
+        const RankResult r = rank_finish(ix, job[w], words[w]);
+        rem[w]--;
+        const uint32_t b = (code[w] >> rem[w]) & 1u;
+        idx[w] -= b ? r.o0 : r.o1;
+        const int child = b ? nd[w].child[1] : nd[w].child[0];
+        if (idx[w] == 0 || rem[w] == 0 || child < 0) walking[w] = false;
+        else nodei[w] = node_base[w] + uint32_t(child);
+      }
+    }
+  }
+}
+
+enum : int { LT_ITEM = 0, LT_ROW = 1, LT_WT = 2, LT_MARK = 3 };
+
+// locate walk (do_back_query / do_context_query), flattened: one rank per loop iteration
+__global__ __launch_bounds__(256) void locate_kernel_flat(const DevIndex ix, const int64_t npats,
+                                                          const int64_t* __restrict__ first,
+                                                          const int64_t* __restrict__ out_starts, const int64_t total,
+                                                          int64_t* __restrict__ offsets) {
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  int st = LT_ITEM;
+  int64_t row = 0, steps = 0, gb = 0;
+  uint32_t idx = 0, node_base = 0, nodei = 0, seq_base = 0, n_in_use = 0, mch = 0;
+  LaneBseq mbs{0, 0, 0};
+  uint64_t marr = 0;
+
+  for (;;) {
+    if (st == LT_ITEM) {
+      if (item >= total) break;
+      int64_t lo = 0, hi = npats;  // largest q with out_starts[q] <= item
+      while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (out_starts[mid] <= item) lo = mid; else hi = mid;
+      }
+      row = first[lo] + (item - out_starts[lo]);
+      steps = 0;
+      st = LT_ROW;
+    }
+    if (st == LT_ROW) {
+      if (row < 0) {  // walked past a document start without meeting a mark
+        offsets[item] = -1;
+        item += stride;
+        st = LT_ITEM;
+        continue;
+      }
+      uint32_t idx1;
+      gb = bucket_of(ix, row, &idx1);
+      const DevBucket bk = ix.buckets[gb];
+      idx = idx1;
+      node_base = bk.node_base;
+      nodei = node_base;
+      seq_base = bk.seq_base;
+      n_in_use = bk.n_in_use;
+      st = LT_WT;
+    }
+    if (st == LT_WT) {  // one level of wtree_rank (src/main/wtree.c:1117-1148)
+      const LaneNode nd = ix.lnodes[nodei];
+      const RankResult r = bseq_rank_lane(ix, nd.bs, idx);
+      idx -= r.bit ? r.o0 : r.o1;
+      const int child = r.bit ? nd.child[1] : nd.child[0];
+      if (child >= 0) {
+        nodei = node_base + uint32_t(child);
+      } else {
+        const uint32_t seq = uint32_t(-1 - child);
+        if (seq >= n_in_use) {  // corrupt data guard
+          row = -1;
+          st = LT_ROW;
+        } else {
+          const LaneSeq sq = ix.lseqs[seq_base + seq];
+          mbs = sq.mark_table;
+          marr = sq.mark_array;
+          mch = sq.ch;
+          st = LT_MARK;
+        }
+      }
+    } else if (st == LT_MARK) {  // mark table rank at Occ-in-bucket(L[row], row) (index.c:2102-2140)
+      const RankResult m = bseq_rank_lane(ix, mbs, idx);
+      if (m.bit) {
+        const uint64_t rec = uint64_t(m.o1) - 1;
+        offsets[item] = int64_t(read_bits(ix.image, marr * 8 + rec * uint64_t(ix.text_size_bits), ix.text_size_bits)) + steps;
+        item += stride;
+        st = LT_ITEM;
+      } else if (mch <= uint32_t(kSEOF)) {
+        row = -1;  // server.c:2336-2342
+        st = LT_ROW;
+      } else {
+        row = ix.occ[gb * kAlphaSize + mch].base + int64_t(idx) - 1;  // LF (server.c:2279-2282)
+        steps++;
+        st = LT_ROW;
+      }
+    }
+  }
 }
 
 }  // namespace femto_amd

@@ -133,10 +133,12 @@ int femto_amd_block_requests(femto_amd_index_t* ix, int64_t n, const int64_t* ro
                              uint16_t* ch_out, int32_t* occ_out, int64_t* off_out);
 
 /* ---- kernel family ---------------------------------------------------------------------------- */
-/* mode 1 (default): one LANE per query over the derived 24-byte block directory (one directory load
- * + one 64-byte segment per rank).  mode 0: one WAVEFRONT per query walking femto's own A0/A1/AP
- * group tables and varbyte S sums with __ballot/ds_bpermute (no derived rank tables).  Both are
- * bit-exact; FEMTO_AMD_RANK_MODE=raw|dir selects the default at open. */
+/* mode 1 (default): one LANE per query; a rank reads one cumulative-count entry and one 64-byte
+ * aligned segment slot from tables derived at load time (RLE segments also a 64-byte skip table).
+ * mode 2: the same per-lane rank inside one flat loop on a persistent grid (one wavelet level per
+ * iteration, lanes refill with the next query).  mode 0: one WAVEFRONT per query walking femto's own
+ * A0/A1/AP group tables and varbyte S sums with __ballot/ds_bpermute (no derived rank tables).  All
+ * are bit-exact; FEMTO_AMD_RANK_MODE=lane|flat|raw selects the default at open. */
 int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode);
 int femto_amd_get_rank_mode(const femto_amd_index_t* ix);
 

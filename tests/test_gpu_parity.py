@@ -21,7 +21,7 @@ def gpu_ok():
     return True
 
 
-MODES = [1, 0]   # 1: lane-per-query over the block directory (default); 0: wavefront-per-query raw A/S/D walk
+MODES = [1, 2, 0]   # 1: lane per query (default); 2: flattened persistent lanes; 0: wavefront-per-query raw walk
 
 
 @pytest.mark.parametrize("mode", MODES)
