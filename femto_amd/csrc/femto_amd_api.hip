@@ -16,6 +16,13 @@
 
 using namespace femto_amd;
 
+namespace femto_amd {
+size_t query_sort_temp_bytes(int64_t npats);
+hipError_t query_sort(int64_t npats, const int32_t* d_plen, const uint16_t* d_pats, const int64_t* d_starts,
+                      uint64_t* keys, uint64_t* keys2, uint32_t* idx, uint32_t* idx2, void* tmp, size_t tmp_bytes,
+                      hipStream_t stream);
+}
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -109,6 +116,9 @@ struct femto_amd_index {
   // scratch for the host-pointer API and the locate plan
   DeviceBuffer s_plen, s_pats, s_starts, s_first, s_last, s_noccs, s_noccs64, s_out_starts, s_offsets, s_scan[3];
   DeviceBuffer s_rows, s_ch, s_occ, s_off;
+  DeviceBuffer s_keys, s_keys2, s_idx, s_idx2, s_sorttmp;
+  bool sort_queries = true;   // FEMTO_AMD_SORT=0 disables
+  int64_t sort_min = 4096;
   bool timing = false;
   KernelTimer t_count, t_locate;
 };
@@ -149,10 +159,10 @@ int launch_count(femto_amd_index* ix, int64_t npats, const int32_t* d_plen, cons
   const int64_t blocks = (threads + kBlockThreads - 1) / kBlockThreads;
   if (blocks > 0x7fffffffLL) return set_err(FEMTO_AMD_ERR_PARAM, "batch too large for one launch");
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (ix->timing) {
+  if (ix->timing) {  // events bracket the search kernel itself (the suffix-order sort is a separate, small launch)
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, stream));
+    if (ix->mode != 1) HIP_TRY(hipEventRecord(e0, stream));
   }
   if (ix->mode == 2) {
     int64_t lblocks = (npats + kBlockThreads - 1) / kBlockThreads;
@@ -174,8 +184,23 @@ int launch_count(femto_amd_index* ix, int64_t npats, const int32_t* d_plen, cons
                          d_plen, d_pats, d_starts, d_first, d_last, ix->d_err);
   } else if (ix->mode == 1) {
     const int64_t lblocks = (npats + kBlockThreads - 1) / kBlockThreads;
+    const uint32_t* perm = nullptr;
+    if (ix->sort_queries && npats >= ix->sort_min && npats < (int64_t(1) << 32)) {
+      // order the batch by pattern suffix (query_sort.hip); results still land at the caller's indexes
+      int rc;
+      if ((rc = ix->s_keys.reserve(size_t(npats) * 8))) return rc;
+      if ((rc = ix->s_keys2.reserve(size_t(npats) * 8))) return rc;
+      if ((rc = ix->s_idx.reserve(size_t(npats) * 4))) return rc;
+      if ((rc = ix->s_idx2.reserve(size_t(npats) * 4))) return rc;
+      const size_t tb = query_sort_temp_bytes(npats);
+      if ((rc = ix->s_sorttmp.reserve(tb ? tb : 16))) return rc;
+      HIP_TRY(query_sort(npats, d_plen, d_pats, d_starts, ix->s_keys.as<uint64_t>(), ix->s_keys2.as<uint64_t>(),
+                         ix->s_idx.as<uint32_t>(), ix->s_idx2.as<uint32_t>(), ix->s_sorttmp.p, tb, stream));
+      perm = ix->s_idx2.as<uint32_t>();
+    }
+    if (ix->timing) HIP_TRY(hipEventRecord(e0, stream));
     hipLaunchKernelGGL(count_kernel_lane, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
-                       d_pats, d_starts, d_first, d_last, ix->d_err);
+                       d_pats, d_starts, d_first, d_last, ix->d_err, perm);
   } else {
     hipLaunchKernelGGL((count_kernel<kGroupW>), dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats,
                        d_plen, d_pats, d_starts, d_first, d_last, ix->d_err);
@@ -344,6 +369,7 @@ int femto_amd_open(const char* index_path, int device, femto_amd_index_t** out) 
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         ix->num_cus = prop.multiProcessorCount;
+        if (const char* so = getenv("FEMTO_AMD_SORT")) ix->sort_queries = atoi(so) != 0;
         if (const char* ql = getenv("FEMTO_AMD_QUERIES_PER_LANE")) ix->queries_per_lane = atoi(ql);
         if (const char* pb = getenv("FEMTO_AMD_BLOCKS_PER_CU")) ix->blocks_per_cu_override = atoi(pb);
       }
@@ -387,7 +413,8 @@ void femto_amd_close(femto_amd_index_t* ix) {
     (void)hipFree(ix->d_err);
     for (DeviceBuffer* b : {&ix->s_plen, &ix->s_pats, &ix->s_starts, &ix->s_first, &ix->s_last, &ix->s_noccs,
                             &ix->s_noccs64, &ix->s_out_starts, &ix->s_offsets, &ix->s_scan[0], &ix->s_scan[1],
-                            &ix->s_scan[2], &ix->s_rows, &ix->s_ch, &ix->s_occ, &ix->s_off})
+                            &ix->s_scan[2], &ix->s_rows, &ix->s_ch, &ix->s_occ, &ix->s_off, &ix->s_keys, &ix->s_keys2, &ix->s_idx,
+                            &ix->s_idx2, &ix->s_sorttmp})
       b->release();
   }
   delete ix;

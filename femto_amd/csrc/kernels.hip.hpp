@@ -657,14 +657,18 @@ __device__ __forceinline__ int64_t c_plus_occ_lane(const DevIndex& ix, uint32_t 
 }
 
 // do_string_query (src/main/server.c:713-946): one LANE per pattern
+// `perm` (optional): lane j processes pattern perm[j] -- the batch ordered by pattern suffix
+// (query_sort.hip) so that neighbouring lanes share the rows of their first steps.
 __global__ __launch_bounds__(256) void count_kernel_lane(const DevIndex ix, const int64_t npats,
                                                          const int32_t* __restrict__ plen,
                                                          const uint16_t* __restrict__ pats,
                                                          const int64_t* __restrict__ starts,
                                                          int64_t* __restrict__ first_out,
-                                                         int64_t* __restrict__ last_out, int* __restrict__ err_flag) {
-  const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (q >= npats) return;
+                                                         int64_t* __restrict__ last_out, int* __restrict__ err_flag,
+                                                         const uint32_t* __restrict__ perm) {
+  const int64_t slot = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (slot >= npats) return;
+  const int64_t q = perm ? int64_t(perm[slot]) : slot;
   const int len = plen[q];
   const uint16_t* pat = pats + starts[q];
   int64_t first, last;
