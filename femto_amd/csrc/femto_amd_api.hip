@@ -20,7 +20,7 @@ namespace femto_amd {
 size_t query_sort_temp_bytes(int64_t npats);
 hipError_t query_sort(int64_t npats, const int32_t* d_plen, const uint16_t* d_pats, const int64_t* d_starts,
                       uint64_t* keys, uint64_t* keys2, uint32_t* idx, uint32_t* idx2, void* tmp, size_t tmp_bytes,
-                      hipStream_t stream);
+                      hipStream_t stream, int levels);
 }
 
 namespace {
@@ -117,7 +117,8 @@ struct femto_amd_index {
   DeviceBuffer s_plen, s_pats, s_starts, s_first, s_last, s_noccs, s_noccs64, s_out_starts, s_offsets, s_scan[3];
   DeviceBuffer s_rows, s_ch, s_occ, s_off;
   DeviceBuffer s_keys, s_keys2, s_idx, s_idx2, s_sorttmp;
-  bool sort_queries = true;   // FEMTO_AMD_SORT=0 disables
+  bool sort_queries = true;   // FEMTO_AMD_SORT=0 disables, =2 sorts on 16 symbols
+  int sort_levels = 1;
   int64_t sort_min = 4096;
   bool timing = false;
   KernelTimer t_count, t_locate;
@@ -195,7 +196,7 @@ int launch_count(femto_amd_index* ix, int64_t npats, const int32_t* d_plen, cons
       const size_t tb = query_sort_temp_bytes(npats);
       if ((rc = ix->s_sorttmp.reserve(tb ? tb : 16))) return rc;
       HIP_TRY(query_sort(npats, d_plen, d_pats, d_starts, ix->s_keys.as<uint64_t>(), ix->s_keys2.as<uint64_t>(),
-                         ix->s_idx.as<uint32_t>(), ix->s_idx2.as<uint32_t>(), ix->s_sorttmp.p, tb, stream));
+                         ix->s_idx.as<uint32_t>(), ix->s_idx2.as<uint32_t>(), ix->s_sorttmp.p, tb, stream, ix->sort_levels));
       perm = ix->s_idx2.as<uint32_t>();
     }
     if (ix->timing) HIP_TRY(hipEventRecord(e0, stream));
@@ -369,7 +370,7 @@ int femto_amd_open(const char* index_path, int device, femto_amd_index_t** out) 
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         ix->num_cus = prop.multiProcessorCount;
-        if (const char* so = getenv("FEMTO_AMD_SORT")) ix->sort_queries = atoi(so) != 0;
+        if (const char* so = getenv("FEMTO_AMD_SORT")) { ix->sort_queries = atoi(so) != 0; ix->sort_levels = atoi(so) >= 2 ? 2 : 1; }
         if (const char* ql = getenv("FEMTO_AMD_QUERIES_PER_LANE")) ix->queries_per_lane = atoi(ql);
         if (const char* pb = getenv("FEMTO_AMD_BLOCKS_PER_CU")) ix->blocks_per_cu_override = atoi(pb);
       }

@@ -4,7 +4,11 @@ label=$1; shift
 envs=()
 while [ $# -gt 0 ] && [ "$1" != "--" ]; do envs+=("$1"); shift; done
 [ "${1:-}" = "--" ] && shift
-env "${envs[@]}" python bench.py --cpu-sample 20000 "$@" 2>/dev/null | python -c "
+env "${envs[@]}" python bench.py --cpu-sample 20000 --no-extra "$@" 2>/tmp/qb.err | python -c "
 import sys,json
-d=json.loads(sys.stdin.read()); r=d['roofline']
-print('$label', '|', round(d['value']/1e6,1), 'Mpat/s', round(d['ms_per_step'],2), 'ms/step frac', round(r['frac'],3), r['kernel'], 'count_ms', round(r['kernel_ms']-(r['locate_kernel_ms'] or 0),2), 'locate_ms', r['locate_kernel_ms'])"
+t=sys.stdin.read()
+try:
+    d=json.loads(t); r=d['roofline']
+    print('$label', '|', round(d['value']/1e6,1), 'Mpat/s', round(d['ms_per_step'],2), 'ms/step frac', round(r['frac'],3), r['kernel'], 'count_ms', round(r['count_kernel_ms'],2), 'locate_ms', round(r['locate_kernel_ms'],2), 'rows', d['config']['located_rows_per_gpu'])
+except Exception as e:
+    print('$label FAILED', e, t[:300]); print(open('/tmp/qb.err').read()[-1500:])"
