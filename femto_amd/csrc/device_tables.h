@@ -49,9 +49,11 @@ struct DirEntry {           // 24 bytes
 };
 
 // ---- lane-kernel view of a binary sequence (derived at load time) --------------------------
-// segs  : every sequence's D words copied into 64-byte-ALIGNED segment slots (native-endian
-//         u64, most significant bit first; the last slot zero padded), so one rank reads exactly
-//         one 64-byte sector instead of an 8-byte-aligned run straddling two;
+// segs  : every sequence's D words copied into 128-byte-ALIGNED lines, one per segment: words 0..7
+//         = the segment (native-endian u64, most significant bit first; zero padded), word 8 = the
+//         zeros/ones before the segment (uniform sequences) or words 8..15 = the RLE skip table.
+//         gfx950's L2 fetches 128-byte lines (all TCC_EA0_RDREQ are 128 B), so a rank on a uniform
+//         sequence costs exactly ONE memory line;
 // cum   : per segment the zeros/ones BEFORE it (the varbyte S sums and A0/A1 group tables,
 //         prefix-summed), plus one terminal entry per sequence;
 // hint  : per 512-bit block the segment holding the block's first bit.  Every segment but a
@@ -68,7 +70,7 @@ struct DirEntry {           // 24 bytes
 struct CumEntry { uint32_t o0, o1; };
 constexpr uint32_t kNoHint = 0xffffffffu;
 struct LaneBseq {           // 16 bytes
-  uint64_t seg_base;        // first 64-byte slot of this sequence in DevIndex::segs
+  uint64_t seg_base;        // first 64-byte slot of this sequence in DevIndex::segs (two slots per segment)
   uint32_t cum_base;        // first CumEntry
   uint32_t hint_base;       // first hint entry, or kNoHint for uniform 511-bit segments
 };

@@ -175,7 +175,11 @@ int build_directory(const std::vector<uint8_t>& img, DevBseq* bs, std::vector<Di
     }
     // copy the D words into 64-byte aligned native-endian slots (bseq_segment's zero fill included);
     // non-uniform sequences get a second slot per segment holding the RLE skip table
-    const int stride = uniform ? 1 : 2;
+    // every sequence uses two 64-byte slots (one 128-byte memory line) per segment: the line the
+    // memory system fetches anyway (all L2 read requests are 128 B on gfx950, TCC_EA0_RDREQ_128B).
+    // Uniform sequences keep the segment's cumulative (zeros, ones) in word 8 of the line, so a rank
+    // costs exactly ONE line; sequences with RLE segments keep the skip table there.
+    const int stride = 2;
     const uint8_t* Dsrc = img.data() + bs->off + bs->d_off;
     const size_t at = lt->segs->size();
     lt->segs->resize(at + size_t(nseg) * kSegmentWords * size_t(stride), 0);
@@ -187,7 +191,11 @@ int build_directory(const std::vector<uint8_t>& img, DevBseq* bs, std::vector<Di
       }
       uint64_t* dst = lt->segs->data() + at + size_t(sg) * kSegmentWords * size_t(stride);
       memcpy(dst, w, sizeof w);
-      if (stride == 2 && (w[0] >> 63)) {
+      if (uniform) {
+        const CumEntry& ce = (*lt->cum)[cum0 + size_t(sg)];
+        dst[kSegmentWords] = uint64_t(ce.o0) | (uint64_t(ce.o1) << 32);
+      }
+      if (!uniform && (w[0] >> 63)) {
         // decode the whole RLE segment once (wtree.c:690-712) and record the state at each 64-bit boundary
         uint64_t* aux = dst + kSegmentWords;
         for (int k = 1; k < kSegmentWords; k++) aux[k] = 0xffffffffull;
@@ -220,6 +228,7 @@ int build_directory(const std::vector<uint8_t>& img, DevBseq* bs, std::vector<Di
         aux[0] = pk;
       }
     }
+    if (uniform) lt->cum->resize(cum0);
   }
   return OK;
 }

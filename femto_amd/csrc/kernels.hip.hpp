@@ -527,11 +527,10 @@ __device__ __forceinline__ void rle_skip(const uint64_t* __restrict__ aux, uint3
 __device__ __forceinline__ RankResult bseq_rank_lane(const DevIndex& ix, const LaneBseq bs, uint32_t index1) {
   const uint32_t t = index1 - 1;
   uint32_t seg, o0, o1;
-  if (bs.hint_base == kNoHint) {
-    seg = t / 511u;  // all segments literal and full: 511 data bits each
-    const uint64_t c = *reinterpret_cast<const uint64_t*>(ix.cum + (uint64_t(bs.cum_base) + seg));
-    o0 = uint32_t(c);
-    o1 = uint32_t(c >> 32);
+  const bool uniform = bs.hint_base == kNoHint;
+  if (uniform) {
+    seg = t / 511u;  // all segments literal and full: 511 data bits each; counts ride in the segment's line
+    o0 = o1 = 0;
   } else {
     seg = ix.hint[uint64_t(bs.hint_base) + (t >> 9)];
     const uint64_t* cp = reinterpret_cast<const uint64_t*>(ix.cum + (uint64_t(bs.cum_base) + seg));
@@ -547,13 +546,18 @@ __device__ __forceinline__ RankResult bseq_rank_lane(const DevIndex& ix, const L
   }
   uint64_t w[kSegmentWords];
   {
-    const uint64_t slot = bs.hint_base == kNoHint ? bs.seg_base + seg : bs.seg_base + 2ull * seg;
+    const uint64_t slot = bs.seg_base + 2ull * seg;
     const ulonglong2* sp = reinterpret_cast<const ulonglong2*>(ix.segs + slot * kSegmentWords);
 #pragma unroll
     for (int k = 0; k < kSegmentWords / 2; k++) {
       const ulonglong2 v = sp[k];
       w[2 * k] = v.x;
       w[2 * k + 1] = v.y;
+    }
+    if (uniform) {
+      const uint64_t c = reinterpret_cast<const uint64_t*>(sp)[kSegmentWords];
+      o0 = uint32_t(c);
+      o1 = uint32_t(c >> 32);
     }
   }
 
@@ -801,9 +805,7 @@ __device__ __forceinline__ void rank_locate_segment(const DevIndex& ix, const La
   j.t = index1 - 1;
   if (bs.hint_base == kNoHint) {
     j.seg = j.t / 511u;
-    const uint64_t c = *reinterpret_cast<const uint64_t*>(ix.cum + (uint64_t(bs.cum_base) + j.seg));
-    j.o0 = uint32_t(c);
-    j.o1 = uint32_t(c >> 32);
+    j.o0 = j.o1 = 0;   // read from word 8 of the segment's line in rank_load_segment
   } else {
     j.seg = ix.hint[uint64_t(bs.hint_base) + (j.t >> 9)];
     const uint64_t* cp = reinterpret_cast<const uint64_t*>(ix.cum + (uint64_t(bs.cum_base) + j.seg));
@@ -817,17 +819,22 @@ __device__ __forceinline__ void rank_locate_segment(const DevIndex& ix, const La
       j.seg++;
     }
   }
-  j.slot = bs.hint_base == kNoHint ? bs.seg_base + j.seg : bs.seg_base + 2ull * j.seg;
+  j.slot = bs.seg_base + 2ull * j.seg;
   j.has_aux = bs.hint_base != kNoHint;
 }
 
-__device__ __forceinline__ void rank_load_segment(const DevIndex& ix, const RankJob& j, uint64_t (&w)[kSegmentWords]) {
+__device__ __forceinline__ void rank_load_segment(const DevIndex& ix, RankJob& j, uint64_t (&w)[kSegmentWords]) {
   const ulonglong2* sp = reinterpret_cast<const ulonglong2*>(ix.segs + j.slot * kSegmentWords);
 #pragma unroll
   for (int k = 0; k < kSegmentWords / 2; k++) {
     const ulonglong2 v = sp[k];
     w[2 * k] = v.x;
     w[2 * k + 1] = v.y;
+  }
+  if (!j.has_aux) {
+    const uint64_t c = reinterpret_cast<const uint64_t*>(sp)[kSegmentWords];
+    j.o0 = uint32_t(c);
+    j.o1 = uint32_t(c >> 32);
   }
 }
 
