@@ -70,6 +70,7 @@ def lib():
         L.femto_amd_kernel_time_enable.restype = None
         L.femto_amd_build_index.argtypes = [C.c_char_p, i32, vp, vp, vp, C.c_char_p, i32]
         L.femto_amd_build_index_from_sa.argtypes = [C.c_char_p, i32, vp, vp, vp, C.c_char_p, vp]
+        L.femto_amd_forward_steps.argtypes = [vp, i64, vp, vp, vp, vp]
         L.femto_amd_set_rank_mode.argtypes = [vp, i32]
         L.femto_amd_get_rank_mode.argtypes = [vp]
         L.femto_amd_bseq_encode.argtypes = [vp, i64, i32, vp, i64, C.POINTER(i64)]
@@ -164,6 +165,16 @@ class Index:
         chin = np.ascontiguousarray(ch_in, dtype=np.uint16) if ch_in is not None else None
         _check(lib().femto_amd_block_requests(self._h, n, _ptr(rows), _ptr(chin), _ptr(ch), _ptr(occ), _ptr(off)))
         return ch, occ, off
+
+    def forward_steps(self, rows):
+        """do_forward_query per row: (ch, LF^-1 row or -1, mark offset or -1)"""
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        n = len(rows)
+        ch = np.zeros(n, dtype=np.uint16)
+        nr = np.zeros(n, dtype=np.int64)
+        off = np.zeros(n, dtype=np.int64)
+        _check(lib().femto_amd_forward_steps(self._h, n, _ptr(rows), _ptr(ch), _ptr(nr), _ptr(off)))
+        return ch, nr, off
 
     def resolve_location(self, offset):
         d, o = C.c_int64(), C.c_int64()

@@ -657,6 +657,32 @@ int femto_amd_block_requests(femto_amd_index_t* ix, int64_t n, const int64_t* ro
   return FEMTO_AMD_OK;
 }
 
+int femto_amd_forward_steps(femto_amd_index_t* ix, int64_t n, const int64_t* rows, uint16_t* ch_out, int64_t* row_out,
+                            int64_t* off_out) {
+  if (!ix || (n && (!rows || !ch_out || !row_out || !off_out))) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  int rc = ensure_device(ix);
+  if (rc) return rc;
+  if (!ix->host.dir_regular) return set_err(FEMTO_AMD_ERR_INVALID, "forward steps need the derived mark-table directory");
+  for (int64_t i = 0; i < n; i++)
+    if (rows[i] < 0 || rows[i] >= ix->host.total_length) return set_err(FEMTO_AMD_ERR_PARAM, "row out of range");
+  if (n == 0) return FEMTO_AMD_OK;
+  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  if ((rc = ix->s_rows.reserve(size_t(n) * 8))) return rc;
+  if ((rc = ix->s_ch.reserve(size_t(n) * 4))) return rc;
+  if ((rc = ix->s_occ.reserve(size_t(n) * 8))) return rc;
+  if ((rc = ix->s_off.reserve(size_t(n) * 8))) return rc;
+  HIP_TRY(hipMemcpy(ix->s_rows.p, rows, size_t(n) * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(forward_kernel, dim3(uint32_t((n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, nullptr,
+                     ix->dev, n, ix->s_rows.as<int64_t>(), ix->s_ch.as<uint16_t>(), ix->s_occ.as<int64_t>(),
+                     ix->s_off.as<int64_t>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(ch_out, ix->s_ch.p, size_t(n) * 2, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(row_out, ix->s_occ.p, size_t(n) * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(off_out, ix->s_off.p, size_t(n) * 8, hipMemcpyDeviceToHost));
+  return FEMTO_AMD_OK;
+}
+
 int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode) {
   if (!ix || mode < 0 || mode > 2) return set_err(FEMTO_AMD_ERR_PARAM, "bad rank mode");
   if (mode >= 1 && !ix->host.dir_regular)

@@ -1133,4 +1133,174 @@ __global__ __launch_bounds__(256) void locate_kernel_flat(const DevIndex ix, con
   }
 }
 
+
+// =====================================================================================
+// LF^-1 (do_forward_query, src/main/server.c:2424-2565): not needed for exact locate results (the
+// backward walk always meets a mark first) but part of the reference's leaf interface
+// (BLOCK_REQUEST_ROW, wtree_select, bseq_select).  One lane per row, on femto's RAW tables
+// (A0/A1/AP group arrays, varbyte S sums, D segments in `image`), following the reference's own
+// select algorithm step for step.
+// =====================================================================================
+
+// bseq_select (src/main/wtree.c:770-885): occs[] such that occs[0]+occs[1] is the 1-based index of the
+// rank1'th occurrence of `bit`.
+__device__ __forceinline__ void bseq_select_lane(const uint8_t* __restrict__ image, const DevBseq bs, const uint32_t bit,
+                                                 const uint32_t rank1, uint32_t& out0, uint32_t& out1) {
+  const uint32_t rank = rank1 - 1;
+  const uint8_t* z = image + bs.off;
+  const uint32_t NG = bs.num_groups;
+  const uint8_t* A0 = z + 16;
+  const uint8_t* A1 = A0 + 4ull * NG;
+  const uint8_t* AP = A1 + 4ull * NG;
+  const uint8_t* S = AP + 4ull * NG;
+  const uint8_t* Ab = bit ? A1 : A0;
+  // bsearch_A0A1 on one array (wtree.c:609-629)
+  uint32_t a = 0, b = NG - 1, group;
+  if (rank >= ld_be32(Ab + 4ull * b)) group = b;
+  else {
+    while (b - a > 1) {
+      const uint32_t m = (a + b) / 2;
+      if (rank < ld_be32(Ab + 4ull * m)) b = m; else a = m;
+    }
+    group = a;
+  }
+  uint32_t o[2] = {ld_be32(A0 + 4ull * group), ld_be32(A1 + 4ull * group)};
+  const uint8_t* sp = S + ld_be32(AP + 4ull * group);
+  uint32_t segment = 0;
+  for (int j = 0; j < kGroupSize; j++) {  // decode_varbyte pairs (wtree_funcs.h:458)
+    uint32_t s[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      uint32_t val = 0;
+      for (int i = 0; i < 5; i++) {
+        const uint32_t w = *sp++;
+        val |= (w & 0x7fu) << (7 * i);
+        if (w & 0x80u) break;
+      }
+      s[k] = val;
+    }
+    const uint32_t ob = bit ? o[1] : o[0], sb = bit ? s[1] : s[0];
+    if (ob + sb <= rank) { o[0] += s[0]; o[1] += s[1]; segment++; }
+    else break;
+  }
+  segment += uint32_t(kGroupSize) * group;
+  uint64_t w[kSegmentWords];
+#pragma unroll
+  for (int k = 0; k < kSegmentWords; k++) {
+    const uint32_t wi = kSegmentWords * segment + uint32_t(k);
+    w[k] = wi < bs.total_words ? ld_be64(z + bs.d_off + 8ull * wi) : 0;
+  }
+  uint32_t o0 = o[0], o1 = o[1];
+  if (w[0] >> 63) {  // RLE: wtree.c:818-832
+    uint32_t rb = uint32_t(w[0] >> 62) & 1u;
+    int p = 2;
+    for (int it = 0; it < 512; it++) {
+      const int wi = p >> 6, sh = p & 63;
+      const uint64_t x = sel8(w, wi), y = sel8(w, wi + 1);
+      const uint64_t win = (x << sh) | (sh ? (y >> (64 - sh)) : 0);
+      if (!win) break;
+      const int k = __clzll(win);
+      if (k >= 32) break;
+      const int nb = 2 * k + 1;
+      const uint32_t v = uint32_t(win >> (64 - nb));
+      p += nb;
+      const uint32_t ob = bit ? o1 : o0;
+      if (bit != rb || ob + v <= rank) {
+        if (rb) o1 += v; else o0 += v;
+        rb ^= 1u;
+      } else {
+        if (bit) o1 = rank + 1; else o0 = rank + 1;  // o[bit] += 1 + rank - o[bit]
+        break;
+      }
+    }
+  } else {  // literal: wtree.c:833-880
+    int word_idx = 0;
+    for (; word_idx < kSegmentWords; word_idx++) {
+      const uint32_t c1 = uint32_t(__popcll(sel8(w, word_idx)));
+      uint32_t c0 = 64 - c1;
+      if (word_idx == 0) c0--;  // the is_rle flag bit
+      const uint32_t ob = bit ? o1 : o0, cb = bit ? c1 : c0;
+      if (ob + cb <= rank) { o0 += c0; o1 += c1; }
+      else break;
+    }
+    uint64_t tmp = sel8(w, word_idx);
+    if (word_idx == 0) tmp <<= 1;
+    for (int k = 0; k < 64; k++) {
+      const uint32_t rb = uint32_t(tmp >> 63);
+      const uint32_t ob = bit ? o1 : o0;
+      if (bit != rb || ob + 1 <= rank) {
+        if (rb) o1++; else o0++;
+      } else {
+        if (bit) o1 = rank + 1; else o0 = rank + 1;
+        break;
+      }
+      tmp <<= 1;
+    }
+  }
+  out0 = o0;
+  out1 = o1;
+}
+
+// do_forward_query for one row per lane: chr = F[row] (bsearch_C, index.c:1522), the bucket holding the
+// (row+1-C[chr])'th occurrence of chr (bsearch_block_occs + bsearch_bucket_occs, index.c:1571,1847, here one
+// search over the combined Occ bases), wtree_select (wtree.c:1150-1178) and the mark lookup at the row found.
+__global__ __launch_bounds__(256) void forward_kernel(const DevIndex ix, const int64_t n, const int64_t* __restrict__ rows,
+                                                      uint16_t* __restrict__ ch_out, int64_t* __restrict__ row_out,
+                                                      int64_t* __restrict__ off_out) {
+  const int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (item >= n) return;
+  const int64_t row = rows[item];
+  int lo = 0, hi = kAlphaSize;  // largest ch with C[ch] <= row (C[0] == 0)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (ix.C[mid] <= row) lo = mid; else hi = mid;
+  }
+  const uint32_t ch = uint32_t(lo);
+  int64_t new_row = -1, off = -1;
+  if (ch > uint32_t(kSEOF)) {
+    int64_t a = 0, b = ix.total_buckets;  // largest gb with base(gb, ch) <= row
+    while (b - a > 1) {
+      const int64_t mid = (a + b) >> 1;
+      if (ix.occ[mid * kAlphaSize + ch].base <= row) a = mid; else b = mid;
+    }
+    const int64_t gb = a;
+    const OccEntry oe = ix.occ[gb * kAlphaSize + ch];
+    const DevBucket bk = ix.buckets[gb];
+    uint32_t rank = uint32_t(row + 1 - oe.base);  // which occurrence of ch inside the bucket
+    const uint32_t count = rank;
+    const uint32_t code = oe.code;
+    if (code) {
+      const int len = 31 - __clz(int(code));
+      // root-to-leaf node indexes of ch's code, then select bottom-up
+      int path[20];
+      int cur = 0, seq = -1;
+      for (int i = 1; i <= len; i++) {
+        path[i - 1] = cur;
+        const DevNode nd = ix.nodes[bk.node_base + uint32_t(cur)];
+        const uint32_t bbit = (code >> (len - i)) & 1u;
+        const int c = bbit ? nd.child[1] : nd.child[0];
+        if (c < 0) { seq = -1 - c; break; }
+        cur = c;
+      }
+      for (int i = len; i >= 1; i--) {
+        const DevNode nd = ix.nodes[bk.node_base + uint32_t(path[i - 1])];
+        const uint32_t bbit = (code >> (len - i)) & 1u;
+        uint32_t s0, s1;
+        bseq_select_lane(ix.image, nd.bs, bbit, rank, s0, s1);
+        rank = s0 + s1;
+      }
+      new_row = gb * int64_t(ix.b_size) + int64_t(rank) - 1;
+      if (seq >= 0 && uint32_t(seq) < bk.n_in_use) {  // BLOCK_REQUEST_LOCATION at the row found
+        const LaneSeq sq = ix.lseqs[bk.seq_base + uint32_t(seq)];
+        const RankResult m = bseq_rank_lane(ix, sq.mark_table, count);
+        if (m.bit)
+          off = int64_t(read_bits(ix.image, sq.mark_array * 8 + (uint64_t(m.o1) - 1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
+      }
+    }
+  }
+  ch_out[item] = uint16_t(ch);
+  row_out[item] = new_row;
+  off_out[item] = off;
+}
+
 }  // namespace femto_amd

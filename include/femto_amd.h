@@ -132,6 +132,13 @@ int femto_amd_locate_walk_device(femto_amd_index_t* ix, int64_t npats, const int
 int femto_amd_block_requests(femto_amd_index_t* ix, int64_t n, const int64_t* rows, const uint16_t* ch_in,
                              uint16_t* ch_out, int32_t* occ_out, int64_t* off_out);
 
+/* One LF^-1 step per row (do_forward_query, src/main/server.c:2424; HDR_BSEARCH_C|HDR_BSEARCH_BLOCK_OCCS|
+ * HDR_FORWARD then BLOCK_REQUEST_ROW|BLOCK_REQUEST_LOCATION, src/main/index.c:1698,1915): ch_out = first
+ * character of the row, row_out = the row whose LF step leads here (-1 when ch <= SEOF), off_out = that
+ * row's mark offset or -1.  Exercises bseq_select / wtree_select (src/main/wtree.c:770,1150) on the GPU. */
+int femto_amd_forward_steps(femto_amd_index_t* ix, int64_t n, const int64_t* rows, uint16_t* ch_out,
+                            int64_t* row_out, int64_t* off_out);
+
 /* ---- kernel family ---------------------------------------------------------------------------- */
 /* mode 1 (default): one LANE per query; a rank reads one cumulative-count entry and one 64-byte
  * aligned segment slot from tables derived at load time (RLE segments also a 64-byte skip table).

@@ -145,6 +145,70 @@ void fo_bseq_rank(const unsigned char* z, int index1, int occs[2], int* bit_out,
   occs[0] = (int)o0; occs[1] = (int)o1; *bit_out = bit;
 }
 
+/* bseq_select, src/main/wtree.c:770-885 (+ bsearch_A0A1 with one array, :609-629): position of the
+   rank'th (1-based) occurrence of `bit`; returns occs[] like the reference (index = occs[0]+occs[1]) */
+void fo_bseq_select(const unsigned char* z, int bit, int rank1, int occs[2])
+{
+  unsigned int rank = (unsigned int)rank1 - 1;
+  int G = (int)be32(z + 4);
+  const unsigned char* A0 = z + 16;
+  const unsigned char* A1 = A0 + 4 * (size_t)G;
+  const unsigned char* AP = A1 + 4 * (size_t)G;
+  const unsigned char* S = AP + 4 * (size_t)G;
+  const unsigned char* Ab = bit ? A1 : A0;
+#define VAL(g) (be32(Ab + 4 * (size_t)(g)))
+  int a = 0, b = G - 1, group;
+  if (rank >= VAL(b)) group = b;
+  else {
+    while (b - a > 1) { int m = (a + b) / 2; if (rank < VAL(m)) b = m; else a = m; }
+    group = a;
+  }
+#undef VAL
+  unsigned int o[2];
+  o[0] = be32(A0 + 4 * (size_t)group);
+  o[1] = be32(A1 + 4 * (size_t)group);
+  const unsigned char* sums = S + be32(AP + 4 * (size_t)group);
+  int segment = 0, i = 0;
+  for (;;) {
+    unsigned int s[2];
+    i += fo_decode_varbyte(sums + i, &s[0]);
+    i += fo_decode_varbyte(sums + i, &s[1]);
+    if (o[bit] + s[bit] <= rank) { o[0] += s[0]; o[1] += s[1]; segment++; }
+    else break;
+  }
+  segment += GROUP_SIZE * group;
+  seg_t sg = load_segment(z, segment);
+  if (sg.w[0] >> 63) {
+    int rb = (int)((sg.w[0] >> 62) & 1);
+    int p = 2;
+    for (;;) {
+      unsigned int v;
+      p += fo_decode_gamma(seg_window(&sg, p), &v);
+      if (bit != rb || o[bit] + v <= rank) { o[rb] += v; rb = !rb; }
+      else { o[bit] += 1 + rank - o[bit]; break; }
+    }
+  } else {
+    int word_idx;
+    for (word_idx = 0; word_idx < SEGMENT_WORDS; word_idx++) {
+      unsigned int cnt[2];
+      cnt[1] = (unsigned)__builtin_popcountll(sg.w[word_idx]);
+      cnt[0] = 64 - cnt[1];
+      if (word_idx == 0) cnt[0]--;
+      if (o[bit] + cnt[bit] <= rank) { o[0] += cnt[0]; o[1] += cnt[1]; }
+      else break;
+    }
+    uint64_t tmp = word_idx < SEGMENT_WORDS ? sg.w[word_idx] : 0;
+    if (word_idx == 0) tmp <<= 1;
+    for (int k = 0; k < 64; k++) {
+      int rb = (int)(tmp >> 63);
+      if (bit != rb || o[bit] + 1 <= rank) o[rb] += 1;
+      else { o[bit] += 1 + rank - o[bit]; break; }
+      tmp <<= 1;
+    }
+  }
+  occs[0] = (int)o[0]; occs[1] = (int)o[1];
+}
+
 /* test helper: rank at every index 1..nbits -> out[3*i] = {occs0, occs1, bit} */
 void fo_bseq_rank_all(const unsigned char* z, int nbits, int64_t* out)
 {
@@ -211,6 +275,21 @@ void fo_wtree_rank(const unsigned char* wt, int index, int* leaf, int* count, fo
     index -= occs[!bit];
   }
   *leaf = node; *count = index;
+}
+
+/* wtree_select, src/main/wtree.c:1150-1178: index (1-based) of the count'th occurrence of `leaf` */
+int fo_wtree_select(const unsigned char* wt, int leaf, int count)
+{
+  int rank = count, node = leaf;
+  while (node > 1) {
+    int bit = node & 1;
+    node >>= 1;
+    const unsigned char* bs = wtree_node(wt, (unsigned)node);
+    int occs[2];
+    fo_bseq_select(bs, bit, rank, occs);
+    rank = occs[0] + occs[1];
+  }
+  return rank;
 }
 
 /* ------------------------------------------------------------------ L2 */
@@ -585,6 +664,39 @@ int fo_back_step(fo_index_t* ix, int64_t row, int64_t* new_row, int* ch_out, int
   *new_row = r; *ch_out = ch;
   if (c) c->n_lf++;
   return FO_OK;
+}
+
+/* do_forward_query, src/main/server.c:2424-2565: one LF^-1 step.  Header part
+   (HDR_BSEARCH_C | HDR_BSEARCH_BLOCK_OCCS | HDR_REQUEST_BLOCK_ROWS | HDR_FORWARD, index.c:1698-1765),
+   then block_request_row (index.c:1915-1966) + LOCATION at the row found. */
+int fo_forward_step(fo_index_t* ix, int64_t row, int64_t* new_row, int* ch_out, int64_t* offset, fo_counters_t* c)
+{
+  /* bsearch_C: largest ch with C[ch] <= row (bsearch_int64_ntoh_arr, src/utils/util.c:346) */
+  int ch = -1;
+  for (int k = 0; k < FO_ALPHA_SIZE; k++) if (fo_get_C(ix, k) <= row) ch = k; else break;
+  *ch_out = ch;
+  *new_row = -1;
+  *offset = -1;
+  if (ch <= FO_SEOF) return FO_OK;
+  int64_t occs = row + 1 - fo_get_C(ix, ch);
+  /* bsearch_block_occs: largest block with block_occs[ch][block] <= occs - 1 (index.c:1571) */
+  int64_t block = -1;
+  for (int64_t b = 0; b < ix->nblocks; b++) if (fo_get_block_occs(ix, ch, b) <= occs - 1) block = b; else break;
+  if (block < 0) return FO_ERR_INVALID;
+  int occs_in_block = (int)(occs - fo_get_block_occs(ix, ch, block));
+  dblock_t* blk = &ix->blocks[block];
+  /* bsearch_bucket_occs: largest bucket with bucket_occs < occs_in_block (index.c:1847) */
+  int bucket = -1;
+  for (int b = 0; b < blk->num_buckets; b++) if (get_bucket_occs(ix, blk, ch, b) <= occs_in_block - 1) bucket = b; else break;
+  if (bucket < 0) return FO_ERR_INVALID;
+  bucket_t* e = &blk->buckets[bucket];
+  if (!e->inUse[ch]) return 8; /* ERR_MISSING */
+  int count = occs_in_block - get_bucket_occs(ix, blk, ch, bucket);
+  int index = fo_wtree_select(blk->blob.data + e->wtree_offset, e->leaf[e->unseqToSeq[ch]], count);
+  int row_in_block = bucket * ix->b_size + index - 1;
+  *new_row = block * (int64_t)ix->block_size + row_in_block;
+  int chv = 0x1ff, occ = 0;
+  return fo_block_request(ix, block, 4, row_in_block, &chv, &occ, offset, c);
 }
 
 /* do_context_query with LOCATE_STRONG, no context (src/main/server.c:2627-2795): the reference

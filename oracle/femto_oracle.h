@@ -78,6 +78,10 @@ int  fo_locate(fo_index_t* ix, int64_t npats, const int32_t* plen, const uint16_
                const int64_t* starts, int max_occs_each, int32_t* noccs, int64_t* offsets_flat,
                int nthreads, fo_counters_t* c);
 /* single LF step with mark lookup: do_back_query, src/main/server.c:2228 */
+void fo_bseq_select(const unsigned char* z, int bit, int rank1, int occs[2]);
+int  fo_wtree_select(const unsigned char* wt, int leaf, int count);
+/* single LF^-1 step with mark lookup: do_forward_query, src/main/server.c:2424 */
+int  fo_forward_step(fo_index_t* ix, int64_t row, int64_t* new_row, int* ch, int64_t* offset, fo_counters_t* c);
 int  fo_back_step(fo_index_t* ix, int64_t row, int64_t* new_row, int* ch, int64_t* offset, fo_counters_t* c);
 
 #ifdef __cplusplus

@@ -67,6 +67,8 @@ def lib():
                                C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.fo_locate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.fo_forward_step.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.c_void_p]
+        L.fo_back_step.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.c_void_p]
         L.fo_bseq_rank_all.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.fo_decode_gamma.argtypes = [C.c_uint64, C.POINTER(C.c_uint)]
         L.fo_decode_varbyte.argtypes = [C.c_char_p, C.POINTER(C.c_uint)]
@@ -124,6 +126,22 @@ class Oracle:
         if rc:
             raise RuntimeError(f"fo_block_request -> {rc}")
         return c.value, occ.value, off.value
+
+    def forward_step(self, row):
+        """do_forward_query: (chr, new_row, offset)"""
+        nr, ch, off = C.c_int64(), C.c_int(), C.c_int64()
+        rc = lib().fo_forward_step(self.h, row, C.byref(nr), C.byref(ch), C.byref(off), None)
+        if rc:
+            raise RuntimeError(f"fo_forward_step -> {rc}")
+        return ch.value, nr.value, off.value
+
+    def back_step(self, row):
+        """do_back_query: (chr, new_row, offset)"""
+        nr, ch, off = C.c_int64(), C.c_int(), C.c_int64()
+        rc = lib().fo_back_step(self.h, row, C.byref(nr), C.byref(ch), C.byref(off), None)
+        if rc:
+            raise RuntimeError(f"fo_back_step -> {rc}")
+        return ch.value, nr.value, off.value
 
     def count_flat(self, plen, flat, starts, threads=1, counters=None):
         n = len(plen)
@@ -217,6 +235,16 @@ def ref_dump(index_path, tmp):
     off = np.frombuffer(raw, dtype=np.int64, count=n, offset=o)
     return dict(n=int(n), nblocks=int(nblocks), C=Carr.copy(), block_occs=bo.copy(), L=L.copy(),
                 occ=occ.copy(), off=off.copy())
+
+
+def ref_forward(index_path, tmp):
+    ref_tool("forward", index_path, tmp)
+    raw = open(tmp, "rb").read()
+    n = len(raw) // 18
+    ch = np.frombuffer(raw, dtype=np.uint16, count=n).copy()
+    nr = np.frombuffer(raw, dtype=np.int64, count=n, offset=2 * n).copy()
+    off = np.frombuffer(raw, dtype=np.int64, count=n, offset=10 * n).copy()
+    return ch, nr, off
 
 
 def ref_count(index_path, patterns, tmpdir):

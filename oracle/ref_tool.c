@@ -12,6 +12,7 @@
  *   count   : parallel_count  (src/main/femto.c:275)
  *   locate  : parallel_locate (src/main/femto.c:331)
  *   bench   : the same two calls, timed (wall clock of the batch call only)
+ *   forward : the leaf requests of do_forward_query (src/main/server.c:2424) for every row
  *   bseq    : bseq_construct_forcetype (src/main/wtree.c:365) -> encoded image
  *   flatten : flatten_index (src/main/index.c:2260)
  *
@@ -264,6 +265,52 @@ static int cmd_occs(int argc, char** argv)
   return 0;
 }
 
+/* forward <index> <out.bin>: for every row the two leaf requests of do_forward_query
+   (src/main/server.c:2424-2565): header HDR_BSEARCH_C|HDR_BSEARCH_BLOCK_OCCS|HDR_REQUEST_BLOCK_ROWS|HDR_FORWARD,
+   then block BLOCK_REQUEST_ROW|BLOCK_REQUEST_LOCATION.  out: u16 chr[n], i64 new_row[n] (-1 when chr <= SEOF), i64 offset[n] */
+static int cmd_forward(int argc, char** argv)
+{
+  if (argc < 2) return 2;
+  error_t err;
+  path_translator_t pt;
+  index_locator_t loc;
+  header_block_t hb;
+  memset(&pt, 0, sizeof pt);
+  err = path_translator_init(&pt);
+  if (err) die("path_translator_init", err);
+  err = path_translator_id_for_path(&pt, argv[0], &loc);
+  if (err) die("id_for_path", err);
+  err = open_header_block(&hb, &pt, loc);
+  if (err) die("open_header_block", err);
+  int64_t n = hb.hdr.total_length, nblocks = hb.hdr.number_of_blocks;
+  uint16_t* chr = malloc(2 * n);
+  int64_t* nrow = malloc(8 * n);
+  int64_t* off = malloc(8 * n);
+  data_block_t* blks = calloc(nblocks, sizeof(data_block_t));
+  for (int64_t b = 0; b < nblocks; b++) {
+    err = open_data_block(&blks[b], &pt, loc, b, 4);
+    if (err) die("open_data_block", err);
+  }
+  for (int64_t row = 0; row < n; row++) {
+    header_occs_request_t r; memset(&r, 0, sizeof r);
+    r.ch = INVALID_ALPHA; r.occs = row;   /* setup_header_occs_query(..., chr, row=0, occs=row) */
+    err = header_occs_request(&hb, HDR_BSEARCH_C | HDR_BSEARCH_BLOCK_OCCS | HDR_REQUEST_BLOCK_ROWS | HDR_FORWARD, &r);
+    if (err) die("header_occs_request", err);
+    chr[row] = r.ch; nrow[row] = -1; off[row] = -1;
+    if (r.ch <= ESCAPE_CODE_SEOF) continue;
+    block_request_t q; memset(&q, 0, sizeof q);
+    q.ch = r.ch; q.occs_in_block = (int) r.occs;
+    err = block_request(&blks[r.block_num], BLOCK_REQUEST_ROW | BLOCK_REQUEST_LOCATION, &q);
+    if (err) die("block_request ROW", err);
+    nrow[row] = r.row + q.row_in_block;
+    off[row] = q.offset;
+  }
+  FILE* out = fopen(argv[1], "wb");
+  fwrite(chr, 2, n, out); fwrite(nrow, 8, n, out); fwrite(off, 8, n, out);
+  fclose(out);
+  return 0;
+}
+
 static femto_server_t start_srv(int threads)
 {
   femto_server_t srv;
@@ -409,6 +456,7 @@ int main(int argc, char** argv)
   if (!strcmp(c, "count")) return cmd_count(argc - 2, argv + 2);
   if (!strcmp(c, "locate")) return cmd_locate(argc - 2, argv + 2);
   if (!strcmp(c, "bench")) return cmd_bench(argc - 2, argv + 2);
+  if (!strcmp(c, "forward")) return cmd_forward(argc - 2, argv + 2);
   if (!strcmp(c, "bseq")) return cmd_bseq(argc - 2, argv + 2);
   if (!strcmp(c, "flatten")) return cmd_flatten(argc - 2, argv + 2);
   fprintf(stderr, "unknown command %s\n", c);

@@ -82,6 +82,8 @@ def make_index_fixture(name, docs, params, seed, flatten=False, occ_chars=(), ma
         ipath = os.path.join(td, "index")
         d = po.ref_dump(ipath, os.path.join(td, "dump.bin"))
         gold = dict(C=d["C"], block_occs=d["block_occs"], L=d["L"], occ=d["occ"], off=d["off"])
+        # LF^-1 per row through the reference's forward leaf requests (do_forward_query, server.c:2424)
+        gold["fwd_ch"], gold["fwd_row"], gold["fwd_off"] = po.ref_forward(ipath, os.path.join(td, "fwd.bin"))
         for ch in occ_chars:
             po.ref_tool("occs", ipath, ch, os.path.join(td, "occs.bin"))
             gold[f"occs_ch{ch}"] = np.fromfile(os.path.join(td, "occs.bin"), dtype=np.int32)

@@ -64,6 +64,24 @@ def test_count_locate_match_reference_goldens(fixtures, gpu_ok, name, mode):
     ix.close()
 
 
+@pytest.mark.parametrize("name", INDEX_FIXTURES)
+def test_forward_steps_match_reference(fixtures, gpu_ok, name):
+    """do_forward_query (LF^-1 via bseq_select / wtree_select) for every row, against the leaf answers
+    captured from the reference; and LF(LF^-1(row)) == row."""
+    fx = fixtures(name)
+    g = fx.gold
+    ix = femto_amd.Index(fx.index, device=0)
+    n = ix.info.total_length
+    rows = np.arange(n, dtype=np.int64)
+    ch, nr, off = ix.forward_steps(rows)
+    assert np.array_equal(ch, g["fwd_ch"])
+    assert np.array_equal(nr, g["fwd_row"])
+    assert np.array_equal(off, g["fwd_off"])
+    valid = nr >= 0
+    lch, locc, _ = ix.block_requests(nr[valid])
+    assert np.array_equal(lch, ch[valid])     # L[LF^-1(r)] == F[r]
+
+
 def test_flattened_index(fixtures, gpu_ok):
     fx = fixtures("acgt48k")
     a = femto_amd.Index(fx.index, device=0)

@@ -137,6 +137,23 @@ def test_count_locate_brute_force(fixtures, name):
     o.close()
 
 
+@pytest.mark.parametrize("name", INDEX_FIXTURES)
+def test_forward_steps_match_reference(fixtures, name):
+    """do_forward_query's leaf requests (LF^-1: bsearch_C, bsearch_block_occs, block_request_row with
+    wtree_select / bseq_select, LOCATION) against the reference's answers for the same rows."""
+    fx = fixtures(name)
+    g = fx.gold
+    o = po.Oracle(fx.index)
+    n = o.total_length
+    step = 1 if n <= 6000 else 11
+    for row in list(range(0, n, step)) + [n - 1]:
+        assert o.forward_step(row) == (g["fwd_ch"][row], g["fwd_row"][row], g["fwd_off"][row]), row
+        ch, nr, _ = o.back_step(row)            # LF^-1(LF(row)) == row unless the walk stops at SEOF
+        if nr >= 0:
+            assert o.forward_step(nr)[1] == row
+    o.close()
+
+
 def test_flattened_index_equals_directory(fixtures):
     fx = fixtures("acgt48k")
     a, b = po.Oracle(fx.index), po.Oracle(fx.flat)
