@@ -73,6 +73,7 @@ def lib():
         L.femto_amd_forward_steps.argtypes = [vp, i64, vp, vp, vp, vp]
         L.femto_amd_set_rank_mode.argtypes = [vp, i32]
         L.femto_amd_get_rank_mode.argtypes = [vp]
+        L.femto_amd_flatten_index.argtypes = [C.c_char_p, C.c_char_p]
         L.femto_amd_bseq_encode.argtypes = [vp, i64, i32, vp, i64, C.POINTER(i64)]
         _lib = L
     return _lib
@@ -249,3 +250,8 @@ def build_index_from_sa(out_dir, docs, sa, params=None, infos=None):
     sa = np.ascontiguousarray(sa, dtype=np.int64)
     _check(lib().femto_amd_build_index_from_sa(os.fsencode(out_dir), n, ptrs, _ptr(lens), iarr,
                                                params.encode() if params else None, _ptr(sa)))
+
+
+def flatten_index(index_dir, out_path):
+    """flatten_index (src/main/index.c:2260): directory index -> single flattened file."""
+    _check(lib().femto_amd_flatten_index(os.fsencode(index_dir), os.fsencode(out_path)))

@@ -769,6 +769,13 @@ int femto_amd_build_index(const char* out_dir, int ndocs, const uint8_t* const* 
   return FEMTO_AMD_OK;
 }
 
+int femto_amd_flatten_index(const char* index_dir, const char* out_path) {
+  if (!index_dir || !out_path) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  Error e{0, ""};
+  int rc = flatten_index_dir(index_dir, out_path, &e);
+  return rc ? set_err(rc, e.msg) : FEMTO_AMD_OK;
+}
+
 /* test hook: bseq_construct_forcetype-compatible encoder (src/main/wtree.c:365) */
 int femto_amd_bseq_encode(const uint8_t* bits_msb_first, int64_t bitlen, int force_type, uint8_t* out, int64_t cap,
                           int64_t* out_len) {

@@ -531,6 +531,50 @@ void bseq_encode(const uint8_t* bits, int64_t bitlen, int force_type, std::vecto
   enc.encode(bits, bitlen, force_type, out);
 }
 
+// flatten_index, src/main/index.c:2260-2365: {u32 0xb1497dea, u32 6, i64 nblocks+1}, (nblocks+2) i64
+// start/end offsets, then the header block and every data block, each padded to the page size.
+int flatten_index_dir(const std::string& index_dir, const std::string& out_path, Error* e) {
+  auto slurp = [&](const std::string& path, std::vector<uint8_t>* out) -> int {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return fail(e, ERR_IO, "Could not open " + path);
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out->resize(size_t(n));
+    if (n && fread(out->data(), 1, size_t(n), f) != size_t(n)) { fclose(f); return fail(e, ERR_IO, "short read " + path); }
+    fclose(f);
+    return OK;
+  };
+  std::vector<uint8_t> hdr;
+  int rc = slurp(index_dir + "/00", &hdr);
+  if (rc) return rc;
+  if (hdr.size() < 88 || hdr[0] != 0xb1 || hdr[1] != 0x17 || hdr[2] != 0x7d || hdr[3] != 0xea) return fail(e, ERR_FORMAT, "Invalid block start");
+  uint64_t nblocks = 0;
+  for (int k = 0; k < 8; k++) nblocks = (nblocks << 8) | hdr[16 + size_t(k)];
+  const size_t page = 4096;  // get_page_size() on the platforms femto runs on (src/utils/page_utils.c)
+  std::vector<uint8_t> out;
+  put32(out, 0xb1497deau);
+  put32(out, 6);
+  put64(out, nblocks + 1);
+  for (uint64_t b = 0; b < nblocks + 2; b++) put64(out, 0);
+  while (out.size() % page) out.push_back(0);
+  for (uint64_t b = 0; b < nblocks + 1; b++) {
+    std::vector<uint8_t> blk;
+    if (b == 0) blk = hdr;
+    else {
+      char name[64];
+      snprintf(name, sizeof name, "/%02llx", (unsigned long long)b);
+      if ((rc = slurp(index_dir + name, &blk))) return rc;
+    }
+    const uint64_t start = out.size();
+    out.insert(out.end(), blk.begin(), blk.end());
+    while (out.size() % page) out.push_back(0);
+    set64(out, 16 + 8 * size_t(b), start);
+    set64(out, 16 + 8 * (size_t(b) + 1), out.size());
+  }
+  return write_file(out_path, out, e);
+}
+
 int build_index_from_sa(const std::string& out_dir, const std::vector<Document>& docs, const BuildParams& params,
                         const int64_t* sa, int nthreads, Error* e) {
   if (docs.empty()) return fail(e, ERR_PARAM, "an index needs at least one document");

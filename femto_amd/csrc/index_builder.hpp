@@ -39,6 +39,9 @@ void bseq_encode(const uint8_t* bits_msb_first, int64_t bitlen, int force_type, 
 int build_index_from_sa(const std::string& out_dir, const std::vector<Document>& docs, const BuildParams& params,
                         const int64_t* sa, int nthreads, Error* e);
 
+// flatten_index (src/main/index.c:2260): directory index -> single flattened file, byte-identical
+int flatten_index_dir(const std::string& index_dir, const std::string& out_path, Error* e);
+
 // GPU suffix sort of the prepared text (suffix_sort.hip); sa_out has text.size() entries.
 int gpu_suffix_sort(const std::vector<uint16_t>& text, int device, std::vector<int64_t>* sa_out, Error* e);
 

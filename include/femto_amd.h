@@ -169,6 +169,10 @@ int femto_amd_build_index_from_sa(const char* out_dir, int ndocs, const uint8_t*
                                   const int64_t* doc_lens, const char* const* doc_infos,
                                   const char* params, const int64_t* sa);
 
+/* flatten_index (src/main/index.c:2260; the femto_flatten tool): directory index -> one flattened file that
+ * both femto and femto_amd_open read; byte-identical to the reference's output. */
+int femto_amd_flatten_index(const char* index_dir, const char* out_path);
+
 /* Test hook: encodes one binary sequence exactly as bseq_construct_forcetype does
  * (src/main/wtree.c:365; force_type -1 literal only, 0 automatic, 1 RLE only).  out may be NULL to size. */
 int femto_amd_bseq_encode(const uint8_t* bits_msb_first, int64_t bitlen, int force_type, uint8_t* out,

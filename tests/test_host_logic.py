@@ -131,3 +131,11 @@ def test_builder_parameter_validation(tmp_path):
     for bad in ("block_size=10,bucket_size=4", "bucket_size=0", "bogus=1", "mark_period=0"):
         with pytest.raises(femto_amd.FemtoAmdError):
             femto_amd.build_index_from_sa(str(tmp_path / "x"), docs, sa, params=bad)
+
+
+def test_flatten_is_byte_identical_to_reference(fixtures, tmp_path):
+    fx = fixtures("acgt48k")
+    out = str(tmp_path / "mine.flat")
+    femto_amd.flatten_index(fx.index, out)
+    assert filecmp.cmp(fx.flat, out, shallow=False)
+    assert femto_amd.Index(out, device=-1).info.total_length == femto_amd.Index(fx.index, device=-1).info.total_length
