@@ -290,6 +290,7 @@ def main():
                 "kernel_ms": k_ms, "launches_timed": cnt_n,
                 "count_kernel_ms": cnt_ms, "locate_kernel_ms": loc_ms,
                 "algorithmic_bytes_per_launch": alg_launch,
+                "occ_per_s": k_c["n_occ"] * scale / (k_ms * 1e-3), "bseq_rank_per_s": k_c["n_rank"] * scale / (k_ms * 1e-3),
                 "per_pattern": {"bseq_rank": k_c["n_rank"] / sample, "occ": k_c["n_occ"] / sample,
                                 "S_bytes_per_rank": k_c["s_bytes"] / max(1, k_c["n_rank"]),
                                 "bytes": alg(k_c) / sample},

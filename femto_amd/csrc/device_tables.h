@@ -15,9 +15,7 @@
 //                  src/main/index.c:290-300) of ch in that bucket, 0 if ch does not occur
 //   seqs[]       : one DevSeq per in-use character per bucket: its alpha code, its mark table
 //                  (a bseq) and its mark array
-//   dir[]        : 24-byte block-directory entries, one per 512 bits of every binary sequence
-//                  (wavelet nodes and mark tables): the varbyte S sums and the A0/A1/AP group
-//                  tables re-expressed so that one lane finds a rank's segment with ONE load
+//   segs/cum/hint: the lane kernels' view of every binary sequence (see LaneBseq below)
 #pragma once
 #include <stdint.h>
 
@@ -33,18 +31,6 @@ struct DevBseq {            // one encoded binary sequence (src/main/wtree_funcs
   uint32_t num_groups;      // NUM_GROUPS
   uint32_t d_off;           // D_OFFSET (relative to off)
   uint32_t total_words;     // TOTAL_SEGMENT_WORDS
-  uint32_t dir_base;        // first DirEntry of this sequence in DevIndex::dir (block directory)
-};
-
-// Block directory (derived at load time from the sequence's own A0/A1/AP/S tables): entry p
-// describes the segment that holds bit position 512*p of the sequence.  Every segment but the
-// last of a sequence stores >= 511 bits (literal segments are topped up to 511 bits, RLE is only
-// chosen once >= 511 bits are stored: save_run, src/main/wtree.c:240-290), so a 512-bit block
-// overlaps at most two segments and bit t = 512*p + r lies in `seg` or in `seg + 1`.
-struct DirEntry {           // 24 bytes
-  uint32_t o0, o1;          // zeros / ones before segment `seg`
-  uint32_t s0, s1;          // zeros / ones inside segment `seg`
-  uint32_t seg;             // segment number
   uint32_t pad;
 };
 
@@ -118,7 +104,6 @@ struct DevIndex {           // passed by value to kernels
   const int64_t* occ_base;  // [gb*261 + ch]
   const uint32_t* leaf_code;// [gb*261 + ch]
   const int64_t* C;         // [262]; C[261] == total_length (get_C, src/main/index.c:1545)
-  const DirEntry* dir;      // block directories of all sequences (unused by the current kernels)
   const uint64_t* segs;     // 64-byte aligned native-endian segment slots (8 words each)
   const CumEntry* cum;
   const uint32_t* hint;

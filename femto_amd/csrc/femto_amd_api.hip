@@ -110,7 +110,6 @@ struct femto_amd_index {
   int mode = 1;  // 1: lane-per-query kernels (default); 2: flattened persistent-lane kernels; 0: wavefront-cooperative raw A/S/D walk
   int num_cus = 256;
   int blocks_per_cu_override = 0;
-  int queries_per_lane = 1;
   DevIndex dev{};
   int64_t table_bytes = 0;
   // scratch for the host-pointer API and the locate plan
@@ -169,19 +168,13 @@ int launch_count(femto_amd_index* ix, int64_t npats, const int32_t* d_plen, cons
     int64_t lblocks = (npats + kBlockThreads - 1) / kBlockThreads;
     {  // persistent grid: exactly the resident blocks, lanes stride over the batch
       int per_cu = 0;
-      hipError_t oe = ix->queries_per_lane >= 2
-                          ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, count_kernel_flat<2>, kBlockThreads, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, count_kernel_flat<1>, kBlockThreads, 0);
+      hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, count_kernel_flat<1>, kBlockThreads, 0);
       if (oe != hipSuccess || per_cu < 1) per_cu = 1;
       int64_t cap = int64_t(ix->num_cus) * per_cu;
       if (ix->blocks_per_cu_override > 0) cap = int64_t(ix->num_cus) * ix->blocks_per_cu_override;
       if (lblocks > cap) lblocks = cap;
     }
-    if (ix->queries_per_lane >= 2)
-      hipLaunchKernelGGL((count_kernel_flat<2>), dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats,
-                         d_plen, d_pats, d_starts, d_first, d_last, ix->d_err);
-    else
-      hipLaunchKernelGGL((count_kernel_flat<1>), dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats,
+    hipLaunchKernelGGL((count_kernel_flat<1>), dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats,
                          d_plen, d_pats, d_starts, d_first, d_last, ix->d_err);
   } else if (ix->mode == 1) {
     const int64_t lblocks = (npats + kBlockThreads - 1) / kBlockThreads;
@@ -354,7 +347,6 @@ int femto_amd_open(const char* index_path, int device, femto_amd_index_t** out) 
       d.occ_base = ix->d_occ_base;
       d.leaf_code = ix->d_leaf_code;
       d.C = ix->d_C;
-      d.dir = nullptr;
       d.segs = ix->d_segs;
       d.cum = ix->d_cum;
       d.hint = ix->d_hint;
@@ -371,7 +363,6 @@ int femto_amd_open(const char* index_path, int device, femto_amd_index_t** out) 
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         ix->num_cus = prop.multiProcessorCount;
         if (const char* so = getenv("FEMTO_AMD_SORT")) { ix->sort_queries = atoi(so) != 0; ix->sort_levels = atoi(so) >= 2 ? 2 : 1; }
-        if (const char* ql = getenv("FEMTO_AMD_QUERIES_PER_LANE")) ix->queries_per_lane = atoi(ql);
         if (const char* pb = getenv("FEMTO_AMD_BLOCKS_PER_CU")) ix->blocks_per_cu_override = atoi(pb);
       }
       ix->mode = h.dir_regular ? 1 : 0;

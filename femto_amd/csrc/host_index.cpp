@@ -98,19 +98,16 @@ struct BitReader {  // MSB-first, like bsR24 (src/utils/buffer_funcs.h:136)
   }
 };
 
-// Re-expresses one sequence's A0/A1/AP + varbyte S tables (src/main/wtree_funcs.h:294-358) as a
-// block directory: for every 512-bit block the segment holding its first bit, with the
-// cumulative and in-segment (zeros, ones).
+// Re-expresses one sequence's A0/A1/AP + varbyte S tables (src/main/wtree_funcs.h:294-358) as the lane
+// kernels' tables (device_tables.h): 128-byte segment lines, per-segment cumulative (zeros, ones), the
+// per-block segment hint and the RLE skip tables.
 struct LaneTables {
   std::vector<uint64_t>* segs;
   std::vector<CumEntry>* cum;
   std::vector<uint32_t>* hint;
 };
 
-int build_directory(const std::vector<uint8_t>& img, DevBseq* bs, std::vector<DirEntry>* dir, bool* regular, Error* e,
-                    LaneTables* lt = nullptr, LaneBseq* lane = nullptr) {
-  bs->dir_base = 0;
-  (void)dir;
+int build_lane_tables(const std::vector<uint8_t>& img, DevBseq* bs, bool* regular, Error* e, LaneTables* lt, LaneBseq* lane) {
   const size_t cum0 = lt ? lt->cum->size() : 0;
   const size_t hint0 = lt ? lt->hint->size() : 0;
   bool uniform = true;
@@ -240,7 +237,7 @@ int parse_bseq(const std::vector<uint8_t>& img, uint64_t abs, uint64_t limit, De
   out->num_groups = be32(z + 4);
   out->total_words = be32(z + 8);
   out->d_off = be32(z + 12);
-  out->dir_base = 0;
+  out->pad = 0;
   if (be32(z) != 0) return fail(e, ERR_FORMAT, "bseq header word 0 not zero");
   uint64_t need_dir = 16 + 12ull * out->num_groups;
   if (out->d_off < need_dir || abs + out->d_off + 8ull * out->total_words > limit)
@@ -458,7 +455,7 @@ int HostIndex::load(const std::string& path, Error* e) {
           rc = parse_bseq(image, boff + wt_off + off, blimit, &nd.bs, e);
           if (rc) return rc;
           LaneTables lt{&segs, &cum, &hint};
-          rc = build_directory(image, &nd.bs, &dir, &dir_regular, e, &lt, &ln.bs);
+          rc = build_lane_tables(image, &nd.bs, &dir_regular, e, &lt, &ln.bs);
           if (rc) return rc;
         }
         for (int bit = 0; bit < 2; bit++) {
@@ -492,7 +489,7 @@ int HostIndex::load(const std::string& path, Error* e) {
         LaneSeq lsq;
         memset(&lsq, 0, sizeof lsq);
         LaneTables lt{&segs, &cum, &hint};
-        rc = build_directory(image, &sq.mark_table, &dir, &dir_regular, e, &lt, &lsq.mark_table);
+        rc = build_lane_tables(image, &sq.mark_table, &dir_regular, e, &lt, &lsq.mark_table);
         if (rc) return rc;
         uint32_t aoff = be32(d + ma_off + 4 * size_t(s));
         sq.mark_array = boff + ma_off + aoff;

@@ -32,7 +32,6 @@ struct HostIndex {
   std::vector<DevNode> nodes;
   std::vector<DevBucket> buckets;
   std::vector<DevSeq> seqs;
-  std::vector<DirEntry> dir;            // block directories (see device_tables.h)
   std::vector<uint64_t> segs;           // 64-byte aligned native-endian segment slots
   std::vector<CumEntry> cum;
   std::vector<uint32_t> hint;

@@ -473,14 +473,14 @@ __global__ __launch_bounds__(256) void block_request_kernel(const DevIndex ix, c
 
 
 // =====================================================================================
-// Lane-per-item kernels over the block directory (device_tables.h: DirEntry).
+// Lane-per-item kernels over the derived segment lines (device_tables.h: LaneBseq) -- the default.
 //
 // Measured on MI355X (profiles/r01_v1_*): the wavefront-cooperative walk above spends ~190 VALU
 // wave-instructions per rank (cross-lane scans/shuffles) and is VALU-issue + latency bound at 5 %
-// of the HBM roofline.  Here every LANE owns a whole query: a rank is one 8-byte cumulative-count
-// load (which segment, zeros/ones before it) plus the 64-byte aligned segment slot itself, a few
-// instructions per rank per lane once amortised over the 64 lanes of a wavefront, so the kernel is
-// limited by the memory system (random 64-byte segment reads), which is what the roofline prices.
+// of the HBM roofline.  Here every LANE owns a whole query: a rank on an all-literal sequence is ONE
+// 128-byte line (segment words + the zeros/ones before it), a few instructions per rank per lane once
+// amortised over the 64 lanes of a wavefront, so the kernel is limited by the memory system
+// (scattered 128-byte lines), which is what the roofline prices.
 // Lanes of a wavefront start their patterns together, so the early backward-search steps (few
 // distinct ranges) hit the same cache lines; measured, this beats the flattened variant below.
 // =====================================================================================
