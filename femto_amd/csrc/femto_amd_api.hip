@@ -19,8 +19,8 @@ using namespace femto_amd;
 namespace femto_amd {
 size_t query_sort_temp_bytes(int64_t npats);
 hipError_t query_sort(int64_t npats, const int32_t* d_plen, const uint16_t* d_pats, const int64_t* d_starts,
-                      uint64_t* keys, uint64_t* keys2, uint32_t* idx, uint32_t* idx2, void* tmp, size_t tmp_bytes,
-                      hipStream_t stream, int levels);
+                      const uint8_t* d_dense, int bits, uint64_t* keys, uint64_t* keys2, uint32_t* idx, uint32_t* idx2,
+                      void* tmp, size_t tmp_bytes, hipStream_t stream);
 }
 
 namespace {
@@ -116,8 +116,9 @@ struct femto_amd_index {
   DeviceBuffer s_plen, s_pats, s_starts, s_first, s_last, s_noccs, s_noccs64, s_out_starts, s_offsets, s_scan[3];
   DeviceBuffer s_rows, s_ch, s_occ, s_off;
   DeviceBuffer s_keys, s_keys2, s_idx, s_idx2, s_sorttmp;
-  bool sort_queries = true;   // FEMTO_AMD_SORT=0 disables, =2 sorts on 16 symbols
-  int sort_levels = 1;
+  bool sort_queries = true;   // FEMTO_AMD_SORT=0 disables
+  uint8_t* d_dense = nullptr;  // alpha code -> dense sort digit (characters present in the text)
+  int dense_bits = 8;
   int64_t sort_min = 4096;
   bool timing = false;
   KernelTimer t_count, t_locate;
@@ -188,8 +189,9 @@ int launch_count(femto_amd_index* ix, int64_t npats, const int32_t* d_plen, cons
       if ((rc = ix->s_idx2.reserve(size_t(npats) * 4))) return rc;
       const size_t tb = query_sort_temp_bytes(npats);
       if ((rc = ix->s_sorttmp.reserve(tb ? tb : 16))) return rc;
-      HIP_TRY(query_sort(npats, d_plen, d_pats, d_starts, ix->s_keys.as<uint64_t>(), ix->s_keys2.as<uint64_t>(),
-                         ix->s_idx.as<uint32_t>(), ix->s_idx2.as<uint32_t>(), ix->s_sorttmp.p, tb, stream, ix->sort_levels));
+      HIP_TRY(query_sort(npats, d_plen, d_pats, d_starts, ix->d_dense, ix->dense_bits, ix->s_keys.as<uint64_t>(),
+                         ix->s_keys2.as<uint64_t>(), ix->s_idx.as<uint32_t>(), ix->s_idx2.as<uint32_t>(), ix->s_sorttmp.p, tb,
+                         stream));
       perm = ix->s_idx2.as<uint32_t>();
     }
     if (ix->timing) HIP_TRY(hipEventRecord(e0, stream));
@@ -337,6 +339,16 @@ int femto_amd_open(const char* index_path, int device, femto_amd_index_t** out) 
       if ((r = upload(&ix->d_lnodes, h.lnodes, &ix->table_bytes))) return r;
       if ((r = upload(&ix->d_lseqs, h.lseqs, &ix->table_bytes))) return r;
       if ((r = upload(&ix->d_occ, h.occ, &ix->table_bytes))) return r;
+      {  // dense sort digits: characters with C[ch+1] > C[ch] occur in the text
+        std::vector<uint8_t> dense(512, 0);
+        int sigma = 0;
+        for (int ch = 0; ch < kAlphaSize; ch++)
+          if (h.C[size_t(ch) + 1] > h.C[size_t(ch)]) dense[size_t(ch)] = uint8_t(++sigma > 255 ? 255 : sigma);
+        int bits = 1;
+        while ((1 << bits) <= (sigma > 255 ? 255 : sigma)) bits++;
+        ix->dense_bits = bits;
+        if ((r = upload(&ix->d_dense, dense, &ix->table_bytes))) return r;
+      }
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_err), sizeof(int)));
       HIP_TRY(hipMemset(ix->d_err, 0, sizeof(int)));
       DevIndex& d = ix->dev;
@@ -362,7 +374,7 @@ int femto_amd_open(const char* index_path, int device, femto_amd_index_t** out) 
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         ix->num_cus = prop.multiProcessorCount;
-        if (const char* so = getenv("FEMTO_AMD_SORT")) { ix->sort_queries = atoi(so) != 0; ix->sort_levels = atoi(so) >= 2 ? 2 : 1; }
+        if (const char* so = getenv("FEMTO_AMD_SORT")) ix->sort_queries = atoi(so) != 0;
         if (const char* pb = getenv("FEMTO_AMD_BLOCKS_PER_CU")) ix->blocks_per_cu_override = atoi(pb);
       }
       ix->mode = h.dir_regular ? 1 : 0;
@@ -403,6 +415,7 @@ void femto_amd_close(femto_amd_index_t* ix) {
     (void)hipFree(ix->d_lseqs);
     (void)hipFree(ix->d_occ);
     (void)hipFree(ix->d_err);
+    (void)hipFree(ix->d_dense);
     for (DeviceBuffer* b : {&ix->s_plen, &ix->s_pats, &ix->s_starts, &ix->s_first, &ix->s_last, &ix->s_noccs,
                             &ix->s_noccs64, &ix->s_out_starts, &ix->s_offsets, &ix->s_scan[0], &ix->s_scan[1],
                             &ix->s_scan[2], &ix->s_rows, &ix->s_ch, &ix->s_occ, &ix->s_off, &ix->s_keys, &ix->s_keys2, &ix->s_idx,

@@ -663,7 +663,7 @@ __device__ __forceinline__ int64_t c_plus_occ_lane(const DevIndex& ix, uint32_t 
 // do_string_query (src/main/server.c:713-946): one LANE per pattern
 // `perm` (optional): lane j processes pattern perm[j] -- the batch ordered by pattern suffix
 // (query_sort.hip) so that neighbouring lanes share the rows of their first steps.
-__global__ __launch_bounds__(256) void count_kernel_lane(const DevIndex ix, const int64_t npats,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void count_kernel_lane(const DevIndex ix, const int64_t npats,
                                                          const int32_t* __restrict__ plen,
                                                          const uint16_t* __restrict__ pats,
                                                          const int64_t* __restrict__ starts,
