@@ -553,6 +553,15 @@ int femto_amd_locate_flat(femto_amd_index_t* ix, int64_t npats, const int32_t* p
                                     ix->s_out_starts.as<int64_t>(), nullptr);
   if (rc) return rc;
   if ((rc = check_err_flag(ix, nullptr))) return rc;
+  if (max_occs_each == 0 && npats) {
+    // The reference fails here: a pattern with more than one match is clamped to an empty locate range and
+    // setup_locate_range rejects it (src/main/server.c:4411-4421 -> ERR_PARAM); one match is returned whole.
+    std::vector<int64_t> f((size_t(npats))), l((size_t(npats)));
+    HIP_TRY(hipMemcpy(f.data(), ix->s_first.p, size_t(npats) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(l.data(), ix->s_last.p, size_t(npats) * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < npats; i++)
+      if (l[size_t(i)] - f[size_t(i)] > 0) return set_err(FEMTO_AMD_ERR_PARAM, "max_occs_each == 0 with a multi-match pattern: Error during query processing");
+  }
   HIP_TRY(hipMemcpy(&total, ix->s_out_starts.as<int64_t>() + npats, 8, hipMemcpyDeviceToHost));
   if (total_out) *total_out = total;
   if (noccs && npats) HIP_TRY(hipMemcpy(noccs, ix->s_noccs.p, size_t(npats) * 4, hipMemcpyDeviceToHost));

@@ -11,7 +11,8 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 # built by the reference with index_documents(map=NULL): our writer reproduces them byte for byte
-WRITER_FIXTURES = ["acgt48k", "eng2doc", "counter400_small", "counter400_default", "runs3doc", "construct_kat"]
+WRITER_FIXTURES = ["acgt48k", "eng2doc", "counter400_small", "counter400_default", "runs3doc", "construct_kat",
+                   "b1000", "bytes256"]
 # + one built WITH a document map (buckets carry document chunks, the production femto_index layout)
 INDEX_FIXTURES = WRITER_FIXTURES + ["chunks2doc"]
 

@@ -179,6 +179,15 @@ def main():
     cd = [rng2.choice(np.frombuffer(b"abcdefgh \n", dtype=np.uint8), k).astype(np.uint8) for k in (3000, 2500)]
     make_index_fixture("chunks2doc", cd, "block_size=2048,bucket_size=2048,chunk_size=256,mark_period=10", seed=107,
                        occ_chars=(5 + ord("a"),), with_map=True)
+    # the reference tests' "big buckets" parameter set (index_test_funcs.c:55-65): bucket size NOT a power of two
+    rng3 = np.random.Generator(np.random.PCG64(79))
+    b1000 = np.concatenate([tg.t_counter(3000), rng3.choice(np.frombuffer(b"abcdef", dtype=np.uint8), 4500)]).astype(np.uint8)
+    make_index_fixture("b1000", [b1000], "block_size=10000,bucket_size=1000,chunk_size=1000,mark_period=20", seed=108,
+                       occ_chars=(5 + ord("a"), 5 + ord("f")))
+    # all 256 byte values (deep Huffman codes, every inUse16 group set) in two documents
+    by = rng3.integers(0, 256, 12000, dtype=np.uint8)
+    make_index_fixture("bytes256", [by[:7000], by[7000:]], "block_size=8192,bucket_size=4096,mark_period=9", seed=109,
+                       occ_chars=(5, 260, 5 + 128))
     make_bseq_kat()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden dir bytes:", tot)

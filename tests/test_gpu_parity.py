@@ -138,6 +138,25 @@ def test_invalid_pattern_character_is_param_error(fixtures, gpu_ok):
     assert l[0] >= f[0]
 
 
+def test_max_occs_zero_mirrors_reference(fixtures, gpu_ok):
+    """parallel_locate with max_occs_each == 0: the reference returns a single match whole but fails with
+    ERR_PARAM as soon as one pattern has more than one match (observed with oracle/_ref: "invalid
+    parameters: Error during query processing", femto.c:204)."""
+    fx = fixtures("acgt48k")
+    ix = femto_amd.Index(fx.index, device=0)
+    text = fx.docs[0]
+    single = tg.to_alpha(text[1000:1024])          # a 24-mer of a 48 KiB random text: exactly one match
+    f, l = ix.count([single])
+    assert l[0] - f[0] == 0
+    noccs, offs = ix.locate([single], 0)
+    assert noccs[0] == 1 and offs[0] == 1000
+    with pytest.raises(femto_amd.FemtoAmdError) as e:
+        ix.locate([tg.to_alpha(text[:2])], 0)         # a 2-mer: many matches
+    assert e.value.code == 3
+    with pytest.raises(femto_amd.FemtoAmdError):
+        ix.locate([single], -1)
+
+
 def _random_index(tmp_path, text, params, name):
     out = str(tmp_path / name)
     femto_amd.build_index(out, [text], params=params, infos=[name], device=0)
