@@ -226,3 +226,58 @@ def test_full_text_lf_walk_recovers_every_offset(tmp_path, gpu_ok):
     ch, _, _ = ix.block_requests(np.arange(n, dtype=np.int64))
     prepared = np.concatenate([text.astype(np.uint16) + 5, [2]])
     assert np.array_equal(ch, prepared[offs - 1])           # SA[row]==0 wraps to the final SEOF
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_indexes_vs_oracle(tmp_path, gpu_ok, seed):
+    """Randomised parity sweep: random alphabets / run structure / document splits / index parameters,
+    index built on the GPU (suffix sorter + writer), then count, locate (random clamps), leaf requests and
+    LF^-1 steps compared with the oracle, in every kernel mode."""
+    rng = np.random.Generator(np.random.PCG64(9000 + seed))
+    n = int(rng.integers(2000, 60000))
+    sigma = int(rng.choice([1, 2, 3, 4, 8, 20, 64, 200, 256]))
+    alphabet = rng.choice(256, sigma, replace=False).astype(np.uint8)
+    if rng.random() < 0.5:      # skewed, run-heavy text (RLE segments, single-character buckets)
+        runs = rng.geometric(1.0 / float(rng.choice([2, 20, 400])), n)
+        syms = alphabet[rng.integers(0, sigma, n)]
+        text = np.repeat(syms, runs)[:n]
+    else:
+        text = alphabet[rng.integers(0, sigma, n)]
+    ndocs = int(rng.integers(1, 5))
+    cuts = sorted(rng.choice(np.arange(1, len(text)), ndocs - 1, replace=False)) if ndocs > 1 else []
+    docs = np.split(text, cuts)
+    b_size = int(rng.choice([64, 100, 1000, 4096, 1 << 20]))
+    block = b_size * int(rng.choice([1, 2, 5]))
+    mark = int(rng.integers(1, 40))
+    params = f"block_size={block},bucket_size={b_size},chunk_size={b_size},mark_period={mark}"
+    path = str(tmp_path / f"rnd{seed}")
+    femto_amd.build_index(path, docs, params=params, infos=[f"d{i}" for i in range(len(docs))], device=0)
+    o = po.Oracle(path)
+    ix = femto_amd.Index(path, device=0)
+    nrows = ix.info.total_length
+    assert nrows == o.total_length == len(text) + len(docs)
+    pats = []
+    for _ in range(300):
+        l = int(rng.integers(0, 30))
+        if rng.random() < 0.6 and len(text) > l:
+            s0 = int(rng.integers(0, len(text) - l + 1))
+            pats.append(tg.to_alpha(text[s0:s0 + l]))
+        else:
+            pats.append(tg.to_alpha(rng.integers(0, 256, l).astype(np.uint8)))
+    plen, flat, starts = femto_amd.flatten(pats)
+    of, ol = o.count_flat(plen, flat, starts)
+    mo = int(rng.integers(1, 50))
+    on, oo = o.locate_flat(plen, flat, starts, mo)
+    rows = rng.integers(0, nrows, 500).astype(np.int64)
+    want_fw = [o.forward_step(int(r)) for r in rows]
+    want_bw = [o.block_request(int(r), 7) for r in rows]
+    for mode in MODES:
+        ix.set_rank_mode(mode)
+        f, l_ = ix.count_flat(plen, flat, starts)
+        assert np.array_equal(f, of) and np.array_equal(l_, ol), (seed, mode, params)
+        nn, offs = ix.locate_flat(plen, flat, starts, mo)
+        assert np.array_equal(nn, on) and np.array_equal(offs, oo), (seed, mode, params)
+        ch, occ, off = ix.block_requests(rows)
+        assert [(int(a), int(b), int(c)) for a, b, c in zip(ch, occ, off)] == want_bw, (seed, mode)
+    ch, nr, off = ix.forward_steps(rows)
+    assert [(int(a), int(b), int(c)) for a, b, c in zip(ch, nr, off)] == want_fw, seed
