@@ -281,3 +281,38 @@ def test_random_indexes_vs_oracle(tmp_path, gpu_ok, seed):
         assert [(int(a), int(b), int(c)) for a, b, c in zip(ch, occ, off)] == want_bw, (seed, mode)
     ch, nr, off = ix.forward_steps(rows)
     assert [(int(a), int(b), int(c)) for a, b, c in zip(ch, nr, off)] == want_fw, seed
+
+
+@pytest.mark.parametrize("kind", ["acgt", "eng", "runs"])
+def test_large_text_suffix_sorter_path(tmp_path, gpu_ok, kind, monkeypatch):
+    """The 64-bit, partitioned suffix sorter used for texts of 2^32 symbols and more, forced onto small
+    inputs (FEMTO_AMD_LARGE_SORT_CAP = part capacity) and checked through the byte-identity of the index it
+    yields with the index built by the 32-bit sorter, and against numpy's suffix array."""
+    from sa_util import suffix_array
+    if kind == "acgt":
+        text = tg.t_acgt(200000, 77)
+        cap = 60000
+    elif kind == "eng":
+        text = tg.t_eng(150000, 78)
+        cap = 150002
+    else:
+        rng = np.random.Generator(np.random.PCG64(5))
+        text = np.repeat(rng.choice(np.frombuffer(b"ab", dtype=np.uint8), 3000), rng.integers(1, 60, 3000)).astype(np.uint8)
+        cap = len(text) + 2
+    params = "block_size=65536,bucket_size=8192,mark_period=20"
+    a, b = str(tmp_path / "small"), str(tmp_path / "large")
+    femto_amd.build_index(a, [text], params=params, infos=["x"], device=0)
+    monkeypatch.setenv("FEMTO_AMD_LARGE_SORT_CAP", str(cap))
+    femto_amd.build_index(b, [text], params=params, infos=["x"], device=0)
+    monkeypatch.delenv("FEMTO_AMD_LARGE_SORT_CAP")
+    import filecmp
+    files = sorted(f for f in os.listdir(a) if f != "_femto_index")
+    assert files == sorted(f for f in os.listdir(b) if f != "_femto_index")
+    for f in files:
+        assert filecmp.cmp(os.path.join(a, f), os.path.join(b, f), shallow=False), f
+    # and the suffix array itself, read back through locate of the empty pattern
+    ix = femto_amd.Index(b, device=0)
+    n = ix.info.total_length
+    _, offs = ix.locate([np.zeros(0, dtype=np.uint16)], n)
+    sa = suffix_array(np.concatenate([text.astype(np.uint16) + 5, [2]]))
+    assert np.array_equal(offs, sa)
