@@ -2,6 +2,7 @@
 // owns device memory, streams and launch configuration; no compute happens on the host.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -152,8 +153,8 @@ int check_err_flag(femto_amd_index* ix, hipStream_t stream) {
   return 0;
 }
 
-int launch_count(femto_amd_index* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
-                 const int64_t* d_starts, int64_t* d_first, int64_t* d_last, hipStream_t stream) {
+int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
+                       const int64_t* d_starts, int64_t* d_first, int64_t* d_last, hipStream_t stream) {
   if (npats <= 0) return 0;
   constexpr int lanes_per_query = 2 * kGroupW;
   const int64_t threads = npats * lanes_per_query;
@@ -209,6 +210,19 @@ int launch_count(femto_amd_index* ix, int64_t npats, const int32_t* d_plen, cons
   return 0;
 }
 
+// An AQL dispatch carries at most 2^32 - 1 work-items per dimension: larger batches go out in chunks
+// (pattern starts are absolute, so only the per-pattern arrays are offset).
+int launch_count(femto_amd_index* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
+                 const int64_t* d_starts, int64_t* d_first, int64_t* d_last, hipStream_t stream) {
+  const int64_t max_chunk = ix->mode == 0 ? (int64_t(1) << 25) : (int64_t(1) << 31);
+  for (int64_t off = 0; off < npats; off += max_chunk) {
+    const int64_t cnt = std::min<int64_t>(max_chunk, npats - off);
+    int rc = launch_count_chunk(ix, cnt, d_plen + off, d_pats, d_starts + off, d_first + off, d_last ? d_last + off : nullptr, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 int device_scan(femto_amd_index* ix, int64_t n, const int64_t* in, int64_t* out /* n+1 */, int level, hipStream_t stream) {
   if (n <= 0) {
     HIP_TRY(hipMemsetAsync(out, 0, sizeof(int64_t), stream));
@@ -236,7 +250,7 @@ int launch_locate(femto_amd_index* ix, int64_t npats, const int64_t* d_first, co
   if (total <= 0) return 0;
   const int64_t threads = total * kGroupW;
   const int64_t blocks = (threads + kBlockThreads - 1) / kBlockThreads;
-  if (blocks > 0x7fffffffLL) return set_err(FEMTO_AMD_ERR_PARAM, "too many rows to locate in one launch");
+  if (threads >= (int64_t(1) << 32)) return set_err(FEMTO_AMD_ERR_PARAM, "too many rows to locate in one call (2^32 work-items per launch): lower max_occs_each or split the batch");
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ix->timing) {
     HIP_TRY(hipEventCreate(&e0));

@@ -13,6 +13,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -211,24 +212,29 @@ __global__ void hist12_kernel(const uint8_t* __restrict__ D, int64_t n, int bits
 __global__ void compact_part_kernel(const uint8_t* __restrict__ D, int64_t n, int bits, int k, int keybits, uint32_t lo_bin,
                                     uint32_t hi_bin, uint64_t* __restrict__ keys, uint64_t* __restrict__ vals,
                                     unsigned long long* __restrict__ counter) {
-  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  bool take = false;
-  uint64_t key = 0;
-  if (i < n) {
-    key = key_at(D, n, i, bits, k);
-    const uint32_t bin = uint32_t(key >> (keybits - 12));
-    take = bin >= lo_bin && bin < hi_bin;
-  }
-  const unsigned long long m = __ballot(take);
-  if (!m) return;
+  // grid-stride: an AQL dispatch carries at most 2^32 - 1 work-items per dimension, fewer than the suffixes
+  // of an 8 GiB text.  Every lane of a wavefront runs the same number of iterations (the ballot needs that).
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
   const int lane = threadIdx.x & 63;
-  unsigned long long base = 0;
-  if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counter, (unsigned long long)__popcll(m));
-  base = (unsigned long long)__shfl((long long)base, __ffsll((long long)m) - 1, 64);
-  if (take) {
-    const unsigned long long pos = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1));
-    keys[pos] = key;
-    vals[pos] = uint64_t(i);
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i - lane < n; i += stride) {
+    bool take = false;
+    uint64_t key = 0;
+    if (i < n) {
+      key = key_at(D, n, i, bits, k);
+      const uint32_t bin = uint32_t(key >> (keybits - 12));
+      take = bin >= lo_bin && bin < hi_bin;
+    }
+    const unsigned long long m = __ballot(take);
+    if (!m) continue;
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(m));
+    base = (unsigned long long)__shfl((long long)base, leader, 64);
+    if (take) {
+      const unsigned long long pos = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1));
+      keys[pos] = key;
+      vals[pos] = uint64_t(i);
+    }
   }
 }
 
@@ -361,6 +367,12 @@ int gpu_suffix_sort_large(const std::vector<uint16_t>& text, int device, int64_t
     parts.push_back({lo, 4096});
     part_size.push_back(acc);
   }
+  const bool dbg = getenv("FEMTO_AMD_SORT_DEBUG") != nullptr;
+  if (dbg) {
+    fprintf(stderr, "[sort] n=%lld sigma=%d bits=%d k=%d parts=%zu:", (long long)n, sigma, bits, k, parts.size());
+    for (size_t p = 0; p < parts.size(); p++) fprintf(stderr, " [%u,%u)=%lld", parts[p].first, parts[p].second, (long long)part_size[p]);
+    fprintf(stderr, "\n");
+  }
   int64_t cap = 0;
   for (int64_t sz : part_size) cap = std::max(cap, sz);
   cap = std::max<int64_t>(cap, 1);
@@ -390,8 +402,13 @@ int gpu_suffix_sort_large(const std::vector<uint16_t>& text, int device, int64_t
     const int64_t cnt = part_size[p];
     if (cnt == 0) continue;
     SS_TRY(hipMemset(d_cnt.p, 0, 8));
-    hipLaunchKernelGGL(compact_part_kernel, grid_for(n), dim3(256), 0, nullptr, D, n, bits, k, keybits, parts[p].first, parts[p].second,
+    hipLaunchKernelGGL(compact_part_kernel, dim3(1u << 20), dim3(256), 0, nullptr, D, n, bits, k, keybits, parts[p].first, parts[p].second,
                        keys, vals, static_cast<unsigned long long*>(d_cnt.p));
+    if (dbg) {
+      unsigned long long got = 0;
+      SS_TRY(hipMemcpy(&got, d_cnt.p, 8, hipMemcpyDeviceToHost));
+      fprintf(stderr, "[sort] part %zu compacted %llu (expected %lld)\n", p, got, (long long)cnt);
+    }
     size_t tb = tmp_bytes;
     SS_TRY(rocprim::radix_sort_pairs(d_tmp.p, tb, keys, keys2, vals, vals2, size_t(cnt), 0, unsigned(keybits), nullptr));
     hipLaunchKernelGGL(part_heads_kernel, grid_for(cnt), dim3(256), 0, nullptr, keys2, cnt, off, head);
@@ -421,6 +438,7 @@ int gpu_suffix_sort_large(const std::vector<uint16_t>& text, int device, int64_t
                              static_cast<unsigned long long*>(d_cnt.p), size_t(cnt), static_cast<hipStream_t>(nullptr)));
       unsigned long long got = 0;
       SS_TRY(hipMemcpy(&got, d_cnt.p, 8, hipMemcpyDeviceToHost));
+      if (dbg) fprintf(stderr, "[sort] round %d chunk base %lld: tied %llu\n", round, (long long)base, got);
       if (T + int64_t(got) > cap) {
         if (err) { err->code = 3; err->msg = "suffix sorter: too many tied suffixes for the large-text sorter (text too repetitive)"; }
         return 3;
