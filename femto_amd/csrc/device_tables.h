@@ -54,6 +54,15 @@ struct DevBseq {            // one encoded binary sequence (src/main/wtree_funcs
 //   aux word k (1-7): low 32 bits = data bits covered by the codes before p_k (0xffffffff: no such
 //                     code), high 32 bits = ones among them | (value of the run starting at p_k) << 31
 struct CumEntry { uint32_t o0, o1; };
+// One 32-byte entry per 512-bit block of a sequence that has RLE segments: the segment holding the
+// block's first bit, the zeros/ones before it, and the zeros/ones before the NEXT segment (the only other
+// segment a bit of this block can lie in).  One load replaces hint[] + two cum[] entries.
+struct BlockDir {
+  uint32_t seg;
+  uint32_t o0, o1;      // before segment seg
+  uint32_t n0, n1;      // before segment seg + 1
+  uint32_t pad[3];
+};
 constexpr uint32_t kNoHint = 0xffffffffu;
 struct LaneBseq {           // 16 bytes
   uint64_t seg_base;        // first 64-byte slot of this sequence in DevIndex::segs (two slots per segment)
@@ -107,6 +116,7 @@ struct DevIndex {           // passed by value to kernels
   const uint64_t* segs;     // 64-byte aligned native-endian segment slots (8 words each)
   const CumEntry* cum;
   const uint32_t* hint;
+  const BlockDir* bdir;     // indexed like hint[]
   const LaneNode* lnodes;   // parallel to nodes[]
   const LaneSeq* lseqs;     // parallel to seqs[]
   const OccEntry* occ;      // [gb*261 + ch]

@@ -104,6 +104,7 @@ struct femto_amd_index {
   uint64_t* d_segs = nullptr;
   CumEntry* d_cum = nullptr;
   uint32_t* d_hint = nullptr;
+  BlockDir* d_bdir = nullptr;
   LaneNode* d_lnodes = nullptr;
   LaneSeq* d_lseqs = nullptr;
   OccEntry* d_occ = nullptr;
@@ -350,6 +351,7 @@ int femto_amd_open(const char* index_path, int device, femto_amd_index_t** out) 
       if ((r = upload(&ix->d_segs, h.segs, &ix->table_bytes))) return r;
       if ((r = upload(&ix->d_cum, h.cum, &ix->table_bytes))) return r;
       if ((r = upload(&ix->d_hint, h.hint, &ix->table_bytes))) return r;
+      if ((r = upload(&ix->d_bdir, h.bdir, &ix->table_bytes))) return r;
       if ((r = upload(&ix->d_lnodes, h.lnodes, &ix->table_bytes))) return r;
       if ((r = upload(&ix->d_lseqs, h.lseqs, &ix->table_bytes))) return r;
       if ((r = upload(&ix->d_occ, h.occ, &ix->table_bytes))) return r;
@@ -376,6 +378,7 @@ int femto_amd_open(const char* index_path, int device, femto_amd_index_t** out) 
       d.segs = ix->d_segs;
       d.cum = ix->d_cum;
       d.hint = ix->d_hint;
+      d.bdir = ix->d_bdir;
       d.lnodes = ix->d_lnodes;
       d.lseqs = ix->d_lseqs;
       d.occ = ix->d_occ;
@@ -425,6 +428,7 @@ void femto_amd_close(femto_amd_index_t* ix) {
     (void)hipFree(ix->d_segs);
     (void)hipFree(ix->d_cum);
     (void)hipFree(ix->d_hint);
+    (void)hipFree(ix->d_bdir);
     (void)hipFree(ix->d_lnodes);
     (void)hipFree(ix->d_lseqs);
     (void)hipFree(ix->d_occ);
@@ -454,7 +458,7 @@ int femto_amd_info(const femto_amd_index_t* ix, femto_amd_info_t* out) {
   out->image_bytes = int64_t(h.image.size());
   out->table_bytes = int64_t(h.nodes.size() * sizeof(DevNode) + h.buckets.size() * sizeof(DevBucket) +
                              h.seqs.size() * sizeof(DevSeq) + h.occ_base.size() * 8 + h.leaf_code.size() * 4 +
-                             h.C.size() * 8 + h.segs.size() * 8 + h.cum.size() * sizeof(CumEntry) + h.hint.size() * 4 +
+                             h.C.size() * 8 + h.segs.size() * 8 + h.cum.size() * sizeof(CumEntry) + h.hint.size() * 4 + h.bdir.size() * sizeof(BlockDir) +
                              h.lnodes.size() * sizeof(LaneNode) + h.lseqs.size() * sizeof(LaneSeq) +
                              h.occ.size() * sizeof(OccEntry));
   return FEMTO_AMD_OK;

@@ -105,6 +105,7 @@ struct LaneTables {
   std::vector<uint64_t>* segs;
   std::vector<CumEntry>* cum;
   std::vector<uint32_t>* hint;
+  std::vector<BlockDir>* bdir;
 };
 
 int build_lane_tables(const std::vector<uint8_t>& img, DevBseq* bs, bool* regular, Error* e, LaneTables* lt, LaneBseq* lane) {
@@ -169,6 +170,14 @@ int build_lane_tables(const std::vector<uint8_t>& img, DevBseq* bs, bool* regula
       lane->hint_base = kNoHint;
     } else {
       lane->hint_base = uint32_t(hint0);
+      // merged block directory, parallel to hint[]: both candidate segments' cumulative counts in one entry
+      lt->bdir->resize(hint0);
+      for (size_t hpos = hint0; hpos < lt->hint->size(); hpos++) {
+        const uint32_t sg = (*lt->hint)[hpos];
+        const CumEntry& ca = (*lt->cum)[cum0 + sg];
+        const CumEntry& cb = (*lt->cum)[cum0 + sg + 1];
+        lt->bdir->push_back(BlockDir{sg, ca.o0, ca.o1, cb.o0, cb.o1, {0, 0, 0}});
+      }
     }
     // copy the D words into 64-byte aligned native-endian slots (bseq_segment's zero fill included);
     // non-uniform sequences get a second slot per segment holding the RLE skip table
@@ -454,7 +463,7 @@ int HostIndex::load(const std::string& path, Error* e) {
         } else {
           rc = parse_bseq(image, boff + wt_off + off, blimit, &nd.bs, e);
           if (rc) return rc;
-          LaneTables lt{&segs, &cum, &hint};
+          LaneTables lt{&segs, &cum, &hint, &bdir};
           rc = build_lane_tables(image, &nd.bs, &dir_regular, e, &lt, &ln.bs);
           if (rc) return rc;
         }
@@ -488,7 +497,7 @@ int HostIndex::load(const std::string& path, Error* e) {
         if (rc) return rc;
         LaneSeq lsq;
         memset(&lsq, 0, sizeof lsq);
-        LaneTables lt{&segs, &cum, &hint};
+        LaneTables lt{&segs, &cum, &hint, &bdir};
         rc = build_lane_tables(image, &sq.mark_table, &dir_regular, e, &lt, &lsq.mark_table);
         if (rc) return rc;
         uint32_t aoff = be32(d + ma_off + 4 * size_t(s));

@@ -35,6 +35,7 @@ struct HostIndex {
   std::vector<uint64_t> segs;           // 64-byte aligned native-endian segment slots
   std::vector<CumEntry> cum;
   std::vector<uint32_t> hint;
+  std::vector<BlockDir> bdir;           // parallel to hint
   std::vector<LaneNode> lnodes;
   std::vector<LaneSeq> lseqs;
   std::vector<OccEntry> occ;

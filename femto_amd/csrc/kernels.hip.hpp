@@ -532,14 +532,14 @@ __device__ __forceinline__ RankResult bseq_rank_lane(const DevIndex& ix, const L
     seg = t / 511u;  // all segments literal and full: 511 data bits each; counts ride in the segment's line
     o0 = o1 = 0;
   } else {
-    seg = ix.hint[uint64_t(bs.hint_base) + (t >> 9)];
-    const uint64_t* cp = reinterpret_cast<const uint64_t*>(ix.cum + (uint64_t(bs.cum_base) + seg));
-    const uint64_t c0 = cp[0], c1 = cp[1];
-    o0 = uint32_t(c0);
-    o1 = uint32_t(c0 >> 32);
-    const uint32_t n0 = uint32_t(c1), n1 = uint32_t(c1 >> 32);
-    if (t >= n0 + n1) {  // the block's second segment
-      o0 = n0;
+    const uint4* dp = reinterpret_cast<const uint4*>(ix.bdir + (uint64_t(bs.hint_base) + (t >> 9)));
+    const uint4 d0 = dp[0];            // seg, o0, o1, n0
+    const uint32_t n1 = reinterpret_cast<const uint32_t*>(dp)[4];
+    seg = d0.x;
+    o0 = d0.y;
+    o1 = d0.z;
+    if (t >= d0.w + n1) {  // the block's second segment
+      o0 = d0.w;
       o1 = n1;
       seg++;
     }
@@ -807,14 +807,14 @@ __device__ __forceinline__ void rank_locate_segment(const DevIndex& ix, const La
     j.seg = j.t / 511u;
     j.o0 = j.o1 = 0;   // read from word 8 of the segment's line in rank_load_segment
   } else {
-    j.seg = ix.hint[uint64_t(bs.hint_base) + (j.t >> 9)];
-    const uint64_t* cp = reinterpret_cast<const uint64_t*>(ix.cum + (uint64_t(bs.cum_base) + j.seg));
-    const uint64_t c0 = cp[0], c1 = cp[1];
-    j.o0 = uint32_t(c0);
-    j.o1 = uint32_t(c0 >> 32);
-    const uint32_t n0 = uint32_t(c1), n1 = uint32_t(c1 >> 32);
-    if (j.t >= n0 + n1) {
-      j.o0 = n0;
+    const uint4* dp = reinterpret_cast<const uint4*>(ix.bdir + (uint64_t(bs.hint_base) + (j.t >> 9)));
+    const uint4 d0 = dp[0];
+    const uint32_t n1 = reinterpret_cast<const uint32_t*>(dp)[4];
+    j.seg = d0.x;
+    j.o0 = d0.y;
+    j.o1 = d0.z;
+    if (j.t >= d0.w + n1) {
+      j.o0 = d0.w;
       j.o1 = n1;
       j.seg++;
     }

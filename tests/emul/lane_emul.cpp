@@ -32,10 +32,11 @@ static RR rank_lane(const LaneBseq bs, uint32_t index1) {
   const bool uniform = bs.hint_base == kNoHint;
   if (uniform) seg = t / 511u;
   else {
-    seg = at(H->hint, uint64_t(bs.hint_base) + (t >> 9), "hint");
-    const CumEntry c0 = at(H->cum, uint64_t(bs.cum_base) + seg, "cum"), c1 = at(H->cum, uint64_t(bs.cum_base) + seg + 1, "cum+1");
-    o0 = c0.o0; o1 = c0.o1;
-    if (t >= c1.o0 + c1.o1) { o0 = c1.o0; o1 = c1.o1; seg++; }
+    const BlockDir d = at(H->bdir, uint64_t(bs.hint_base) + (t >> 9), "bdir");
+    seg = d.seg; o0 = d.o0; o1 = d.o1;
+    if (t >= d.n0 + d.n1) { o0 = d.n0; o1 = d.n1; seg++; }
+    // the merged directory must agree with hint[] / cum[]
+    if (seg != at(H->hint, uint64_t(bs.hint_base) + (t >> 9), "hint") && seg != at(H->hint, uint64_t(bs.hint_base) + (t >> 9), "hint") + 1) abort();
   }
   const uint64_t slot = bs.seg_base + 2ull * seg;
   uint64_t w[8];
