@@ -522,52 +522,62 @@ __device__ __forceinline__ void rle_skip(const uint64_t* __restrict__ aux, uint3
   }
 }
 
-// bseq_rank (src/main/wtree.c:635-763) by ONE lane: which segment (cum/hint tables) -> the aligned
-// 64-byte segment -> popcount / gamma runs.
-__device__ __forceinline__ RankResult bseq_rank_lane(const DevIndex& ix, const LaneBseq bs, uint32_t index1) {
-  const uint32_t t = index1 - 1;
+// bseq_rank (src/main/wtree.c:635-763) by ONE lane, in three stages so that callers may interleave the loads
+// of independent ranks: (1) which segment -- t/511 for all-literal sequences, one 32-byte block-directory
+// entry otherwise; (2) the segment's 128-byte line; (3) masked popcount (literal) or gamma runs (RLE, entered
+// through the skip table).
+struct RankJob {
+  uint32_t t;          // 0-based bit position
   uint32_t seg, o0, o1;
-  const bool uniform = bs.hint_base == kNoHint;
-  if (uniform) {
-    seg = t / 511u;  // all segments literal and full: 511 data bits each; counts ride in the segment's line
-    o0 = o1 = 0;
-  } else {
-    const uint4* dp = reinterpret_cast<const uint4*>(ix.bdir + (uint64_t(bs.hint_base) + (t >> 9)));
-    const uint4 d0 = dp[0];            // seg, o0, o1, n0
-    const uint32_t n1 = reinterpret_cast<const uint32_t*>(dp)[4];
-    seg = d0.x;
-    o0 = d0.y;
-    o1 = d0.z;
-    if (t >= d0.w + n1) {  // the block's second segment
-      o0 = d0.w;
-      o1 = n1;
-      seg++;
-    }
-  }
-  uint64_t w[kSegmentWords];
-  {
-    const uint64_t slot = bs.seg_base + 2ull * seg;
-    const ulonglong2* sp = reinterpret_cast<const ulonglong2*>(ix.segs + slot * kSegmentWords);
-#pragma unroll
-    for (int k = 0; k < kSegmentWords / 2; k++) {
-      const ulonglong2 v = sp[k];
-      w[2 * k] = v.x;
-      w[2 * k + 1] = v.y;
-    }
-    if (uniform) {
-      const uint64_t c = reinterpret_cast<const uint64_t*>(sp)[kSegmentWords];
-      o0 = uint32_t(c);
-      o1 = uint32_t(c >> 32);
-    }
-  }
+  uint64_t slot;       // segment slot index in DevIndex::segs
+  bool has_aux;        // the next slot holds the RLE skip table
+};
 
+__device__ __forceinline__ void rank_locate_segment(const DevIndex& ix, const LaneBseq bs, uint32_t index1, RankJob& j) {
+  j.t = index1 - 1;
+  if (bs.hint_base == kNoHint) {
+    j.seg = j.t / 511u;
+    j.o0 = j.o1 = 0;   // read from word 8 of the segment's line in rank_load_segment
+  } else {
+    const uint4* dp = reinterpret_cast<const uint4*>(ix.bdir + (uint64_t(bs.hint_base) + (j.t >> 9)));
+    const uint4 d0 = dp[0];
+    const uint32_t n1 = reinterpret_cast<const uint32_t*>(dp)[4];
+    j.seg = d0.x;
+    j.o0 = d0.y;
+    j.o1 = d0.z;
+    if (j.t >= d0.w + n1) {
+      j.o0 = d0.w;
+      j.o1 = n1;
+      j.seg++;
+    }
+  }
+  j.slot = bs.seg_base + 2ull * j.seg;
+  j.has_aux = bs.hint_base != kNoHint;
+}
+
+__device__ __forceinline__ void rank_load_segment(const DevIndex& ix, RankJob& j, uint64_t (&w)[kSegmentWords]) {
+  const ulonglong2* sp = reinterpret_cast<const ulonglong2*>(ix.segs + j.slot * kSegmentWords);
+#pragma unroll
+  for (int k = 0; k < kSegmentWords / 2; k++) {
+    const ulonglong2 v = sp[k];
+    w[2 * k] = v.x;
+    w[2 * k + 1] = v.y;
+  }
+  if (!j.has_aux) {
+    const uint64_t c = reinterpret_cast<const uint64_t*>(sp)[kSegmentWords];
+    j.o0 = uint32_t(c);
+    j.o1 = uint32_t(c >> 32);
+  }
+}
+
+__device__ __forceinline__ RankResult rank_finish(const DevIndex& ix, const RankJob& j, const uint64_t (&w)[kSegmentWords]) {
+  uint32_t o0 = j.o0, o1 = j.o1;
+  const uint32_t t = j.t;
   RankResult r;
-  if (w[0] >> 63) {
-    // RLE segment (wtree.c:690-712)
+  if (w[0] >> 63) {  // RLE segment (wtree.c:690-712)
     uint32_t bit = uint32_t(w[0] >> 62) & 1u;
     int p = 2;
-    if (bs.hint_base != kNoHint)
-      rle_skip(ix.segs + ((bs.seg_base + 2ull * seg) + 1) * kSegmentWords, t - o0 - o1, o0, o1, bit, p);
+    if (j.has_aux) rle_skip(ix.segs + (j.slot + 1) * kSegmentWords, t - o0 - o1, o0, o1, bit, p);
     uint64_t win = 0;
     int avail = 0;
     for (int it = 0; it < 512; it++) {
@@ -579,7 +589,7 @@ __device__ __forceinline__ RankResult bseq_rank_lane(const DevIndex& ix, const L
         win = (a << sh) | (sh ? (c >> (64 - sh)) : 0);
         avail = 64;
         k = win ? __clzll(win) : 64;
-        if (k >= 32) break;  // corrupt data guard
+        if (k >= 32) break;
       }
       const int nb = 2 * k + 1;
       const uint32_t v = uint32_t(win >> (64 - nb));
@@ -597,8 +607,7 @@ __device__ __forceinline__ RankResult bseq_rank_lane(const DevIndex& ix, const L
       }
     }
     r.bit = bit;
-  } else {
-    // literal segment (wtree.c:713-759): count ones in segment bits 1..nb
+  } else {  // literal segment (wtree.c:713-759)
     const uint32_t nb = 1 + t - o0 - o1;
     uint32_t ones = 0;
     uint64_t bw = 0;
@@ -617,6 +626,14 @@ __device__ __forceinline__ RankResult bseq_rank_lane(const DevIndex& ix, const L
   r.o0 = o0;
   r.o1 = o1;
   return r;
+}
+
+__device__ __forceinline__ RankResult bseq_rank_lane(const DevIndex& ix, const LaneBseq bs, uint32_t index1) {
+  RankJob j;
+  uint64_t w[kSegmentWords];
+  rank_locate_segment(ix, bs, index1, j);
+  rank_load_segment(ix, j, w);
+  return rank_finish(ix, j, w);
 }
 
 // wtree_occs (src/main/wtree.c:1081-1115), one lane
@@ -790,111 +807,6 @@ __global__ __launch_bounds__(256) void block_request_kernel_lane(const DevIndex 
 // machine; finished lanes pull their next query (grid-stride), so a wavefront's 64 lanes always
 // rank together and only the rank itself (literal popcount vs gamma runs) can diverge.
 // =====================================================================================
-
-// ---- staged rank: the loads of several independent ranks are issued stage by stage so that one
-// lane keeps several 64-byte segment reads in flight (the walk of row first-1, the walk of row
-// last, and the same for a second query).
-struct RankJob {
-  uint32_t t;          // 0-based bit position
-  uint32_t seg, o0, o1;
-  uint64_t slot;       // segment slot index in DevIndex::segs
-  bool has_aux;        // the next slot holds the RLE skip table
-};
-
-__device__ __forceinline__ void rank_locate_segment(const DevIndex& ix, const LaneBseq bs, uint32_t index1, RankJob& j) {
-  j.t = index1 - 1;
-  if (bs.hint_base == kNoHint) {
-    j.seg = j.t / 511u;
-    j.o0 = j.o1 = 0;   // read from word 8 of the segment's line in rank_load_segment
-  } else {
-    const uint4* dp = reinterpret_cast<const uint4*>(ix.bdir + (uint64_t(bs.hint_base) + (j.t >> 9)));
-    const uint4 d0 = dp[0];
-    const uint32_t n1 = reinterpret_cast<const uint32_t*>(dp)[4];
-    j.seg = d0.x;
-    j.o0 = d0.y;
-    j.o1 = d0.z;
-    if (j.t >= d0.w + n1) {
-      j.o0 = d0.w;
-      j.o1 = n1;
-      j.seg++;
-    }
-  }
-  j.slot = bs.seg_base + 2ull * j.seg;
-  j.has_aux = bs.hint_base != kNoHint;
-}
-
-__device__ __forceinline__ void rank_load_segment(const DevIndex& ix, RankJob& j, uint64_t (&w)[kSegmentWords]) {
-  const ulonglong2* sp = reinterpret_cast<const ulonglong2*>(ix.segs + j.slot * kSegmentWords);
-#pragma unroll
-  for (int k = 0; k < kSegmentWords / 2; k++) {
-    const ulonglong2 v = sp[k];
-    w[2 * k] = v.x;
-    w[2 * k + 1] = v.y;
-  }
-  if (!j.has_aux) {
-    const uint64_t c = reinterpret_cast<const uint64_t*>(sp)[kSegmentWords];
-    j.o0 = uint32_t(c);
-    j.o1 = uint32_t(c >> 32);
-  }
-}
-
-__device__ __forceinline__ RankResult rank_finish(const DevIndex& ix, const RankJob& j, const uint64_t (&w)[kSegmentWords]) {
-  uint32_t o0 = j.o0, o1 = j.o1;
-  const uint32_t t = j.t;
-  RankResult r;
-  if (w[0] >> 63) {  // RLE segment (wtree.c:690-712)
-    uint32_t bit = uint32_t(w[0] >> 62) & 1u;
-    int p = 2;
-    if (j.has_aux) rle_skip(ix.segs + (j.slot + 1) * kSegmentWords, t - o0 - o1, o0, o1, bit, p);
-    uint64_t win = 0;
-    int avail = 0;
-    for (int it = 0; it < 512; it++) {
-      int k = win ? __clzll(win) : 64;
-      if (2 * k + 1 > avail) {
-        const int wi = p >> 6, sh = p & 63;
-        const uint64_t a = sel8(w, wi);
-        const uint64_t c = sel8(w, wi + 1);
-        win = (a << sh) | (sh ? (c >> (64 - sh)) : 0);
-        avail = 64;
-        k = win ? __clzll(win) : 64;
-        if (k >= 32) break;
-      }
-      const int nb = 2 * k + 1;
-      const uint32_t v = uint32_t(win >> (64 - nb));
-      win = nb < 64 ? (win << nb) : 0;
-      avail -= nb;
-      p += nb;
-      const uint32_t tot = o0 + o1;
-      if (tot + v <= t) {
-        if (bit) o1 += v; else o0 += v;
-        bit ^= 1u;
-      } else {
-        const uint32_t rem = t + 1 - tot;
-        if (bit) o1 += rem; else o0 += rem;
-        break;
-      }
-    }
-    r.bit = bit;
-  } else {  // literal segment (wtree.c:713-759)
-    const uint32_t nb = 1 + t - o0 - o1;
-    uint32_t ones = 0;
-    uint64_t bw = 0;
-#pragma unroll
-    for (int k = 0; k < kSegmentWords; k++) {
-      const uint32_t lo = 64u * uint32_t(k);
-      uint64_t m = 0;
-      if (nb >= lo) m = (nb - lo >= 63) ? ~0ull : (~0ull << (63 - (nb - lo)));
-      ones += uint32_t(__popcll(w[k] & m));
-      if ((nb >> 6) == uint32_t(k)) bw = w[k];
-    }
-    o1 += ones;
-    o0 += nb - ones;
-    r.bit = uint32_t(bw >> (63 - (nb & 63))) & 1u;
-  }
-  r.o0 = o0;
-  r.o1 = o1;
-  return r;
-}
 
 enum : int { ST_QUERY = 0, ST_STEP = 1, ST_WALK = 2, ST_DONE = 3 };
 
