@@ -34,5 +34,22 @@ def build(force=False, verbose=False):
     return LIB
 
 
+TOOL_SRC = os.path.join(os.path.dirname(HERE), "tools", "femto_amd_multiquery.cpp")
+TOOL = os.path.join(HERE, "femto_amd_multiquery")
+
+
+def build_tools(force=False, verbose=False):
+    """The C++ host program over the C ABI (femto_multiquery's counterpart); plain g++, links the library."""
+    if not force and os.path.exists(TOOL) and os.path.getmtime(TOOL) > max(os.path.getmtime(TOOL_SRC), os.path.getmtime(LIB)):
+        return TOOL
+    cmd = ["g++", "-std=c++17", "-O2", "-o", TOOL, TOOL_SRC, "-L" + HERE, "-lfemto_amd", "-Wl,-rpath,$ORIGIN",
+           "-Wl,-rpath-link," + HERE, "-Wl,--allow-shlib-undefined"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return TOOL
+
+
 if __name__ == "__main__":
     build(force=True, verbose=True)
+    build_tools(force=True, verbose=True)

@@ -367,3 +367,31 @@ def test_full_size_1gib_properties(tmp_path, gpu_ok):
     gn, go = ix.locate_flat(p2, f2, s2, 100)
     on, oo = o.locate_flat(p2, f2, s2, 100, threads=16)
     assert np.array_equal(gn, on) and np.array_equal(go, oo)
+
+
+def test_multiquery_cpp_tool(fixtures, tmp_path, gpu_ok):
+    """femto_amd_multiquery (C++ host over the C ABI, femto_multiquery's counterpart): Pizza&Chili query file on
+    stdin, -count / -locate [max]; dumped results must equal the oracle's."""
+    import subprocess
+    from femto_amd import build as b
+    tool = b.build_tools()
+    fx = fixtures("eng2doc")
+    text = np.concatenate(fx.docs)
+    rng = np.random.Generator(np.random.PCG64(1))
+    n, m = 500, 6
+    startpos = rng.integers(0, len(text) - m, n)
+    pats = np.stack([text[s0:s0 + m] for s0 in startpos])
+    qfile = f"# number={n} length={m} file=test forbidden=\n".encode() + pats.tobytes()
+    o = po.Oracle(fx.index)
+    alpha = [tg.to_alpha(p) for p in pats]
+    of, ol = o.count(alpha)
+    dump = str(tmp_path / "c.bin")
+    r = subprocess.run([tool, fx.index, "-count", "--dump", dump], input=qfile, capture_output=True, check=True)
+    assert f"Counted {int((ol - of + 1).sum())} results".encode() in r.stdout
+    got = np.fromfile(dump, dtype=np.int64)
+    assert np.array_equal(got[:n], of) and np.array_equal(got[n:], ol)
+    on, oo = o.locate(alpha, 5)
+    r = subprocess.run([tool, fx.index, "-locate", "5", "--dump", dump], input=qfile, capture_output=True, check=True)
+    raw = open(dump, "rb").read()
+    assert np.array_equal(np.frombuffer(raw, dtype=np.int32, count=n), on)
+    assert np.array_equal(np.frombuffer(raw, dtype=np.int64, offset=4 * n), oo)

@@ -139,3 +139,16 @@ def test_flatten_is_byte_identical_to_reference(fixtures, tmp_path):
     femto_amd.flatten_index(fx.index, out)
     assert filecmp.cmp(fx.flat, out, shallow=False)
     assert femto_amd.Index(out, device=-1).info.total_length == femto_amd.Index(fx.index, device=-1).info.total_length
+
+
+def test_multiquery_tool_fails_loudly_without_gpu(fixtures):
+    """The C++ host program (tools/femto_amd_multiquery.cpp) is pure C ABI: without a GPU it must stop with the
+    library's error, not fall back to anything."""
+    import subprocess
+    import torch
+    from femto_amd import build as b
+    tool = b.build_tools()
+    fx = fixtures("acgt48k")
+    if not torch.cuda.is_available():
+        r = subprocess.run([tool, fx.index, "-count"], input=b"# number=1 length=4 x\nACGT", capture_output=True)
+        assert r.returncode == 1 and b"no CPU fallback" in r.stderr
