@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--workload", default="acgt", choices=["acgt", "acgt_hit", "eng"],
                     help="acgt = configs[1] (default, headline): random 20-mers; acgt_hit = same index, 20-mers sampled "
                          "from the text (every pattern is located); eng = configs[2]: sigma~96 text, sampled lengths 8..64")
+    ap.add_argument("--layout", default="replicated", choices=["replicated", "split"],
+                    help="split: range-split index (BASELINE configs[4]) -- every rank keeps 1/N of the blocks and reads the "
+                         "rest from its peers' HBM over xGMI (femto_amd.parallel.open_range_split)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary P_hit line (N=1 default workload only)")
     ap.add_argument("--workdir", default=os.environ.get("FEMTO_AMD_BENCH_DIR", "/tmp/femto_amd_bench"))
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "latest_pmc.json"))
@@ -136,7 +139,11 @@ def main():
     if world > 1:
         dist.barrier()
     t0 = time.time()
-    ix = femto_amd.Index(index_path, device=local_rank)
+    if args.layout == "split" and world > 1:
+        from femto_amd import parallel as fpar
+        ix = fpar.open_range_split(index_path, local_rank)
+    else:
+        ix = femto_amd.Index(index_path, device=local_rank)
     open_s = time.time() - t0
     info = ix.info
 
@@ -338,7 +345,7 @@ def main():
                    "located_rows_per_gpu": batch.total, "matched_patterns_frac": float(np.mean(last >= first)),
                    "index": {"rows": int(info.total_length), "blocks": int(info.number_of_blocks), "buckets": int(info.total_buckets),
                              "image_bytes": int(info.image_bytes), "table_bytes": int(info.table_bytes)},
-                   "parallelism": f"replicated index, query shards x{world}" + (", RCCL gather of (first,last) to rank 0 every step, overlapped with the next step's kernels" if world > 1 else ""),
+                   "parallelism": ("range-split index (1/N of the blocks per GPU, peer loads over xGMI)" if args.layout == "split" and world > 1 else "replicated index") + f", query shards x{world}" + (", RCCL gather of (first,last) to rank 0 every step, overlapped with the next step's kernels" if world > 1 else ""),
                    "build_s": build_s, "open_s": open_s},
         "roofline": roof, "cpu_baseline": cpu,
         "gpu_vs_cpu": (value / cpu["value"]) if cpu else None,

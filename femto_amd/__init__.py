@@ -75,6 +75,12 @@ def lib():
         L.femto_amd_get_rank_mode.argtypes = [vp]
         L.femto_amd_flatten_index.argtypes = [C.c_char_p, C.c_char_p]
         L.femto_amd_bseq_encode.argtypes = [vp, i64, i32, vp, i64, C.POINTER(i64)]
+        L.femto_amd_open_split.argtypes = [C.c_char_p, i32, i32, i32, C.POINTER(vp)]
+        L.femto_amd_split_export.argtypes = [vp, vp]
+        L.femto_amd_split_attach.argtypes = [vp, i32, vp]
+        L.femto_amd_split_attach_local.argtypes = [vp, vp]
+        L.femto_amd_split_commit.argtypes = [vp]
+        L.femto_amd_split_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64), C.POINTER(i64)]
         _lib = L
     return _lib
 
@@ -102,12 +108,40 @@ def flatten(patterns):
 class Index:
     """A femto index resident in the HBM of one GPU.  device=-1 parses only (host logic tests)."""
 
-    def __init__(self, path, device=0):
+    def __init__(self, path, device=0, part=None, nparts=None):
         self._h = C.c_void_p()
-        _check(lib().femto_amd_open(os.fsencode(path), device, C.byref(self._h)))
+        self._peers = []   # range-split: the parts attached in-process must outlive this handle's use
+        if nparts is None:
+            _check(lib().femto_amd_open(os.fsencode(path), device, C.byref(self._h)))
+        else:
+            _check(lib().femto_amd_open_split(os.fsencode(path), device, int(part), int(nparts), C.byref(self._h)))
         self.device = device
+        self.part, self.nparts = part, nparts
         self.info = Info()
         _check(lib().femto_amd_info(self._h, C.byref(self.info)))
+
+    # ---- range-split index (femto_amd_open_split): part p holds blocks [nb*p/nparts, nb*(p+1)/nparts)
+    def split_export(self):
+        """128-byte blob (two hipIpcMemHandle_t) other PROCESSES pass to split_attach"""
+        blob = C.create_string_buffer(128)
+        _check(lib().femto_amd_split_export(self._h, blob))
+        return blob.raw
+
+    def split_attach(self, part, blob):
+        _check(lib().femto_amd_split_attach(self._h, int(part), C.create_string_buffer(bytes(blob), 128)))
+
+    def split_attach_local(self, owner):
+        """attach a part opened in THIS process (same GPU, or another GPU with peer access)"""
+        _check(lib().femto_amd_split_attach_local(self._h, owner._h))
+        self._peers.append(owner)
+
+    def split_commit(self):
+        _check(lib().femto_amd_split_commit(self._h))
+
+    def split_info(self):
+        part, nparts, sb, ib = C.c_int(0), C.c_int(0), C.c_int64(0), C.c_int64(0)
+        _check(lib().femto_amd_split_info(self._h, C.byref(part), C.byref(nparts), C.byref(sb), C.byref(ib)))
+        return {"part": part.value, "nparts": nparts.value, "seg_bytes": sb.value, "image_bytes": ib.value}
 
     def close(self):
         if self._h:

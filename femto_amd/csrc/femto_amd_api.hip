@@ -124,6 +124,14 @@ struct femto_amd_index {
   int64_t sort_min = 4096;
   bool timing = false;
   KernelTimer t_count, t_locate;
+  // range-split index (femto_amd_open_split): this handle holds the segment lines and the block images of
+  // data blocks [split_blo[part], split_blo[part+1]); the other parts' slices are mapped from their owners
+  int split_parts = 0, split_part = 0;
+  bool split_ready = false;
+  std::vector<int64_t> split_blo;        // nparts + 1 block boundaries
+  std::vector<void*> peer_segs, peer_image;  // per part: base of that part's slices as seen from this process
+  std::vector<char> peer_ipc;            // per part: 1 if opened with hipIpcOpenMemHandle (close on release)
+  int64_t split_seg_bytes = 0, split_image_bytes = 0;
 };
 
 namespace {
@@ -139,8 +147,17 @@ int upload(T** dst, const std::vector<T>& src, int64_t* bytes) {
 
 int ensure_device(femto_amd_index* ix) {
   if (ix->device < 0) return set_err(FEMTO_AMD_ERR_INVALID, "index was opened without a device (parse-only handle)");
+  if (ix->split_parts > 0 && !ix->split_ready)
+    return set_err(FEMTO_AMD_ERR_INVALID, "range-split index: attach every part and call femto_amd_split_commit first");
   HIP_TRY(hipSetDevice(ix->device));
   return 0;
+}
+
+// image byte range [lo, hi) of data blocks [b0, b1) (block starts are 256-byte aligned inside HostIndex::image)
+void block_image_range(const HostIndex& h, int64_t b0, int64_t b1, uint64_t* lo, uint64_t* hi) {
+  if (b0 >= b1) { *lo = *hi = 0; return; }
+  *lo = h.block_off[size_t(b0)];
+  *hi = h.block_off[size_t(b1) - 1] + h.block_len[size_t(b1) - 1];
 }
 
 int check_err_flag(femto_amd_index* ix, hipStream_t stream) {
@@ -316,9 +333,10 @@ extern "C" {
 
 const char* femto_amd_last_error(void) { return g_last_error.c_str(); }
 
-int femto_amd_open(const char* index_path, int device, femto_amd_index_t** out) {
+static int open_impl(const char* index_path, int device, int part, int nparts, femto_amd_index_t** out) {
   if (!index_path || !out) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
   *out = nullptr;
+  const bool split = nparts > 0;
   femto_amd_index* ix = new (std::nothrow) femto_amd_index();
   if (!ix) return set_err(FEMTO_AMD_ERR_MEM, "out of memory");
   Error err{0, ""};
@@ -339,21 +357,50 @@ int femto_amd_open(const char* index_path, int device, femto_amd_index_t** out) 
     auto up = [&]() -> int {
       HIP_TRY(hipSetDevice(device));
       HostIndex& h = ix->host;
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_image), h.image.size()));
-      HIP_TRY(hipMemcpy(ix->d_image, h.image.data(), h.image.size(), hipMemcpyHostToDevice));
       int r;
-      if ((r = upload(&ix->d_nodes, h.nodes, &ix->table_bytes))) return r;
+      if (!split) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_image), h.image.size()));
+        HIP_TRY(hipMemcpy(ix->d_image, h.image.data(), h.image.size(), hipMemcpyHostToDevice));
+        if ((r = upload(&ix->d_nodes, h.nodes, &ix->table_bytes))) return r;
+        if ((r = upload(&ix->d_seqs, h.seqs, &ix->table_bytes))) return r;
+        if ((r = upload(&ix->d_leaf_code, h.leaf_code, &ix->table_bytes))) return r;
+        if ((r = upload(&ix->d_segs, h.segs, &ix->table_bytes))) return r;
+        if ((r = upload(&ix->d_cum, h.cum, &ix->table_bytes))) return r;
+        if ((r = upload(&ix->d_hint, h.hint, &ix->table_bytes))) return r;
+        if ((r = upload(&ix->d_lnodes, h.lnodes, &ix->table_bytes))) return r;
+        if ((r = upload(&ix->d_lseqs, h.lseqs, &ix->table_bytes))) return r;
+      } else {
+        // Only this part's blocks: their segment lines and their images (mark arrays).  The lane tables that
+        // point into them (lnodes/lseqs) are uploaded by femto_amd_split_commit once every owner is mapped.
+        if (!h.dir_regular) return set_err(FEMTO_AMD_ERR_INVALID, "range-split needs the lane tables (index has a short non-final segment)");
+        const int64_t nb = h.number_of_blocks;
+        ix->split_parts = nparts;
+        ix->split_part = part;
+        ix->split_blo.resize(size_t(nparts) + 1);
+        for (int p = 0; p <= nparts; p++) ix->split_blo[size_t(p)] = nb * p / nparts;
+        const int64_t b0 = ix->split_blo[size_t(part)], b1 = ix->split_blo[size_t(part) + 1];
+        const uint64_t s0 = h.block_slot_start[size_t(b0)], s1 = h.block_slot_start[size_t(b1)];
+        uint64_t i0, i1;
+        block_image_range(h, b0, b1, &i0, &i1);
+        ix->split_seg_bytes = int64_t((s1 - s0) * kSegmentWords * 8);
+        ix->split_image_bytes = int64_t(i1 - i0);
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_segs), size_t(ix->split_seg_bytes) + 256));
+        HIP_TRY(hipMemset(ix->d_segs, 0, size_t(ix->split_seg_bytes) + 256));
+        if (s1 > s0) HIP_TRY(hipMemcpy(ix->d_segs, h.segs.data() + s0 * kSegmentWords, size_t(ix->split_seg_bytes), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_image), size_t(ix->split_image_bytes) + 256));  // + tail pad: mark reads load 16 bytes
+        HIP_TRY(hipMemset(ix->d_image, 0, size_t(ix->split_image_bytes) + 256));
+        if (i1 > i0) HIP_TRY(hipMemcpy(ix->d_image, h.image.data() + i0, size_t(ix->split_image_bytes), hipMemcpyHostToDevice));
+        ix->table_bytes += ix->split_seg_bytes;
+        ix->peer_segs.assign(size_t(nparts), nullptr);
+        ix->peer_image.assign(size_t(nparts), nullptr);
+        ix->peer_ipc.assign(size_t(nparts), 0);
+        ix->peer_segs[size_t(part)] = ix->d_segs;
+        ix->peer_image[size_t(part)] = ix->d_image;
+      }
       if ((r = upload(&ix->d_buckets, h.buckets, &ix->table_bytes))) return r;
-      if ((r = upload(&ix->d_seqs, h.seqs, &ix->table_bytes))) return r;
       if ((r = upload(&ix->d_occ_base, h.occ_base, &ix->table_bytes))) return r;
-      if ((r = upload(&ix->d_leaf_code, h.leaf_code, &ix->table_bytes))) return r;
       if ((r = upload(&ix->d_C, h.C, &ix->table_bytes))) return r;
-      if ((r = upload(&ix->d_segs, h.segs, &ix->table_bytes))) return r;
-      if ((r = upload(&ix->d_cum, h.cum, &ix->table_bytes))) return r;
-      if ((r = upload(&ix->d_hint, h.hint, &ix->table_bytes))) return r;
       if ((r = upload(&ix->d_bdir, h.bdir, &ix->table_bytes))) return r;
-      if ((r = upload(&ix->d_lnodes, h.lnodes, &ix->table_bytes))) return r;
-      if ((r = upload(&ix->d_lseqs, h.lseqs, &ix->table_bytes))) return r;
       if ((r = upload(&ix->d_occ, h.occ, &ix->table_bytes))) return r;
       {  // dense sort digits: characters with C[ch+1] > C[ch] occur in the text
         std::vector<uint8_t> dense(512, 0);
@@ -395,6 +442,7 @@ int femto_amd_open(const char* index_path, int device, femto_amd_index_t** out) 
         if (const char* pb = getenv("FEMTO_AMD_BLOCKS_PER_CU")) ix->blocks_per_cu_override = atoi(pb);
       }
       ix->mode = h.dir_regular ? 1 : 0;
+      if (split) return 0;  // lane kernels only
       if (const char* m = getenv("FEMTO_AMD_RANK_MODE")) {
         if (!strcmp(m, "raw")) ix->mode = 0;
         else if (!strcmp(m, "lane") && h.dir_regular) ix->mode = 1;
@@ -412,12 +460,138 @@ int femto_amd_open(const char* index_path, int device, femto_amd_index_t** out) 
   return FEMTO_AMD_OK;
 }
 
+int femto_amd_open(const char* index_path, int device, femto_amd_index_t** out) {
+  return open_impl(index_path, device, 0, 0, out);
+}
+
+int femto_amd_open_split(const char* index_path, int device, int part, int nparts, femto_amd_index_t** out) {
+  if (nparts < 1 || nparts > 64 || part < 0 || part >= nparts) return set_err(FEMTO_AMD_ERR_PARAM, "bad part / nparts");
+  if (device < 0) return set_err(FEMTO_AMD_ERR_PARAM, "a range-split index needs a device");
+  return open_impl(index_path, device, part, nparts, out);
+}
+
+int femto_amd_split_export(femto_amd_index_t* ix, void* handles /* 128 bytes */) {
+  if (!ix || !handles) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  if (ix->split_parts <= 0) return set_err(FEMTO_AMD_ERR_INVALID, "not a range-split index");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle blob layout");
+  HIP_TRY(hipSetDevice(ix->device));
+  hipIpcMemHandle_t hs[2];
+  HIP_TRY(hipIpcGetMemHandle(&hs[0], ix->d_segs));
+  HIP_TRY(hipIpcGetMemHandle(&hs[1], ix->d_image));
+  memcpy(handles, hs, sizeof hs);
+  return FEMTO_AMD_OK;
+}
+
+int femto_amd_split_attach(femto_amd_index_t* ix, int part, const void* handles) {
+  if (!ix || !handles) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  if (ix->split_parts <= 0) return set_err(FEMTO_AMD_ERR_INVALID, "not a range-split index");
+  if (part < 0 || part >= ix->split_parts) return set_err(FEMTO_AMD_ERR_PARAM, "bad part");
+  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  if (ix->split_ready) return set_err(FEMTO_AMD_ERR_INVALID, "already committed");
+  if (part == ix->split_part || ix->peer_segs[size_t(part)]) return FEMTO_AMD_OK;  // own slices / already mapped
+  HIP_TRY(hipSetDevice(ix->device));
+  hipIpcMemHandle_t hs[2];
+  memcpy(hs, handles, sizeof hs);
+  void *ps = nullptr, *pi = nullptr;
+  HIP_TRY(hipIpcOpenMemHandle(&ps, hs[0], hipIpcMemLazyEnablePeerAccess));
+  hipError_t e2 = hipIpcOpenMemHandle(&pi, hs[1], hipIpcMemLazyEnablePeerAccess);
+  if (e2 != hipSuccess) {
+    (void)hipIpcCloseMemHandle(ps);
+    return set_err(FEMTO_AMD_ERR_INVALID, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e2));
+  }
+  ix->peer_segs[size_t(part)] = ps;
+  ix->peer_image[size_t(part)] = pi;
+  ix->peer_ipc[size_t(part)] = 1;
+  return FEMTO_AMD_OK;
+}
+
+int femto_amd_split_attach_local(femto_amd_index_t* ix, femto_amd_index_t* owner) {
+  if (!ix || !owner) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  if (ix->split_parts <= 0 || owner->split_parts != ix->split_parts)
+    return set_err(FEMTO_AMD_ERR_INVALID, "both handles must be parts of the same range-split");
+  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  if (ix->split_ready) return set_err(FEMTO_AMD_ERR_INVALID, "already committed");
+  const int part = owner->split_part;
+  if (part == ix->split_part || ix->peer_segs[size_t(part)]) return FEMTO_AMD_OK;
+  if (owner->device != ix->device) {  // same process, another GPU: direct peer loads over xGMI
+    int can = 0;
+    HIP_TRY(hipDeviceCanAccessPeer(&can, ix->device, owner->device));
+    if (!can) return set_err(FEMTO_AMD_ERR_INVALID, "no peer access between the two devices");
+    HIP_TRY(hipSetDevice(ix->device));
+    hipError_t pe = hipDeviceEnablePeerAccess(owner->device, 0);
+    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+      return set_err(FEMTO_AMD_ERR_INVALID, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(pe));
+    (void)hipGetLastError();
+  }
+  ix->peer_segs[size_t(part)] = owner->d_segs;
+  ix->peer_image[size_t(part)] = owner->d_image;
+  return FEMTO_AMD_OK;
+}
+
+int femto_amd_split_commit(femto_amd_index_t* ix) {
+  if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
+  if (ix->split_parts <= 0) return set_err(FEMTO_AMD_ERR_INVALID, "not a range-split index");
+  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  if (ix->split_ready) return FEMTO_AMD_OK;
+  for (int p = 0; p < ix->split_parts; p++)
+    if (!ix->peer_segs[size_t(p)] || !ix->peer_image[size_t(p)])
+      return set_err(FEMTO_AMD_ERR_INVALID, "part " + std::to_string(p) + " is not attached");
+  HIP_TRY(hipSetDevice(ix->device));
+  HostIndex& h = ix->host;
+  // Rebase every sequence onto its owner's slice: offsets are relative to THIS part's bases and wrap
+  // modulo 2^64 (kernels add them with integer arithmetic, wrap_ptr in kernels.hip.hpp).
+  std::vector<LaneNode> ln = h.lnodes;
+  std::vector<LaneSeq> ls = h.lseqs;
+  const uint64_t my_segs = uint64_t(reinterpret_cast<uintptr_t>(ix->d_segs));
+  const uint64_t my_img = uint64_t(reinterpret_cast<uintptr_t>(ix->d_image));
+  for (int p = 0; p < ix->split_parts; p++) {
+    const int64_t b0 = ix->split_blo[size_t(p)], b1 = ix->split_blo[size_t(p) + 1];
+    if (b0 >= b1) continue;
+    const uint64_t dseg = uint64_t(reinterpret_cast<uintptr_t>(ix->peer_segs[size_t(p)])) - my_segs;
+    const uint64_t dimg = uint64_t(reinterpret_cast<uintptr_t>(ix->peer_image[size_t(p)])) - my_img;
+    if (dseg & 63) return set_err(FEMTO_AMD_ERR_INVALID, "peer mapping is not 64-byte aligned");
+    const uint64_t slot_delta = (dseg >> 6) - h.block_slot_start[size_t(b0)];   // in 64-byte slots, mod 2^58
+    uint64_t i0, i1;
+    block_image_range(h, b0, b1, &i0, &i1);
+    const uint64_t img_delta = dimg - i0;
+    for (uint64_t i = h.block_lnode_start[size_t(b0)]; i < h.block_lnode_start[size_t(b1)]; i++)
+      ln[size_t(i)].bs.seg_base += slot_delta;
+    for (uint64_t i = h.block_lseq_start[size_t(b0)]; i < h.block_lseq_start[size_t(b1)]; i++) {
+      ls[size_t(i)].mark_table.seg_base += slot_delta;
+      ls[size_t(i)].mark_array += img_delta;
+    }
+  }
+  int r;
+  if ((r = upload(&ix->d_lnodes, ln, &ix->table_bytes))) return r;
+  if ((r = upload(&ix->d_lseqs, ls, &ix->table_bytes))) return r;
+  ix->dev.lnodes = ix->d_lnodes;
+  ix->dev.lseqs = ix->d_lseqs;
+  ix->split_ready = true;
+  // the host copies of the big tables are no longer needed
+  std::vector<uint64_t>().swap(h.segs);
+  return FEMTO_AMD_OK;
+}
+
+int femto_amd_split_info(const femto_amd_index_t* ix, int* part, int* nparts, int64_t* seg_bytes, int64_t* image_bytes) {
+  if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
+  if (part) *part = ix->split_part;
+  if (nparts) *nparts = ix->split_parts;
+  if (seg_bytes) *seg_bytes = ix->split_seg_bytes;
+  if (image_bytes) *image_bytes = ix->split_image_bytes;
+  return FEMTO_AMD_OK;
+}
+
 void femto_amd_close(femto_amd_index_t* ix) {
   if (!ix) return;
   if (ix->device >= 0) {
     (void)hipSetDevice(ix->device);
     ix->t_count.drain();
     ix->t_locate.drain();
+    for (size_t p = 0; p < ix->peer_ipc.size(); p++)
+      if (ix->peer_ipc[p]) {
+        (void)hipIpcCloseMemHandle(ix->peer_segs[p]);
+        (void)hipIpcCloseMemHandle(ix->peer_image[p]);
+      }
     (void)hipFree(ix->d_image);
     (void)hipFree(ix->d_nodes);
     (void)hipFree(ix->d_buckets);
@@ -694,6 +868,7 @@ int femto_amd_forward_steps(femto_amd_index_t* ix, int64_t n, const int64_t* row
   int rc = ensure_device(ix);
   if (rc) return rc;
   if (!ix->host.dir_regular) return set_err(FEMTO_AMD_ERR_INVALID, "forward steps need the derived mark-table directory");
+  if (ix->split_parts > 0) return set_err(FEMTO_AMD_ERR_INVALID, "forward steps are not available on a range-split index");
   for (int64_t i = 0; i < n; i++)
     if (rows[i] < 0 || rows[i] >= ix->host.total_length) return set_err(FEMTO_AMD_ERR_PARAM, "row out of range");
   if (n == 0) return FEMTO_AMD_OK;
@@ -718,6 +893,7 @@ int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode) {
   if (!ix || mode < 0 || mode > 2) return set_err(FEMTO_AMD_ERR_PARAM, "bad rank mode");
   if (mode >= 1 && !ix->host.dir_regular)
     return set_err(FEMTO_AMD_ERR_INVALID, "this index has a short non-final segment: only the raw walk (mode 0) applies");
+  if (ix->split_parts > 0 && mode != 1) return set_err(FEMTO_AMD_ERR_INVALID, "a range-split index runs the lane kernels (mode 1) only");
   std::lock_guard<std::recursive_mutex> lk(ix->mu);
   ix->mode = mode;
   return FEMTO_AMD_OK;

@@ -359,6 +359,9 @@ int HostIndex::load(const std::string& path, Error* e) {
     const uint64_t boff = block_off[size_t(b)];
     const uint64_t blimit = boff + block_len[size_t(b)];
     const uint8_t* d = image.data() + boff;
+    block_slot_start.push_back(segs.size() / kSegmentWords);
+    block_lnode_start.push_back(lnodes.size());
+    block_lseq_start.push_back(lseqs.size());
     BlockHeader bh;
     rc = parse_block_header(d, block_len[size_t(b)], kDataBlockStart, &bh, e);
     if (rc) return rc;
@@ -522,6 +525,9 @@ int HostIndex::load(const std::string& path, Error* e) {
     }
   }
   if (gb != total_buckets) return fail(e, ERR_FORMAT, "bucket count mismatch");
+  block_slot_start.push_back(segs.size() / kSegmentWords);
+  block_lnode_start.push_back(lnodes.size());
+  block_lseq_start.push_back(lseqs.size());
   occ.resize(size_t(total_buckets) * kAlphaSize);
   for (int64_t g = 0; g < total_buckets; g++)
     for (int ch = 0; ch < kAlphaSize; ch++) {

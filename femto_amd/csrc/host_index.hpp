@@ -27,6 +27,9 @@ struct HostIndex {
   std::vector<uint8_t> image;           // all data blocks, each start 256-byte aligned (+ tail pad)
   std::vector<uint64_t> block_off;      // offset of data block b inside image
   std::vector<uint64_t> block_len;
+  // first segs slot / LaneNode / LaneSeq of every data block (+ one terminal entry): the derived tables are
+  // laid out block after block, which is what a range-split index (femto_amd_open_split) partitions on
+  std::vector<uint64_t> block_slot_start, block_lnode_start, block_lseq_start;
 
   // derived tables
   std::vector<DevNode> nodes;

@@ -394,6 +394,24 @@ __device__ __forceinline__ uint64_t read_bits(const uint8_t* __restrict__ image,
   return v >> (64 - bits);
 }
 
+// Range-split indexes (femto_amd_open_split) keep a sequence's segment lines / a character's mark array in
+// ANOTHER GPU's memory, mapped into this process (hipIpcOpenMemHandle / peer access over xGMI).  The lane tables
+// then hold offsets relative to the local base that wrap modulo 2^64, so the address arithmetic is done on
+// integers and the same kernels serve both layouts with no owner lookup.
+__device__ __forceinline__ const uint8_t* wrap_ptr(const void* base, uint64_t byte_off) {
+  return reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(base) + uintptr_t(byte_off));
+}
+// read_bits for an arbitrary (wrapped) base pointer: `bits` bits starting `bitpos` bits after p
+__device__ __forceinline__ uint64_t read_bits_ptr(const uint8_t* p, uint64_t bitpos, int bits) {
+  const uintptr_t a0 = reinterpret_cast<uintptr_t>(p) + uintptr_t(bitpos >> 3);
+  const uintptr_t al = a0 & ~uintptr_t(7);
+  const int s = int((a0 & 7) * 8 + (bitpos & 7));
+  const uint64_t a = ld_be64(reinterpret_cast<const uint8_t*>(al));
+  const uint64_t b = ld_be64(reinterpret_cast<const uint8_t*>(al + 8));
+  const uint64_t v = (a << s) | (s ? (b >> (64 - s)) : 0);
+  return v >> (64 - bits);
+}
+
 // One row per group: walk LF backwards until a marked row (do_back_query, src/main/server.c:2228-2359,
 // driven as do_context_query does with LOCATE_STRONG, :2627-2795).  offset = mark + steps (server.c:2718).
 template <int W>
@@ -556,7 +574,7 @@ __device__ __forceinline__ void rank_locate_segment(const DevIndex& ix, const La
 }
 
 __device__ __forceinline__ void rank_load_segment(const DevIndex& ix, RankJob& j, uint64_t (&w)[kSegmentWords]) {
-  const ulonglong2* sp = reinterpret_cast<const ulonglong2*>(ix.segs + j.slot * kSegmentWords);
+  const ulonglong2* sp = reinterpret_cast<const ulonglong2*>(wrap_ptr(ix.segs, j.slot * (kSegmentWords * 8ull)));
 #pragma unroll
   for (int k = 0; k < kSegmentWords / 2; k++) {
     const ulonglong2 v = sp[k];
@@ -577,7 +595,7 @@ __device__ __forceinline__ RankResult rank_finish(const DevIndex& ix, const Rank
   if (w[0] >> 63) {  // RLE segment (wtree.c:690-712)
     uint32_t bit = uint32_t(w[0] >> 62) & 1u;
     int p = 2;
-    if (j.has_aux) rle_skip(ix.segs + (j.slot + 1) * kSegmentWords, t - o0 - o1, o0, o1, bit, p);
+    if (j.has_aux) rle_skip(reinterpret_cast<const uint64_t*>(wrap_ptr(ix.segs, (j.slot + 1) * (kSegmentWords * 8ull))), t - o0 - o1, o0, o1, bit, p);
     uint64_t win = 0;
     int avail = 0;
     for (int it = 0; it < 512; it++) {
@@ -753,7 +771,7 @@ __global__ __launch_bounds__(256) void locate_kernel_lane(const DevIndex ix, con
     const RankResult m = bseq_rank_lane(ix, sq.mark_table, cnt);
     if (m.bit) {
       const uint64_t rec = uint64_t(m.o1) - 1;
-      result = int64_t(read_bits(ix.image, sq.mark_array * 8 + rec * uint64_t(ix.text_size_bits), ix.text_size_bits)) + steps;
+      result = int64_t(read_bits_ptr(wrap_ptr(ix.image, sq.mark_array), rec * uint64_t(ix.text_size_bits), ix.text_size_bits)) + steps;
       break;
     }
     if (sq.ch <= uint32_t(kSEOF)) break;
@@ -781,7 +799,7 @@ __global__ __launch_bounds__(256) void block_request_kernel_lane(const DevIndex 
   const LaneSeq sq = ix.lseqs[bk.seq_base + uint32_t(seq)];
   int64_t off = -1;
   const RankResult m = bseq_rank_lane(ix, sq.mark_table, cnt);
-  if (m.bit) off = int64_t(read_bits(ix.image, sq.mark_array * 8 + (uint64_t(m.o1) - 1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
+  if (m.bit) off = int64_t(read_bits_ptr(wrap_ptr(ix.image, sq.mark_array), (uint64_t(m.o1) - 1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
   int64_t occ;
   uint32_t ch = sq.ch;
   if (ch_in) {
@@ -1030,7 +1048,7 @@ __global__ __launch_bounds__(256) void locate_kernel_flat(const DevIndex ix, con
       const RankResult m = bseq_rank_lane(ix, mbs, idx);
       if (m.bit) {
         const uint64_t rec = uint64_t(m.o1) - 1;
-        offsets[item] = int64_t(read_bits(ix.image, marr * 8 + rec * uint64_t(ix.text_size_bits), ix.text_size_bits)) + steps;
+        offsets[item] = int64_t(read_bits_ptr(wrap_ptr(ix.image, marr), rec * uint64_t(ix.text_size_bits), ix.text_size_bits)) + steps;
         item += stride;
         st = LT_ITEM;
       } else if (mch <= uint32_t(kSEOF)) {

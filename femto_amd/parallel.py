@@ -93,3 +93,22 @@ def sharded_locate(locate_fn, plen, flat, starts, max_occs, device="cpu", dst=0)
     if rank != dst:
         return None
     return gn.cpu().numpy().astype(np.int32), go.cpu().numpy()
+
+
+def open_range_split(path, device, group=None):
+    """Open `path` RANGE-SPLIT over the ranks of `group` (one process per GPU): every rank keeps the
+    segment lines and block images of its own range of data blocks in HBM and maps the other ranks'
+    slices (hipIpc handles exchanged with one all_gather_object) -- remote lines are then read by
+    the kernels directly over xGMI; no collective runs during a query (femto_amd.h, "range-split")."""
+    import femto_amd
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    ix = femto_amd.Index(path, device=device, part=rank, nparts=world)
+    blobs = [None] * world
+    dist.all_gather_object(blobs, ix.split_export(), group=group)
+    for p, blob in enumerate(blobs):
+        if p != rank:
+            ix.split_attach(p, blob)
+    ix.split_commit()
+    dist.barrier(group=group)   # nobody queries before every owner's slices are mapped everywhere
+    return ix

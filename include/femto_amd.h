@@ -139,6 +139,32 @@ int femto_amd_block_requests(femto_amd_index_t* ix, int64_t n, const int64_t* ro
 int femto_amd_forward_steps(femto_amd_index_t* ix, int64_t n, const int64_t* rows, uint16_t* ch_out,
                             int64_t* row_out, int64_t* off_out);
 
+/* ---- range-split index (BASELINE.json configs[4]) ------------------------------
+ * The reference scales an index past memory by block: a row belongs to data block row / block_size
+ * (bsearch_block_rows, src/main/index.c:1613-1617) and blocks are faulted from disk one by one through
+ * its block cache.  On one MI355X node the blocks are partitioned over the GPUs and a "block fault" is a plain
+ * load: part p keeps the segment lines and block images of blocks [nblocks*p/nparts,
+ * nblocks*(p+1)/nparts) in its own HBM, maps the other parts' slices into its address space
+ * (hipIpcOpenMemHandle across processes, peer access inside one process) and the SAME lane kernels
+ * read remote lines over xGMI.  The small per-bucket tables (Occ bases, tree shapes, block
+ * directories) are replicated.  Every part answers any query; batches are sharded as with a
+ * replicated index.
+ *
+ *   femto_amd_open_split(path, dev, part, nparts, &ix)      on every part
+ *   femto_amd_split_export(ix, blob)                         128-byte blob, send to all other parts
+ *   femto_amd_split_attach(ix, p, blob_of_p)                 for every other part p   (other process)
+ *   femto_amd_split_attach_local(ix, handle_of_p)            ... or, same process
+ *   femto_amd_split_commit(ix)                               then count/locate as usual
+ * A part must stay open while any other part that attached it is in use.  Only the lane kernels
+ * (mode 1) run on a range-split index; femto_amd_forward_steps is not available. */
+int femto_amd_open_split(const char* index_path, int device, int part, int nparts, femto_amd_index_t** out);
+int femto_amd_split_export(femto_amd_index_t* ix, void* blob128);
+int femto_amd_split_attach(femto_amd_index_t* ix, int part, const void* blob128);
+int femto_amd_split_attach_local(femto_amd_index_t* ix, femto_amd_index_t* owner);
+int femto_amd_split_commit(femto_amd_index_t* ix);
+/* bytes of this part's own slices (segment lines, block images) */
+int femto_amd_split_info(const femto_amd_index_t* ix, int* part, int* nparts, int64_t* seg_bytes, int64_t* image_bytes);
+
 /* ---- kernel family ---------------------------------------------------------------------------- */
 /* mode 1 (default): one LANE per query; a rank reads one cumulative-count entry and one 64-byte
  * aligned segment slot from tables derived at load time (RLE segments also a 64-byte skip table).

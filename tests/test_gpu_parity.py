@@ -395,3 +395,86 @@ def test_multiquery_cpp_tool(fixtures, tmp_path, gpu_ok):
     raw = open(dump, "rb").read()
     assert np.array_equal(np.frombuffer(raw, dtype=np.int32, count=n), on)
     assert np.array_equal(np.frombuffer(raw, dtype=np.int64, offset=4 * n), oo)
+
+
+# ---- range-split index (femto_amd_open_split): blocks partitioned over parts, remote slices mapped ----------
+
+def _open_split_local(path, nparts):
+    parts = [femto_amd.Index(path, device=0, part=p, nparts=nparts) for p in range(nparts)]
+    for a in parts:
+        for b in parts:
+            if a is not b:
+                a.split_attach_local(b)
+    for a in parts:
+        a.split_commit()
+    return parts
+
+
+@pytest.mark.parametrize("nparts", [2, 3, 8])
+@pytest.mark.parametrize("name", INDEX_FIXTURES)
+def test_range_split_matches_reference_goldens(fixtures, gpu_ok, name, nparts):
+    """Every part of a range-split index (its own blocks in its own allocation, the others' reached through
+    rebased offsets) answers leaf requests, count and locate exactly like the reference."""
+    fx = fixtures(name)
+    g = fx.gold
+    parts = _open_split_local(fx.index, nparts)
+    nb = parts[0].info.number_of_blocks
+    infos = [p.split_info() for p in parts]
+    assert sum(1 for i in infos if i["seg_bytes"] > 0) == min(nb, nparts)
+    whole = femto_amd.Index(fx.index, device=-1)
+    assert sum(i["image_bytes"] for i in infos) <= whole.info.image_bytes
+    plen, flat, starts = fx.patterns
+    n = parts[0].info.total_length
+    rows = np.arange(n, dtype=np.int64)
+    for ix in parts:
+        ch, occ, off = ix.block_requests(rows)
+        assert np.array_equal(ch, g["L"])
+        assert np.array_equal(occ, g["occ"])
+        assert np.array_equal(off, g["off"])
+        first, last = ix.count_flat(plen, flat, starts)
+        assert np.array_equal(first, g["count_first"])
+        assert np.array_equal(last, g["count_last"])
+        for mo, noccs, offs in fx.locate_cases():
+            k, got = ix.locate_flat(plen, flat, starts, mo)
+            assert np.array_equal(k, noccs), mo
+            assert np.array_equal(got, offs), mo
+    for ix in parts:
+        ix.close()
+
+
+def test_range_split_needs_every_part(fixtures, gpu_ok):
+    fx = fixtures("acgt48k")
+    a = femto_amd.Index(fx.index, device=0, part=0, nparts=2)
+    plen, flat, starts = fx.patterns
+    with pytest.raises(femto_amd.FemtoAmdError) as ei:
+        a.count_flat(plen, flat, starts)
+    assert ei.value.code == 6   # ERR_INVALID
+    with pytest.raises(femto_amd.FemtoAmdError):
+        a.split_commit()
+    b = femto_amd.Index(fx.index, device=0, part=1, nparts=2)
+    a.split_attach_local(b)
+    a.split_commit()
+    with pytest.raises(femto_amd.FemtoAmdError):
+        a.set_rank_mode(0)
+    with pytest.raises(femto_amd.FemtoAmdError):
+        a.forward_steps(np.arange(4, dtype=np.int64))
+    first, last = a.count_flat(plen, flat, starts)
+    assert np.array_equal(first, fx.gold["count_first"])
+    a.close()
+    b.close()
+
+
+def test_range_split_across_processes(fixtures, gpu_ok, tmp_path):
+    """Two PROCESSES (one rank each, both on this box's single GPU): hipIpc handles travel through
+    torch.distributed, each rank maps the other's slices and answers the whole golden batch."""
+    import subprocess
+    import sys
+    fx = fixtures("acgt48k")
+    script = os.path.join(os.path.dirname(__file__), "split_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29577", script, fx.index, os.path.join(os.path.dirname(__file__), "golden", "acgt48k.npz"),
+                          str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    for r in range(2):
+        assert (tmp_path / f"ok{r}").exists()
