@@ -59,6 +59,7 @@ def lib():
         L.femto_amd_parallel_count.argtypes = [vp, i32, vp, vp, vp, vp]
         L.femto_amd_parallel_locate.argtypes = [vp, i32, vp, vp, i32, vp, vp]
         L.femto_amd_resolve_location.argtypes = [vp, i64, C.POINTER(i64), C.POINTER(i64)]
+        L.femto_amd_document_info.argtypes = [vp, i64, C.POINTER(C.c_char_p), C.POINTER(i64)]
         L.femto_amd_count_device.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
         L.femto_amd_locate_plan_device.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, vp, vp, vp]
         L.femto_amd_locate_walk_device.argtypes = [vp, i64, vp, vp, i64, vp, vp]
@@ -190,6 +191,12 @@ class Index:
 
     def locate(self, patterns, max_occs):
         return self.locate_flat(*flatten(patterns), max_occs)
+
+    def document_info(self, doc):
+        p, n = C.c_char_p(), C.c_int64(0)
+        pv = C.c_void_p()
+        _check(lib().femto_amd_document_info(self._h, int(doc), C.cast(C.byref(pv), C.POINTER(C.c_char_p)), C.byref(n)))
+        return C.string_at(pv.value, n.value) if n.value else b""
 
     def block_requests(self, rows, ch_in=None):
         rows = np.ascontiguousarray(rows, dtype=np.int64)

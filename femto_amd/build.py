@@ -38,15 +38,21 @@ TOOL_SRC = os.path.join(os.path.dirname(HERE), "tools", "femto_amd_multiquery.cp
 TOOL = os.path.join(HERE, "femto_amd_multiquery")
 
 
+SEARCH_SRC = os.path.join(os.path.dirname(HERE), "tools", "femto_amd_search.cpp")
+SEARCH = os.path.join(HERE, "femto_amd_search")
+
+
 def build_tools(force=False, verbose=False):
-    """The C++ host program over the C ABI (femto_multiquery's counterpart); plain g++, links the library."""
-    if not force and os.path.exists(TOOL) and os.path.getmtime(TOOL) > max(os.path.getmtime(TOOL_SRC), os.path.getmtime(LIB)):
-        return TOOL
-    cmd = ["g++", "-std=c++17", "-O2", "-o", TOOL, TOOL_SRC, "-L" + HERE, "-lfemto_amd", "-Wl,-rpath,$ORIGIN",
-           "-Wl,-rpath-link," + HERE, "-Wl,--allow-shlib-undefined"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    """The C++ host programs over the C ABI (femto_multiquery's and femto_search's counterparts); plain g++,
+    linked against the library."""
+    for src, exe in ((TOOL_SRC, TOOL), (SEARCH_SRC, SEARCH)):
+        if not force and os.path.exists(exe) and os.path.getmtime(exe) > max(os.path.getmtime(src), os.path.getmtime(LIB)):
+            continue
+        cmd = ["g++", "-std=c++17", "-O2", "-o", exe, src, "-L" + HERE, "-lfemto_amd", "-Wl,-rpath,$ORIGIN",
+               "-Wl,-rpath-link," + HERE, "-Wl,--allow-shlib-undefined"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
     return TOOL
 
 

@@ -643,6 +643,15 @@ int femto_amd_resolve_location(const femto_amd_index_t* ix, int64_t offset, int6
   return ix->host.resolve_location(offset, doc, doc_offset);
 }
 
+int femto_amd_document_info(const femto_amd_index_t* ix, int64_t doc, const char** info, int64_t* len) {
+  if (!ix || !info || !len) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  const uint8_t* p = nullptr;
+  int rc = ix->host.document_info(doc, &p, len);
+  if (rc) return set_err(rc, rc == FEMTO_AMD_ERR_PARAM ? "document number out of range" : "corrupt document info table");
+  *info = reinterpret_cast<const char*>(p);
+  return FEMTO_AMD_OK;
+}
+
 int femto_amd_count_device(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
                            const int64_t* d_starts, int64_t* d_first, int64_t* d_last, void* stream) {
   if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");

@@ -272,6 +272,16 @@ int HostIndex::resolve_location(int64_t offset, int64_t* doc, int64_t* doc_offse
   return OK;
 }
 
+int HostIndex::document_info(int64_t doc, const uint8_t** info, int64_t* len) const {
+  if (doc < 0 || doc >= number_of_documents) return ERR_PARAM;
+  const uint64_t start = be64(header.data() + doc_info_off + 8 * size_t(doc));
+  const uint64_t end = be64(header.data() + doc_info_off + 8 * size_t(doc) + 8);
+  if (start > end || end > header.size()) return ERR_FORMAT;
+  *info = header.data() + start;
+  *len = int64_t(end - start);
+  return OK;
+}
+
 int HostIndex::load(const std::string& path, Error* e) {
   struct stat st;
   if (stat(path.c_str(), &st)) return fail(e, ERR_IO, "Could not stat " + path);
@@ -319,7 +329,8 @@ int HostIndex::load(const std::string& path, Error* e) {
   const size_t c_off = kBlockHeaderSize;
   const size_t bo_off = c_off + 8 * size_t(kAlphaSize);
   const size_t de_off = bo_off + 8 * size_t(kAlphaSize) * size_t(number_of_blocks);
-  if (de_off + 8 * size_t(number_of_documents) > header.size()) return fail(e, ERR_FORMAT, "header block too short");
+  doc_info_off = de_off + 16 * size_t(number_of_documents);  // doc_ends, doc_eof_rows, then ndocs+1 info offsets
+  if (doc_info_off + 8 * (size_t(number_of_documents) + 1) > header.size()) return fail(e, ERR_FORMAT, "header block too short");
   C.resize(kAlphaSize + 1);
   for (int ch = 0; ch < kAlphaSize; ch++) C[size_t(ch)] = int64_t(be64(header.data() + c_off + 8 * size_t(ch)));
   C[kAlphaSize] = total_length;  // get_C, src/main/index.c:1545

@@ -51,6 +51,9 @@ struct HostIndex {
   // Returns 0 or an err_code_t value; fills err.msg.
   int load(const std::string& path, Error* err);
   int resolve_location(int64_t offset, int64_t* doc, int64_t* doc_offset) const;
+  // document_info (src/main/index.c:1768): the info string stored for a document (points into `header`)
+  int document_info(int64_t doc, const uint8_t** info, int64_t* len) const;
+  size_t doc_info_off = 0;              // header_block_doc_info_offset, src/main/index.c:895
 };
 
 }  // namespace femto_amd

@@ -106,6 +106,9 @@ int femto_amd_count_bytes(femto_amd_index_t* ix, int64_t npats, const int32_t* p
 
 /* Offset -> (document, offset in document): resolve_location (src/main/index.c:1587). */
 int femto_amd_resolve_location(const femto_amd_index_t* ix, int64_t offset, int64_t* doc, int64_t* doc_offset);
+/* The info string stored with a document (its path/URL): document_info (src/main/index.c:1768).  *info points
+ * into memory owned by the handle (valid until femto_amd_close; NOT NUL-terminated), *len its length. */
+int femto_amd_document_info(const femto_amd_index_t* ix, int64_t doc, const char** info, int64_t* len);
 
 /* ---- device-pointer batch API (inputs and outputs already resident in HBM) ---------------- */
 /* All pointers are device pointers on the index's device; `stream` is a hipStream_t passed as

@@ -478,3 +478,45 @@ def test_range_split_across_processes(fixtures, gpu_ok, tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     for r in range(2):
         assert (tmp_path / f"ok{r}").exists()
+
+
+def test_search_cli(fixtures, tmp_path, gpu_ok):
+    """femto_amd_search (femto_search's counterpart for literal patterns, search_tool.cc:1082-1113): --count,
+    --matches, document list and --offsets; expected text derived from the document bytes themselves."""
+    import subprocess
+    from femto_amd import build as b
+    b.build_tools()
+    tool = b.SEARCH
+    fx = fixtures("eng2doc")
+    infos = [os.path.basename(p).encode() for p in fx.doc_paths]
+    for pattern in [b"the", b"and ", b"zzzzqq", bytes(fx.docs[1][100:117])]:
+        hits = []
+        for d, doc in enumerate(fx.docs):
+            raw = doc.tobytes()
+            pos = raw.find(pattern)
+            while pos >= 0:
+                hits.append((d, pos))
+                pos = raw.find(pattern, pos + 1)
+        total = len(hits)
+        r = subprocess.run([tool, "--literal", "--count", fx.index, pattern], capture_output=True, check=True)
+        assert r.stdout == b"% 4d total matches\n" % total
+        r = subprocess.run([tool, "--literal", "--matches", "--pattern", pattern, fx.index], capture_output=True, check=True)
+        row = (b"% 4d \"" % total) + pattern + b"\"\n" if total else b""
+        assert r.stdout == row + b"% 4d total matches\n" % total
+        want_docs, want_offs = b"", b""
+        for d in sorted({h[0] for h in hits}):
+            want_docs += infos[d] + b"\n"
+            want_offs += infos[d] + b"\n\t" + b"".join(b" %d" % o for dd, o in hits if dd == d) + b"\n"
+        r = subprocess.run([tool, "--literal", fx.index, pattern], capture_output=True, check=True)
+        assert r.stdout == want_docs
+        out = str(tmp_path / "o.txt")
+        subprocess.run([tool, "--literal", "--offsets", "--output", out, fx.index, pattern], check=True)
+        assert open(out, "rb").read() == want_offs
+        r = subprocess.run([tool, "--literal", "--offsets", "--null", fx.index, pattern], capture_output=True, check=True)
+        assert r.stdout == want_offs.replace(b"\n", b"\0")
+    # two indexes: counts add up; a regular expression is refused rather than misread
+    r = subprocess.run([tool, "--count", fx.index, fx.index, "the"], capture_output=True, check=True)
+    n1 = int(subprocess.run([tool, "--count", fx.index, "the"], capture_output=True, check=True).stdout.split()[0])
+    assert int(r.stdout.split()[0]) == 2 * n1
+    r = subprocess.run([tool, "--count", fx.index, "th.*e"], capture_output=True)
+    assert r.returncode != 0 and b"regular expressions are not supported" in r.stderr

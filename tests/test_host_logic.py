@@ -152,3 +152,16 @@ def test_multiquery_tool_fails_loudly_without_gpu(fixtures):
     if not torch.cuda.is_available():
         r = subprocess.run([tool, fx.index, "-count"], input=b"# number=1 length=4 x\nACGT", capture_output=True)
         assert r.returncode == 1 and b"no CPU fallback" in r.stderr
+
+
+def test_document_info_matches_what_the_reference_stored(fixtures):
+    """document_info (src/main/index.c:1768): the reference-built fixtures carry the document file names."""
+    for name in ["eng2doc", "runs3doc", "chunks2doc", "acgt48k"]:
+        fx = fixtures(name)
+        ix = femto_amd.Index(fx.index, device=-1)
+        assert ix.info.number_of_documents == len(fx.docs)
+        for d, p in enumerate(fx.doc_paths):
+            assert ix.document_info(d) == os.path.basename(p).encode()
+        with pytest.raises(femto_amd.FemtoAmdError):
+            ix.document_info(len(fx.docs))
+        ix.close()
