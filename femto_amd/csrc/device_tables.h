@@ -120,6 +120,13 @@ struct DevIndex {           // passed by value to kernels
   const LaneNode* lnodes;   // parallel to nodes[]
   const LaneSeq* lseqs;     // parallel to seqs[]
   const OccEntry* occ;      // [gb*261 + ch]
+  // small-alphabet packed lines (pack_kernels.hip.hpp); null when the index has more than 8 characters
+  const uint32_t* pack;     // 32 dwords per 160 rows
+  const int64_t* pack_sa;   // offsets of the marked rows, row order
+  const uint8_t* pack_code; // [261] alpha code -> dense code 0..7, 0xff: not in the text
+  uint16_t pack_alpha[8];   // dense code -> alpha code
+  int32_t pack_sigma;
+  uint32_t pack_stop;       // bit c: alpha code of dense code c is <= SEOF (a locate walk stops there)
   int64_t total_length;
   int64_t total_buckets;
   int32_t b_size;

@@ -14,6 +14,7 @@
 #include "host_index.hpp"
 #include "index_builder.hpp"
 #include "kernels.hip.hpp"
+#include "pack_kernels.hip.hpp"
 
 using namespace femto_amd;
 
@@ -109,7 +110,13 @@ struct femto_amd_index {
   LaneSeq* d_lseqs = nullptr;
   OccEntry* d_occ = nullptr;
   int* d_err = nullptr;
-  int mode = 1;  // 1: lane-per-query kernels (default); 2: flattened persistent-lane kernels; 0: wavefront-cooperative raw A/S/D walk
+  int mode = 1;  // 3: packed small-alphabet lines (default when the index has <= 8 characters); 1: lane-per-query kernels
+                 // (default otherwise); 2: flattened persistent-lane kernels; 0: wavefront-cooperative raw A/S/D walk
+  uint32_t* d_pack = nullptr;
+  int64_t* d_pack_sa = nullptr;
+  uint8_t* d_pack_code = nullptr;
+  int64_t pack_bytes = 0;
+  double pack_build_ms = 0;
   int num_cus = 256;
   int blocks_per_cu_override = 0;
   DevIndex dev{};
@@ -182,7 +189,7 @@ int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen
   if (ix->timing) {  // events bracket the search kernel itself (the suffix-order sort is a separate, small launch)
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    if (ix->mode != 1) HIP_TRY(hipEventRecord(e0, stream));
+    if (ix->mode != 1 && ix->mode != 3) HIP_TRY(hipEventRecord(e0, stream));
   }
   if (ix->mode == 2) {
     int64_t lblocks = (npats + kBlockThreads - 1) / kBlockThreads;
@@ -196,7 +203,7 @@ int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen
     }
     hipLaunchKernelGGL((count_kernel_flat<1>), dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats,
                          d_plen, d_pats, d_starts, d_first, d_last, ix->d_err);
-  } else if (ix->mode == 1) {
+  } else if (ix->mode == 1 || ix->mode == 3) {
     const int64_t lblocks = (npats + kBlockThreads - 1) / kBlockThreads;
     const uint32_t* perm = nullptr;
     if (ix->sort_queries && npats >= ix->sort_min && npats < (int64_t(1) << 32)) {
@@ -214,8 +221,12 @@ int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen
       perm = ix->s_idx2.as<uint32_t>();
     }
     if (ix->timing) HIP_TRY(hipEventRecord(e0, stream));
-    hipLaunchKernelGGL(count_kernel_lane, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
-                       d_pats, d_starts, d_first, d_last, ix->d_err, perm);
+    if (ix->mode == 3)
+      hipLaunchKernelGGL(count_kernel_pack, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
+                         d_pats, d_starts, d_first, d_last, ix->d_err, perm);
+    else
+      hipLaunchKernelGGL(count_kernel_lane, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
+                         d_pats, d_starts, d_first, d_last, ix->d_err, perm);
   } else {
     hipLaunchKernelGGL((count_kernel<kGroupW>), dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats,
                        d_plen, d_pats, d_starts, d_first, d_last, ix->d_err);
@@ -286,6 +297,10 @@ int launch_locate(femto_amd_index* ix, int64_t npats, const int64_t* d_first, co
     }
     hipLaunchKernelGGL(locate_kernel_flat, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_first,
                        d_out_starts, total, d_offsets);
+  } else if (ix->mode == 3) {
+    const int64_t lblocks = (total + kBlockThreads - 1) / kBlockThreads;
+    hipLaunchKernelGGL(locate_kernel_pack, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_first,
+                       d_out_starts, total, d_offsets);
   } else if (ix->mode == 1) {
     const int64_t lblocks = (total + kBlockThreads - 1) / kBlockThreads;
     hipLaunchKernelGGL(locate_kernel_lane, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_first,
@@ -325,6 +340,84 @@ int stage_patterns(femto_amd_index* ix, int64_t npats, const int32_t* plen, cons
   }
   if (total) HIP_TRY(hipMemcpy(ix->s_pats.p, pats, size_t(total) * 2, hipMemcpyHostToDevice));
   return 0;
+}
+
+
+// Derives the packed lines of pack_kernels.hip.hpp on the GPU from the uploaded index (needs the lane tables).
+int build_pack(femto_amd_index* ix) {
+  HostIndex& h = ix->host;
+  if (!h.dir_regular || h.total_length <= 0) return 0;
+  if (const char* e = getenv("FEMTO_AMD_PACK")) if (atoi(e) == 0) return 0;
+  std::vector<uint8_t> code(264, 0xff);
+  int sigma = 0;
+  for (int ch = 0; ch < kAlphaSize; ch++)
+    if (h.C[size_t(ch) + 1] > h.C[size_t(ch)]) {
+      if (sigma == 8) return 0;  // more than 8 distinct characters: the wavelet path stays
+      ix->dev.pack_alpha[sigma] = uint16_t(ch);
+      if (ch <= kSEOF) ix->dev.pack_stop |= 1u << sigma;
+      code[size_t(ch)] = uint8_t(sigma++);
+    }
+  for (int c = sigma; c < 8; c++) ix->dev.pack_alpha[c] = uint16_t(kAlphaSize);
+  ix->dev.pack_sigma = sigma;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, nullptr));
+  int r;
+  if ((r = upload(&ix->d_pack_code, code, &ix->table_bytes))) return r;
+  ix->dev.pack_code = ix->d_pack_code;
+  const int64_t n = h.total_length;
+  const int64_t nlines = (n + kPackRows - 1) / kPackRows;
+  const int64_t stride = nlines + 1;
+  DeviceBuffer sym, counts, scans;
+  auto cleanup = [&]() { sym.release(); counts.release(); scans.release(); };
+  auto body = [&]() -> int {
+    int rc;
+    if ((rc = sym.reserve(size_t(nlines) * kPackRows))) return rc;
+    if ((rc = counts.reserve(size_t(9 * stride) * 8))) return rc;
+    if ((rc = scans.reserve(size_t(9 * stride) * 8))) return rc;
+    HIP_TRY(hipMemset(sym.p, 0, size_t(nlines) * kPackRows));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_pack), size_t(nlines) * kPackLineWords * 4));
+    const int64_t chunk = int64_t(1) << 30;
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+      const int64_t cn = std::min(chunk, n - r0);
+      hipLaunchKernelGGL(pack_extract_kernel, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, r0, cn, sym.as<uint8_t>());
+    }
+    hipLaunchKernelGGL(pack_planes_kernel, dim3(uint32_t((nlines + 255) / 256)), dim3(256), 0, nullptr, nlines, sym.as<uint8_t>(),
+                       ix->d_pack, counts.as<int64_t>(), stride);
+    HIP_TRY(hipGetLastError());
+    for (int c = 0; c < 9; c++)
+      if ((rc = device_scan(ix, nlines, counts.as<int64_t>() + c * stride, scans.as<int64_t>() + c * stride, 0, nullptr))) return rc;
+    hipLaunchKernelGGL(pack_counts_kernel, dim3(uint32_t((nlines + 255) / 256)), dim3(256), 0, nullptr, ix->dev, nlines, ix->d_pack,
+                       scans.as<int64_t>(), stride);
+    HIP_TRY(hipGetLastError());
+    int64_t nmarks = 0;
+    HIP_TRY(hipMemcpy(&nmarks, scans.as<int64_t>() + 8 * stride + nlines, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_pack_sa), size_t(nmarks > 0 ? nmarks : 1) * 8));
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+      const int64_t cn = std::min(chunk, n - r0);
+      hipLaunchKernelGGL(pack_sa_kernel, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, r0, cn, sym.as<uint8_t>(),
+                         ix->d_pack, ix->d_pack_sa);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    ix->pack_bytes = nlines * kPackLineWords * 4 + nmarks * 8;
+    ix->table_bytes += ix->pack_bytes;
+    return 0;
+  };
+  r = body();
+  cleanup();
+  if (r == 0) {
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    ix->pack_build_ms = ms;
+    ix->dev.pack = ix->d_pack;
+    ix->dev.pack_sa = ix->d_pack_sa;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return r;
 }
 
 }  // namespace
@@ -443,10 +536,13 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
       }
       ix->mode = h.dir_regular ? 1 : 0;
       if (split) return 0;  // lane kernels only
+      if ((r = build_pack(ix))) return r;
+      if (ix->dev.pack) ix->mode = 3;
       if (const char* m = getenv("FEMTO_AMD_RANK_MODE")) {
         if (!strcmp(m, "raw")) ix->mode = 0;
         else if (!strcmp(m, "lane") && h.dir_regular) ix->mode = 1;
         else if (!strcmp(m, "flat") && h.dir_regular) ix->mode = 2;
+        else if (!strcmp(m, "pack") && ix->dev.pack) ix->mode = 3;
       }
       return 0;
     };
@@ -608,6 +704,9 @@ void femto_amd_close(femto_amd_index_t* ix) {
     (void)hipFree(ix->d_occ);
     (void)hipFree(ix->d_err);
     (void)hipFree(ix->d_dense);
+    (void)hipFree(ix->d_pack);
+    (void)hipFree(ix->d_pack_sa);
+    (void)hipFree(ix->d_pack_code);
     for (DeviceBuffer* b : {&ix->s_plen, &ix->s_pats, &ix->s_starts, &ix->s_first, &ix->s_last, &ix->s_noccs,
                             &ix->s_noccs64, &ix->s_out_starts, &ix->s_offsets, &ix->s_scan[0], &ix->s_scan[1],
                             &ix->s_scan[2], &ix->s_rows, &ix->s_ch, &ix->s_occ, &ix->s_off, &ix->s_keys, &ix->s_keys2, &ix->s_idx,
@@ -841,7 +940,11 @@ int femto_amd_block_requests(femto_amd_index_t* ix, int64_t n, const int64_t* ro
     HIP_TRY(hipMemcpy(d_chin, ch_in, size_t(n) * 2, hipMemcpyHostToDevice));
   }
   const int64_t blocks = (n * kGroupW + kBlockThreads - 1) / kBlockThreads;
-  if (ix->mode >= 1)
+  if (ix->mode == 3)
+    hipLaunchKernelGGL(block_request_kernel_pack, dim3(uint32_t((n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads),
+                       0, nullptr, ix->dev, n, ix->s_rows.as<int64_t>(), d_chin, d_chout, ix->s_occ.as<int64_t>(),
+                       ix->s_off.as<int64_t>());
+  else if (ix->mode >= 1)
     hipLaunchKernelGGL(block_request_kernel_lane, dim3(uint32_t((n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads),
                        0, nullptr, ix->dev, n, ix->s_rows.as<int64_t>(), d_chin, d_chout, ix->s_occ.as<int64_t>(),
                        ix->s_off.as<int64_t>());
@@ -899,7 +1002,9 @@ int femto_amd_forward_steps(femto_amd_index_t* ix, int64_t n, const int64_t* row
 }
 
 int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode) {
-  if (!ix || mode < 0 || mode > 2) return set_err(FEMTO_AMD_ERR_PARAM, "bad rank mode");
+  if (!ix || mode < 0 || mode > 3) return set_err(FEMTO_AMD_ERR_PARAM, "bad rank mode");
+  if (mode == 3 && !ix->dev.pack)
+    return set_err(FEMTO_AMD_ERR_INVALID, "packed lines (mode 3) exist only for indexes with at most 8 distinct characters");
   if (mode >= 1 && !ix->host.dir_regular)
     return set_err(FEMTO_AMD_ERR_INVALID, "this index has a short non-final segment: only the raw walk (mode 0) applies");
   if (ix->split_parts > 0 && mode != 1) return set_err(FEMTO_AMD_ERR_INVALID, "a range-split index runs the lane kernels (mode 1) only");
@@ -909,6 +1014,14 @@ int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode) {
 }
 
 int femto_amd_get_rank_mode(const femto_amd_index_t* ix) { return ix ? ix->mode : -1; }
+
+int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* bytes, double* build_ms) {
+  if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
+  if (available) *available = ix->dev.pack != nullptr;
+  if (bytes) *bytes = ix->pack_bytes;
+  if (build_ms) *build_ms = ix->pack_build_ms;
+  return FEMTO_AMD_OK;
+}
 
 void femto_amd_kernel_time_enable(femto_amd_index_t* ix, int on) {
   if (ix) ix->timing = on != 0;

@@ -176,6 +176,12 @@ int femto_amd_split_info(const femto_amd_index_t* ix, int* part, int* nparts, in
  * A0/A1/AP group tables and varbyte S sums with __ballot/ds_bpermute (no derived rank tables).  All
  * are bit-exact; FEMTO_AMD_RANK_MODE=lane|flat|raw selects the default at open. */
 int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode);
+/* mode 3 ("pack", the default when it applies): for indexes with at most 8 distinct characters (DNA) the
+ * loader derives, on the GPU, one self-contained 128-byte line per 160 rows -- three bit planes of the dense
+ * character code, a "row is marked" plane, and C[ch]+Occ before the line for each character -- plus the
+ * marked rows' offsets in row order, so that an Occ and a whole locate step each read ONE memory line instead of
+ * 2-5 (femto_amd/csrc/pack_kernels.hip.hpp).  Same results, bit for bit.  FEMTO_AMD_PACK=0 skips the derivation. */
+int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* bytes, double* build_ms);
 int femto_amd_get_rank_mode(const femto_amd_index_t* ix);
 
 /* ---- profiling hooks ---------------------------------------------------------------------- */

@@ -21,7 +21,17 @@ def gpu_ok():
     return True
 
 
-MODES = [1, 2, 0]   # 1: lane per query (default); 2: flattened persistent lanes; 0: wavefront-per-query raw walk
+# 3: packed small-alphabet lines (default when the index has <= 8 characters); 1: lane per query (default otherwise);
+# 2: flattened persistent lanes; 0: wavefront-per-query raw walk
+MODES = [3, 1, 2, 0]
+
+
+def _set_mode(ix, mode):
+    if mode == 3 and not ix.pack_info()["available"]:
+        ix.close()
+        pytest.skip("more than 8 distinct characters: no packed lines for this index")
+    ix.set_rank_mode(mode)
+    assert ix.rank_mode == mode
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -31,7 +41,7 @@ def test_leaf_requests_match_reference(fixtures, gpu_ok, name, mode):
     fx = fixtures(name)
     g = fx.gold
     ix = femto_amd.Index(fx.index, device=0)
-    ix.set_rank_mode(mode)
+    _set_mode(ix, mode)
     n = ix.info.total_length
     rows = np.arange(n, dtype=np.int64)
     ch, occ, off = ix.block_requests(rows)
@@ -51,8 +61,7 @@ def test_leaf_requests_match_reference(fixtures, gpu_ok, name, mode):
 def test_count_locate_match_reference_goldens(fixtures, gpu_ok, name, mode):
     fx = fixtures(name)
     ix = femto_amd.Index(fx.index, device=0)
-    ix.set_rank_mode(mode)
-    assert ix.rank_mode == mode
+    _set_mode(ix, mode)
     plen, flat, starts = fx.patterns
     first, last = ix.count_flat(plen, flat, starts)
     assert np.array_equal(first, fx.gold["count_first"])
@@ -171,7 +180,8 @@ def test_gpu_built_index_vs_oracle_medium(tmp_path, gpu_ok, mode):
     text = tg.t_acgt(1 << 22, 2024)
     path = _random_index(tmp_path, text, None, "acgt4m")
     ix = femto_amd.Index(path, device=0)
-    ix.set_rank_mode(mode)
+    assert ix.rank_mode == 3          # DNA alphabet: the packed lines are the default path
+    _set_mode(ix, mode)
     o = po.Oracle(path)
     assert ix.info.total_length == o.total_length == len(text) + 1
     plen_r, flat_r = tg.p_rand(20, 50000, 7)
@@ -201,7 +211,8 @@ def test_gpu_built_english_like_vs_oracle(tmp_path, gpu_ok, mode):
     text = tg.t_eng(3 << 20, 99)
     path = _random_index(tmp_path, text, "block_size=2097152,bucket_size=262144,mark_period=20", "eng3m")
     ix = femto_amd.Index(path, device=0)
-    ix.set_rank_mode(mode)
+    assert ix.rank_mode == 1 and not ix.pack_info()["available"]
+    _set_mode(ix, mode)
     o = po.Oracle(path)
     plen, flat = tg.p_hit(8, 64, 40000, 5, text)
     starts = tg.starts_of(plen)
@@ -271,7 +282,12 @@ def test_random_indexes_vs_oracle(tmp_path, gpu_ok, seed):
     rows = rng.integers(0, nrows, 500).astype(np.int64)
     want_fw = [o.forward_step(int(r)) for r in rows]
     want_bw = [o.block_request(int(r), 7) for r in rows]
+    distinct = len(np.unique(text)) + 1          # + SEOF
+    assert ix.pack_info()["available"] == (distinct <= 8)
+    assert ix.rank_mode == (3 if distinct <= 8 else 1)
     for mode in MODES:
+        if mode == 3 and distinct > 8:
+            continue
         ix.set_rank_mode(mode)
         f, l_ = ix.count_flat(plen, flat, starts)
         assert np.array_equal(f, of) and np.array_equal(l_, ol), (seed, mode, params)
@@ -367,6 +383,19 @@ def test_full_size_1gib_properties(tmp_path, gpu_ok):
     gn, go = ix.locate_flat(p2, f2, s2, 100)
     on, oo = o.locate_flat(p2, f2, s2, 100, threads=16)
     assert np.array_equal(gn, on) and np.array_equal(go, oo)
+    # the packed lines (default here) and the wavelet path agree on the whole million-pattern batch and on
+    # two million leaf requests spread over all rows
+    assert ix.rank_mode == 3
+    rows2 = np.random.Generator(np.random.PCG64(17)).integers(0, ix.info.total_length, 2_000_000).astype(np.int64)
+    leaf3 = ix.block_requests(rows2)
+    ix.set_rank_mode(1)
+    first1, last1 = ix.count_flat(plen, flat, starts)
+    assert np.array_equal(first1, first) and np.array_equal(last1, last)
+    noccs1, offs1 = ix.locate_flat(plen, flat, starts, 100)
+    assert np.array_equal(noccs1, noccs) and np.array_equal(offs1, offs)
+    leaf1 = ix.block_requests(rows2)
+    for a, b in zip(leaf3, leaf1):
+        assert np.array_equal(a, b)
 
 
 def test_multiquery_cpp_tool(fixtures, tmp_path, gpu_ok):
