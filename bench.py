@@ -32,8 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-KERNEL_NAMES = {1: "count_kernel_lane", 2: "count_kernel_flat<1>", 0: "count_kernel<32>"}
-LOCATE_NAMES = {1: "locate_kernel_lane", 2: "locate_kernel_flat", 0: "locate_kernel<32>"}
+KERNEL_NAMES = {3: "count_kernel_pack<true>", 1: "count_kernel_lane", 2: "count_kernel_flat<1>", 0: "count_kernel<32>"}
+LOCATE_NAMES = {3: "locate_kernel_pack", 1: "locate_kernel_lane", 2: "locate_kernel_flat", 0: "locate_kernel<32>"}
 
 
 def log(*a):
@@ -300,7 +300,12 @@ def main():
     # ---- roofline of the dominant kernel: algorithmic bytes per launch / average kernel duration
     roof = None
     if sample > 0 and cnt_n > 0:
-        def alg(c):   # N_rank*(12 + 64 + S_rank) + N_occ*20 + N_mark*8, counters from the CPU restatement
+        packed = ix.rank_mode == 3
+
+        def alg(c):
+            if packed:    # packed lines: every Occ / LF step (= one leaf request of the restatement) reads ONE 128-byte line,
+                return c["n_occ"] * 128 + c["n_mark"] * 8   # every located row one 8-byte offset
+            # wavelet path, SURVEY.md 8(d): N_rank*(12 + 64 + S_rank) + N_occ*20 + N_mark*8, counters from the CPU restatement
             return c["n_rank"] * (12 + 64) + c["s_bytes"] + c["n_occ"] * 20 + c["n_mark"] * 8
         cc, ca = c_count.asdict(), c_all.asdict()
         cl = {k: ca[k] - cc[k] for k in ca}       # locate_flat re-runs the count: walk only = all - count
@@ -315,7 +320,7 @@ def main():
             try:
                 tj = json.load(open(args.traffic_json))
                 if (tj.get("npats") == npats and tj.get("text_log2") == args.text_log2 and tj.get("workload") == args.workload
-                        and dominant_is_count):
+                        and tj.get("kernel") == (KERNEL_NAMES if dominant_is_count else LOCATE_NAMES)[ix.rank_mode]):
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -330,8 +335,12 @@ def main():
                                 "S_bytes_per_rank": k_c["s_bytes"] / max(1, k_c["n_rank"]),
                                 "bytes": alg(k_c) / sample},
                 "contract_335B_per_occ_GBs": 335.0 * k_c["n_occ"] * scale / (k_ms * 1e-3) / 1e9,
-                "note": "frac can exceed 1: the batch is processed in suffix order, so neighbouring lanes share cache lines "
-                        "and part of the algorithmic bytes never leaves L1/L2 (see traffic)"}
+                "wavelet_path_equivalent_GBs": (k_c["n_rank"] * (12 + 64) + k_c["s_bytes"] + k_c["n_occ"] * 20 + k_c["n_mark"] * 8)
+                * scale / (k_ms * 1e-3) / 1e9,
+                "bytes_model": ("packed lines: 128 B per Occ / LF step + 8 B per located row" if packed else
+                                "wavelet path: N_rank*(12+64+S) + N_occ*20 + N_mark*8 (SURVEY 8d)"),
+                "note": "the batch is processed in suffix order, so neighbouring lanes share cache lines and part of the "
+                        "algorithmic bytes never leaves L1/L2 (traffic < algorithmic bytes; frac may exceed 1)"}
 
     wl = {"acgt": f"T_acgt(2^{args.text_log2}) femto index (default params), {npats} P_rand 20-mers per GPU, count()+locate(max_occs={args.max_occs})",
           "acgt_hit": f"T_acgt(2^{args.text_log2}) femto index (default params), {npats} P_hit 20-mers per GPU, count()+locate(max_occs={args.max_occs})",
@@ -343,8 +352,9 @@ def main():
         "vs_baseline": None, "dtype": "int64", "data": "synthetic",
         "config": {"workload": wl, "text_bytes": n_text, "patterns_per_gpu": npats, "pattern_len": args.plen, "seed": args.seed,
                    "located_rows_per_gpu": batch.total, "matched_patterns_frac": float(np.mean(last >= first)),
-                   "index": {"rows": int(info.total_length), "blocks": int(info.number_of_blocks), "buckets": int(info.total_buckets),
-                             "image_bytes": int(info.image_bytes), "table_bytes": int(info.table_bytes)},
+                   "rank_mode": {3: "pack", 1: "lane", 2: "flat", 0: "raw"}[ix.rank_mode], "index": {"rows": int(info.total_length), "blocks": int(info.number_of_blocks), "buckets": int(info.total_buckets),
+                             "image_bytes": int(info.image_bytes), "table_bytes": int(info.table_bytes),
+                             "packed_lines": ix.pack_info()},
                    "parallelism": ("range-split index (1/N of the blocks per GPU, peer loads over xGMI)" if args.layout == "split" and world > 1 else "replicated index") + f", query shards x{world}" + (", RCCL gather of (first,last) to rank 0 every step, overlapped with the next step's kernels" if world > 1 else ""),
                    "build_s": build_s, "open_s": open_s},
         "roofline": roof, "cpu_baseline": cpu,

@@ -115,6 +115,7 @@ struct femto_amd_index {
   uint32_t* d_pack = nullptr;
   int64_t* d_pack_sa = nullptr;
   uint8_t* d_pack_code = nullptr;
+  int64_t* d_pack_c = nullptr;
   int64_t pack_bytes = 0;
   double pack_build_ms = 0;
   int num_cus = 256;
@@ -221,9 +222,13 @@ int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen
       perm = ix->s_idx2.as<uint32_t>();
     }
     if (ix->timing) HIP_TRY(hipEventRecord(e0, stream));
-    if (ix->mode == 3)
-      hipLaunchKernelGGL(count_kernel_pack, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
-                         d_pats, d_starts, d_first, d_last, ix->d_err, perm);
+    if (ix->mode == 3 && perm)
+      hipLaunchKernelGGL(count_kernel_pack<true>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
+                         d_pats, d_starts, d_first, d_last, ix->d_err, perm, ix->s_keys2.as<uint64_t>(), ix->dense_bits,
+                         64 / ix->dense_bits);
+    else if (ix->mode == 3)
+      hipLaunchKernelGGL(count_kernel_pack<false>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
+                         d_pats, d_starts, d_first, d_last, ix->d_err, perm, nullptr, 1, 0);
     else
       hipLaunchKernelGGL(count_kernel_lane, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
                          d_pats, d_starts, d_first, d_last, ix->d_err, perm);
@@ -358,6 +363,11 @@ int build_pack(femto_amd_index* ix) {
       code[size_t(ch)] = uint8_t(sigma++);
     }
   for (int c = sigma; c < 8; c++) ix->dev.pack_alpha[c] = uint16_t(kAlphaSize);
+  std::vector<int64_t> pc(16, 0);
+  for (int c = 0; c < sigma; c++) {
+    pc[size_t(c)] = h.C[ix->dev.pack_alpha[c]];
+    pc[8 + size_t(c)] = h.C[size_t(ix->dev.pack_alpha[c]) + 1] - 1;
+  }
   ix->dev.pack_sigma = sigma;
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
@@ -366,6 +376,8 @@ int build_pack(femto_amd_index* ix) {
   int r;
   if ((r = upload(&ix->d_pack_code, code, &ix->table_bytes))) return r;
   ix->dev.pack_code = ix->d_pack_code;
+  if ((r = upload(&ix->d_pack_c, pc, &ix->table_bytes))) return r;
+  ix->dev.pack_c = ix->d_pack_c;
   const int64_t n = h.total_length;
   const int64_t nlines = (n + kPackRows - 1) / kPackRows;
   const int64_t stride = nlines + 1;
@@ -707,6 +719,7 @@ void femto_amd_close(femto_amd_index_t* ix) {
     (void)hipFree(ix->d_pack);
     (void)hipFree(ix->d_pack_sa);
     (void)hipFree(ix->d_pack_code);
+    (void)hipFree(ix->d_pack_c);
     for (DeviceBuffer* b : {&ix->s_plen, &ix->s_pats, &ix->s_starts, &ix->s_first, &ix->s_last, &ix->s_noccs,
                             &ix->s_noccs64, &ix->s_out_starts, &ix->s_offsets, &ix->s_scan[0], &ix->s_scan[1],
                             &ix->s_scan[2], &ix->s_rows, &ix->s_ch, &ix->s_occ, &ix->s_off, &ix->s_keys, &ix->s_keys2, &ix->s_idx,

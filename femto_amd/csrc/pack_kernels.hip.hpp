@@ -66,70 +66,74 @@ __device__ __forceinline__ uint32_t pack_match(const PackPlanes& P, uint32_t cod
   return cnt;
 }
 
-// do_string_query (src/main/server.c:713-946): one lane per pattern, one line per Occ
+// do_string_query (src/main/server.c:713-946): one lane per pattern, one line per Occ.
+// kKeys: the batch was suffix-sorted (query_sort.hip) and keys[slot] holds the dense codes (1 + pack code, 0 = none)
+// of the pattern's last `nsym` symbols, last symbol in the most significant field: the symbols are then taken from
+// the key -- one coalesced 8-byte read per pattern -- instead of 2-byte reads scattered over the batch, which cost a
+// 128-byte memory line per symbol once the batch is processed out of order.
+template <bool kKeys>
 __global__ __launch_bounds__(256) void count_kernel_pack(const DevIndex ix, const int64_t npats, const int32_t* __restrict__ plen,
                                                          const uint16_t* __restrict__ pats, const int64_t* __restrict__ starts,
                                                          int64_t* __restrict__ first_out, int64_t* __restrict__ last_out,
-                                                         int* __restrict__ err_flag, const uint32_t* __restrict__ perm) {
+                                                         int* __restrict__ err_flag, const uint32_t* __restrict__ perm,
+                                                         const uint64_t* __restrict__ keys, const int bits, const int nsym) {
   const int64_t slot = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (slot >= npats) return;
   const int64_t q = perm ? int64_t(perm[slot]) : slot;
   const int len = plen[q];
+  const uint64_t key = kKeys ? keys[slot] : 0;
   const uint16_t* pat = pats + starts[q];
   const uint32_t* __restrict__ pack = ix.pack;
-  int64_t first, last;
-  if (len == 0) {
-    first = 0;
-    last = ix.total_length - 1;
-  } else {
-    int i = len - 1;
-    uint32_t ch = pat[i];
-    if (ch >= uint32_t(kAlphaSize)) {
-      atomicOr(err_flag, 1);
-      first = 0;
-      last = -1;
-    } else {
-      first = ix.C[ch];
-      last = ix.C[ch + 1] - 1;
-      while (first <= last && i > 0) {
-        ch = pat[i - 1];
-        if (ch >= uint32_t(kAlphaSize)) {
-          atomicOr(err_flag, 1);
-          first = 0;
-          last = -1;
-          break;
-        }
-        const uint32_t code = ix.pack_code[ch];
-        if (code > 7u) {  // the character does not occur in the text: Occ == 0 (index.c:2080-2089)
-          first = ix.C[ch];
-          last = first - 1;
-          break;
-        }
-        uint64_t lineL, lineF = 0;
-        uint32_t rL, rF = 0;
-        pack_split(last, &lineL, &rL);
-        PackPlanes PL, PF;
-        pack_load_planes(pack, lineL, PL);
-        int64_t bL = pack_base(pack, lineL, code), bF = 0;
-        bool other = false;
-        if (first != 0) {
-          pack_split(first - 1, &lineF, &rF);
-          other = lineF != lineL;
-        }
-        if (other) {  // both ends of a narrow range usually share the line
-          pack_load_planes(pack, lineF, PF);
-          bF = pack_base(pack, lineF, code);
-        }
-        const int64_t nl = bL + int64_t(pack_match(PL, code, rL + 1));
-        int64_t nf;
-        if (first == 0) nf = ix.C[ch];
-        else if (other) nf = bF + int64_t(pack_match(PF, code, rF + 1));
-        else nf = bL + int64_t(pack_match(PL, code, rF + 1));
-        first = nf;
-        last = nl - 1;
-        i--;
+  int64_t first = 0, last = ix.total_length - 1;
+  for (int j = 0; j < len; j++) {  // j-th symbol from the end
+    uint32_t code = 8;
+    if (kKeys && j < nsym) code = uint32_t(key >> (bits * (nsym - 1 - j))) & ((1u << bits) - 1u);
+    if (kKeys && j < nsym && code != 0) {
+      code -= 1;
+    } else {  // not covered by the key, or a character outside the indexed alphabet: read it
+      const uint32_t ch = pat[len - 1 - j];
+      if (ch >= uint32_t(kAlphaSize)) {
+        atomicOr(err_flag, 1);
+        first = 0;
+        last = -1;
+        break;
+      }
+      code = ix.pack_code[ch];
+      if (code > 7u) {  // the character does not occur in the text: Occ == 0 (index.c:2080-2089)
+        first = ix.C[ch];
+        last = first - 1;
+        break;
       }
     }
+    if (j == 0) {
+      first = ix.pack_c[code];
+      last = ix.pack_c[8 + code];
+    } else {
+      uint64_t lineL, lineF = 0;
+      uint32_t rL, rF = 0;
+      pack_split(last, &lineL, &rL);
+      PackPlanes PL, PF;
+      pack_load_planes(pack, lineL, PL);
+      const int64_t bL = pack_base(pack, lineL, code);
+      int64_t bF = 0;
+      bool other = false;
+      if (first != 0) {
+        pack_split(first - 1, &lineF, &rF);
+        other = lineF != lineL;
+      }
+      if (other) {  // both ends of a narrow range usually share the line
+        pack_load_planes(pack, lineF, PF);
+        bF = pack_base(pack, lineF, code);
+      }
+      const int64_t nl = bL + int64_t(pack_match(PL, code, rL + 1));
+      int64_t nf;
+      if (first == 0) nf = ix.pack_c[code];
+      else if (other) nf = bF + int64_t(pack_match(PF, code, rF + 1));
+      else nf = bL + int64_t(pack_match(PL, code, rF + 1));
+      first = nf;
+      last = nl - 1;
+    }
+    if (first > last) break;
   }
   first_out[q] = first;
   if (last_out) last_out[q] = last;
