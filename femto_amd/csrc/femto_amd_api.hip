@@ -19,10 +19,10 @@
 using namespace femto_amd;
 
 namespace femto_amd {
-size_t query_sort_temp_bytes(int64_t npats);
+size_t query_sort_temp_bytes(int64_t npats, int bits, int sort_syms);
 hipError_t query_sort(int64_t npats, const int32_t* d_plen, const uint16_t* d_pats, const int64_t* d_starts,
-                      const uint8_t* d_dense, int bits, uint64_t* keys, uint64_t* keys2, uint32_t* idx, uint32_t* idx2,
-                      void* tmp, size_t tmp_bytes, hipStream_t stream);
+                      const uint8_t* d_dense, int bits, int sort_syms, uint64_t* keys, uint64_t* keys2, uint32_t* idx,
+                      uint32_t* idx2, void* tmp, size_t tmp_bytes, hipStream_t stream);
 }
 
 namespace {
@@ -129,6 +129,7 @@ struct femto_amd_index {
   bool sort_queries = true;   // FEMTO_AMD_SORT=0 disables
   uint8_t* d_dense = nullptr;  // alpha code -> dense sort digit (characters present in the text)
   int dense_bits = 8;
+  double dense_sigma = 256;    // distinct characters of the indexed text
   int64_t sort_min = 4096;
   bool timing = false;
   KernelTimer t_count, t_locate;
@@ -214,9 +215,12 @@ int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen
       if ((rc = ix->s_keys2.reserve(size_t(npats) * 8))) return rc;
       if ((rc = ix->s_idx.reserve(size_t(npats) * 4))) return rc;
       if ((rc = ix->s_idx2.reserve(size_t(npats) * 4))) return rc;
-      const size_t tb = query_sort_temp_bytes(npats);
+      // symbols that matter for the order: sigma^s >= 4 * npats
+      int sort_syms = 1;
+      for (double reach = ix->dense_sigma; reach < 4.0 * double(npats) && sort_syms < 64; reach *= ix->dense_sigma) sort_syms++;
+      const size_t tb = query_sort_temp_bytes(npats, ix->dense_bits, sort_syms);
       if ((rc = ix->s_sorttmp.reserve(tb ? tb : 16))) return rc;
-      HIP_TRY(query_sort(npats, d_plen, d_pats, d_starts, ix->d_dense, ix->dense_bits, ix->s_keys.as<uint64_t>(),
+      HIP_TRY(query_sort(npats, d_plen, d_pats, d_starts, ix->d_dense, ix->dense_bits, sort_syms, ix->s_keys.as<uint64_t>(),
                          ix->s_keys2.as<uint64_t>(), ix->s_idx.as<uint32_t>(), ix->s_idx2.as<uint32_t>(), ix->s_sorttmp.p, tb,
                          stream));
       perm = ix->s_idx2.as<uint32_t>();
@@ -225,7 +229,7 @@ int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen
     if (ix->mode == 3 && perm)
       hipLaunchKernelGGL(count_kernel_pack<true>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
                          d_pats, d_starts, d_first, d_last, ix->d_err, perm, ix->s_keys2.as<uint64_t>(), ix->dense_bits,
-                         64 / ix->dense_bits);
+                         63 / ix->dense_bits);
     else if (ix->mode == 3)
       hipLaunchKernelGGL(count_kernel_pack<false>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
                          d_pats, d_starts, d_first, d_last, ix->d_err, perm, nullptr, 1, 0);
@@ -515,6 +519,7 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
         int bits = 1;
         while ((1 << bits) <= (sigma > 255 ? 255 : sigma)) bits++;
         ix->dense_bits = bits;
+        ix->dense_sigma = sigma < 2 ? 2 : sigma;
         if ((r = upload(&ix->d_dense, dense, &ix->table_bytes))) return r;
       }
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_err), sizeof(int)));

@@ -68,9 +68,10 @@ __device__ __forceinline__ uint32_t pack_match(const PackPlanes& P, uint32_t cod
 
 // do_string_query (src/main/server.c:713-946): one lane per pattern, one line per Occ.
 // kKeys: the batch was suffix-sorted (query_sort.hip) and keys[slot] holds the dense codes (1 + pack code, 0 = none)
-// of the pattern's last `nsym` symbols, last symbol in the most significant field: the symbols are then taken from
-// the key -- one coalesced 8-byte read per pattern -- instead of 2-byte reads scattered over the batch, which cost a
-// 128-byte memory line per symbol once the batch is processed out of order.
+// of the pattern's last `nsym` symbols, last symbol in the top field, and in bit 0 "the key is the whole pattern".
+// The symbols are then taken from the key -- one coalesced 8-byte read per pattern -- instead of 2-byte reads
+// scattered over the batch (a 128-byte memory line per symbol once the batch is processed out of order); plen /
+// starts / the pattern are only touched for patterns the key does not describe completely.
 template <bool kKeys>
 __global__ __launch_bounds__(256) void count_kernel_pack(const DevIndex ix, const int64_t npats, const int32_t* __restrict__ plen,
                                                          const uint16_t* __restrict__ pats, const int64_t* __restrict__ starts,
@@ -80,17 +81,20 @@ __global__ __launch_bounds__(256) void count_kernel_pack(const DevIndex ix, cons
   const int64_t slot = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (slot >= npats) return;
   const int64_t q = perm ? int64_t(perm[slot]) : slot;
-  const int len = plen[q];
   const uint64_t key = kKeys ? keys[slot] : 0;
-  const uint16_t* pat = pats + starts[q];
+  const bool whole = kKeys && (key & 1u);
+  const int len = whole ? nsym : plen[q];   // whole: the first empty field ends the pattern
+  const uint16_t* pat = whole ? pats : pats + starts[q];
   const uint32_t* __restrict__ pack = ix.pack;
   int64_t first = 0, last = ix.total_length - 1;
   for (int j = 0; j < len; j++) {  // j-th symbol from the end
-    uint32_t code = 8;
-    if (kKeys && j < nsym) code = uint32_t(key >> (bits * (nsym - 1 - j))) & ((1u << bits) - 1u);
-    if (kKeys && j < nsym && code != 0) {
+    uint32_t code = 0;
+    if (kKeys && j < nsym) code = uint32_t(key >> (64 - bits * (j + 1))) & ((1u << bits) - 1u);
+    if (code != 0) {
       code -= 1;
-    } else {  // not covered by the key, or a character outside the indexed alphabet: read it
+    } else {
+      if (whole) break;  // pattern exhausted
+      // not covered by the key, or a character outside the indexed alphabet: read it
       const uint32_t ch = pat[len - 1 - j];
       if (ch >= uint32_t(kAlphaSize)) {
         atomicOr(err_flag, 1);

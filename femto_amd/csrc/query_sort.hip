@@ -19,10 +19,12 @@
 
 namespace femto_amd {
 
-// key = the pattern's last `nsym` symbols (the last one most significant), each mapped through `dense`
-// to `bits` bits: dense[ch] = 1 + rank of ch among the characters that occur in the indexed text, 0 for
-// "pattern exhausted" and for characters that do not occur (such patterns die at once anyway).  For
-// ACGT texts bits = 3, so a whole 20-mer fits one 64-bit key and the batch is fully suffix-sorted.
+// key = the pattern's last `nsym` = 63/bits symbols, the last one in the most significant field, each mapped through
+// `dense` to `bits` bits: dense[ch] = 1 + rank of ch among the characters that occur in the indexed text, 0 for
+// "pattern exhausted" and for characters that do not occur (such patterns die at once anyway).  The fields sit at
+// the top of the key; bit 0 is a flag: 1 = the key describes the WHOLE pattern (it has at most nsym symbols, all of
+// them characters of the text), so a kernel that works on dense codes never has to read the pattern itself.  For
+// ACGT texts bits = 3: a whole 20-mer fits the key and the batch is fully suffix-sorted.
 __global__ void suffix_key_kernel(const int64_t npats, const int32_t* __restrict__ plen,
                                   const uint16_t* __restrict__ pats, const int64_t* __restrict__ starts,
                                   const uint8_t* __restrict__ dense, const int bits, const int nsym,
@@ -32,38 +34,58 @@ __global__ void suffix_key_kernel(const int64_t npats, const int32_t* __restrict
   const int len = plen[q];
   const uint16_t* p = pats + starts[q];
   uint64_t key = 0;
+  bool whole = len <= nsym;
   for (int k = 0; k < nsym; k++) {
     const int pos = len - 1 - k;
     uint64_t c = 0;
     if (pos >= 0) {
       const uint32_t ch = p[pos];
       c = ch < 261u ? dense[ch] : 0;
+      whole = whole && c != 0;
     }
     key = (key << bits) | c;
   }
-  keys[q] = key;
+  keys[q] = (key << (64 - nsym * bits)) | (whole ? 1u : 0u);
   idx[q] = uint32_t(q);
 }
 
-size_t query_sort_temp_bytes(int64_t npats) {
+static int clamp_sort_syms(int bits, int sort_syms) {
+  const int nsym = 63 / bits;
+  return (sort_syms > nsym || sort_syms <= 0) ? nsym : sort_syms;
+}
+
+// first key bit that takes part in the sort.  Batches of up to 2^20 patterns go through rocPRIM's merge-sort
+// path, which returned a non-permutation for a partial bit range on this ROCm (7.2.0, observed on gfx950 with
+// 4096..100000 keys and begin_bit 37..43): they are sorted on whole keys -- at that size the passes cost nothing.
+static unsigned sort_begin_bit(int64_t npats, int bits, int sort_syms) {
+  if (npats <= (int64_t(1) << 20)) return 0;
+  return unsigned(64 - clamp_sort_syms(bits, sort_syms) * bits);
+}
+
+// temporary storage of the sort for exactly the bit range query_sort() will use (rocPRIM picks its algorithm,
+// and with it the storage it needs, from the size and the bit range)
+size_t query_sort_temp_bytes(int64_t npats, int bits, int sort_syms) {
   size_t bytes = 0;
   (void)rocprim::radix_sort_pairs(nullptr, bytes, static_cast<uint64_t*>(nullptr), static_cast<uint64_t*>(nullptr),
-                                  static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), size_t(npats), 0, 64,
-                                  nullptr);
+                                  static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), size_t(npats),
+                                  sort_begin_bit(npats, bits, sort_syms), 64, nullptr);
   return bytes;
 }
 
 // keys/keys2: npats u64 each; idx/idx2: npats u32 each; tmp: query_sort_temp_bytes(npats).
-// On return idx2 holds the processing order (a permutation of 0..npats-1).
+// On return idx2 holds the processing order (a permutation of 0..npats-1) and keys2 the keys in that order.
+// Only the top `sort_syms` symbols take part in the sort: once sigma^s exceeds the batch size, patterns that agree
+// on s symbols are (almost) alone, and deeper order buys no locality -- fewer radix passes.
 hipError_t query_sort(int64_t npats, const int32_t* d_plen, const uint16_t* d_pats, const int64_t* d_starts,
-                      const uint8_t* d_dense, int bits, uint64_t* keys, uint64_t* keys2, uint32_t* idx, uint32_t* idx2,
-                      void* tmp, size_t tmp_bytes, hipStream_t stream) {
-  const int nsym = 64 / bits;
+                      const uint8_t* d_dense, int bits, int sort_syms, uint64_t* keys, uint64_t* keys2, uint32_t* idx,
+                      uint32_t* idx2, void* tmp, size_t tmp_bytes, hipStream_t stream) {
+  const int nsym = 63 / bits;
   hipLaunchKernelGGL(suffix_key_kernel, dim3(uint32_t((npats + 255) / 256)), dim3(256), 0, stream, npats, d_plen, d_pats,
                      d_starts, d_dense, bits, nsym, keys, idx);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  return rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, idx, idx2, size_t(npats), 0, unsigned(nsym * bits), stream);
+  return rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, idx, idx2, size_t(npats), sort_begin_bit(npats, bits, sort_syms), 64,
+                                   stream);
 }
 
 }  // namespace femto_amd

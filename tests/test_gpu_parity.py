@@ -204,6 +204,31 @@ def test_gpu_built_index_vs_oracle_medium(tmp_path, gpu_ok, mode):
             assert np.array_equal(text[off:off + len(p)], p)
 
 
+@pytest.mark.parametrize("mode", [3, 1])
+def test_batch_above_a_million_patterns(tmp_path, gpu_ok, mode):
+    """Batches above 2^20 patterns are suffix-sorted on the leading symbols only (a partial-bit radix sort,
+    query_sort.hip) and, in mode 3, searched from the sorted keys: 1.5 M mixed-length patterns, some longer than a
+    key holds, some with characters outside the text's alphabet, against the oracle."""
+    text = tg.t_acgt(1 << 21, 31)
+    path = _random_index(tmp_path, text, None, "acgt2m")
+    ix = femto_amd.Index(path, device=0)
+    _set_mode(ix, mode)
+    o = po.Oracle(path)
+    rng = np.random.Generator(np.random.PCG64(77))
+    n = 1_500_000
+    plen = rng.integers(0, 30, n).astype(np.int32)           # 0..29 symbols: a key holds 21
+    starts = tg.starts_of(plen)
+    flat = (np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(plen.sum()))].astype(np.uint16) + 5)
+    odd = rng.integers(0, len(flat), 20000)                  # sprinkle characters that do not occur in the text
+    flat[odd] = rng.integers(0, 261, len(odd)).astype(np.uint16)
+    first, last = ix.count_flat(plen, flat, starts)
+    of, ol = o.count_flat(plen, flat, starts, threads=16)
+    assert np.array_equal(first, of) and np.array_equal(last, ol)
+    noccs, offs = ix.locate_flat(plen, flat, starts, 3)
+    on, oo = o.locate_flat(plen, flat, starts, 3, threads=16)
+    assert np.array_equal(noccs, on) and np.array_equal(offs, oo)
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_gpu_built_english_like_vs_oracle(tmp_path, gpu_ok, mode):
     """sigma ~ 96 text (RLE-heavy wavelet nodes, deep Huffman codes), mixed-length patterns 8..64
