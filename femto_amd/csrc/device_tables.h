@@ -125,6 +125,8 @@ struct DevIndex {           // passed by value to kernels
   const int64_t* pack_sa;   // offsets of the marked rows, row order
   const uint8_t* pack_code; // [261] alpha code -> dense code 0..7, 0xff: not in the text
   const int64_t* pack_c;    // [16]: C[ch(code)] for code 0..7, then C[ch(code)+1]-1
+  const int64_t* ktab;      // [2^ktab_bits][2]: backward search of the first ktab_syms key fields, precomputed (pack_kernels.hip.hpp)
+  int32_t ktab_bits, ktab_syms;
   uint16_t pack_alpha[8];   // dense code -> alpha code
   int32_t pack_sigma;
   uint32_t pack_stop;       // bit c: alpha code of dense code c is <= SEOF (a locate walk stops there)

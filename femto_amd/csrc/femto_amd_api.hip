@@ -116,6 +116,7 @@ struct femto_amd_index {
   int64_t* d_pack_sa = nullptr;
   uint8_t* d_pack_code = nullptr;
   int64_t* d_pack_c = nullptr;
+  int64_t* d_ktab = nullptr;
   int64_t pack_bytes = 0;
   double pack_build_ms = 0;
   int num_cus = 256;
@@ -430,6 +431,22 @@ int build_pack(femto_amd_index* ix) {
     ix->pack_build_ms = ms;
     ix->dev.pack = ix->d_pack;
     ix->dev.pack_sa = ix->d_pack_sa;
+    // precomputed first steps (ktab): as many key fields as give at most 2^21 entries
+    const char* kt = getenv("FEMTO_AMD_KTAB");
+    if (!kt || atoi(kt) != 0) {
+      const int bits = ix->dense_bits;
+      const int syms = std::min(21 / bits, 63 / bits);
+      const size_t entries = size_t(1) << (bits * syms);
+      if (hipMalloc(reinterpret_cast<void**>(&ix->d_ktab), entries * 16) != hipSuccess) return set_err(FEMTO_AMD_ERR_MEM, "hipMalloc ktab");
+      hipLaunchKernelGGL(ktab_build_kernel, dim3(uint32_t((entries + 255) / 256)), dim3(256), 0, nullptr, ix->dev, bits, syms,
+                         reinterpret_cast<longlong2*>(ix->d_ktab));
+      if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return set_err(FEMTO_AMD_ERR_INVALID, "ktab build failed");
+      ix->dev.ktab = ix->d_ktab;
+      ix->dev.ktab_bits = bits * syms;
+      ix->dev.ktab_syms = syms;
+      ix->pack_bytes += int64_t(entries * 16);
+      ix->table_bytes += int64_t(entries * 16);
+    }
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
@@ -725,6 +742,7 @@ void femto_amd_close(femto_amd_index_t* ix) {
     (void)hipFree(ix->d_pack_sa);
     (void)hipFree(ix->d_pack_code);
     (void)hipFree(ix->d_pack_c);
+    (void)hipFree(ix->d_ktab);
     for (DeviceBuffer* b : {&ix->s_plen, &ix->s_pats, &ix->s_starts, &ix->s_first, &ix->s_last, &ix->s_noccs,
                             &ix->s_noccs64, &ix->s_out_starts, &ix->s_offsets, &ix->s_scan[0], &ix->s_scan[1],
                             &ix->s_scan[2], &ix->s_rows, &ix->s_ch, &ix->s_occ, &ix->s_off, &ix->s_keys, &ix->s_keys2, &ix->s_idx,

@@ -66,6 +66,60 @@ __device__ __forceinline__ uint32_t pack_match(const PackPlanes& P, uint32_t cod
   return cnt;
 }
 
+// one step of the backward search with dense code `code` (server.c:909-936): [first,last] -> rows preceded by code
+__device__ __forceinline__ void pack_search_step(const DevIndex& ix, const uint32_t* __restrict__ pack, int j, uint32_t code,
+                                                 int64_t& first, int64_t& last) {
+  if (j == 0) {
+    first = ix.pack_c[code];
+    last = ix.pack_c[8 + code];
+    return;
+  }
+  uint64_t lineL, lineF = 0;
+  uint32_t rL, rF = 0;
+  pack_split(last, &lineL, &rL);
+  PackPlanes PL, PF;
+  pack_load_planes(pack, lineL, PL);
+  const int64_t bL = pack_base(pack, lineL, code);
+  int64_t bF = 0;
+  bool other = false;
+  if (first != 0) {
+    pack_split(first - 1, &lineF, &rF);
+    other = lineF != lineL;
+  }
+  if (other) {  // both ends of a narrow range usually share the line
+    pack_load_planes(pack, lineF, PF);
+    bF = pack_base(pack, lineF, code);
+  }
+  const int64_t nl = bL + int64_t(pack_match(PL, code, rL + 1));
+  int64_t nf;
+  if (first == 0) nf = ix.pack_c[code];
+  else if (other) nf = bF + int64_t(pack_match(PF, code, rF + 1));
+  else nf = bL + int64_t(pack_match(PL, code, rF + 1));
+  first = nf;
+  last = nl - 1;
+}
+
+// The first steps of every search are shared by huge numbers of patterns (a batch of 10 M 20-mers over ACGT holds
+// every 7-mer 600 times), so they are precomputed: ktab[f] for f = the top ktab_syms key fields (dense codes, last
+// pattern symbol first) holds the range after searching the leading non-empty fields of f -- exactly the values the
+// stepping loop would hold at that point, including an early death -- and how many fields that were:
+//   x = first,  y = (last + 1) | fields_consumed << 48.
+constexpr uint64_t kKtabLastMask = (uint64_t(1) << 48) - 1;
+
+__global__ __launch_bounds__(256) void ktab_build_kernel(const DevIndex ix, const int bits, const int syms, longlong2* __restrict__ tab) {
+  const uint64_t f = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (f >= (uint64_t(1) << (bits * syms))) return;
+  int64_t first = 0, last = ix.total_length - 1;
+  int j = 0;
+  for (; j < syms; j++) {
+    const uint32_t c = uint32_t(f >> (bits * (syms - 1 - j))) & ((1u << bits) - 1u);
+    if (c == 0 || int(c) > ix.pack_sigma) break;
+    pack_search_step(ix, ix.pack, j, c - 1, first, last);
+    if (first > last) { j++; break; }
+  }
+  tab[f] = make_longlong2(first, int64_t(uint64_t(last + 1) | (uint64_t(j) << 48)));
+}
+
 // do_string_query (src/main/server.c:713-946): one lane per pattern, one line per Occ.
 // kKeys: the batch was suffix-sorted (query_sort.hip) and keys[slot] holds the dense codes (1 + pack code, 0 = none)
 // of the pattern's last `nsym` symbols, last symbol in the top field, and in bit 0 "the key is the whole pattern".
@@ -87,7 +141,15 @@ __global__ __launch_bounds__(256) void count_kernel_pack(const DevIndex ix, cons
   const uint16_t* pat = whole ? pats : pats + starts[q];
   const uint32_t* __restrict__ pack = ix.pack;
   int64_t first = 0, last = ix.total_length - 1;
-  for (int j = 0; j < len; j++) {  // j-th symbol from the end
+  int j = 0;
+  if (kKeys && ix.ktab) {
+    const longlong2 e = reinterpret_cast<const longlong2*>(ix.ktab)[key >> (64 - ix.ktab_bits)];
+    first = e.x;
+    last = int64_t(uint64_t(e.y) & kKtabLastMask) - 1;
+    j = int(uint64_t(e.y) >> 48);   // fields consumed; a pattern that ends (or leaves the alphabet) there goes on below
+    if (first > last) j = len;
+  }
+  for (; j < len; j++) {  // j-th symbol from the end
     uint32_t code = 0;
     if (kKeys && j < nsym) code = uint32_t(key >> (64 - bits * (j + 1))) & ((1u << bits) - 1u);
     if (code != 0) {
@@ -109,34 +171,7 @@ __global__ __launch_bounds__(256) void count_kernel_pack(const DevIndex ix, cons
         break;
       }
     }
-    if (j == 0) {
-      first = ix.pack_c[code];
-      last = ix.pack_c[8 + code];
-    } else {
-      uint64_t lineL, lineF = 0;
-      uint32_t rL, rF = 0;
-      pack_split(last, &lineL, &rL);
-      PackPlanes PL, PF;
-      pack_load_planes(pack, lineL, PL);
-      const int64_t bL = pack_base(pack, lineL, code);
-      int64_t bF = 0;
-      bool other = false;
-      if (first != 0) {
-        pack_split(first - 1, &lineF, &rF);
-        other = lineF != lineL;
-      }
-      if (other) {  // both ends of a narrow range usually share the line
-        pack_load_planes(pack, lineF, PF);
-        bF = pack_base(pack, lineF, code);
-      }
-      const int64_t nl = bL + int64_t(pack_match(PL, code, rL + 1));
-      int64_t nf;
-      if (first == 0) nf = ix.pack_c[code];
-      else if (other) nf = bF + int64_t(pack_match(PF, code, rF + 1));
-      else nf = bL + int64_t(pack_match(PL, code, rF + 1));
-      first = nf;
-      last = nl - 1;
-    }
+    pack_search_step(ix, pack, j, code, first, last);
     if (first > last) break;
   }
   first_out[q] = first;
