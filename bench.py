@@ -300,14 +300,25 @@ def main():
     # ---- roofline of the dominant kernel: algorithmic bytes per launch / average kernel duration
     roof = None
     if sample > 0 and cnt_n > 0:
+        cc, ca = c_count.asdict(), c_all.asdict()
         packed = ix.rank_mode == 3
+        ktab_syms = ix.pack_info()["ktab_syms"] if packed else 0
+        c_tab = po.Counters()
+        if packed and ktab_syms:   # Occ evaluations the precomputed table answers: those of each pattern's last ktab_syms symbols
+            t_len = np.minimum(s_plen, ktab_syms).astype(np.int32)
+            t_starts = (s_starts + (s_plen - t_len)).astype(np.int64)
+            o.count_flat(t_len, s_flat, t_starts, threads=nthr, counters=c_tab)
+        n_occ_tab = c_tab.asdict()["n_occ"]
 
         def alg(c):
             if packed:    # packed lines: every Occ / LF step (= one leaf request of the restatement) reads ONE 128-byte line,
-                return c["n_occ"] * 128 + c["n_mark"] * 8   # every located row one 8-byte offset
+                # every located row one 8-byte offset; a sorted batch reads 8 B key + 4 B order + 16 B table entry per
+                # pattern instead of the steps the table covers, and writes 16 B
+                if c is cc and ktab_syms:
+                    return (c["n_occ"] - n_occ_tab) * 128 + sample * (8 + 4 + 16 + 16)
+                return c["n_occ"] * 128 + c["n_mark"] * 8
             # wavelet path, SURVEY.md 8(d): N_rank*(12 + 64 + S_rank) + N_occ*20 + N_mark*8, counters from the CPU restatement
             return c["n_rank"] * (12 + 64) + c["s_bytes"] + c["n_occ"] * 20 + c["n_mark"] * 8
-        cc, ca = c_count.asdict(), c_all.asdict()
         cl = {k: ca[k] - cc[k] for k in ca}       # locate_flat re-runs the count: walk only = all - count
         scale = npats / sample
         dominant_is_count = cnt_ms >= loc_ms
@@ -337,7 +348,9 @@ def main():
                 "contract_335B_per_occ_GBs": 335.0 * k_c["n_occ"] * scale / (k_ms * 1e-3) / 1e9,
                 "wavelet_path_equivalent_GBs": (k_c["n_rank"] * (12 + 64) + k_c["s_bytes"] + k_c["n_occ"] * 20 + k_c["n_mark"] * 8)
                 * scale / (k_ms * 1e-3) / 1e9,
-                "bytes_model": ("packed lines: 128 B per Occ / LF step + 8 B per located row" if packed else
+                "occ_answered_by_table_per_pattern": (n_occ_tab / sample) if (packed and dominant_is_count) else 0.0,
+                "bytes_model": ("packed lines: 128 B per Occ / LF step not covered by the first-steps table, + 44 B per pattern "
+                                "(key, order, table entry, results), + 8 B per located row" if packed else
                                 "wavelet path: N_rank*(12+64+S) + N_occ*20 + N_mark*8 (SURVEY 8d)"),
                 "note": "the batch is processed in suffix order, so neighbouring lanes share cache lines and part of the "
                         "algorithmic bytes never leaves L1/L2 (traffic < algorithmic bytes; frac may exceed 1)"}

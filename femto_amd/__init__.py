@@ -74,7 +74,7 @@ def lib():
         L.femto_amd_forward_steps.argtypes = [vp, i64, vp, vp, vp, vp]
         L.femto_amd_set_rank_mode.argtypes = [vp, i32]
         L.femto_amd_get_rank_mode.argtypes = [vp]
-        L.femto_amd_pack_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i64), C.POINTER(C.c_double)]
+        L.femto_amd_pack_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(i32)]
         L.femto_amd_flatten_index.argtypes = [C.c_char_p, C.c_char_p]
         L.femto_amd_bseq_encode.argtypes = [vp, i64, i32, vp, i64, C.POINTER(i64)]
         L.femto_amd_open_split.argtypes = [C.c_char_p, i32, i32, i32, C.POINTER(vp)]
@@ -194,10 +194,10 @@ class Index:
         return self.locate_flat(*flatten(patterns), max_occs)
 
     def pack_info(self):
-        """small-alphabet packed lines (mode 3): {'available', 'bytes', 'build_ms'}"""
-        a, b, ms = C.c_int(0), C.c_int64(0), C.c_double(0)
-        _check(lib().femto_amd_pack_info(self._h, C.byref(a), C.byref(b), C.byref(ms)))
-        return {"available": bool(a.value), "bytes": b.value, "build_ms": ms.value}
+        """small-alphabet packed lines (mode 3): {'available', 'bytes', 'build_ms', 'ktab_syms'}"""
+        a, b, ms, k = C.c_int(0), C.c_int64(0), C.c_double(0), C.c_int(0)
+        _check(lib().femto_amd_pack_info(self._h, C.byref(a), C.byref(b), C.byref(ms), C.byref(k)))
+        return {"available": bool(a.value), "bytes": b.value, "build_ms": ms.value, "ktab_syms": k.value}
 
     def document_info(self, doc):
         p, n = C.c_char_p(), C.c_int64(0)

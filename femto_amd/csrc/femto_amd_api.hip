@@ -1051,9 +1051,10 @@ int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode) {
 
 int femto_amd_get_rank_mode(const femto_amd_index_t* ix) { return ix ? ix->mode : -1; }
 
-int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* bytes, double* build_ms) {
+int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* bytes, double* build_ms, int* ktab_syms) {
   if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
   if (available) *available = ix->dev.pack != nullptr;
+  if (ktab_syms) *ktab_syms = ix->dev.ktab ? ix->dev.ktab_syms : 0;
   if (bytes) *bytes = ix->pack_bytes;
   if (build_ms) *build_ms = ix->pack_build_ms;
   return FEMTO_AMD_OK;

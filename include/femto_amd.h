@@ -180,8 +180,11 @@ int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode);
  * loader derives, on the GPU, one self-contained 128-byte line per 160 rows -- three bit planes of the dense
  * character code, a "row is marked" plane, and C[ch]+Occ before the line for each character -- plus the
  * marked rows' offsets in row order, so that an Occ and a whole locate step each read ONE memory line instead of
- * 2-5 (femto_amd/csrc/pack_kernels.hip.hpp).  Same results, bit for bit.  FEMTO_AMD_PACK=0 skips the derivation. */
-int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* bytes, double* build_ms);
+ * 2-5 (femto_amd/csrc/pack_kernels.hip.hpp).  Batches large enough to be suffix-sorted are searched from their
+ * sort keys (dense codes, no scattered pattern reads), and the first ktab_syms steps of every search -- shared by
+ * huge numbers of patterns -- come from a table precomputed at open (FEMTO_AMD_KTAB=0 disables it).  Same results,
+ * bit for bit.  FEMTO_AMD_PACK=0 skips the derivation. */
+int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* bytes, double* build_ms, int* ktab_syms);
 int femto_amd_get_rank_mode(const femto_amd_index_t* ix);
 
 /* ---- profiling hooks ---------------------------------------------------------------------- */
