@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -12,6 +13,7 @@
 
 #include "../../include/femto_amd.h"
 #include "host_index.hpp"
+#include "host_pipeline.hpp"
 #include "index_builder.hpp"
 #include "kernels.hip.hpp"
 #include "pack_kernels.hip.hpp"
@@ -134,6 +136,17 @@ struct femto_amd_index {
   int64_t sort_min = 4096;
   bool timing = false;
   KernelTimer t_count, t_locate;
+  // host-pointer batches: pinned double buffers + worker pool (host_pipeline.hpp), created on first use
+  struct HostPipe {
+    std::unique_ptr<WorkerPool> pool;
+    void* h_in[2] = {nullptr, nullptr};    // [plen i32 x chunk | starts i64 x chunk | symbols u16 x sym_cap]
+    void* h_out[2] = {nullptr, nullptr};   // [first i64 x chunk | last i64 x chunk]
+    void* d_in[2] = {nullptr, nullptr};
+    void* d_out[2] = {nullptr, nullptr};
+    hipStream_t s_h2d = nullptr, s_k = nullptr, s_d2h = nullptr;
+    hipEvent_t in_done[2] = {nullptr, nullptr}, k_done[2] = {nullptr, nullptr}, out_done[2] = {nullptr, nullptr};
+    bool ready = false;
+  } pipe;
   // range-split index (femto_amd_open_split): this handle holds the segment lines and the block images of
   // data blocks [split_blo[part], split_blo[part+1]); the other parts' slices are mapped from their owners
   int split_parts = 0, split_part = 0;
@@ -453,6 +466,185 @@ int build_pack(femto_amd_index* ix) {
   return r;
 }
 
+// ---- host-pointer batches, pipelined ----------------------------------------------------------------------------
+constexpr int64_t kPipeChunk = int64_t(1) << 21;      // patterns per chunk
+constexpr int64_t kPipeSymCap = int64_t(1) << 26;     // symbols per chunk (128 MB)
+constexpr int64_t kPipeMin = int64_t(1) << 18;        // smaller batches take the plain path
+
+size_t pipe_in_bytes() { return size_t(kPipeChunk) * 12 + size_t(kPipeSymCap) * 2; }
+
+int pipe_init(femto_amd_index* ix) {
+  auto& P = ix->pipe;
+  if (P.ready) return 0;
+  int nthreads = int(std::thread::hardware_concurrency());
+  if (const char* e = getenv("FEMTO_AMD_HOST_THREADS")) nthreads = atoi(e);
+  nthreads = std::max(1, std::min(nthreads, 16));
+  P.pool.reset(new WorkerPool(nthreads));
+  for (int b = 0; b < 2; b++) {
+    HIP_TRY(hipHostMalloc(&P.h_in[b], pipe_in_bytes(), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&P.h_out[b], size_t(kPipeChunk) * 16, hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&P.d_in[b], pipe_in_bytes()));
+    HIP_TRY(hipMalloc(&P.d_out[b], size_t(kPipeChunk) * 16));
+    HIP_TRY(hipEventCreateWithFlags(&P.in_done[b], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&P.k_done[b], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&P.out_done[b], hipEventDisableTiming));
+  }
+  HIP_TRY(hipStreamCreateWithFlags(&P.s_h2d, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&P.s_k, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&P.s_d2h, hipStreamNonBlocking));
+  P.ready = true;
+  return 0;
+}
+
+void pipe_release(femto_amd_index* ix) {
+  auto& P = ix->pipe;
+  for (int b = 0; b < 2; b++) {
+    if (P.h_in[b]) (void)hipHostFree(P.h_in[b]);
+    if (P.h_out[b]) (void)hipHostFree(P.h_out[b]);
+    if (P.d_in[b]) (void)hipFree(P.d_in[b]);
+    if (P.d_out[b]) (void)hipFree(P.d_out[b]);
+    if (P.in_done[b]) (void)hipEventDestroy(P.in_done[b]);
+    if (P.k_done[b]) (void)hipEventDestroy(P.k_done[b]);
+    if (P.out_done[b]) (void)hipEventDestroy(P.out_done[b]);
+  }
+  if (P.s_h2d) (void)hipStreamDestroy(P.s_h2d);
+  if (P.s_k) (void)hipStreamDestroy(P.s_k);
+  if (P.s_d2h) (void)hipStreamDestroy(P.s_d2h);
+  P.pool.reset();
+  P.ready = false;
+}
+
+// One chunk's patterns, in either calling convention, copied into a pinned buffer.  Returns the number of symbols
+// staged, -1 when the chunk does not fit the buffer (the caller falls back to the unpipelined path), or -2 - code
+// on invalid input.
+struct HostBatch {
+  int64_t npats = 0;
+  const int32_t* plen = nullptr;
+  const uint16_t* flat = nullptr;          // flat form: pattern i = flat[starts[i] .. +plen[i])
+  const int64_t* starts = nullptr;
+  const uint16_t* const* ptrs = nullptr;   // pointer-array form (parallel_count's alpha_t**)
+};
+
+int64_t pipe_stage(WorkerPool& pool, const HostBatch& hb, int64_t a, int64_t b, void* h_in) {
+  const int64_t n = b - a;
+  int32_t* o_plen = static_cast<int32_t*>(h_in);
+  int64_t* o_starts = reinterpret_cast<int64_t*>(static_cast<char*>(h_in) + size_t(kPipeChunk) * 4);
+  uint16_t* o_sym = reinterpret_cast<uint16_t*>(static_cast<char*>(h_in) + size_t(kPipeChunk) * 12);
+  const int T = pool.size();
+  std::vector<int64_t> part(size_t(T) + 1, 0), lo_t(size_t(T), INT64_MAX), hi_t(size_t(T), 0);
+  std::vector<int> bad(size_t(T), 0);
+  // pass 1: validate; flat form: symbol range of the chunk; pointer form: symbols per thread slice
+  pool.run([&](int t, int nt) {
+    const int64_t i0 = a + n * t / nt, i1 = a + n * (t + 1) / nt;
+    int64_t sum = 0, lo = INT64_MAX, hi = 0;
+    for (int64_t i = i0; i < i1; i++) {
+      const int64_t l = hb.plen[i];
+      if (l < 0) { bad[size_t(t)] = 1; return; }
+      if (hb.ptrs) {
+        if (l && !hb.ptrs[i]) { bad[size_t(t)] = 1; return; }
+        sum += l;
+      } else {
+        const int64_t s0 = hb.starts[i];
+        if (s0 < 0) { bad[size_t(t)] = 1; return; }
+        lo = std::min(lo, s0);
+        hi = std::max(hi, s0 + l);
+      }
+    }
+    part[size_t(t) + 1] = sum;
+    lo_t[size_t(t)] = lo;
+    hi_t[size_t(t)] = hi;
+  });
+  for (int t = 0; t < T; t++) if (bad[size_t(t)]) return -2 - FEMTO_AMD_ERR_PARAM;
+  int64_t nsym, lo = 0;
+  if (hb.ptrs) {
+    for (int t = 0; t < T; t++) part[size_t(t) + 1] += part[size_t(t)];
+    nsym = part[size_t(T)];
+  } else {
+    lo = INT64_MAX;
+    int64_t hi = 0;
+    for (int t = 0; t < T; t++) { lo = std::min(lo, lo_t[size_t(t)]); hi = std::max(hi, hi_t[size_t(t)]); }
+    if (lo == INT64_MAX) lo = 0;
+    nsym = std::max<int64_t>(0, hi - lo);
+  }
+  if (nsym > kPipeSymCap) return -1;
+  // pass 2: copy
+  pool.run([&](int t, int nt) {
+    const int64_t i0 = a + n * t / nt, i1 = a + n * (t + 1) / nt;
+    if (hb.ptrs) {
+      int64_t at = part[size_t(t)];
+      for (int64_t i = i0; i < i1; i++) {  // patterns are copied, as setup_string_query does (src/main/server.c:691-695)
+        const int64_t l = hb.plen[i];
+        o_plen[i - a] = int32_t(l);
+        o_starts[i - a] = at;
+        if (l) memcpy(o_sym + at, hb.ptrs[i], size_t(l) * 2);
+        at += l;
+      }
+    } else {
+      memcpy(o_plen + (i0 - a), hb.plen + i0, size_t(i1 - i0) * 4);
+      for (int64_t i = i0; i < i1; i++) o_starts[i - a] = hb.starts[i] - lo;
+      const int64_t s0 = nsym * t / nt, s1 = nsym * (t + 1) / nt;
+      if (s1 > s0) memcpy(o_sym + s0, hb.flat + lo + s0, size_t(s1 - s0) * 2);
+    }
+  });
+  return nsym;
+}
+
+// returns 0, an error code, or -1: "not applicable, use the plain path"
+int count_host_pipelined(femto_amd_index* ix, const HostBatch& hb, int64_t* first, int64_t* last) {
+  if (hb.npats < kPipeMin) return -1;
+  if (const char* e = getenv("FEMTO_AMD_HOST_PIPELINE")) if (atoi(e) == 0) return -1;
+  int rc = pipe_init(ix);
+  if (rc) return rc;
+  auto& P = ix->pipe;
+  const int64_t nchunks = (hb.npats + kPipeChunk - 1) / kPipeChunk;
+  auto fail = [&](int code) {
+    (void)hipDeviceSynchronize();
+    return code;
+  };
+  for (int64_t c = 0; c <= nchunks; c++) {
+    if (c < nchunks) {
+      const int b = int(c & 1);
+      const int64_t a = c * kPipeChunk, e = std::min(hb.npats, a + kPipeChunk), n = e - a;
+      if (c >= 2) HIP_TRY(hipEventSynchronize(P.k_done[b]));  // chunk c-2 no longer reads d_in[b] (and h_in[b] was uploaded)
+      const int64_t nsym = pipe_stage(*P.pool, hb, a, e, P.h_in[b]);
+      if (nsym == -1) return fail(-1);
+      if (nsym < -1) return fail(set_err(int(-2 - nsym), "negative pattern length/start or null pattern"));
+      char* din = static_cast<char*>(P.d_in[b]);
+      const char* hin = static_cast<const char*>(P.h_in[b]);
+      HIP_TRY(hipMemcpyAsync(din, hin, size_t(n) * 4, hipMemcpyHostToDevice, P.s_h2d));
+      HIP_TRY(hipMemcpyAsync(din + size_t(kPipeChunk) * 4, hin + size_t(kPipeChunk) * 4, size_t(n) * 8, hipMemcpyHostToDevice, P.s_h2d));
+      if (nsym)
+        HIP_TRY(hipMemcpyAsync(din + size_t(kPipeChunk) * 12, hin + size_t(kPipeChunk) * 12, size_t(nsym) * 2, hipMemcpyHostToDevice, P.s_h2d));
+      HIP_TRY(hipEventRecord(P.in_done[b], P.s_h2d));
+      HIP_TRY(hipStreamWaitEvent(P.s_k, P.in_done[b], 0));
+      if (c >= 2) HIP_TRY(hipStreamWaitEvent(P.s_k, P.out_done[b], 0));  // results of chunk c-2 have left d_out[b]
+      int64_t* d_first = static_cast<int64_t*>(P.d_out[b]);
+      int64_t* d_last = last ? d_first + kPipeChunk : nullptr;
+      rc = launch_count(ix, n, reinterpret_cast<const int32_t*>(din), reinterpret_cast<const uint16_t*>(din + size_t(kPipeChunk) * 12),
+                        reinterpret_cast<const int64_t*>(din + size_t(kPipeChunk) * 4), d_first, d_last, P.s_k);
+      if (rc) return fail(rc);
+      HIP_TRY(hipEventRecord(P.k_done[b], P.s_k));
+      HIP_TRY(hipStreamWaitEvent(P.s_d2h, P.k_done[b], 0));
+      char* hout = static_cast<char*>(P.h_out[b]);
+      HIP_TRY(hipMemcpyAsync(hout, d_first, size_t(n) * 8, hipMemcpyDeviceToHost, P.s_d2h));
+      if (last) HIP_TRY(hipMemcpyAsync(hout + size_t(kPipeChunk) * 8, d_last, size_t(n) * 8, hipMemcpyDeviceToHost, P.s_d2h));
+      HIP_TRY(hipEventRecord(P.out_done[b], P.s_d2h));
+    }
+    if (c >= 1) {  // hand chunk c-1 back while chunk c is on its way
+      const int b = int((c - 1) & 1);
+      const int64_t a = (c - 1) * kPipeChunk, e = std::min(hb.npats, a + kPipeChunk), n = e - a;
+      HIP_TRY(hipEventSynchronize(P.out_done[b]));
+      const char* hout = static_cast<const char*>(P.h_out[b]);
+      P.pool->run([&](int t, int nt) {
+        const int64_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
+        memcpy(first + a + i0, hout + size_t(i0) * 8, size_t(i1 - i0) * 8);
+        if (last) memcpy(last + a + i0, hout + size_t(kPipeChunk) * 8 + size_t(i0) * 8, size_t(i1 - i0) * 8);
+      });
+    }
+  }
+  return check_err_flag(ix, P.s_k);
+}
+
 }  // namespace
 
 extern "C" {
@@ -717,6 +909,7 @@ void femto_amd_close(femto_amd_index_t* ix) {
     (void)hipSetDevice(ix->device);
     ix->t_count.drain();
     ix->t_locate.drain();
+    pipe_release(ix);
     for (size_t p = 0; p < ix->peer_ipc.size(); p++)
       if (ix->peer_ipc[p]) {
         (void)hipIpcCloseMemHandle(ix->peer_segs[p]);
@@ -802,6 +995,15 @@ int femto_amd_count_flat(femto_amd_index_t* ix, int64_t npats, const int32_t* pl
   int rc = ensure_device(ix);
   if (rc) return rc;
   std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  if (npats && plen && starts && pats) {
+    HostBatch hb;
+    hb.npats = npats;
+    hb.plen = plen;
+    hb.flat = pats;
+    hb.starts = starts;
+    rc = count_host_pipelined(ix, hb, first, last);
+    if (rc != -1) return rc;
+  }
   if ((rc = stage_patterns(ix, npats, plen, pats, starts))) return rc;
   if ((rc = ix->s_first.reserve(size_t(npats + 1) * 8))) return rc;
   if ((rc = ix->s_last.reserve(size_t(npats + 1) * 8))) return rc;
@@ -830,6 +1032,17 @@ int femto_amd_count_bytes(femto_amd_index_t* ix, int64_t npats, const int32_t* p
 int femto_amd_parallel_count(femto_amd_index_t* ix, int npats, const int* plen, const uint16_t* const* pats,
                              int64_t* first, int64_t* last) {
   if (npats < 0 || (npats && (!plen || !pats))) return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
+  if (ix && first && npats >= kPipeMin && ix->device >= 0) {  // large batches: gathered chunk by chunk into pinned memory
+    int rc = ensure_device(ix);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lk(ix->mu);
+    HostBatch hb;
+    hb.npats = npats;
+    hb.plen = plen;
+    hb.ptrs = pats;
+    rc = count_host_pipelined(ix, hb, first, last);
+    if (rc != -1) return rc;
+  }
   std::vector<int64_t> starts(size_t(npats) + 1, 0);
   for (int i = 0; i < npats; i++) {
     if (plen[i] < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative pattern length");

@@ -227,6 +227,29 @@ def test_batch_above_a_million_patterns(tmp_path, gpu_ok, mode):
     noccs, offs = ix.locate_flat(plen, flat, starts, 3)
     on, oo = o.locate_flat(plen, flat, starts, 3, threads=16)
     assert np.array_equal(noccs, on) and np.array_equal(offs, oo)
+    # the same batch through the host-pointer pipeline in its other forms: pointer array (parallel_count's
+    # alpha_t**), counts only (last == NULL), patterns stored in reverse order (starts not monotone)
+    L = femto_amd.lib()
+    m = 400_000
+    addr = flat.ctypes.data + starts[:m] * 2
+    parr = (C.c_void_p * m)(*[int(x) for x in addr])
+    pl = np.ascontiguousarray(plen[:m])
+    f2 = np.zeros(m, dtype=np.int64)
+    l2 = np.zeros(m, dtype=np.int64)
+    assert L.femto_amd_parallel_count(ix.handle, m, pl.ctypes.data, parr, f2.ctypes.data, l2.ctypes.data) == 0
+    assert np.array_equal(f2, of[:m]) and np.array_equal(l2, ol[:m])
+    assert L.femto_amd_parallel_count(ix.handle, m, pl.ctypes.data, parr, f2.ctypes.data, None) == 0
+    assert np.array_equal(f2, (ol - of + 1)[:m])
+    order = np.arange(n)[::-1]
+    fr, lr = ix.count_flat(np.ascontiguousarray(plen[order]), flat, np.ascontiguousarray(starts[order]))
+    assert np.array_equal(fr, of[order]) and np.array_equal(lr, ol[order])
+    bad = plen.copy()
+    bad[n // 2] = -1
+    with pytest.raises(femto_amd.FemtoAmdError) as ei:
+        ix.count_flat(bad, flat, starts)
+    assert ei.value.code == 3
+    first3, last3 = ix.count_flat(plen, flat, starts)          # the handle stays usable
+    assert np.array_equal(first3, of) and np.array_equal(last3, ol)
 
 
 @pytest.mark.parametrize("mode", MODES)
