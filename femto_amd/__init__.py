@@ -56,6 +56,7 @@ def lib():
         L.femto_amd_count_flat.argtypes = [vp, i64, vp, vp, vp, vp, vp]
         L.femto_amd_count_bytes.argtypes = [vp, i64, vp, vp, vp, vp, vp]
         L.femto_amd_locate_flat.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, vp, i64, C.POINTER(i64)]
+        L.femto_amd_locate_flat_alloc.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, C.POINTER(vp), C.POINTER(i64)]
         L.femto_amd_parallel_count.argtypes = [vp, i32, vp, vp, vp, vp]
         L.femto_amd_parallel_locate.argtypes = [vp, i32, vp, vp, i32, vp, vp]
         L.femto_amd_resolve_location.argtypes = [vp, i64, C.POINTER(i64), C.POINTER(i64)]
@@ -85,6 +86,12 @@ def lib():
         L.femto_amd_split_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64), C.POINTER(i64)]
         _lib = L
     return _lib
+
+
+def _libc_free(p):
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(p)
 
 
 def _check(rc):
@@ -175,6 +182,25 @@ class Index:
         return self.count_flat(*flatten(patterns))
 
     def locate_flat(self, plen, flat, starts, max_occs):
+        n = len(plen)
+        plen = np.ascontiguousarray(plen, dtype=np.int32)
+        flat = np.ascontiguousarray(flat, dtype=np.uint16)
+        starts = np.ascontiguousarray(starts, dtype=np.int64)
+        noccs = np.zeros(n, dtype=np.int32)
+        total = C.c_int64(0)
+        buf = C.c_void_p()
+        _check(lib().femto_amd_locate_flat_alloc(self._h, n, _ptr(plen), _ptr(flat), _ptr(starts), max_occs, _ptr(noccs), None,
+                                                 C.byref(buf), C.byref(total)))
+        if not total.value:
+            return noccs, np.zeros(0, dtype=np.int64)
+        try:
+            offs = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_int64)), shape=(total.value,)).copy()
+        finally:
+            _libc_free(buf)
+        return noccs, offs
+
+    def locate_flat_two_call(self, plen, flat, starts, max_occs):
+        """femto_amd_locate_flat's sizing protocol: first call sizes, second fills a caller-provided buffer"""
         n = len(plen)
         plen = np.ascontiguousarray(plen, dtype=np.int32)
         flat = np.ascontiguousarray(flat, dtype=np.uint16)

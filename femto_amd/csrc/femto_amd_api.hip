@@ -590,7 +590,10 @@ int64_t pipe_stage(WorkerPool& pool, const HostBatch& hb, int64_t a, int64_t b, 
 }
 
 // returns 0, an error code, or -1: "not applicable, use the plain path"
-int count_host_pipelined(femto_amd_index* ix, const HostBatch& hb, int64_t* first, int64_t* last) {
+// With dev_first != nullptr the ranges stay on the device (whole-batch arrays dev_first / dev_last, the locate plan's
+// input) and nothing is copied back.
+int count_host_pipelined(femto_amd_index* ix, const HostBatch& hb, int64_t* first, int64_t* last, int64_t* dev_first = nullptr,
+                         int64_t* dev_last = nullptr) {
   if (hb.npats < kPipeMin) return -1;
   if (const char* e = getenv("FEMTO_AMD_HOST_PIPELINE")) if (atoi(e) == 0) return -1;
   int rc = pipe_init(ix);
@@ -620,17 +623,22 @@ int count_host_pipelined(femto_amd_index* ix, const HostBatch& hb, int64_t* firs
       if (c >= 2) HIP_TRY(hipStreamWaitEvent(P.s_k, P.out_done[b], 0));  // results of chunk c-2 have left d_out[b]
       int64_t* d_first = static_cast<int64_t*>(P.d_out[b]);
       int64_t* d_last = last ? d_first + kPipeChunk : nullptr;
+      if (dev_first) {
+        d_first = dev_first + a;
+        d_last = dev_last + a;
+      }
       rc = launch_count(ix, n, reinterpret_cast<const int32_t*>(din), reinterpret_cast<const uint16_t*>(din + size_t(kPipeChunk) * 12),
                         reinterpret_cast<const int64_t*>(din + size_t(kPipeChunk) * 4), d_first, d_last, P.s_k);
       if (rc) return fail(rc);
       HIP_TRY(hipEventRecord(P.k_done[b], P.s_k));
+      if (dev_first) continue;
       HIP_TRY(hipStreamWaitEvent(P.s_d2h, P.k_done[b], 0));
       char* hout = static_cast<char*>(P.h_out[b]);
       HIP_TRY(hipMemcpyAsync(hout, d_first, size_t(n) * 8, hipMemcpyDeviceToHost, P.s_d2h));
       if (last) HIP_TRY(hipMemcpyAsync(hout + size_t(kPipeChunk) * 8, d_last, size_t(n) * 8, hipMemcpyDeviceToHost, P.s_d2h));
       HIP_TRY(hipEventRecord(P.out_done[b], P.s_d2h));
     }
-    if (c >= 1) {  // hand chunk c-1 back while chunk c is on its way
+    if (c >= 1 && !dev_first) {  // hand chunk c-1 back while chunk c is on its way
       const int b = int((c - 1) & 1);
       const int64_t a = (c - 1) * kPipeChunk, e = std::min(hb.npats, a + kPipeChunk), n = e - a;
       HIP_TRY(hipEventSynchronize(P.out_done[b]));
@@ -642,7 +650,76 @@ int count_host_pipelined(femto_amd_index* ix, const HostBatch& hb, int64_t* firs
       });
     }
   }
+  if (dev_first) {
+    HIP_TRY(hipStreamSynchronize(P.s_k));
+    return 0;
+  }
   return check_err_flag(ix, P.s_k);
+}
+
+// count (pipelined staging when the batch is large) + clamp + scan: fills s_first/s_last/s_noccs/s_out_starts
+int plan_host(femto_amd_index* ix, const HostBatch& hb, int max_occs_each, int64_t* total) {
+  const int64_t npats = hb.npats;
+  int rc;
+  if ((rc = ix->s_first.reserve(size_t(npats + 1) * 8))) return rc;
+  if ((rc = ix->s_last.reserve(size_t(npats + 1) * 8))) return rc;
+  if ((rc = ix->s_noccs.reserve(size_t(npats + 1) * 4))) return rc;
+  if ((rc = ix->s_out_starts.reserve(size_t(npats + 2) * 8))) return rc;
+  if ((rc = ix->s_noccs64.reserve(size_t(npats + 1) * 8))) return rc;
+  rc = count_host_pipelined(ix, hb, nullptr, ix->s_last.as<int64_t>(), ix->s_first.as<int64_t>(), ix->s_last.as<int64_t>());
+  if (rc == -1) {
+    if (hb.ptrs) return -1;
+    if ((rc = stage_patterns(ix, npats, hb.plen, hb.flat, hb.starts))) return rc;
+    rc = launch_count(ix, npats, ix->s_plen.as<int32_t>(), ix->s_pats.as<uint16_t>(), ix->s_starts.as<int64_t>(),
+                      ix->s_first.as<int64_t>(), ix->s_last.as<int64_t>(), nullptr);
+  }
+  if (rc) return rc;
+  if (npats) {
+    hipLaunchKernelGGL(clamp_kernel, dim3(uint32_t((npats + 255) / 256)), dim3(256), 0, nullptr, npats, ix->s_first.as<int64_t>(),
+                       ix->s_last.as<int64_t>(), max_occs_each, ix->s_noccs.as<int32_t>(), ix->s_noccs64.as<int64_t>());
+    HIP_TRY(hipGetLastError());
+  }
+  if ((rc = device_scan(ix, npats, ix->s_noccs64.as<int64_t>(), ix->s_out_starts.as<int64_t>(), 0, nullptr))) return rc;
+  if ((rc = check_err_flag(ix, nullptr))) return rc;
+  if (max_occs_each == 0 && npats) {
+    // The reference fails here: a pattern with more than one match is clamped to an empty locate range and
+    // setup_locate_range rejects it (src/main/server.c:4411-4421 -> ERR_PARAM); one match is returned whole.
+    std::vector<int64_t> f((size_t(npats))), l((size_t(npats)));
+    HIP_TRY(hipMemcpy(f.data(), ix->s_first.p, size_t(npats) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(l.data(), ix->s_last.p, size_t(npats) * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < npats; i++)
+      if (l[size_t(i)] - f[size_t(i)] > 0) return set_err(FEMTO_AMD_ERR_PARAM, "max_occs_each == 0 with a multi-match pattern: Error during query processing");
+  }
+  HIP_TRY(hipMemcpy(total, ix->s_out_starts.as<int64_t>() + npats, 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// one pass: plan, walk, offsets returned in one malloc()ed array (caller frees); noccs / out_starts optional
+int locate_host(femto_amd_index* ix, const HostBatch& hb, int max_occs_each, int32_t* noccs, int64_t* out_starts, int64_t** offsets_out,
+                int64_t* total_out) {
+  int64_t total = 0;
+  int rc = plan_host(ix, hb, max_occs_each, &total);
+  if (rc) return rc;
+  const int64_t npats = hb.npats;
+  if (total_out) *total_out = total;
+  if (noccs && npats) HIP_TRY(hipMemcpy(noccs, ix->s_noccs.p, size_t(npats) * 4, hipMemcpyDeviceToHost));
+  if (out_starts) HIP_TRY(hipMemcpy(out_starts, ix->s_out_starts.p, size_t(npats + 1) * 8, hipMemcpyDeviceToHost));
+  *offsets_out = nullptr;
+  if (total == 0) return 0;
+  int64_t* buf = static_cast<int64_t*>(malloc(size_t(total) * 8));
+  if (!buf) return set_err(FEMTO_AMD_ERR_MEM, "malloc failed");
+  if ((rc = ix->s_offsets.reserve(size_t(total) * 8)) ||
+      (rc = launch_locate(ix, npats, ix->s_first.as<int64_t>(), ix->s_out_starts.as<int64_t>(), total, ix->s_offsets.as<int64_t>(), nullptr))) {
+    free(buf);
+    return rc;
+  }
+  hipError_t he = hipMemcpy(buf, ix->s_offsets.p, size_t(total) * 8, hipMemcpyDeviceToHost);
+  if (he != hipSuccess) {
+    free(buf);
+    return set_err(FEMTO_AMD_ERR_INVALID, std::string("hipMemcpy: ") + hipGetErrorString(he));
+  }
+  *offsets_out = buf;
+  return 0;
 }
 
 }  // namespace
@@ -1089,29 +1166,15 @@ int femto_amd_locate_flat(femto_amd_index_t* ix, int64_t npats, const int32_t* p
   if (max_occs_each < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative max_occs_each");
   int rc = ensure_device(ix);
   if (rc) return rc;
+  if ((rc = validate_patterns(npats, plen, starts))) return rc;
   int64_t total = 0;
   std::lock_guard<std::recursive_mutex> lk(ix->mu);
-  if ((rc = stage_patterns(ix, npats, plen, pats, starts))) return rc;
-  if ((rc = ix->s_first.reserve(size_t(npats + 1) * 8))) return rc;
-  if ((rc = ix->s_last.reserve(size_t(npats + 1) * 8))) return rc;
-  if ((rc = ix->s_noccs.reserve(size_t(npats + 1) * 4))) return rc;
-  if ((rc = ix->s_out_starts.reserve(size_t(npats + 2) * 8))) return rc;
-  rc = femto_amd_locate_plan_device(ix, npats, ix->s_plen.as<int32_t>(), ix->s_pats.as<uint16_t>(),
-                                    ix->s_starts.as<int64_t>(), max_occs_each, ix->s_first.as<int64_t>(),
-                                    ix->s_last.as<int64_t>(), ix->s_noccs.as<int32_t>(),
-                                    ix->s_out_starts.as<int64_t>(), nullptr);
-  if (rc) return rc;
-  if ((rc = check_err_flag(ix, nullptr))) return rc;
-  if (max_occs_each == 0 && npats) {
-    // The reference fails here: a pattern with more than one match is clamped to an empty locate range and
-    // setup_locate_range rejects it (src/main/server.c:4411-4421 -> ERR_PARAM); one match is returned whole.
-    std::vector<int64_t> f((size_t(npats))), l((size_t(npats)));
-    HIP_TRY(hipMemcpy(f.data(), ix->s_first.p, size_t(npats) * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(l.data(), ix->s_last.p, size_t(npats) * 8, hipMemcpyDeviceToHost));
-    for (int64_t i = 0; i < npats; i++)
-      if (l[size_t(i)] - f[size_t(i)] > 0) return set_err(FEMTO_AMD_ERR_PARAM, "max_occs_each == 0 with a multi-match pattern: Error during query processing");
-  }
-  HIP_TRY(hipMemcpy(&total, ix->s_out_starts.as<int64_t>() + npats, 8, hipMemcpyDeviceToHost));
+  HostBatch hb;
+  hb.npats = npats;
+  hb.plen = plen;
+  hb.flat = pats;
+  hb.starts = starts;
+  if ((rc = plan_host(ix, hb, max_occs_each, &total))) return rc;
   if (total_out) *total_out = total;
   if (noccs && npats) HIP_TRY(hipMemcpy(noccs, ix->s_noccs.p, size_t(npats) * 4, hipMemcpyDeviceToHost));
   if (out_starts) HIP_TRY(hipMemcpy(out_starts, ix->s_out_starts.p, size_t(npats + 1) * 8, hipMemcpyDeviceToHost));
@@ -1119,49 +1182,75 @@ int femto_amd_locate_flat(femto_amd_index_t* ix, int64_t npats, const int32_t* p
   if (offsets_capacity < total) return set_err(FEMTO_AMD_ERR_PARAM, "offsets buffer too small");
   if (total == 0) return FEMTO_AMD_OK;
   if ((rc = ix->s_offsets.reserve(size_t(total) * 8))) return rc;
-  rc = femto_amd_locate_walk_device(ix, npats, ix->s_first.as<int64_t>(), ix->s_out_starts.as<int64_t>(), total,
-                                    ix->s_offsets.as<int64_t>(), nullptr);
+  rc = launch_locate(ix, npats, ix->s_first.as<int64_t>(), ix->s_out_starts.as<int64_t>(), total, ix->s_offsets.as<int64_t>(), nullptr);
   if (rc) return rc;
   HIP_TRY(hipMemcpy(offsets, ix->s_offsets.p, size_t(total) * 8, hipMemcpyDeviceToHost));
   return FEMTO_AMD_OK;
 }
 
+int femto_amd_locate_flat_alloc(femto_amd_index_t* ix, int64_t npats, const int32_t* plen, const uint16_t* pats,
+                                const int64_t* starts, int max_occs_each, int32_t* noccs, int64_t* out_starts,
+                                int64_t** offsets_out, int64_t* total_out) {
+  if (!ix || !offsets_out) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  if (max_occs_each < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative max_occs_each");
+  int rc = ensure_device(ix);
+  if (rc) return rc;
+  if ((rc = validate_patterns(npats, plen, starts))) return rc;
+  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  HostBatch hb;
+  hb.npats = npats;
+  hb.plen = plen;
+  hb.flat = pats;
+  hb.starts = starts;
+  return locate_host(ix, hb, max_occs_each, noccs, out_starts, offsets_out, total_out);
+}
+
 int femto_amd_parallel_locate(femto_amd_index_t* ix, int npats, const int* plen, const uint16_t* const* pats,
                               int max_occs_each, int* noccs, int64_t** offsets) {
   if (npats < 0 || (npats && (!plen || !pats || !noccs || !offsets))) return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
-  std::vector<int64_t> starts(size_t(npats) + 1, 0);
-  for (int i = 0; i < npats; i++) {
-    if (plen[i] < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative pattern length");
-    starts[size_t(i) + 1] = starts[size_t(i)] + plen[i];
-  }
-  std::vector<uint16_t> flat(size_t(starts[size_t(npats)]) + 1);
-  for (int i = 0; i < npats; i++)
-    if (plen[i]) memcpy(flat.data() + starts[size_t(i)], pats[i], size_t(plen[i]) * 2);
-  std::vector<int32_t> n32(size_t(npats) + 1);
-  std::vector<int64_t> ostarts(size_t(npats) + 2);
-  int64_t total = 0;
-  int rc = femto_amd_locate_flat(ix, npats, plen, flat.data(), starts.data(), max_occs_each, n32.data(), ostarts.data(),
-                                 nullptr, 0, &total);
+  if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
+  if (max_occs_each < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative max_occs_each");
+  int rc = ensure_device(ix);
   if (rc) return rc;
-  std::vector<int64_t> all(size_t(total) + 1);
-  if (total) {
-    // second call re-runs the (cheap) plan; keeps the flat entry point stateless
-    rc = femto_amd_locate_flat(ix, npats, plen, flat.data(), starts.data(), max_occs_each, n32.data(), ostarts.data(),
-                               all.data(), total, &total);
+  std::vector<int64_t> ostarts(size_t(npats) + 2);
+  int64_t* all = nullptr;
+  int64_t total = 0;
+  {
+    std::lock_guard<std::recursive_mutex> lk(ix->mu);
+    HostBatch hb;
+    hb.npats = npats;
+    hb.plen = plen;
+    hb.ptrs = pats;
+    rc = locate_host(ix, hb, max_occs_each, noccs, ostarts.data(), &all, &total);
+    if (rc == -1) {  // small batch: flatten here (patterns are copied, as setup_string_query does, server.c:691-695)
+      std::vector<int64_t> starts(size_t(npats) + 1, 0);
+      for (int i = 0; i < npats; i++) {
+        if (plen[i] < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative pattern length");
+        starts[size_t(i) + 1] = starts[size_t(i)] + plen[i];
+      }
+      std::vector<uint16_t> flat(size_t(starts[size_t(npats)]) + 1);
+      for (int i = 0; i < npats; i++)
+        if (plen[i]) memcpy(flat.data() + starts[size_t(i)], pats[i], size_t(plen[i]) * 2);
+      hb.ptrs = nullptr;
+      hb.flat = flat.data();
+      hb.starts = starts.data();
+      rc = locate_host(ix, hb, max_occs_each, noccs, ostarts.data(), &all, &total);
+    }
     if (rc) return rc;
   }
   for (int i = 0; i < npats; i++) {  // femto.c:372-386
-    noccs[i] = n32[size_t(i)];
     offsets[i] = nullptr;
     if (noccs[i] > 0) {
       offsets[i] = static_cast<int64_t*>(malloc(sizeof(int64_t) * size_t(noccs[i])));
       if (!offsets[i]) {
         for (int j = 0; j < i; j++) { free(offsets[j]); offsets[j] = nullptr; }
+        free(all);
         return set_err(FEMTO_AMD_ERR_MEM, "malloc failed");
       }
-      memcpy(offsets[i], all.data() + ostarts[size_t(i)], sizeof(int64_t) * size_t(noccs[i]));
+      memcpy(offsets[i], all + ostarts[size_t(i)], sizeof(int64_t) * size_t(noccs[i]));
     }
   }
+  free(all);
   return FEMTO_AMD_OK;
 }
 

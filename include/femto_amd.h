@@ -99,6 +99,12 @@ int femto_amd_locate_flat(femto_amd_index_t* ix, int64_t npats, const int32_t* p
                           int32_t* noccs, int64_t* out_starts, int64_t* offsets,
                           int64_t offsets_capacity, int64_t* total_out);
 
+/* One-pass form of locate_flat: *offsets_out receives ONE malloc()ed array holding all offsets (pattern i's are
+ * [out_starts[i], out_starts[i+1]); NULL when *total_out == 0); the caller free()s it.  noccs / out_starts may be NULL. */
+int femto_amd_locate_flat_alloc(femto_amd_index_t* ix, int64_t npats, const int32_t* plen,
+                                const uint16_t* pats, const int64_t* starts, int max_occs_each,
+                                int32_t* noccs, int64_t* out_starts, int64_t** offsets_out, int64_t* total_out);
+
 /* Raw-byte convenience form: patterns given as bytes (each +5 -> alpha_t), as femto_search does
  * for literal patterns. */
 int femto_amd_count_bytes(femto_amd_index_t* ix, int64_t npats, const int32_t* plen,

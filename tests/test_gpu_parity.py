@@ -67,7 +67,10 @@ def test_count_locate_match_reference_goldens(fixtures, gpu_ok, name, mode):
     assert np.array_equal(first, fx.gold["count_first"])
     assert np.array_equal(last, fx.gold["count_last"])
     for mo, noccs, offs in fx.locate_cases():
-        n, got = ix.locate_flat(plen, flat, starts, mo)
+        n, got = ix.locate_flat(plen, flat, starts, mo)                # one-pass form (femto_amd_locate_flat_alloc)
+        assert np.array_equal(n, noccs), mo
+        assert np.array_equal(got, offs), mo
+        n, got = ix.locate_flat_two_call(plen, flat, starts, mo)       # sizing call + fill call (femto_amd_locate_flat)
         assert np.array_equal(n, noccs), mo
         assert np.array_equal(got, offs), mo
     ix.close()
@@ -240,6 +243,20 @@ def test_batch_above_a_million_patterns(tmp_path, gpu_ok, mode):
     assert np.array_equal(f2, of[:m]) and np.array_equal(l2, ol[:m])
     assert L.femto_amd_parallel_count(ix.handle, m, pl.ctypes.data, parr, f2.ctypes.data, None) == 0
     assert np.array_equal(f2, (ol - of + 1)[:m])
+    noccs_p = np.zeros(m, dtype=np.int32)
+    offs_p = (C.POINTER(C.c_int64) * m)()
+    assert L.femto_amd_parallel_locate(ix.handle, m, pl.ctypes.data, parr, 3, noccs_p.ctypes.data, offs_p) == 0
+    assert np.array_equal(noccs_p, on[:m])
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    pos = np.concatenate([[0], np.cumsum(on[:m])])
+    for i in range(m):
+        if noccs_p[i]:
+            if i % 97 == 0:
+                assert [offs_p[i][j] for j in range(noccs_p[i])] == list(oo[pos[i]:pos[i + 1]])
+            libc.free(offs_p[i])
+        else:
+            assert not offs_p[i]
     order = np.arange(n)[::-1]
     fr, lr = ix.count_flat(np.ascontiguousarray(plen[order]), flat, np.ascontiguousarray(starts[order]))
     assert np.array_equal(fr, of[order]) and np.array_equal(lr, ol[order])
