@@ -128,7 +128,7 @@ struct femto_amd_index {
   // scratch for the host-pointer API and the locate plan
   DeviceBuffer s_plen, s_pats, s_starts, s_first, s_last, s_noccs, s_noccs64, s_out_starts, s_offsets, s_scan[3];
   DeviceBuffer s_rows, s_ch, s_occ, s_off;
-  DeviceBuffer s_keys, s_keys2, s_idx, s_idx2, s_sorttmp;
+  DeviceBuffer s_keys, s_keys2, s_idx, s_idx2, s_sorttmp, s_pairs;
   bool sort_queries = true;   // FEMTO_AMD_SORT=0 disables
   uint8_t* d_dense = nullptr;  // alpha code -> dense sort digit (characters present in the text)
   int dense_bits = 8;
@@ -201,6 +201,7 @@ int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen
   const int64_t threads = npats * lanes_per_query;
   const int64_t blocks = (threads + kBlockThreads - 1) / kBlockThreads;
   if (blocks > 0x7fffffffLL) return set_err(FEMTO_AMD_ERR_PARAM, "batch too large for one launch");
+  bool split_pairs = false;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ix->timing) {  // events bracket the search kernel itself (the suffix-order sort is a separate, small launch)
     HIP_TRY(hipEventCreate(&e0));
@@ -240,13 +241,16 @@ int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen
       perm = ix->s_idx2.as<uint32_t>();
     }
     if (ix->timing) HIP_TRY(hipEventRecord(e0, stream));
-    if (ix->mode == 3 && perm)
+    if (ix->mode == 3 && perm) {
+      int rc2 = ix->s_pairs.reserve(size_t(npats) * 16);
+      if (rc2) return rc2;
       hipLaunchKernelGGL(count_kernel_pack<true>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
                          d_pats, d_starts, d_first, d_last, ix->d_err, perm, ix->s_keys2.as<uint64_t>(), ix->dense_bits,
-                         63 / ix->dense_bits);
-    else if (ix->mode == 3)
+                         63 / ix->dense_bits, ix->s_pairs.as<longlong2>());
+      split_pairs = true;
+    } else if (ix->mode == 3)
       hipLaunchKernelGGL(count_kernel_pack<false>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
-                         d_pats, d_starts, d_first, d_last, ix->d_err, perm, nullptr, 1, 0);
+                         d_pats, d_starts, d_first, d_last, ix->d_err, perm, nullptr, 1, 0, nullptr);
     else
       hipLaunchKernelGGL(count_kernel_lane, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
                          d_pats, d_starts, d_first, d_last, ix->d_err, perm);
@@ -258,6 +262,11 @@ int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen
   if (ix->timing) {
     HIP_TRY(hipEventRecord(e1, stream));
     ix->t_count.events.emplace_back(e0, e1);
+  }
+  if (split_pairs) {
+    hipLaunchKernelGGL(split_pairs_kernel, dim3(uint32_t((npats + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, stream,
+                       npats, ix->s_pairs.as<longlong2>(), d_first, d_last);
+    HIP_TRY(hipGetLastError());
   }
   return 0;
 }
@@ -1016,7 +1025,7 @@ void femto_amd_close(femto_amd_index_t* ix) {
     for (DeviceBuffer* b : {&ix->s_plen, &ix->s_pats, &ix->s_starts, &ix->s_first, &ix->s_last, &ix->s_noccs,
                             &ix->s_noccs64, &ix->s_out_starts, &ix->s_offsets, &ix->s_scan[0], &ix->s_scan[1],
                             &ix->s_scan[2], &ix->s_rows, &ix->s_ch, &ix->s_occ, &ix->s_off, &ix->s_keys, &ix->s_keys2, &ix->s_idx,
-                            &ix->s_idx2, &ix->s_sorttmp})
+                            &ix->s_idx2, &ix->s_sorttmp, &ix->s_pairs})
       b->release();
   }
   delete ix;

@@ -131,7 +131,8 @@ __global__ __launch_bounds__(256) void count_kernel_pack(const DevIndex ix, cons
                                                          const uint16_t* __restrict__ pats, const int64_t* __restrict__ starts,
                                                          int64_t* __restrict__ first_out, int64_t* __restrict__ last_out,
                                                          int* __restrict__ err_flag, const uint32_t* __restrict__ perm,
-                                                         const uint64_t* __restrict__ keys, const int bits, const int nsym) {
+                                                         const uint64_t* __restrict__ keys, const int bits, const int nsym,
+                                                         longlong2* __restrict__ pair_out) {
   const int64_t slot = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (slot >= npats) return;
   const int64_t q = perm ? int64_t(perm[slot]) : slot;
@@ -174,9 +175,27 @@ __global__ __launch_bounds__(256) void count_kernel_pack(const DevIndex ix, cons
     pack_search_step(ix, pack, j, code, first, last);
     if (first > last) break;
   }
+  if (pair_out) {  // sorted batch: ONE scattered 16-byte store per pattern; split_pairs_kernel restores the two arrays
+    pair_out[q] = make_longlong2(first, last);
+    return;
+  }
   first_out[q] = first;
   if (last_out) last_out[q] = last;
   else first_out[q] = last - first + 1;
+}
+
+// (first,last) pairs -> the API's separate arrays (coalesced); last_out == NULL: first_out receives the counts
+__global__ __launch_bounds__(256) void split_pairs_kernel(const int64_t n, const longlong2* __restrict__ pairs, int64_t* __restrict__ first_out,
+                                                          int64_t* __restrict__ last_out) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const longlong2 p = pairs[i];
+  if (last_out) {
+    first_out[i] = p.x;
+    last_out[i] = p.y;
+  } else {
+    first_out[i] = p.y - p.x + 1;
+  }
 }
 
 struct PackLine { uint32_t w[kPackLineWords]; };

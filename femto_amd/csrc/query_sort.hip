@@ -25,26 +25,39 @@ namespace femto_amd {
 // the top of the key; bit 0 is a flag: 1 = the key describes the WHOLE pattern (it has at most nsym symbols, all of
 // them characters of the text), so a kernel that works on dense codes never has to read the pattern itself.  For
 // ACGT texts bits = 3: a whole 20-mer fits the key and the batch is fully suffix-sorted.
-__global__ void suffix_key_kernel(const int64_t npats, const int32_t* __restrict__ plen,
-                                  const uint16_t* __restrict__ pats, const int64_t* __restrict__ starts,
-                                  const uint8_t* __restrict__ dense, const int bits, const int nsym,
-                                  uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+__global__ __launch_bounds__(256) void suffix_key_kernel(const int64_t npats, const int32_t* __restrict__ plen,
+                                                         const uint16_t* __restrict__ pats, const int64_t* __restrict__ starts,
+                                                         const uint8_t* __restrict__ dense, const int bits, const int nsym,
+                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+  __shared__ uint8_t s_dense[264];
+  for (int i = threadIdx.x; i < 261; i += blockDim.x) s_dense[i] = dense[i];
+  __syncthreads();
   const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (q >= npats) return;
   const int len = plen[q];
-  const uint16_t* p = pats + starts[q];
+  const int take = len < nsym ? len : nsym;
   uint64_t key = 0;
   bool whole = len <= nsym;
-  for (int k = 0; k < nsym; k++) {
-    const int pos = len - 1 - k;
-    uint64_t c = 0;
-    if (pos >= 0) {
-      const uint32_t ch = p[pos];
-      c = ch < 261u ? dense[ch] : 0;
-      whole = whole && c != 0;
+  if (take > 0) {
+    // the pattern's tail is read as aligned 8-byte words, last word first (4 symbols per load instead of one);
+    // a word never crosses a page, so touching the few bytes around the pattern inside its first/last word is safe
+    const uintptr_t last_sym = reinterpret_cast<uintptr_t>(pats + starts[q] + len) - 2;
+    uintptr_t wa = last_sym & ~uintptr_t(7);
+    int s_in_word = int((last_sym - wa) >> 1);
+    int got = 0;
+    while (got < take) {
+      const uint64_t w = *reinterpret_cast<const uint64_t*>(wa);
+      for (int s = s_in_word; s >= 0 && got < take; s--, got++) {
+        const uint32_t ch = uint32_t(w >> (16 * s)) & 0xffffu;
+        const uint64_t c = ch < 261u ? s_dense[ch] : 0;
+        whole = whole && c != 0;
+        key = (key << bits) | c;
+      }
+      wa -= 8;
+      s_in_word = 3;
     }
-    key = (key << bits) | c;
   }
+  key <<= bits * (nsym - take);
   keys[q] = (key << (64 - nsym * bits)) | (whole ? 1u : 0u);
   idx[q] = uint32_t(q);
 }
@@ -59,7 +72,9 @@ static int clamp_sort_syms(int bits, int sort_syms) {
 // 4096..100000 keys and begin_bit 37..43): they are sorted on whole keys -- at that size the passes cost nothing.
 static unsigned sort_begin_bit(int64_t npats, int bits, int sort_syms) {
   if (npats <= (int64_t(1) << 20)) return 0;
-  return unsigned(64 - clamp_sort_syms(bits, sort_syms) * bits);
+  int nbits = clamp_sort_syms(bits, sort_syms) * bits;
+  if (nbits > 8 && (nbits & 7) != 0 && (nbits & 7) <= 4) nbits &= ~7;  // a radix pass for <= 4 bits of the last symbols is not worth it
+  return unsigned(64 - nbits);
 }
 
 // temporary storage of the sort for exactly the bit range query_sort() will use (rocPRIM picks its algorithm,
