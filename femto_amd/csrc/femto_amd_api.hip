@@ -309,9 +309,12 @@ int device_scan(femto_amd_index* ix, int64_t n, const int64_t* in, int64_t* out 
 int launch_locate(femto_amd_index* ix, int64_t npats, const int64_t* d_first, const int64_t* d_out_starts,
                   int64_t total, int64_t* d_offsets, hipStream_t stream) {
   if (total <= 0) return 0;
-  const int64_t threads = total * kGroupW;
-  const int64_t blocks = (threads + kBlockThreads - 1) / kBlockThreads;
+  const int64_t threads = ix->mode == 0 ? total * kGroupW : total;   // mode 0 walks with a 32-lane group per row
+  const int64_t blocks = (total * kGroupW + kBlockThreads - 1) / kBlockThreads;
   if (threads >= (int64_t(1) << 32)) return set_err(FEMTO_AMD_ERR_PARAM, "too many rows to locate in one call (2^32 work-items per launch): lower max_occs_each or split the batch");
+  if (ix->mode == 3)  // rows first (one thread per pattern), then the walk -- no per-row search for the owning pattern
+    hipLaunchKernelGGL(expand_rows_kernel, dim3(uint32_t((npats + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, stream,
+                       npats, d_first, d_out_starts, d_offsets);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ix->timing) {
     HIP_TRY(hipEventCreate(&e0));
@@ -331,8 +334,7 @@ int launch_locate(femto_amd_index* ix, int64_t npats, const int64_t* d_first, co
                        d_out_starts, total, d_offsets);
   } else if (ix->mode == 3) {
     const int64_t lblocks = (total + kBlockThreads - 1) / kBlockThreads;
-    hipLaunchKernelGGL(locate_kernel_pack, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_first,
-                       d_out_starts, total, d_offsets);
+    hipLaunchKernelGGL(locate_kernel_pack, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, total, d_offsets);
   } else if (ix->mode == 1) {
     const int64_t lblocks = (total + kBlockThreads - 1) / kBlockThreads;
     hipLaunchKernelGGL(locate_kernel_lane, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_first,

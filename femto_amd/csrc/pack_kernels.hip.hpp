@@ -251,18 +251,26 @@ __device__ __forceinline__ PackStep pack_step(const PackLine& L, uint32_t r) {
   return s;
 }
 
-// locate walk (do_back_query / do_context_query, src/main/server.c:2228-2359, :2627-2795): one line per LF step
-__global__ __launch_bounds__(256) void locate_kernel_pack(const DevIndex ix, const int64_t npats, const int64_t* __restrict__ first,
-                                                          const int64_t* __restrict__ out_starts, const int64_t total,
-                                                          int64_t* __restrict__ offsets) {
+// rows to locate, written where their offsets will go: pattern q's rows first[q] .. first[q]+noccs-1 at
+// offsets[out_starts[q] ..] (setup_locate_range, src/main/server.c:4047).  One thread per pattern; the walk kernel
+// then needs no search for "which pattern owns output slot i".
+__global__ __launch_bounds__(256) void expand_rows_kernel(const int64_t npats, const int64_t* __restrict__ first,
+                                                          const int64_t* __restrict__ out_starts, int64_t* __restrict__ offsets) {
+  const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (q >= npats) return;
+  const int64_t base = out_starts[q], n = out_starts[q + 1] - base, f = first[q];
+  for (int64_t j = 0; j < n; j++) offsets[base + j] = f + j;
+}
+
+// locate walk (do_back_query / do_context_query, src/main/server.c:2228-2359, :2627-2795): one line per LF step;
+// offsets[item] holds the row on entry and the row's text offset on return
+// (A persistent-lane variant -- finished lanes pull the next row instead of idling until the slowest lane of the
+// wavefront is done -- and the removal of the per-row owner search both measured neutral: 105 M random line
+// fetches per 10 M rows run at 30 G lines/s = 4 TB/s either way, the rate of purely random 128-byte reads.)
+__global__ __launch_bounds__(256) void locate_kernel_pack(const DevIndex ix, const int64_t total, int64_t* __restrict__ offsets) {
   const int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (item >= total) return;
-  int64_t lo = 0, hi = npats;
-  while (hi - lo > 1) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (out_starts[mid] <= item) lo = mid; else hi = mid;
-  }
-  int64_t row = first[lo] + (item - out_starts[lo]);
+  int64_t row = offsets[item];
   int64_t steps = 0, result = -1;
   while (row >= 0) {
     uint64_t line;
