@@ -52,6 +52,7 @@ class Batch:
         self.d_starts = torch.from_numpy(self.starts).to(dev)
         self.d_res2 = [torch.empty((2, self.n), dtype=torch.int64, device=dev) for _ in range(2)]   # [first; last], double buffered
         self.d_res = self.d_res2[0]
+        self.d_wire2 = None       # multi-GPU: the ranges as they travel to rank 0 (see wire())
         self.d_noccs = torch.empty(self.n, dtype=torch.int32, device=dev)
         self.d_ostarts = torch.empty(self.n + 1, dtype=torch.int64, device=dev)
         self.offsets = None
@@ -70,6 +71,18 @@ class Batch:
         self.total = total
         ix.locate_walk_device(self.n, self.d_res[0].data_ptr(), self.d_ostarts.data_ptr(), total,
                               self.offsets.data_ptr(), stream)
+
+
+    def wire(self, rows, buf=0):
+        """The (first,last) ranges of this step in the form that is gathered to rank 0: row numbers of an index with
+        fewer than 2^31 rows fit int32 (values -1 .. rows), so they travel as 8 instead of 16 bytes per pattern --
+        a lossless narrowing; larger indexes send int64."""
+        if rows >= (1 << 31) - 1:
+            return self.d_res
+        if self.d_wire2 is None:
+            self.d_wire2 = [self.torch.empty((2, self.n), dtype=self.torch.int32, device=self.dev) for _ in range(2)]
+        self.d_wire2[buf].copy_(self.d_res)
+        return self.d_wire2[buf]
 
 
 def main():
@@ -159,7 +172,7 @@ def main():
     batch = Batch(torch, dev, plen, flat)
     gather_lists = None
     if world > 1 and rank == 0:
-        gather_lists = [[torch.empty_like(batch.d_res) for _ in range(world)] for _ in range(2)]
+        gather_lists = [[torch.empty_like(batch.wire(info.total_length)) for _ in range(world)] for _ in range(2)]
     stream = torch.cuda.current_stream().cuda_stream
     pending = [None, None]
     counter = {"k": 0}
@@ -174,7 +187,7 @@ def main():
             pending[b] = None
         batch.step(ix, args.max_occs, stream, b)
         if world > 1:
-            pending[b] = dist.gather(batch.d_res, gather_lists[b] if rank == 0 else None, dst=0, async_op=True)
+            pending[b] = dist.gather(batch.wire(info.total_length, b), gather_lists[b] if rank == 0 else None, dst=0, async_op=True)
 
     def drain():
         for b in range(2):
@@ -375,7 +388,7 @@ def main():
                    "rank_mode": {3: "pack", 1: "lane", 2: "flat", 0: "raw"}[ix.rank_mode], "index": {"rows": int(info.total_length), "blocks": int(info.number_of_blocks), "buckets": int(info.total_buckets),
                              "image_bytes": int(info.image_bytes), "table_bytes": int(info.table_bytes),
                              "packed_lines": ix.pack_info()},
-                   "parallelism": ("range-split index (1/N of the blocks per GPU, peer loads over xGMI)" if args.layout == "split" and world > 1 else "replicated index") + f", query shards x{world}" + (", RCCL gather of (first,last) to rank 0 every step, overlapped with the next step's kernels" if world > 1 else ""),
+                   "parallelism": ("range-split index (1/N of the blocks per GPU, peer loads over xGMI)" if args.layout == "split" and world > 1 else "replicated index") + f", query shards x{world}" + (", RCCL gather of (first,last) to rank 0 every step (int32 rows when the index has < 2^31 rows), overlapped with the next step's kernels" if world > 1 else ""),
                    "build_s": build_s, "open_s": open_s},
         "roofline": roof, "cpu_baseline": cpu,
         "gpu_vs_cpu": (value / cpu["value"]) if cpu else None,
