@@ -223,7 +223,8 @@ class Index:
         """small-alphabet packed lines (mode 3): {'available', 'bytes', 'build_ms', 'ktab_syms'}"""
         a, b, ms, k = C.c_int(0), C.c_int64(0), C.c_double(0), C.c_int(0)
         _check(lib().femto_amd_pack_info(self._h, C.byref(a), C.byref(b), C.byref(ms), C.byref(k)))
-        return {"available": bool(a.value), "bytes": b.value, "build_ms": ms.value, "ktab_syms": k.value}
+        return {"available": bool(a.value & 1), "available2": bool(a.value & 2), "bytes": b.value, "build_ms": ms.value,
+                "ktab_syms": k.value}
 
     def document_info(self, doc):
         p, n = C.c_char_p(), C.c_int64(0)

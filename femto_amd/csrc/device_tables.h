@@ -130,6 +130,15 @@ struct DevIndex {           // passed by value to kernels
   uint16_t pack_alpha[8];   // dense code -> alpha code
   int32_t pack_sigma;
   uint32_t pack_stop;       // bit c: alpha code of dense code c is <= SEOF (a locate walk stops there)
+  // two-level 16-ary lines for byte alphabets (pack2_kernels.hip.hpp); null when more than 256 characters occur
+  const uint32_t* p2_l1;    // 32 dwords per 64 rows
+  const uint32_t* p2_l2;    // 32 dwords per 96 level-2 positions
+  const int64_t* p2_base;   // [16] first level-2 line of every h
+  const int64_t* p2_c;      // [512]: C[ch(code)] for code 0..255, then C[ch(code)+1]-1
+  const uint16_t* p2_code;  // [261] alpha code -> dense code 0..255, 0xffff: not in the text
+  const uint16_t* p2_alpha; // [256] dense code -> alpha code
+  int32_t p2_sigma;
+  uint32_t p2_stop_below;   // dense codes below this are <= SEOF (a locate walk stops there)
   int64_t total_length;
   int64_t total_buckets;
   int32_t b_size;

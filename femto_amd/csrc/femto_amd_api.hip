@@ -17,6 +17,7 @@
 #include "index_builder.hpp"
 #include "kernels.hip.hpp"
 #include "pack_kernels.hip.hpp"
+#include "pack2_kernels.hip.hpp"
 
 using namespace femto_amd;
 
@@ -119,6 +120,11 @@ struct femto_amd_index {
   uint8_t* d_pack_code = nullptr;
   int64_t* d_pack_c = nullptr;
   int64_t* d_ktab = nullptr;
+  uint32_t *d_p2_l1 = nullptr, *d_p2_l2 = nullptr;
+  int64_t *d_p2_base = nullptr, *d_p2_c = nullptr;
+  uint16_t *d_p2_code = nullptr, *d_p2_alpha = nullptr;
+  int64_t pack2_bytes = 0;
+  double pack2_build_ms = 0;
   int64_t pack_bytes = 0;
   double pack_build_ms = 0;
   int num_cus = 256;
@@ -206,7 +212,7 @@ int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen
   if (ix->timing) {  // events bracket the search kernel itself (the suffix-order sort is a separate, small launch)
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    if (ix->mode != 1 && ix->mode != 3) HIP_TRY(hipEventRecord(e0, stream));
+    if (ix->mode != 1 && ix->mode != 3 && ix->mode != 4) HIP_TRY(hipEventRecord(e0, stream));
   }
   if (ix->mode == 2) {
     int64_t lblocks = (npats + kBlockThreads - 1) / kBlockThreads;
@@ -220,7 +226,7 @@ int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen
     }
     hipLaunchKernelGGL((count_kernel_flat<1>), dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats,
                          d_plen, d_pats, d_starts, d_first, d_last, ix->d_err);
-  } else if (ix->mode == 1 || ix->mode == 3) {
+  } else if (ix->mode == 1 || ix->mode == 3 || ix->mode == 4) {
     const int64_t lblocks = (npats + kBlockThreads - 1) / kBlockThreads;
     const uint32_t* perm = nullptr;
     if (ix->sort_queries && npats >= ix->sort_min && npats < (int64_t(1) << 32)) {
@@ -248,7 +254,17 @@ int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen
                          d_pats, d_starts, d_first, d_last, ix->d_err, perm, ix->s_keys2.as<uint64_t>(), ix->dense_bits,
                          63 / ix->dense_bits, ix->s_pairs.as<longlong2>());
       split_pairs = true;
-    } else if (ix->mode == 3)
+    } else if (ix->mode == 4 && perm) {
+      int rc2 = ix->s_pairs.reserve(size_t(npats) * 16);
+      if (rc2) return rc2;
+      hipLaunchKernelGGL(count_kernel_pack2<true>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
+                         d_pats, d_starts, d_first, d_last, ix->d_err, perm, ix->s_keys2.as<uint64_t>(), ix->dense_bits,
+                         63 / ix->dense_bits, ix->s_pairs.as<longlong2>());
+      split_pairs = true;
+    } else if (ix->mode == 4)
+      hipLaunchKernelGGL(count_kernel_pack2<false>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
+                         d_pats, d_starts, d_first, d_last, ix->d_err, perm, nullptr, 1, 0, nullptr);
+    else if (ix->mode == 3)
       hipLaunchKernelGGL(count_kernel_pack<false>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
                          d_pats, d_starts, d_first, d_last, ix->d_err, perm, nullptr, 1, 0, nullptr);
     else
@@ -312,7 +328,7 @@ int launch_locate(femto_amd_index* ix, int64_t npats, const int64_t* d_first, co
   const int64_t threads = ix->mode == 0 ? total * kGroupW : total;   // mode 0 walks with a 32-lane group per row
   const int64_t blocks = (total * kGroupW + kBlockThreads - 1) / kBlockThreads;
   if (threads >= (int64_t(1) << 32)) return set_err(FEMTO_AMD_ERR_PARAM, "too many rows to locate in one call (2^32 work-items per launch): lower max_occs_each or split the batch");
-  if (ix->mode == 3)  // rows first (one thread per pattern), then the walk -- no per-row search for the owning pattern
+  if (ix->mode == 3 || ix->mode == 4)  // rows first (one thread per pattern), then the walk -- no per-row search for the owning pattern
     hipLaunchKernelGGL(expand_rows_kernel, dim3(uint32_t((npats + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, stream,
                        npats, d_first, d_out_starts, d_offsets);
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -332,6 +348,9 @@ int launch_locate(femto_amd_index* ix, int64_t npats, const int64_t* d_first, co
     }
     hipLaunchKernelGGL(locate_kernel_flat, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_first,
                        d_out_starts, total, d_offsets);
+  } else if (ix->mode == 4) {
+    const int64_t lblocks = (total + kBlockThreads - 1) / kBlockThreads;
+    hipLaunchKernelGGL(locate_kernel_pack2, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, total, d_offsets);
   } else if (ix->mode == 3) {
     const int64_t lblocks = (total + kBlockThreads - 1) / kBlockThreads;
     hipLaunchKernelGGL(locate_kernel_pack, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, total, d_offsets);
@@ -376,6 +395,27 @@ int stage_patterns(femto_amd_index* ix, int64_t npats, const int32_t* plen, cons
   return 0;
 }
 
+
+// first-steps table (ktab): as many key fields as give at most 2^21 entries; the ranges do not depend on which
+// layout computes them, so pack and pack2 share it
+template <class Kernel>
+int build_ktab(femto_amd_index* ix, Kernel kernel) {
+  if (ix->dev.ktab) return 0;
+  const char* kt = getenv("FEMTO_AMD_KTAB");
+  if (kt && atoi(kt) == 0) return 0;
+  const int bits = ix->dense_bits;
+  const int syms = std::min(21 / bits, 63 / bits);
+  const size_t entries = size_t(1) << (bits * syms);
+  if (hipMalloc(reinterpret_cast<void**>(&ix->d_ktab), entries * 16) != hipSuccess) return set_err(FEMTO_AMD_ERR_MEM, "hipMalloc ktab");
+  hipLaunchKernelGGL(kernel, dim3(uint32_t((entries + 255) / 256)), dim3(256), 0, nullptr, ix->dev, bits, syms,
+                     reinterpret_cast<longlong2*>(ix->d_ktab));
+  if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return set_err(FEMTO_AMD_ERR_INVALID, "ktab build failed");
+  ix->dev.ktab = ix->d_ktab;
+  ix->dev.ktab_bits = bits * syms;
+  ix->dev.ktab_syms = syms;
+  ix->table_bytes += int64_t(entries * 16);
+  return 0;
+}
 
 // Derives the packed lines of pack_kernels.hip.hpp on the GPU from the uploaded index (needs the lane tables).
 int build_pack(femto_amd_index* ix) {
@@ -455,22 +495,135 @@ int build_pack(femto_amd_index* ix) {
     ix->pack_build_ms = ms;
     ix->dev.pack = ix->d_pack;
     ix->dev.pack_sa = ix->d_pack_sa;
-    // precomputed first steps (ktab): as many key fields as give at most 2^21 entries
-    const char* kt = getenv("FEMTO_AMD_KTAB");
-    if (!kt || atoi(kt) != 0) {
-      const int bits = ix->dense_bits;
-      const int syms = std::min(21 / bits, 63 / bits);
-      const size_t entries = size_t(1) << (bits * syms);
-      if (hipMalloc(reinterpret_cast<void**>(&ix->d_ktab), entries * 16) != hipSuccess) return set_err(FEMTO_AMD_ERR_MEM, "hipMalloc ktab");
-      hipLaunchKernelGGL(ktab_build_kernel, dim3(uint32_t((entries + 255) / 256)), dim3(256), 0, nullptr, ix->dev, bits, syms,
-                         reinterpret_cast<longlong2*>(ix->d_ktab));
-      if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return set_err(FEMTO_AMD_ERR_INVALID, "ktab build failed");
-      ix->dev.ktab = ix->d_ktab;
-      ix->dev.ktab_bits = bits * syms;
-      ix->dev.ktab_syms = syms;
-      ix->pack_bytes += int64_t(entries * 16);
-      ix->table_bytes += int64_t(entries * 16);
+    r = build_ktab(ix, ktab_build_kernel);
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return r;
+}
+
+// Derives the two-level lines of pack2_kernels.hip.hpp on the GPU (needs the lane tables).
+int build_pack2(femto_amd_index* ix) {
+  HostIndex& h = ix->host;
+  if (!h.dir_regular || h.total_length <= 0) return 0;
+  const char* env = getenv("FEMTO_AMD_PACK2");
+  if (env && atoi(env) == 0) return 0;
+  if (ix->dev.pack && !(env && atoi(env) != 0)) return 0;   // the 3-bit lines already serve this index
+  std::vector<uint16_t> code(264, 0xffff), alpha(256, uint16_t(kAlphaSize));
+  std::vector<int64_t> pc(512, 0);
+  int sigma = 0;
+  uint32_t stop_below = 0;
+  for (int ch = 0; ch < kAlphaSize; ch++)
+    if (h.C[size_t(ch) + 1] > h.C[size_t(ch)]) {
+      if (sigma == 256) return 0;  // more than 256 distinct characters: the wavelet path stays
+      alpha[size_t(sigma)] = uint16_t(ch);
+      pc[size_t(sigma)] = h.C[size_t(ch)];
+      pc[256 + size_t(sigma)] = h.C[size_t(ch) + 1] - 1;
+      if (ch <= kSEOF) stop_below = uint32_t(sigma) + 1;
+      code[size_t(ch)] = uint16_t(sigma++);
     }
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, nullptr));
+  int r;
+  int64_t bytes0 = ix->table_bytes;
+  if ((r = upload(&ix->d_p2_code, code, &ix->table_bytes))) return r;
+  if ((r = upload(&ix->d_p2_alpha, alpha, &ix->table_bytes))) return r;
+  if ((r = upload(&ix->d_p2_c, pc, &ix->table_bytes))) return r;
+  DevIndex& d = ix->dev;
+  d.p2_code = ix->d_p2_code;
+  d.p2_alpha = ix->d_p2_alpha;
+  d.p2_c = ix->d_p2_c;
+  d.p2_sigma = sigma;
+  d.p2_stop_below = stop_below;
+  const int64_t n = h.total_length;
+  const int64_t nl1 = (n + kP2Rows1 - 1) / kP2Rows1, stride1 = nl1 + 1;
+  DeviceBuffer sym, counts, scans, lo2;
+  auto body = [&]() -> int {
+    int rc;
+    if ((rc = sym.reserve(size_t(n) * 2))) return rc;
+    if ((rc = counts.reserve(size_t(17 * stride1) * 8))) return rc;
+    if ((rc = scans.reserve(size_t(17 * stride1) * 8))) return rc;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_p2_l1), size_t(nl1) * 128));
+    const int64_t chunk = int64_t(1) << 30;
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+      const int64_t cn = std::min(chunk, n - r0);
+      hipLaunchKernelGGL(p2_extract_kernel, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, r0, cn, sym.as<uint16_t>());
+    }
+    hipLaunchKernelGGL(p2_l1_planes_kernel, dim3(uint32_t((nl1 + 255) / 256)), dim3(256), 0, nullptr, nl1, n, sym.as<uint16_t>(), ix->d_p2_l1,
+                       counts.as<int64_t>(), stride1);
+    HIP_TRY(hipGetLastError());
+    for (int c = 0; c < 17; c++)
+      if ((rc = device_scan(ix, nl1, counts.as<int64_t>() + c * stride1, scans.as<int64_t>() + c * stride1, 0, nullptr))) return rc;
+    hipLaunchKernelGGL(p2_l1_counts_kernel, dim3(uint32_t((nl1 + 255) / 256)), dim3(256), 0, nullptr, nl1, ix->d_p2_l1, scans.as<int64_t>(), stride1);
+    HIP_TRY(hipGetLastError());
+    d.p2_l1 = ix->d_p2_l1;
+    // level 2: every h starts on a line boundary
+    std::vector<int64_t> tot(17), base(16);
+    for (int c = 0; c < 17; c++) HIP_TRY(hipMemcpy(&tot[size_t(c)], scans.as<int64_t>() + c * stride1 + nl1, 8, hipMemcpyDeviceToHost));
+    int64_t nl2 = 0;
+    for (int k = 0; k < 16; k++) {
+      base[size_t(k)] = nl2;
+      nl2 += (tot[size_t(k)] + kP2Rows2 - 1) / kP2Rows2;
+    }
+    if (nl2 == 0) nl2 = 1;
+    if ((rc = upload(&ix->d_p2_base, base, &ix->table_bytes))) return rc;
+    d.p2_base = ix->d_p2_base;
+    const int64_t stride2 = nl2 + 1;
+    if ((rc = lo2.reserve(size_t(nl2) * kP2Rows2))) return rc;
+    HIP_TRY(hipMemset(lo2.p, 0, size_t(nl2) * kP2Rows2));
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+      const int64_t cn = std::min(chunk, n - r0);
+      hipLaunchKernelGGL(p2_scatter_kernel, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, r0, cn, sym.as<uint16_t>(),
+                         lo2.as<uint8_t>());
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_p2_l2), size_t(nl2) * 128));
+    // the level-1 scratch is free again: reuse it for the level-2 counts when it is large enough
+    if ((rc = counts.reserve(size_t(16 * stride2) * 8))) return rc;
+    if ((rc = scans.reserve(size_t(16 * stride2) * 8))) return rc;
+    hipLaunchKernelGGL(p2_l2_planes_kernel, dim3(uint32_t((nl2 + 255) / 256)), dim3(256), 0, nullptr, nl2, lo2.as<uint8_t>(), ix->d_p2_l2,
+                       counts.as<int64_t>(), stride2);
+    HIP_TRY(hipGetLastError());
+    for (int c = 0; c < 16; c++)
+      if ((rc = device_scan(ix, nl2, counts.as<int64_t>() + c * stride2, scans.as<int64_t>() + c * stride2, 0, nullptr))) return rc;
+    hipLaunchKernelGGL(p2_l2_counts_kernel, dim3(uint32_t((nl2 + 255) / 256)), dim3(256), 0, nullptr, ix->dev, nl2, ix->d_p2_l2,
+                       scans.as<int64_t>(), stride2);
+    HIP_TRY(hipGetLastError());
+    d.p2_l2 = ix->d_p2_l2;
+    int64_t sa_bytes = 0;
+    if (!ix->d_pack_sa) {  // offsets of the marked rows (shared with the 3-bit lines when both exist)
+      const int64_t nmarks = tot[16];
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_pack_sa), size_t(nmarks > 0 ? nmarks : 1) * 8));
+      for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+        const int64_t cn = std::min(chunk, n - r0);
+        hipLaunchKernelGGL(p2_sa_kernel, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, r0, cn, sym.as<uint16_t>(),
+                           ix->d_pack_sa);
+      }
+      HIP_TRY(hipGetLastError());
+      d.pack_sa = ix->d_pack_sa;
+      sa_bytes = nmarks * 8;
+    }
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    ix->table_bytes += (nl1 + nl2) * 128 + sa_bytes;
+    return 0;
+  };
+  r = body();
+  sym.release();
+  counts.release();
+  scans.release();
+  lo2.release();
+  if (r == 0) {
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    ix->pack2_build_ms = ms;
+    ix->pack2_bytes = ix->table_bytes - bytes0;
+    r = build_ktab(ix, ktab_build_kernel2);
+  } else {
+    d.p2_l1 = nullptr;
+    d.p2_l2 = nullptr;
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
@@ -851,12 +1004,15 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
       ix->mode = h.dir_regular ? 1 : 0;
       if (split) return 0;  // lane kernels only
       if ((r = build_pack(ix))) return r;
+      if ((r = build_pack2(ix))) return r;
       if (ix->dev.pack) ix->mode = 3;
+      else if (ix->dev.p2_l1) ix->mode = 4;
       if (const char* m = getenv("FEMTO_AMD_RANK_MODE")) {
         if (!strcmp(m, "raw")) ix->mode = 0;
         else if (!strcmp(m, "lane") && h.dir_regular) ix->mode = 1;
         else if (!strcmp(m, "flat") && h.dir_regular) ix->mode = 2;
         else if (!strcmp(m, "pack") && ix->dev.pack) ix->mode = 3;
+        else if (!strcmp(m, "pack2") && ix->dev.p2_l1) ix->mode = 4;
       }
       return 0;
     };
@@ -1024,6 +1180,12 @@ void femto_amd_close(femto_amd_index_t* ix) {
     (void)hipFree(ix->d_pack_code);
     (void)hipFree(ix->d_pack_c);
     (void)hipFree(ix->d_ktab);
+    (void)hipFree(ix->d_p2_l1);
+    (void)hipFree(ix->d_p2_l2);
+    (void)hipFree(ix->d_p2_base);
+    (void)hipFree(ix->d_p2_c);
+    (void)hipFree(ix->d_p2_code);
+    (void)hipFree(ix->d_p2_alpha);
     for (DeviceBuffer* b : {&ix->s_plen, &ix->s_pats, &ix->s_starts, &ix->s_first, &ix->s_last, &ix->s_noccs,
                             &ix->s_noccs64, &ix->s_out_starts, &ix->s_offsets, &ix->s_scan[0], &ix->s_scan[1],
                             &ix->s_scan[2], &ix->s_rows, &ix->s_ch, &ix->s_occ, &ix->s_off, &ix->s_keys, &ix->s_keys2, &ix->s_idx,
@@ -1289,7 +1451,11 @@ int femto_amd_block_requests(femto_amd_index_t* ix, int64_t n, const int64_t* ro
     HIP_TRY(hipMemcpy(d_chin, ch_in, size_t(n) * 2, hipMemcpyHostToDevice));
   }
   const int64_t blocks = (n * kGroupW + kBlockThreads - 1) / kBlockThreads;
-  if (ix->mode == 3)
+  if (ix->mode == 4)
+    hipLaunchKernelGGL(block_request_kernel_pack2, dim3(uint32_t((n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads),
+                       0, nullptr, ix->dev, n, ix->s_rows.as<int64_t>(), d_chin, d_chout, ix->s_occ.as<int64_t>(),
+                       ix->s_off.as<int64_t>());
+  else if (ix->mode == 3)
     hipLaunchKernelGGL(block_request_kernel_pack, dim3(uint32_t((n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads),
                        0, nullptr, ix->dev, n, ix->s_rows.as<int64_t>(), d_chin, d_chout, ix->s_occ.as<int64_t>(),
                        ix->s_off.as<int64_t>());
@@ -1351,7 +1517,9 @@ int femto_amd_forward_steps(femto_amd_index_t* ix, int64_t n, const int64_t* row
 }
 
 int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode) {
-  if (!ix || mode < 0 || mode > 3) return set_err(FEMTO_AMD_ERR_PARAM, "bad rank mode");
+  if (!ix || mode < 0 || mode > 4) return set_err(FEMTO_AMD_ERR_PARAM, "bad rank mode");
+  if (mode == 4 && !ix->dev.p2_l1)
+    return set_err(FEMTO_AMD_ERR_INVALID, "two-level lines (mode 4) are built for indexes with 9..256 distinct characters (FEMTO_AMD_PACK2=1 forces them for fewer)");
   if (mode == 3 && !ix->dev.pack)
     return set_err(FEMTO_AMD_ERR_INVALID, "packed lines (mode 3) exist only for indexes with at most 8 distinct characters");
   if (mode >= 1 && !ix->host.dir_regular)
@@ -1368,6 +1536,9 @@ int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* by
   if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
   if (available) *available = ix->dev.pack != nullptr;
   if (ktab_syms) *ktab_syms = ix->dev.ktab ? ix->dev.ktab_syms : 0;
+  if (available && ix->dev.p2_l1) *available |= 2;   // bit 1: the two-level lines (mode 4) exist
+  if (bytes && !ix->dev.pack) *bytes = ix->pack2_bytes;
+  if (build_ms && !ix->dev.pack) *build_ms = ix->pack2_build_ms;
   if (bytes) *bytes = ix->pack_bytes;
   if (build_ms) *build_ms = ix->pack_build_ms;
   return FEMTO_AMD_OK;

@@ -1,0 +1,512 @@
+// pack2_kernels.hip.hpp -- fast path for byte alphabets (mode 4, "pack2"): up to 256 distinct characters.
+//
+// The generalisation of pack_kernels.hip.hpp's one-line-per-step layout to alphabets that do not fit three bits:
+// a two-level 16-ary decomposition of the dense character code c = 16*h + l (a wavelet tree of arity 16 and
+// depth 2 in place of femto's binary Huffman-shaped tree of RLE/literal sequences, src/main/wtree.c):
+//
+//   level 1, one 128-byte line per 64 rows:
+//     dword  0.. 7  four bit planes of h for rows 64*line + [0,64)      (plane p = dwords 2p, 2p+1)
+//     dword  8.. 9  1 = the row is marked (its offset is in pack_sa)
+//     dword 10..25  low 32 bits of  #rows before this line whose h == k            k = 0..15
+//     dword 26..29  bits 32..39 of those counts (four per dword)
+//     dword 30, 31  number of marked rows before this line (low 32 bits, bits 32..39)
+//   level 2: for every h the l-digits of the rows with that h, in row order, each h starting on a line
+//   boundary (p2_base[h] = its first line); one 128-byte line per 96 positions:
+//     dword  0..11  four bit planes of l                                   (plane p = dwords 3p..3p+2)
+//     dword 12..27  low 32 bits of  C[ch(16h+k)] + #earlier positions of this h whose l == k   k = 0..15
+//     dword 28..31  bits 32..39 of those
+//
+// Occ(c,row): rank of h among rows <= row from ONE level-1 line, then the l-count from ONE level-2 line -- two
+// memory lines instead of ~4.5 wavelet levels of one or two lines each plus Elias-gamma decoding; an LF step of
+// locate (character of the row, its Occ, the mark test) is the same two lines.  Derived at open on the GPU from the
+// uploaded femto blocks (lane kernels); results identical to every other mode (tests compare all of them).
+#pragma once
+
+namespace femto_amd {
+
+constexpr int kP2Rows1 = 64;
+constexpr int kP2Rows2 = 96;
+
+__device__ __forceinline__ uint64_t p2_below_incl(uint32_t r) {  // bits 0..r
+  return r >= 63u ? ~0ull : ((1ull << (r + 1)) - 1ull);
+}
+
+// rows of the level-1 line, among its first r+1, whose h equals `h`  (+ the count before the line): global rank of h
+__device__ __forceinline__ int64_t p2_rank_h(const uint32_t* __restrict__ l1, uint64_t line, uint32_t r, uint32_t h) {
+  const uint32_t* lp = l1 + line * 32;
+  const uint4 a = reinterpret_cast<const uint4*>(lp)[0], b = reinterpret_cast<const uint4*>(lp)[1];
+  const uint32_t lo = lp[10 + h];
+  const uint32_t hi = (lp[26 + (h >> 2)] >> (8 * (h & 3u))) & 0xffu;
+  const uint64_t p0 = (uint64_t(a.y) << 32) | a.x, p1 = (uint64_t(a.w) << 32) | a.z;
+  const uint64_t p2 = (uint64_t(b.y) << 32) | b.x, p3 = (uint64_t(b.w) << 32) | b.z;
+  const uint64_t eq = (p0 ^ ((h & 1u) ? 0ull : ~0ull)) & (p1 ^ ((h & 2u) ? 0ull : ~0ull)) & (p2 ^ ((h & 4u) ? 0ull : ~0ull)) &
+                      (p3 ^ ((h & 8u) ? 0ull : ~0ull));
+  return int64_t((uint64_t(hi) << 32) | lo) + int64_t(__popcll(eq & p2_below_incl(r)));
+}
+
+struct P2Planes2 { uint32_t w[12]; };
+
+__device__ __forceinline__ void p2_load2(const uint32_t* __restrict__ l2, uint64_t line, P2Planes2& P) {
+  const uint4* lp = reinterpret_cast<const uint4*>(l2 + line * 32);
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const uint4 v = lp[k];
+    P.w[4 * k] = v.x; P.w[4 * k + 1] = v.y; P.w[4 * k + 2] = v.z; P.w[4 * k + 3] = v.w;
+  }
+}
+
+// positions among the first n (1..96) of a level-2 line whose l equals `l`
+__device__ __forceinline__ uint32_t p2_match2(const P2Planes2& P, uint32_t l, uint32_t n) {
+  const uint32_t c0 = (l & 1u) ? 0u : ~0u, c1 = (l & 2u) ? 0u : ~0u, c2 = (l & 4u) ? 0u : ~0u, c3 = (l & 8u) ? 0u : ~0u;
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const uint32_t eq = (P.w[k] ^ c0) & (P.w[3 + k] ^ c1) & (P.w[6 + k] ^ c2) & (P.w[9 + k] ^ c3);
+    const int bits = int(n) - 32 * k;
+    const uint32_t m = bits >= 32 ? ~0u : (bits <= 0 ? 0u : ((1u << bits) - 1u));
+    cnt += uint32_t(__popc(eq & m));
+  }
+  return cnt;
+}
+
+__device__ __forceinline__ void p2_split2(int64_t p, uint64_t* line_in_h, uint32_t* r) {
+  const uint32_t q = uint32_t(uint64_t(p) >> 5);
+  const uint32_t l = q / 3u;
+  *line_in_h = l;
+  *r = uint32_t(uint64_t(p) - uint64_t(l) * kP2Rows2);
+}
+
+// C[ch] + Occ(code, row) (row included), row >= 0
+__device__ __forceinline__ int64_t p2_c_plus_occ(const DevIndex& ix, uint32_t code, int64_t row) {
+  const uint32_t h = code >> 4, l = code & 15u;
+  const int64_t rank = p2_rank_h(ix.p2_l1, uint64_t(row) >> 6, uint32_t(row) & 63u, h);
+  if (rank == 0) return ix.p2_c[code];
+  uint64_t lh;
+  uint32_t r2;
+  p2_split2(rank - 1, &lh, &r2);
+  const uint64_t line2 = uint64_t(ix.p2_base[h]) + lh;
+  P2Planes2 P;
+  p2_load2(ix.p2_l2, line2, P);
+  const uint32_t* lp = ix.p2_l2 + line2 * 32;
+  const uint32_t lo = lp[12 + l];
+  const uint32_t hi = (lp[28 + (l >> 2)] >> (8 * (l & 3u))) & 0xffu;
+  return int64_t((uint64_t(hi) << 32) | lo) + int64_t(p2_match2(P, l, r2 + 1));
+}
+
+// one step of the backward search (server.c:909-936): the two ends are two independent two-line chains
+__device__ __forceinline__ void p2_search_step(const DevIndex& ix, int j, uint32_t code, int64_t& first, int64_t& last) {
+  if (j == 0) {
+    first = ix.p2_c[code];
+    last = ix.p2_c[256 + code];
+    return;
+  }
+  const uint32_t h = code >> 4, l = code & 15u;
+  const uint32_t* __restrict__ l1 = ix.p2_l1;
+  const uint32_t* __restrict__ l2 = ix.p2_l2;
+  const int64_t base = ix.p2_base[h];
+  const bool haveF = first != 0;
+  const int64_t rkL = p2_rank_h(l1, uint64_t(last) >> 6, uint32_t(last) & 63u, h);
+  const int64_t rkF = haveF ? p2_rank_h(l1, uint64_t(first - 1) >> 6, uint32_t(first - 1) & 63u, h) : 0;
+  const int64_t c0 = ix.p2_c[code];
+  int64_t nl = c0, nf = c0;
+  uint64_t lineL = 0, lineF = 0;
+  uint32_t rL = 0, rF = 0;
+  if (rkL) {
+    uint64_t lh;
+    p2_split2(rkL - 1, &lh, &rL);
+    lineL = uint64_t(base) + lh;
+  }
+  if (rkF) {
+    uint64_t lh;
+    p2_split2(rkF - 1, &lh, &rF);
+    lineF = uint64_t(base) + lh;
+  }
+  P2Planes2 PL, PF;
+  uint32_t loL = 0, hiL = 0, loF = 0, hiF = 0;
+  const bool other = rkF && (!rkL || lineF != lineL);
+  if (rkL) {
+    p2_load2(l2, lineL, PL);
+    loL = l2[lineL * 32 + 12 + l];
+    hiL = l2[lineL * 32 + 28 + (l >> 2)];
+  }
+  if (other) {
+    p2_load2(l2, lineF, PF);
+    loF = l2[lineF * 32 + 12 + l];
+    hiF = l2[lineF * 32 + 28 + (l >> 2)];
+  }
+  if (rkL) nl = int64_t((uint64_t((hiL >> (8 * (l & 3u))) & 0xffu) << 32) | loL) + int64_t(p2_match2(PL, l, rL + 1));
+  if (rkF) {
+    if (other) nf = int64_t((uint64_t((hiF >> (8 * (l & 3u))) & 0xffu) << 32) | loF) + int64_t(p2_match2(PF, l, rF + 1));
+    else nf = int64_t((uint64_t((hiL >> (8 * (l & 3u))) & 0xffu) << 32) | loL) + int64_t(p2_match2(PL, l, rF + 1));
+  }
+  first = nf;
+  last = nl - 1;
+}
+
+__global__ __launch_bounds__(256) void ktab_build_kernel2(const DevIndex ix, const int bits, const int syms, longlong2* __restrict__ tab) {
+  const uint64_t f = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (f >= (uint64_t(1) << (bits * syms))) return;
+  int64_t first = 0, last = ix.total_length - 1;
+  int j = 0;
+  for (; j < syms; j++) {
+    const uint32_t c = uint32_t(f >> (bits * (syms - 1 - j))) & ((1u << bits) - 1u);
+    if (c == 0 || int(c) > ix.p2_sigma) break;
+    p2_search_step(ix, j, c - 1, first, last);
+    if (first > last) { j++; break; }
+  }
+  tab[f] = make_longlong2(first, int64_t(uint64_t(last + 1) | (uint64_t(j) << 48)));
+}
+
+// do_string_query (src/main/server.c:713-946), one lane per pattern; see count_kernel_pack for the key / table /
+// pair-store conventions.  Symbols the key does not hold are read from the pattern four at a time (aligned words).
+template <bool kKeys>
+__global__ __launch_bounds__(256) void count_kernel_pack2(const DevIndex ix, const int64_t npats, const int32_t* __restrict__ plen,
+                                                          const uint16_t* __restrict__ pats, const int64_t* __restrict__ starts,
+                                                          int64_t* __restrict__ first_out, int64_t* __restrict__ last_out,
+                                                          int* __restrict__ err_flag, const uint32_t* __restrict__ perm,
+                                                          const uint64_t* __restrict__ keys, const int bits, const int nsym,
+                                                          longlong2* __restrict__ pair_out) {
+  const int64_t slot = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (slot >= npats) return;
+  const int64_t q = perm ? int64_t(perm[slot]) : slot;
+  const uint64_t key = kKeys ? keys[slot] : 0;
+  const bool whole = kKeys && (key & 1u);
+  const int len = whole ? nsym : plen[q];
+  const uint16_t* pat = whole ? pats : pats + starts[q];
+  int64_t first = 0, last = ix.total_length - 1;
+  int j = 0;
+  if (kKeys && ix.ktab) {
+    const longlong2 e = reinterpret_cast<const longlong2*>(ix.ktab)[key >> (64 - ix.ktab_bits)];
+    first = e.x;
+    last = int64_t(uint64_t(e.y) & kKtabLastMask) - 1;
+    j = int(uint64_t(e.y) >> 48);
+    if (first > last) j = len;
+  }
+  uint64_t word = 0;           // the aligned 8-byte word of the pattern that holds symbol index `word_at`..+3
+  uintptr_t word_addr = 0;
+  for (; j < len; j++) {
+    uint32_t code = 0;
+    if (kKeys && j < nsym) code = uint32_t(key >> (64 - bits * (j + 1))) & ((1u << bits) - 1u);
+    if (code != 0) {
+      code -= 1;
+    } else {
+      if (whole) break;
+      const uintptr_t sa = reinterpret_cast<uintptr_t>(pat + (len - 1 - j));
+      const uintptr_t wa = sa & ~uintptr_t(7);
+      if (wa != word_addr) {
+        word = *reinterpret_cast<const uint64_t*>(wa);
+        word_addr = wa;
+      }
+      const uint32_t ch = uint32_t(word >> (8 * (sa - wa))) & 0xffffu;
+      if (ch >= uint32_t(kAlphaSize)) {
+        atomicOr(err_flag, 1);
+        first = 0;
+        last = -1;
+        break;
+      }
+      code = ix.p2_code[ch];
+      if (code > 255u) {  // the character does not occur in the text: Occ == 0 (index.c:2080-2089)
+        first = ix.C[ch];
+        last = first - 1;
+        break;
+      }
+    }
+    p2_search_step(ix, j, code, first, last);
+    if (first > last) break;
+  }
+  if (pair_out) {
+    pair_out[q] = make_longlong2(first, last);
+    return;
+  }
+  first_out[q] = first;
+  if (last_out) last_out[q] = last;
+  else first_out[q] = last - first + 1;
+}
+
+// what an LF step / leaf request needs from a row: its character, C+Occ of it, the mark test
+struct P2Step {
+  uint32_t code;
+  int64_t c_plus_occ;
+  bool marked;
+  int64_t sa_index;
+};
+
+__device__ __forceinline__ P2Step p2_step(const DevIndex& ix, int64_t row) {
+  P2Step s;
+  const uint64_t line1 = uint64_t(row) >> 6;
+  const uint32_t r = uint32_t(row) & 63u;
+  const uint32_t* lp = ix.p2_l1 + line1 * 32;
+  uint32_t w[32];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint4 v = reinterpret_cast<const uint4*>(lp)[k];
+    w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+  }
+  const uint64_t p0 = (uint64_t(w[1]) << 32) | w[0], p1 = (uint64_t(w[3]) << 32) | w[2];
+  const uint64_t p2 = (uint64_t(w[5]) << 32) | w[4], p3 = (uint64_t(w[7]) << 32) | w[6];
+  const uint64_t pm = (uint64_t(w[9]) << 32) | w[8];
+  const uint32_t h = uint32_t((p0 >> r) & 1u) | (uint32_t((p1 >> r) & 1u) << 1) | (uint32_t((p2 >> r) & 1u) << 2) |
+                     (uint32_t((p3 >> r) & 1u) << 3);
+  s.marked = (pm >> r) & 1u;
+  const uint64_t below = r ? ((1ull << r) - 1ull) : 0ull;
+  s.sa_index = int64_t((uint64_t(w[31] & 0xffu) << 32) | w[30]) + int64_t(__popcll(pm & below));
+  uint32_t lo = 0, hb = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const uint32_t is = h == uint32_t(k) ? ~0u : 0u;
+    lo |= w[10 + k] & is;
+    hb |= ((w[26 + (k >> 2)] >> (8 * (k & 3))) & 0xffu) & is;
+  }
+  const uint64_t eq = (p0 ^ ((h & 1u) ? 0ull : ~0ull)) & (p1 ^ ((h & 2u) ? 0ull : ~0ull)) & (p2 ^ ((h & 4u) ? 0ull : ~0ull)) &
+                      (p3 ^ ((h & 8u) ? 0ull : ~0ull));
+  const int64_t rank = int64_t((uint64_t(hb) << 32) | lo) + int64_t(__popcll(eq & p2_below_incl(r)));  // >= 1: the row itself
+  uint64_t lh;
+  uint32_t r2;
+  p2_split2(rank - 1, &lh, &r2);
+  const uint64_t line2 = uint64_t(ix.p2_base[h]) + lh;
+  const uint32_t* lq = ix.p2_l2 + line2 * 32;
+  uint32_t v[32];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint4 t = reinterpret_cast<const uint4*>(lq)[k];
+    v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+  }
+  uint32_t x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const uint32_t d = r2 - 32u * uint32_t(k);
+    const uint32_t hot = d < 32u ? (1u << d) : 0u;
+    x0 |= v[k] & hot; x1 |= v[3 + k] & hot; x2 |= v[6 + k] & hot; x3 |= v[9 + k] & hot;
+  }
+  const uint32_t l = (x0 ? 1u : 0u) | (x1 ? 2u : 0u) | (x2 ? 4u : 0u) | (x3 ? 8u : 0u);
+  s.code = (h << 4) | l;
+  P2Planes2 P;
+#pragma unroll
+  for (int k = 0; k < 12; k++) P.w[k] = v[k];
+  uint32_t lo2 = 0, hb2 = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const uint32_t is = l == uint32_t(k) ? ~0u : 0u;
+    lo2 |= v[12 + k] & is;
+    hb2 |= ((v[28 + (k >> 2)] >> (8 * (k & 3))) & 0xffu) & is;
+  }
+  s.c_plus_occ = int64_t((uint64_t(hb2) << 32) | lo2) + int64_t(p2_match2(P, l, r2 + 1));
+  return s;
+}
+
+__global__ __launch_bounds__(256) void locate_kernel_pack2(const DevIndex ix, const int64_t total, int64_t* __restrict__ offsets) {
+  const int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (item >= total) return;
+  int64_t row = offsets[item];
+  int64_t steps = 0, result = -1;
+  while (row >= 0) {
+    const P2Step s = p2_step(ix, row);
+    if (s.marked) {
+      result = ix.pack_sa[s.sa_index] + steps;
+      break;
+    }
+    if (s.code < ix.p2_stop_below) break;                  // cannot walk past a document start (server.c:2336-2342)
+    row = s.c_plus_occ - 1;                                // LF (server.c:2279-2282)
+    steps++;
+  }
+  offsets[item] = result;
+}
+
+__global__ __launch_bounds__(256) void block_request_kernel_pack2(const DevIndex ix, const int64_t n, const int64_t* __restrict__ rows,
+                                                                  const uint16_t* __restrict__ ch_in, uint16_t* __restrict__ ch_out,
+                                                                  int64_t* __restrict__ occ_out, int64_t* __restrict__ off_out) {
+  const int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (item >= n) return;
+  const int64_t row = rows[item];
+  const P2Step s = p2_step(ix, row);
+  int64_t occ = s.c_plus_occ;
+  if (ch_in) {
+    const uint32_t ch = ch_in[item];
+    const uint32_t code = ix.p2_code[ch];
+    occ = code > 255u ? ix.C[ch] : p2_c_plus_occ(ix, code, row);
+  }
+  if (ch_out) ch_out[item] = ix.p2_alpha[s.code];
+  if (occ_out) occ_out[item] = occ;
+  if (off_out) off_out[item] = s.marked ? ix.pack_sa[s.sa_index] : -1;
+}
+
+// ---- construction (at open, on the GPU, from the lane tables) -------------------------------------------------------
+
+// phase A: sym[row] = dense code | 0x8000 if the row is marked
+__global__ __launch_bounds__(256) void p2_extract_kernel(const DevIndex ix, const int64_t row0, const int64_t n, uint16_t* __restrict__ sym) {
+  const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (row >= row0 + n) return;
+  uint32_t idx1;
+  const int64_t gb = bucket_of(ix, row, &idx1);
+  const DevBucket bk = ix.buckets[gb];
+  int seq;
+  uint32_t cnt;
+  wt_rank_lane(ix, bk.node_base, idx1, &seq, &cnt);
+  const LaneSeq sq = ix.lseqs[bk.seq_base + uint32_t(seq)];
+  const RankResult m = bseq_rank_lane(ix, sq.mark_table, cnt);
+  sym[row] = uint16_t(ix.p2_code[sq.ch] | (m.bit ? 0x8000u : 0u));
+}
+
+// phase B1: level-1 planes of one line (64 rows) + its 16 h-counts and mark count (SoA counts[k*stride + line], k=16: marks)
+__global__ __launch_bounds__(256) void p2_l1_planes_kernel(const int64_t nlines, const int64_t nrows, const uint16_t* __restrict__ sym,
+                                                           uint32_t* __restrict__ l1, int64_t* __restrict__ counts, const int64_t stride) {
+  const int64_t line = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (line >= nlines) return;
+  uint64_t pl[5] = {0, 0, 0, 0, 0};
+  uint32_t cnt[17];
+#pragma unroll
+  for (int k = 0; k < 17; k++) cnt[k] = 0;
+  const int64_t r0 = line * kP2Rows1;
+  for (int i = 0; i < kP2Rows1; i++) {
+    if (r0 + i >= nrows) break;
+    const uint32_t s = sym[r0 + i];
+    const uint32_t h = (s >> 4) & 15u;
+    pl[0] |= uint64_t(h & 1u) << i;
+    pl[1] |= uint64_t((h >> 1) & 1u) << i;
+    pl[2] |= uint64_t((h >> 2) & 1u) << i;
+    pl[3] |= uint64_t((h >> 3) & 1u) << i;
+    pl[4] |= uint64_t(s >> 15) << i;
+  }
+  const int valid = int(nrows - r0 < kP2Rows1 ? nrows - r0 : kP2Rows1);
+  const uint64_t vm = valid >= 64 ? ~0ull : ((1ull << valid) - 1ull);
+#pragma unroll
+  for (uint32_t k = 0; k < 16; k++) {
+    const uint64_t eq = (pl[0] ^ ((k & 1u) ? 0ull : ~0ull)) & (pl[1] ^ ((k & 2u) ? 0ull : ~0ull)) & (pl[2] ^ ((k & 4u) ? 0ull : ~0ull)) &
+                        (pl[3] ^ ((k & 8u) ? 0ull : ~0ull));
+    cnt[k] = uint32_t(__popcll(eq & vm));
+  }
+  cnt[16] = uint32_t(__popcll(pl[4]));
+  uint32_t* lp = l1 + line * 32;
+#pragma unroll
+  for (int p = 0; p < 5; p++) {
+    lp[2 * p] = uint32_t(pl[p]);
+    lp[2 * p + 1] = uint32_t(pl[p] >> 32);
+  }
+#pragma unroll
+  for (int k = 0; k < 17; k++) counts[int64_t(k) * stride + line] = int64_t(cnt[k]);
+}
+
+// phase B3: counts before every line -> dwords 10..31
+__global__ __launch_bounds__(256) void p2_l1_counts_kernel(const int64_t nlines, uint32_t* __restrict__ l1, const int64_t* __restrict__ scans,
+                                                           const int64_t stride) {
+  const int64_t line = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (line >= nlines) return;
+  uint32_t* lp = l1 + line * 32;
+  uint32_t hi[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const uint64_t v = uint64_t(scans[int64_t(k) * stride + line]);
+    lp[10 + k] = uint32_t(v);
+    hi[k >> 2] |= (uint32_t(v >> 32) & 0xffu) << (8 * (k & 3));
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) lp[26 + k] = hi[k];
+  const uint64_t m = uint64_t(scans[16 * stride + line]);
+  lp[30] = uint32_t(m);
+  lp[31] = uint32_t(m >> 32) & 0xffu;
+}
+
+// phase C: scatter every row's l digit to its level-2 position: lo2[p2_base[h]*96 + rank_h(row) - 1]
+__global__ __launch_bounds__(256) void p2_scatter_kernel(const DevIndex ix, const int64_t row0, const int64_t n, const uint16_t* __restrict__ sym,
+                                                         uint8_t* __restrict__ lo2) {
+  const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (row >= row0 + n) return;
+  const uint32_t s = sym[row];
+  const uint32_t h = (s >> 4) & 15u;
+  const int64_t rank = p2_rank_h(ix.p2_l1, uint64_t(row) >> 6, uint32_t(row) & 63u, h);
+  lo2[ix.p2_base[h] * kP2Rows2 + rank - 1] = uint8_t(s & 15u);
+}
+
+// phase D1: level-2 planes of one line (96 positions) + its 16 l-counts
+__global__ __launch_bounds__(256) void p2_l2_planes_kernel(const int64_t nlines, const uint8_t* __restrict__ lo2, uint32_t* __restrict__ l2,
+                                                           int64_t* __restrict__ counts, const int64_t stride) {
+  const int64_t line = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (line >= nlines) return;
+  uint32_t pl[4][3];
+#pragma unroll
+  for (int p = 0; p < 4; p++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) pl[p][k] = 0;
+  const uint4* sp = reinterpret_cast<const uint4*>(lo2 + line * kP2Rows2);
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+#pragma unroll
+    for (int hlf = 0; hlf < 2; hlf++) {
+      const uint4 v = sp[2 * k + hlf];
+      const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          const uint32_t by = (d[j] >> (8 * b)) & 0xffu;
+          const int pos = 16 * hlf + 4 * j + b;
+          pl[0][k] |= (by & 1u) << pos;
+          pl[1][k] |= ((by >> 1) & 1u) << pos;
+          pl[2][k] |= ((by >> 2) & 1u) << pos;
+          pl[3][k] |= ((by >> 3) & 1u) << pos;
+        }
+    }
+  uint32_t* lp = l2 + line * 32;
+#pragma unroll
+  for (int p = 0; p < 4; p++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) lp[3 * p + k] = pl[p][k];
+#pragma unroll
+  for (uint32_t c = 0; c < 16; c++) {
+    uint32_t n = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      n += uint32_t(__popc((pl[0][k] ^ ((c & 1u) ? 0u : ~0u)) & (pl[1][k] ^ ((c & 2u) ? 0u : ~0u)) & (pl[2][k] ^ ((c & 4u) ? 0u : ~0u)) &
+                           (pl[3][k] ^ ((c & 8u) ? 0u : ~0u))));
+    counts[int64_t(c) * stride + line] = int64_t(n);
+  }
+}
+
+// phase D3: C[ch(16h+k)] + earlier positions of the same h with l == k -> dwords 12..31.  Padding positions (value 0)
+// sit at the end of an h's last line, i.e. after every real position of that h, and the next h subtracts the scan
+// value at its own first line, so they are never counted.
+__global__ __launch_bounds__(256) void p2_l2_counts_kernel(const DevIndex ix, const int64_t nlines, uint32_t* __restrict__ l2,
+                                                           const int64_t* __restrict__ scans, const int64_t stride) {
+  const int64_t line = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (line >= nlines) return;
+  int h = 0;
+#pragma unroll
+  for (int k = 1; k < 16; k++) if (line >= ix.p2_base[k]) h = k;
+  const int64_t first_line = ix.p2_base[h];
+  uint32_t* lp = l2 + line * 32;
+  uint32_t hi[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const uint32_t code = uint32_t(h) * 16u + uint32_t(k);
+    int64_t v = scans[int64_t(k) * stride + line] - scans[int64_t(k) * stride + first_line];
+    if (int(code) < ix.p2_sigma) v += ix.p2_c[code];
+    lp[12 + k] = uint32_t(uint64_t(v));
+    hi[k >> 2] |= (uint32_t(uint64_t(v) >> 32) & 0xffu) << (8 * (k & 3));
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) lp[28 + k] = hi[k];
+}
+
+// phase E: offsets of the marked rows in row order
+__global__ __launch_bounds__(256) void p2_sa_kernel(const DevIndex ix, const int64_t row0, const int64_t n, const uint16_t* __restrict__ sym,
+                                                    int64_t* __restrict__ sa) {
+  const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (row >= row0 + n) return;
+  if (!(sym[row] & 0x8000u)) return;
+  uint32_t idx1;
+  const int64_t gb = bucket_of(ix, row, &idx1);
+  const DevBucket bk = ix.buckets[gb];
+  int seq;
+  uint32_t cnt;
+  wt_rank_lane(ix, bk.node_base, idx1, &seq, &cnt);
+  const LaneSeq sq = ix.lseqs[bk.seq_base + uint32_t(seq)];
+  const RankResult m = bseq_rank_lane(ix, sq.mark_table, cnt);
+  const int64_t off = int64_t(read_bits_ptr(wrap_ptr(ix.image, sq.mark_array), (uint64_t(m.o1) - 1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
+  const uint32_t* lp = ix.p2_l1 + (uint64_t(row) >> 6) * 32;
+  const uint32_t r = uint32_t(row) & 63u;
+  const uint64_t pm = (uint64_t(lp[9]) << 32) | lp[8];
+  const uint64_t below = r ? ((1ull << r) - 1ull) : 0ull;
+  sa[int64_t((uint64_t(lp[31] & 0xffu) << 32) | lp[30]) + int64_t(__popcll(pm & below))] = off;
+}
+
+}  // namespace femto_amd

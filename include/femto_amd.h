@@ -190,6 +190,10 @@ int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode);
  * sort keys (dense codes, no scattered pattern reads), and the first ktab_syms steps of every search -- shared by
  * huge numbers of patterns -- come from a table precomputed at open (FEMTO_AMD_KTAB=0 disables it).  Same results,
  * bit for bit.  FEMTO_AMD_PACK=0 skips the derivation. */
+/* mode 4 ("pack2", the default for 9..256 distinct characters): the same idea for byte alphabets -- a two-level
+ * 16-ary decomposition of the dense character code, one 128-byte line per level (femto_amd/csrc/pack2_kernels.hip.hpp):
+ * an Occ or a locate step reads TWO lines and decodes no Elias-gamma runs.  FEMTO_AMD_PACK2=0 skips it, =1 also builds
+ * it for small alphabets.  *available: bit 0 = mode 3 lines exist, bit 1 = mode 4 lines exist. */
 int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* bytes, double* build_ms, int* ktab_syms);
 int femto_amd_get_rank_mode(const femto_amd_index_t* ix);
 

@@ -21,15 +21,35 @@ def gpu_ok():
     return True
 
 
-# 3: packed small-alphabet lines (default when the index has <= 8 characters); 1: lane per query (default otherwise);
-# 2: flattened persistent lanes; 0: wavefront-per-query raw walk
-MODES = [3, 1, 2, 0]
+# 3: packed small-alphabet lines (default when the index has <= 8 characters); 4: two-level 16-ary lines (default for
+# 9..256 characters); 1: lane per query on femto's wavelet tree (default otherwise); 2: flattened persistent lanes;
+# 0: wavefront-per-query raw walk
+MODES = [3, 4, 1, 2, 0]
+
+
+def _open(path, mode=None):
+    """open on GPU 0; mode 4 is built for small alphabets too (FEMTO_AMD_PACK2=1) so that every fixture exercises it"""
+    old = os.environ.get("FEMTO_AMD_PACK2")
+    os.environ["FEMTO_AMD_PACK2"] = "1"
+    try:
+        ix = femto_amd.Index(path, device=0)
+    finally:
+        if old is None:
+            del os.environ["FEMTO_AMD_PACK2"]
+        else:
+            os.environ["FEMTO_AMD_PACK2"] = old
+    if mode is not None:
+        _set_mode(ix, mode)
+    return ix
 
 
 def _set_mode(ix, mode):
     if mode == 3 and not ix.pack_info()["available"]:
         ix.close()
         pytest.skip("more than 8 distinct characters: no packed lines for this index")
+    if mode == 4 and not ix.pack_info()["available2"]:
+        ix.close()
+        pytest.skip("more than 256 distinct characters: no two-level lines for this index")
     ix.set_rank_mode(mode)
     assert ix.rank_mode == mode
 
@@ -40,8 +60,7 @@ def test_leaf_requests_match_reference(fixtures, gpu_ok, name, mode):
     """block_request CHAR|OCCS|LOCATION for every row (index_test.c:60-476 checks the same leaves)."""
     fx = fixtures(name)
     g = fx.gold
-    ix = femto_amd.Index(fx.index, device=0)
-    _set_mode(ix, mode)
+    ix = _open(fx.index, mode)
     n = ix.info.total_length
     rows = np.arange(n, dtype=np.int64)
     ch, occ, off = ix.block_requests(rows)
@@ -60,8 +79,7 @@ def test_leaf_requests_match_reference(fixtures, gpu_ok, name, mode):
 @pytest.mark.parametrize("name", INDEX_FIXTURES)
 def test_count_locate_match_reference_goldens(fixtures, gpu_ok, name, mode):
     fx = fixtures(name)
-    ix = femto_amd.Index(fx.index, device=0)
-    _set_mode(ix, mode)
+    ix = _open(fx.index, mode)
     plen, flat, starts = fx.patterns
     first, last = ix.count_flat(plen, flat, starts)
     assert np.array_equal(first, fx.gold["count_first"])
@@ -183,8 +201,9 @@ def test_gpu_built_index_vs_oracle_medium(tmp_path, gpu_ok, mode):
     text = tg.t_acgt(1 << 22, 2024)
     path = _random_index(tmp_path, text, None, "acgt4m")
     ix = femto_amd.Index(path, device=0)
-    assert ix.rank_mode == 3          # DNA alphabet: the packed lines are the default path
-    _set_mode(ix, mode)
+    assert ix.rank_mode == 3 and not ix.pack_info()["available2"]    # DNA alphabet: the packed lines are the default path
+    ix.close()
+    ix = _open(path, mode)
     o = po.Oracle(path)
     assert ix.info.total_length == o.total_length == len(text) + 1
     plen_r, flat_r = tg.p_rand(20, 50000, 7)
@@ -207,15 +226,14 @@ def test_gpu_built_index_vs_oracle_medium(tmp_path, gpu_ok, mode):
             assert np.array_equal(text[off:off + len(p)], p)
 
 
-@pytest.mark.parametrize("mode", [3, 1])
+@pytest.mark.parametrize("mode", [3, 4, 1])
 def test_batch_above_a_million_patterns(tmp_path, gpu_ok, mode):
     """Batches above 2^20 patterns are suffix-sorted on the leading symbols only (a partial-bit radix sort,
     query_sort.hip) and, in mode 3, searched from the sorted keys: 1.5 M mixed-length patterns, some longer than a
     key holds, some with characters outside the text's alphabet, against the oracle."""
     text = tg.t_acgt(1 << 21, 31)
     path = _random_index(tmp_path, text, None, "acgt2m")
-    ix = femto_amd.Index(path, device=0)
-    _set_mode(ix, mode)
+    ix = _open(path, mode)
     o = po.Oracle(path)
     rng = np.random.Generator(np.random.PCG64(77))
     n = 1_500_000
@@ -276,7 +294,7 @@ def test_gpu_built_english_like_vs_oracle(tmp_path, gpu_ok, mode):
     text = tg.t_eng(3 << 20, 99)
     path = _random_index(tmp_path, text, "block_size=2097152,bucket_size=262144,mark_period=20", "eng3m")
     ix = femto_amd.Index(path, device=0)
-    assert ix.rank_mode == 1 and not ix.pack_info()["available"]
+    assert ix.rank_mode == 4 and not ix.pack_info()["available"]    # byte alphabet: the two-level lines are the default
     _set_mode(ix, mode)
     o = po.Oracle(path)
     plen, flat = tg.p_hit(8, 64, 40000, 5, text)
@@ -330,6 +348,10 @@ def test_random_indexes_vs_oracle(tmp_path, gpu_ok, seed):
     femto_amd.build_index(path, docs, params=params, infos=[f"d{i}" for i in range(len(docs))], device=0)
     o = po.Oracle(path)
     ix = femto_amd.Index(path, device=0)
+    distinct = len(np.unique(text)) + 1          # + SEOF
+    assert ix.rank_mode == (3 if distinct <= 8 else 4 if distinct <= 256 else 1)
+    ix.close()
+    ix = _open(path)
     nrows = ix.info.total_length
     assert nrows == o.total_length == len(text) + len(docs)
     pats = []
@@ -347,11 +369,9 @@ def test_random_indexes_vs_oracle(tmp_path, gpu_ok, seed):
     rows = rng.integers(0, nrows, 500).astype(np.int64)
     want_fw = [o.forward_step(int(r)) for r in rows]
     want_bw = [o.block_request(int(r), 7) for r in rows]
-    distinct = len(np.unique(text)) + 1          # + SEOF
-    assert ix.pack_info()["available"] == (distinct <= 8)
-    assert ix.rank_mode == (3 if distinct <= 8 else 1)
+    assert ix.pack_info()["available"] == (distinct <= 8) and ix.pack_info()["available2"] == (distinct <= 256)
     for mode in MODES:
-        if mode == 3 and distinct > 8:
+        if (mode == 3 and distinct > 8) or (mode == 4 and distinct > 256):
             continue
         ix.set_rank_mode(mode)
         f, l_ = ix.count_flat(plen, flat, starts)
