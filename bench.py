@@ -32,8 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-KERNEL_NAMES = {3: "count_kernel_pack<true>", 1: "count_kernel_lane", 2: "count_kernel_flat<1>", 0: "count_kernel<32>"}
-LOCATE_NAMES = {3: "locate_kernel_pack", 1: "locate_kernel_lane", 2: "locate_kernel_flat", 0: "locate_kernel<32>"}
+KERNEL_NAMES = {4: "count_kernel_pack2<true>", 3: "count_kernel_pack<true>", 1: "count_kernel_lane", 2: "count_kernel_flat<1>", 0: "count_kernel<32>"}
+LOCATE_NAMES = {4: "locate_kernel_pack2", 3: "locate_kernel_pack", 1: "locate_kernel_lane", 2: "locate_kernel_flat", 0: "locate_kernel<32>"}
 
 
 def log(*a):
@@ -321,7 +321,8 @@ def main():
     roof = None
     if sample > 0 and cnt_n > 0:
         cc, ca = c_count.asdict(), c_all.asdict()
-        packed = ix.rank_mode == 3
+        packed = ix.rank_mode in (3, 4)
+        line_bytes = 128 if ix.rank_mode == 3 else 256     # pack2: one level-1 and one level-2 line per Occ / LF step
         ktab_syms = ix.pack_info()["ktab_syms"] if packed else 0
         c_tab = po.Counters()
         if packed and ktab_syms:   # Occ evaluations the precomputed table answers: those of each pattern's last ktab_syms symbols
@@ -335,8 +336,8 @@ def main():
                 # every located row one 8-byte offset; a sorted batch reads 8 B key + 4 B order + 16 B table entry per
                 # pattern instead of the steps the table covers, and writes 16 B
                 if c is cc and ktab_syms:
-                    return (c["n_occ"] - n_occ_tab) * 128 + sample * (8 + 4 + 16 + 16)
-                return c["n_occ"] * 128 + c["n_mark"] * 8
+                    return (c["n_occ"] - n_occ_tab) * line_bytes + sample * (8 + 4 + 16 + 16)
+                return c["n_occ"] * line_bytes + c["n_mark"] * 8
             # wavelet path, SURVEY.md 8(d): N_rank*(12 + 64 + S_rank) + N_occ*20 + N_mark*8, counters from the CPU restatement
             return c["n_rank"] * (12 + 64) + c["s_bytes"] + c["n_occ"] * 20 + c["n_mark"] * 8
         cl = {k: ca[k] - cc[k] for k in ca}       # locate_flat re-runs the count: walk only = all - count
@@ -369,7 +370,7 @@ def main():
                 "wavelet_path_equivalent_GBs": (k_c["n_rank"] * (12 + 64) + k_c["s_bytes"] + k_c["n_occ"] * 20 + k_c["n_mark"] * 8)
                 * scale / (k_ms * 1e-3) / 1e9,
                 "occ_answered_by_table_per_pattern": (n_occ_tab / sample) if (packed and dominant_is_count) else 0.0,
-                "bytes_model": ("packed lines: 128 B per Occ / LF step not covered by the first-steps table, + 44 B per pattern "
+                "bytes_model": (f"packed lines: {line_bytes} B per Occ / LF step not covered by the first-steps table, + 44 B per pattern "
                                 "(key, order, table entry, results), + 8 B per located row" if packed else
                                 "wavelet path: N_rank*(12+64+S) + N_occ*20 + N_mark*8 (SURVEY 8d)"),
                 "note": "the batch is processed in suffix order, so neighbouring lanes share cache lines and part of the "
@@ -385,7 +386,7 @@ def main():
         "vs_baseline": None, "dtype": "int64", "data": "synthetic",
         "config": {"workload": wl, "text_bytes": n_text, "patterns_per_gpu": npats, "pattern_len": args.plen, "seed": args.seed,
                    "located_rows_per_gpu": batch.total, "matched_patterns_frac": float(np.mean(last >= first)),
-                   "rank_mode": {3: "pack", 1: "lane", 2: "flat", 0: "raw"}[ix.rank_mode], "index": {"rows": int(info.total_length), "blocks": int(info.number_of_blocks), "buckets": int(info.total_buckets),
+                   "rank_mode": {4: "pack2", 3: "pack", 1: "lane", 2: "flat", 0: "raw"}[ix.rank_mode], "index": {"rows": int(info.total_length), "blocks": int(info.number_of_blocks), "buckets": int(info.total_buckets),
                              "image_bytes": int(info.image_bytes), "table_bytes": int(info.table_bytes),
                              "packed_lines": ix.pack_info()},
                    "parallelism": ("range-split index (1/N of the blocks per GPU, peer loads over xGMI)" if args.layout == "split" and world > 1 else "replicated index") + f", query shards x{world}" + (", RCCL gather of (first,last) to rank 0 every step (int32 rows when the index has < 2^31 rows), overlapped with the next step's kernels" if world > 1 else ""),

@@ -1537,10 +1537,8 @@ int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* by
   if (available) *available = ix->dev.pack != nullptr;
   if (ktab_syms) *ktab_syms = ix->dev.ktab ? ix->dev.ktab_syms : 0;
   if (available && ix->dev.p2_l1) *available |= 2;   // bit 1: the two-level lines (mode 4) exist
-  if (bytes && !ix->dev.pack) *bytes = ix->pack2_bytes;
-  if (build_ms && !ix->dev.pack) *build_ms = ix->pack2_build_ms;
-  if (bytes) *bytes = ix->pack_bytes;
-  if (build_ms) *build_ms = ix->pack_build_ms;
+  if (bytes) *bytes = ix->pack_bytes + ix->pack2_bytes;
+  if (build_ms) *build_ms = ix->pack_build_ms + ix->pack2_build_ms;
   return FEMTO_AMD_OK;
 }
 
