@@ -272,6 +272,39 @@ def main():
         extra["host_pointer_count"] = {"what": "femto_amd_count_flat on the same 10M-pattern batch, pageable host arrays in and out (staging threads + PCIe + kernels, pipelined in 2M-pattern chunks)",
                                        "value": npats / hs, "unit": "patterns/s", "ms": 1e3 * hs,
                                        "equal_to_device_path": bool(np.array_equal(hf_, first) and np.array_equal(hl_, last))}
+        del hf_, hl_
+        # BASELINE configs[2] shape: a sigma~96 text of the same size, sampled patterns of length 8..64 (the two-level
+        # 16-ary lines, mode 4).  A failure here must not cost the headline line.
+        try:
+            e_path = os.path.join(args.workdir, f"eng_2p{args.text_log2}_s{args.seed}")
+            e_text = tg.t_eng_torch(n_text, args.seed, f"cuda:{local_rank}")
+            if not os.path.exists(os.path.join(e_path, "_femto_index")):
+                femto_amd.build_index(e_path, [e_text], params=None, infos=["bench"], device=local_rank)
+            eix = femto_amd.Index(e_path, device=local_rank)
+            ep, ef = tg.p_hit(8, 64, npats, args.seed + 3000, e_text)
+            del e_text
+            eb = Batch(torch, dev, ep, ef)
+            for _ in range(2):
+                eb.step(eix, args.max_occs, stream)
+            torch.cuda.synchronize()
+            eix.kernel_time_reset()
+            eix.kernel_time_enable(True)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                eb.step(eix, args.max_occs, stream)
+            torch.cuda.synchronize()
+            ee = time.perf_counter() - t0
+            eix.kernel_time_enable(False)
+            extra["cfg3_text96_count_locate"] = {
+                "workload": f"T_eng(2^{args.text_log2}) sigma~96 index, {npats} sampled patterns of length 8..64, count()+locate(max_occs={args.max_occs})",
+                "rank_mode": {4: "pack2", 3: "pack", 1: "lane", 2: "flat", 0: "raw"}[eix.rank_mode],
+                "value": npats * 3 / ee, "unit": "patterns/s", "ms_per_step": 1e3 * ee / 3, "located_rows": eb.total,
+                "count_kernel_ms": eix.kernel_time("count")[0], "locate_kernel_ms": eix.kernel_time("locate")[0],
+                "parity": "tests/test_gpu_parity.py (oracle, all modes); profiles/r01_cfg3_eng_1GiB_pack2_bench.json has the run with the reference timed beside it"}
+            del eb
+            eix.close()
+        except Exception as ex:      # noqa: BLE001
+            extra["cfg3_text96_count_locate"] = {"error": repr(ex)}
 
     # ---- CPU baseline + bit-exact check on a bounded sample of the same batch (rank 0 only)
     from oracle import pyoracle as po
