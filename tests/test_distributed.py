@@ -66,3 +66,54 @@ def test_shard_range_partitions():
             cover = [shard_range(n, r, w) for r in range(w)]
             assert cover[0][0] == 0 and cover[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+
+
+def _wire_worker(rank, world, port, q):
+    """bench.py's per-step gather: ranges narrowed to int32 (index below 2^31 rows), double buffered, async"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    n = 1000
+    plen = np.full(n, 4, dtype=np.int32)
+    flat = np.full(4 * n, 70, dtype=np.uint16)
+    b = bench.Batch(torch, torch.device("cpu"), plen, flat)
+    rng = np.random.Generator(np.random.PCG64(rank))
+    first = rng.integers(0, 1 << 30, n)
+    last = first + rng.integers(-1, 50, n)
+    first[0], last[0] = 0, -1                      # the "no match / error" encoding must survive the narrowing
+    b.d_res = b.d_res2[1]
+    b.d_res.copy_(torch.from_numpy(np.stack([first, last])))
+    small = b.wire((1 << 30) + 1, 1)
+    assert small.dtype == torch.int32 and torch.equal(small.to(torch.int64), b.d_res)
+    big = b.wire((1 << 33) + 1, 1)
+    assert big.dtype == torch.int64 and big is b.d_res
+    out = [torch.empty_like(small) for _ in range(world)] if rank == 0 else None
+    w = dist.gather(small, out, dst=0, async_op=True)
+    w.wait()
+    if rank == 0:
+        ok = True
+        for r in range(world):
+            g = np.random.Generator(np.random.PCG64(r))
+            f = g.integers(0, 1 << 30, n)
+            l_ = f + g.integers(-1, 50, n)
+            f[0], l_[0] = 0, -1
+            ok = ok and np.array_equal(out[r][0].numpy(), f) and np.array_equal(out[r][1].numpy(), l_)
+        q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_wire_format_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wire_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
