@@ -1003,8 +1003,27 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
       }
       ix->mode = h.dir_regular ? 1 : 0;
       if (split) return 0;  // lane kernels only
-      if ((r = build_pack(ix))) return r;
-      if ((r = build_pack2(ix))) return r;
+      // The derived fast-path layouts are optional: when HBM is too small for them the index still opens and
+      // runs the wavelet-path kernels (on the GPU -- there is no CPU path to fall back to).
+      r = build_pack(ix);
+      if (r == FEMTO_AMD_ERR_MEM) {
+        (void)hipGetLastError();
+        (void)hipFree(ix->d_pack); ix->d_pack = nullptr;
+        if (!ix->dev.pack_sa) { (void)hipFree(ix->d_pack_sa); ix->d_pack_sa = nullptr; }
+        ix->dev.pack = nullptr;
+        r = 0;
+      }
+      if (r) return r;
+      r = build_pack2(ix);
+      if (r == FEMTO_AMD_ERR_MEM) {
+        (void)hipGetLastError();
+        (void)hipFree(ix->d_p2_l1); ix->d_p2_l1 = nullptr;
+        (void)hipFree(ix->d_p2_l2); ix->d_p2_l2 = nullptr;
+        ix->dev.p2_l1 = nullptr;
+        ix->dev.p2_l2 = nullptr;
+        r = 0;
+      }
+      if (r) return r;
       if (ix->dev.pack) ix->mode = 3;
       else if (ix->dev.p2_l1) ix->mode = 4;
       if (const char* m = getenv("FEMTO_AMD_RANK_MODE")) {
@@ -1213,6 +1232,7 @@ int femto_amd_info(const femto_amd_index_t* ix, femto_amd_info_t* out) {
                              h.C.size() * 8 + h.segs.size() * 8 + h.cum.size() * sizeof(CumEntry) + h.hint.size() * 4 + h.bdir.size() * sizeof(BlockDir) +
                              h.lnodes.size() * sizeof(LaneNode) + h.lseqs.size() * sizeof(LaneSeq) +
                              h.occ.size() * sizeof(OccEntry));
+  if (ix->device >= 0) out->table_bytes = ix->table_bytes;   // what is actually resident, derived fast-path layouts included
   return FEMTO_AMD_OK;
 }
 
