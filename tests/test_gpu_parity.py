@@ -483,6 +483,46 @@ def test_full_size_1gib_properties(tmp_path, gpu_ok):
         assert np.array_equal(a, b)
 
 
+def test_full_size_text96_properties(tmp_path, gpu_ok):
+    """BASELINE configs[2] at FULL size (1 GiB sigma~96 text, reference default parameters) on the two-level lines
+    (mode 4): every sampled pattern of length 8..64 is found; every located offset really is an occurrence; the
+    wavelet path (mode 1) agrees on a 200 k-pattern batch and on a million leaf requests; oracle spot check."""
+    text = tg.t_eng_torch(1 << 30, 515, "cuda:0")
+    path = str(tmp_path / "eng1g")
+    femto_amd.build_index(path, [text], params=None, infos=["full"], device=0)
+    ix = femto_amd.Index(path, device=0)
+    assert ix.info.total_length == (1 << 30) + 1 and ix.rank_mode == 4
+    npat = 200_000
+    plen, flat = tg.p_hit(8, 64, npat, 12, text)
+    starts = tg.starts_of(plen)
+    first, last = ix.count_flat(plen, flat, starts)
+    cnt = last - first + 1
+    assert (cnt >= 1).all()
+    noccs, offs = ix.locate_flat(plen, flat, starts, 20)
+    assert np.array_equal(noccs, np.minimum(cnt, np.where(cnt - 1 > 20, 20, cnt)))
+    owner = np.repeat(np.arange(npat), noccs)
+    for k in range(8):                                   # the first 8 symbols of every located occurrence
+        assert np.array_equal(text[offs + k].astype(np.uint16) + 5, flat[starts[owner] + k]), k
+    tail = plen[owner] - 1                               # ... and the last one
+    assert np.array_equal(text[offs + tail].astype(np.uint16) + 5, flat[starts[owner] + tail])
+    rows = np.random.Generator(np.random.PCG64(3)).integers(0, ix.info.total_length, 1_000_000).astype(np.int64)
+    leaf4 = ix.block_requests(rows)
+    ix.set_rank_mode(1)
+    f1, l1 = ix.count_flat(plen, flat, starts)
+    assert np.array_equal(f1, first) and np.array_equal(l1, last)
+    n1, o1 = ix.locate_flat(plen, flat, starts, 20)
+    assert np.array_equal(n1, noccs) and np.array_equal(o1, offs)
+    for a, b in zip(leaf4, ix.block_requests(rows)):
+        assert np.array_equal(a, b)
+    ix.set_rank_mode(4)
+    o = po.Oracle(path)
+    m = 2000
+    of, ol = o.count_flat(plen[:m], flat, starts[:m], threads=16)
+    assert np.array_equal(of, first[:m]) and np.array_equal(ol, last[:m])
+    on, oo = o.locate_flat(plen[:m], flat, starts[:m], 20, threads=16)
+    assert np.array_equal(on, noccs[:m]) and np.array_equal(oo, offs[:int(noccs[:m].sum())])
+
+
 def test_multiquery_cpp_tool(fixtures, tmp_path, gpu_ok):
     """femto_amd_multiquery (C++ host over the C ABI, femto_multiquery's counterpart): Pizza&Chili query file on
     stdin, -count / -locate [max]; dumped results must equal the oracle's."""
