@@ -621,13 +621,18 @@ def test_range_split_needs_every_part(fixtures, gpu_ok):
 def test_range_split_across_processes(fixtures, gpu_ok, tmp_path):
     """Two PROCESSES (one rank each, both on this box's single GPU): hipIpc handles travel through
     torch.distributed, each rank maps the other's slices and answers the whole golden batch."""
+    import socket
     import subprocess
     import sys
     fx = fixtures("acgt48k")
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
     script = os.path.join(os.path.dirname(__file__), "split_worker.py")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29577", script, fx.index, os.path.join(os.path.dirname(__file__), "golden", "acgt48k.npz"),
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), script, fx.index, os.path.join(os.path.dirname(__file__), "golden", "acgt48k.npz"),
                           str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     for r in range(2):
