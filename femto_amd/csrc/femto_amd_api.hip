@@ -417,6 +417,14 @@ int build_ktab(femto_amd_index* ix, Kernel kernel) {
   return 0;
 }
 
+// distance between marks in the derived lines (see "denser marks" in pack_kernels.hip.hpp); 0: keep femto's own
+int derived_mark_every(const HostIndex& h) {
+  int every = 5;
+  if (const char* e = getenv("FEMTO_AMD_MARK_EVERY")) every = atoi(e);
+  if (every <= 0 || every >= h.mark_period) return 0;
+  return every;
+}
+
 // Derives the packed lines of pack_kernels.hip.hpp on the GPU from the uploaded index (needs the lane tables).
 int build_pack(femto_amd_index* ix) {
   HostIndex& h = ix->host;
@@ -472,13 +480,32 @@ int build_pack(femto_amd_index* ix) {
     hipLaunchKernelGGL(pack_counts_kernel, dim3(uint32_t((nlines + 255) / 256)), dim3(256), 0, nullptr, ix->dev, nlines, ix->d_pack,
                        scans.as<int64_t>(), stride);
     HIP_TRY(hipGetLastError());
+    const int every = derived_mark_every(h);
+    if (every) {  // denser marks: set the extra bits, then recount the marks before every line
+      for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+        const int64_t cn = std::min(chunk, n - r0);
+        hipLaunchKernelGGL(pack_densify_kernel<false>, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, ix->d_pack, r0, cn,
+                           sym.as<uint8_t>(), every, int(h.mark_period), static_cast<int64_t*>(nullptr));
+      }
+      hipLaunchKernelGGL(pack_recount_marks_kernel, dim3(uint32_t((nlines + 255) / 256)), dim3(256), 0, nullptr, nlines, ix->d_pack,
+                         counts.as<int64_t>() + 8 * stride);
+      HIP_TRY(hipGetLastError());
+      if ((rc = device_scan(ix, nlines, counts.as<int64_t>() + 8 * stride, scans.as<int64_t>() + 8 * stride, 0, nullptr))) return rc;
+      hipLaunchKernelGGL(pack_markcount_kernel, dim3(uint32_t((nlines + 255) / 256)), dim3(256), 0, nullptr, nlines, ix->d_pack,
+                         scans.as<int64_t>() + 8 * stride);
+      HIP_TRY(hipGetLastError());
+    }
     int64_t nmarks = 0;
     HIP_TRY(hipMemcpy(&nmarks, scans.as<int64_t>() + 8 * stride + nlines, 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_pack_sa), size_t(nmarks > 0 ? nmarks : 1) * 8));
     for (int64_t r0 = 0; r0 < n; r0 += chunk) {
       const int64_t cn = std::min(chunk, n - r0);
-      hipLaunchKernelGGL(pack_sa_kernel, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, r0, cn, sym.as<uint8_t>(),
-                         ix->d_pack, ix->d_pack_sa);
+      if (every)
+        hipLaunchKernelGGL(pack_densify_kernel<true>, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, ix->d_pack, r0, cn,
+                           sym.as<uint8_t>(), every, int(h.mark_period), ix->d_pack_sa);
+      else
+        hipLaunchKernelGGL(pack_sa_kernel, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, r0, cn, sym.as<uint8_t>(),
+                           ix->d_pack, ix->d_pack_sa);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e1, nullptr));
@@ -593,13 +620,33 @@ int build_pack2(femto_amd_index* ix) {
     HIP_TRY(hipGetLastError());
     d.p2_l2 = ix->d_p2_l2;
     int64_t sa_bytes = 0;
+    const int every = derived_mark_every(h);
+    int64_t nmarks = tot[16];
+    if (every) {  // denser marks (the same rows the 3-bit lines mark, so the offsets array can be shared)
+      for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+        const int64_t cn = std::min(chunk, n - r0);
+        hipLaunchKernelGGL(p2_densify_kernel<false>, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, ix->d_p2_l1, r0, cn,
+                           sym.as<uint16_t>(), every, int(h.mark_period), static_cast<int64_t*>(nullptr));
+      }
+      if ((rc = counts.reserve(size_t(2 * stride1) * 8))) return rc;
+      hipLaunchKernelGGL(p2_recount_marks_kernel, dim3(uint32_t((nl1 + 255) / 256)), dim3(256), 0, nullptr, nl1, ix->d_p2_l1, counts.as<int64_t>());
+      HIP_TRY(hipGetLastError());
+      if ((rc = device_scan(ix, nl1, counts.as<int64_t>(), counts.as<int64_t>() + stride1, 0, nullptr))) return rc;
+      hipLaunchKernelGGL(p2_markcount_kernel, dim3(uint32_t((nl1 + 255) / 256)), dim3(256), 0, nullptr, nl1, ix->d_p2_l1,
+                         counts.as<int64_t>() + stride1);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpy(&nmarks, counts.as<int64_t>() + stride1 + nl1, 8, hipMemcpyDeviceToHost));
+    }
     if (!ix->d_pack_sa) {  // offsets of the marked rows (shared with the 3-bit lines when both exist)
-      const int64_t nmarks = tot[16];
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_pack_sa), size_t(nmarks > 0 ? nmarks : 1) * 8));
       for (int64_t r0 = 0; r0 < n; r0 += chunk) {
         const int64_t cn = std::min(chunk, n - r0);
-        hipLaunchKernelGGL(p2_sa_kernel, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, r0, cn, sym.as<uint16_t>(),
-                           ix->d_pack_sa);
+        if (every)
+          hipLaunchKernelGGL(p2_densify_kernel<true>, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, ix->d_p2_l1, r0, cn,
+                             sym.as<uint16_t>(), every, int(h.mark_period), ix->d_pack_sa);
+        else
+          hipLaunchKernelGGL(p2_sa_kernel, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, r0, cn, sym.as<uint16_t>(),
+                             ix->d_pack_sa);
       }
       HIP_TRY(hipGetLastError());
       d.pack_sa = ix->d_pack_sa;

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void block_request_kernel_pack2(const DevIndex
   }
   if (ch_out) ch_out[item] = ix.p2_alpha[s.code];
   if (occ_out) occ_out[item] = occ;
-  if (off_out) off_out[item] = s.marked ? ix.pack_sa[s.sa_index] : -1;
+  if (off_out) off_out[item] = lane_mark_offset(ix, row);   // femto's own marks (the derived lines may mark more rows)
 }
 
 // ---- construction (at open, on the GPU, from the lane tables) -------------------------------------------------------
@@ -507,6 +507,53 @@ __global__ __launch_bounds__(256) void p2_sa_kernel(const DevIndex ix, const int
   const uint64_t pm = (uint64_t(lp[9]) << 32) | lp[8];
   const uint64_t below = r ? ((1ull << r) - 1ull) : 0ull;
   sa[int64_t((uint64_t(lp[31] & 0xffu) << 32) | lp[30]) + int64_t(__popcll(pm & below))] = off;
+}
+
+// ---- denser marks (derived), see pack_kernels.hip.hpp ---------------------------------------------------------------
+__device__ __forceinline__ int64_t p2_mark_rank(const uint32_t* __restrict__ l1, int64_t row) {
+  const uint32_t* lp = l1 + (uint64_t(row) >> 6) * 32;
+  const uint32_t r = uint32_t(row) & 63u;
+  const uint64_t pm = (uint64_t(lp[9]) << 32) | lp[8];
+  const uint64_t below = r ? ((1ull << r) - 1ull) : 0ull;
+  return int64_t((uint64_t(lp[31] & 0xffu) << 32) | lp[30]) + int64_t(__popcll(pm & below));
+}
+
+template <bool kStore>
+__global__ __launch_bounds__(256) void p2_densify_kernel(const DevIndex ix, uint32_t* __restrict__ l1, const int64_t row0, const int64_t n,
+                                                         const uint16_t* __restrict__ sym, const int every, const int period,
+                                                         int64_t* __restrict__ sa) {
+  const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (row >= row0 + n) return;
+  if (!(sym[row] & 0x8000u)) return;
+  int64_t off = 0;
+  if (kStore) {
+    off = lane_mark_offset(ix, row);
+    sa[p2_mark_rank(l1, row)] = off;
+  }
+  int64_t r = row;
+  for (int j = 1; j < period; j++) {
+    const P2Step s = p2_step(ix, r);
+    if (s.code < ix.p2_stop_below) break;
+    r = s.c_plus_occ - 1;
+    if (j % every == 0) {
+      if (kStore) sa[p2_mark_rank(l1, r)] = off - j;
+      else atomicOr(l1 + (uint64_t(r) >> 6) * 32 + 8 + ((uint32_t(r) & 63u) >> 5), 1u << (uint32_t(r) & 31u));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void p2_recount_marks_kernel(const int64_t nlines, const uint32_t* __restrict__ l1, int64_t* __restrict__ counts) {
+  const int64_t line = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (line >= nlines) return;
+  counts[line] = int64_t(__popc(l1[line * 32 + 8]) + __popc(l1[line * 32 + 9]));
+}
+
+__global__ __launch_bounds__(256) void p2_markcount_kernel(const int64_t nlines, uint32_t* __restrict__ l1, const int64_t* __restrict__ scan) {
+  const int64_t line = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (line >= nlines) return;
+  const uint64_t m = uint64_t(scan[line]);
+  l1[line * 32 + 30] = uint32_t(m);
+  l1[line * 32 + 31] = uint32_t(m >> 32) & 0xffu;
 }
 
 }  // namespace femto_amd

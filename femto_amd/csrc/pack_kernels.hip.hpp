@@ -290,6 +290,20 @@ __global__ __launch_bounds__(256) void locate_kernel_pack(const DevIndex ix, con
   offsets[item] = result;
 }
 
+// BLOCK_REQUEST_LOCATION exactly as the reference answers it: the row's entry in its character's mark table / array
+__device__ __forceinline__ int64_t lane_mark_offset(const DevIndex& ix, int64_t row) {
+  uint32_t idx1;
+  const int64_t gb = bucket_of(ix, row, &idx1);
+  const DevBucket bk = ix.buckets[gb];
+  int seq;
+  uint32_t cnt;
+  wt_rank_lane(ix, bk.node_base, idx1, &seq, &cnt);
+  const LaneSeq sq = ix.lseqs[bk.seq_base + uint32_t(seq)];
+  const RankResult m = bseq_rank_lane(ix, sq.mark_table, cnt);
+  if (!m.bit) return -1;
+  return int64_t(read_bits_ptr(wrap_ptr(ix.image, sq.mark_array), (uint64_t(m.o1) - 1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
+}
+
 // leaf requests (block_request CHAR|OCCS|LOCATION, src/main/index.c:1973-2144) from the packed lines
 __global__ __launch_bounds__(256) void block_request_kernel_pack(const DevIndex ix, const int64_t n, const int64_t* __restrict__ rows,
                                                                  const uint16_t* __restrict__ ch_in, uint16_t* __restrict__ ch_out,
@@ -322,7 +336,7 @@ __global__ __launch_bounds__(256) void block_request_kernel_pack(const DevIndex 
     ch_out[item] = uint16_t(a);
   }
   if (occ_out) occ_out[item] = occ;
-  if (off_out) off_out[item] = s.marked ? ix.pack_sa[s.sa_index] : -1;
+  if (off_out) off_out[item] = lane_mark_offset(ix, row);   // femto's own marks (the derived lines may mark more rows)
 }
 
 // ---- construction of the packed lines (at open, on the GPU, from the lane tables) ------------------------------
@@ -437,6 +451,86 @@ __global__ __launch_bounds__(256) void pack_sa_kernel(const DevIndex ix, const i
     mb += uint32_t(__popc(lp[15 + j] & msk));
   }
   sa[int64_t((uint64_t(lp[31] & 0xffu) << 32) | lp[28]) + int64_t(mb)] = off;
+}
+
+// ---- denser marks (derived) ---------------------------------------------------------------------------------------
+// femto marks every mark_period-th text position (default 20), so a locate walks ~mark_period/2 LF steps -- each a
+// random memory line.  The index files stay as they are, but the DERIVED lines may mark more rows: from every
+// original mark (offset o) the LF walk visits the rows of offsets o-1, o-2, ...; those at distance `every`,
+// 2*every, ... get a mark of their own (offset o-j), so a walk ends after at most `every`-1 steps.  Offsets returned
+// are the same numbers; leaf requests keep answering from femto's own mark tables (BLOCK_REQUEST_LOCATION parity).
+// pass 1 sets the extra bits (atomicOr into the mark plane; walking reads only the code planes and counts),
+// then the mark counts are recomputed, then pass 2 repeats the walk and stores the offsets at their ranks.
+__device__ __forceinline__ int64_t pack_mark_rank(const uint32_t* __restrict__ pack, int64_t row) {
+  uint64_t line;
+  uint32_t r;
+  pack_split(row, &line, &r);
+  const uint32_t* lp = pack + line * kPackLineWords;
+  uint32_t mb = 0;
+  for (int j = 0; j < kPackPlaneWords; j++) {
+    const int bits = int(r) - 32 * j;
+    const uint32_t msk = bits >= 32 ? ~0u : (bits <= 0 ? 0u : ((1u << bits) - 1u));
+    mb += uint32_t(__popc(lp[15 + j] & msk));
+  }
+  return int64_t((uint64_t(lp[31] & 0xffu) << 32) | lp[28]) + int64_t(mb);
+}
+
+template <bool kStore>
+__global__ __launch_bounds__(256) void pack_densify_kernel(const DevIndex ix, uint32_t* __restrict__ pack, const int64_t row0, const int64_t n,
+                                                           const uint8_t* __restrict__ sym, const int every, const int period,
+                                                           int64_t* __restrict__ sa) {
+  const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (row >= row0 + n) return;
+  if (!(sym[row] & 0x80u)) return;
+  int64_t off = 0;
+  if (kStore) {  // the original mark's offset, from femto's mark table and array (index.c:2102-2140)
+    uint32_t idx1;
+    const int64_t gb = bucket_of(ix, row, &idx1);
+    const DevBucket bk = ix.buckets[gb];
+    int seq;
+    uint32_t cnt;
+    wt_rank_lane(ix, bk.node_base, idx1, &seq, &cnt);
+    const LaneSeq sq = ix.lseqs[bk.seq_base + uint32_t(seq)];
+    const RankResult m = bseq_rank_lane(ix, sq.mark_table, cnt);
+    off = int64_t(read_bits_ptr(wrap_ptr(ix.image, sq.mark_array), (uint64_t(m.o1) - 1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
+    sa[pack_mark_rank(pack, row)] = off;
+  }
+  int64_t r = row;
+  for (int j = 1; j < period; j++) {
+    uint64_t line;
+    uint32_t rr;
+    pack_split(r, &line, &rr);
+    PackLine L;
+    pack_load_line(pack, line, L);
+    const PackStep s = pack_step(L, rr);
+    if ((ix.pack_stop >> s.code) & 1u) break;     // a document starts here: nothing precedes it
+    r = s.c_plus_occ - 1;
+    if (j % every == 0) {
+      if (kStore) {
+        sa[pack_mark_rank(pack, r)] = off - j;
+      } else {
+        pack_split(r, &line, &rr);
+        atomicOr(pack + line * kPackLineWords + 15 + (rr >> 5), 1u << (rr & 31u));
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_recount_marks_kernel(const int64_t nlines, const uint32_t* __restrict__ pack, int64_t* __restrict__ counts) {
+  const int64_t line = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (line >= nlines) return;
+  const uint32_t* lp = pack + line * kPackLineWords;
+  uint32_t c = 0;
+  for (int j = 0; j < kPackPlaneWords; j++) c += uint32_t(__popc(lp[15 + j]));
+  counts[line] = int64_t(c);
+}
+
+__global__ __launch_bounds__(256) void pack_markcount_kernel(const int64_t nlines, uint32_t* __restrict__ pack, const int64_t* __restrict__ scan) {
+  const int64_t line = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (line >= nlines) return;
+  const uint64_t m = uint64_t(scan[line]);
+  pack[line * kPackLineWords + 28] = uint32_t(m);
+  pack[line * kPackLineWords + 31] = uint32_t(m >> 32) & 0xffu;
 }
 
 }  // namespace femto_amd
