@@ -105,8 +105,23 @@ __device__ __forceinline__ void p2_search_step(const DevIndex& ix, int j, uint32
   const uint32_t* __restrict__ l2 = ix.p2_l2;
   const int64_t base = ix.p2_base[h];
   const bool haveF = first != 0;
-  const int64_t rkL = p2_rank_h(l1, uint64_t(last) >> 6, uint32_t(last) & 63u, h);
-  const int64_t rkF = haveF ? p2_rank_h(l1, uint64_t(first - 1) >> 6, uint32_t(first - 1) & 63u, h) : 0;
+  // level 1: both ends usually fall into the same 64-row line once the range is narrow -- load it once
+  const uint64_t l1L = uint64_t(last) >> 6, l1F = haveF ? uint64_t(first - 1) >> 6 : l1L;
+  int64_t rkL, rkF = 0;
+  {
+    const uint32_t* lp = l1 + l1L * 32;
+    const uint4 a = reinterpret_cast<const uint4*>(lp)[0], b = reinterpret_cast<const uint4*>(lp)[1];
+    const uint32_t lo = lp[10 + h];
+    const uint32_t hi = (lp[26 + (h >> 2)] >> (8 * (h & 3u))) & 0xffu;
+    const uint64_t p0 = (uint64_t(a.y) << 32) | a.x, p1 = (uint64_t(a.w) << 32) | a.z;
+    const uint64_t p2 = (uint64_t(b.y) << 32) | b.x, p3 = (uint64_t(b.w) << 32) | b.z;
+    const uint64_t eq = (p0 ^ ((h & 1u) ? 0ull : ~0ull)) & (p1 ^ ((h & 2u) ? 0ull : ~0ull)) & (p2 ^ ((h & 4u) ? 0ull : ~0ull)) &
+                        (p3 ^ ((h & 8u) ? 0ull : ~0ull));
+    const int64_t before = int64_t((uint64_t(hi) << 32) | lo);
+    rkL = before + int64_t(__popcll(eq & p2_below_incl(uint32_t(last) & 63u)));
+    if (haveF && l1F == l1L) rkF = before + int64_t(__popcll(eq & p2_below_incl(uint32_t(first - 1) & 63u)));
+  }
+  if (haveF && l1F != l1L) rkF = p2_rank_h(l1, l1F, uint32_t(first - 1) & 63u, h);
   const int64_t c0 = ix.p2_c[code];
   int64_t nl = c0, nf = c0;
   uint64_t lineL = 0, lineF = 0;
