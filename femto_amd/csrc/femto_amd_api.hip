@@ -200,8 +200,17 @@ int check_err_flag(femto_amd_index* ix, hipStream_t stream) {
   return 0;
 }
 
+// The locate plan can take over the clamp: when the count kernel stored (first,last) pairs, one pass splits them
+// into the caller's arrays AND computes the per-pattern row counts.
+struct PlanClamp {
+  int max_occs;
+  int32_t* noccs;
+  int64_t* noccs64;
+  bool done;
+};
+
 int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
-                       const int64_t* d_starts, int64_t* d_first, int64_t* d_last, hipStream_t stream) {
+                       const int64_t* d_starts, int64_t* d_first, int64_t* d_last, hipStream_t stream, PlanClamp* plan = nullptr) {
   if (npats <= 0) return 0;
   constexpr int lanes_per_query = 2 * kGroupW;
   const int64_t threads = npats * lanes_per_query;
@@ -279,7 +288,12 @@ int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen
     HIP_TRY(hipEventRecord(e1, stream));
     ix->t_count.events.emplace_back(e0, e1);
   }
-  if (split_pairs) {
+  if (split_pairs && plan && d_last) {
+    hipLaunchKernelGGL(split_clamp_kernel, dim3(uint32_t((npats + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, stream,
+                       npats, ix->s_pairs.as<longlong2>(), d_first, d_last, plan->max_occs, plan->noccs, plan->noccs64);
+    HIP_TRY(hipGetLastError());
+    plan->done = true;
+  } else if (split_pairs) {
     hipLaunchKernelGGL(split_pairs_kernel, dim3(uint32_t((npats + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, stream,
                        npats, ix->s_pairs.as<longlong2>(), d_first, d_last);
     HIP_TRY(hipGetLastError());
@@ -290,8 +304,9 @@ int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen
 // An AQL dispatch carries at most 2^32 - 1 work-items per dimension: larger batches go out in chunks
 // (pattern starts are absolute, so only the per-pattern arrays are offset).
 int launch_count(femto_amd_index* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
-                 const int64_t* d_starts, int64_t* d_first, int64_t* d_last, hipStream_t stream) {
+                 const int64_t* d_starts, int64_t* d_first, int64_t* d_last, hipStream_t stream, PlanClamp* plan = nullptr) {
   const int64_t max_chunk = ix->mode == 0 ? (int64_t(1) << 25) : (int64_t(1) << 31);
+  if (plan && npats <= max_chunk) return launch_count_chunk(ix, npats, d_plen, d_pats, d_starts, d_first, d_last, stream, plan);
   for (int64_t off = 0; off < npats; off += max_chunk) {
     const int64_t cnt = std::min<int64_t>(max_chunk, npats - off);
     int rc = launch_count_chunk(ix, cnt, d_plen + off, d_pats, d_starts + off, d_first + off, d_last ? d_last + off : nullptr, stream);
@@ -1380,9 +1395,10 @@ int femto_amd_locate_plan_device(femto_amd_index_t* ix, int64_t npats, const int
   if (rc) return rc;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   std::lock_guard<std::recursive_mutex> lk(ix->mu);
-  if ((rc = launch_count(ix, npats, d_plen, d_pats, d_starts, d_first, d_last, stream))) return rc;
   if ((rc = ix->s_noccs64.reserve(size_t(npats + 1) * 8))) return rc;
-  if (npats) {
+  PlanClamp pc{max_occs_each, d_noccs, ix->s_noccs64.as<int64_t>(), false};
+  if ((rc = launch_count(ix, npats, d_plen, d_pats, d_starts, d_first, d_last, stream, &pc))) return rc;
+  if (npats && !pc.done) {
     hipLaunchKernelGGL(clamp_kernel, dim3(uint32_t((npats + 255) / 256)), dim3(256), 0, stream, npats, d_first, d_last,
                        max_occs_each, d_noccs, ix->s_noccs64.as<int64_t>());
     HIP_TRY(hipGetLastError());

@@ -184,6 +184,23 @@ __global__ __launch_bounds__(256) void count_kernel_pack(const DevIndex ix, cons
   else first_out[q] = last - first + 1;
 }
 
+// split + the locate clamp of do_locate_query (src/main/server.c:4405-4415, note `last-first > max_occs`) in one pass
+__global__ __launch_bounds__(256) void split_clamp_kernel(const int64_t n, const longlong2* __restrict__ pairs, int64_t* __restrict__ first_out,
+                                                          int64_t* __restrict__ last_out, const int max_occs, int32_t* __restrict__ noccs,
+                                                          int64_t* __restrict__ noccs64) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const longlong2 p = pairs[i];
+  first_out[i] = p.x;
+  last_out[i] = p.y;
+  int64_t c;
+  if (p.x > p.y) c = 0;
+  else if (p.y - p.x > int64_t(max_occs)) c = max_occs;
+  else c = p.y - p.x + 1;
+  noccs[i] = int32_t(c);
+  noccs64[i] = c;
+}
+
 // (first,last) pairs -> the API's separate arrays (coalesced); last_out == NULL: first_out receives the counts
 __global__ __launch_bounds__(256) void split_pairs_kernel(const int64_t n, const longlong2* __restrict__ pairs, int64_t* __restrict__ first_out,
                                                           int64_t* __restrict__ last_out) {
