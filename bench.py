@@ -391,6 +391,8 @@ def main():
                 traffic = None
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_GBs": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,      # measured memory-side rate of the same kernel
+                "traffic_frac_of_peak": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "kernel": (KERNEL_NAMES if dominant_is_count else LOCATE_NAMES)[ix.rank_mode],
                 "kernel_ms": k_ms, "launches_timed": cnt_n,
                 "count_kernel_ms": cnt_ms, "locate_kernel_ms": loc_ms,
