@@ -1027,7 +1027,13 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
         std::vector<uint8_t> dense(512, 0);
         int sigma = 0;
         for (int ch = 0; ch < kAlphaSize; ch++)
-          if (h.C[size_t(ch) + 1] > h.C[size_t(ch)]) dense[size_t(ch)] = uint8_t(++sigma > 255 ? 255 : sigma);
+          if (h.C[size_t(ch) + 1] > h.C[size_t(ch)]) {
+            // digit = 1 + rank of the character; an 8-bit digit holds ranks 0..254 -- the 256th (and 257th) character of a
+            // full byte alphabet gets digit 0 ("not in the key"): kernels that search from the keys then read that
+            // symbol from the pattern itself, and the sort merely loses locality for such patterns
+            ++sigma;
+            dense[size_t(ch)] = uint8_t(sigma <= 255 ? sigma : 0);
+          }
         int bits = 1;
         while ((1 << bits) <= (sigma > 255 ? 255 : sigma)) bits++;
         ix->dense_bits = bits;

@@ -33,7 +33,7 @@ namespace {
     }                                                                                           \
   } while (0)
 
-__global__ void pack_keys_kernel(const uint16_t* __restrict__ text, const uint8_t* __restrict__ dense, int64_t n,
+__global__ void pack_keys_kernel(const uint16_t* __restrict__ text, const uint16_t* __restrict__ dense, int64_t n,
                                  int bits, int k, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -105,18 +105,20 @@ int gpu_suffix_sort(const std::vector<uint16_t>& text, int device, std::vector<i
   }
   SS_TRY(hipSetDevice(device));
 
-  // dense symbol ranks: 0 is reserved for the end marker
-  std::vector<uint8_t> present(512, 0), dense(512, 0);
+  // dense symbol ranks: 0 is reserved for the end marker.  A text with all 256 byte values plus SEOF has 257 symbols,
+  // so the ranks need 16 bits (an 8-bit table wrapped rank 256 onto the end marker: wrong order for such texts).
+  std::vector<uint8_t> present(512, 0);
+  std::vector<uint16_t> dense(512, 0);
   for (uint16_t c : text) present[c] = 1;  // alpha codes are < 261
   int sigma = 0;
-  for (int c = 0; c < 512; c++) if (present[size_t(c)]) dense[size_t(c)] = uint8_t(++sigma);
+  for (int c = 0; c < 512; c++) if (present[size_t(c)]) dense[size_t(c)] = uint16_t(++sigma);
   int bits = 1;
   while ((1 << bits) <= sigma) bits++;
   const int k = 64 / bits;
 
   DevMem d_text, d_dense, d_keys, d_keys2, d_idx, d_idx2, d_rank, d_head, d_tmp, d_cnt;
   SS_TRY(hipMalloc(&d_text.p, size_t(n) * 2));
-  SS_TRY(hipMalloc(&d_dense.p, 512));
+  SS_TRY(hipMalloc(&d_dense.p, 1024));
   SS_TRY(hipMalloc(&d_keys.p, size_t(n) * 8));
   SS_TRY(hipMalloc(&d_keys2.p, size_t(n) * 8));
   SS_TRY(hipMalloc(&d_idx.p, size_t(n) * 4));
@@ -125,7 +127,7 @@ int gpu_suffix_sort(const std::vector<uint16_t>& text, int device, std::vector<i
   SS_TRY(hipMalloc(&d_head.p, size_t(n) * 4));
   SS_TRY(hipMalloc(&d_cnt.p, 8));
   SS_TRY(hipMemcpy(d_text.p, text.data(), size_t(n) * 2, hipMemcpyHostToDevice));
-  SS_TRY(hipMemcpy(d_dense.p, dense.data(), 512, hipMemcpyHostToDevice));
+  SS_TRY(hipMemcpy(d_dense.p, dense.data(), 1024, hipMemcpyHostToDevice));
 
   uint64_t* keys = static_cast<uint64_t*>(d_keys.p);
   uint64_t* keys2 = static_cast<uint64_t*>(d_keys2.p);
@@ -142,7 +144,7 @@ int gpu_suffix_sort(const std::vector<uint16_t>& text, int device, std::vector<i
 
   const dim3 blk(256), grd(uint32_t((n + 255) / 256));
   hipLaunchKernelGGL(pack_keys_kernel, grd, blk, 0, nullptr, static_cast<const uint16_t*>(d_text.p),
-                     static_cast<const uint8_t*>(d_dense.p), n, bits, k, keys, idx);
+                     static_cast<const uint16_t*>(d_dense.p), n, bits, k, keys, idx);
   int64_t h = k;
   for (int round = 0; round < 40; round++) {
     size_t tb = tmp_bytes;
@@ -185,7 +187,7 @@ int gpu_suffix_sort(const std::vector<uint16_t>& text, int device, std::vector<i
 // =====================================================================================
 namespace {
 
-__device__ __forceinline__ uint64_t key_at(const uint8_t* __restrict__ D, int64_t n, int64_t i, int bits, int k) {
+__device__ __forceinline__ uint64_t key_at(const uint16_t* __restrict__ D, int64_t n, int64_t i, int bits, int k) {
   uint64_t key = 0;
   for (int j = 0; j < k; j++) {
     const int64_t p = i + j;
@@ -194,7 +196,7 @@ __device__ __forceinline__ uint64_t key_at(const uint8_t* __restrict__ D, int64_
   return key;
 }
 
-__global__ void hist12_kernel(const uint8_t* __restrict__ D, int64_t n, int bits, int k, int keybits,
+__global__ void hist12_kernel(const uint16_t* __restrict__ D, int64_t n, int bits, int k, int keybits,
                               unsigned long long* __restrict__ hist) {
   __shared__ unsigned int h[4096];
   for (int t = threadIdx.x; t < 4096; t += blockDim.x) h[t] = 0;
@@ -209,7 +211,7 @@ __global__ void hist12_kernel(const uint8_t* __restrict__ D, int64_t n, int bits
     if (h[t]) atomicAdd(&hist[t], (unsigned long long)h[t]);
 }
 
-__global__ void compact_part_kernel(const uint8_t* __restrict__ D, int64_t n, int bits, int k, int keybits, uint32_t lo_bin,
+__global__ void compact_part_kernel(const uint16_t* __restrict__ D, int64_t n, int bits, int k, int keybits, uint32_t lo_bin,
                                     uint32_t hi_bin, uint64_t* __restrict__ keys, uint64_t* __restrict__ vals,
                                     unsigned long long* __restrict__ counter) {
   // grid-stride: an AQL dispatch carries at most 2^32 - 1 work-items per dimension, fewer than the suffixes
@@ -316,10 +318,11 @@ int gpu_suffix_sort_large(const std::vector<uint16_t>& text, int device, int64_t
     return 6;
   }
   SS_TRY(hipSetDevice(device));
-  std::vector<uint8_t> present(512, 0), dense(512, 0);
+  std::vector<uint8_t> present(512, 0);
+  std::vector<uint16_t> dense(512, 0);   // up to 257 symbols: 16-bit ranks (see gpu_suffix_sort)
   for (uint16_t c : text) present[c] = 1;
   int sigma = 0;
-  for (int c = 0; c < 512; c++) if (present[size_t(c)]) dense[size_t(c)] = uint8_t(++sigma);
+  for (int c = 0; c < 512; c++) if (present[size_t(c)]) dense[size_t(c)] = uint16_t(++sigma);
   int bits = 1;
   while ((1 << bits) <= sigma) bits++;
   const int k = 64 / bits;
@@ -328,17 +331,17 @@ int gpu_suffix_sort_large(const std::vector<uint16_t>& text, int device, int64_t
 
   DevMem d_D, d_SA, d_ISA, d_keys, d_keys2, d_vals, d_vals2, d_head, d_tmp, d_cnt, d_hist, d_flag, d_pos, d_grp;
   {
-    std::vector<uint8_t> Dh(static_cast<size_t>(n));
+    std::vector<uint16_t> Dh(static_cast<size_t>(n));
     for (int64_t i = 0; i < n; i++) Dh[size_t(i)] = dense[text[size_t(i)]];
-    SS_TRY(hipMalloc(&d_D.p, size_t(n)));
-    SS_TRY(hipMemcpy(d_D.p, Dh.data(), size_t(n), hipMemcpyHostToDevice));
+    SS_TRY(hipMalloc(&d_D.p, size_t(n) * 2));
+    SS_TRY(hipMemcpy(d_D.p, Dh.data(), size_t(n) * 2, hipMemcpyHostToDevice));
   }
   SS_TRY(hipMalloc(&d_SA.p, size_t(n) * 8));
   SS_TRY(hipMalloc(&d_ISA.p, size_t(n) * 8));
   SS_TRY(hipMalloc(&d_cnt.p, 8));
   SS_TRY(hipMalloc(&d_hist.p, 4096 * 8));
   SS_TRY(hipMemset(d_hist.p, 0, 4096 * 8));
-  const uint8_t* D = static_cast<const uint8_t*>(d_D.p);
+  const uint16_t* D = static_cast<const uint16_t*>(d_D.p);
   uint64_t* SA = static_cast<uint64_t*>(d_SA.p);
   uint64_t* ISA = static_cast<uint64_t*>(d_ISA.p);
 

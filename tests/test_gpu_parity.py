@@ -346,6 +346,15 @@ def test_random_indexes_vs_oracle(tmp_path, gpu_ok, seed):
     params = f"block_size={block},bucket_size={b_size},chunk_size={b_size},mark_period={mark}"
     path = str(tmp_path / f"rnd{seed}")
     femto_amd.build_index(path, docs, params=params, infos=[f"d{i}" for i in range(len(docs))], device=0)
+    # the GPU suffix sorter against a CPU suffix array of the same prepared text: identical index files
+    from sa_util import suffix_array
+    import filecmp
+    prepared = np.concatenate([np.concatenate([d.astype(np.uint16) + 5, [2]]) for d in docs])
+    ref_path = str(tmp_path / f"rnd{seed}_cpu_sa")
+    femto_amd.build_index_from_sa(ref_path, docs, suffix_array(prepared), params=params, infos=[f"d{i}" for i in range(len(docs))])
+    for f in sorted(os.listdir(ref_path)):
+        if f != "_femto_index":
+            assert filecmp.cmp(os.path.join(path, f), os.path.join(ref_path, f), shallow=False), (seed, f, params)
     o = po.Oracle(path)
     ix = femto_amd.Index(path, device=0)
     distinct = len(np.unique(text)) + 1          # + SEOF
@@ -382,6 +391,38 @@ def test_random_indexes_vs_oracle(tmp_path, gpu_ok, seed):
         assert [(int(a), int(b), int(c)) for a, b, c in zip(ch, occ, off)] == want_bw, (seed, mode)
     ch, nr, off = ix.forward_steps(rows)
     assert [(int(a), int(b), int(c)) for a, b, c in zip(ch, nr, off)] == want_fw, seed
+
+
+@pytest.mark.parametrize("large", [False, True])
+@pytest.mark.parametrize("ndocs", [1, 3])
+def test_gpu_sorter_full_byte_alphabet(tmp_path, gpu_ok, ndocs, large, monkeypatch):
+    """Texts that use (almost) every byte value: 256-257 symbols with SEOF, which do not fit 8-bit ranks (an
+    earlier 8-bit rank table wrapped the last symbol onto the end marker).  Both sorter paths, checked through the
+    byte identity of the index with the one built from a CPU suffix array, and through locate-all == that array."""
+    import filecmp
+    from sa_util import suffix_array
+    rng = np.random.Generator(np.random.PCG64(41 + ndocs))
+    n = 150_000
+    text = rng.integers(0, 256, n).astype(np.uint8)
+    assert len(np.unique(text)) == 256
+    cuts = sorted(rng.choice(np.arange(1, n), ndocs - 1, replace=False)) if ndocs > 1 else []
+    docs = np.split(text, cuts)
+    params = "block_size=65536,bucket_size=4096,chunk_size=4096,mark_period=8"
+    if large:
+        monkeypatch.setenv("FEMTO_AMD_LARGE_SORT_CAP", "40000")
+    a, b = str(tmp_path / "gpu"), str(tmp_path / "cpu")
+    femto_amd.build_index(a, docs, params=params, infos=[f"d{i}" for i in range(len(docs))], device=0)
+    prepared = np.concatenate([np.concatenate([d.astype(np.uint16) + 5, [2]]) for d in docs])
+    sa = suffix_array(prepared)
+    femto_amd.build_index_from_sa(b, docs, sa, params=params, infos=[f"d{i}" for i in range(len(docs))])
+    for f in sorted(os.listdir(b)):
+        if f != "_femto_index":
+            assert filecmp.cmp(os.path.join(a, f), os.path.join(b, f), shallow=False), f
+    if ndocs == 1:
+        ix = femto_amd.Index(a, device=0)
+        assert ix.rank_mode == 1                     # 257 symbols: the wavelet path
+        _, offs = ix.locate([np.zeros(0, dtype=np.uint16)], len(sa))
+        assert np.array_equal(offs, sa)
 
 
 @pytest.mark.parametrize("kind", ["acgt", "eng", "runs"])

@@ -1,0 +1,77 @@
+"""Randomised parity soak at medium sizes (run on the GPU box): python tools/soak.py [n_indexes] [seed0]
+Random alphabets / run structure / document splits / index parameters at 0.3-6 M rows, every kernel family against
+the oracle (count, locate with random clamps, leaf requests).  The committed test-suite runs the same comparison at
+2-60 k rows (tests/test_gpu_parity.py::test_random_indexes_vs_oracle) and at fixed medium/full sizes."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import femto_amd  # noqa: E402
+from femto_amd import textgen as tg  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+
+
+def one(seed, root):
+    rng = np.random.Generator(np.random.PCG64(777000 + seed))
+    n = int(rng.integers(300_000, 6_000_000))
+    sigma = int(rng.choice([2, 4, 5, 7, 8, 9, 17, 33, 100, 200, 255, 256]))
+    alphabet = rng.choice(256, sigma, replace=False).astype(np.uint8)
+    if rng.random() < 0.4:
+        runs = rng.geometric(1.0 / float(rng.choice([2, 20, 400])), n // 2 + 10)
+        text = np.repeat(alphabet[rng.integers(0, sigma, len(runs))], runs)[:n]
+    elif rng.random() < 0.5:       # skewed frequencies
+        p = rng.dirichlet(np.full(sigma, 0.3))
+        text = alphabet[rng.choice(sigma, n, p=p)]
+    else:
+        text = alphabet[rng.integers(0, sigma, n)]
+    ndocs = int(rng.integers(1, 4))
+    cuts = sorted(rng.choice(np.arange(1, len(text)), ndocs - 1, replace=False)) if ndocs > 1 else []
+    docs = np.split(text, cuts)
+    b_size = int(rng.choice([4096, 65536, 1 << 20]))
+    block = b_size * int(rng.choice([1, 4, 16]))
+    mark = int(rng.choice([1, 3, 5, 8, 20, 37]))
+    params = f"block_size={block},bucket_size={b_size},chunk_size={b_size},mark_period={mark}"
+    path = os.path.join(root, f"soak{seed}")
+    femto_amd.build_index(path, docs, params=params, infos=[f"d{i}" for i in range(len(docs))], device=0)
+    o = po.Oracle(path)
+    os.environ["FEMTO_AMD_PACK2"] = "1"
+    ix = femto_amd.Index(path, device=0)
+    pats = []
+    for _ in range(20000):
+        ln = int(rng.integers(0, 40))
+        if rng.random() < 0.7 and len(text) > ln:
+            s0 = int(rng.integers(0, len(text) - ln + 1))
+            pats.append(tg.to_alpha(text[s0:s0 + ln]))
+        else:
+            pats.append(tg.to_alpha(alphabet[rng.integers(0, sigma, ln)]))
+    plen, flat, starts = femto_amd.flatten(pats)
+    of, ol = o.count_flat(plen, flat, starts, threads=16)
+    mo = int(rng.integers(1, 30))
+    on, oo = o.locate_flat(plen, flat, starts, mo, threads=16)
+    rows = rng.integers(0, ix.info.total_length, 2000).astype(np.int64)
+    want = [o.block_request(int(r), 7) for r in rows]
+    info = ix.pack_info()
+    modes = [m for m in (3, 4, 1, 2, 0) if not (m == 3 and not info["available"]) and not (m == 4 and not info["available2"])]
+    for mode in modes:
+        ix.set_rank_mode(mode)
+        f, l_ = ix.count_flat(plen, flat, starts)
+        assert np.array_equal(f, of) and np.array_equal(l_, ol), (seed, mode, params, "count")
+        nn, offs = ix.locate_flat(plen, flat, starts, mo)
+        assert np.array_equal(nn, on) and np.array_equal(offs, oo), (seed, mode, params, "locate")
+        ch, occ, off = ix.block_requests(rows)
+        assert [(int(a), int(b), int(c)) for a, b, c in zip(ch, occ, off)] == want, (seed, mode, "leaf")
+    ix.close()
+    distinct = len(np.unique(text)) + 1
+    print(f"seed {seed}: rows {n} sigma {distinct} docs {ndocs} {params} modes {modes} located {int(on.sum())} ok", flush=True)
+
+
+if __name__ == "__main__":
+    count = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    with tempfile.TemporaryDirectory() as td:
+        for s in range(seed0, seed0 + count):
+            one(s, td)
+    print("soak ok")
