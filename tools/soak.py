@@ -51,6 +51,16 @@ def one(seed, root):
     of, ol = o.count_flat(plen, flat, starts, threads=16)
     mo = int(rng.integers(1, 30))
     on, oo = o.locate_flat(plen, flat, starts, mo, threads=16)
+    # the index itself against the TEXT (a wrong suffix order would be self-consistent between GPU and oracle):
+    # every located offset is an occurrence, sampled substrings are found, offsets of a pattern are distinct
+    prepared = np.concatenate([np.concatenate([d.astype(np.uint16) + 5, [2]]) for d in docs])
+    pos = np.concatenate([[0], np.cumsum(on)])
+    for i in range(0, len(pats), 7):
+        p_ = pats[i]
+        got = oo[pos[i]:pos[i + 1]]
+        assert len(set(got.tolist())) == len(got), (seed, "duplicate offsets")
+        for off in got:
+            assert np.array_equal(prepared[off:off + len(p_)], p_), (seed, i, "located offset is not an occurrence")
     rows = rng.integers(0, ix.info.total_length, 2000).astype(np.int64)
     want = [o.block_request(int(r), 7) for r in rows]
     info = ix.pack_info()
