@@ -144,6 +144,8 @@ struct DevIndex {           // passed by value to kernels
   int32_t b_size;
   int32_t b_shift;          // log2(b_size) when b_size is a power of two, else -1
   int32_t text_size_bits;
+  int32_t walk_limit;       // a locate walk of a well-formed index ends within mark_period steps; beyond this many the
+                            // index is inconsistent (e.g. an LF cycle without marks) and the row is reported as -1
 };
 
 }  // namespace femto_amd

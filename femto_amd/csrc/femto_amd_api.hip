@@ -1062,6 +1062,7 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
       d.b_size = h.b_size;
       d.b_shift = (h.b_size & (h.b_size - 1)) == 0 ? __builtin_ctz(unsigned(h.b_size)) : -1;
       d.text_size_bits = h.text_size_bits;
+      d.walk_limit = 2 * (h.mark_period > 0 ? h.mark_period : 1) + 8;
       {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));

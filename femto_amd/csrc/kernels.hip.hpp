@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void locate_kernel(const DevIndex ix, const in
   }
   int64_t row = first[lo] + (item - out_starts[lo]);
   int64_t steps = 0, result = -1;
-  while (row >= 0) {
+  while (row >= 0 && steps <= int64_t(ix.walk_limit)) {
     uint32_t idx1;
     const int64_t gb = bucket_of(ix, row, &idx1);
     const DevBucket bk = ix.buckets[gb];
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256) void locate_kernel_lane(const DevIndex ix, con
   }
   int64_t row = first[lo] + (item - out_starts[lo]);
   int64_t steps = 0, result = -1;
-  while (row >= 0) {
+  while (row >= 0 && steps <= int64_t(ix.walk_limit)) {
     uint32_t idx1;
     const int64_t gb = bucket_of(ix, row, &idx1);
     const DevBucket bk = ix.buckets[gb];
@@ -1057,6 +1057,7 @@ __global__ __launch_bounds__(256) void locate_kernel_flat(const DevIndex ix, con
       } else {
         row = ix.occ[gb * kAlphaSize + mch].base + int64_t(idx) - 1;  // LF (server.c:2279-2282)
         steps++;
+        if (steps > int64_t(ix.walk_limit)) row = -1;   // inconsistent index: give up on this row (-1)
         st = LT_ROW;
       }
     }

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void locate_kernel_pack2(const DevIndex ix, co
   if (item >= total) return;
   int64_t row = offsets[item];
   int64_t steps = 0, result = -1;
-  while (row >= 0) {
+  while (row >= 0 && steps <= int64_t(ix.walk_limit)) {
     const P2Step s = p2_step(ix, row);
     if (s.marked) {
       result = ix.pack_sa[s.sa_index] + steps;

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void locate_kernel_pack(const DevIndex ix, con
   if (item >= total) return;
   int64_t row = offsets[item];
   int64_t steps = 0, result = -1;
-  while (row >= 0) {
+  while (row >= 0 && steps <= int64_t(ix.walk_limit)) {
     uint64_t line;
     uint32_t r;
     pack_split(row, &line, &r);
