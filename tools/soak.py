@@ -74,6 +74,39 @@ def one(seed, root):
         ch, occ, off = ix.block_requests(rows)
         assert [(int(a), int(b), int(c)) for a, b, c in zip(ch, occ, off)] == want, (seed, mode, "leaf")
     ix.close()
+    if seed % 4 == 0:     # range-split three ways in this process: every part answers like the whole index
+        parts = [femto_amd.Index(path, device=0, part=p_, nparts=3) for p_ in range(3)]
+        for a in parts:
+            for b in parts:
+                if a is not b:
+                    a.split_attach_local(b)
+        for a in parts:
+            a.split_commit()
+        for a in parts:
+            f, l_ = a.count_flat(plen, flat, starts)
+            assert np.array_equal(f, of) and np.array_equal(l_, ol), (seed, "split count")
+            nn, offs = a.locate_flat(plen, flat, starts, mo)
+            assert np.array_equal(nn, on) and np.array_equal(offs, oo), (seed, "split locate")
+        for a in parts:
+            a.close()
+    if seed % 4 == 1:     # host-pointer pipeline: a batch above the pipeline threshold, in both calling conventions,
+        big = 300_000     # and one whose symbols overflow a pinned chunk (falls back to the plain path)
+        sel = rng.integers(0, len(pats), big)
+        bl = plen[sel]
+        bs = starts[sel]                       # not monotone: patterns referenced out of order
+        ix = femto_amd.Index(path, device=0)
+        f, l_ = ix.count_flat(bl, flat, bs)
+        assert np.array_equal(f, of[sel]) and np.array_equal(l_, ol[sel]), (seed, "pipeline count")
+        nn, offs = ix.locate_flat(bl, flat, bs, mo)
+        assert np.array_equal(nn, on[sel]), (seed, "pipeline locate")
+        longp = tg.to_alpha(np.tile(text[:400], 1))
+        lp = np.full(big, len(longp), dtype=np.int32)
+        lflat = np.tile(longp, 2).astype(np.uint16)
+        lst = rng.integers(0, len(longp), big).astype(np.int64)      # overlapping windows of one long string
+        f2, l2 = ix.count_flat(lp, lflat, lst)
+        f3, l3 = o.count_flat(lp, lflat, lst, threads=16)
+        assert np.array_equal(f2, f3) and np.array_equal(l2, l3), (seed, "pipeline fallback count")
+        ix.close()
     distinct = len(np.unique(text)) + 1
     print(f"seed {seed}: rows {n} sigma {distinct} docs {ndocs} {params} modes {modes} located {int(on.sum())} ok", flush=True)
 
