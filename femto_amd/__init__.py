@@ -57,6 +57,7 @@ def lib():
         L.femto_amd_count_bytes.argtypes = [vp, i64, vp, vp, vp, vp, vp]
         L.femto_amd_locate_flat.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, vp, i64, C.POINTER(i64)]
         L.femto_amd_locate_flat_alloc.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, C.POINTER(vp), C.POINTER(i64)]
+        L.femto_amd_parallel_locate_range.argtypes = [vp, i64, i64, vp]
         L.femto_amd_parallel_count.argtypes = [vp, i32, vp, vp, vp, vp]
         L.femto_amd_parallel_locate.argtypes = [vp, i32, vp, vp, i32, vp, vp]
         L.femto_amd_resolve_location.argtypes = [vp, i64, C.POINTER(i64), C.POINTER(i64)]
@@ -215,6 +216,12 @@ class Index:
             _check(lib().femto_amd_locate_flat(self._h, n, _ptr(plen), _ptr(flat), _ptr(starts), max_occs,
                                                _ptr(noccs), _ptr(ostarts), _ptr(offs), total.value, C.byref(total)))
         return noccs, offs[:total.value]
+
+    def locate_range(self, first, last):
+        """text offsets of rows first..last (parallel_locate_range)"""
+        out = np.zeros(max(0, last - first + 1), dtype=np.int64)
+        _check(lib().femto_amd_parallel_locate_range(self._h, int(first), int(last), _ptr(out)))
+        return out
 
     def locate(self, patterns, max_occs):
         return self.locate_flat(*flatten(patterns), max_occs)

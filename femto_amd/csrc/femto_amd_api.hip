@@ -1517,6 +1517,28 @@ int femto_amd_parallel_locate(femto_amd_index_t* ix, int npats, const int* plen,
   return FEMTO_AMD_OK;
 }
 
+int femto_amd_parallel_locate_range(femto_amd_index_t* ix, int64_t first, int64_t last, int64_t* offsets) {
+  if (!ix || !offsets) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  int rc = ensure_device(ix);
+  if (rc) return rc;
+  if (first < 0 || last < first || last >= ix->host.total_length)
+    return set_err(FEMTO_AMD_ERR_PARAM, "row range outside the index");   // the reference has no query to set up (server.c:4061)
+  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  const int64_t max_chunk = int64_t(1) << 26;   // rows per launch (bounded scratch; far below the 2^32 work-item limit)
+  if ((rc = ix->s_first.reserve(16))) return rc;
+  if ((rc = ix->s_out_starts.reserve(32))) return rc;
+  for (int64_t at = first; at <= last; at += max_chunk) {
+    const int64_t cnt = std::min<int64_t>(max_chunk, last - at + 1);
+    const int64_t os[2] = {0, cnt};
+    HIP_TRY(hipMemcpy(ix->s_first.p, &at, 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ix->s_out_starts.p, os, 16, hipMemcpyHostToDevice));
+    if ((rc = ix->s_offsets.reserve(size_t(cnt) * 8))) return rc;
+    if ((rc = launch_locate(ix, 1, ix->s_first.as<int64_t>(), ix->s_out_starts.as<int64_t>(), cnt, ix->s_offsets.as<int64_t>(), nullptr))) return rc;
+    HIP_TRY(hipMemcpy(offsets + (at - first), ix->s_offsets.p, size_t(cnt) * 8, hipMemcpyDeviceToHost));
+  }
+  return FEMTO_AMD_OK;
+}
+
 int femto_amd_block_requests(femto_amd_index_t* ix, int64_t n, const int64_t* rows, const uint16_t* ch_in,
                              uint16_t* ch_out, int32_t* occ_out, int64_t* off_out) {
   if (!ix || (n && !rows)) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");

@@ -88,6 +88,11 @@ int femto_amd_parallel_locate(femto_amd_index_t* ix, int npats, const int* plen,
                               const uint16_t* const* pats, int max_occs_each,
                               int* noccs, int64_t** offsets);
 
+/* Replaces parallel_locate_range (src/main/femto.c:481; setup_locate_range src/main/server.c:4047): the text offset
+ * of every row in [first, last]; offsets must have room for last-first+1 entries.  (serial_locate, femto.c:402, is the
+ * reference's single-threaded test twin of parallel_locate: call femto_amd_parallel_locate.) */
+int femto_amd_parallel_locate_range(femto_amd_index_t* ix, int64_t first, int64_t last, int64_t* offsets);
+
 /* Flat forms of the two calls above (no per-pattern pointers): pattern i is
  * pats[starts[i] .. starts[i]+plen[i]).  locate_flat writes out_starts[npats+1] (exclusive prefix
  * sum of noccs) and at most offsets_capacity offsets; *total_out receives sum(noccs) -- call with

@@ -157,6 +157,25 @@ def test_pointer_array_forms(fixtures, gpu_ok):
     assert np.array_equal(np.array(got, dtype=np.int64), fx.gold["loc7_offs"])
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_locate_range_matches_reference(fixtures, gpu_ok, mode):
+    """parallel_locate_range (femto.c:481): every row's offset, against the per-row LOCATION answers captured from the
+    reference walked back to a mark -- here simply against locate of the empty pattern, which the goldens pin."""
+    fx = fixtures("eng2doc")
+    ix = _open(fx.index, mode)
+    n = ix.info.total_length
+    _, every = ix.locate([np.zeros(0, dtype=np.uint16)], n)
+    assert np.array_equal(ix.locate_range(0, n - 1), every)
+    assert np.array_equal(ix.locate_range(123, 4567), every[123:4568])
+    marked = fx.gold["off"] >= 0                      # rows the reference marks answer with their own offset
+    assert np.array_equal(every[marked], fx.gold["off"][marked])
+    for bad in [(-1, 5), (7, 3), (0, n)]:
+        with pytest.raises(femto_amd.FemtoAmdError) as ei:
+            ix.locate_range(*bad)
+        assert ei.value.code == 3
+    ix.close()
+
+
 def test_invalid_pattern_character_is_param_error(fixtures, gpu_ok):
     fx = fixtures("acgt48k")
     ix = femto_amd.Index(fx.index, device=0)
