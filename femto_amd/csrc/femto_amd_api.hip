@@ -343,9 +343,14 @@ int launch_locate(femto_amd_index* ix, int64_t npats, const int64_t* d_first, co
   const int64_t threads = ix->mode == 0 ? total * kGroupW : total;   // mode 0 walks with a 32-lane group per row
   const int64_t blocks = (total * kGroupW + kBlockThreads - 1) / kBlockThreads;
   if (threads >= (int64_t(1) << 32)) return set_err(FEMTO_AMD_ERR_PARAM, "too many rows to locate in one call (2^32 work-items per launch): lower max_occs_each or split the batch");
-  if (ix->mode == 3 || ix->mode == 4)  // rows first (one thread per pattern), then the walk -- no per-row search for the owning pattern
+  if (ix->mode == 3 || ix->mode == 4) {  // rows first (one thread per pattern), then the walk -- no per-row search for the owning pattern
+    int* big_flag = ix->d_err + 1;
+    HIP_TRY(hipMemsetAsync(big_flag, 0, sizeof(int), stream));
     hipLaunchKernelGGL(expand_rows_kernel, dim3(uint32_t((npats + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, stream,
-                       npats, d_first, d_out_starts, d_offsets);
+                       npats, d_first, d_out_starts, d_offsets, big_flag);
+    hipLaunchKernelGGL(expand_big_rows_kernel, dim3(uint32_t((total + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, stream,
+                       npats, d_first, d_out_starts, total, d_offsets, big_flag);
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ix->timing) {
     HIP_TRY(hipEventCreate(&e0));
@@ -1040,8 +1045,8 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
         ix->dense_sigma = sigma < 2 ? 2 : sigma;
         if ((r = upload(&ix->d_dense, dense, &ix->table_bytes))) return r;
       }
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_err), sizeof(int)));
-      HIP_TRY(hipMemset(ix->d_err, 0, sizeof(int)));
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_err), 4 * sizeof(int)));   // [0] error flag, [1] "long ranges" flag of the locate walk
+      HIP_TRY(hipMemset(ix->d_err, 0, 4 * sizeof(int)));
       DevIndex& d = ix->dev;
       d.image = ix->d_image;
       d.nodes = ix->d_nodes;

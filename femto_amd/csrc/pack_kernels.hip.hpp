@@ -271,12 +271,34 @@ __device__ __forceinline__ PackStep pack_step(const PackLine& L, uint32_t r) {
 // rows to locate, written where their offsets will go: pattern q's rows first[q] .. first[q]+noccs-1 at
 // offsets[out_starts[q] ..] (setup_locate_range, src/main/server.c:4047).  One thread per pattern; the walk kernel
 // then needs no search for "which pattern owns output slot i".
+constexpr int64_t kExpandSerialMax = 4096;   // a longer range (e.g. the empty pattern's) is filled by one thread per row
+
 __global__ __launch_bounds__(256) void expand_rows_kernel(const int64_t npats, const int64_t* __restrict__ first,
-                                                          const int64_t* __restrict__ out_starts, int64_t* __restrict__ offsets) {
+                                                          const int64_t* __restrict__ out_starts, int64_t* __restrict__ offsets,
+                                                          int* __restrict__ big_flag) {
   const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (q >= npats) return;
   const int64_t base = out_starts[q], n = out_starts[q + 1] - base, f = first[q];
+  if (n > kExpandSerialMax) {
+    atomicOr(big_flag, 1);
+    return;
+  }
   for (int64_t j = 0; j < n; j++) offsets[base + j] = f + j;
+}
+
+// the long ranges left over by expand_rows_kernel: one thread per output slot (idle unless the flag is set)
+__global__ __launch_bounds__(256) void expand_big_rows_kernel(const int64_t npats, const int64_t* __restrict__ first,
+                                                              const int64_t* __restrict__ out_starts, const int64_t total,
+                                                              int64_t* __restrict__ offsets, const int* __restrict__ big_flag) {
+  if (!*big_flag) return;
+  const int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (item >= total) return;
+  int64_t lo = 0, hi = npats;   // largest q with out_starts[q] <= item
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (out_starts[mid] <= item) lo = mid; else hi = mid;
+  }
+  if (out_starts[lo + 1] - out_starts[lo] > kExpandSerialMax) offsets[item] = first[lo] + (item - out_starts[lo]);
 }
 
 // locate walk (do_back_query / do_context_query, src/main/server.c:2228-2359, :2627-2795): one line per LF step;
