@@ -16,7 +16,8 @@ from oracle import pyoracle as po  # noqa: E402
 
 def one(seed, root):
     rng = np.random.Generator(np.random.PCG64(777000 + seed))
-    n = int(rng.integers(300_000, 6_000_000))
+    lo_n, hi_n = [int(x) for x in os.environ.get("FEMTO_AMD_SOAK_ROWS", "300000,6000000").split(",")]
+    n = int(rng.integers(lo_n, hi_n))
     sigma = int(rng.choice([2, 4, 5, 7, 8, 9, 17, 33, 100, 200, 255, 256]))
     alphabet = rng.choice(256, sigma, replace=False).astype(np.uint8)
     if rng.random() < 0.4:
