@@ -116,11 +116,19 @@ def main():
     if world != args.gpus:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    # FEMTO_AMD_BENCH_BACKEND=gloo: control-flow smoke test of the N > 1 path on a box with fewer GPUs than ranks
+    # (ranks share devices, the gather travels through host memory); never a measurement.
+    backend = os.environ.get("FEMTO_AMD_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import femto_amd
     from femto_amd import textgen as tg
@@ -172,7 +180,8 @@ def main():
     batch = Batch(torch, dev, plen, flat)
     gather_lists = None
     if world > 1 and rank == 0:
-        gather_lists = [[torch.empty_like(batch.wire(info.total_length)) for _ in range(world)] for _ in range(2)]
+        gather_lists = [[torch.empty_like(batch.wire(info.total_length), device=None if backend == "nccl" else "cpu")
+                         for _ in range(world)] for _ in range(2)]
     stream = torch.cuda.current_stream().cuda_stream
     pending = [None, None]
     counter = {"k": 0}
@@ -187,7 +196,10 @@ def main():
             pending[b] = None
         batch.step(ix, args.max_occs, stream, b)
         if world > 1:
-            pending[b] = dist.gather(batch.wire(info.total_length, b), gather_lists[b] if rank == 0 else None, dst=0, async_op=True)
+            payload = batch.wire(info.total_length, b)
+            if backend != "nccl":
+                payload = payload.cpu()
+            pending[b] = dist.gather(payload, gather_lists[b] if rank == 0 else None, dst=0, async_op=True)
 
     def drain():
         for b in range(2):
@@ -214,7 +226,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ix.kernel_time_enable(False)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     cnt_ms, cnt_n = ix.kernel_time("count")
