@@ -739,3 +739,28 @@ def test_search_cli(fixtures, tmp_path, gpu_ok):
     assert int(r.stdout.split()[0]) == 2 * n1
     r = subprocess.run([tool, "--count", fx.index, "th.*e"], capture_output=True)
     assert r.returncode != 0 and b"regular expressions are not supported" in r.stderr
+
+
+def test_bench_two_ranks_control_flow(tmp_path, gpu_ok):
+    """bench.py's N > 1 path (rank 0 builds, everybody opens, sharded steps, double-buffered gather of the narrowed
+    ranges, max-over-ranks timing, one JSON line from rank 0) with two ranks sharing this box's GPU and the gather routed
+    through gloo -- the control flow the driver runs with RCCL on 2/4/8 GPUs."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    root = os.path.join(os.path.dirname(__file__), "..")
+    env = dict(os.environ, FEMTO_AMD_BENCH_BACKEND="gloo", FEMTO_AMD_BENCH_DIR=str(tmp_path), MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--text-log2", "22", "--npats", "200000", "--cpu-sample", "2000"],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
+    assert line["value"] > 0 and line["cpu_baseline"]["bit_exact_vs_gpu"] is True
+    assert line["config"]["patterns_per_gpu"] == 200000
