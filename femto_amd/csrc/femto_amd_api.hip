@@ -1434,7 +1434,7 @@ int femto_amd_locate_flat(femto_amd_index_t* ix, int64_t npats, const int32_t* p
   if (max_occs_each < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative max_occs_each");
   int rc = ensure_device(ix);
   if (rc) return rc;
-  if ((rc = validate_patterns(npats, plen, starts))) return rc;
+  if (npats < 0 || (npats && (!plen || !starts))) return set_err(FEMTO_AMD_ERR_PARAM, "null pattern arrays");
   int64_t total = 0;
   std::lock_guard<std::recursive_mutex> lk(ix->mu);
   HostBatch hb;
@@ -1463,7 +1463,7 @@ int femto_amd_locate_flat_alloc(femto_amd_index_t* ix, int64_t npats, const int3
   if (max_occs_each < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative max_occs_each");
   int rc = ensure_device(ix);
   if (rc) return rc;
-  if ((rc = validate_patterns(npats, plen, starts))) return rc;
+  if (npats < 0 || (npats && (!plen || !starts))) return set_err(FEMTO_AMD_ERR_PARAM, "null pattern arrays");
   std::lock_guard<std::recursive_mutex> lk(ix->mu);
   HostBatch hb;
   hb.npats = npats;
