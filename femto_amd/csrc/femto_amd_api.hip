@@ -165,11 +165,15 @@ struct femto_amd_index {
 
 namespace {
 
+// `slack` zero bytes follow the data: a damaged index (counts that disagree with the bits they summarise) can make a
+// kernel index a little past the end of the table it is walking -- at most one bucket's worth -- and must read
+// zeros there, not fault.  (Results for such an index are garbage either way, as they are in the reference.)
 template <class T>
-int upload(T** dst, const std::vector<T>& src, int64_t* bytes) {
+int upload(T** dst, const std::vector<T>& src, int64_t* bytes, size_t slack = 0) {
   size_t n = src.size() * sizeof(T);
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(dst), n ? n : 16));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(dst), n + slack ? n + slack : 16));
   if (n) HIP_TRY(hipMemcpy(*dst, src.data(), n, hipMemcpyHostToDevice));
+  if (slack) HIP_TRY(hipMemset(reinterpret_cast<char*>(*dst) + n, 0, slack));
   if (bytes) *bytes += int64_t(n);
   return 0;
 }
@@ -985,12 +989,14 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
       HostIndex& h = ix->host;
       int r;
       if (!split) {
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_image), h.image.size()));
+        const size_t image_slack = size_t(h.b_size) * size_t(h.text_size_bits) / 8 + 64;   // a mark array read one bucket too far
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_image), h.image.size() + image_slack));
         HIP_TRY(hipMemcpy(ix->d_image, h.image.data(), h.image.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(ix->d_image + h.image.size(), 0, image_slack));
         if ((r = upload(&ix->d_nodes, h.nodes, &ix->table_bytes))) return r;
         if ((r = upload(&ix->d_seqs, h.seqs, &ix->table_bytes))) return r;
         if ((r = upload(&ix->d_leaf_code, h.leaf_code, &ix->table_bytes))) return r;
-        if ((r = upload(&ix->d_segs, h.segs, &ix->table_bytes))) return r;
+        if ((r = upload(&ix->d_segs, h.segs, &ix->table_bytes, (size_t(h.b_size) / 511 + 4) * 128))) return r;
         if ((r = upload(&ix->d_cum, h.cum, &ix->table_bytes))) return r;
         if ((r = upload(&ix->d_hint, h.hint, &ix->table_bytes))) return r;
         if ((r = upload(&ix->d_lnodes, h.lnodes, &ix->table_bytes))) return r;
@@ -1023,11 +1029,11 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
         ix->peer_segs[size_t(part)] = ix->d_segs;
         ix->peer_image[size_t(part)] = ix->d_image;
       }
-      if ((r = upload(&ix->d_buckets, h.buckets, &ix->table_bytes))) return r;
-      if ((r = upload(&ix->d_occ_base, h.occ_base, &ix->table_bytes))) return r;
+      if ((r = upload(&ix->d_buckets, h.buckets, &ix->table_bytes, 4 * sizeof(DevBucket)))) return r;
+      if ((r = upload(&ix->d_occ_base, h.occ_base, &ix->table_bytes, 4 * kAlphaSize * 8))) return r;
       if ((r = upload(&ix->d_C, h.C, &ix->table_bytes))) return r;
-      if ((r = upload(&ix->d_bdir, h.bdir, &ix->table_bytes))) return r;
-      if ((r = upload(&ix->d_occ, h.occ, &ix->table_bytes))) return r;
+      if ((r = upload(&ix->d_bdir, h.bdir, &ix->table_bytes, (size_t(h.b_size) / 512 + 4) * sizeof(BlockDir)))) return r;
+      if ((r = upload(&ix->d_occ, h.occ, &ix->table_bytes, 4 * kAlphaSize * sizeof(OccEntry)))) return r;
       {  // dense sort digits: characters with C[ch+1] > C[ch] occur in the text
         std::vector<uint8_t> dense(512, 0);
         int sigma = 0;

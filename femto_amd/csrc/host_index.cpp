@@ -336,6 +336,13 @@ int HostIndex::load(const std::string& path, Error* e) {
   C[kAlphaSize] = total_length;  // get_C, src/main/index.c:1545
   doc_ends.resize(size_t(number_of_documents));
   for (int64_t d = 0; d < number_of_documents; d++) doc_ends[size_t(d)] = int64_t(be64(header.data() + de_off + 8 * size_t(d)));
+  // The kernels trust these tables for every row number they form (LF steps, range ends): reject a header whose
+  // cumulative counts are not monotone or leave [0, total_length] -- a damaged file must fail here, not fault a GPU.
+  for (int ch = 0; ch < kAlphaSize; ch++)
+    if (C[size_t(ch)] < 0 || C[size_t(ch)] > C[size_t(ch) + 1]) return fail(e, ERR_FORMAT, "header C table is not monotone");
+  for (int64_t d = 0; d < number_of_documents; d++)
+    if (doc_ends[size_t(d)] < 0 || doc_ends[size_t(d)] > total_length || (d && doc_ends[size_t(d)] < doc_ends[size_t(d) - 1]))
+      return fail(e, ERR_FORMAT, "header document ends are not monotone");
 
   total_buckets = (total_length + b_size - 1) / b_size;
   occ_base.assign(size_t(total_buckets) * kAlphaSize, 0);
@@ -536,6 +543,19 @@ int HostIndex::load(const std::string& path, Error* e) {
     }
   }
   if (gb != total_buckets) return fail(e, ERR_FORMAT, "bucket count mismatch");
+  // per bucket and character: C[ch] <= Occ base <= C[ch+1], non-decreasing from bucket to bucket, and the counts of a
+  // bucket add up to its rows (block_occs + bucket_occs, src/main/index.c:1538-1569, :1828-1843)
+  for (int64_t g = 0; g < total_buckets; g++) {
+    int64_t rows_here = 0;
+    for (int ch = 0; ch < kAlphaSize; ch++) {
+      const int64_t v = occ_base[size_t(g) * kAlphaSize + size_t(ch)];
+      const int64_t nx = g + 1 < total_buckets ? occ_base[size_t(g + 1) * kAlphaSize + size_t(ch)] : C[size_t(ch) + 1];
+      if (v < C[size_t(ch)] || v > nx || nx > C[size_t(ch) + 1]) return fail(e, ERR_FORMAT, "occurrence tables are not monotone");
+      rows_here += nx - v;
+    }
+    const int64_t expect = std::min<int64_t>(b_size, total_length - g * int64_t(b_size));
+    if (rows_here != expect) return fail(e, ERR_FORMAT, "occurrence tables do not add up to the bucket's rows");
+  }
   block_slot_start.push_back(segs.size() / kSegmentWords);
   block_lnode_start.push_back(lnodes.size());
   block_lseq_start.push_back(lseqs.size());
