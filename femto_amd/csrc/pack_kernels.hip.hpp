@@ -150,6 +150,8 @@ __global__ __launch_bounds__(256) void count_kernel_pack(const DevIndex ix, cons
     j = int(uint64_t(e.y) >> 48);   // fields consumed; a pattern that ends (or leaves the alphabet) there goes on below
     if (first > last) j = len;
   }
+  uint64_t word = 0;           // aligned 8-byte word of the pattern holding the symbol being read (4 symbols per load:
+  uintptr_t word_addr = 0;     // reads longer than a key -- 100-150 bp -- would otherwise cost a memory line per symbol)
   for (; j < len; j++) {  // j-th symbol from the end
     uint32_t code = 0;
     if (kKeys && j < nsym) code = uint32_t(key >> (64 - bits * (j + 1))) & ((1u << bits) - 1u);
@@ -158,7 +160,13 @@ __global__ __launch_bounds__(256) void count_kernel_pack(const DevIndex ix, cons
     } else {
       if (whole) break;  // pattern exhausted
       // not covered by the key, or a character outside the indexed alphabet: read it
-      const uint32_t ch = pat[len - 1 - j];
+      const uintptr_t sa = reinterpret_cast<uintptr_t>(pat + (len - 1 - j));
+      const uintptr_t wa = sa & ~uintptr_t(7);
+      if (wa != word_addr) {
+        word = *reinterpret_cast<const uint64_t*>(wa);
+        word_addr = wa;
+      }
+      const uint32_t ch = uint32_t(word >> (8 * (sa - wa))) & 0xffffu;
       if (ch >= uint32_t(kAlphaSize)) {
         atomicOr(err_flag, 1);
         first = 0;
