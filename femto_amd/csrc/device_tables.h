@@ -139,6 +139,11 @@ struct DevIndex {           // passed by value to kernels
   const uint16_t* p2_alpha; // [256] dense code -> alpha code
   int32_t p2_sigma;
   uint32_t p2_stop_below;   // dense codes below this are <= SEOF (a locate walk stops there)
+  // long-pattern tail (text_kernels.hip.hpp); null when not derived
+  const uint8_t* txt;       // dense character code of every text position
+  const int64_t* isa8;      // row of the suffix at every 8th text position
+  void* tail_items;         // TailItem work list of the current count launch
+  int* tail_count;
   int64_t total_length;
   int64_t total_buckets;
   int32_t b_size;

@@ -18,6 +18,7 @@
 #include "kernels.hip.hpp"
 #include "pack_kernels.hip.hpp"
 #include "pack2_kernels.hip.hpp"
+#include "text_kernels.hip.hpp"
 
 using namespace femto_amd;
 
@@ -120,6 +121,9 @@ struct femto_amd_index {
   uint8_t* d_pack_code = nullptr;
   int64_t* d_pack_c = nullptr;
   int64_t* d_ktab = nullptr;
+  uint8_t* d_txt = nullptr;
+  int64_t* d_isa8 = nullptr;
+  int64_t text_bytes = 0;
   uint32_t *d_p2_l1 = nullptr, *d_p2_l2 = nullptr;
   int64_t *d_p2_base = nullptr, *d_p2_c = nullptr;
   uint16_t *d_p2_code = nullptr, *d_p2_alpha = nullptr;
@@ -134,7 +138,7 @@ struct femto_amd_index {
   // scratch for the host-pointer API and the locate plan
   DeviceBuffer s_plen, s_pats, s_starts, s_first, s_last, s_noccs, s_noccs64, s_out_starts, s_offsets, s_scan[3];
   DeviceBuffer s_rows, s_ch, s_occ, s_off;
-  DeviceBuffer s_keys, s_keys2, s_idx, s_idx2, s_sorttmp, s_pairs;
+  DeviceBuffer s_keys, s_keys2, s_idx, s_idx2, s_sorttmp, s_pairs, s_tail;
   bool sort_queries = true;   // FEMTO_AMD_SORT=0 disables
   uint8_t* d_dense = nullptr;  // alpha code -> dense sort digit (characters present in the text)
   int dense_bits = 8;
@@ -220,7 +224,7 @@ int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen
   const int64_t threads = npats * lanes_per_query;
   const int64_t blocks = (threads + kBlockThreads - 1) / kBlockThreads;
   if (blocks > 0x7fffffffLL) return set_err(FEMTO_AMD_ERR_PARAM, "batch too large for one launch");
-  bool split_pairs = false;
+  bool split_pairs = false, tail_launch = false;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ix->timing) {  // events bracket the search kernel itself (the suffix-order sort is a separate, small launch)
     HIP_TRY(hipEventCreate(&e0));
@@ -260,6 +264,15 @@ int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen
       perm = ix->s_idx2.as<uint32_t>();
     }
     if (ix->timing) HIP_TRY(hipEventRecord(e0, stream));
+    bool tail = false;
+    if ((ix->mode == 3 || ix->mode == 4) && perm && ix->dev.txt) {   // long patterns may be handed to count_tail_kernel
+      int rc2 = ix->s_tail.reserve(size_t(npats) * sizeof(TailItem));
+      if (rc2) return rc2;
+      ix->dev.tail_items = ix->s_tail.p;
+      ix->dev.tail_count = ix->d_err + 2;
+      HIP_TRY(hipMemsetAsync(ix->dev.tail_count, 0, sizeof(int), stream));
+      tail = true;
+    }
     if (ix->mode == 3 && perm) {
       int rc2 = ix->s_pairs.reserve(size_t(npats) * 16);
       if (rc2) return rc2;
@@ -267,6 +280,7 @@ int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen
                          d_pats, d_starts, d_first, d_last, ix->d_err, perm, ix->s_keys2.as<uint64_t>(), ix->dense_bits,
                          63 / ix->dense_bits, ix->s_pairs.as<longlong2>());
       split_pairs = true;
+      tail_launch = tail;
     } else if (ix->mode == 4 && perm) {
       int rc2 = ix->s_pairs.reserve(size_t(npats) * 16);
       if (rc2) return rc2;
@@ -274,6 +288,7 @@ int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen
                          d_pats, d_starts, d_first, d_last, ix->d_err, perm, ix->s_keys2.as<uint64_t>(), ix->dense_bits,
                          63 / ix->dense_bits, ix->s_pairs.as<longlong2>());
       split_pairs = true;
+      tail_launch = tail;
     } else if (ix->mode == 4)
       hipLaunchKernelGGL(count_kernel_pack2<false>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
                          d_pats, d_starts, d_first, d_last, ix->d_err, perm, nullptr, 1, 0, nullptr);
@@ -286,6 +301,18 @@ int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen
   } else {
     hipLaunchKernelGGL((count_kernel<kGroupW>), dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats,
                        d_plen, d_pats, d_starts, d_first, d_last, ix->d_err);
+  }
+  if (tail_launch) {
+    if (ix->mode == 3)
+      hipLaunchKernelGGL(count_tail_kernel<PackPolicy>, dim3(uint32_t((npats + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, stream,
+                         ix->dev, static_cast<const TailItem*>(ix->s_tail.p), ix->dev.tail_count, d_plen, d_pats, d_starts,
+                         ix->s_idx2.as<uint32_t>(), ix->s_keys2.as<uint64_t>(), ix->dense_bits, 63 / ix->dense_bits, ix->s_pairs.as<longlong2>(),
+                         ix->d_err);
+    else
+      hipLaunchKernelGGL(count_tail_kernel<Pack2Policy>, dim3(uint32_t((npats + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, stream,
+                         ix->dev, static_cast<const TailItem*>(ix->s_tail.p), ix->dev.tail_count, d_plen, d_pats, d_starts,
+                         ix->s_idx2.as<uint32_t>(), ix->s_keys2.as<uint64_t>(), ix->dense_bits, 63 / ix->dense_bits, ix->s_pairs.as<longlong2>(),
+                         ix->d_err);
   }
   HIP_TRY(hipGetLastError());
   if (ix->timing) {
@@ -701,6 +728,36 @@ int build_pack2(femto_amd_index* ix) {
   return r;
 }
 
+// text + sampled inverse suffix array for the long-pattern tail (text_kernels.hip.hpp); optional (FEMTO_AMD_TEXT=0)
+int build_text(femto_amd_index* ix) {
+  if (const char* e = getenv("FEMTO_AMD_TEXT")) if (atoi(e) == 0) return 0;
+  const int64_t n = ix->host.total_length;
+  const size_t tb = size_t(n) + 64, ib = (size_t(n >> kIsaShift) + 2) * 8;
+  if (hipMalloc(reinterpret_cast<void**>(&ix->d_txt), tb) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&ix->d_isa8), ib) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(ix->d_txt); ix->d_txt = nullptr;
+    (void)hipFree(ix->d_isa8); ix->d_isa8 = nullptr;
+    return FEMTO_AMD_ERR_MEM;
+  }
+  HIP_TRY(hipMemset(ix->d_txt, 0xff, tb));
+  HIP_TRY(hipMemset(ix->d_isa8, 0, ib));
+  const int64_t chunk = int64_t(1) << 30;
+  for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+    const int64_t cn = std::min(chunk, n - r0);
+    if (ix->dev.pack)
+      hipLaunchKernelGGL(text_isa_build_kernel<PackPolicy>, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, r0, cn, ix->d_txt, ix->d_isa8);
+    else
+      hipLaunchKernelGGL(text_isa_build_kernel<Pack2Policy>, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, r0, cn, ix->d_txt, ix->d_isa8);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  ix->dev.txt = ix->d_txt;
+  ix->dev.isa8 = ix->d_isa8;
+  ix->text_bytes = int64_t(tb + ib);
+  ix->table_bytes += ix->text_bytes;
+  return 0;
+}
+
 // ---- host-pointer batches, pipelined ----------------------------------------------------------------------------
 constexpr int64_t kPipeChunk = int64_t(1) << 21;      // patterns per chunk
 constexpr int64_t kPipeSymCap = int64_t(1) << 26;     // symbols per chunk (128 MB)
@@ -1097,13 +1154,16 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
       r = build_pack2(ix);
       if (r == FEMTO_AMD_ERR_MEM) {
         (void)hipGetLastError();
-        (void)hipFree(ix->d_p2_l1); ix->d_p2_l1 = nullptr;
+        (void)hipFree(ix->d_txt);
+    (void)hipFree(ix->d_isa8);
+    (void)hipFree(ix->d_p2_l1); ix->d_p2_l1 = nullptr;
         (void)hipFree(ix->d_p2_l2); ix->d_p2_l2 = nullptr;
         ix->dev.p2_l1 = nullptr;
         ix->dev.p2_l2 = nullptr;
         r = 0;
       }
       if (r) return r;
+      if ((ix->dev.pack || ix->dev.p2_l1) && (r = build_text(ix)) && r != FEMTO_AMD_ERR_MEM) return r;
       if (ix->dev.pack) ix->mode = 3;
       else if (ix->dev.p2_l1) ix->mode = 4;
       if (const char* m = getenv("FEMTO_AMD_RANK_MODE")) {
@@ -1279,6 +1339,8 @@ void femto_amd_close(femto_amd_index_t* ix) {
     (void)hipFree(ix->d_pack_code);
     (void)hipFree(ix->d_pack_c);
     (void)hipFree(ix->d_ktab);
+    (void)hipFree(ix->d_txt);
+    (void)hipFree(ix->d_isa8);
     (void)hipFree(ix->d_p2_l1);
     (void)hipFree(ix->d_p2_l2);
     (void)hipFree(ix->d_p2_base);
@@ -1288,7 +1350,7 @@ void femto_amd_close(femto_amd_index_t* ix) {
     for (DeviceBuffer* b : {&ix->s_plen, &ix->s_pats, &ix->s_starts, &ix->s_first, &ix->s_last, &ix->s_noccs,
                             &ix->s_noccs64, &ix->s_out_starts, &ix->s_offsets, &ix->s_scan[0], &ix->s_scan[1],
                             &ix->s_scan[2], &ix->s_rows, &ix->s_ch, &ix->s_occ, &ix->s_off, &ix->s_keys, &ix->s_keys2, &ix->s_idx,
-                            &ix->s_idx2, &ix->s_sorttmp, &ix->s_pairs})
+                            &ix->s_idx2, &ix->s_sorttmp, &ix->s_pairs, &ix->s_tail})
       b->release();
   }
   delete ix;

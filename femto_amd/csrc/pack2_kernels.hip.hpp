@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void ktab_build_kernel2(const DevIndex ix, con
 // do_string_query (src/main/server.c:713-946), one lane per pattern; see count_kernel_pack for the key / table /
 // pair-store conventions.  Symbols the key does not hold are read from the pattern four at a time (aligned words).
 template <bool kKeys>
-__global__ __launch_bounds__(256) void count_kernel_pack2(const DevIndex ix, const int64_t npats, const int32_t* __restrict__ plen,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void count_kernel_pack2(const DevIndex ix, const int64_t npats, const int32_t* __restrict__ plen,
                                                           const uint16_t* __restrict__ pats, const int64_t* __restrict__ starts,
                                                           int64_t* __restrict__ first_out, int64_t* __restrict__ last_out,
                                                           int* __restrict__ err_flag, const uint32_t* __restrict__ perm,
@@ -200,6 +200,10 @@ __global__ __launch_bounds__(256) void count_kernel_pack2(const DevIndex ix, con
   uint64_t word = 0;           // the aligned 8-byte word of the pattern that holds symbol index `word_at`..+3
   uintptr_t word_addr = 0;
   for (; j < len; j++) {
+    if (kKeys && !whole && ix.txt && first == last && j > 0 && len - j >= kTailMinSymbols) {
+      tail_append(ix, slot, j, first);   // one row left, a long tail to go: compare it with the text instead
+      return;
+    }
     uint32_t code = 0;
     if (kKeys && j < nsym) code = uint32_t(key >> (64 - bits * (j + 1))) & ((1u << bits) - 1u);
     if (code != 0) {

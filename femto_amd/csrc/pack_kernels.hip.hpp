@@ -120,6 +120,21 @@ __global__ __launch_bounds__(256) void ktab_build_kernel(const DevIndex ix, cons
   tab[f] = make_longlong2(first, int64_t(uint64_t(last + 1) | (uint64_t(j) << 48)));
 }
 
+// hand a pattern whose range is down to one row, with many symbols to go, over to count_tail_kernel
+// (text_kernels.hip.hpp): one atomic per wavefront, entries {slot, symbols done, row}
+__device__ __forceinline__ void tail_append(const DevIndex& ix, int64_t slot, int done, int64_t row) {
+  const unsigned long long m = __ballot(1);
+  const int lane = int(threadIdx.x & 63u);
+  const int leader = __ffsll((long long)m) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(ix.tail_count, __popcll(m));
+  base = __shfl(base, leader, 64);
+  const int at = base + __popcll(m & ((1ull << lane) - 1ull));
+  int4* dst = reinterpret_cast<int4*>(ix.tail_items) + at;
+  *dst = make_int4(int(uint32_t(slot)), done, int(uint32_t(uint64_t(row))), int(uint32_t(uint64_t(row) >> 32)));
+}
+constexpr int kTailMinSymbols = 16;   // == kTailMin
+
 // do_string_query (src/main/server.c:713-946): one lane per pattern, one line per Occ.
 // kKeys: the batch was suffix-sorted (query_sort.hip) and keys[slot] holds the dense codes (1 + pack code, 0 = none)
 // of the pattern's last `nsym` symbols, last symbol in the top field, and in bit 0 "the key is the whole pattern".
@@ -127,7 +142,7 @@ __global__ __launch_bounds__(256) void ktab_build_kernel(const DevIndex ix, cons
 // scattered over the batch (a 128-byte memory line per symbol once the batch is processed out of order); plen /
 // starts / the pattern are only touched for patterns the key does not describe completely.
 template <bool kKeys>
-__global__ __launch_bounds__(256) void count_kernel_pack(const DevIndex ix, const int64_t npats, const int32_t* __restrict__ plen,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void count_kernel_pack(const DevIndex ix, const int64_t npats, const int32_t* __restrict__ plen,
                                                          const uint16_t* __restrict__ pats, const int64_t* __restrict__ starts,
                                                          int64_t* __restrict__ first_out, int64_t* __restrict__ last_out,
                                                          int* __restrict__ err_flag, const uint32_t* __restrict__ perm,
@@ -153,6 +168,10 @@ __global__ __launch_bounds__(256) void count_kernel_pack(const DevIndex ix, cons
   uint64_t word = 0;           // aligned 8-byte word of the pattern holding the symbol being read (4 symbols per load:
   uintptr_t word_addr = 0;     // reads longer than a key -- 100-150 bp -- would otherwise cost a memory line per symbol)
   for (; j < len; j++) {  // j-th symbol from the end
+    if (kKeys && !whole && ix.txt && first == last && j > 0 && len - j >= kTailMinSymbols) {
+      tail_append(ix, slot, j, first);   // one row left, a long tail to go: compare it with the text instead
+      return;
+    }
     uint32_t code = 0;
     if (kKeys && j < nsym) code = uint32_t(key >> (64 - bits * (j + 1))) & ((1u << bits) - 1u);
     if (code != 0) {

@@ -1,0 +1,230 @@
+// text_kernels.hip.hpp -- long patterns: once the range of a backward search is a SINGLE row, the rest of the
+// pattern is compared against the text itself instead of being searched symbol by symbol.
+//
+// A search step costs one (mode 3) or two (mode 4) scattered memory lines.  A 100-symbol read, or a 40-symbol phrase,
+// is down to one row after ~16 / ~8 symbols; every further step can only keep that row or empty the range.  With the
+// text (dense codes, one byte per position, rebuilt at open from the index by locating every row:
+// txt[SA[row]-1] = L[row]) and a sampled inverse suffix array (isa8[i] = row of the suffix at position 8i) the tail is
+//   1. p = SA[row]                                   (LF walk to the next derived mark: <= 4 steps)
+//   2. compare the remaining symbols with txt[p-1], txt[p-2], ...      (one or two lines)
+//   3. the row of the last matching position from isa8 + <= 7 LF steps; if a symbol mismatched, ONE ordinary search
+//      step with that symbol yields exactly the (first, last) the symbol-by-symbol search dies with.
+// The count kernels only hand such patterns over (slot, row, symbols done) to count_tail_kernel; patterns that meet a
+// document boundary, a character <= SEOF, or the last few text positions simply continue symbol by symbol there.
+#pragma once
+
+namespace femto_amd {
+
+constexpr int kTailMin = 16;          // hand over when at least this many symbols remain
+constexpr int kIsaShift = 3;          // isa8: every 8th text position
+
+struct TailItem {
+  uint32_t slot;      // position in the sorted batch
+  int32_t done;       // symbols already searched (j)
+  int64_t row;        // first == last
+};
+
+struct PackPolicy {
+  static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
+    pack_search_step(ix, ix.pack, j, code, f, l);
+  }
+  // one LF step from `row`: its character, mark state and the row of the preceding position
+  static __device__ __forceinline__ void lf(const DevIndex& ix, int64_t row, uint32_t& code, bool& marked, int64_t& sa_index, int64_t& next) {
+    uint64_t line;
+    uint32_t r;
+    pack_split(row, &line, &r);
+    PackLine L;
+    pack_load_line(ix.pack, line, L);
+    const PackStep s = pack_step(L, r);
+    code = s.code;
+    marked = s.marked;
+    sa_index = s.sa_index;
+    next = s.c_plus_occ - 1;
+  }
+  static __device__ __forceinline__ bool is_stop(const DevIndex& ix, uint32_t code) { return (ix.pack_stop >> code) & 1u; }
+  static __device__ __forceinline__ uint32_t code_of(const DevIndex& ix, uint32_t ch) {
+    const uint32_t c = ix.pack_code[ch];
+    return c > 7u ? 0xffffu : c;
+  }
+};
+
+struct Pack2Policy {
+  static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
+    p2_search_step(ix, j, code, f, l);
+  }
+  static __device__ __forceinline__ void lf(const DevIndex& ix, int64_t row, uint32_t& code, bool& marked, int64_t& sa_index, int64_t& next) {
+    const P2Step s = p2_step(ix, row);
+    code = s.code;
+    marked = s.marked;
+    sa_index = s.sa_index;
+    next = s.c_plus_occ - 1;
+  }
+  static __device__ __forceinline__ bool is_stop(const DevIndex& ix, uint32_t code) { return code < ix.p2_stop_below; }
+  static __device__ __forceinline__ uint32_t code_of(const DevIndex& ix, uint32_t ch) {
+    const uint32_t c = ix.p2_code[ch];
+    return c > 255u ? 0xffffu : c;
+  }
+};
+
+// SA[row] by the locate walk; false when the walk cannot finish (never for a well-formed index)
+template <class P>
+__device__ __forceinline__ bool tail_locate(const DevIndex& ix, int64_t row, int64_t* pos, uint32_t* first_code) {
+  int64_t steps = 0;
+  for (;;) {
+    uint32_t code;
+    bool marked;
+    int64_t sa_index, next;
+    P::lf(ix, row, code, marked, sa_index, next);
+    if (steps == 0 && first_code) *first_code = code;
+    if (marked) {
+      *pos = ix.pack_sa[sa_index] + steps;
+      return true;
+    }
+    if (P::is_stop(ix, code) || steps > int64_t(ix.walk_limit)) return false;
+    row = next;
+    steps++;
+  }
+}
+
+// build: txt[SA[row] - 1] = L[row] (position -1 wraps to the last one), isa8[SA[row] / 8] = row for SA[row] % 8 == 0
+template <class P>
+__global__ __launch_bounds__(256) void text_isa_build_kernel(const DevIndex ix, const int64_t row0, const int64_t n, uint8_t* __restrict__ txt,
+                                                             int64_t* __restrict__ isa8) {
+  const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (row >= row0 + n) return;
+  int64_t pos;
+  uint32_t code = 0;
+  if (!tail_locate<P>(ix, row, &pos, &code)) return;
+  txt[pos == 0 ? ix.total_length - 1 : pos - 1] = uint8_t(code);
+  if ((pos & ((int64_t(1) << kIsaShift) - 1)) == 0) isa8[pos >> kIsaShift] = row;
+}
+
+// row of the suffix starting at text position x (sampled ISA + LF walk); false near the text end or a document end
+template <class P>
+__device__ __forceinline__ bool tail_row_of(const DevIndex& ix, int64_t x, int64_t* row_out) {
+  const int64_t K = int64_t(1) << kIsaShift;
+  const int64_t s = (x + K - 1) & ~(K - 1);
+  if (s >= ix.total_length) return false;
+  int64_t row = ix.isa8[s >> kIsaShift];
+  for (int64_t k = s; k > x; k--) {
+    uint32_t code;
+    bool marked;
+    int64_t sa_index, next;
+    P::lf(ix, row, code, marked, sa_index, next);
+    if (P::is_stop(ix, code)) return false;
+    row = next;
+  }
+  *row_out = row;
+  return true;
+}
+
+// One pattern symbol, (j)-th from the end: from the sort key when it holds it, else from the pattern (four symbols per
+// aligned load).  Returns 0: `code` valid; 1: pattern exhausted (key says so); 2: symbol >= 261; 3: character not in the
+// text (`ch` set).
+struct SymbolReader {
+  uint64_t key;
+  bool whole;
+  int bits, nsym, len;
+  const uint16_t* pat;
+  uint64_t word;
+  uintptr_t word_addr;
+};
+
+template <class P>
+__device__ __forceinline__ int tail_symbol(const DevIndex& ix, SymbolReader& R, int j, uint32_t* code, uint32_t* ch_out) {
+  uint32_t c = 0;
+  if (j < R.nsym) c = uint32_t(R.key >> (64 - R.bits * (j + 1))) & ((1u << R.bits) - 1u);
+  if (c != 0) {
+    *code = c - 1;
+    return 0;
+  }
+  if (R.whole) return 1;
+  const uintptr_t sa = reinterpret_cast<uintptr_t>(R.pat + (R.len - 1 - j));
+  const uintptr_t wa = sa & ~uintptr_t(7);
+  if (wa != R.word_addr) {
+    R.word = *reinterpret_cast<const uint64_t*>(wa);
+    R.word_addr = wa;
+  }
+  const uint32_t ch = uint32_t(R.word >> (8 * (sa - wa))) & 0xffffu;
+  *ch_out = ch;
+  if (ch >= uint32_t(kAlphaSize)) return 2;
+  const uint32_t cc = P::code_of(ix, ch);
+  if (cc == 0xffffu) return 3;
+  *code = cc;
+  return 0;
+}
+
+template <class P>
+__global__ __launch_bounds__(256) void count_tail_kernel(const DevIndex ix, const TailItem* __restrict__ items, const int* __restrict__ n_items,
+                                                         const int32_t* __restrict__ plen, const uint16_t* __restrict__ pats,
+                                                         const int64_t* __restrict__ starts, const uint32_t* __restrict__ perm,
+                                                         const uint64_t* __restrict__ keys, const int bits, const int nsym,
+                                                         longlong2* __restrict__ pair_out, int* __restrict__ err_flag) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= int64_t(*n_items)) return;
+  const TailItem it = items[t];
+  const int64_t q = int64_t(perm[it.slot]);
+  SymbolReader R;
+  R.key = keys[it.slot];
+  R.whole = false;
+  R.bits = bits;
+  R.nsym = nsym;
+  R.len = plen[q];
+  R.pat = pats + starts[q];
+  R.word = 0;
+  R.word_addr = 0;
+  const int len = R.len;
+  int j = it.done;
+  int64_t first = it.row, last = it.row;
+
+  // ---- the shortcut: position of the row, compare against the text, row of the last matching position
+  int64_t p;
+  if (tail_locate<P>(ix, first, &p, nullptr) && p >= int64_t(len - j)) {
+    const int remaining = len - j;
+    int m = 0;                       // symbols matched
+    uint64_t tw = 0;                 // aligned 8-byte word of txt holding the byte being compared
+    uintptr_t tw_addr = 0;
+    for (; m < remaining; m++) {
+      uint32_t code = 0, ch = 0;
+      if (tail_symbol<P>(ix, R, j + m, &code, &ch) != 0) break;   // leave anything unusual to the ordinary step below
+      if (P::is_stop(ix, code)) break;
+      const uintptr_t ta = reinterpret_cast<uintptr_t>(ix.txt + (p - 1 - m));
+      const uintptr_t wa = ta & ~uintptr_t(7);
+      if (wa != tw_addr) {
+        tw = *reinterpret_cast<const uint64_t*>(wa);
+        tw_addr = wa;
+      }
+      const uint32_t tc = uint32_t(tw >> (8 * (ta - wa))) & 0xffu;
+      if (tc != code) break;
+    }
+    if (m > 0) {
+      int64_t row;
+      if (tail_row_of<P>(ix, p - m, &row)) {
+        first = last = row;
+        j += m;
+      }
+    }
+  }
+  // ---- whatever is left (the mismatching symbol, or everything when the shortcut did not apply): ordinary steps
+  for (; j < len; j++) {
+    uint32_t code = 0, ch = 0;
+    const int st = tail_symbol<P>(ix, R, j, &code, &ch);
+    if (st == 1) break;
+    if (st == 2) {
+      atomicOr(err_flag, 1);
+      first = 0;
+      last = -1;
+      break;
+    }
+    if (st == 3) {  // the character does not occur in the text: Occ == 0 (index.c:2080-2089)
+      first = ix.C[ch];
+      last = first - 1;
+      break;
+    }
+    P::search_step(ix, j, code, first, last);
+    if (first > last) break;
+  }
+  pair_out[q] = make_longlong2(first, last);
+}
+
+}  // namespace femto_amd

@@ -306,6 +306,56 @@ def test_batch_above_a_million_patterns(tmp_path, gpu_ok, mode):
     assert np.array_equal(first3, of) and np.array_equal(last3, ol)
 
 
+@pytest.mark.parametrize("sigma", [4, 60])
+@pytest.mark.parametrize("mode", [3, 4, 1])
+def test_long_patterns_text_tail(tmp_path, gpu_ok, mode, sigma):
+    """Patterns much longer than a sort key, on a three-document text: once their range is one row the packed modes
+    compare the tail with the text (text_kernels.hip.hpp).  Exact reads, reads with one substituted / inserted symbol
+    (the search must die with the reference's values at the reference's step), reads running over a document boundary
+    (they contain SEOF), reads from the first positions of the text, random long strings -- all against the oracle."""
+    rng = np.random.Generator(np.random.PCG64(900 + sigma))
+    alphabet = (np.frombuffer(b"ACGT", dtype=np.uint8) if sigma == 4 else rng.choice(np.arange(32, 127), sigma, replace=False).astype(np.uint8))
+    n = 1_500_000
+    text = alphabet[rng.integers(0, len(alphabet), n)]
+    text[700_000:700_300] = text[100_000:100_300]                    # a repeat: long patterns with two occurrences
+    cuts = [400_000, 1_000_000]
+    docs = np.split(text, cuts)
+    path = str(tmp_path / "longp")
+    femto_amd.build_index(path, docs, params="block_size=262144,bucket_size=65536,mark_period=20", infos=["a", "b", "c"], device=0)
+    prepared = np.concatenate([np.concatenate([d.astype(np.uint16) + 5, [2]]) for d in docs])
+    if mode == 3 and sigma != 4:
+        pytest.skip("packed lines need <= 8 characters")
+    ix = _open(path, mode)
+    o = po.Oracle(path)
+    pats = []
+    N = len(prepared)
+    for _ in range(3000):
+        ln = int(rng.integers(17, 160))
+        s0 = int(rng.integers(0, N - ln))
+        p_ = prepared[s0:s0 + ln].copy()                              # may run over a document boundary (contains SEOF)
+        kind = rng.integers(0, 5)
+        if kind == 1:
+            p_[int(rng.integers(0, ln))] = alphabet[int(rng.integers(0, len(alphabet)))] + 5    # substitution anywhere
+        elif kind == 2:
+            p_ = np.insert(p_, int(rng.integers(0, ln)), alphabet[int(rng.integers(0, len(alphabet)))] + 5)
+        elif kind == 3:
+            p_ = prepared[:ln].copy() if rng.random() < 0.5 else prepared[int(rng.integers(0, 40)):][:ln].copy()   # text start
+        elif kind == 4:
+            p_[int(rng.integers(0, ln))] = int(rng.choice([2, 3, 200, 260]))                       # SEOF / absent characters
+        pats.append(p_.astype(np.uint16))
+    pats.append(prepared[100_000:100_300].astype(np.uint16))          # the repeat: two rows all the way
+    pats += [pats[i % 3000] for i in range(3001)]                     # 6 002 patterns: above the sort threshold
+    plen, flat, starts = femto_amd.flatten(pats)
+    first, last = ix.count_flat(plen, flat, starts)
+    of, ol = o.count_flat(plen, flat, starts, threads=16)
+    assert np.array_equal(first, of) and np.array_equal(last, ol)
+    assert (ol[:3000] >= of[:3000]).sum() > 500 and (ol[:3000] < of[:3000]).sum() > 500      # both outcomes well represented
+    noccs, offs = ix.locate_flat(plen, flat, starts, 4)
+    on, oo = o.locate_flat(plen, flat, starts, 4, threads=16)
+    assert np.array_equal(noccs, on) and np.array_equal(offs, oo)
+    assert on[3000] == 2
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_gpu_built_english_like_vs_oracle(tmp_path, gpu_ok, mode):
     """sigma ~ 96 text (RLE-heavy wavelet nodes, deep Huffman codes), mixed-length patterns 8..64
