@@ -42,7 +42,7 @@ def one(seed, root):
     ix = femto_amd.Index(path, device=0)
     pats = []
     for _ in range(20000):
-        ln = int(rng.integers(0, 40))
+        ln = int(rng.integers(0, 40)) if rng.random() < 0.6 else int(rng.integers(40, 200))
         if rng.random() < 0.7 and len(text) > ln:
             s0 = int(rng.integers(0, len(text) - ln + 1))
             pats.append(tg.to_alpha(text[s0:s0 + ln]))
