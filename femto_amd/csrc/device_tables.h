@@ -144,6 +144,7 @@ struct DevIndex {           // passed by value to kernels
   const int64_t* isa8;      // row of the suffix at every 8th text position
   void* tail_items;         // TailItem work list of the current count launch
   int* tail_count;
+  int32_t tail_min;         // hand a one-row range over when at least this many symbols remain
   int64_t total_length;
   int64_t total_buckets;
   int32_t b_size;

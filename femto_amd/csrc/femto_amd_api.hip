@@ -269,6 +269,8 @@ int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen
       int rc2 = ix->s_tail.reserve(size_t(npats) * sizeof(TailItem));
       if (rc2) return rc2;
       ix->dev.tail_items = ix->s_tail.p;
+      ix->dev.tail_min = ix->mode == 3 ? 12 : 10;   // about where the walk + compare + ISA lookup beats stepping (1 / 2 lines a step)
+      if (const char* tm = getenv("FEMTO_AMD_TAIL_MIN")) ix->dev.tail_min = std::max(2, atoi(tm));
       ix->dev.tail_count = ix->d_err + 2;
       HIP_TRY(hipMemsetAsync(ix->dev.tail_count, 0, sizeof(int), stream));
       tail = true;

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   uint64_t word = 0;           // the aligned 8-byte word of the pattern that holds symbol index `word_at`..+3
   uintptr_t word_addr = 0;
   for (; j < len; j++) {
-    if (kKeys && !whole && ix.txt && first == last && j > 0 && len - j >= kTailMinSymbols) {
+    if (kKeys && !whole && ix.txt && first == last && j > 0 && len - j >= ix.tail_min) {
       tail_append(ix, slot, j, first);   // one row left, a long tail to go: compare it with the text instead
       return;
     }

@@ -133,7 +133,6 @@ __device__ __forceinline__ void tail_append(const DevIndex& ix, int64_t slot, in
   int4* dst = reinterpret_cast<int4*>(ix.tail_items) + at;
   *dst = make_int4(int(uint32_t(slot)), done, int(uint32_t(uint64_t(row))), int(uint32_t(uint64_t(row) >> 32)));
 }
-constexpr int kTailMinSymbols = 16;   // == kTailMin
 
 // do_string_query (src/main/server.c:713-946): one lane per pattern, one line per Occ.
 // kKeys: the batch was suffix-sorted (query_sort.hip) and keys[slot] holds the dense codes (1 + pack code, 0 = none)
@@ -168,7 +167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   uint64_t word = 0;           // aligned 8-byte word of the pattern holding the symbol being read (4 symbols per load:
   uintptr_t word_addr = 0;     // reads longer than a key -- 100-150 bp -- would otherwise cost a memory line per symbol)
   for (; j < len; j++) {  // j-th symbol from the end
-    if (kKeys && !whole && ix.txt && first == last && j > 0 && len - j >= kTailMinSymbols) {
+    if (kKeys && !whole && ix.txt && first == last && j > 0 && len - j >= ix.tail_min) {
       tail_append(ix, slot, j, first);   // one row left, a long tail to go: compare it with the text instead
       return;
     }

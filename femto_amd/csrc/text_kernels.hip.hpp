@@ -15,7 +15,6 @@
 
 namespace femto_amd {
 
-constexpr int kTailMin = 16;          // hand over when at least this many symbols remain
 constexpr int kIsaShift = 3;          // isa8: every 8th text position
 
 struct TailItem {
