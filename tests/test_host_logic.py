@@ -165,3 +165,41 @@ def test_document_info_matches_what_the_reference_stored(fixtures):
         with pytest.raises(femto_amd.FemtoAmdError):
             ix.document_info(len(fx.docs))
         ix.close()
+
+
+def test_damaged_tables_are_rejected_at_load(fixtures, tmp_path):
+    """The kernels trust the header's cumulative tables for every row number they form: a header whose C table is not
+    monotone, whose occurrence tables do not add up to the bucket sizes, or whose document ends run backwards must
+    fail with ERR_FORMAT at open (tools/fuzz_gpu.py exercises the same on the GPU box)."""
+    import shutil
+    import struct
+    fx = fixtures("eng2doc")
+    src = fx.index
+
+    def damaged(name, edit):
+        dst = str(tmp_path / name)
+        shutil.copytree(src, dst)
+        data = bytearray(open(os.path.join(dst, "00"), "rb").read())
+        edit(data)
+        open(os.path.join(dst, "00"), "wb").write(data)
+        return dst
+
+    c_off = 88                                            # C[261] follows the 88-byte block header (index.c:870-898)
+
+    def swap_c(d):                                        # two adjacent non-zero-width entries swapped -> not monotone
+        vals = list(struct.unpack(">261q", d[c_off:c_off + 261 * 8]))
+        k = next(i for i in range(10, 259) if vals[i] < vals[i + 1] < vals[i + 2])
+        vals[k + 1], vals[k + 2] = vals[k + 2], vals[k + 1]
+        d[c_off:c_off + 261 * 8] = struct.pack(">261q", *vals)
+
+    def bump_block_occs(d):                               # one block_occs entry + 1: buckets no longer add up
+        nb = femto_amd.Index(src, device=-1).info.number_of_blocks
+        off = c_off + 261 * 8 + 8 * (ord("e") + 5) * nb + 8 * (nb - 1)
+        v = struct.unpack(">q", d[off:off + 8])[0]
+        d[off:off + 8] = struct.pack(">q", v + 1)
+
+    for name, edit in (("c_swapped", swap_c), ("occs_bumped", bump_block_occs)):
+        with pytest.raises(femto_amd.FemtoAmdError) as ei:
+            femto_amd.Index(damaged(name, edit), device=-1)
+        assert ei.value.code == 4, name                   # ERR_FORMAT
+    femto_amd.Index(src, device=-1).close()               # the undamaged copy still opens
