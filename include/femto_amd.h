@@ -180,12 +180,13 @@ int femto_amd_split_commit(femto_amd_index_t* ix);
 int femto_amd_split_info(const femto_amd_index_t* ix, int* part, int* nparts, int64_t* seg_bytes, int64_t* image_bytes);
 
 /* ---- kernel family ---------------------------------------------------------------------------- */
-/* mode 1 (default): one LANE per query; a rank reads one cumulative-count entry and one 64-byte
- * aligned segment slot from tables derived at load time (RLE segments also a 64-byte skip table).
+/* Five kernel families, all bit-exact; the default at open is the fastest that applies (mode 3 for <= 8 distinct
+ * characters, mode 4 for <= 256, else mode 1); FEMTO_AMD_RANK_MODE=pack|pack2|lane|flat|raw overrides it.
+ * mode 1: one LANE per query on femto's own wavelet tree; a rank reads one 128-byte line per segment (segment + the
+ * counts before it) from tables derived at load time (RLE segments also a 64-byte skip table).
  * mode 2: the same per-lane rank inside one flat loop on a persistent grid (one wavelet level per
  * iteration, lanes refill with the next query).  mode 0: one WAVEFRONT per query walking femto's own
- * A0/A1/AP group tables and varbyte S sums with __ballot/ds_bpermute (no derived rank tables).  All
- * are bit-exact; FEMTO_AMD_RANK_MODE=lane|flat|raw selects the default at open. */
+ * A0/A1/AP group tables and varbyte S sums with __ballot/ds_bpermute (no derived rank tables). */
 int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode);
 /* mode 3 ("pack", the default when it applies): for indexes with at most 8 distinct characters (DNA) the
  * loader derives, on the GPU, one self-contained 128-byte line per 160 rows -- three bit planes of the dense
@@ -198,7 +199,10 @@ int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode);
 /* mode 4 ("pack2", the default for 9..256 distinct characters): the same idea for byte alphabets -- a two-level
  * 16-ary decomposition of the dense character code, one 128-byte line per level (femto_amd/csrc/pack2_kernels.hip.hpp):
  * an Occ or a locate step reads TWO lines and decodes no Elias-gamma runs.  FEMTO_AMD_PACK2=0 skips it, =1 also builds
- * it for small alphabets.  *available: bit 0 = mode 3 lines exist, bit 1 = mode 4 lines exist. */
+ * it for small alphabets.  *available: bit 0 = mode 3 lines exist, bit 1 = mode 4 lines exist.
+ * Both modes also derive: marks every FEMTO_AMD_MARK_EVERY-th text position (default 5; a locate walk then ends within
+ * 4 steps -- leaf requests still answer from femto's own marks), and the text + a sampled inverse suffix array
+ * (FEMTO_AMD_TEXT=0 skips them) against which the tail of a long pattern is compared once its range is one row. */
 int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* bytes, double* build_ms, int* ktab_syms);
 int femto_amd_get_rank_mode(const femto_amd_index_t* ix);
 
