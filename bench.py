@@ -421,7 +421,9 @@ def main():
                                 "(key, order, table entry, results), + 8 B per located row" if packed else
                                 "wavelet path: N_rank*(12+64+S) + N_occ*20 + N_mark*8 (SURVEY 8d)"),
                 "note": "the batch is processed in suffix order, so neighbouring lanes share cache lines and part of the "
-                        "algorithmic bytes never leaves L1/L2 (traffic < algorithmic bytes; frac may exceed 1)"}
+                        "algorithmic bytes never leaves L1/L2 (traffic < algorithmic bytes; frac may exceed 1)"
+                        + ("; patterns longer than a sort key finish by a text comparison once their range is one row, so for "
+                           "this workload the per-step byte model overstates what the count kernel reads" if (packed and args.plen > 21 or eng) else "")}
 
     wl = {"acgt": f"T_acgt(2^{args.text_log2}) femto index (default params), {npats} P_rand 20-mers per GPU, count()+locate(max_occs={args.max_occs})",
           "acgt_hit": f"T_acgt(2^{args.text_log2}) femto index (default params), {npats} P_hit 20-mers per GPU, count()+locate(max_occs={args.max_occs})",
