@@ -203,3 +203,47 @@ def test_damaged_tables_are_rejected_at_load(fixtures, tmp_path):
             femto_amd.Index(damaged(name, edit), device=-1)
         assert ei.value.code == 4, name                   # ERR_FORMAT
     femto_amd.Index(src, device=-1).close()               # the undamaged copy still opens
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/femto_amd.h is the drop-in boundary for a C code base (femto is C99): it must compile with a C compiler,
+    pedantically, and a C program must link against the library and get a clean error without a GPU."""
+    import subprocess
+    from femto_amd import build as b
+    src = tmp_path / "shim.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "femto_amd.h"
+int main(int argc, char** argv) {
+  femto_amd_index_t* ix = NULL;
+  int rc = femto_amd_open(argc > 1 ? argv[1] : "/nonexistent", -1, &ix);
+  printf("rc=%d msg=%s\n", rc, femto_amd_last_error());
+  if (rc == 0) {
+    femto_amd_info_t info;
+    if (femto_amd_info(ix, &info)) return 3;
+    printf("rows=%lld docs=%lld\n", (long long) info.total_length, (long long) info.number_of_documents);
+    {
+      int64_t first = 0, last = 0;
+      int plen = 1;
+      const uint16_t sym = 70, *pat = &sym;
+      rc = femto_amd_parallel_count(ix, 1, &plen, &pat, &first, &last);   /* parse-only handle: must refuse, not compute */
+      printf("count rc=%d\n", rc);
+    }
+    femto_amd_close(ix);
+  }
+  return 0;
+}
+''')
+    exe = tmp_path / "shim"
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.dirname(b.LIB)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, "-o", str(exe), str(src),
+                    "-L", libdir, "-lfemto_amd", "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    assert "rc=2" in out                                       # ERR_IO for a missing path, femto's code
+    fx_index = os.path.join(str(tmp_path), "ix")
+    import tarfile
+    with tarfile.open(os.path.join(GOLDEN, "eng2doc.tar.gz")) as tf:
+        tf.extractall(fx_index)
+    out = subprocess.run([str(exe), os.path.join(fx_index, "index")], capture_output=True, text=True, check=True).stdout
+    assert "rc=0" in out and "docs=2" in out and "count rc=6" in out     # ERR_INVALID: no device behind this handle
