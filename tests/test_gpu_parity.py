@@ -27,6 +27,25 @@ def gpu_ok():
 MODES = [3, 4, 1, 2, 0]
 
 
+def _torchrun(nproc, script_and_args, env, cwd=None, attempts=2):
+    """python -m torch.distributed.run on 127.0.0.1 with a free port; one retry (a port can be taken between probing and use)"""
+    import socket
+    import subprocess
+    import sys
+    out = None
+    for _ in range(attempts):
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+                              "--master-addr", "127.0.0.1", "--master-port", str(port)] + script_and_args,
+                             env=env, capture_output=True, text=True, timeout=600, cwd=cwd)
+        if out.returncode == 0:
+            break
+    return out
+
+
 def _open(path, mode=None):
     """open on GPU 0; mode 4 is built for small alphabets too (FEMTO_AMD_PACK2=1) so that every fixture exercises it"""
     old = os.environ.get("FEMTO_AMD_PACK2")
@@ -731,19 +750,10 @@ def test_range_split_needs_every_part(fixtures, gpu_ok):
 def test_range_split_across_processes(fixtures, gpu_ok, tmp_path):
     """Two PROCESSES (one rank each, both on this box's single GPU): hipIpc handles travel through
     torch.distributed, each rank maps the other's slices and answers the whole golden batch."""
-    import socket
-    import subprocess
-    import sys
     fx = fixtures("acgt48k")
-    sk = socket.socket()
-    sk.bind(("127.0.0.1", 0))
-    port = sk.getsockname()[1]
-    sk.close()
     script = os.path.join(os.path.dirname(__file__), "split_worker.py")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port), script, fx.index, os.path.join(os.path.dirname(__file__), "golden", "acgt48k.npz"),
-                          str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+    out = _torchrun(2, [script, fx.index, os.path.join(os.path.dirname(__file__), "golden", "acgt48k.npz"), str(tmp_path)], env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     for r in range(2):
         assert (tmp_path / f"ok{r}").exists()
@@ -796,19 +806,10 @@ def test_bench_two_ranks_control_flow(tmp_path, gpu_ok):
     ranges, max-over-ranks timing, one JSON line from rank 0) with two ranks sharing this box's GPU and the gather routed
     through gloo -- the control flow the driver runs with RCCL on 2/4/8 GPUs."""
     import json
-    import socket
-    import subprocess
-    import sys
-    sk = socket.socket()
-    sk.bind(("127.0.0.1", 0))
-    port = sk.getsockname()[1]
-    sk.close()
     root = os.path.join(os.path.dirname(__file__), "..")
     env = dict(os.environ, FEMTO_AMD_BENCH_BACKEND="gloo", FEMTO_AMD_BENCH_DIR=str(tmp_path), MASTER_ADDR="127.0.0.1")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                          "--text-log2", "22", "--npats", "200000", "--cpu-sample", "2000"],
-                         env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    out = _torchrun(2, [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--text-log2", "22",
+                        "--npats", "200000", "--cpu-sample", "2000"], env, cwd=root)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
