@@ -32,8 +32,83 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-KERNEL_NAMES = {4: "count_kernel_pack2<true>", 3: "count_kernel_pack<true>", 1: "count_kernel_lane", 2: "count_kernel_flat<1>", 0: "count_kernel<32>"}
-LOCATE_NAMES = {4: "locate_kernel_pack2", 3: "locate_kernel_pack", 1: "locate_kernel_lane", 2: "locate_kernel_flat", 0: "locate_kernel<32>"}
+# (rank mode, direct pipeline?) -> name of the search / walk kernel as rocprofv3 prints it
+KERNEL_NAMES = {(4, True): "count_direct_kernel<femto_amd::Pack2Policy, true>", (3, True): "count_direct_kernel<femto_amd::PackPolicy, true>",
+                (4, False): "count_kernel_pack2<true>", (3, False): "count_kernel_pack<true>",
+                (1, False): "count_kernel_lane", (2, False): "count_kernel_flat<1>", (0, False): "count_kernel<32>"}
+LOCATE_NAMES = {(4, True): "locate_walk_kernel<femto_amd::Pack2Policy>", (3, True): "locate_walk_kernel<femto_amd::PackPolicy>",
+                (4, False): "locate_kernel_pack2", (3, False): "locate_kernel_pack",
+                (1, False): "locate_kernel_lane", (2, False): "locate_kernel_flat", (0, False): "locate_kernel<32>"}
+for _m in (0, 1, 2):
+    KERNEL_NAMES[(_m, True)] = KERNEL_NAMES[(_m, False)]
+    LOCATE_NAMES[(_m, True)] = LOCATE_NAMES[(_m, False)]
+PMC_REGEX = "count_direct_kernel|locate_walk_kernel|count_kernel|locate_kernel|count_tail_kernel"
+
+
+def source_hash():
+    """hash of the kernel / host sources: ties a committed PMC file to the code it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "femto_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(args, kname):
+    """HBM-side bytes per launch of kernel `kname`, measured NOW: two separate `rocprofv3 --pmc` passes over a short child
+    run of this script (FETCH_SIZE; WRITE_SIZE + request counters -- never combined with any trace domain).  Per the
+    guide (MI355X_MICROARCH.md, HBM): on gfx950 FETCH_SIZE tallies a 128-byte request as 64 bytes -> x2; both are KiB."""
+    import csv
+    import glob
+    import shutil
+    if not shutil.which("rocprofv3"):
+        return None, None
+    base = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "2", "--warmup", "1", "--text-log2", str(args.text_log2),
+            "--npats", str(args.npats), "--plen", str(args.plen), "--seed", str(args.seed), "--max-occs", str(args.max_occs),
+            "--workload", args.workload, "--workdir", args.workdir]
+    means = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for i, ctrs in enumerate((["FETCH_SIZE"], ["WRITE_SIZE", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_128B_sum"])):
+            out = os.path.join(td, f"p{i}")
+            cmd = ["rocprofv3", "--pmc"] + ctrs + ["--kernel-include-regex", PMC_REGEX, "-f", "csv", "-d", out, "-o", "pmc", "--"] + base
+            subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, cwd="/tmp", env=env)
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if kname.split("<")[0] in r.get("Kernel_Name", "") and _same_kernel(kname, r.get("Kernel_Name", "")):
+                            means.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    if "FETCH_SIZE" not in means or "WRITE_SIZE" not in means:
+        return None, None
+    m = {k: sum(v) / len(v) for k, v in means.items()}
+    traffic = 2.0 * m["FETCH_SIZE"] * 1024 + m["WRITE_SIZE"] * 1024
+    src = {"how": "live: 2 separate rocprofv3 --pmc passes over a 2-step child run of this script in this very run",
+           "FETCH_SIZE_KiB": m["FETCH_SIZE"], "WRITE_SIZE_KiB": m["WRITE_SIZE"], "TCC_EA0_RDREQ": m.get("TCC_EA0_RDREQ_sum"),
+           "TCC_EA0_RDREQ_128B": m.get("TCC_EA0_RDREQ_128B_sum"), "dispatches": len(means["FETCH_SIZE"]), "source_hash": source_hash(),
+           "formula": "2 x FETCH_SIZE KiB x 1024 (gfx950 tallies 128-B requests as 64 B) + WRITE_SIZE KiB x 1024"}
+    return traffic, src
+
+
+def _same_kernel(kname, full):
+    """template arguments must match too (count_direct_kernel<..., true> vs <..., false>)"""
+    if "<" not in kname:
+        return True
+    want = kname[kname.index("<"):].replace(" ", "")
+    return want in full.replace(" ", "")
+
+
+def committed_traffic(args, kname, npats):
+    """fallback: a committed profiles/latest_pmc.json, accepted only when it was measured on these very sources"""
+    try:
+        tj = json.load(open(args.traffic_json))
+        if (tj.get("source_hash") == source_hash() and tj.get("npats") == npats and tj.get("text_log2") == args.text_log2
+                and tj.get("workload") == args.workload and tj.get("kernel") == kname):
+            return tj.get("hbm_bytes_per_launch"), {"how": "committed " + os.path.relpath(args.traffic_json, ROOT) + " (same source hash)"}
+    except Exception:      # noqa: BLE001
+        pass
+    return None, None
 
 
 def log(*a):
@@ -56,22 +131,29 @@ class Batch:
         self.d_noccs = torch.empty(self.n, dtype=torch.int32, device=dev)
         self.d_ostarts = torch.empty(self.n + 1, dtype=torch.int64, device=dev)
         self.offsets = None
+        self.d_total = torch.zeros(2, dtype=torch.int64, device=dev)
         self.total = 0
         self.torch, self.dev = torch, dev
 
     def step(self, ix, max_occs, stream, buf=0):
-        """count (+clamp +prefix sum), then the locate walk of every matching row"""
+        """one enqueue-only call: count, clamp, prefix sum and the locate walk of every matching row -- a single
+        stream-ordered chain on the GPU (femto_amd_locate_device); nothing returns to the host inside a step"""
         self.d_res = self.d_res2[buf]
-        ix.locate_plan_device(self.n, self.d_plen.data_ptr(), self.d_flat.data_ptr(), self.d_starts.data_ptr(), max_occs,
-                              self.d_res[0].data_ptr(), self.d_res[1].data_ptr(), self.d_noccs.data_ptr(),
-                              self.d_ostarts.data_ptr(), stream)
-        total = int(self.d_ostarts[self.n].item())      # one device->host word per step sizes the output
-        if self.offsets is None or self.offsets.numel() < total:
-            self.offsets = self.torch.empty(max(total, 1), dtype=self.torch.int64, device=self.dev)
-        self.total = total
-        ix.locate_walk_device(self.n, self.d_res[0].data_ptr(), self.d_ostarts.data_ptr(), total,
-                              self.offsets.data_ptr(), stream)
+        if self.offsets is None:
+            self.offsets = self.torch.empty(max(1 << 20, self.n // 4), dtype=self.torch.int64, device=self.dev)
+        ix.locate_device(self.n, self.d_plen.data_ptr(), self.d_flat.data_ptr(), self.d_starts.data_ptr(), max_occs,
+                         self.d_res[0].data_ptr(), self.d_res[1].data_ptr(), self.d_noccs.data_ptr(),
+                         self.d_ostarts.data_ptr(), self.offsets.data_ptr(), self.offsets.numel(), self.d_total.data_ptr(), stream)
 
+    def settle(self, ix, max_occs, stream):
+        """untimed: run one step, read the row count and grow the offsets buffer until everything fits"""
+        while True:
+            self.step(ix, max_occs, stream)
+            tot = self.d_total.cpu().numpy()
+            self.total = int(tot[0])
+            if not tot[1]:
+                return
+            self.offsets = self.torch.empty(int(self.total * 1.25) + 1024, dtype=self.torch.int64, device=self.dev)
 
     def wire(self, rows, buf=0):
         """The (first,last) ranges of this step in the form that is gathered to rank 0: row numbers of an index with
@@ -102,6 +184,9 @@ def main():
     ap.add_argument("--layout", default="replicated", choices=["replicated", "split"],
                     help="split: range-split index (BASELINE configs[4]) -- every rank keeps 1/N of the blocks and reads the "
                          "rest from its peers' HBM over xGMI (femto_amd.parallel.open_range_split)")
+    ap.add_argument("--ref-sample", type=int, default=100_000, help="patterns per timed pass of the genuine reference (3 passes + warm-up)")
+    ap.add_argument("--pmc", default="auto", choices=["auto", "off"], help="auto: roofline.traffic from live rocprofv3 --pmc passes (N=1)")
+    ap.add_argument("--pmc-child", action="store_true", help="internal: the short run the PMC passes profile")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary P_hit line (N=1 default workload only)")
     ap.add_argument("--workdir", default=os.environ.get("FEMTO_AMD_BENCH_DIR", "/tmp/femto_amd_bench"))
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "latest_pmc.json"))
@@ -135,7 +220,7 @@ def main():
 
     eng = args.workload == "eng"
     hit = args.workload != "acgt"
-    want_extra = (args.workload == "acgt" and world == 1 and not args.no_extra)
+    want_extra = (args.workload == "acgt" and world == 1 and not args.no_extra and not args.pmc_child)
     need_text = hit or want_extra
     n_text = 1 << args.text_log2
     os.makedirs(args.workdir, exist_ok=True)
@@ -178,6 +263,15 @@ def main():
     else:
         plen, flat = tg.p_rand(args.plen, npats, args.seed + 1000 + rank)
     batch = Batch(torch, dev, plen, flat)
+    direct = bool(ix.pack_info().get("level_table")) and os.environ.get("FEMTO_AMD_DIRECT", "1") != "0" and ix.rank_mode in (3, 4)
+    if args.pmc_child:      # the short run the PMC passes of pmc_traffic() profile: same index, same batch, a few steps
+        st = torch.cuda.current_stream().cuda_stream
+        batch.settle(ix, args.max_occs, st)
+        for _ in range(args.warmup + args.steps):
+            batch.step(ix, args.max_occs, st)
+        torch.cuda.synchronize()
+        ix.close()
+        return
     gather_lists = None
     if world > 1 and rank == 0:
         gather_lists = [[torch.empty_like(batch.wire(info.total_length), device=None if backend == "nccl" else "cpu")
@@ -207,6 +301,7 @@ def main():
                 pending[b].wait()
                 pending[b] = None
 
+    batch.settle(ix, args.max_occs, stream)      # untimed: sizes the offsets buffer (the timed steps never read the total back)
     for _ in range(args.warmup):
         step()
     drain()
@@ -252,6 +347,7 @@ def main():
         hp, hf = tg.p_hit(args.plen, args.plen, npats, args.seed + 2000, np.asarray(text))
         del text
         hb = Batch(torch, dev, hp, hf)
+        hb.settle(ix, args.max_occs, stream)
         for _ in range(2):
             hb.step(ix, args.max_occs, stream)
         torch.cuda.synchronize()
@@ -296,6 +392,7 @@ def main():
             ep, ef = tg.p_hit(8, 64, npats, args.seed + 3000, e_text)
             del e_text
             eb = Batch(torch, dev, ep, ef)
+            eb.settle(eix, args.max_occs, stream)
             for _ in range(2):
                 eb.step(eix, args.max_occs, stream)
             torch.cuda.synchronize()
@@ -321,109 +418,91 @@ def main():
     # ---- CPU baseline + bit-exact check on a bounded sample of the same batch (rank 0 only)
     from oracle import pyoracle as po
     cpu = None
-    c_count, c_all = po.Counters(), po.Counters()
+    host_cores = os.cpu_count() or 1
     sample = min(args.cpu_sample, npats)
     if sample > 0:
         o = po.Oracle(index_path)
         s_plen, s_starts = plen[:sample], batch.starts[:sample]
         s_flat = flat[:int(s_starts[-1] + s_plen[-1])]
-        nthr = min(64, os.cpu_count() or 1)
+        nthr = min(64, host_cores)
         t0 = time.perf_counter()
-        of, ol = o.count_flat(s_plen, s_flat, s_starts, threads=nthr, counters=c_count)
-        on, oo = o.locate_flat(s_plen, s_flat, s_starts, args.max_occs, threads=nthr, counters=c_all)
+        of, ol = o.count_flat(s_plen, s_flat, s_starts, threads=nthr)
+        on, oo = o.locate_flat(s_plen, s_flat, s_starts, args.max_occs, threads=nthr)
         port_mt_s = time.perf_counter() - t0
         assert np.array_equal(of, first[:sample]) and np.array_equal(ol, last[:sample]), "GPU count differs from the oracle"
         assert np.array_equal(on, g_noccs[:sample]) and np.array_equal(oo, g_offs[:g_ost[sample]]), "GPU locate differs from the oracle"
         if po.have_ref():
+            rsample = min(sample, args.ref_sample)       # ~5 s per pass at the reference's ~19 k patterns/s
             with tempfile.TemporaryDirectory() as td:
                 pf, rf = os.path.join(td, "p.fpat"), os.path.join(td, "r.bin")
-                po.write_fpat_flat(pf, s_plen, s_flat)
-                out = subprocess.run([po.REF_TOOL, "bench", index_path, pf, "locate", str(args.max_occs), "1", "1"],
+                po.write_fpat_flat(pf, s_plen[:rsample], s_flat[:int(s_starts[rsample - 1] + s_plen[rsample - 1])])
+                out = subprocess.run([po.REF_TOOL, "bench", index_path, pf, "locate", str(args.max_occs), "1", "3"],
                                      check=True, stdout=subprocess.PIPE).stdout.decode()
                 rj = json.loads(out.strip().splitlines()[-1])
-                assert int(rj["results"]) == int(g_ost[sample]), "located-row count differs from the genuine reference"
-                sub = min(sample, 50_000)   # direct range check against the reference's parallel_count
+                assert int(rj["results"]) == int(g_ost[rsample]), "located-row count differs from the genuine reference"
+                sub = min(rsample, 50_000)   # direct range check against the reference's parallel_count
                 po.write_fpat_flat(pf, s_plen[:sub], s_flat[:int(s_starts[sub - 1] + s_plen[sub - 1])])
                 subprocess.run([po.REF_TOOL, "count", index_path, pf, rf], check=True, stdout=subprocess.PIPE)
                 ref = np.fromfile(rf, dtype=np.int64)
                 assert np.array_equal(ref[:sub], first[:sub]) and np.array_equal(ref[sub:], last[:sub]), \
                     "GPU ranges differ from the genuine reference"
-            cpu = {"value": rj["patterns_per_s"], "unit": "patterns/s", "cores": 1, "kind": "reference",
-                   "sample": f"first {sample} patterns of the batch through femto's parallel_locate (count + locate, max_occs "
-                             f"{args.max_occs}; 1 worker thread = the reference's hard-wired default), index in page cache, "
-                             f"1 warm-up + 1 timed pass",
+            cpu = {"value": rsample / rj["mean_s"], "unit": "patterns/s", "cores": 1, "host_cores": host_cores, "kind": "reference",
+                   "sample": f"first {rsample} patterns of the batch through femto's parallel_locate (count + locate, max_occs "
+                             f"{args.max_occs}; 1 worker thread = the reference's hard-wired default, src/main/server.c:3597), index in "
+                             f"page cache, 1 warm-up + 3 timed passes (mean; best {rsample / rj['best_s']:.0f} patterns/s)",
                    "bit_exact_vs_gpu": True,
-                   "port_all_cores": {"value": sample / port_mt_s, "threads": nthr, "what": "oracle/femto_oracle.c count+locate"}}
+                   "port_all_cores": {"value": sample / port_mt_s, "threads": nthr, "host_cores": host_cores,
+                                      "what": f"oracle/femto_oracle.c count+locate on the first {sample} patterns"}}
         else:
             t0 = time.perf_counter()
             o.locate_flat(s_plen, s_flat, s_starts, args.max_occs, threads=1)
-            cpu = {"value": sample / (time.perf_counter() - t0), "unit": "patterns/s", "cores": 1, "kind": "port",
+            cpu = {"value": sample / (time.perf_counter() - t0), "unit": "patterns/s", "cores": 1, "host_cores": host_cores, "kind": "port",
                    "sample": f"first {sample} patterns of the batch, oracle/femto_oracle.c count+locate, single thread",
                    "bit_exact_vs_gpu": True,
-                   "port_all_cores": {"value": sample / port_mt_s, "threads": nthr}}
+                   "port_all_cores": {"value": sample / port_mt_s, "threads": nthr, "host_cores": host_cores}}
 
-    # ---- roofline of the dominant kernel: algorithmic bytes per launch / average kernel duration
+    # ---- roofline of the dominant kernel.  achieved = COMPULSORY bytes per launch / average kernel duration, where the
+    # compulsory bytes are what the launch must move at least once: 128 B for every DISTINCT line of a derived array it
+    # loads (counted on the GPU by a traced run of the same batch, femto_amd_trace_lines) + the arrays it streams
+    # exactly once (pattern lengths / starts / symbols in, ranges and row counts out).  frac <= 1 by construction.
     roof = None
-    if sample > 0 and cnt_n > 0:
-        cc, ca = c_count.asdict(), c_all.asdict()
-        packed = ix.rank_mode in (3, 4)
-        line_bytes = 128 if ix.rank_mode == 3 else 256     # pack2: one level-1 and one level-2 line per Occ / LF step
-        ktab_syms = ix.pack_info()["ktab_syms"] if packed else 0
-        c_tab = po.Counters()
-        if packed and ktab_syms:   # Occ evaluations the precomputed table answers: those of each pattern's last ktab_syms symbols
-            t_len = np.minimum(s_plen, ktab_syms).astype(np.int32)
-            t_starts = (s_starts + (s_plen - t_len)).astype(np.int64)
-            o.count_flat(t_len, s_flat, t_starts, threads=nthr, counters=c_tab)
-        n_occ_tab = c_tab.asdict()["n_occ"]
-
-        def alg(c):
-            if packed:    # packed lines: every Occ / LF step (= one leaf request of the restatement) reads ONE 128-byte line,
-                # every located row one 8-byte offset; a sorted batch reads 8 B key + 4 B order + 16 B table entry per
-                # pattern instead of the steps the table covers, and writes 16 B
-                if c is cc and ktab_syms:
-                    return (c["n_occ"] - n_occ_tab) * line_bytes + sample * (8 + 4 + 16 + 16)
-                return c["n_occ"] * line_bytes + c["n_mark"] * 8
-            # wavelet path, SURVEY.md 8(d): N_rank*(12 + 64 + S_rank) + N_occ*20 + N_mark*8, counters from the CPU restatement
-            return c["n_rank"] * (12 + 64) + c["s_bytes"] + c["n_occ"] * 20 + c["n_mark"] * 8
-        cl = {k: ca[k] - cc[k] for k in ca}       # locate_flat re-runs the count: walk only = all - count
-        scale = npats / sample
+    if cnt_n > 0:
+        cl, ll, trows = ix.trace_lines(npats, batch.d_plen.data_ptr(), batch.d_flat.data_ptr(), batch.d_starts.data_ptr(), args.max_occs)
+        n_sym = int(plen.astype(np.int64).sum())
+        stream_count = npats * (4 + 8) + 2 * n_sym + npats * (8 + 8 + 4) + 8 * ((npats + 255) // 256)
+        stream_locate = trows * (8 + 8)                    # the row in, its text offset out
+        comp_count = 128 * sum(cl.values()) + stream_count
+        comp_locate = 128 * sum(ll.values()) + stream_locate
         dominant_is_count = cnt_ms >= loc_ms
         k_ms = cnt_ms if dominant_is_count else loc_ms
-        k_c = cc if dominant_is_count else cl
-        alg_launch = alg(k_c) * scale
-        achieved = alg_launch / (k_ms * 1e-3) / 1e9
-        traffic = None
-        if os.path.exists(args.traffic_json):
+        comp = comp_count if dominant_is_count else comp_locate
+        kname = (KERNEL_NAMES if dominant_is_count else LOCATE_NAMES)[(ix.rank_mode, direct)]
+        achieved = comp / (k_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        if args.pmc != "off" and world == 1:
             try:
-                tj = json.load(open(args.traffic_json))
-                if (tj.get("npats") == npats and tj.get("text_log2") == args.text_log2 and tj.get("workload") == args.workload
-                        and tj.get("kernel") == (KERNEL_NAMES if dominant_is_count else LOCATE_NAMES)[ix.rank_mode]):
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+                traffic, traffic_src = pmc_traffic(args, kname)
+            except Exception as ex:      # noqa: BLE001
+                log("pmc pass failed:", repr(ex))
+        if traffic is None:
+            traffic, traffic_src = committed_traffic(args, kname, npats)
+        step_bytes = comp_count + comp_locate
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_GBs": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,      # measured memory-side rate of the same kernel
-                "traffic_frac_of_peak": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                "kernel": (KERNEL_NAMES if dominant_is_count else LOCATE_NAMES)[ix.rank_mode],
-                "kernel_ms": k_ms, "launches_timed": cnt_n,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_GBs": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
+                "traffic_over_compulsory": (traffic / comp) if traffic else None,
+                "kernel": kname, "kernel_ms": k_ms, "launches_timed": cnt_n,
                 "count_kernel_ms": cnt_ms, "locate_kernel_ms": loc_ms,
-                "algorithmic_bytes_per_launch": alg_launch,
-                "occ_per_s": k_c["n_occ"] * scale / (k_ms * 1e-3), "bseq_rank_per_s": k_c["n_rank"] * scale / (k_ms * 1e-3),
-                "per_pattern": {"bseq_rank": k_c["n_rank"] / sample, "occ": k_c["n_occ"] / sample,
-                                "S_bytes_per_rank": k_c["s_bytes"] / max(1, k_c["n_rank"]),
-                                "bytes": alg(k_c) / sample},
-                "contract_335B_per_occ_GBs": 335.0 * k_c["n_occ"] * scale / (k_ms * 1e-3) / 1e9,
-                "wavelet_path_equivalent_GBs": (k_c["n_rank"] * (12 + 64) + k_c["s_bytes"] + k_c["n_occ"] * 20 + k_c["n_mark"] * 8)
-                * scale / (k_ms * 1e-3) / 1e9,
-                "occ_answered_by_table_per_pattern": (n_occ_tab / sample) if (packed and dominant_is_count) else 0.0,
-                "bytes_model": (f"packed lines: {line_bytes} B per Occ / LF step not covered by the first-steps table, + 44 B per pattern "
-                                "(key, order, table entry, results), + 8 B per located row" if packed else
-                                "wavelet path: N_rank*(12+64+S) + N_occ*20 + N_mark*8 (SURVEY 8d)"),
-                "note": "the batch is processed in suffix order, so neighbouring lanes share cache lines and part of the "
-                        "algorithmic bytes never leaves L1/L2 (traffic < algorithmic bytes; frac may exceed 1)"
-                        + ("; patterns longer than a sort key finish by a text comparison once their range is one row, so for "
-                           "this workload the per-step byte model overstates what the count kernel reads" if (packed and args.plen > 21 or eng) else "")}
+                "compulsory_bytes_per_launch": comp,
+                "compulsory": {"count": {"distinct_lines": cl, "streamed_bytes": stream_count, "bytes": comp_count},
+                               "locate": {"distinct_lines": ll, "streamed_bytes": stream_locate, "bytes": comp_locate, "rows": trows}},
+                "per_pattern_bytes": comp / npats,
+                "whole_step_GBs": step_bytes / (1e-3 * 1e3 * elapsed / args.steps) / 1e9,   # cross-check: compulsory bytes of the step / ms_per_step < peak
+                "bytes_model": "compulsory bytes: 128 B x distinct lines loaded from each derived array (GPU line trace of the same "
+                               "batch, femto_amd_trace_lines) + arrays streamed once (count: 12 B/pattern + 2 B/symbol in, 20 B/pattern "
+                               "out; locate: 16 B/row); kernel time from HIP events on the launch stream",
+                "note": "reference-format equivalent (SURVEY 8d: 335 B per Occ on femto's own wavelet tree) is not what this kernel "
+                        "reads: it walks the derived packed lines after a level table of the first steps"}
 
     wl = {"acgt": f"T_acgt(2^{args.text_log2}) femto index (default params), {npats} P_rand 20-mers per GPU, count()+locate(max_occs={args.max_occs})",
           "acgt_hit": f"T_acgt(2^{args.text_log2}) femto index (default params), {npats} P_hit 20-mers per GPU, count()+locate(max_occs={args.max_occs})",

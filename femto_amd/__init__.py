@@ -65,6 +65,9 @@ def lib():
         L.femto_amd_count_device.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
         L.femto_amd_locate_plan_device.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, vp, vp, vp]
         L.femto_amd_locate_walk_device.argtypes = [vp, i64, vp, vp, i64, vp, vp]
+        L.femto_amd_locate_device.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, vp, vp]
+        L.femto_amd_trace_lines.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, C.POINTER(i64)]
+        L.femto_amd_set_option.argtypes = [vp, C.c_char_p, i32]
         L.femto_amd_block_requests.argtypes = [vp, i64, vp, vp, vp, vp, vp]
         L.femto_amd_kernel_time_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]
         L.femto_amd_kernel_time_reset.argtypes = [vp]
@@ -230,8 +233,8 @@ class Index:
         """small-alphabet packed lines (mode 3): {'available', 'bytes', 'build_ms', 'ktab_syms'}"""
         a, b, ms, k = C.c_int(0), C.c_int64(0), C.c_double(0), C.c_int(0)
         _check(lib().femto_amd_pack_info(self._h, C.byref(a), C.byref(b), C.byref(ms), C.byref(k)))
-        return {"available": bool(a.value & 1), "available2": bool(a.value & 2), "bytes": b.value, "build_ms": ms.value,
-                "ktab_syms": k.value}
+        return {"available": bool(a.value & 1), "available2": bool(a.value & 2), "level_table": bool(a.value & 4),
+                "bytes": b.value, "build_ms": ms.value, "ktab_syms": k.value}
 
     def document_info(self, doc):
         p, n = C.c_char_p(), C.c_int64(0)
@@ -277,6 +280,26 @@ class Index:
     def locate_walk_device(self, npats, d_first, d_out_starts, total, d_offsets, stream=0):
         _check(lib().femto_amd_locate_walk_device(self._h, npats, d_first, d_out_starts, total, d_offsets,
                                                   stream or None))
+
+    def locate_device(self, npats, d_plen, d_pats, d_starts, max_occs, d_first, d_last, d_noccs, d_out_starts, d_offsets,
+                      capacity, d_total, stream=0):
+        """count + clamp + prefix sum + locate walk in ONE enqueue-only call (femto_amd_locate_device)"""
+        _check(lib().femto_amd_locate_device(self._h, npats, d_plen, d_pats, d_starts, max_occs, d_first, d_last, d_noccs,
+                                             d_out_starts, d_offsets, capacity, d_total, stream or None))
+
+    TRACE_REGIONS = ("pack_lines", "level_table", "mark_offsets", "level1_lines", "level2_lines", "text", "isa", "ktab_r1")
+
+    def trace_lines(self, npats, d_plen, d_pats, d_starts, max_occs):
+        """distinct 128-byte lines per derived array loaded by the count phase and by the locate phase of this batch"""
+        cl = np.zeros(8, dtype=np.int64)
+        ll = np.zeros(8, dtype=np.int64)
+        rows = C.c_int64(0)
+        _check(lib().femto_amd_trace_lines(self._h, npats, d_plen, d_pats, d_starts, max_occs, _ptr(cl), _ptr(ll), C.byref(rows)))
+        return dict(zip(self.TRACE_REGIONS, cl.tolist())), dict(zip(self.TRACE_REGIONS, ll.tolist())), rows.value
+
+    def set_option(self, name, value):
+        """'direct' (modes 3/4: caller-order pipeline, default 1) / 'sort' (suffix-order batches of the other paths)"""
+        _check(lib().femto_amd_set_option(self._h, name.encode(), int(value)))
 
     def set_rank_mode(self, mode):
         """1 = lane per query (default), 2 = flattened persistent lanes, 0 = wavefront-per-query raw walk"""

@@ -105,6 +105,10 @@ struct DevBucket {          // 16 bytes
   uint32_t n_in_use;
 };
 
+// regions of the compulsory-traffic trace (femto_amd_trace_lines): every 128-byte line a query kernel loads from one
+// of these arrays sets one bit; the number of set bits x 128 B is what the launch MUST move from HBM at least once
+enum { kTracePack = 0, kTraceKtab = 1, kTraceSa = 2, kTraceL1 = 3, kTraceL2 = 4, kTraceTxt = 5, kTraceIsa = 6, kTraceKtab1 = 7 };
+
 struct DevIndex {           // passed by value to kernels
   const uint8_t* image;
   const DevNode* nodes;
@@ -127,6 +131,13 @@ struct DevIndex {           // passed by value to kernels
   const int64_t* pack_c;    // [16]: C[ch(code)] for code 0..7, then C[ch(code)+1]-1
   const int64_t* ktab;      // [2^ktab_bits][2]: backward search of the first ktab_syms key fields, precomputed (pack_kernels.hip.hpp)
   int32_t ktab_bits, ktab_syms;
+  const int64_t* ktab2;     // level table of the first steps, heap-numbered over the table characters (direct_kernels.hip.hpp)
+  int32_t kt2_syms;         // deepest level K
+  int32_t kt2_base;         // t = number of table characters (characters of the text that are not <= SEOF)
+  int32_t kt2_nstop;        // dense codes below this are <= SEOF: digit = dense code - kt2_nstop
+  int32_t kt2_pad;
+  uint32_t* trace;          // NULL, or the line bitmaps of femto_amd_trace_lines: bit trace_off[region] + line index
+  int64_t trace_off[8];     // first bit of every traced region (kTrace* below)
   uint16_t pack_alpha[8];   // dense code -> alpha code
   int32_t pack_sigma;
   uint32_t pack_stop;       // bit c: alpha code of dense code c is <= SEOF (a locate walk stops there)

@@ -1,0 +1,291 @@
+// direct_kernels.hip.hpp -- the batch pipeline of the packed layouts (modes 3 and 4) WITHOUT a batch sort.
+//
+// Round 1 ordered every batch by pattern suffix (key kernel + four radix-sort passes), searched from the sort keys
+// and scattered 16-byte results back to the caller's order: 35 % of the headline step was not the search kernel.
+// This pipeline processes the batch in the CALLER's order with one lane per pattern:
+//
+//   count_direct_kernel   pattern symbols are read straight from the caller's buffer (lane q reads pattern q: the
+//                         wavefront's loads cover one contiguous span, so they are coalesced -- the line-per-symbol cost
+//                         that made round 1 search from sort keys only exists when a batch is processed out of order);
+//                         the first steps come from the LEVEL TABLE below; the remaining steps walk the packed lines;
+//                         (first,last) and the clamped row count are stored coalesced, and the block's row-count sum
+//                         goes to block_sums[] (do_locate_query's clamp, src/main/server.c:4405-4415, fused);
+//   count_tail_kernel     (text_kernels.hip.hpp) long patterns whose range is one row: compared against the text;
+//   plan_scan_kernel      exclusive scan of the block sums (one workgroup), total -> device word;
+//   plan_rows_kernel      out_starts[] = block offset + in-block scan; the rows to locate are written where their
+//                         offsets will go (setup_locate_range, src/main/server.c:4047);
+//   locate_walk_kernel    persistent grid, reads the total from the device word: no host round trip inside a step.
+//
+// LEVEL TABLE (ktab2).  The first steps of a backward search depend only on the pattern's last symbols and are shared by
+// huge numbers of patterns, so they are precomputed at open, on the GPU, from the packed lines themselves: for every
+// string s of at most K "table characters" (the characters of the text that are not <= SEOF; digit = dense code -
+// nstop, base t) the entry at heap position pos(s) -- pos(empty) = 0, pos(s.c) = pos(s)*t + 1 + digit(c), so level m
+// occupies [ (t^m-1)/(t-1), (t^(m+1)-1)/(t-1) ) -- holds exactly the values do_string_query's loop
+// (src/main/server.c:832-936) holds after searching s, including an early death:  x = first,  y = (last + 1) | m << 48.
+// A pattern shorter than K, or one that meets a character outside the table, leaves the table at its level and
+// continues symbol by symbol.  K is chosen from a byte budget (FEMTO_AMD_KTAB_MB; default half a byte per row, so the
+// table stays a fraction of the packed lines: K = 12 for a 2^30-row DNA index = 358 MB).
+#pragma once
+
+namespace femto_amd {
+
+// ---- level table construction: one launch per level, entries of level m+1 from their parents in level m -----------
+template <class P>
+__global__ __launch_bounds__(256) void ktab2_level_kernel(const DevIndex ix, const int level /* m+1 >= 1 */, const int64_t lo, const int64_t n,
+                                                          longlong2* __restrict__ tab) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t pos = lo + i;
+  const int64_t t = ix.kt2_base;
+  const int64_t parent = (pos - 1) / t;
+  const uint32_t digit = uint32_t((pos - 1) - parent * t);
+  const longlong2 e = tab[parent];
+  int64_t first = e.x, last = int64_t(uint64_t(e.y) & kKtabLastMask) - 1;
+  if (first <= last) P::search_step(ix, level - 1, digit + uint32_t(ix.kt2_nstop), first, last);
+  tab[pos] = make_longlong2(first, int64_t(uint64_t(last + 1) | (uint64_t(level) << 48)));
+}
+
+__global__ void ktab2_root_kernel(const DevIndex ix, longlong2* __restrict__ tab) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) tab[0] = make_longlong2(0, ix.total_length);   // empty pattern: [0, n-1] (server.c:782-808)
+}
+
+// sum of `v` over the 256-thread block (all threads must call); valid in thread 0
+__device__ __forceinline__ int64_t block_sum_256(int64_t v, int64_t* s_w /* [4] */) {
+  uint32_t lo = uint32_t(uint64_t(v)), hi = uint32_t(uint64_t(v) >> 32);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t lo2 = uint32_t(__shfl_down(int(lo), d, 64)), hi2 = uint32_t(__shfl_down(int(hi), d, 64));
+    const uint64_t s = ((uint64_t(hi) << 32) | lo) + ((uint64_t(hi2) << 32) | lo2);
+    lo = uint32_t(s);
+    hi = uint32_t(s >> 32);
+  }
+  if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = int64_t((uint64_t(hi) << 32) | lo);
+  __syncthreads();
+  return s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// do_string_query (src/main/server.c:713-946), one lane per pattern in the caller's order.
+// kPlan: also do_locate_query's clamp (server.c:4405-4415): noccs[q] and the block's sum of them.
+template <class P, bool kPlan>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void count_direct_kernel(
+    const DevIndex ix, const int64_t npats, const int32_t* __restrict__ plen, const uint16_t* __restrict__ pats,
+    const int64_t* __restrict__ starts, int64_t* __restrict__ first_out, int64_t* __restrict__ last_out, int* __restrict__ err_flag,
+    const int max_occs, int32_t* __restrict__ noccs, int64_t* __restrict__ block_sums) {
+  __shared__ uint16_t s_code[264];
+  __shared__ int64_t s_w[4];
+  for (int i = threadIdx.x; i < kAlphaSize; i += blockDim.x) s_code[i] = uint16_t(P::code_of(ix, uint32_t(i)));
+  __syncthreads();
+  const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  int64_t nocc = 0;
+  if (q < npats) {
+    const int len = plen[q];
+    const uint16_t* pat = pats + starts[q];
+    uint64_t word = 0;           // aligned 8-byte word of the pattern holding the symbol being read (4 symbols per load);
+    uintptr_t word_addr = 0;     // a word never crosses a page, so the bytes around the pattern inside it are safe to touch
+    auto symbol = [&](int j) -> uint32_t {   // j-th symbol from the end
+      const uintptr_t sa = reinterpret_cast<uintptr_t>(pat + (len - 1 - j));
+      const uintptr_t wa = sa & ~uintptr_t(7);
+      if (wa != word_addr) {
+        word = *reinterpret_cast<const uint64_t*>(wa);
+        word_addr = wa;
+      }
+      return uint32_t(word >> (8 * (sa - wa))) & 0xffffu;
+    };
+    int64_t first = 0, last = ix.total_length - 1;
+    int j = 0;
+    if (ix.ktab2) {
+      const int kmax = len < ix.kt2_syms ? len : ix.kt2_syms;
+      const uint32_t nstop = uint32_t(ix.kt2_nstop);
+      const int64_t t = ix.kt2_base;
+      int64_t pos = 0;
+      for (; j < kmax; j++) {
+        const uint32_t ch = symbol(j);
+        if (ch >= uint32_t(kAlphaSize)) break;
+        const uint32_t code = s_code[ch];
+        if (code == 0xffffu || code < nstop) break;   // not a table character: the ordinary step below deals with it
+        pos = pos * t + 1 + int64_t(code - nstop);
+      }
+      const longlong2 e = reinterpret_cast<const longlong2*>(ix.ktab2)[pos];
+      trace_touch(ix, kTraceKtab, uint64_t(pos) >> 3);
+      first = e.x;
+      last = int64_t(uint64_t(e.y) & kKtabLastMask) - 1;
+      if (first > last) j = len;
+    }
+    bool handed = false;
+    for (; j < len; j++) {
+      if (ix.txt && first == last && j > 0 && len - j >= ix.tail_min) {
+        tail_append(ix, q, j, first);   // one row left, a long tail to go: compare it with the text instead
+        handed = true;
+        break;
+      }
+      const uint32_t ch = symbol(j);
+      if (ch >= uint32_t(kAlphaSize)) {
+        atomicOr(err_flag, 1);
+        first = 0;
+        last = -1;
+        break;
+      }
+      const uint32_t code = s_code[ch];
+      if (code == 0xffffu) {  // the character does not occur in the text: Occ == 0 (index.c:2080-2089)
+        first = ix.C[ch];
+        last = first - 1;
+        break;
+      }
+      P::search_step(ix, j, code, first, last);
+      if (first > last) break;
+    }
+    if (!handed) {
+      if (last_out) {
+        first_out[q] = first;
+        last_out[q] = last;
+      } else {
+        first_out[q] = last - first + 1;   // femto.c:313-318
+      }
+      if (kPlan) {
+        if (first > last) nocc = 0;
+        else if (last - first > int64_t(max_occs)) nocc = max_occs;
+        else nocc = last - first + 1;
+        noccs[q] = int32_t(nocc);
+      }
+    } else if (kPlan) {
+      noccs[q] = 0;    // count_tail_kernel stores the real value and adds it to the block's sum
+    }
+  }
+  if (kPlan) {
+    const int64_t s = block_sum_256(nocc, s_w);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s;
+  }
+}
+
+// exclusive scan of n block sums in place (one 1024-thread workgroup); total -> total_out[0]; total_out[1] = 1 when the
+// total exceeds `capacity` rows (the rows beyond it are not located)
+__global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t n, int64_t* __restrict__ sums, int64_t* __restrict__ total_out,
+                                                         const int64_t capacity, int64_t* __restrict__ out_starts_end) {
+  __shared__ int64_t s_part[1024];
+  const int tid = threadIdx.x;
+  const int64_t per = (n + 1023) / 1024;
+  const int64_t a = int64_t(tid) * per, b = a + per < n ? a + per : n;
+  int64_t s = 0;
+  for (int64_t i = a; i < b; i++) s += sums[i];
+  s_part[tid] = s;
+  __syncthreads();
+  // Hillis-Steele inclusive scan over 1024 partials
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int64_t v = tid >= d ? s_part[tid - d] : 0;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  int64_t run = s_part[tid] - s;
+  for (int64_t i = a; i < b; i++) {
+    const int64_t v = sums[i];
+    sums[i] = run;
+    run += v;
+  }
+  if (tid == 1023) {
+    const int64_t total = s_part[1023];
+    total_out[0] = total;
+    total_out[1] = total > capacity ? 1 : 0;
+    if (out_starts_end) *out_starts_end = total;
+  }
+}
+
+// set bits of trace words [w0, w1) added to *out (femto_amd_trace_lines)
+__global__ __launch_bounds__(256) void trace_popcount_kernel(const uint32_t* __restrict__ bitmap, const int64_t w0, const int64_t w1,
+                                                             unsigned long long* __restrict__ out) {
+  unsigned long long c = 0;
+  for (int64_t i = w0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < w1; i += int64_t(gridDim.x) * blockDim.x) c += uint32_t(__popc(bitmap[i]));
+  for (int d = 32; d >= 1; d >>= 1) c += (unsigned long long)__shfl_down((long long)c, d, 64);
+  if ((threadIdx.x & 63u) == 0 && c) atomicAdd(out, c);
+}
+
+// paths that scanned the row counts themselves: publish the total the same way plan_scan_kernel does
+__global__ void copy_total_kernel(const int64_t* __restrict__ src, int64_t* __restrict__ total_out, const int64_t capacity) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    total_out[0] = *src;
+    total_out[1] = *src > capacity ? 1 : 0;
+  }
+}
+
+// out_starts[q] = rows located for the patterns before q; pattern q's rows first[q] .. first[q]+noccs-1 are written at
+// offsets[out_starts[q] ..] (the walk replaces each row by its text offset).  Ranges longer than kExpandSerialMax rows
+// (the empty pattern with a huge max_occs) are left to expand_big_rows_kernel.
+__global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npats, const int32_t* __restrict__ noccs, const int64_t* __restrict__ first,
+                                                        const int64_t* __restrict__ block_offs, int64_t* __restrict__ out_starts,
+                                                        int64_t* __restrict__ offsets, const int64_t capacity, int* __restrict__ big_flag) {
+  __shared__ int64_t s_w[4];
+  const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t n = q < npats ? int64_t(noccs[q]) : 0;
+  // inclusive scan inside the wavefront, then across the four wavefronts
+  uint32_t x = uint32_t(n);    // a block's rows: <= 256 * (2^31 - 1), kept in 64 bits below
+  uint64_t incl = uint64_t(n);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  (void)x;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t lo = uint32_t(__shfl_up(int(uint32_t(incl)), d, 64)), hi = uint32_t(__shfl_up(int(uint32_t(incl >> 32)), d, 64));
+    if (lane >= d) incl += (uint64_t(hi) << 32) | lo;
+  }
+  if (lane == 63) s_w[wave] = int64_t(incl);
+  __syncthreads();
+  int64_t woff = 0;
+  for (int k = 0; k < wave; k++) woff += s_w[k];
+  if (q >= npats) return;
+  const int64_t base = block_offs[blockIdx.x] + woff + int64_t(incl) - n;
+  out_starts[q] = base;
+  if (!offsets || n == 0) return;
+  if (n > kExpandSerialMax) {
+    atomicOr(big_flag, 1);
+    return;
+  }
+  const int64_t f = first[q];
+  const int64_t lim = base + n <= capacity ? n : (capacity > base ? capacity - base : 0);
+  for (int64_t k = 0; k < lim; k++) offsets[base + k] = f + k;
+}
+
+// the long ranges left over by plan_rows_kernel: grid-stride, one thread per output slot (idle unless the flag is set)
+__global__ __launch_bounds__(256) void plan_big_rows_kernel(const int64_t npats, const int64_t* __restrict__ first,
+                                                            const int64_t* __restrict__ out_starts, const int64_t* __restrict__ total_ptr,
+                                                            const int64_t capacity, int64_t* __restrict__ offsets, const int* __restrict__ big_flag) {
+  if (!*big_flag) return;
+  const int64_t total = *total_ptr < capacity ? *total_ptr : capacity;
+  for (int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; item < total; item += int64_t(gridDim.x) * blockDim.x) {
+    int64_t lo = 0, hi = npats;   // largest q with out_starts[q] <= item
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (out_starts[mid] <= item) lo = mid; else hi = mid;
+    }
+    const int64_t end = lo + 1 < npats ? out_starts[lo + 1] : *total_ptr;
+    if (end - out_starts[lo] > kExpandSerialMax) offsets[item] = first[lo] + (item - out_starts[lo]);
+  }
+}
+
+// locate walk (do_back_query / do_context_query, src/main/server.c:2228-2359, :2627-2795), persistent grid: the number
+// of rows is read from the device word the plan wrote, so count -> plan -> walk is one stream-ordered chain.
+// offsets[item] holds the row on entry and the row's text offset on return.
+template <class P>
+__global__ __launch_bounds__(256) void locate_walk_kernel(const DevIndex ix, const int64_t* __restrict__ total_ptr, const int64_t capacity,
+                                                          int64_t* __restrict__ offsets) {
+  const int64_t total = *total_ptr < capacity ? *total_ptr : capacity;
+  for (int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; item < total; item += int64_t(gridDim.x) * blockDim.x) {
+    int64_t row = offsets[item];
+    int64_t steps = 0, result = -1;
+    while (row >= 0 && steps <= int64_t(ix.walk_limit)) {
+      uint32_t code;
+      bool marked;
+      int64_t sa_index, next;
+      P::lf(ix, row, code, marked, sa_index, next);
+      if (marked) {
+        result = ix.pack_sa[sa_index] + steps;
+        trace_touch(ix, kTraceSa, uint64_t(sa_index) >> 4);
+        break;
+      }
+      if (P::is_stop(ix, code)) break;              // cannot walk past a document start (server.c:2336-2342)
+      row = next;                                    // LF (server.c:2279-2282)
+      steps++;
+    }
+    offsets[item] = result;
+  }
+}
+
+}  // namespace femto_amd

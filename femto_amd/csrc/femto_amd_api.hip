@@ -3,6 +3,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
+#include <condition_variable>
+#include <new>
+#include <stdexcept>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -19,6 +23,7 @@
 #include "pack_kernels.hip.hpp"
 #include "pack2_kernels.hip.hpp"
 #include "text_kernels.hip.hpp"
+#include "direct_kernels.hip.hpp"
 
 using namespace femto_amd;
 
@@ -75,9 +80,21 @@ struct DeviceBuffer {
 };
 
 struct KernelTimer {
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // recorded, not yet read
+  std::vector<hipEvent_t> free_list;                       // created once, reused
   double total_ms = 0;
   int64_t launches = 0;
+  bool take(hipEvent_t* e0, hipEvent_t* e1) {
+    while (free_list.size() < 2) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreate(&e) != hipSuccess) return false;
+      free_list.push_back(e);
+    }
+    *e0 = free_list.back(); free_list.pop_back();
+    *e1 = free_list.back(); free_list.pop_back();
+    return true;
+  }
+  void give(hipEvent_t e0, hipEvent_t e1) { free_list.push_back(e0); free_list.push_back(e1); }
   void drain() {
     for (auto& pr : events) {
       float ms = 0;
@@ -85,10 +102,72 @@ struct KernelTimer {
         total_ms += ms;
         launches++;
       }
-      (void)hipEventDestroy(pr.first);
-      (void)hipEventDestroy(pr.second);
+      give(pr.first, pr.second);
     }
     events.clear();
+  }
+  void destroy() {
+    drain();
+    for (hipEvent_t e : free_list) (void)hipEventDestroy(e);
+    free_list.clear();
+  }
+};
+
+// ---- per-call scratch ----------------------------------------------------------------------------------------------
+// The reference accepts blocking calls from many threads at once (each request has its own mutex and condition variable,
+// src/main/server.c:3732-3793).  Here every call leases a Scratch -- all the device buffers, flags and (for host-pointer
+// batches) the stream and pinned staging a call writes -- from a small pool owned by the handle, so concurrent calls
+// on one handle never share mutable device state and overlap on the GPU.  An enqueue-only (device-pointer) call
+// returns its lease with an event recorded on the caller's stream; the scratch is reused once that event is done.
+struct HostPipe {
+  void* h_in[2] = {nullptr, nullptr};    // [plen i32 x chunk | starts i64 x chunk | symbols u16 x sym_cap]
+  void* h_out[2] = {nullptr, nullptr};   // [first i64 x chunk | last i64 x chunk]
+  void* d_in[2] = {nullptr, nullptr};
+  void* d_out[2] = {nullptr, nullptr};
+  hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+  hipEvent_t in_done[2] = {nullptr, nullptr}, k_done[2] = {nullptr, nullptr}, out_done[2] = {nullptr, nullptr};
+  bool ready = false;
+};
+
+struct Scratch {
+  DeviceBuffer plen, pats, starts, first, last, noccs, noccs64, out_starts, offsets, scan[3];
+  DeviceBuffer rows, ch, occ, off;
+  DeviceBuffer keys, keys2, idx, idx2, sorttmp, pairs, tail, bsums;
+  int* d_flags = nullptr;       // [0] error flag, [1] "long ranges" flag of the row expansion, [2] tail item count
+  int64_t* d_total = nullptr;   // [0] rows to locate, [1] 1 = more rows than the caller's buffer holds
+  hipStream_t stream = nullptr; // host-pointer calls launch here (non-blocking stream: calls of different threads overlap)
+  hipEvent_t done = nullptr;
+  bool busy = false, in_flight = false;
+  HostPipe pipe;
+
+  int init() {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_flags), 8 * sizeof(int)));
+    HIP_TRY(hipMemset(d_flags, 0, 8 * sizeof(int)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_total), 4 * sizeof(int64_t)));
+    HIP_TRY(hipMemset(d_total, 0, 4 * sizeof(int64_t)));
+    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    return 0;
+  }
+  void release() {
+    for (DeviceBuffer* b : {&plen, &pats, &starts, &first, &last, &noccs, &noccs64, &out_starts, &offsets, &scan[0], &scan[1], &scan[2],
+                            &rows, &ch, &occ, &off, &keys, &keys2, &idx, &idx2, &sorttmp, &pairs, &tail, &bsums})
+      b->release();
+    for (int b = 0; b < 2; b++) {
+      if (pipe.h_in[b]) (void)hipHostFree(pipe.h_in[b]);
+      if (pipe.h_out[b]) (void)hipHostFree(pipe.h_out[b]);
+      if (pipe.d_in[b]) (void)hipFree(pipe.d_in[b]);
+      if (pipe.d_out[b]) (void)hipFree(pipe.d_out[b]);
+      if (pipe.in_done[b]) (void)hipEventDestroy(pipe.in_done[b]);
+      if (pipe.k_done[b]) (void)hipEventDestroy(pipe.k_done[b]);
+      if (pipe.out_done[b]) (void)hipEventDestroy(pipe.out_done[b]);
+    }
+    if (pipe.s_h2d) (void)hipStreamDestroy(pipe.s_h2d);
+    if (pipe.s_d2h) (void)hipStreamDestroy(pipe.s_d2h);
+    if (d_flags) (void)hipFree(d_flags);
+    if (d_total) (void)hipFree(d_total);
+    if (stream) (void)hipStreamDestroy(stream);
+    if (done) (void)hipEventDestroy(done);
   }
 };
 
@@ -97,7 +176,7 @@ struct KernelTimer {
 struct femto_amd_index {
   HostIndex host;
   int device = -1;
-  std::recursive_mutex mu;
+  std::mutex mu;   // mode switches, timers
   // device-resident index
   uint8_t* d_image = nullptr;
   DevNode* d_nodes = nullptr;
@@ -113,17 +192,21 @@ struct femto_amd_index {
   LaneNode* d_lnodes = nullptr;
   LaneSeq* d_lseqs = nullptr;
   OccEntry* d_occ = nullptr;
-  int* d_err = nullptr;
-  int mode = 1;  // 3: packed small-alphabet lines (default when the index has <= 8 characters); 1: lane-per-query kernels
-                 // (default otherwise); 2: flattened persistent-lane kernels; 0: wavefront-cooperative raw A/S/D walk
+  int mode = 1;  // 3: packed small-alphabet lines (default when the index has <= 8 characters); 4: two-level lines (<= 256
+                 // characters); 1: lane-per-query kernels on femto's wavelet tree (default otherwise); 2: flattened
+                 // persistent-lane kernels; 0: wavefront-cooperative raw A/S/D walk
   uint32_t* d_pack = nullptr;
   int64_t* d_pack_sa = nullptr;
   uint8_t* d_pack_code = nullptr;
   int64_t* d_pack_c = nullptr;
   int64_t* d_ktab = nullptr;
+  int64_t* d_ktab2 = nullptr;
+  int64_t ktab2_bytes = 0;
   uint8_t* d_txt = nullptr;
   int64_t* d_isa8 = nullptr;
   int64_t text_bytes = 0;
+  int64_t n_marks = 0;         // entries of pack_sa
+  int64_t p2_lines1 = 0, p2_lines2 = 0;
   uint32_t *d_p2_l1 = nullptr, *d_p2_l2 = nullptr;
   int64_t *d_p2_base = nullptr, *d_p2_c = nullptr;
   uint16_t *d_p2_code = nullptr, *d_p2_alpha = nullptr;
@@ -135,28 +218,22 @@ struct femto_amd_index {
   int blocks_per_cu_override = 0;
   DevIndex dev{};
   int64_t table_bytes = 0;
-  // scratch for the host-pointer API and the locate plan
-  DeviceBuffer s_plen, s_pats, s_starts, s_first, s_last, s_noccs, s_noccs64, s_out_starts, s_offsets, s_scan[3];
-  DeviceBuffer s_rows, s_ch, s_occ, s_off;
-  DeviceBuffer s_keys, s_keys2, s_idx, s_idx2, s_sorttmp, s_pairs, s_tail;
-  bool sort_queries = true;   // FEMTO_AMD_SORT=0 disables
+  DeviceBuffer open_scan[3];   // scan scratch of the derivations at open
+  // scratch pool (see Scratch)
+  std::mutex pool_mu;
+  std::condition_variable pool_cv;
+  std::vector<std::unique_ptr<Scratch>> pool;
+  int pool_max = 8;
+  std::unique_ptr<WorkerPool> workers;   // staging threads of host-pointer batches, created on first use
+  std::mutex workers_mu;                 // one staged batch at a time uses the worker pool
+  bool sort_queries = true;    // FEMTO_AMD_SORT=0 disables the suffix-order batch sort of the paths that use one
+  bool direct = true;          // FEMTO_AMD_DIRECT=0: modes 3/4 go back to the sorted-batch kernels of round 1
   uint8_t* d_dense = nullptr;  // alpha code -> dense sort digit (characters present in the text)
   int dense_bits = 8;
   double dense_sigma = 256;    // distinct characters of the indexed text
   int64_t sort_min = 4096;
   bool timing = false;
   KernelTimer t_count, t_locate;
-  // host-pointer batches: pinned double buffers + worker pool (host_pipeline.hpp), created on first use
-  struct HostPipe {
-    std::unique_ptr<WorkerPool> pool;
-    void* h_in[2] = {nullptr, nullptr};    // [plen i32 x chunk | starts i64 x chunk | symbols u16 x sym_cap]
-    void* h_out[2] = {nullptr, nullptr};   // [first i64 x chunk | last i64 x chunk]
-    void* d_in[2] = {nullptr, nullptr};
-    void* d_out[2] = {nullptr, nullptr};
-    hipStream_t s_h2d = nullptr, s_k = nullptr, s_d2h = nullptr;
-    hipEvent_t in_done[2] = {nullptr, nullptr}, k_done[2] = {nullptr, nullptr}, out_done[2] = {nullptr, nullptr};
-    bool ready = false;
-  } pipe;
   // range-split index (femto_amd_open_split): this handle holds the segment lines and the block images of
   // data blocks [split_blo[part], split_blo[part+1]); the other parts' slices are mapped from their owners
   int split_parts = 0, split_part = 0;
@@ -169,6 +246,67 @@ struct femto_amd_index {
 
 namespace {
 
+// lease of one Scratch for the duration of a call
+Scratch* scratch_acquire(femto_amd_index* ix, int* rc) {
+  std::unique_lock<std::mutex> lk(ix->pool_mu);
+  for (;;) {
+    Scratch* waiting = nullptr;
+    for (auto& s : ix->pool) {
+      if (s->busy) continue;
+      if (s->in_flight) {
+        if (hipEventQuery(s->done) != hipSuccess) {
+          (void)hipGetLastError();
+          waiting = s.get();
+          continue;
+        }
+        s->in_flight = false;
+      }
+      s->busy = true;
+      return s.get();
+    }
+    if (int(ix->pool.size()) < ix->pool_max) {
+      std::unique_ptr<Scratch> s(new (std::nothrow) Scratch());
+      if (!s) { *rc = set_err(FEMTO_AMD_ERR_MEM, "out of memory"); return nullptr; }
+      if ((*rc = s->init())) { s->release(); return nullptr; }
+      s->busy = true;
+      ix->pool.push_back(std::move(s));
+      return ix->pool.back().get();
+    }
+    if (waiting) {   // every scratch is leased or still in flight on some stream: wait for the device
+      waiting->busy = true;
+      lk.unlock();
+      (void)hipEventSynchronize(waiting->done);
+      lk.lock();
+      waiting->in_flight = false;
+      return waiting;
+    }
+    ix->pool_cv.wait(lk);
+  }
+}
+
+void scratch_release(femto_amd_index* ix, Scratch* s, bool async, hipStream_t stream) {
+  if (!s) return;
+  bool flying = false;
+  if (async) flying = hipEventRecord(s->done, stream) == hipSuccess;
+  {
+    std::lock_guard<std::mutex> lk(ix->pool_mu);
+    s->busy = false;
+    s->in_flight = flying;
+  }
+  ix->pool_cv.notify_one();
+}
+
+struct Lease {
+  femto_amd_index* ix;
+  Scratch* s = nullptr;
+  bool async = false;           // enqueue-only call: the work is still running when the lease ends
+  hipStream_t stream = nullptr;
+  int rc = 0;
+  explicit Lease(femto_amd_index* i) : ix(i) { s = scratch_acquire(ix, &rc); }
+  ~Lease() { scratch_release(ix, s, async, stream); }
+  Lease(const Lease&) = delete;
+  Lease& operator=(const Lease&) = delete;
+};
 // `slack` zero bytes follow the data: a damaged index (counts that disagree with the bits they summarise) can make a
 // kernel index a little past the end of the table it is walking -- at most one bucket's worth -- and must read
 // zeros there, not fault.  (Results for such an index are garbage either way, as they are in the reference.)
@@ -197,41 +335,119 @@ void block_image_range(const HostIndex& h, int64_t b0, int64_t b1, uint64_t* lo,
   *hi = h.block_off[size_t(b1) - 1] + h.block_len[size_t(b1) - 1];
 }
 
-int check_err_flag(femto_amd_index* ix, hipStream_t stream) {
+int check_err_flag(Scratch& S, hipStream_t stream) {
   int flag = 0;
-  HIP_TRY(hipMemcpyAsync(&flag, ix->d_err, sizeof(int), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(&flag, S.d_flags, sizeof(int), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   if (flag) {
-    HIP_TRY(hipMemsetAsync(ix->d_err, 0, sizeof(int), stream));
+    HIP_TRY(hipMemsetAsync(S.d_flags, 0, sizeof(int), stream));
     return set_err(FEMTO_AMD_ERR_PARAM, "pattern contains a character code >= ALPHA_SIZE (261)");
   }
   return 0;
 }
 
-// The locate plan can take over the clamp: when the count kernel stored (first,last) pairs, one pass splits them
-// into the caller's arrays AND computes the per-pattern row counts.
-struct PlanClamp {
+// timing events are created once and reused (the timer keeps a free list)
+bool timer_begin(femto_amd_index* ix, KernelTimer& t, hipStream_t stream, hipEvent_t* e0, hipEvent_t* e1) {
+  *e0 = *e1 = nullptr;
+  if (!ix->timing) return false;
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (!t.take(e0, e1)) return false;
+  if (hipEventRecord(*e0, stream) != hipSuccess) { t.give(*e0, *e1); *e0 = *e1 = nullptr; return false; }
+  return true;
+}
+void timer_end(femto_amd_index* ix, KernelTimer& t, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
+  if (!e0) return;
+  (void)hipEventRecord(e1, stream);
+  std::lock_guard<std::mutex> lk(ix->mu);
+  t.events.emplace_back(e0, e1);
+}
+
+// The locate plan that can ride along with a count: do_locate_query's clamp (src/main/server.c:4405-4415) and the
+// exclusive prefix sum of the row counts.  `done` is set when the count path produced noccs[], the block offsets in
+// S.bsums and S.d_total (the direct pipeline); otherwise the caller runs clamp_kernel + device_scan.
+struct Plan {
   int max_occs;
-  int32_t* noccs;
-  int64_t* noccs64;
+  int32_t* noccs;        // device, npats
+  int64_t* out_starts;   // device, npats + 1
+  int64_t capacity;      // rows the caller's offsets buffer holds (INT64_MAX when it is sized afterwards)
   bool done;
 };
 
-int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
-                       const int64_t* d_starts, int64_t* d_first, int64_t* d_last, hipStream_t stream, PlanClamp* plan = nullptr) {
+bool use_direct(const femto_amd_index* ix) {
+  return ix->direct && (ix->mode == 3 || ix->mode == 4) && ix->dev.ktab2 != nullptr;
+}
+
+int tail_setup(femto_amd_index* ix, Scratch& S, DevIndex& d, int64_t npats, hipStream_t stream) {
+  int rc = S.tail.reserve(size_t(npats) * sizeof(TailItem));
+  if (rc) return rc;
+  d.tail_items = S.tail.p;
+  d.tail_min = ix->mode == 3 ? 12 : 10;   // about where the walk + compare + ISA lookup beats stepping (1 / 2 lines a step)
+  if (const char* tm = getenv("FEMTO_AMD_TAIL_MIN")) d.tail_min = std::max(2, atoi(tm));
+  d.tail_count = S.d_flags + 2;
+  HIP_TRY(hipMemsetAsync(d.tail_count, 0, sizeof(int), stream));
+  return 0;
+}
+
+// modes 3/4, caller order, no sort (direct_kernels.hip.hpp)
+int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
+                        const int64_t* d_starts, int64_t* d_first, int64_t* d_last, hipStream_t stream, Plan* plan) {
+  const int64_t nblocks = (npats + kBlockThreads - 1) / kBlockThreads;
+  DevIndex d = ix->dev;
+  int rc;
+  const bool tail = d.txt != nullptr;
+  if (tail && (rc = tail_setup(ix, S, d, npats, stream))) return rc;
+  if (!tail) d.txt = nullptr;
+  int64_t* bsums = nullptr;
+  if (plan) {
+    if ((rc = S.bsums.reserve(size_t(nblocks + 1) * 8))) return rc;
+    bsums = S.bsums.as<int64_t>();
+  }
+  hipEvent_t e0, e1;
+  timer_begin(ix, ix->t_count, stream, &e0, &e1);
+  const dim3 grid{uint32_t(nblocks)}, block{uint32_t(kBlockThreads)};
+  const int mo = plan ? plan->max_occs : 0;
+  int32_t* noccs = plan ? plan->noccs : nullptr;
+  if (ix->mode == 3) {
+    if (plan) hipLaunchKernelGGL((count_direct_kernel<PackPolicy, true>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.d_flags, mo, noccs, bsums);
+    else hipLaunchKernelGGL((count_direct_kernel<PackPolicy, false>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.d_flags, mo, noccs, bsums);
+  } else {
+    if (plan) hipLaunchKernelGGL((count_direct_kernel<Pack2Policy, true>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.d_flags, mo, noccs, bsums);
+    else hipLaunchKernelGGL((count_direct_kernel<Pack2Policy, false>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.d_flags, mo, noccs, bsums);
+  }
+  HIP_TRY(hipGetLastError());
+  if (tail) {   // persistent grid: the number of handed-over patterns is only known on the device
+    const TailOut out{nullptr, d_first, d_last, noccs, bsums, mo};
+    const dim3 tgrid{uint32_t(std::min<int64_t>(nblocks, int64_t(ix->num_cus) * 8))};
+    if (ix->mode == 3)
+      hipLaunchKernelGGL(count_tail_kernel<PackPolicy>, tgrid, block, 0, stream, d, static_cast<const TailItem*>(S.tail.p), d.tail_count, d_plen, d_pats,
+                         d_starts, static_cast<const uint32_t*>(nullptr), static_cast<const uint64_t*>(nullptr), 1, 0, out, S.d_flags);
+    else
+      hipLaunchKernelGGL(count_tail_kernel<Pack2Policy>, tgrid, block, 0, stream, d, static_cast<const TailItem*>(S.tail.p), d.tail_count, d_plen, d_pats,
+                         d_starts, static_cast<const uint32_t*>(nullptr), static_cast<const uint64_t*>(nullptr), 1, 0, out, S.d_flags);
+    HIP_TRY(hipGetLastError());
+  }
+  timer_end(ix, ix->t_count, stream, e0, e1);
+  if (plan) {
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, stream, nblocks, bsums, S.d_total, plan->capacity, plan->out_starts + npats);
+    HIP_TRY(hipGetLastError());
+    plan->done = true;
+  }
+  return 0;
+}
+
+int launch_count_chunk(femto_amd_index* ix, Scratch& S, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
+                       const int64_t* d_starts, int64_t* d_first, int64_t* d_last, hipStream_t stream, Plan* plan = nullptr) {
   if (npats <= 0) return 0;
+  if (use_direct(ix)) return launch_count_direct(ix, S, npats, d_plen, d_pats, d_starts, d_first, d_last, stream, plan);
   constexpr int lanes_per_query = 2 * kGroupW;
   const int64_t threads = npats * lanes_per_query;
   const int64_t blocks = (threads + kBlockThreads - 1) / kBlockThreads;
   if (blocks > 0x7fffffffLL) return set_err(FEMTO_AMD_ERR_PARAM, "batch too large for one launch");
   bool split_pairs = false, tail_launch = false;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (ix->timing) {  // events bracket the search kernel itself (the suffix-order sort is a separate, small launch)
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    if (ix->mode != 1 && ix->mode != 3 && ix->mode != 4) HIP_TRY(hipEventRecord(e0, stream));
-  }
+  DevIndex d = ix->dev;
   if (ix->mode == 2) {
+    timer_begin(ix, ix->t_count, stream, &e0, &e1);
     int64_t lblocks = (npats + kBlockThreads - 1) / kBlockThreads;
     {  // persistent grid: exactly the resident blocks, lanes stride over the batch
       int per_cu = 0;
@@ -241,94 +457,81 @@ int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen
       if (ix->blocks_per_cu_override > 0) cap = int64_t(ix->num_cus) * ix->blocks_per_cu_override;
       if (lblocks > cap) lblocks = cap;
     }
-    hipLaunchKernelGGL((count_kernel_flat<1>), dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats,
-                         d_plen, d_pats, d_starts, d_first, d_last, ix->d_err);
+    hipLaunchKernelGGL((count_kernel_flat<1>), dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, d, npats,
+                         d_plen, d_pats, d_starts, d_first, d_last, S.d_flags);
   } else if (ix->mode == 1 || ix->mode == 3 || ix->mode == 4) {
     const int64_t lblocks = (npats + kBlockThreads - 1) / kBlockThreads;
     const uint32_t* perm = nullptr;
     if (ix->sort_queries && npats >= ix->sort_min && npats < (int64_t(1) << 32)) {
       // order the batch by pattern suffix (query_sort.hip); results still land at the caller's indexes
       int rc;
-      if ((rc = ix->s_keys.reserve(size_t(npats) * 8))) return rc;
-      if ((rc = ix->s_keys2.reserve(size_t(npats) * 8))) return rc;
-      if ((rc = ix->s_idx.reserve(size_t(npats) * 4))) return rc;
-      if ((rc = ix->s_idx2.reserve(size_t(npats) * 4))) return rc;
+      if ((rc = S.keys.reserve(size_t(npats) * 8))) return rc;
+      if ((rc = S.keys2.reserve(size_t(npats) * 8))) return rc;
+      if ((rc = S.idx.reserve(size_t(npats) * 4))) return rc;
+      if ((rc = S.idx2.reserve(size_t(npats) * 4))) return rc;
       // symbols that matter for the order: sigma^s >= 4 * npats
       int sort_syms = 1;
       for (double reach = ix->dense_sigma; reach < 4.0 * double(npats) && sort_syms < 64; reach *= ix->dense_sigma) sort_syms++;
       const size_t tb = query_sort_temp_bytes(npats, ix->dense_bits, sort_syms);
-      if ((rc = ix->s_sorttmp.reserve(tb ? tb : 16))) return rc;
-      HIP_TRY(query_sort(npats, d_plen, d_pats, d_starts, ix->d_dense, ix->dense_bits, sort_syms, ix->s_keys.as<uint64_t>(),
-                         ix->s_keys2.as<uint64_t>(), ix->s_idx.as<uint32_t>(), ix->s_idx2.as<uint32_t>(), ix->s_sorttmp.p, tb,
-                         stream));
-      perm = ix->s_idx2.as<uint32_t>();
+      if ((rc = S.sorttmp.reserve(tb ? tb : 16))) return rc;
+      HIP_TRY(query_sort(npats, d_plen, d_pats, d_starts, ix->d_dense, ix->dense_bits, sort_syms, S.keys.as<uint64_t>(),
+                         S.keys2.as<uint64_t>(), S.idx.as<uint32_t>(), S.idx2.as<uint32_t>(), S.sorttmp.p, tb, stream));
+      perm = S.idx2.as<uint32_t>();
     }
-    if (ix->timing) HIP_TRY(hipEventRecord(e0, stream));
     bool tail = false;
-    if ((ix->mode == 3 || ix->mode == 4) && perm && ix->dev.txt) {   // long patterns may be handed to count_tail_kernel
-      int rc2 = ix->s_tail.reserve(size_t(npats) * sizeof(TailItem));
+    if ((ix->mode == 3 || ix->mode == 4) && perm && d.txt) {   // long patterns may be handed to count_tail_kernel
+      int rc2 = tail_setup(ix, S, d, npats, stream);
       if (rc2) return rc2;
-      ix->dev.tail_items = ix->s_tail.p;
-      ix->dev.tail_min = ix->mode == 3 ? 12 : 10;   // about where the walk + compare + ISA lookup beats stepping (1 / 2 lines a step)
-      if (const char* tm = getenv("FEMTO_AMD_TAIL_MIN")) ix->dev.tail_min = std::max(2, atoi(tm));
-      ix->dev.tail_count = ix->d_err + 2;
-      HIP_TRY(hipMemsetAsync(ix->dev.tail_count, 0, sizeof(int), stream));
       tail = true;
     }
+    timer_begin(ix, ix->t_count, stream, &e0, &e1);   // events bracket the search kernel itself (the sort is separate)
     if (ix->mode == 3 && perm) {
-      int rc2 = ix->s_pairs.reserve(size_t(npats) * 16);
+      int rc2 = S.pairs.reserve(size_t(npats) * 16);
       if (rc2) return rc2;
-      hipLaunchKernelGGL(count_kernel_pack<true>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
-                         d_pats, d_starts, d_first, d_last, ix->d_err, perm, ix->s_keys2.as<uint64_t>(), ix->dense_bits,
-                         63 / ix->dense_bits, ix->s_pairs.as<longlong2>());
+      hipLaunchKernelGGL(count_kernel_pack<true>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, d, npats, d_plen,
+                         d_pats, d_starts, d_first, d_last, S.d_flags, perm, S.keys2.as<uint64_t>(), ix->dense_bits,
+                         63 / ix->dense_bits, S.pairs.as<longlong2>());
       split_pairs = true;
       tail_launch = tail;
     } else if (ix->mode == 4 && perm) {
-      int rc2 = ix->s_pairs.reserve(size_t(npats) * 16);
+      int rc2 = S.pairs.reserve(size_t(npats) * 16);
       if (rc2) return rc2;
-      hipLaunchKernelGGL(count_kernel_pack2<true>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
-                         d_pats, d_starts, d_first, d_last, ix->d_err, perm, ix->s_keys2.as<uint64_t>(), ix->dense_bits,
-                         63 / ix->dense_bits, ix->s_pairs.as<longlong2>());
+      hipLaunchKernelGGL(count_kernel_pack2<true>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, d, npats, d_plen,
+                         d_pats, d_starts, d_first, d_last, S.d_flags, perm, S.keys2.as<uint64_t>(), ix->dense_bits,
+                         63 / ix->dense_bits, S.pairs.as<longlong2>());
       split_pairs = true;
       tail_launch = tail;
     } else if (ix->mode == 4)
-      hipLaunchKernelGGL(count_kernel_pack2<false>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
-                         d_pats, d_starts, d_first, d_last, ix->d_err, perm, nullptr, 1, 0, nullptr);
+      hipLaunchKernelGGL(count_kernel_pack2<false>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, d, npats, d_plen,
+                         d_pats, d_starts, d_first, d_last, S.d_flags, perm, nullptr, 1, 0, nullptr);
     else if (ix->mode == 3)
-      hipLaunchKernelGGL(count_kernel_pack<false>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
-                         d_pats, d_starts, d_first, d_last, ix->d_err, perm, nullptr, 1, 0, nullptr);
+      hipLaunchKernelGGL(count_kernel_pack<false>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, d, npats, d_plen,
+                         d_pats, d_starts, d_first, d_last, S.d_flags, perm, nullptr, 1, 0, nullptr);
     else
-      hipLaunchKernelGGL(count_kernel_lane, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_plen,
-                         d_pats, d_starts, d_first, d_last, ix->d_err, perm);
+      hipLaunchKernelGGL(count_kernel_lane, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, d, npats, d_plen,
+                         d_pats, d_starts, d_first, d_last, S.d_flags, perm);
   } else {
-    hipLaunchKernelGGL((count_kernel<kGroupW>), dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats,
-                       d_plen, d_pats, d_starts, d_first, d_last, ix->d_err);
+    timer_begin(ix, ix->t_count, stream, &e0, &e1);
+    hipLaunchKernelGGL((count_kernel<kGroupW>), dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, stream, d, npats,
+                       d_plen, d_pats, d_starts, d_first, d_last, S.d_flags);
   }
   if (tail_launch) {
+    const TailOut out{S.pairs.as<longlong2>(), nullptr, nullptr, nullptr, nullptr, 0};
+    const dim3 tgrid{uint32_t(std::min<int64_t>((npats + kBlockThreads - 1) / kBlockThreads, int64_t(ix->num_cus) * 8))};
     if (ix->mode == 3)
-      hipLaunchKernelGGL(count_tail_kernel<PackPolicy>, dim3(uint32_t((npats + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, stream,
-                         ix->dev, static_cast<const TailItem*>(ix->s_tail.p), ix->dev.tail_count, d_plen, d_pats, d_starts,
-                         ix->s_idx2.as<uint32_t>(), ix->s_keys2.as<uint64_t>(), ix->dense_bits, 63 / ix->dense_bits, ix->s_pairs.as<longlong2>(),
-                         ix->d_err);
+      hipLaunchKernelGGL(count_tail_kernel<PackPolicy>, tgrid, dim3(kBlockThreads), 0, stream,
+                         d, static_cast<const TailItem*>(S.tail.p), d.tail_count, d_plen, d_pats, d_starts,
+                         static_cast<const uint32_t*>(S.idx2.as<uint32_t>()), static_cast<const uint64_t*>(S.keys2.as<uint64_t>()), ix->dense_bits, 63 / ix->dense_bits, out, S.d_flags);
     else
-      hipLaunchKernelGGL(count_tail_kernel<Pack2Policy>, dim3(uint32_t((npats + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, stream,
-                         ix->dev, static_cast<const TailItem*>(ix->s_tail.p), ix->dev.tail_count, d_plen, d_pats, d_starts,
-                         ix->s_idx2.as<uint32_t>(), ix->s_keys2.as<uint64_t>(), ix->dense_bits, 63 / ix->dense_bits, ix->s_pairs.as<longlong2>(),
-                         ix->d_err);
+      hipLaunchKernelGGL(count_tail_kernel<Pack2Policy>, tgrid, dim3(kBlockThreads), 0, stream,
+                         d, static_cast<const TailItem*>(S.tail.p), d.tail_count, d_plen, d_pats, d_starts,
+                         static_cast<const uint32_t*>(S.idx2.as<uint32_t>()), static_cast<const uint64_t*>(S.keys2.as<uint64_t>()), ix->dense_bits, 63 / ix->dense_bits, out, S.d_flags);
   }
   HIP_TRY(hipGetLastError());
-  if (ix->timing) {
-    HIP_TRY(hipEventRecord(e1, stream));
-    ix->t_count.events.emplace_back(e0, e1);
-  }
-  if (split_pairs && plan && d_last) {
-    hipLaunchKernelGGL(split_clamp_kernel, dim3(uint32_t((npats + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, stream,
-                       npats, ix->s_pairs.as<longlong2>(), d_first, d_last, plan->max_occs, plan->noccs, plan->noccs64);
-    HIP_TRY(hipGetLastError());
-    plan->done = true;
-  } else if (split_pairs) {
+  timer_end(ix, ix->t_count, stream, e0, e1);
+  if (split_pairs) {
     hipLaunchKernelGGL(split_pairs_kernel, dim3(uint32_t((npats + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, stream,
-                       npats, ix->s_pairs.as<longlong2>(), d_first, d_last);
+                       npats, S.pairs.as<longlong2>(), d_first, d_last);
     HIP_TRY(hipGetLastError());
   }
   return 0;
@@ -336,32 +539,32 @@ int launch_count_chunk(femto_amd_index* ix, int64_t npats, const int32_t* d_plen
 
 // An AQL dispatch carries at most 2^32 - 1 work-items per dimension: larger batches go out in chunks
 // (pattern starts are absolute, so only the per-pattern arrays are offset).
-int launch_count(femto_amd_index* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
-                 const int64_t* d_starts, int64_t* d_first, int64_t* d_last, hipStream_t stream, PlanClamp* plan = nullptr) {
+int launch_count(femto_amd_index* ix, Scratch& S, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
+                 const int64_t* d_starts, int64_t* d_first, int64_t* d_last, hipStream_t stream, Plan* plan = nullptr) {
   const int64_t max_chunk = ix->mode == 0 ? (int64_t(1) << 25) : (int64_t(1) << 31);
-  if (plan && npats <= max_chunk) return launch_count_chunk(ix, npats, d_plen, d_pats, d_starts, d_first, d_last, stream, plan);
+  if (plan && npats <= max_chunk) return launch_count_chunk(ix, S, npats, d_plen, d_pats, d_starts, d_first, d_last, stream, plan);
   for (int64_t off = 0; off < npats; off += max_chunk) {
     const int64_t cnt = std::min<int64_t>(max_chunk, npats - off);
-    int rc = launch_count_chunk(ix, cnt, d_plen + off, d_pats, d_starts + off, d_first + off, d_last ? d_last + off : nullptr, stream);
+    int rc = launch_count_chunk(ix, S, cnt, d_plen + off, d_pats, d_starts + off, d_first + off, d_last ? d_last + off : nullptr, stream);
     if (rc) return rc;
   }
   return 0;
 }
 
-int device_scan(femto_amd_index* ix, int64_t n, const int64_t* in, int64_t* out /* n+1 */, int level, hipStream_t stream) {
+int device_scan(DeviceBuffer* scan, int64_t n, const int64_t* in, int64_t* out /* n+1 */, int level, hipStream_t stream) {
   if (n <= 0) {
     HIP_TRY(hipMemsetAsync(out, 0, sizeof(int64_t), stream));
     return 0;
   }
   const int64_t tiles = (n + kScanTile - 1) / kScanTile;
   if (level >= 3) return set_err(FEMTO_AMD_ERR_PARAM, "scan too deep");
-  int rc = ix->s_scan[level].reserve(size_t(2 * (tiles + 1)) * sizeof(int64_t));
+  int rc = scan[level].reserve(size_t(2 * (tiles + 1)) * sizeof(int64_t));
   if (rc) return rc;
-  int64_t* tile_sums = ix->s_scan[level].as<int64_t>();
+  int64_t* tile_sums = scan[level].as<int64_t>();
   int64_t* tile_offs = tile_sums + tiles + 1;
   hipLaunchKernelGGL(scan_tile_kernel, dim3(uint32_t(tiles)), dim3(kScanBlock), 0, stream, n, in, out, tile_sums);
   if (tiles > 1) {
-    rc = device_scan(ix, tiles, tile_sums, tile_offs, level + 1, stream);
+    rc = device_scan(scan, tiles, tile_sums, tile_offs, level + 1, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(scan_add_kernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, stream, n, out, tile_offs);
   }
@@ -370,14 +573,68 @@ int device_scan(femto_amd_index* ix, int64_t n, const int64_t* in, int64_t* out 
   return 0;
 }
 
-int launch_locate(femto_amd_index* ix, int64_t npats, const int64_t* d_first, const int64_t* d_out_starts,
+// count + locate plan: on return (stream order) d_noccs[npats], d_out_starts[npats+1] and S.d_total are valid; with
+// the direct pipeline d_out_starts[0..npats) is filled by launch_plan_rows (which also expands the rows)
+int launch_count_plan(femto_amd_index* ix, Scratch& S, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
+                      const int64_t* d_starts, int64_t* d_first, int64_t* d_last, Plan* plan, hipStream_t stream) {
+  plan->done = false;
+  int rc;
+  if (npats <= 0) {
+    HIP_TRY(hipMemsetAsync(plan->out_starts, 0, sizeof(int64_t), stream));
+    HIP_TRY(hipMemsetAsync(S.d_total, 0, 2 * sizeof(int64_t), stream));
+    return 0;
+  }
+  if ((rc = launch_count(ix, S, npats, d_plen, d_pats, d_starts, d_first, d_last, stream, plan))) return rc;
+  if (plan->done) return 0;
+  if ((rc = S.noccs64.reserve(size_t(npats + 1) * 8))) return rc;
+  hipLaunchKernelGGL(clamp_kernel, dim3(uint32_t((npats + 255) / 256)), dim3(256), 0, stream, npats, d_first, d_last,
+                     plan->max_occs, plan->noccs, S.noccs64.as<int64_t>());
+  HIP_TRY(hipGetLastError());
+  if ((rc = device_scan(S.scan, npats, S.noccs64.as<int64_t>(), plan->out_starts, 0, stream))) return rc;
+  hipLaunchKernelGGL(copy_total_kernel, dim3(1), dim3(64), 0, stream, plan->out_starts + npats, S.d_total, plan->capacity);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// direct pipeline, after launch_count_plan: out_starts[] and -- when d_offsets is given -- the rows to locate
+int launch_plan_rows(femto_amd_index* ix, Scratch& S, int64_t npats, const int32_t* d_noccs, const int64_t* d_first,
+                     int64_t* d_out_starts, int64_t* d_offsets, int64_t capacity, hipStream_t stream) {
+  if (npats <= 0) return 0;
+  int* big_flag = S.d_flags + 1;
+  HIP_TRY(hipMemsetAsync(big_flag, 0, sizeof(int), stream));
+  const int64_t nblocks = (npats + kBlockThreads - 1) / kBlockThreads;
+  hipLaunchKernelGGL(plan_rows_kernel, dim3(uint32_t(nblocks)), dim3(kBlockThreads), 0, stream, npats, d_noccs, d_first,
+                     static_cast<const int64_t*>(S.bsums.as<int64_t>()), d_out_starts, d_offsets, capacity, big_flag);
+  if (d_offsets)
+    hipLaunchKernelGGL(plan_big_rows_kernel, dim3(uint32_t(std::min<int64_t>(nblocks, int64_t(ix->num_cus) * 8))), dim3(kBlockThreads), 0, stream, npats,
+                       d_first, static_cast<const int64_t*>(d_out_starts), static_cast<const int64_t*>(S.d_total), capacity, d_offsets, static_cast<const int*>(big_flag));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// direct pipeline: the walk of the rows plan_rows_kernel wrote; the row count is read from the device
+int launch_walk_device_total(femto_amd_index* ix, Scratch& S, int64_t* d_offsets, int64_t capacity, hipStream_t stream) {
+  hipEvent_t e0, e1;
+  timer_begin(ix, ix->t_locate, stream, &e0, &e1);
+  int64_t want = (capacity + kBlockThreads - 1) / kBlockThreads;
+  const dim3 grid{uint32_t(std::max<int64_t>(1, std::min<int64_t>(want, int64_t(ix->num_cus) * 8)))};
+  if (ix->mode == 3)
+    hipLaunchKernelGGL(locate_walk_kernel<PackPolicy>, grid, dim3(kBlockThreads), 0, stream, ix->dev, static_cast<const int64_t*>(S.d_total), capacity, d_offsets);
+  else
+    hipLaunchKernelGGL(locate_walk_kernel<Pack2Policy>, grid, dim3(kBlockThreads), 0, stream, ix->dev, static_cast<const int64_t*>(S.d_total), capacity, d_offsets);
+  HIP_TRY(hipGetLastError());
+  timer_end(ix, ix->t_locate, stream, e0, e1);
+  return 0;
+}
+
+int launch_locate(femto_amd_index* ix, Scratch& S, int64_t npats, const int64_t* d_first, const int64_t* d_out_starts,
                   int64_t total, int64_t* d_offsets, hipStream_t stream) {
   if (total <= 0) return 0;
   const int64_t threads = ix->mode == 0 ? total * kGroupW : total;   // mode 0 walks with a 32-lane group per row
   const int64_t blocks = (total * kGroupW + kBlockThreads - 1) / kBlockThreads;
   if (threads >= (int64_t(1) << 32)) return set_err(FEMTO_AMD_ERR_PARAM, "too many rows to locate in one call (2^32 work-items per launch): lower max_occs_each or split the batch");
   if (ix->mode == 3 || ix->mode == 4) {  // rows first (one thread per pattern), then the walk -- no per-row search for the owning pattern
-    int* big_flag = ix->d_err + 1;
+    int* big_flag = S.d_flags + 1;
     HIP_TRY(hipMemsetAsync(big_flag, 0, sizeof(int), stream));
     hipLaunchKernelGGL(expand_rows_kernel, dim3(uint32_t((npats + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, stream,
                        npats, d_first, d_out_starts, d_offsets, big_flag);
@@ -385,11 +642,7 @@ int launch_locate(femto_amd_index* ix, int64_t npats, const int64_t* d_first, co
                        npats, d_first, d_out_starts, total, d_offsets, big_flag);
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (ix->timing) {
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, stream));
-  }
+  timer_begin(ix, ix->t_locate, stream, &e0, &e1);
   if (ix->mode == 2) {
     int64_t lblocks = (total + kBlockThreads - 1) / kBlockThreads;
     {
@@ -416,10 +669,7 @@ int launch_locate(femto_amd_index* ix, int64_t npats, const int64_t* d_first, co
                        d_first, d_out_starts, total, d_offsets);
   }
   HIP_TRY(hipGetLastError());
-  if (ix->timing) {
-    HIP_TRY(hipEventRecord(e1, stream));
-    ix->t_locate.events.emplace_back(e0, e1);
-  }
+  timer_end(ix, ix->t_locate, stream, e0, e1);
   return 0;
 }
 
@@ -431,23 +681,23 @@ int validate_patterns(int64_t npats, const int32_t* plen, const int64_t* starts)
   return 0;
 }
 
-// copies a flat host pattern set to device scratch; returns total symbols
-int stage_patterns(femto_amd_index* ix, int64_t npats, const int32_t* plen, const uint16_t* pats, const int64_t* starts) {
+// copies a flat host pattern set to device scratch
+int stage_patterns(Scratch& S, int64_t npats, const int32_t* plen, const uint16_t* pats, const int64_t* starts) {
   int rc = validate_patterns(npats, plen, starts);
   if (rc) return rc;
   int64_t total = 0;
   for (int64_t i = 0; i < npats; i++) total = std::max<int64_t>(total, starts[i] + plen[i]);
-  if ((rc = ix->s_plen.reserve(size_t(npats + 1) * 4))) return rc;
-  if ((rc = ix->s_starts.reserve(size_t(npats + 1) * 8))) return rc;
-  if ((rc = ix->s_pats.reserve(size_t(total + 1) * 2))) return rc;
+  if (total && !pats) return set_err(FEMTO_AMD_ERR_PARAM, "null pattern symbols");
+  if ((rc = S.plen.reserve(size_t(npats + 1) * 4))) return rc;
+  if ((rc = S.starts.reserve(size_t(npats + 1) * 8))) return rc;
+  if ((rc = S.pats.reserve(size_t(total + 4) * 2))) return rc;
   if (npats) {
-    HIP_TRY(hipMemcpy(ix->s_plen.p, plen, size_t(npats) * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ix->s_starts.p, starts, size_t(npats) * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(S.plen.p, plen, size_t(npats) * 4, hipMemcpyHostToDevice, S.stream));
+    HIP_TRY(hipMemcpyAsync(S.starts.p, starts, size_t(npats) * 8, hipMemcpyHostToDevice, S.stream));
   }
-  if (total) HIP_TRY(hipMemcpy(ix->s_pats.p, pats, size_t(total) * 2, hipMemcpyHostToDevice));
+  if (total) HIP_TRY(hipMemcpyAsync(S.pats.p, pats, size_t(total) * 2, hipMemcpyHostToDevice, S.stream));
   return 0;
 }
-
 
 // first-steps table (ktab): as many key fields as give at most 2^21 entries; the ranges do not depend on which
 // layout computes them, so pack and pack2 share it
@@ -467,6 +717,73 @@ int build_ktab(femto_amd_index* ix, Kernel kernel) {
   ix->dev.ktab_bits = bits * syms;
   ix->dev.ktab_syms = syms;
   ix->table_bytes += int64_t(entries * 16);
+  return 0;
+}
+
+// Level table of the direct pipeline (direct_kernels.hip.hpp): all strings of at most K table characters, heap-numbered.
+// K: the deepest level has at most one entry per four rows (t^K <= rows / 4, never fewer than 2^16 entries) -- deeper
+// levels would mostly hold one-row or empty ranges -- and the whole table takes at most a quarter of the free HBM.
+// For a 2^30-row DNA index: K = 14, 5.7 GB (bowtie-style "ftab", but of femto's own ranges: x = first, y = last + 1).
+// FEMTO_AMD_KTAB_MB bounds the bytes instead, FEMTO_AMD_KTAB_SYMS pins K, FEMTO_AMD_KTAB=0 disables the table.
+template <class P>
+int build_ktab2(femto_amd_index* ix, int sigma, int nstop) {
+  if (ix->dev.ktab2) return 0;
+  if (const char* kt = getenv("FEMTO_AMD_KTAB")) if (atoi(kt) == 0) return 0;
+  const int64_t t = sigma - nstop;
+  if (t < 1) return 0;
+  int64_t level_cap = std::max<int64_t>(int64_t(1) << 16, ix->host.total_length / 4);
+  int64_t budget = INT64_MAX;
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = int64_t(free_b / 4);
+  }
+  if (const char* mb = getenv("FEMTO_AMD_KTAB_MB")) {
+    budget = std::max<int64_t>(1, atoll(mb)) << 20;
+    level_cap = INT64_MAX;
+  }
+  int want = -1;
+  if (const char* ks = getenv("FEMTO_AMD_KTAB_SYMS")) want = atoi(ks);
+  // level m holds t^m entries; entries(K) = 1 + t + ... + t^K
+  int K = 0;
+  int64_t entries = 1, level = 1;
+  std::vector<int64_t> lo{0};
+  for (;;) {
+    if (K >= 24 || level > (int64_t(1) << 40) / t) break;
+    const int64_t next_level = level * t;
+    if (want >= 0 ? K >= want : (next_level > level_cap || (entries + next_level) > budget / 16)) break;
+    lo.push_back(entries);
+    entries += next_level;
+    level = next_level;
+    K++;
+  }
+  if (K < 1) return 0;
+  if (hipMalloc(reinterpret_cast<void**>(&ix->d_ktab2), size_t(entries) * 16) != hipSuccess) {
+    (void)hipGetLastError();
+    ix->d_ktab2 = nullptr;
+    return FEMTO_AMD_ERR_MEM;
+  }
+  DevIndex d = ix->dev;
+  d.kt2_syms = K;
+  d.kt2_base = int32_t(t);
+  d.kt2_nstop = nstop;
+  longlong2* tab = reinterpret_cast<longlong2*>(ix->d_ktab2);
+  hipLaunchKernelGGL(ktab2_root_kernel, dim3(1), dim3(64), 0, nullptr, d, tab);
+  int64_t cnt = 1;
+  for (int m = 1; m <= K; m++) {
+    cnt *= t;
+    const int64_t chunk = int64_t(1) << 30;
+    for (int64_t o = 0; o < cnt; o += chunk) {
+      const int64_t cn = std::min(chunk, cnt - o);
+      hipLaunchKernelGGL(ktab2_level_kernel<P>, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, d, m, lo[size_t(m)] + o, cn, tab);
+    }
+  }
+  if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return set_err(FEMTO_AMD_ERR_INVALID, "level table build failed");
+  ix->dev.ktab2 = ix->d_ktab2;
+  ix->dev.kt2_syms = K;
+  ix->dev.kt2_base = int32_t(t);
+  ix->dev.kt2_nstop = nstop;
+  ix->ktab2_bytes = entries * 16;
+  ix->table_bytes += ix->ktab2_bytes;
   return 0;
 }
 
@@ -529,7 +846,7 @@ int build_pack(femto_amd_index* ix) {
                        ix->d_pack, counts.as<int64_t>(), stride);
     HIP_TRY(hipGetLastError());
     for (int c = 0; c < 9; c++)
-      if ((rc = device_scan(ix, nlines, counts.as<int64_t>() + c * stride, scans.as<int64_t>() + c * stride, 0, nullptr))) return rc;
+      if ((rc = device_scan(ix->open_scan, nlines, counts.as<int64_t>() + c * stride, scans.as<int64_t>() + c * stride, 0, nullptr))) return rc;
     hipLaunchKernelGGL(pack_counts_kernel, dim3(uint32_t((nlines + 255) / 256)), dim3(256), 0, nullptr, ix->dev, nlines, ix->d_pack,
                        scans.as<int64_t>(), stride);
     HIP_TRY(hipGetLastError());
@@ -543,7 +860,7 @@ int build_pack(femto_amd_index* ix) {
       hipLaunchKernelGGL(pack_recount_marks_kernel, dim3(uint32_t((nlines + 255) / 256)), dim3(256), 0, nullptr, nlines, ix->d_pack,
                          counts.as<int64_t>() + 8 * stride);
       HIP_TRY(hipGetLastError());
-      if ((rc = device_scan(ix, nlines, counts.as<int64_t>() + 8 * stride, scans.as<int64_t>() + 8 * stride, 0, nullptr))) return rc;
+      if ((rc = device_scan(ix->open_scan, nlines, counts.as<int64_t>() + 8 * stride, scans.as<int64_t>() + 8 * stride, 0, nullptr))) return rc;
       hipLaunchKernelGGL(pack_markcount_kernel, dim3(uint32_t((nlines + 255) / 256)), dim3(256), 0, nullptr, nlines, ix->d_pack,
                          scans.as<int64_t>() + 8 * stride);
       HIP_TRY(hipGetLastError());
@@ -563,6 +880,7 @@ int build_pack(femto_amd_index* ix) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipDeviceSynchronize());
+    ix->n_marks = nmarks;
     ix->pack_bytes = nlines * kPackLineWords * 4 + nmarks * 8;
     ix->table_bytes += ix->pack_bytes;
     return 0;
@@ -635,7 +953,7 @@ int build_pack2(femto_amd_index* ix) {
                        counts.as<int64_t>(), stride1);
     HIP_TRY(hipGetLastError());
     for (int c = 0; c < 17; c++)
-      if ((rc = device_scan(ix, nl1, counts.as<int64_t>() + c * stride1, scans.as<int64_t>() + c * stride1, 0, nullptr))) return rc;
+      if ((rc = device_scan(ix->open_scan, nl1, counts.as<int64_t>() + c * stride1, scans.as<int64_t>() + c * stride1, 0, nullptr))) return rc;
     hipLaunchKernelGGL(p2_l1_counts_kernel, dim3(uint32_t((nl1 + 255) / 256)), dim3(256), 0, nullptr, nl1, ix->d_p2_l1, scans.as<int64_t>(), stride1);
     HIP_TRY(hipGetLastError());
     d.p2_l1 = ix->d_p2_l1;
@@ -667,7 +985,7 @@ int build_pack2(femto_amd_index* ix) {
                        counts.as<int64_t>(), stride2);
     HIP_TRY(hipGetLastError());
     for (int c = 0; c < 16; c++)
-      if ((rc = device_scan(ix, nl2, counts.as<int64_t>() + c * stride2, scans.as<int64_t>() + c * stride2, 0, nullptr))) return rc;
+      if ((rc = device_scan(ix->open_scan, nl2, counts.as<int64_t>() + c * stride2, scans.as<int64_t>() + c * stride2, 0, nullptr))) return rc;
     hipLaunchKernelGGL(p2_l2_counts_kernel, dim3(uint32_t((nl2 + 255) / 256)), dim3(256), 0, nullptr, ix->dev, nl2, ix->d_p2_l2,
                        scans.as<int64_t>(), stride2);
     HIP_TRY(hipGetLastError());
@@ -684,7 +1002,7 @@ int build_pack2(femto_amd_index* ix) {
       if ((rc = counts.reserve(size_t(2 * stride1) * 8))) return rc;
       hipLaunchKernelGGL(p2_recount_marks_kernel, dim3(uint32_t((nl1 + 255) / 256)), dim3(256), 0, nullptr, nl1, ix->d_p2_l1, counts.as<int64_t>());
       HIP_TRY(hipGetLastError());
-      if ((rc = device_scan(ix, nl1, counts.as<int64_t>(), counts.as<int64_t>() + stride1, 0, nullptr))) return rc;
+      if ((rc = device_scan(ix->open_scan, nl1, counts.as<int64_t>(), counts.as<int64_t>() + stride1, 0, nullptr))) return rc;
       hipLaunchKernelGGL(p2_markcount_kernel, dim3(uint32_t((nl1 + 255) / 256)), dim3(256), 0, nullptr, nl1, ix->d_p2_l1,
                          counts.as<int64_t>() + stride1);
       HIP_TRY(hipGetLastError());
@@ -707,6 +1025,9 @@ int build_pack2(femto_amd_index* ix) {
     }
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipDeviceSynchronize());
+    ix->p2_lines1 = nl1;
+    ix->p2_lines2 = nl2;
+    if (sa_bytes) ix->n_marks = nmarks;
     ix->table_bytes += (nl1 + nl2) * 128 + sa_bytes;
     return 0;
   };
@@ -765,15 +1086,20 @@ constexpr int64_t kPipeChunk = int64_t(1) << 21;      // patterns per chunk
 constexpr int64_t kPipeSymCap = int64_t(1) << 26;     // symbols per chunk (128 MB)
 constexpr int64_t kPipeMin = int64_t(1) << 18;        // smaller batches take the plain path
 
-size_t pipe_in_bytes() { return size_t(kPipeChunk) * 12 + size_t(kPipeSymCap) * 2; }
+size_t pipe_in_bytes() { return size_t(kPipeChunk) * 12 + size_t(kPipeSymCap) * 2 + 64; }
 
-int pipe_init(femto_amd_index* ix) {
-  auto& P = ix->pipe;
+int pipe_init(femto_amd_index* ix, Scratch& S) {
+  {
+    std::lock_guard<std::mutex> lk(ix->workers_mu);
+    if (!ix->workers) {
+      int nthreads = int(std::thread::hardware_concurrency());
+      if (const char* e = getenv("FEMTO_AMD_HOST_THREADS")) nthreads = atoi(e);
+      nthreads = std::max(1, std::min(nthreads, 16));
+      ix->workers.reset(new WorkerPool(nthreads));
+    }
+  }
+  auto& P = S.pipe;
   if (P.ready) return 0;
-  int nthreads = int(std::thread::hardware_concurrency());
-  if (const char* e = getenv("FEMTO_AMD_HOST_THREADS")) nthreads = atoi(e);
-  nthreads = std::max(1, std::min(nthreads, 16));
-  P.pool.reset(new WorkerPool(nthreads));
   for (int b = 0; b < 2; b++) {
     HIP_TRY(hipHostMalloc(&P.h_in[b], pipe_in_bytes(), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(&P.h_out[b], size_t(kPipeChunk) * 16, hipHostMallocDefault));
@@ -784,28 +1110,9 @@ int pipe_init(femto_amd_index* ix) {
     HIP_TRY(hipEventCreateWithFlags(&P.out_done[b], hipEventDisableTiming));
   }
   HIP_TRY(hipStreamCreateWithFlags(&P.s_h2d, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&P.s_k, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&P.s_d2h, hipStreamNonBlocking));
   P.ready = true;
   return 0;
-}
-
-void pipe_release(femto_amd_index* ix) {
-  auto& P = ix->pipe;
-  for (int b = 0; b < 2; b++) {
-    if (P.h_in[b]) (void)hipHostFree(P.h_in[b]);
-    if (P.h_out[b]) (void)hipHostFree(P.h_out[b]);
-    if (P.d_in[b]) (void)hipFree(P.d_in[b]);
-    if (P.d_out[b]) (void)hipFree(P.d_out[b]);
-    if (P.in_done[b]) (void)hipEventDestroy(P.in_done[b]);
-    if (P.k_done[b]) (void)hipEventDestroy(P.k_done[b]);
-    if (P.out_done[b]) (void)hipEventDestroy(P.out_done[b]);
-  }
-  if (P.s_h2d) (void)hipStreamDestroy(P.s_h2d);
-  if (P.s_k) (void)hipStreamDestroy(P.s_k);
-  if (P.s_d2h) (void)hipStreamDestroy(P.s_d2h);
-  P.pool.reset();
-  P.ready = false;
 }
 
 // One chunk's patterns, in either calling convention, copied into a pinned buffer.  Returns the number of symbols
@@ -819,7 +1126,9 @@ struct HostBatch {
   const uint16_t* const* ptrs = nullptr;   // pointer-array form (parallel_count's alpha_t**)
 };
 
-int64_t pipe_stage(WorkerPool& pool, const HostBatch& hb, int64_t a, int64_t b, void* h_in) {
+int64_t pipe_stage(femto_amd_index* ix, const HostBatch& hb, int64_t a, int64_t b, void* h_in) {
+  WorkerPool& pool = *ix->workers;
+  std::lock_guard<std::mutex> wl(ix->workers_mu);   // the pool runs one job at a time; concurrent batches take turns per chunk
   const int64_t n = b - a;
   int32_t* o_plen = static_cast<int32_t*>(h_in);
   int64_t* o_starts = reinterpret_cast<int64_t*>(static_cast<char*>(h_in) + size_t(kPipeChunk) * 4);
@@ -886,138 +1195,166 @@ int64_t pipe_stage(WorkerPool& pool, const HostBatch& hb, int64_t a, int64_t b, 
 // returns 0, an error code, or -1: "not applicable, use the plain path"
 // With dev_first != nullptr the ranges stay on the device (whole-batch arrays dev_first / dev_last, the locate plan's
 // input) and nothing is copied back.
-int count_host_pipelined(femto_amd_index* ix, const HostBatch& hb, int64_t* first, int64_t* last, int64_t* dev_first = nullptr,
+int count_host_pipelined(femto_amd_index* ix, Scratch& S, const HostBatch& hb, int64_t* first, int64_t* last, int64_t* dev_first = nullptr,
                          int64_t* dev_last = nullptr) {
   if (hb.npats < kPipeMin) return -1;
   if (const char* e = getenv("FEMTO_AMD_HOST_PIPELINE")) if (atoi(e) == 0) return -1;
-  int rc = pipe_init(ix);
+  int rc = pipe_init(ix, S);
   if (rc) return rc;
-  auto& P = ix->pipe;
+  auto& P = S.pipe;
+  hipStream_t s_k = S.stream;
   const int64_t nchunks = (hb.npats + kPipeChunk - 1) / kPipeChunk;
+  // every exit leaves nothing in flight on the pinned buffers
   auto fail = [&](int code) {
-    (void)hipDeviceSynchronize();
+    (void)hipStreamSynchronize(P.s_h2d);
+    (void)hipStreamSynchronize(s_k);
+    (void)hipStreamSynchronize(P.s_d2h);
     return code;
   };
+#define PIPE_TRY(expr)                                                                                              \
+  do {                                                                                                              \
+    hipError_t e_ = (expr);                                                                                         \
+    if (e_ != hipSuccess)                                                                                           \
+      return fail(set_err(e_ == hipErrorOutOfMemory ? FEMTO_AMD_ERR_MEM : FEMTO_AMD_ERR_INVALID,                    \
+                          std::string(#expr) + ": " + hipGetErrorString(e_)));                                      \
+  } while (0)
   for (int64_t c = 0; c <= nchunks; c++) {
     if (c < nchunks) {
       const int b = int(c & 1);
       const int64_t a = c * kPipeChunk, e = std::min(hb.npats, a + kPipeChunk), n = e - a;
-      if (c >= 2) HIP_TRY(hipEventSynchronize(P.k_done[b]));  // chunk c-2 no longer reads d_in[b] (and h_in[b] was uploaded)
-      const int64_t nsym = pipe_stage(*P.pool, hb, a, e, P.h_in[b]);
+      if (c >= 2) PIPE_TRY(hipEventSynchronize(P.k_done[b]));  // chunk c-2 no longer reads d_in[b] (and h_in[b] was uploaded)
+      const int64_t nsym = pipe_stage(ix, hb, a, e, P.h_in[b]);
       if (nsym == -1) return fail(-1);
       if (nsym < -1) return fail(set_err(int(-2 - nsym), "negative pattern length/start or null pattern"));
       char* din = static_cast<char*>(P.d_in[b]);
       const char* hin = static_cast<const char*>(P.h_in[b]);
-      HIP_TRY(hipMemcpyAsync(din, hin, size_t(n) * 4, hipMemcpyHostToDevice, P.s_h2d));
-      HIP_TRY(hipMemcpyAsync(din + size_t(kPipeChunk) * 4, hin + size_t(kPipeChunk) * 4, size_t(n) * 8, hipMemcpyHostToDevice, P.s_h2d));
+      PIPE_TRY(hipMemcpyAsync(din, hin, size_t(n) * 4, hipMemcpyHostToDevice, P.s_h2d));
+      PIPE_TRY(hipMemcpyAsync(din + size_t(kPipeChunk) * 4, hin + size_t(kPipeChunk) * 4, size_t(n) * 8, hipMemcpyHostToDevice, P.s_h2d));
       if (nsym)
-        HIP_TRY(hipMemcpyAsync(din + size_t(kPipeChunk) * 12, hin + size_t(kPipeChunk) * 12, size_t(nsym) * 2, hipMemcpyHostToDevice, P.s_h2d));
-      HIP_TRY(hipEventRecord(P.in_done[b], P.s_h2d));
-      HIP_TRY(hipStreamWaitEvent(P.s_k, P.in_done[b], 0));
-      if (c >= 2) HIP_TRY(hipStreamWaitEvent(P.s_k, P.out_done[b], 0));  // results of chunk c-2 have left d_out[b]
+        PIPE_TRY(hipMemcpyAsync(din + size_t(kPipeChunk) * 12, hin + size_t(kPipeChunk) * 12, size_t(nsym) * 2, hipMemcpyHostToDevice, P.s_h2d));
+      PIPE_TRY(hipEventRecord(P.in_done[b], P.s_h2d));
+      PIPE_TRY(hipStreamWaitEvent(s_k, P.in_done[b], 0));
+      if (c >= 2) PIPE_TRY(hipStreamWaitEvent(s_k, P.out_done[b], 0));  // results of chunk c-2 have left d_out[b]
       int64_t* d_first = static_cast<int64_t*>(P.d_out[b]);
       int64_t* d_last = last ? d_first + kPipeChunk : nullptr;
       if (dev_first) {
         d_first = dev_first + a;
         d_last = dev_last + a;
       }
-      rc = launch_count(ix, n, reinterpret_cast<const int32_t*>(din), reinterpret_cast<const uint16_t*>(din + size_t(kPipeChunk) * 12),
-                        reinterpret_cast<const int64_t*>(din + size_t(kPipeChunk) * 4), d_first, d_last, P.s_k);
+      rc = launch_count(ix, S, n, reinterpret_cast<const int32_t*>(din), reinterpret_cast<const uint16_t*>(din + size_t(kPipeChunk) * 12),
+                        reinterpret_cast<const int64_t*>(din + size_t(kPipeChunk) * 4), d_first, d_last, s_k);
       if (rc) return fail(rc);
-      HIP_TRY(hipEventRecord(P.k_done[b], P.s_k));
+      PIPE_TRY(hipEventRecord(P.k_done[b], s_k));
       if (dev_first) continue;
-      HIP_TRY(hipStreamWaitEvent(P.s_d2h, P.k_done[b], 0));
+      PIPE_TRY(hipStreamWaitEvent(P.s_d2h, P.k_done[b], 0));
       char* hout = static_cast<char*>(P.h_out[b]);
-      HIP_TRY(hipMemcpyAsync(hout, d_first, size_t(n) * 8, hipMemcpyDeviceToHost, P.s_d2h));
-      if (last) HIP_TRY(hipMemcpyAsync(hout + size_t(kPipeChunk) * 8, d_last, size_t(n) * 8, hipMemcpyDeviceToHost, P.s_d2h));
-      HIP_TRY(hipEventRecord(P.out_done[b], P.s_d2h));
+      PIPE_TRY(hipMemcpyAsync(hout, d_first, size_t(n) * 8, hipMemcpyDeviceToHost, P.s_d2h));
+      if (last) PIPE_TRY(hipMemcpyAsync(hout + size_t(kPipeChunk) * 8, d_last, size_t(n) * 8, hipMemcpyDeviceToHost, P.s_d2h));
+      PIPE_TRY(hipEventRecord(P.out_done[b], P.s_d2h));
     }
     if (c >= 1 && !dev_first) {  // hand chunk c-1 back while chunk c is on its way
       const int b = int((c - 1) & 1);
       const int64_t a = (c - 1) * kPipeChunk, e = std::min(hb.npats, a + kPipeChunk), n = e - a;
-      HIP_TRY(hipEventSynchronize(P.out_done[b]));
+      PIPE_TRY(hipEventSynchronize(P.out_done[b]));
       const char* hout = static_cast<const char*>(P.h_out[b]);
-      P.pool->run([&](int t, int nt) {
+      std::lock_guard<std::mutex> wl(ix->workers_mu);
+      ix->workers->run([&](int t, int nt) {
         const int64_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
         memcpy(first + a + i0, hout + size_t(i0) * 8, size_t(i1 - i0) * 8);
         if (last) memcpy(last + a + i0, hout + size_t(kPipeChunk) * 8 + size_t(i0) * 8, size_t(i1 - i0) * 8);
       });
     }
   }
+#undef PIPE_TRY
   if (dev_first) {
-    HIP_TRY(hipStreamSynchronize(P.s_k));
+    HIP_TRY(hipStreamSynchronize(s_k));
     return 0;
   }
-  return check_err_flag(ix, P.s_k);
+  return check_err_flag(S, s_k);
 }
 
-// count (pipelined staging when the batch is large) + clamp + scan: fills s_first/s_last/s_noccs/s_out_starts
-int plan_host(femto_amd_index* ix, const HostBatch& hb, int max_occs_each, int64_t* total) {
+// count (pipelined staging when the batch is large) + clamp + scan: fills S.first/S.last/S.noccs/S.out_starts and
+// S.d_total; with the direct pipeline the rows are expanded into S.offsets as well (*rows_done)
+int plan_host(femto_amd_index* ix, Scratch& S, const HostBatch& hb, int max_occs_each, int64_t* total, bool* direct_plan) {
   const int64_t npats = hb.npats;
+  hipStream_t st = S.stream;
   int rc;
-  if ((rc = ix->s_first.reserve(size_t(npats + 1) * 8))) return rc;
-  if ((rc = ix->s_last.reserve(size_t(npats + 1) * 8))) return rc;
-  if ((rc = ix->s_noccs.reserve(size_t(npats + 1) * 4))) return rc;
-  if ((rc = ix->s_out_starts.reserve(size_t(npats + 2) * 8))) return rc;
-  if ((rc = ix->s_noccs64.reserve(size_t(npats + 1) * 8))) return rc;
-  rc = count_host_pipelined(ix, hb, nullptr, ix->s_last.as<int64_t>(), ix->s_first.as<int64_t>(), ix->s_last.as<int64_t>());
+  *direct_plan = false;
+  if ((rc = S.first.reserve(size_t(npats + 1) * 8))) return rc;
+  if ((rc = S.last.reserve(size_t(npats + 1) * 8))) return rc;
+  if ((rc = S.noccs.reserve(size_t(npats + 1) * 4))) return rc;
+  if ((rc = S.out_starts.reserve(size_t(npats + 2) * 8))) return rc;
+  Plan plan{max_occs_each, S.noccs.as<int32_t>(), S.out_starts.as<int64_t>(), INT64_MAX, false};
+  rc = count_host_pipelined(ix, S, hb, nullptr, S.last.as<int64_t>(), S.first.as<int64_t>(), S.last.as<int64_t>());
   if (rc == -1) {
     if (hb.ptrs) return -1;
-    if ((rc = stage_patterns(ix, npats, hb.plen, hb.flat, hb.starts))) return rc;
-    rc = launch_count(ix, npats, ix->s_plen.as<int32_t>(), ix->s_pats.as<uint16_t>(), ix->s_starts.as<int64_t>(),
-                      ix->s_first.as<int64_t>(), ix->s_last.as<int64_t>(), nullptr);
+    if ((rc = stage_patterns(S, npats, hb.plen, hb.flat, hb.starts))) return rc;
+    rc = launch_count_plan(ix, S, npats, S.plen.as<int32_t>(), S.pats.as<uint16_t>(), S.starts.as<int64_t>(),
+                           S.first.as<int64_t>(), S.last.as<int64_t>(), &plan, st);
+    if (rc) return rc;
+  } else {
+    if (rc) return rc;
+    // the chunks were counted without a plan: clamp + scan over the whole batch
+    if ((rc = S.noccs64.reserve(size_t(npats + 1) * 8))) return rc;
+    if (npats) {
+      hipLaunchKernelGGL(clamp_kernel, dim3(uint32_t((npats + 255) / 256)), dim3(256), 0, st, npats, S.first.as<int64_t>(),
+                         S.last.as<int64_t>(), max_occs_each, S.noccs.as<int32_t>(), S.noccs64.as<int64_t>());
+      HIP_TRY(hipGetLastError());
+    }
+    if ((rc = device_scan(S.scan, npats, S.noccs64.as<int64_t>(), S.out_starts.as<int64_t>(), 0, st))) return rc;
   }
-  if (rc) return rc;
-  if (npats) {
-    hipLaunchKernelGGL(clamp_kernel, dim3(uint32_t((npats + 255) / 256)), dim3(256), 0, nullptr, npats, ix->s_first.as<int64_t>(),
-                       ix->s_last.as<int64_t>(), max_occs_each, ix->s_noccs.as<int32_t>(), ix->s_noccs64.as<int64_t>());
-    HIP_TRY(hipGetLastError());
+  if (plan.done) {
+    *direct_plan = true;
+    if ((rc = launch_plan_rows(ix, S, npats, S.noccs.as<int32_t>(), S.first.as<int64_t>(), S.out_starts.as<int64_t>(), nullptr, INT64_MAX, st))) return rc;
   }
-  if ((rc = device_scan(ix, npats, ix->s_noccs64.as<int64_t>(), ix->s_out_starts.as<int64_t>(), 0, nullptr))) return rc;
-  if ((rc = check_err_flag(ix, nullptr))) return rc;
+  if ((rc = check_err_flag(S, st))) return rc;
   if (max_occs_each == 0 && npats) {
     // The reference fails here: a pattern with more than one match is clamped to an empty locate range and
     // setup_locate_range rejects it (src/main/server.c:4411-4421 -> ERR_PARAM); one match is returned whole.
     std::vector<int64_t> f((size_t(npats))), l((size_t(npats)));
-    HIP_TRY(hipMemcpy(f.data(), ix->s_first.p, size_t(npats) * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(l.data(), ix->s_last.p, size_t(npats) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(f.data(), S.first.p, size_t(npats) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(l.data(), S.last.p, size_t(npats) * 8, hipMemcpyDeviceToHost));
     for (int64_t i = 0; i < npats; i++)
       if (l[size_t(i)] - f[size_t(i)] > 0) return set_err(FEMTO_AMD_ERR_PARAM, "max_occs_each == 0 with a multi-match pattern: Error during query processing");
   }
-  HIP_TRY(hipMemcpy(total, ix->s_out_starts.as<int64_t>() + npats, 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(total, S.out_starts.as<int64_t>() + npats, 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// plan, walk, offsets copied to `dst` (host, room for the total) -- shared by the flat and the malloc forms
+int walk_to_host(femto_amd_index* ix, Scratch& S, int64_t npats, int64_t total, int64_t* dst) {
+  int rc;
+  if ((rc = S.offsets.reserve(size_t(total) * 8))) return rc;
+  if ((rc = launch_locate(ix, S, npats, S.first.as<int64_t>(), S.out_starts.as<int64_t>(), total, S.offsets.as<int64_t>(), S.stream))) return rc;
+  HIP_TRY(hipMemcpyAsync(dst, S.offsets.p, size_t(total) * 8, hipMemcpyDeviceToHost, S.stream));
+  HIP_TRY(hipStreamSynchronize(S.stream));
   return 0;
 }
 
 // one pass: plan, walk, offsets returned in one malloc()ed array (caller frees); noccs / out_starts optional
-int locate_host(femto_amd_index* ix, const HostBatch& hb, int max_occs_each, int32_t* noccs, int64_t* out_starts, int64_t** offsets_out,
+int locate_host(femto_amd_index* ix, Scratch& S, const HostBatch& hb, int max_occs_each, int32_t* noccs, int64_t* out_starts, int64_t** offsets_out,
                 int64_t* total_out) {
   int64_t total = 0;
-  int rc = plan_host(ix, hb, max_occs_each, &total);
+  bool direct_plan = false;
+  int rc = plan_host(ix, S, hb, max_occs_each, &total, &direct_plan);
   if (rc) return rc;
   const int64_t npats = hb.npats;
   if (total_out) *total_out = total;
-  if (noccs && npats) HIP_TRY(hipMemcpy(noccs, ix->s_noccs.p, size_t(npats) * 4, hipMemcpyDeviceToHost));
-  if (out_starts) HIP_TRY(hipMemcpy(out_starts, ix->s_out_starts.p, size_t(npats + 1) * 8, hipMemcpyDeviceToHost));
+  if (noccs && npats) HIP_TRY(hipMemcpy(noccs, S.noccs.p, size_t(npats) * 4, hipMemcpyDeviceToHost));
+  if (out_starts) HIP_TRY(hipMemcpy(out_starts, S.out_starts.p, size_t(npats + 1) * 8, hipMemcpyDeviceToHost));
   *offsets_out = nullptr;
   if (total == 0) return 0;
   int64_t* buf = static_cast<int64_t*>(malloc(size_t(total) * 8));
   if (!buf) return set_err(FEMTO_AMD_ERR_MEM, "malloc failed");
-  if ((rc = ix->s_offsets.reserve(size_t(total) * 8)) ||
-      (rc = launch_locate(ix, npats, ix->s_first.as<int64_t>(), ix->s_out_starts.as<int64_t>(), total, ix->s_offsets.as<int64_t>(), nullptr))) {
+  if ((rc = walk_to_host(ix, S, npats, total, buf))) {
     free(buf);
     return rc;
-  }
-  hipError_t he = hipMemcpy(buf, ix->s_offsets.p, size_t(total) * 8, hipMemcpyDeviceToHost);
-  if (he != hipSuccess) {
-    free(buf);
-    return set_err(FEMTO_AMD_ERR_INVALID, std::string("hipMemcpy: ") + hipGetErrorString(he));
   }
   *offsets_out = buf;
   return 0;
 }
 
 }  // namespace
-
 extern "C" {
 
 const char* femto_amd_last_error(void) { return g_last_error.c_str(); }
@@ -1029,7 +1366,16 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
   femto_amd_index* ix = new (std::nothrow) femto_amd_index();
   if (!ix) return set_err(FEMTO_AMD_ERR_MEM, "out of memory");
   Error err{0, ""};
-  int rc = ix->host.load(index_path, &err);
+  int rc;
+  try {
+    rc = ix->host.load(index_path, &err);
+  } catch (const std::bad_alloc&) {
+    rc = FEMTO_AMD_ERR_MEM;
+    err.msg = "out of memory while reading the index";
+  } catch (const std::exception& ex) {   // a size taken from a damaged header
+    rc = FEMTO_AMD_ERR_FORMAT;
+    err.msg = std::string("damaged index: ") + ex.what();
+  }
   if (rc) {
     delete ix;
     return set_err(rc, err.msg);
@@ -1075,11 +1421,13 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
         block_image_range(h, b0, b1, &i0, &i1);
         ix->split_seg_bytes = int64_t((s1 - s0) * kSegmentWords * 8);
         ix->split_image_bytes = int64_t(i1 - i0);
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_segs), size_t(ix->split_seg_bytes) + 256));
-        HIP_TRY(hipMemset(ix->d_segs, 0, size_t(ix->split_seg_bytes) + 256));
+        // the same zero slack as the full upload: a damaged index may make a kernel read up to a bucket's worth past a table
+        const size_t seg_slack = (size_t(h.b_size) / 511 + 4) * 128, img_slack = size_t(h.b_size) * size_t(h.text_size_bits) / 8 + 256;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_segs), size_t(ix->split_seg_bytes) + seg_slack));
+        HIP_TRY(hipMemset(ix->d_segs, 0, size_t(ix->split_seg_bytes) + seg_slack));
         if (s1 > s0) HIP_TRY(hipMemcpy(ix->d_segs, h.segs.data() + s0 * kSegmentWords, size_t(ix->split_seg_bytes), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_image), size_t(ix->split_image_bytes) + 256));  // + tail pad: mark reads load 16 bytes
-        HIP_TRY(hipMemset(ix->d_image, 0, size_t(ix->split_image_bytes) + 256));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_image), size_t(ix->split_image_bytes) + img_slack));
+        HIP_TRY(hipMemset(ix->d_image, 0, size_t(ix->split_image_bytes) + img_slack));
         if (i1 > i0) HIP_TRY(hipMemcpy(ix->d_image, h.image.data() + i0, size_t(ix->split_image_bytes), hipMemcpyHostToDevice));
         ix->table_bytes += ix->split_seg_bytes;
         ix->peer_segs.assign(size_t(nparts), nullptr);
@@ -1110,8 +1458,6 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
         ix->dense_sigma = sigma < 2 ? 2 : sigma;
         if ((r = upload(&ix->d_dense, dense, &ix->table_bytes))) return r;
       }
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_err), 4 * sizeof(int)));   // [0] error flag, [1] "long ranges" flag of the locate walk
-      HIP_TRY(hipMemset(ix->d_err, 0, 4 * sizeof(int)));
       DevIndex& d = ix->dev;
       d.image = ix->d_image;
       d.nodes = ix->d_nodes;
@@ -1168,6 +1514,11 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
       if ((ix->dev.pack || ix->dev.p2_l1) && (r = build_text(ix)) && r != FEMTO_AMD_ERR_MEM) return r;
       if (ix->dev.pack) ix->mode = 3;
       else if (ix->dev.p2_l1) ix->mode = 4;
+      if (const char* dm = getenv("FEMTO_AMD_DIRECT")) ix->direct = atoi(dm) != 0;
+      if (ix->dev.pack) r = build_ktab2<PackPolicy>(ix, ix->dev.pack_sigma, __builtin_popcount(ix->dev.pack_stop));
+      else if (ix->dev.p2_l1) r = build_ktab2<Pack2Policy>(ix, ix->dev.p2_sigma, int(ix->dev.p2_stop_below));
+      if (r && r != FEMTO_AMD_ERR_MEM) return r;
+      for (DeviceBuffer& b : ix->open_scan) b.release();
       if (const char* m = getenv("FEMTO_AMD_RANK_MODE")) {
         if (!strcmp(m, "raw")) ix->mode = 0;
         else if (!strcmp(m, "lane") && h.dir_regular) ix->mode = 1;
@@ -1177,7 +1528,13 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
       }
       return 0;
     };
-    rc = up();
+    try {
+      rc = up();
+    } catch (const std::bad_alloc&) {
+      rc = set_err(FEMTO_AMD_ERR_MEM, "out of memory");
+    } catch (const std::exception& ex) {
+      rc = set_err(FEMTO_AMD_ERR_FORMAT, std::string("damaged index: ") + ex.what());
+    }
     if (rc) {
       femto_amd_close(ix);
       return rc;
@@ -1213,7 +1570,7 @@ int femto_amd_split_attach(femto_amd_index_t* ix, int part, const void* handles)
   if (!ix || !handles) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
   if (ix->split_parts <= 0) return set_err(FEMTO_AMD_ERR_INVALID, "not a range-split index");
   if (part < 0 || part >= ix->split_parts) return set_err(FEMTO_AMD_ERR_PARAM, "bad part");
-  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  std::lock_guard<std::mutex> lk(ix->mu);
   if (ix->split_ready) return set_err(FEMTO_AMD_ERR_INVALID, "already committed");
   if (part == ix->split_part || ix->peer_segs[size_t(part)]) return FEMTO_AMD_OK;  // own slices / already mapped
   HIP_TRY(hipSetDevice(ix->device));
@@ -1236,7 +1593,7 @@ int femto_amd_split_attach_local(femto_amd_index_t* ix, femto_amd_index_t* owner
   if (!ix || !owner) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
   if (ix->split_parts <= 0 || owner->split_parts != ix->split_parts)
     return set_err(FEMTO_AMD_ERR_INVALID, "both handles must be parts of the same range-split");
-  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  std::lock_guard<std::mutex> lk(ix->mu);
   if (ix->split_ready) return set_err(FEMTO_AMD_ERR_INVALID, "already committed");
   const int part = owner->split_part;
   if (part == ix->split_part || ix->peer_segs[size_t(part)]) return FEMTO_AMD_OK;
@@ -1258,7 +1615,7 @@ int femto_amd_split_attach_local(femto_amd_index_t* ix, femto_amd_index_t* owner
 int femto_amd_split_commit(femto_amd_index_t* ix) {
   if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
   if (ix->split_parts <= 0) return set_err(FEMTO_AMD_ERR_INVALID, "not a range-split index");
-  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  std::lock_guard<std::mutex> lk(ix->mu);
   if (ix->split_ready) return FEMTO_AMD_OK;
   for (int p = 0; p < ix->split_parts; p++)
     if (!ix->peer_segs[size_t(p)] || !ix->peer_image[size_t(p)])
@@ -1312,9 +1669,12 @@ void femto_amd_close(femto_amd_index_t* ix) {
   if (!ix) return;
   if (ix->device >= 0) {
     (void)hipSetDevice(ix->device);
-    ix->t_count.drain();
-    ix->t_locate.drain();
-    pipe_release(ix);
+    ix->t_count.destroy();
+    ix->t_locate.destroy();
+    (void)hipDeviceSynchronize();   // enqueue-only calls may still be running on the caller's streams
+    for (auto& s : ix->pool) s->release();
+    ix->pool.clear();
+    ix->workers.reset();
     for (size_t p = 0; p < ix->peer_ipc.size(); p++)
       if (ix->peer_ipc[p]) {
         (void)hipIpcCloseMemHandle(ix->peer_segs[p]);
@@ -1334,7 +1694,6 @@ void femto_amd_close(femto_amd_index_t* ix) {
     (void)hipFree(ix->d_lnodes);
     (void)hipFree(ix->d_lseqs);
     (void)hipFree(ix->d_occ);
-    (void)hipFree(ix->d_err);
     (void)hipFree(ix->d_dense);
     (void)hipFree(ix->d_pack);
     (void)hipFree(ix->d_pack_sa);
@@ -1349,11 +1708,8 @@ void femto_amd_close(femto_amd_index_t* ix) {
     (void)hipFree(ix->d_p2_c);
     (void)hipFree(ix->d_p2_code);
     (void)hipFree(ix->d_p2_alpha);
-    for (DeviceBuffer* b : {&ix->s_plen, &ix->s_pats, &ix->s_starts, &ix->s_first, &ix->s_last, &ix->s_noccs,
-                            &ix->s_noccs64, &ix->s_out_starts, &ix->s_offsets, &ix->s_scan[0], &ix->s_scan[1],
-                            &ix->s_scan[2], &ix->s_rows, &ix->s_ch, &ix->s_occ, &ix->s_off, &ix->s_keys, &ix->s_keys2, &ix->s_idx,
-                            &ix->s_idx2, &ix->s_sorttmp, &ix->s_pairs, &ix->s_tail})
-      b->release();
+    (void)hipFree(ix->d_ktab2);
+    for (DeviceBuffer& b : ix->open_scan) b.release();
   }
   delete ix;
 }
@@ -1394,157 +1750,227 @@ int femto_amd_document_info(const femto_amd_index_t* ix, int64_t doc, const char
   return FEMTO_AMD_OK;
 }
 
+// Exceptions never cross the C boundary: bad_alloc -> ERR_MEM, anything else -> ERR_INVALID.
+#define API_BEGIN try {
+#define API_END                                                                            \
+  } catch (const std::bad_alloc&) {                                                        \
+    return set_err(FEMTO_AMD_ERR_MEM, "out of memory");                                    \
+  } catch (const std::exception& ex) {                                                     \
+    return set_err(FEMTO_AMD_ERR_INVALID, std::string("internal error: ") + ex.what());    \
+  } catch (...) {                                                                          \
+    return set_err(FEMTO_AMD_ERR_INVALID, "internal error");                               \
+  }
+
 int femto_amd_count_device(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
                            const int64_t* d_starts, int64_t* d_first, int64_t* d_last, void* stream) {
+  API_BEGIN
   if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
   int rc = ensure_device(ix);
   if (rc) return rc;
-  std::lock_guard<std::recursive_mutex> lk(ix->mu);
-  return launch_count(ix, npats, d_plen, d_pats, d_starts, d_first, d_last, static_cast<hipStream_t>(stream));
+  Lease L(ix);
+  if (!L.s) return L.rc;
+  L.async = true;
+  L.stream = static_cast<hipStream_t>(stream);
+  return launch_count(ix, *L.s, npats, d_plen, d_pats, d_starts, d_first, d_last, L.stream);
+  API_END
 }
 
 int femto_amd_count_flat(femto_amd_index_t* ix, int64_t npats, const int32_t* plen, const uint16_t* pats,
                          const int64_t* starts, int64_t* first, int64_t* last) {
+  API_BEGIN
   if (!ix || (npats && !first)) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
   int rc = ensure_device(ix);
   if (rc) return rc;
-  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  Lease L(ix);
+  if (!L.s) return L.rc;
+  Scratch& S = *L.s;
   if (npats && plen && starts && pats) {
     HostBatch hb;
     hb.npats = npats;
     hb.plen = plen;
     hb.flat = pats;
     hb.starts = starts;
-    rc = count_host_pipelined(ix, hb, first, last);
+    rc = count_host_pipelined(ix, S, hb, first, last);
     if (rc != -1) return rc;
   }
-  if ((rc = stage_patterns(ix, npats, plen, pats, starts))) return rc;
-  if ((rc = ix->s_first.reserve(size_t(npats + 1) * 8))) return rc;
-  if ((rc = ix->s_last.reserve(size_t(npats + 1) * 8))) return rc;
-  rc = launch_count(ix, npats, ix->s_plen.as<int32_t>(), ix->s_pats.as<uint16_t>(), ix->s_starts.as<int64_t>(),
-                    ix->s_first.as<int64_t>(), last ? ix->s_last.as<int64_t>() : nullptr, nullptr);
+  if ((rc = stage_patterns(S, npats, plen, pats, starts))) return rc;
+  if ((rc = S.first.reserve(size_t(npats + 1) * 8))) return rc;
+  if ((rc = S.last.reserve(size_t(npats + 1) * 8))) return rc;
+  rc = launch_count(ix, S, npats, S.plen.as<int32_t>(), S.pats.as<uint16_t>(), S.starts.as<int64_t>(),
+                    S.first.as<int64_t>(), last ? S.last.as<int64_t>() : nullptr, S.stream);
   if (rc) return rc;
-  if ((rc = check_err_flag(ix, nullptr))) return rc;
+  if ((rc = check_err_flag(S, S.stream))) return rc;
   if (npats) {
-    HIP_TRY(hipMemcpy(first, ix->s_first.p, size_t(npats) * 8, hipMemcpyDeviceToHost));
-    if (last) HIP_TRY(hipMemcpy(last, ix->s_last.p, size_t(npats) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(first, S.first.p, size_t(npats) * 8, hipMemcpyDeviceToHost, S.stream));
+    if (last) HIP_TRY(hipMemcpyAsync(last, S.last.p, size_t(npats) * 8, hipMemcpyDeviceToHost, S.stream));
+    HIP_TRY(hipStreamSynchronize(S.stream));
   }
   return FEMTO_AMD_OK;
+  API_END
 }
 
 int femto_amd_count_bytes(femto_amd_index_t* ix, int64_t npats, const int32_t* plen, const uint8_t* bytes,
                           const int64_t* starts, int64_t* first, int64_t* last) {
+  API_BEGIN
   int rc = validate_patterns(npats, plen, starts);
   if (rc) return rc;
   int64_t total = 0;
   for (int64_t i = 0; i < npats; i++) total = std::max<int64_t>(total, starts[i] + plen[i]);
+  if (total && !bytes) return set_err(FEMTO_AMD_ERR_PARAM, "null pattern bytes");
   std::vector<uint16_t> codes(size_t(total) + 1);
   for (int64_t i = 0; i < total; i++) codes[size_t(i)] = uint16_t(bytes[i]) + FEMTO_AMD_CHARACTER_OFFSET;
   return femto_amd_count_flat(ix, npats, plen, codes.data(), starts, first, last);
+  API_END
 }
 
 int femto_amd_parallel_count(femto_amd_index_t* ix, int npats, const int* plen, const uint16_t* const* pats,
                              int64_t* first, int64_t* last) {
+  API_BEGIN
   if (npats < 0 || (npats && (!plen || !pats))) return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
   if (ix && first && npats >= kPipeMin && ix->device >= 0) {  // large batches: gathered chunk by chunk into pinned memory
     int rc = ensure_device(ix);
     if (rc) return rc;
-    std::lock_guard<std::recursive_mutex> lk(ix->mu);
+    Lease L(ix);
+    if (!L.s) return L.rc;
     HostBatch hb;
     hb.npats = npats;
     hb.plen = plen;
     hb.ptrs = pats;
-    rc = count_host_pipelined(ix, hb, first, last);
+    rc = count_host_pipelined(ix, *L.s, hb, first, last);
     if (rc != -1) return rc;
   }
   std::vector<int64_t> starts(size_t(npats) + 1, 0);
   for (int i = 0; i < npats; i++) {
     if (plen[i] < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative pattern length");
+    if (plen[i] && !pats[i]) return set_err(FEMTO_AMD_ERR_PARAM, "null pattern");
     starts[size_t(i) + 1] = starts[size_t(i)] + plen[i];
   }
   std::vector<uint16_t> flat(size_t(starts[size_t(npats)]) + 1);
   for (int i = 0; i < npats; i++)  // patterns are copied, as setup_string_query does (src/main/server.c:691-695)
     if (plen[i]) memcpy(flat.data() + starts[size_t(i)], pats[i], size_t(plen[i]) * 2);
   return femto_amd_count_flat(ix, npats, plen, flat.data(), starts.data(), first, last);
+  API_END
 }
 
 int femto_amd_locate_plan_device(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
                                  const int64_t* d_starts, int max_occs_each, int64_t* d_first, int64_t* d_last,
                                  int32_t* d_noccs, int64_t* d_out_starts, void* stream_) {
+  API_BEGIN
   if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
   if (max_occs_each < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative max_occs_each");
   int rc = ensure_device(ix);
   if (rc) return rc;
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  std::lock_guard<std::recursive_mutex> lk(ix->mu);
-  if ((rc = ix->s_noccs64.reserve(size_t(npats + 1) * 8))) return rc;
-  PlanClamp pc{max_occs_each, d_noccs, ix->s_noccs64.as<int64_t>(), false};
-  if ((rc = launch_count(ix, npats, d_plen, d_pats, d_starts, d_first, d_last, stream, &pc))) return rc;
-  if (npats && !pc.done) {
-    hipLaunchKernelGGL(clamp_kernel, dim3(uint32_t((npats + 255) / 256)), dim3(256), 0, stream, npats, d_first, d_last,
-                       max_occs_each, d_noccs, ix->s_noccs64.as<int64_t>());
-    HIP_TRY(hipGetLastError());
-  }
-  return device_scan(ix, npats, ix->s_noccs64.as<int64_t>(), d_out_starts, 0, stream);
+  Lease L(ix);
+  if (!L.s) return L.rc;
+  L.async = true;
+  L.stream = static_cast<hipStream_t>(stream_);
+  Plan plan{max_occs_each, d_noccs, d_out_starts, INT64_MAX, false};
+  if ((rc = launch_count_plan(ix, *L.s, npats, d_plen, d_pats, d_starts, d_first, d_last, &plan, L.stream))) return rc;
+  if (plan.done) rc = launch_plan_rows(ix, *L.s, npats, d_noccs, d_first, d_out_starts, nullptr, INT64_MAX, L.stream);
+  return rc;
+  API_END
 }
 
 int femto_amd_locate_walk_device(femto_amd_index_t* ix, int64_t npats, const int64_t* d_first,
                                  const int64_t* d_out_starts, int64_t total, int64_t* d_offsets, void* stream) {
+  API_BEGIN
   if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
   int rc = ensure_device(ix);
   if (rc) return rc;
-  std::lock_guard<std::recursive_mutex> lk(ix->mu);
-  return launch_locate(ix, npats, d_first, d_out_starts, total, d_offsets, static_cast<hipStream_t>(stream));
+  Lease L(ix);
+  if (!L.s) return L.rc;
+  L.async = true;
+  L.stream = static_cast<hipStream_t>(stream);
+  return launch_locate(ix, *L.s, npats, d_first, d_out_starts, total, d_offsets, L.stream);
+  API_END
+}
+
+int femto_amd_locate_device(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
+                            const int64_t* d_starts, int max_occs_each, int64_t* d_first, int64_t* d_last,
+                            int32_t* d_noccs, int64_t* d_out_starts, int64_t* d_offsets, int64_t offsets_capacity,
+                            int64_t* d_total, void* stream_) {
+  API_BEGIN
+  if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
+  if (max_occs_each < 0 || offsets_capacity < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative max_occs_each / capacity");
+  if (npats && (!d_first || !d_last || !d_noccs || !d_out_starts || !d_total)) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  int rc = ensure_device(ix);
+  if (rc) return rc;
+  Lease L(ix);
+  if (!L.s) return L.rc;
+  Scratch& S = *L.s;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  L.async = true;
+  L.stream = stream;
+  Plan plan{max_occs_each, d_noccs, d_out_starts, offsets_capacity, false};
+  if ((rc = launch_count_plan(ix, S, npats, d_plen, d_pats, d_starts, d_first, d_last, &plan, stream))) return rc;
+  if (plan.done) {   // direct pipeline: one stream-ordered chain, nothing returns to the host
+    if ((rc = launch_plan_rows(ix, S, npats, d_noccs, d_first, d_out_starts, d_offsets, offsets_capacity, stream))) return rc;
+    if (offsets_capacity > 0 && d_offsets && (rc = launch_walk_device_total(ix, S, d_offsets, offsets_capacity, stream))) return rc;
+  } else {           // other kernel families size the walk on the host
+    int64_t tot[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(tot, S.d_total, sizeof tot, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const int64_t walk = std::min(tot[0], offsets_capacity);
+    if (walk == tot[0] && d_offsets && (rc = launch_locate(ix, S, npats, d_first, d_out_starts, walk, d_offsets, stream))) return rc;
+  }
+  HIP_TRY(hipMemcpyAsync(d_total, S.d_total, 2 * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
+  return FEMTO_AMD_OK;
+  API_END
 }
 
 int femto_amd_locate_flat(femto_amd_index_t* ix, int64_t npats, const int32_t* plen, const uint16_t* pats,
                           const int64_t* starts, int max_occs_each, int32_t* noccs, int64_t* out_starts,
                           int64_t* offsets, int64_t offsets_capacity, int64_t* total_out) {
+  API_BEGIN
   if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
   if (max_occs_each < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative max_occs_each");
   int rc = ensure_device(ix);
   if (rc) return rc;
   if (npats < 0 || (npats && (!plen || !starts))) return set_err(FEMTO_AMD_ERR_PARAM, "null pattern arrays");
   int64_t total = 0;
-  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  Lease L(ix);
+  if (!L.s) return L.rc;
+  Scratch& S = *L.s;
   HostBatch hb;
   hb.npats = npats;
   hb.plen = plen;
   hb.flat = pats;
   hb.starts = starts;
-  if ((rc = plan_host(ix, hb, max_occs_each, &total))) return rc;
+  bool direct_plan = false;
+  if ((rc = plan_host(ix, S, hb, max_occs_each, &total, &direct_plan))) return rc;
   if (total_out) *total_out = total;
-  if (noccs && npats) HIP_TRY(hipMemcpy(noccs, ix->s_noccs.p, size_t(npats) * 4, hipMemcpyDeviceToHost));
-  if (out_starts) HIP_TRY(hipMemcpy(out_starts, ix->s_out_starts.p, size_t(npats + 1) * 8, hipMemcpyDeviceToHost));
+  if (noccs && npats) HIP_TRY(hipMemcpy(noccs, S.noccs.p, size_t(npats) * 4, hipMemcpyDeviceToHost));
+  if (out_starts) HIP_TRY(hipMemcpy(out_starts, S.out_starts.p, size_t(npats + 1) * 8, hipMemcpyDeviceToHost));
   if (!offsets) return FEMTO_AMD_OK;
   if (offsets_capacity < total) return set_err(FEMTO_AMD_ERR_PARAM, "offsets buffer too small");
   if (total == 0) return FEMTO_AMD_OK;
-  if ((rc = ix->s_offsets.reserve(size_t(total) * 8))) return rc;
-  rc = launch_locate(ix, npats, ix->s_first.as<int64_t>(), ix->s_out_starts.as<int64_t>(), total, ix->s_offsets.as<int64_t>(), nullptr);
-  if (rc) return rc;
-  HIP_TRY(hipMemcpy(offsets, ix->s_offsets.p, size_t(total) * 8, hipMemcpyDeviceToHost));
-  return FEMTO_AMD_OK;
+  return walk_to_host(ix, S, npats, total, offsets);
+  API_END
 }
 
 int femto_amd_locate_flat_alloc(femto_amd_index_t* ix, int64_t npats, const int32_t* plen, const uint16_t* pats,
                                 const int64_t* starts, int max_occs_each, int32_t* noccs, int64_t* out_starts,
                                 int64_t** offsets_out, int64_t* total_out) {
+  API_BEGIN
   if (!ix || !offsets_out) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
   if (max_occs_each < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative max_occs_each");
   int rc = ensure_device(ix);
   if (rc) return rc;
   if (npats < 0 || (npats && (!plen || !starts))) return set_err(FEMTO_AMD_ERR_PARAM, "null pattern arrays");
-  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  Lease L(ix);
+  if (!L.s) return L.rc;
   HostBatch hb;
   hb.npats = npats;
   hb.plen = plen;
   hb.flat = pats;
   hb.starts = starts;
-  return locate_host(ix, hb, max_occs_each, noccs, out_starts, offsets_out, total_out);
+  return locate_host(ix, *L.s, hb, max_occs_each, noccs, out_starts, offsets_out, total_out);
+  API_END
 }
 
 int femto_amd_parallel_locate(femto_amd_index_t* ix, int npats, const int* plen, const uint16_t* const* pats,
                               int max_occs_each, int* noccs, int64_t** offsets) {
+  API_BEGIN
   if (npats < 0 || (npats && (!plen || !pats || !noccs || !offsets))) return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
   if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
   if (max_occs_each < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative max_occs_each");
@@ -1554,16 +1980,18 @@ int femto_amd_parallel_locate(femto_amd_index_t* ix, int npats, const int* plen,
   int64_t* all = nullptr;
   int64_t total = 0;
   {
-    std::lock_guard<std::recursive_mutex> lk(ix->mu);
+    Lease L(ix);
+    if (!L.s) return L.rc;
     HostBatch hb;
     hb.npats = npats;
     hb.plen = plen;
     hb.ptrs = pats;
-    rc = locate_host(ix, hb, max_occs_each, noccs, ostarts.data(), &all, &total);
+    rc = locate_host(ix, *L.s, hb, max_occs_each, noccs, ostarts.data(), &all, &total);
     if (rc == -1) {  // small batch: flatten here (patterns are copied, as setup_string_query does, server.c:691-695)
       std::vector<int64_t> starts(size_t(npats) + 1, 0);
       for (int i = 0; i < npats; i++) {
         if (plen[i] < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative pattern length");
+        if (plen[i] && !pats[i]) return set_err(FEMTO_AMD_ERR_PARAM, "null pattern");
         starts[size_t(i) + 1] = starts[size_t(i)] + plen[i];
       }
       std::vector<uint16_t> flat(size_t(starts[size_t(npats)]) + 1);
@@ -1572,7 +2000,7 @@ int femto_amd_parallel_locate(femto_amd_index_t* ix, int npats, const int* plen,
       hb.ptrs = nullptr;
       hb.flat = flat.data();
       hb.starts = starts.data();
-      rc = locate_host(ix, hb, max_occs_each, noccs, ostarts.data(), &all, &total);
+      rc = locate_host(ix, *L.s, hb, max_occs_each, noccs, ostarts.data(), &all, &total);
     }
     if (rc) return rc;
   }
@@ -1590,32 +2018,37 @@ int femto_amd_parallel_locate(femto_amd_index_t* ix, int npats, const int* plen,
   }
   free(all);
   return FEMTO_AMD_OK;
+  API_END
 }
 
 int femto_amd_parallel_locate_range(femto_amd_index_t* ix, int64_t first, int64_t last, int64_t* offsets) {
+  API_BEGIN
   if (!ix || !offsets) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
   int rc = ensure_device(ix);
   if (rc) return rc;
   if (first < 0 || last < first || last >= ix->host.total_length)
     return set_err(FEMTO_AMD_ERR_PARAM, "row range outside the index");   // the reference has no query to set up (server.c:4061)
-  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  Lease L(ix);
+  if (!L.s) return L.rc;
+  Scratch& S = *L.s;
   const int64_t max_chunk = int64_t(1) << 26;   // rows per launch (bounded scratch; far below the 2^32 work-item limit)
-  if ((rc = ix->s_first.reserve(16))) return rc;
-  if ((rc = ix->s_out_starts.reserve(32))) return rc;
+  if ((rc = S.first.reserve(16))) return rc;
+  if ((rc = S.out_starts.reserve(32))) return rc;
   for (int64_t at = first; at <= last; at += max_chunk) {
     const int64_t cnt = std::min<int64_t>(max_chunk, last - at + 1);
     const int64_t os[2] = {0, cnt};
-    HIP_TRY(hipMemcpy(ix->s_first.p, &at, 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ix->s_out_starts.p, os, 16, hipMemcpyHostToDevice));
-    if ((rc = ix->s_offsets.reserve(size_t(cnt) * 8))) return rc;
-    if ((rc = launch_locate(ix, 1, ix->s_first.as<int64_t>(), ix->s_out_starts.as<int64_t>(), cnt, ix->s_offsets.as<int64_t>(), nullptr))) return rc;
-    HIP_TRY(hipMemcpy(offsets + (at - first), ix->s_offsets.p, size_t(cnt) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(S.first.p, &at, 8, hipMemcpyHostToDevice, S.stream));
+    HIP_TRY(hipMemcpyAsync(S.out_starts.p, os, 16, hipMemcpyHostToDevice, S.stream));
+    HIP_TRY(hipStreamSynchronize(S.stream));
+    if ((rc = walk_to_host(ix, S, 1, cnt, offsets + (at - first)))) return rc;
   }
   return FEMTO_AMD_OK;
+  API_END
 }
 
 int femto_amd_block_requests(femto_amd_index_t* ix, int64_t n, const int64_t* rows, const uint16_t* ch_in,
                              uint16_t* ch_out, int32_t* occ_out, int64_t* off_out) {
+  API_BEGIN
   if (!ix || (n && !rows)) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
   int rc = ensure_device(ix);
   if (rc) return rc;
@@ -1625,41 +2058,41 @@ int femto_amd_block_requests(femto_amd_index_t* ix, int64_t n, const int64_t* ro
     if (ch_in && ch_in[i] >= kAlphaSize) return set_err(FEMTO_AMD_ERR_PARAM, "character out of range");
   }
   if (n == 0) return FEMTO_AMD_OK;
-  std::lock_guard<std::recursive_mutex> lk(ix->mu);
-  if ((rc = ix->s_rows.reserve(size_t(n) * 8))) return rc;
-  if ((rc = ix->s_ch.reserve(size_t(n) * 4))) return rc;
-  if ((rc = ix->s_occ.reserve(size_t(n) * 8))) return rc;
-  if ((rc = ix->s_off.reserve(size_t(n) * 8))) return rc;
-  HIP_TRY(hipMemcpy(ix->s_rows.p, rows, size_t(n) * 8, hipMemcpyHostToDevice));
+  Lease L(ix);
+  if (!L.s) return L.rc;
+  Scratch& S = *L.s;
+  hipStream_t st = S.stream;
+  if ((rc = S.rows.reserve(size_t(n) * 8))) return rc;
+  if ((rc = S.ch.reserve(size_t(n) * 4))) return rc;
+  if ((rc = S.occ.reserve(size_t(n) * 8))) return rc;
+  if ((rc = S.off.reserve(size_t(n) * 8))) return rc;
+  HIP_TRY(hipMemcpyAsync(S.rows.p, rows, size_t(n) * 8, hipMemcpyHostToDevice, st));
   uint16_t* d_chin = nullptr;
-  uint16_t* d_chout = ix->s_ch.as<uint16_t>();
+  uint16_t* d_chout = S.ch.as<uint16_t>();
   if (ch_in) {
-    d_chin = ix->s_ch.as<uint16_t>() + n;
-    HIP_TRY(hipMemcpy(d_chin, ch_in, size_t(n) * 2, hipMemcpyHostToDevice));
+    d_chin = S.ch.as<uint16_t>() + n;
+    HIP_TRY(hipMemcpyAsync(d_chin, ch_in, size_t(n) * 2, hipMemcpyHostToDevice, st));
   }
   const int64_t blocks = (n * kGroupW + kBlockThreads - 1) / kBlockThreads;
   if (ix->mode == 4)
     hipLaunchKernelGGL(block_request_kernel_pack2, dim3(uint32_t((n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads),
-                       0, nullptr, ix->dev, n, ix->s_rows.as<int64_t>(), d_chin, d_chout, ix->s_occ.as<int64_t>(),
-                       ix->s_off.as<int64_t>());
+                       0, st, ix->dev, n, S.rows.as<int64_t>(), d_chin, d_chout, S.occ.as<int64_t>(), S.off.as<int64_t>());
   else if (ix->mode == 3)
     hipLaunchKernelGGL(block_request_kernel_pack, dim3(uint32_t((n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads),
-                       0, nullptr, ix->dev, n, ix->s_rows.as<int64_t>(), d_chin, d_chout, ix->s_occ.as<int64_t>(),
-                       ix->s_off.as<int64_t>());
+                       0, st, ix->dev, n, S.rows.as<int64_t>(), d_chin, d_chout, S.occ.as<int64_t>(), S.off.as<int64_t>());
   else if (ix->mode >= 1)
     hipLaunchKernelGGL(block_request_kernel_lane, dim3(uint32_t((n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads),
-                       0, nullptr, ix->dev, n, ix->s_rows.as<int64_t>(), d_chin, d_chout, ix->s_occ.as<int64_t>(),
-                       ix->s_off.as<int64_t>());
+                       0, st, ix->dev, n, S.rows.as<int64_t>(), d_chin, d_chout, S.occ.as<int64_t>(), S.off.as<int64_t>());
   else
-    hipLaunchKernelGGL((block_request_kernel<kGroupW>), dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, nullptr, ix->dev, n,
-                       ix->s_rows.as<int64_t>(), d_chin, d_chout, ix->s_occ.as<int64_t>(), ix->s_off.as<int64_t>());
+    hipLaunchKernelGGL((block_request_kernel<kGroupW>), dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, st, ix->dev, n,
+                       S.rows.as<int64_t>(), d_chin, d_chout, S.occ.as<int64_t>(), S.off.as<int64_t>());
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
   std::vector<uint16_t> chs((size_t(n)));
   std::vector<int64_t> occ((size_t(n)));
-  HIP_TRY(hipMemcpy(chs.data(), d_chout, size_t(n) * 2, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(occ.data(), ix->s_occ.p, size_t(n) * 8, hipMemcpyDeviceToHost));
-  if (off_out) HIP_TRY(hipMemcpy(off_out, ix->s_off.p, size_t(n) * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpyAsync(chs.data(), d_chout, size_t(n) * 2, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(occ.data(), S.occ.p, size_t(n) * 8, hipMemcpyDeviceToHost, st));
+  if (off_out) HIP_TRY(hipMemcpyAsync(off_out, S.off.p, size_t(n) * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   if (ch_out) memcpy(ch_out, chs.data(), size_t(n) * 2);
   if (occ_out) {
     // occs_in_block = Occ - (C[ch] + block_occs[ch][block])   (HDR_BACK sum, src/main/index.c:1740-1746)
@@ -1674,10 +2107,12 @@ int femto_amd_block_requests(femto_amd_index_t* ix, int64_t n, const int64_t* ro
     }
   }
   return FEMTO_AMD_OK;
+  API_END
 }
 
 int femto_amd_forward_steps(femto_amd_index_t* ix, int64_t n, const int64_t* rows, uint16_t* ch_out, int64_t* row_out,
                             int64_t* off_out) {
+  API_BEGIN
   if (!ix || (n && (!rows || !ch_out || !row_out || !off_out))) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
   int rc = ensure_device(ix);
   if (rc) return rc;
@@ -1686,21 +2121,102 @@ int femto_amd_forward_steps(femto_amd_index_t* ix, int64_t n, const int64_t* row
   for (int64_t i = 0; i < n; i++)
     if (rows[i] < 0 || rows[i] >= ix->host.total_length) return set_err(FEMTO_AMD_ERR_PARAM, "row out of range");
   if (n == 0) return FEMTO_AMD_OK;
-  std::lock_guard<std::recursive_mutex> lk(ix->mu);
-  if ((rc = ix->s_rows.reserve(size_t(n) * 8))) return rc;
-  if ((rc = ix->s_ch.reserve(size_t(n) * 4))) return rc;
-  if ((rc = ix->s_occ.reserve(size_t(n) * 8))) return rc;
-  if ((rc = ix->s_off.reserve(size_t(n) * 8))) return rc;
-  HIP_TRY(hipMemcpy(ix->s_rows.p, rows, size_t(n) * 8, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(forward_kernel, dim3(uint32_t((n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, nullptr,
-                     ix->dev, n, ix->s_rows.as<int64_t>(), ix->s_ch.as<uint16_t>(), ix->s_occ.as<int64_t>(),
-                     ix->s_off.as<int64_t>());
+  Lease L(ix);
+  if (!L.s) return L.rc;
+  Scratch& S = *L.s;
+  hipStream_t st = S.stream;
+  if ((rc = S.rows.reserve(size_t(n) * 8))) return rc;
+  if ((rc = S.ch.reserve(size_t(n) * 4))) return rc;
+  if ((rc = S.occ.reserve(size_t(n) * 8))) return rc;
+  if ((rc = S.off.reserve(size_t(n) * 8))) return rc;
+  HIP_TRY(hipMemcpyAsync(S.rows.p, rows, size_t(n) * 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(forward_kernel, dim3(uint32_t((n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, st,
+                     ix->dev, n, S.rows.as<int64_t>(), S.ch.as<uint16_t>(), S.occ.as<int64_t>(), S.off.as<int64_t>());
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(ch_out, ix->s_ch.p, size_t(n) * 2, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(row_out, ix->s_occ.p, size_t(n) * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(off_out, ix->s_off.p, size_t(n) * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpyAsync(ch_out, S.ch.p, size_t(n) * 2, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(row_out, S.occ.p, size_t(n) * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(off_out, S.off.p, size_t(n) * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   return FEMTO_AMD_OK;
+  API_END
+}
+
+// Compulsory traffic of a batch: runs count (+ clamp + scan) and then the row expansion + locate walk with the line
+// trace switched on and reports, per traced array, how many DISTINCT 128-byte lines each phase loaded.
+int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
+                          const int64_t* d_starts, int max_occs_each, int64_t* count_lines /* [8] */,
+                          int64_t* locate_lines /* [8] */, int64_t* rows_out) {
+  API_BEGIN
+  if (!ix || !count_lines || !locate_lines) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  int rc = ensure_device(ix);
+  if (rc) return rc;
+  if (npats <= 0 || npats >= (int64_t(1) << 31)) return set_err(FEMTO_AMD_ERR_PARAM, "trace: 1 .. 2^31-1 patterns");
+  Lease L(ix);
+  if (!L.s) return L.rc;
+  Scratch& S = *L.s;
+  hipStream_t st = S.stream;
+  const int64_t n = ix->host.total_length;
+  int64_t region_lines[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  region_lines[kTracePack] = ix->dev.pack ? (n + kPackRows - 1) / kPackRows : 0;
+  region_lines[kTraceKtab] = ix->ktab2_bytes / 128 + 1;
+  region_lines[kTraceSa] = ix->n_marks / 16 + 1;
+  region_lines[kTraceL1] = ix->p2_lines1;
+  region_lines[kTraceL2] = ix->p2_lines2;
+  region_lines[kTraceTxt] = ix->dev.txt ? (n + 64) / 128 + 1 : 0;
+  region_lines[kTraceIsa] = ix->dev.isa8 ? ((n >> kIsaShift) + 2) / 16 + 1 : 0;
+  region_lines[kTraceKtab1] = ix->dev.ktab ? ((int64_t(1) << ix->dev.ktab_bits) * 16) / 128 + 1 : 0;
+  int64_t off[9];
+  off[0] = 0;
+  for (int r = 0; r < 8; r++) off[r + 1] = (off[r] + region_lines[r] + 63) & ~int64_t(63);
+  DeviceBuffer bitmap, counts;
+  auto body = [&]() -> int {
+    int r2;
+    if ((r2 = bitmap.reserve(size_t(off[8]) / 8 + 64))) return r2;
+    if ((r2 = counts.reserve(16 * 8))) return r2;
+    if ((r2 = S.first.reserve(size_t(npats + 1) * 8))) return r2;
+    if ((r2 = S.last.reserve(size_t(npats + 1) * 8))) return r2;
+    if ((r2 = S.noccs.reserve(size_t(npats + 1) * 4))) return r2;
+    if ((r2 = S.out_starts.reserve(size_t(npats + 2) * 8))) return r2;
+    DevIndex saved = ix->dev;
+    auto collect = [&](int64_t* out) -> int {
+      HIP_TRY(hipMemsetAsync(counts.p, 0, 16 * 8, st));
+      for (int r = 0; r < 8; r++)
+        if (region_lines[r])
+          hipLaunchKernelGGL(trace_popcount_kernel, dim3(1024), dim3(256), 0, st, static_cast<const uint32_t*>(bitmap.p), off[r] / 32,
+                             (off[r] + region_lines[r] + 31) / 32, reinterpret_cast<unsigned long long*>(counts.p) + r);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(out, counts.p, 8 * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      return 0;
+    };
+    HIP_TRY(hipMemsetAsync(bitmap.p, 0, size_t(off[8]) / 8 + 64, st));
+    ix->dev.trace = static_cast<uint32_t*>(bitmap.p);
+    for (int r = 0; r < 8; r++) ix->dev.trace_off[r] = off[r];
+    Plan plan{max_occs_each, S.noccs.as<int32_t>(), S.out_starts.as<int64_t>(), INT64_MAX, false};
+    r2 = launch_count_plan(ix, S, npats, d_plen, d_pats, d_starts, S.first.as<int64_t>(), S.last.as<int64_t>(), &plan, st);
+    if (!r2) r2 = collect(count_lines);
+    int64_t total = 0;
+    if (!r2) {
+      HIP_TRY(hipMemsetAsync(bitmap.p, 0, size_t(off[8]) / 8 + 64, st));
+      if (plan.done) r2 = launch_plan_rows(ix, S, npats, S.noccs.as<int32_t>(), S.first.as<int64_t>(), S.out_starts.as<int64_t>(), nullptr, INT64_MAX, st);
+      if (!r2) {
+        HIP_TRY(hipMemcpyAsync(&total, S.out_starts.as<int64_t>() + npats, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (total > 0 && !(r2 = S.offsets.reserve(size_t(total) * 8)))
+          r2 = launch_locate(ix, S, npats, S.first.as<int64_t>(), S.out_starts.as<int64_t>(), total, S.offsets.as<int64_t>(), st);
+      }
+      if (!r2) r2 = collect(locate_lines);
+    }
+    if (rows_out) *rows_out = total;
+    ix->dev = saved;
+    return r2;
+  };
+  rc = body();
+  (void)hipStreamSynchronize(st);
+  bitmap.release();
+  counts.release();
+  return rc;
+  API_END
 }
 
 int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode) {
@@ -1712,18 +2228,28 @@ int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode) {
   if (mode >= 1 && !ix->host.dir_regular)
     return set_err(FEMTO_AMD_ERR_INVALID, "this index has a short non-final segment: only the raw walk (mode 0) applies");
   if (ix->split_parts > 0 && mode != 1) return set_err(FEMTO_AMD_ERR_INVALID, "a range-split index runs the lane kernels (mode 1) only");
-  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  std::lock_guard<std::mutex> lk(ix->mu);
   ix->mode = mode;
   return FEMTO_AMD_OK;
 }
 
 int femto_amd_get_rank_mode(const femto_amd_index_t* ix) { return ix ? ix->mode : -1; }
 
+int femto_amd_set_option(femto_amd_index_t* ix, const char* name, int value) {
+  if (!ix || !name) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (!strcmp(name, "direct")) ix->direct = value != 0;
+  else if (!strcmp(name, "sort")) ix->sort_queries = value != 0;
+  else return set_err(FEMTO_AMD_ERR_PARAM, "unknown option");
+  return FEMTO_AMD_OK;
+}
+
 int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* bytes, double* build_ms, int* ktab_syms) {
   if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
   if (available) *available = ix->dev.pack != nullptr;
-  if (ktab_syms) *ktab_syms = ix->dev.ktab ? ix->dev.ktab_syms : 0;
+  if (ktab_syms) *ktab_syms = ix->dev.ktab2 ? ix->dev.kt2_syms : (ix->dev.ktab ? ix->dev.ktab_syms : 0);
   if (available && ix->dev.p2_l1) *available |= 2;   // bit 1: the two-level lines (mode 4) exist
+  if (available && ix->dev.ktab2) *available |= 4;   // bit 2: the level table of the direct pipeline exists
   if (bytes) *bytes = ix->pack_bytes + ix->pack2_bytes;
   if (build_ms) *build_ms = ix->pack_build_ms + ix->pack2_build_ms;
   return FEMTO_AMD_OK;
@@ -1735,7 +2261,7 @@ void femto_amd_kernel_time_enable(femto_amd_index_t* ix, int on) {
 
 void femto_amd_kernel_time_reset(femto_amd_index_t* ix) {
   if (!ix) return;
-  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  std::lock_guard<std::mutex> lk(ix->mu);
   ix->t_count.drain();
   ix->t_locate.drain();
   ix->t_count.total_ms = ix->t_locate.total_ms = 0;
@@ -1744,7 +2270,7 @@ void femto_amd_kernel_time_reset(femto_amd_index_t* ix) {
 
 int femto_amd_kernel_time_ms(femto_amd_index_t* ix, const char* kernel, double* avg_ms, int64_t* n_launches) {
   if (!ix || !kernel) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
-  std::lock_guard<std::recursive_mutex> lk(ix->mu);
+  std::lock_guard<std::mutex> lk(ix->mu);
   KernelTimer* t = nullptr;
   if (!strcmp(kernel, "count")) t = &ix->t_count;
   else if (!strcmp(kernel, "locate")) t = &ix->t_locate;
@@ -1754,7 +2280,6 @@ int femto_amd_kernel_time_ms(femto_amd_index_t* ix, const char* kernel, double* 
   if (n_launches) *n_launches = t->launches;
   return FEMTO_AMD_OK;
 }
-
 
 namespace {
 int collect_docs(int ndocs, const uint8_t* const* docs, const int64_t* doc_lens, const char* const* doc_infos,

@@ -45,9 +45,9 @@ int fail(Error* e, int code, const std::string& m) {
 int read_file(const std::string& path, std::vector<uint8_t>* out, Error* e) {
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) return fail(e, ERR_IO, "Could not open " + path);
-  fseek(f, 0, SEEK_END);
+  if (fseek(f, 0, SEEK_END)) { fclose(f); return fail(e, ERR_IO, "Could not seek " + path); }
   long n = ftell(f);
-  fseek(f, 0, SEEK_SET);
+  if (n < 0 || fseek(f, 0, SEEK_SET)) { fclose(f); return fail(e, ERR_IO, "Could not size " + path); }
   out->resize(size_t(n));
   if (n && fread(out->data(), 1, size_t(n), f) != size_t(n)) { fclose(f); return fail(e, ERR_IO, "short read " + path); }
   fclose(f);
@@ -297,7 +297,9 @@ int HostIndex::load(const std::string& path, Error* e) {
     if (flat_file.size() < 16 || be32(flat_file.data()) != kFlattenedStart || be32(flat_file.data() + 4) != kBlockVersion)
       return fail(e, ERR_FORMAT, "not a flattened femto index: " + path);
     int64_t nb = int64_t(be64(flat_file.data() + 8));
-    if (nb <= 0 || 16 + 8 * uint64_t(nb + 1) > flat_file.size()) return fail(e, ERR_FORMAT, "bad flattened block count");
+    // bound the count by what the file can hold BEFORE multiplying (a damaged count must not wrap the size check)
+    if (nb <= 0 || uint64_t(nb) > (flat_file.size() - 16) / 8 || uint64_t(nb) + 1 > (flat_file.size() - 16) / 8)
+      return fail(e, ERR_FORMAT, "bad flattened block count");
     for (int64_t i = 0; i <= nb; i++) flat_off.push_back(be64(flat_file.data() + 16 + 8 * size_t(i)));
     for (int64_t i = 0; i < nb; i++)
       if (flat_off[size_t(i)] > flat_off[size_t(i) + 1] || flat_off[size_t(i) + 1] > flat_file.size())
@@ -320,7 +322,12 @@ int HostIndex::load(const std::string& path, Error* e) {
   chunk_size = hh.chunk_size;
   text_size_bits = num_bits64(total_length);  // open_data_block, src/main/index.c:1441
   buckets_per_block = block_size / b_size;
-  if (number_of_blocks < 0 || total_length < 0) return fail(e, ERR_FORMAT, "negative sizes in header");
+  if (number_of_blocks < 0 || total_length < 0 || number_of_documents < 0) return fail(e, ERR_FORMAT, "negative sizes in header");
+  if (block_size <= 0 || b_size <= 0 || b_size > block_size) return fail(e, ERR_FORMAT, "bad block / bucket size in header");
+  // every table below is sized by these counts: bound them by what the header block can hold (by division, so that a
+  // damaged count cannot overflow the offset arithmetic)
+  if (uint64_t(number_of_blocks) > header.size() / (8 * uint64_t(kAlphaSize)) || uint64_t(number_of_documents) > header.size() / 24)
+    return fail(e, ERR_FORMAT, "header block too short for its block / document counts");
   if (flat && int64_t(flat_off.size()) - 2 != number_of_blocks) return fail(e, ERR_FORMAT, "flattened block count mismatch");
   {
     int64_t expect = (total_length + block_size - 1) / block_size;
@@ -524,6 +531,8 @@ int HostIndex::load(const std::string& path, Error* e) {
         uint32_t aoff = be32(d + ma_off + 4 * size_t(s));
         sq.mark_array = boff + ma_off + aoff;
         if (sq.mark_array > blimit) return fail(e, ERR_FORMAT, "mark array out of range");
+        // the arrays of a bucket follow one another (index.c:700-720): a start before its predecessor's is damage
+        if (s > 0 && sq.mark_array < seqs.back().mark_array) return fail(e, ERR_FORMAT, "mark arrays are not in order");
         sq.ch = seqToUnseq[s];
         seqs.push_back(sq);
         lsq.mark_array = sq.mark_array;

@@ -121,7 +121,11 @@ __device__ __forceinline__ void p2_search_step(const DevIndex& ix, int j, uint32
     rkL = before + int64_t(__popcll(eq & p2_below_incl(uint32_t(last) & 63u)));
     if (haveF && l1F == l1L) rkF = before + int64_t(__popcll(eq & p2_below_incl(uint32_t(first - 1) & 63u)));
   }
-  if (haveF && l1F != l1L) rkF = p2_rank_h(l1, l1F, uint32_t(first - 1) & 63u, h);
+  if (haveF && l1F != l1L) {
+    rkF = p2_rank_h(l1, l1F, uint32_t(first - 1) & 63u, h);
+    trace_touch(ix, kTraceL1, l1F);
+  }
+  trace_touch(ix, kTraceL1, l1L);
   const int64_t c0 = ix.p2_c[code];
   int64_t nl = c0, nf = c0;
   uint64_t lineL = 0, lineF = 0;
@@ -140,11 +144,13 @@ __device__ __forceinline__ void p2_search_step(const DevIndex& ix, int j, uint32
   uint32_t loL = 0, hiL = 0, loF = 0, hiF = 0;
   const bool other = rkF && (!rkL || lineF != lineL);
   if (rkL) {
+    trace_touch(ix, kTraceL2, lineL);
     p2_load2(l2, lineL, PL);
     loL = l2[lineL * 32 + 12 + l];
     hiL = l2[lineL * 32 + 28 + (l >> 2)];
   }
   if (other) {
+    trace_touch(ix, kTraceL2, lineF);
     p2_load2(l2, lineF, PF);
     loF = l2[lineF * 32 + 12 + l];
     hiF = l2[lineF * 32 + 28 + (l >> 2)];
@@ -192,6 +198,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   int j = 0;
   if (kKeys && ix.ktab) {
     const longlong2 e = reinterpret_cast<const longlong2*>(ix.ktab)[key >> (64 - ix.ktab_bits)];
+    trace_touch(ix, kTraceKtab1, (key >> (64 - ix.ktab_bits)) >> 3);
     first = e.x;
     last = int64_t(uint64_t(e.y) & kKtabLastMask) - 1;
     j = int(uint64_t(e.y) >> 48);
@@ -283,6 +290,8 @@ __device__ __forceinline__ P2Step p2_step(const DevIndex& ix, int64_t row) {
   uint32_t r2;
   p2_split2(rank - 1, &lh, &r2);
   const uint64_t line2 = uint64_t(ix.p2_base[h]) + lh;
+  trace_touch(ix, kTraceL1, line1);
+  trace_touch(ix, kTraceL2, line2);
   const uint32_t* lq = ix.p2_l2 + line2 * 32;
   uint32_t v[32];
 #pragma unroll
@@ -322,6 +331,7 @@ __global__ __launch_bounds__(256) void locate_kernel_pack2(const DevIndex ix, co
     const P2Step s = p2_step(ix, row);
     if (s.marked) {
       result = ix.pack_sa[s.sa_index] + steps;
+      trace_touch(ix, kTraceSa, uint64_t(s.sa_index) >> 4);
       break;
     }
     if (s.code < ix.p2_stop_below) break;                  // cannot walk past a document start (server.c:2336-2342)

@@ -26,6 +26,15 @@ constexpr int kPackRows = 160;
 constexpr int kPackPlaneWords = 5;
 constexpr int kPackLineWords = 32;
 
+// compulsory-traffic trace (femto_amd_trace_lines): when ix.trace is set, every 128-byte line a query kernel loads from
+// a traced array sets its bit.  The branch is uniform (a kernel argument), so ordinary launches pay one scalar test.
+__device__ __forceinline__ void trace_touch(const DevIndex& ix, int region, uint64_t line) {
+  if (ix.trace) {
+    const uint64_t b = uint64_t(ix.trace_off[region]) + line;
+    atomicOr(ix.trace + (b >> 5), 1u << (b & 31u));
+  }
+}
+
 __device__ __forceinline__ void pack_split(int64_t row, uint64_t* line, uint32_t* r) {
   const uint32_t q = uint32_t(uint64_t(row) >> 5);  // rows < 2^37
   const uint32_t l = q / 5u;
@@ -89,7 +98,9 @@ __device__ __forceinline__ void pack_search_step(const DevIndex& ix, const uint3
   if (other) {  // both ends of a narrow range usually share the line
     pack_load_planes(pack, lineF, PF);
     bF = pack_base(pack, lineF, code);
+    trace_touch(ix, kTracePack, lineF);
   }
+  trace_touch(ix, kTracePack, lineL);
   const int64_t nl = bL + int64_t(pack_match(PL, code, rL + 1));
   int64_t nf;
   if (first == 0) nf = ix.pack_c[code];
@@ -159,6 +170,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   int j = 0;
   if (kKeys && ix.ktab) {
     const longlong2 e = reinterpret_cast<const longlong2*>(ix.ktab)[key >> (64 - ix.ktab_bits)];
+    trace_touch(ix, kTraceKtab1, (key >> (64 - ix.ktab_bits)) >> 3);
     first = e.x;
     last = int64_t(uint64_t(e.y) & kKtabLastMask) - 1;
     j = int(uint64_t(e.y) >> 48);   // fields consumed; a pattern that ends (or leaves the alphabet) there goes on below
@@ -343,9 +355,11 @@ __global__ __launch_bounds__(256) void locate_kernel_pack(const DevIndex ix, con
     pack_split(row, &line, &r);
     PackLine L;
     pack_load_line(ix.pack, line, L);
+    trace_touch(ix, kTracePack, line);
     const PackStep s = pack_step(L, r);
     if (s.marked) {
       result = ix.pack_sa[s.sa_index] + steps;
+      trace_touch(ix, kTraceSa, uint64_t(s.sa_index) >> 4);
       break;
     }
     if ((ix.pack_stop >> s.code) & 1u) break;              // cannot walk past a document start (server.c:2336-2342)

@@ -34,6 +34,7 @@ struct PackPolicy {
     pack_split(row, &line, &r);
     PackLine L;
     pack_load_line(ix.pack, line, L);
+    trace_touch(ix, kTracePack, line);
     const PackStep s = pack_step(L, r);
     code = s.code;
     marked = s.marked;
@@ -77,6 +78,7 @@ __device__ __forceinline__ bool tail_locate(const DevIndex& ix, int64_t row, int
     if (steps == 0 && first_code) *first_code = code;
     if (marked) {
       *pos = ix.pack_sa[sa_index] + steps;
+      trace_touch(ix, kTraceSa, uint64_t(sa_index) >> 4);
       return true;
     }
     if (P::is_stop(ix, code) || steps > int64_t(ix.walk_limit)) return false;
@@ -105,6 +107,7 @@ __device__ __forceinline__ bool tail_row_of(const DevIndex& ix, int64_t x, int64
   const int64_t s = (x + K - 1) & ~(K - 1);
   if (s >= ix.total_length) return false;
   int64_t row = ix.isa8[s >> kIsaShift];
+  trace_touch(ix, kTraceIsa, uint64_t(s >> kIsaShift) >> 4);
   for (int64_t k = s; k > x; k--) {
     uint32_t code;
     bool marked;
@@ -153,21 +156,33 @@ __device__ __forceinline__ int tail_symbol(const DevIndex& ix, SymbolReader& R, 
   return 0;
 }
 
+// Direct batches (direct_kernels.hip.hpp: perm == NULL, slot == pattern index, no sort keys) store into the caller's
+// arrays themselves and, when a locate plan is being made (noccs != NULL), the clamped row count too -- added to the
+// sum of the pattern's 256-pattern block, which plan_scan_kernel scans afterwards.
+struct TailOut {
+  longlong2* pair_out;      // sorted batches: (first,last) pairs, split later
+  int64_t* first_out;       // direct batches
+  int64_t* last_out;        // NULL: first_out receives the count
+  int32_t* noccs;           // locate plan, or NULL
+  int64_t* block_sums;
+  int max_occs;
+};
+
 template <class P>
 __global__ __launch_bounds__(256) void count_tail_kernel(const DevIndex ix, const TailItem* __restrict__ items, const int* __restrict__ n_items,
                                                          const int32_t* __restrict__ plen, const uint16_t* __restrict__ pats,
                                                          const int64_t* __restrict__ starts, const uint32_t* __restrict__ perm,
                                                          const uint64_t* __restrict__ keys, const int bits, const int nsym,
-                                                         longlong2* __restrict__ pair_out, int* __restrict__ err_flag) {
-  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (t >= int64_t(*n_items)) return;
+                                                         const TailOut out, int* __restrict__ err_flag) {
+  const int64_t n_it = int64_t(*n_items);
+  for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < n_it; t += int64_t(gridDim.x) * blockDim.x) {
   const TailItem it = items[t];
-  const int64_t q = int64_t(perm[it.slot]);
+  const int64_t q = perm ? int64_t(perm[it.slot]) : int64_t(it.slot);
   SymbolReader R;
-  R.key = keys[it.slot];
+  R.key = keys ? keys[it.slot] : 0;
   R.whole = false;
   R.bits = bits;
-  R.nsym = nsym;
+  R.nsym = keys ? nsym : 0;
   R.len = plen[q];
   R.pat = pats + starts[q];
   R.word = 0;
@@ -192,6 +207,7 @@ __global__ __launch_bounds__(256) void count_tail_kernel(const DevIndex ix, cons
       if (wa != tw_addr) {
         tw = *reinterpret_cast<const uint64_t*>(wa);
         tw_addr = wa;
+        trace_touch(ix, kTraceTxt, uint64_t(wa - reinterpret_cast<uintptr_t>(ix.txt)) >> 7);
       }
       const uint32_t tc = uint32_t(tw >> (8 * (ta - wa))) & 0xffu;
       if (tc != code) break;
@@ -223,7 +239,25 @@ __global__ __launch_bounds__(256) void count_tail_kernel(const DevIndex ix, cons
     P::search_step(ix, j, code, first, last);
     if (first > last) break;
   }
-  pair_out[q] = make_longlong2(first, last);
+  if (out.pair_out) {
+    out.pair_out[q] = make_longlong2(first, last);
+  } else {
+    if (out.last_out) {
+      out.first_out[q] = first;
+      out.last_out[q] = last;
+    } else {
+      out.first_out[q] = last - first + 1;
+    }
+    if (out.noccs) {   // do_locate_query's clamp (server.c:4405-4415)
+      int64_t c;
+      if (first > last) c = 0;
+      else if (last - first > int64_t(out.max_occs)) c = out.max_occs;
+      else c = last - first + 1;
+      out.noccs[q] = int32_t(c);
+      if (c) atomicAdd(reinterpret_cast<unsigned long long*>(out.block_sums + (q >> 8)), static_cast<unsigned long long>(c));
+    }
+  }
+  }
 }
 
 }  // namespace femto_amd

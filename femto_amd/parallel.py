@@ -47,6 +47,17 @@ def gather_varlen(t, dst=0):
     return torch.cat([o[:s] for o, s in zip(out, sizes)])
 
 
+def _shard_symbols(plen, starts, lo, hi):
+    """Symbol range [f0, f1) of the flat buffer that patterns lo..hi-1 use, and their starts rebased onto it.  The C API
+    accepts arbitrary (unordered, overlapping) starts, so the range is the min / max over the shard, not its ends."""
+    if hi <= lo:
+        return 0, 0, starts[lo:hi]
+    st = np.asarray(starts[lo:hi], dtype=np.int64)
+    f0 = int(st.min())
+    f1 = int((st + np.asarray(plen[lo:hi], dtype=np.int64)).max())
+    return f0, f1, st - f0
+
+
 def sharded_count(count_fn, plen, flat, starts, device="cpu", dst=0):
     """Run count_fn(plen, flat, starts) -> (first, last) numpy int64 on this rank's contiguous shard
     of the batch and gather (first, last) for the WHOLE batch on rank dst."""
@@ -54,9 +65,7 @@ def sharded_count(count_fn, plen, flat, starts, device="cpu", dst=0):
     rank = dist.get_rank() if dist.is_initialized() else 0
     n = len(plen)
     lo, hi = shard_range(n, rank, world)
-    s = starts[lo:hi] - (starts[lo] if hi > lo else 0)
-    f0 = int(starts[lo]) if hi > lo else 0
-    f1 = int(starts[hi - 1] + plen[hi - 1]) if hi > lo else 0
+    f0, f1, s = _shard_symbols(plen, starts, lo, hi)
     first, last = count_fn(plen[lo:hi], flat[f0:f1] if f1 > f0 else flat[:0], s)
     res = torch.from_numpy(np.stack([first, last]).reshape(-1)).to(device)
     if world == 1:
@@ -82,9 +91,7 @@ def sharded_locate(locate_fn, plen, flat, starts, max_occs, device="cpu", dst=0)
     rank = dist.get_rank() if dist.is_initialized() else 0
     n = len(plen)
     lo, hi = shard_range(n, rank, world)
-    s = starts[lo:hi] - (starts[lo] if hi > lo else 0)
-    f0 = int(starts[lo]) if hi > lo else 0
-    f1 = int(starts[hi - 1] + plen[hi - 1]) if hi > lo else 0
+    f0, f1, s = _shard_symbols(plen, starts, lo, hi)
     noccs, offs = locate_fn(plen[lo:hi], flat[f0:f1] if f1 > f0 else flat[:0], s, max_occs)
     if world == 1:
         return noccs, offs

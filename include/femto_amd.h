@@ -139,6 +139,15 @@ int femto_amd_locate_walk_device(femto_amd_index_t* ix, int64_t npats, const int
                                  const int64_t* d_out_starts, int64_t total, int64_t* d_offsets,
                                  void* stream);
 
+/* The whole of parallel_locate (src/main/femto.c:331) as ONE enqueue-only call: count, the reference's clamp, prefix
+ * sum and the locate walk run as one stream-ordered chain; nothing returns to the host in between.  d_offsets has room
+ * for offsets_capacity rows; d_total[0] receives the number of rows (= d_out_starts[npats]) and d_total[1] is 1 when
+ * that exceeds offsets_capacity (the offsets are then incomplete: call again with a larger buffer). */
+int femto_amd_locate_device(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen,
+                            const uint16_t* d_pats, const int64_t* d_starts, int max_occs_each,
+                            int64_t* d_first, int64_t* d_last, int32_t* d_noccs, int64_t* d_out_starts,
+                            int64_t* d_offsets, int64_t offsets_capacity, int64_t* d_total, void* stream);
+
 /* ---- leaf requests (the reference's block_request interface, src/main/index.h:300-394) ---- */
 /* For rows[i] (global row numbers, host memory): ch_out = L[row] (BLOCK_REQUEST_CHAR),
  * occ_out = Occ-in-block(L[row] or ch_in[i], row) (BLOCK_REQUEST_OCCS; ch_in==NULL -> use L[row]),
@@ -203,6 +212,10 @@ int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode);
  * Both modes also derive: marks every FEMTO_AMD_MARK_EVERY-th text position (default 5; a locate walk then ends within
  * 4 steps -- leaf requests still answer from femto's own marks), and the text + a sampled inverse suffix array
  * (FEMTO_AMD_TEXT=0 skips them) against which the tail of a long pattern is compared once its range is one row. */
+/* Runtime switches of an open handle: "direct" (default 1: modes 3/4 process a batch in the caller's order with the
+ * level table of femto_amd/csrc/direct_kernels.hip.hpp; 0: the suffix-sorted kernels of round 1), "sort" (default 1:
+ * suffix-order batches for the paths that use them).  Results are identical either way. */
+int femto_amd_set_option(femto_amd_index_t* ix, const char* name, int value);
 int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* bytes, double* build_ms, int* ktab_syms);
 int femto_amd_get_rank_mode(const femto_amd_index_t* ix);
 
@@ -212,6 +225,15 @@ int femto_amd_get_rank_mode(const femto_amd_index_t* ix);
 int femto_amd_kernel_time_ms(femto_amd_index_t* ix, const char* kernel, double* avg_ms, int64_t* n_launches);
 void femto_amd_kernel_time_reset(femto_amd_index_t* ix);
 void femto_amd_kernel_time_enable(femto_amd_index_t* ix, int on);
+
+/* Compulsory HBM traffic of a batch (bench.py's roofline): runs the batch once with a line trace and reports how many
+ * DISTINCT 128-byte lines of each derived array the count phase (count_lines[8]) and the row expansion + locate walk
+ * (locate_lines[8]) loaded; *rows_out = rows located.  Regions: 0 packed lines (mode 3), 1 level table, 2 offsets of
+ * the marked rows, 3 / 4 level-1 / level-2 lines (mode 4), 5 text, 6 sampled inverse suffix array, 7 round-1 table.
+ * Device pointers as in femto_amd_count_device; blocking; not to be called while other calls use the handle. */
+int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
+                          const int64_t* d_starts, int max_occs_each, int64_t* count_lines, int64_t* locate_lines,
+                          int64_t* rows_out);
 
 /* ---- index construction (femto block-file writer) ------------------------- */
 /* Builds a femto index directory (byte-identical to index_documents(map=NULL),

@@ -20,6 +20,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF_DIR = os.path.join(HERE, "_ref")
 ORACLE_SO = os.path.join(REF_DIR, "libfemto_oracle.so")
 REF_TOOL = os.path.join(REF_DIR, "ref_tool")
+REF_TOOL_AMD = os.path.join(REF_DIR, "ref_tool_amd")       # ref_tool linked with integration/femto_amd_shim.c
+INDEX_TEST_AMD = os.path.join(REF_DIR, "index_test_amd")   # the reference's index_test.c linked with the shim
 FPAT_MAGIC = 0x54415046
 
 
@@ -28,6 +30,9 @@ def build(oracle_only=False):
     checker is not using it."""
     target = ["oracle"] if oracle_only else []
     subprocess.run(["make", "-C", HERE, "-j8", "-s"] + target, check=True)
+    # the reference's own callers linked against integration/femto_amd_shim.c (needs the built product library)
+    if not oracle_only and os.path.exists(os.path.join(os.path.dirname(HERE), "femto_amd", "libfemto_amd.so")):
+        subprocess.run(["make", "-C", HERE, "-j8", "-s", "shim"], check=True)
 
 
 class Counters(C.Structure):

@@ -38,7 +38,7 @@ for f in find("pmc_*/**/*counter_collection.csv"):
 print("\n== PMC per kernel (mean per dispatch; n dispatches)")
 summary = {}
 for k in pmc:
-    if "count_kernel" not in k and "locate_kernel" not in k:
+    if not any(t in k for t in ("count_kernel", "locate_kernel", "count_direct", "locate_walk", "count_tail", "plan_")):
         continue
     print(k)
     for c, v in sorted(pmc[k].items()):
