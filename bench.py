@@ -115,6 +115,16 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+class _EventWork:
+    """the .wait() of a gather enqueued on a side stream (same shape as torch's async work handle)"""
+
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        self.ev.synchronize()
+
+
 class Batch:
     """A pattern batch resident in HBM plus its result buffers."""
 
@@ -187,6 +197,9 @@ def main():
     ap.add_argument("--ref-sample", type=int, default=100_000, help="patterns per timed pass of the genuine reference (3 passes + warm-up)")
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"], help="auto: roofline.traffic from live rocprofv3 --pmc passes (N=1)")
     ap.add_argument("--pmc-child", action="store_true", help="internal: the short run the PMC passes profile")
+    ap.add_argument("--gather", default="torch", choices=["torch", "native"],
+                    help="N > 1: torch = torch.distributed.gather (RCCL); native = the library's own grouped ncclSend/ncclRecv "
+                         "(femto_amd_comm_gather), its id broadcast through torch.distributed")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary P_hit line (N=1 default workload only)")
     ap.add_argument("--workdir", default=os.environ.get("FEMTO_AMD_BENCH_DIR", "/tmp/femto_amd_bench"))
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "latest_pmc.json"))
@@ -276,6 +289,16 @@ def main():
     if world > 1 and rank == 0:
         gather_lists = [[torch.empty_like(batch.wire(info.total_length), device=None if backend == "nccl" else "cpu")
                          for _ in range(world)] for _ in range(2)]
+    native = world > 1 and args.gather == "native" and backend == "nccl"
+    gstream, recv_native = None, None
+    if native:      # the C ABI's own gather: grouped point-to-point transfers on a stream of its own
+        ids = [femto_amd.Index.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ix.comm_init(ids[0], world, rank)
+        gstream = torch.cuda.Stream()
+        w0 = batch.wire(info.total_length)
+        if rank == 0:
+            recv_native = [torch.empty((world,) + tuple(w0.shape), dtype=w0.dtype, device=dev) for _ in range(2)]
     stream = torch.cuda.current_stream().cuda_stream
     pending = [None, None]
     counter = {"k": 0}
@@ -289,7 +312,17 @@ def main():
             pending[b].wait()          # the buffer's previous gather must be done before it is overwritten
             pending[b] = None
         batch.step(ix, args.max_occs, stream, b)
-        if world > 1:
+        if native:
+            payload = batch.wire(info.total_length, b)
+            ev = torch.cuda.Event()
+            ev.record()
+            gstream.wait_event(ev)
+            ix.comm_gather(payload.data_ptr(), recv_native[b].data_ptr() if rank == 0 else 0, payload.numel() * payload.element_size(), 0,
+                           gstream.cuda_stream)
+            done = torch.cuda.Event()
+            done.record(gstream)
+            pending[b] = _EventWork(done)
+        elif world > 1:
             payload = batch.wire(info.total_length, b)
             if backend != "nccl":
                 payload = payload.cpu()
@@ -517,7 +550,8 @@ def main():
                    "rank_mode": {4: "pack2", 3: "pack", 1: "lane", 2: "flat", 0: "raw"}[ix.rank_mode], "index": {"rows": int(info.total_length), "blocks": int(info.number_of_blocks), "buckets": int(info.total_buckets),
                              "image_bytes": int(info.image_bytes), "table_bytes": int(info.table_bytes),
                              "packed_lines": ix.pack_info()},
-                   "parallelism": ("range-split index (1/N of the blocks per GPU, peer loads over xGMI)" if args.layout == "split" and world > 1 else "replicated index") + f", query shards x{world}" + (", RCCL gather of (first,last) to rank 0 every step (int32 rows when the index has < 2^31 rows), overlapped with the next step's kernels" if world > 1 else ""),
+                   "parallelism": ("range-split index (1/N of the blocks per GPU, peer loads over xGMI)" if args.layout == "split" and world > 1 else "replicated index") + f", query shards x{world}" + ((", RCCL gather of (first,last) to rank 0 every step (int32 rows when the index has < 2^31 rows), overlapped with the next step's kernels"
+                                                                                  + ("; gather = femto_amd_comm_gather (grouped ncclSend/ncclRecv)" if native else "; gather = torch.distributed.gather")) if world > 1 else ""),
                    "build_s": build_s, "open_s": open_s},
         "roofline": roof, "cpu_baseline": cpu,
         "gpu_vs_cpu": (value / cpu["value"]) if cpu else None,

@@ -46,6 +46,15 @@ def lib():
         if not os.path.exists(_build.LIB):
             raise ImportError(f"{_build.LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(there is no CPU fallback)")
+        # Load order matters in a process that also uses PyTorch-ROCm: torch ships its own libamdhip64, and two HIP runtimes
+        # in one process do not see each other's devices.  Importing torch first makes this library resolve to the runtime
+        # torch already loaded (observed on the GPU box: loading this library first made hipGetDeviceCount fail later).
+        import sys
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(_build.LIB)
         vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
         L.femto_amd_open.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
@@ -67,6 +76,11 @@ def lib():
         L.femto_amd_locate_walk_device.argtypes = [vp, i64, vp, vp, i64, vp, vp]
         L.femto_amd_locate_device.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, vp, vp]
         L.femto_amd_trace_lines.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, C.POINTER(i64)]
+        L.femto_amd_open_multi.argtypes = [C.c_char_p, i32, vp, C.POINTER(vp)]
+        L.femto_amd_device_count.argtypes = [vp]
+        L.femto_amd_comm_unique_id.argtypes = [vp]
+        L.femto_amd_comm_init.argtypes = [vp, vp, i32, i32]
+        L.femto_amd_comm_gather.argtypes = [vp, vp, vp, i64, i32, vp]
         L.femto_amd_set_option.argtypes = [vp, C.c_char_p, i32]
         L.femto_amd_block_requests.argtypes = [vp, i64, vp, vp, vp, vp, vp]
         L.femto_amd_kernel_time_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]
@@ -121,10 +135,14 @@ def flatten(patterns):
 class Index:
     """A femto index resident in the HBM of one GPU.  device=-1 parses only (host logic tests)."""
 
-    def __init__(self, path, device=0, part=None, nparts=None):
+    def __init__(self, path, device=0, part=None, nparts=None, devices=None):
         self._h = C.c_void_p()
         self._peers = []   # range-split: the parts attached in-process must outlive this handle's use
-        if nparts is None:
+        if devices is not None:     # one handle over several GPUs of this process (femto_amd_open_multi): host-pointer calls only
+            arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+            _check(lib().femto_amd_open_multi(os.fsencode(path), len(devices), arr, C.byref(self._h)))
+            device = list(devices)
+        elif nparts is None:
             _check(lib().femto_amd_open(os.fsencode(path), device, C.byref(self._h)))
         else:
             _check(lib().femto_amd_open_split(os.fsencode(path), device, int(part), int(nparts), C.byref(self._h)))
@@ -234,6 +252,7 @@ class Index:
         a, b, ms, k = C.c_int(0), C.c_int64(0), C.c_double(0), C.c_int(0)
         _check(lib().femto_amd_pack_info(self._h, C.byref(a), C.byref(b), C.byref(ms), C.byref(k)))
         return {"available": bool(a.value & 1), "available2": bool(a.value & 2), "level_table": bool(a.value & 4),
+                "sa_full": bool(a.value & 8), "isa_full": bool(a.value & 16), "char_rank_lines": bool(a.value & 32),
                 "bytes": b.value, "build_ms": ms.value, "ktab_syms": k.value}
 
     def document_info(self, doc):
@@ -287,15 +306,29 @@ class Index:
         _check(lib().femto_amd_locate_device(self._h, npats, d_plen, d_pats, d_starts, max_occs, d_first, d_last, d_noccs,
                                              d_out_starts, d_offsets, capacity, d_total, stream or None))
 
-    TRACE_REGIONS = ("pack_lines", "level_table", "mark_offsets", "level1_lines", "level2_lines", "text", "isa", "ktab_r1")
+    TRACE_REGIONS = ("pack_lines", "level_table", "suffix_array", "level1_lines", "level2_lines", "text", "isa", "ktab_r1", "char_rank_lines",
+                     "unused")
 
     def trace_lines(self, npats, d_plen, d_pats, d_starts, max_occs):
         """distinct 128-byte lines per derived array loaded by the count phase and by the locate phase of this batch"""
-        cl = np.zeros(8, dtype=np.int64)
-        ll = np.zeros(8, dtype=np.int64)
+        cl = np.zeros(10, dtype=np.int64)
+        ll = np.zeros(10, dtype=np.int64)
         rows = C.c_int64(0)
         _check(lib().femto_amd_trace_lines(self._h, npats, d_plen, d_pats, d_starts, max_occs, _ptr(cl), _ptr(ll), C.byref(rows)))
         return dict(zip(self.TRACE_REGIONS, cl.tolist())), dict(zip(self.TRACE_REGIONS, ll.tolist())), rows.value
+
+    # ---- multi-process gather of device-resident results (RCCL send/recv, femto_amd_comm_*)
+    @staticmethod
+    def comm_unique_id():
+        blob = C.create_string_buffer(128)
+        _check(lib().femto_amd_comm_unique_id(blob))
+        return blob.raw
+
+    def comm_init(self, id128, nranks, rank):
+        _check(lib().femto_amd_comm_init(self._h, C.create_string_buffer(bytes(id128), 128), int(nranks), int(rank)))
+
+    def comm_gather(self, d_send, d_recv, bytes_per_rank, root=0, stream=0):
+        _check(lib().femto_amd_comm_gather(self._h, d_send, d_recv or None, int(bytes_per_rank), int(root), stream or None))
 
     def set_option(self, name, value):
         """'direct' (modes 3/4: caller-order pipeline, default 1) / 'sort' (suffix-order batches of the other paths)"""

@@ -107,7 +107,8 @@ struct DevBucket {          // 16 bytes
 
 // regions of the compulsory-traffic trace (femto_amd_trace_lines): every 128-byte line a query kernel loads from one
 // of these arrays sets one bit; the number of set bits x 128 B is what the launch MUST move from HBM at least once
-enum { kTracePack = 0, kTraceKtab = 1, kTraceSa = 2, kTraceL1 = 3, kTraceL2 = 4, kTraceTxt = 5, kTraceIsa = 6, kTraceKtab1 = 7 };
+enum { kTracePack = 0, kTraceKtab = 1, kTraceSa = 2, kTraceL1 = 3, kTraceL2 = 4, kTraceTxt = 5, kTraceIsa = 6, kTraceKtab1 = 7, kTraceInd = 8,
+       kTraceRegions = 10 };
 
 struct DevIndex {           // passed by value to kernels
   const uint8_t* image;
@@ -137,7 +138,7 @@ struct DevIndex {           // passed by value to kernels
   int32_t kt2_nstop;        // dense codes below this are <= SEOF: digit = dense code - kt2_nstop
   int32_t kt2_pad;
   uint32_t* trace;          // NULL, or the line bitmaps of femto_amd_trace_lines: bit trace_off[region] + line index
-  int64_t trace_off[8];     // first bit of every traced region (kTrace* below)
+  int64_t trace_off[kTraceRegions];   // first bit of every traced region (kTrace* above)
   uint16_t pack_alpha[8];   // dense code -> alpha code
   int32_t pack_sigma;
   uint32_t pack_stop;       // bit c: alpha code of dense code c is <= SEOF (a locate walk stops there)
@@ -152,7 +153,12 @@ struct DevIndex {           // passed by value to kernels
   uint32_t p2_stop_below;   // dense codes below this are <= SEOF (a locate walk stops there)
   // long-pattern tail (text_kernels.hip.hpp); null when not derived
   const uint8_t* txt;       // dense character code of every text position
-  const int64_t* isa8;      // row of the suffix at every 8th text position
+  const int64_t* isa8;      // row of the suffix at every (1 << isa_shift)-th text position
+  const uint32_t* ind;      // per-character rank lines for byte alphabets (ind_kernels.hip.hpp), or NULL
+  int64_t ind_stride;       // lines per character
+  const int64_t* sa_full;   // SA[row] of EVERY row when HBM allows (8 B/row), else NULL: locate is then one read, no walk
+  int32_t isa_shift;        // 0: full inverse suffix array (8 B/row), 3: every 8th position
+  int32_t dense_pad;
   void* tail_items;         // TailItem work list of the current count launch
   int* tail_count;
   int32_t tail_min;         // hand a one-row range over when at least this many symbols remain

@@ -66,8 +66,12 @@ __device__ __forceinline__ int64_t block_sum_256(int64_t v, int64_t* s_w /* [4] 
 
 // do_string_query (src/main/server.c:713-946), one lane per pattern in the caller's order.
 // kPlan: also do_locate_query's clamp (server.c:4405-4415): noccs[q] and the block's sum of them.
-template <class P, bool kPlan>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void count_direct_kernel(
+// kDense: the full suffix array and the full inverse suffix array are resident: once the range is ONE row with a long
+// tail to go, the tail is compared with the text right here -- position = SA[row] (one read), compare, row of the
+// last matching position = ISA[..] (one read) -- instead of being handed to count_tail_kernel (whose LF walks only
+// exist because the sampled arrays need them).  Same result as stepping on: see text_kernels.hip.hpp.
+template <class P, bool kPlan, bool kDense>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, P::kWaves))) void count_direct_kernel(
     const DevIndex ix, const int64_t npats, const int32_t* __restrict__ plen, const uint16_t* __restrict__ pats,
     const int64_t* __restrict__ starts, int64_t* __restrict__ first_out, int64_t* __restrict__ last_out, int* __restrict__ err_flag,
     const int max_occs, int32_t* __restrict__ noccs, int64_t* __restrict__ block_sums) {
@@ -112,8 +116,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       if (first > last) j = len;
     }
     bool handed = false;
+    bool tried = false;          // kDense: the text shortcut was taken for the current row (an ordinary step follows)
     for (; j < len; j++) {
-      if (ix.txt && first == last && j > 0 && len - j >= ix.tail_min) {
+      if (kDense) {
+        if (!tried && first == last && j > 0 && len - j >= ix.tail_min) {
+          tried = true;
+          const int64_t p = ix.sa_full[first];
+          trace_touch(ix, kTraceSa, uint64_t(first) >> 4);
+          const int remaining = len - j;
+          if (p >= int64_t(remaining)) {
+            int m = 0;                       // symbols matched
+            uint64_t tw = 0;                 // aligned 8-byte word of txt holding the byte being compared
+            uintptr_t tw_addr = 0;
+            for (; m < remaining; m++) {
+              const uint32_t ch = symbol(j + m);
+              if (ch >= uint32_t(kAlphaSize)) break;          // anything unusual is left to the ordinary step below
+              const uint32_t code = s_code[ch];
+              if (code == 0xffffu || P::is_stop(ix, code)) break;
+              const uintptr_t ta = reinterpret_cast<uintptr_t>(ix.txt + (p - 1 - m));
+              const uintptr_t wa = ta & ~uintptr_t(7);
+              if (wa != tw_addr) {
+                tw = *reinterpret_cast<const uint64_t*>(wa);
+                tw_addr = wa;
+                trace_touch(ix, kTraceTxt, uint64_t(wa - reinterpret_cast<uintptr_t>(ix.txt)) >> 7);
+              }
+              if ((uint32_t(tw >> (8 * (ta - wa))) & 0xffu) != code) break;
+            }
+            if (m > 0) {
+              first = last = ix.isa8[p - m];   // isa_shift == 0: the row of every text position
+              trace_touch(ix, kTraceIsa, uint64_t(p - m) >> 4);
+              j += m;
+              if (j >= len) break;
+            }
+          }
+        }
+      } else if (ix.txt && first == last && j > 0 && len - j >= ix.tail_min) {
         tail_append(ix, q, j, first);   // one row left, a long tail to go: compare it with the text instead
         handed = true;
         break;
@@ -133,6 +170,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       }
       P::search_step(ix, j, code, first, last);
       if (first > last) break;
+      tried = false;
     }
     if (!handed) {
       if (last_out) {
@@ -158,32 +196,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 }
 
 // exclusive scan of n block sums in place (one 1024-thread workgroup); total -> total_out[0]; total_out[1] = 1 when the
-// total exceeds `capacity` rows (the rows beyond it are not located)
+// total exceeds `capacity` rows (the rows beyond it are not located).  Every thread keeps a contiguous chunk of up to 16
+// sums in registers (all loads in flight at once: this kernel sits on the step's critical path), the 1024 chunk totals
+// are scanned with wavefront shuffles; batches of more than 2^14 blocks take further passes.
 __global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t n, int64_t* __restrict__ sums, int64_t* __restrict__ total_out,
                                                          const int64_t capacity, int64_t* __restrict__ out_starts_end) {
-  __shared__ int64_t s_part[1024];
-  const int tid = threadIdx.x;
-  const int64_t per = (n + 1023) / 1024;
-  const int64_t a = int64_t(tid) * per, b = a + per < n ? a + per : n;
-  int64_t s = 0;
-  for (int64_t i = a; i < b; i++) s += sums[i];
-  s_part[tid] = s;
+  constexpr int kPer = 16;
+  __shared__ int64_t s_wave[16];
+  __shared__ int64_t s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_carry = 0;
   __syncthreads();
-  // Hillis-Steele inclusive scan over 1024 partials
-  for (int d = 1; d < 1024; d <<= 1) {
-    const int64_t v = tid >= d ? s_part[tid - d] : 0;
+  for (int64_t base = 0; base < n; base += int64_t(1024) * kPer) {
+    const int64_t left = n - base < int64_t(1024) * kPer ? n - base : int64_t(1024) * kPer;
+    const int per = int((left + 1023) / 1024);
+    const int64_t a = base + int64_t(tid) * per;
+    int64_t v[kPer];
+    int64_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      v[k] = (k < per && a + k < base + left) ? sums[a + k] : 0;
+      sum += v[k];
+    }
+    // inclusive scan of the per-thread totals: within the wavefront, then across the 16 wavefronts
+    uint64_t x = uint64_t(sum);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t lo = uint32_t(__shfl_up(int(uint32_t(x)), d, 64)), hi = uint32_t(__shfl_up(int(uint32_t(x >> 32)), d, 64));
+      if (lane >= d) x += (uint64_t(hi) << 32) | lo;
+    }
+    if (lane == 63) s_wave[wave] = int64_t(x);
     __syncthreads();
-    s_part[tid] += v;
+    int64_t woff = s_carry;
+    for (int k = 0; k < wave; k++) woff += s_wave[k];
+    int64_t run = woff + int64_t(x) - sum;
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      if (k < per && a + k < base + left) sums[a + k] = run;
+      run += v[k];
+    }
+    __syncthreads();
+    if (tid == 1023) s_carry = run;    // the last thread's running value = everything so far
     __syncthreads();
   }
-  int64_t run = s_part[tid] - s;
-  for (int64_t i = a; i < b; i++) {
-    const int64_t v = sums[i];
-    sums[i] = run;
-    run += v;
-  }
-  if (tid == 1023) {
-    const int64_t total = s_part[1023];
+  if (tid == 0) {
+    const int64_t total = s_carry;
     total_out[0] = total;
     total_out[1] = total > capacity ? 1 : 0;
     if (out_starts_end) *out_starts_end = total;
@@ -210,17 +267,19 @@ __global__ void copy_total_kernel(const int64_t* __restrict__ src, int64_t* __re
 // out_starts[q] = rows located for the patterns before q; pattern q's rows first[q] .. first[q]+noccs-1 are written at
 // offsets[out_starts[q] ..] (the walk replaces each row by its text offset).  Ranges longer than kExpandSerialMax rows
 // (the empty pattern with a huge max_occs) are left to expand_big_rows_kernel.
+// kSa: the full suffix array is resident -- the offsets themselves are written (offsets[..] = SA[first + k], consecutive
+// reads) and no walk follows.
+template <bool kSa>
 __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npats, const int32_t* __restrict__ noccs, const int64_t* __restrict__ first,
                                                         const int64_t* __restrict__ block_offs, int64_t* __restrict__ out_starts,
-                                                        int64_t* __restrict__ offsets, const int64_t capacity, int* __restrict__ big_flag) {
+                                                        int64_t* __restrict__ offsets, const int64_t capacity, int* __restrict__ big_flag,
+                                                        const DevIndex ix) {
   __shared__ int64_t s_w[4];
   const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const int64_t n = q < npats ? int64_t(noccs[q]) : 0;
-  // inclusive scan inside the wavefront, then across the four wavefronts
-  uint32_t x = uint32_t(n);    // a block's rows: <= 256 * (2^31 - 1), kept in 64 bits below
+  // inclusive scan inside the wavefront, then across the four wavefronts (a block's rows: <= 256 * (2^31 - 1): 64 bits)
   uint64_t incl = uint64_t(n);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  (void)x;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const uint32_t lo = uint32_t(__shfl_up(int(uint32_t(incl)), d, 64)), hi = uint32_t(__shfl_up(int(uint32_t(incl >> 32)), d, 64));
@@ -230,10 +289,50 @@ __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npats, con
   __syncthreads();
   int64_t woff = 0;
   for (int k = 0; k < wave; k++) woff += s_w[k];
-  if (q >= npats) return;
-  const int64_t base = block_offs[blockIdx.x] + woff + int64_t(incl) - n;
-  out_starts[q] = base;
-  if (!offsets || n == 0) return;
+  const int64_t base = q < npats ? block_offs[blockIdx.x] + woff + int64_t(incl) - n : 0;
+  if (q < npats) out_starts[q] = base;
+  if (!offsets) return;
+  if (kSa) {
+    // The wavefront writes its patterns' offsets TOGETHER: output slot s of the wavefront's span belongs to the lane whose
+    // inclusive in-wave count first exceeds it, so consecutive lanes write consecutive slots (coalesced) and read
+    // consecutive suffix-array entries of a pattern's range.  Long ranges go to plan_big_rows_kernel as before.
+    __shared__ uint32_t s_incl[4][64];
+    __shared__ int64_t s_first[4][64], s_lbase[4][64];
+    const bool big = n > kExpandSerialMax;
+    if (big) atomicOr(big_flag, 1);
+    const uint32_t mine = (q < npats && !big) ? uint32_t(n) : 0u;     // rows this lane contributes to the cooperative part
+    uint32_t inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = uint32_t(__shfl_up(int(inc), d, 64));
+      if (lane >= d) inc += y;
+    }
+    s_incl[wave][lane] = inc;
+    s_first[wave][lane] = q < npats ? first[q] : 0;
+    s_lbase[wave][lane] = base;      // slots are addressed per lane: a long range keeps its slots but is not written here
+    const uint32_t total = uint32_t(__shfl(int(inc), 63, 64));
+    __syncthreads();
+    for (uint32_t s0 = 0; s0 < total; s0 += 64) {
+      const uint32_t sidx = s0 + uint32_t(lane);
+      if (sidx < total) {
+        int lo = 0, hi = 63;                 // first lane whose inclusive count exceeds sidx
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (s_incl[wave][mid] > sidx) hi = mid; else lo = mid + 1;
+        }
+        const uint32_t before = lo ? s_incl[wave][lo - 1] : 0u;
+        const int64_t k = int64_t(sidx - before);
+        const int64_t slot = s_lbase[wave][lo] + k;
+        if (slot < capacity) {
+          const int64_t row = s_first[wave][lo] + k;
+          offsets[slot] = ix.sa_full[row];
+          trace_touch(ix, kTraceSa, uint64_t(row) >> 4);
+        }
+      }
+    }
+    return;
+  }
+  if (q >= npats || n == 0) return;
   if (n > kExpandSerialMax) {
     atomicOr(big_flag, 1);
     return;
@@ -244,9 +343,11 @@ __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npats, con
 }
 
 // the long ranges left over by plan_rows_kernel: grid-stride, one thread per output slot (idle unless the flag is set)
+template <bool kSa>
 __global__ __launch_bounds__(256) void plan_big_rows_kernel(const int64_t npats, const int64_t* __restrict__ first,
                                                             const int64_t* __restrict__ out_starts, const int64_t* __restrict__ total_ptr,
-                                                            const int64_t capacity, int64_t* __restrict__ offsets, const int* __restrict__ big_flag) {
+                                                            const int64_t capacity, int64_t* __restrict__ offsets, const int* __restrict__ big_flag,
+                                                            const DevIndex ix) {
   if (!*big_flag) return;
   const int64_t total = *total_ptr < capacity ? *total_ptr : capacity;
   for (int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; item < total; item += int64_t(gridDim.x) * blockDim.x) {
@@ -256,8 +357,25 @@ __global__ __launch_bounds__(256) void plan_big_rows_kernel(const int64_t npats,
       if (out_starts[mid] <= item) lo = mid; else hi = mid;
     }
     const int64_t end = lo + 1 < npats ? out_starts[lo + 1] : *total_ptr;
-    if (end - out_starts[lo] > kExpandSerialMax) offsets[item] = first[lo] + (item - out_starts[lo]);
+    if (end - out_starts[lo] > kExpandSerialMax) {
+      const int64_t row = first[lo] + (item - out_starts[lo]);
+      if (kSa) {
+        offsets[item] = ix.sa_full[row];
+        trace_touch(ix, kTraceSa, uint64_t(row) >> 4);
+      } else {
+        offsets[item] = row;
+      }
+    }
   }
+}
+
+// the other row expansions (two-call API, host paths): rows already in offsets[] -> their text offsets, full suffix array
+__global__ __launch_bounds__(256) void gather_sa_kernel(const DevIndex ix, const int64_t total, int64_t* __restrict__ offsets) {
+  const int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (item >= total) return;
+  const int64_t row = offsets[item];
+  offsets[item] = ix.sa_full[row];
+  trace_touch(ix, kTraceSa, uint64_t(row) >> 4);
 }
 
 // locate walk (do_back_query / do_context_query, src/main/server.c:2228-2359, :2627-2795), persistent grid: the number

@@ -1,6 +1,8 @@
 // femto_amd_api.hip -- the C ABI (include/femto_amd.h) over the HIP kernels.  C++ host code that
 // owns device memory, streams and launch configuration; no compute happens on the host.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types only: the library is loaded on first use (femto_amd_comm_*), never at link time
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <climits>
@@ -22,8 +24,10 @@
 #include "kernels.hip.hpp"
 #include "pack_kernels.hip.hpp"
 #include "pack2_kernels.hip.hpp"
+#include "ind_kernels.hip.hpp"
 #include "text_kernels.hip.hpp"
 #include "direct_kernels.hip.hpp"
+#include "trace_api.hpp"
 
 using namespace femto_amd;
 
@@ -204,6 +208,9 @@ struct femto_amd_index {
   int64_t ktab2_bytes = 0;
   uint8_t* d_txt = nullptr;
   int64_t* d_isa8 = nullptr;
+  int64_t* d_sa_full = nullptr;
+  uint32_t* d_ind = nullptr;
+  int64_t ind_bytes = 0;
   int64_t text_bytes = 0;
   int64_t n_marks = 0;         // entries of pack_sa
   int64_t p2_lines1 = 0, p2_lines2 = 0;
@@ -242,6 +249,12 @@ struct femto_amd_index {
   std::vector<void*> peer_segs, peer_image;  // per part: base of that part's slices as seen from this process
   std::vector<char> peer_ipc;            // per part: 1 if opened with hipIpcOpenMemHandle (close on release)
   int64_t split_seg_bytes = 0, split_image_bytes = 0;
+  // multi-device handle (femto_amd_open_multi): no device of its own, one replica per GPU; host-pointer batches are
+  // sharded over the replicas by host threads
+  std::vector<femto_amd_index*> children;
+  // RCCL communicator of the multi-process form (femto_amd_comm_init)
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_size = 0;
 };
 
 namespace {
@@ -388,15 +401,37 @@ int tail_setup(femto_amd_index* ix, Scratch& S, DevIndex& d, int64_t npats, hipS
   return 0;
 }
 
+// count_tail_kernel of the handle's layout; with the full suffix array resident the row's position is one read
+void launch_tail(femto_amd_index* ix, const DevIndex& d, dim3 grid, hipStream_t stream, const TailItem* items, const int32_t* d_plen,
+                 const uint16_t* d_pats, const int64_t* d_starts, const uint32_t* perm, const uint64_t* keys, int bits, int nsym,
+                 const TailOut& out, int* err_flag) {
+  const dim3 block{uint32_t(kBlockThreads)};
+  const int* n_items = d.tail_count;
+  if (ix->mode == 3) {
+    if (d.sa_full) hipLaunchKernelGGL((count_tail_kernel<PackPolicy, true>), grid, block, 0, stream, d, items, n_items, d_plen, d_pats, d_starts, perm, keys, bits, nsym, out, err_flag);
+    else hipLaunchKernelGGL((count_tail_kernel<PackPolicy, false>), grid, block, 0, stream, d, items, n_items, d_plen, d_pats, d_starts, perm, keys, bits, nsym, out, err_flag);
+  } else {
+    if (d.sa_full) hipLaunchKernelGGL((count_tail_kernel<Pack2Policy, true>), grid, block, 0, stream, d, items, n_items, d_plen, d_pats, d_starts, perm, keys, bits, nsym, out, err_flag);
+    else hipLaunchKernelGGL((count_tail_kernel<Pack2Policy, false>), grid, block, 0, stream, d, items, n_items, d_plen, d_pats, d_starts, perm, keys, bits, nsym, out, err_flag);
+  }
+}
+
 // modes 3/4, caller order, no sort (direct_kernels.hip.hpp)
 int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
                         const int64_t* d_starts, int64_t* d_first, int64_t* d_last, hipStream_t stream, Plan* plan) {
   const int64_t nblocks = (npats + kBlockThreads - 1) / kBlockThreads;
   DevIndex d = ix->dev;
   int rc;
-  const bool tail = d.txt != nullptr;
+  // DNA (mode 3) with the full suffix array + inverse suffix array resident compares the tail inline: its lanes reach a
+  // one-row range at about the same step, so nothing diverges.  Byte alphabets (word-like text: 5.7 ms + 3.1 ms handed
+  // over vs 19 ms inline, measured) and the sampled arrays hand the pattern over to count_tail_kernel instead.
+  const bool inline_tail = d.txt && ix->mode == 3 && d.sa_full && d.isa8 && d.isa_shift == 0;
+  const bool tail = d.txt != nullptr && !inline_tail;
   if (tail && (rc = tail_setup(ix, S, d, npats, stream))) return rc;
-  if (!tail) d.txt = nullptr;
+  if (d.txt && !tail) {
+    d.tail_min = ix->mode == 3 ? 12 : 10;
+    if (const char* tm = getenv("FEMTO_AMD_TAIL_MIN")) d.tail_min = std::max(2, atoi(tm));
+  }
   int64_t* bsums = nullptr;
   if (plan) {
     if ((rc = S.bsums.reserve(size_t(nblocks + 1) * 8))) return rc;
@@ -407,23 +442,23 @@ int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const in
   const dim3 grid{uint32_t(nblocks)}, block{uint32_t(kBlockThreads)};
   const int mo = plan ? plan->max_occs : 0;
   int32_t* noccs = plan ? plan->noccs : nullptr;
-  if (ix->mode == 3) {
-    if (plan) hipLaunchKernelGGL((count_direct_kernel<PackPolicy, true>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.d_flags, mo, noccs, bsums);
-    else hipLaunchKernelGGL((count_direct_kernel<PackPolicy, false>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.d_flags, mo, noccs, bsums);
-  } else {
-    if (plan) hipLaunchKernelGGL((count_direct_kernel<Pack2Policy, true>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.d_flags, mo, noccs, bsums);
-    else hipLaunchKernelGGL((count_direct_kernel<Pack2Policy, false>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.d_flags, mo, noccs, bsums);
-  }
+  const bool dense = inline_tail;
+#define LAUNCH_COUNT_DIRECT(POLICY)                                                                                                        \
+  do {                                                                                                                                     \
+    if (plan && dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, true, true>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.d_flags, mo, noccs, bsums); \
+    else if (plan) hipLaunchKernelGGL((count_direct_kernel<POLICY, true, false>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.d_flags, mo, noccs, bsums);       \
+    else if (dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, false, true>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.d_flags, mo, noccs, bsums);     \
+    else hipLaunchKernelGGL((count_direct_kernel<POLICY, false, false>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.d_flags, mo, noccs, bsums);              \
+  } while (0)
+  if (ix->mode == 3) LAUNCH_COUNT_DIRECT(PackPolicy);
+  else if (d.ind) LAUNCH_COUNT_DIRECT(IndPolicy);     // per-character rank lines: one line per range end and step
+  else LAUNCH_COUNT_DIRECT(Pack2Policy);
+#undef LAUNCH_COUNT_DIRECT
   HIP_TRY(hipGetLastError());
   if (tail) {   // persistent grid: the number of handed-over patterns is only known on the device
     const TailOut out{nullptr, d_first, d_last, noccs, bsums, mo};
     const dim3 tgrid{uint32_t(std::min<int64_t>(nblocks, int64_t(ix->num_cus) * 8))};
-    if (ix->mode == 3)
-      hipLaunchKernelGGL(count_tail_kernel<PackPolicy>, tgrid, block, 0, stream, d, static_cast<const TailItem*>(S.tail.p), d.tail_count, d_plen, d_pats,
-                         d_starts, static_cast<const uint32_t*>(nullptr), static_cast<const uint64_t*>(nullptr), 1, 0, out, S.d_flags);
-    else
-      hipLaunchKernelGGL(count_tail_kernel<Pack2Policy>, tgrid, block, 0, stream, d, static_cast<const TailItem*>(S.tail.p), d.tail_count, d_plen, d_pats,
-                         d_starts, static_cast<const uint32_t*>(nullptr), static_cast<const uint64_t*>(nullptr), 1, 0, out, S.d_flags);
+    launch_tail(ix, d, tgrid, stream, static_cast<const TailItem*>(S.tail.p), d_plen, d_pats, d_starts, nullptr, nullptr, 1, 0, out, S.d_flags);
     HIP_TRY(hipGetLastError());
   }
   timer_end(ix, ix->t_count, stream, e0, e1);
@@ -518,14 +553,8 @@ int launch_count_chunk(femto_amd_index* ix, Scratch& S, int64_t npats, const int
   if (tail_launch) {
     const TailOut out{S.pairs.as<longlong2>(), nullptr, nullptr, nullptr, nullptr, 0};
     const dim3 tgrid{uint32_t(std::min<int64_t>((npats + kBlockThreads - 1) / kBlockThreads, int64_t(ix->num_cus) * 8))};
-    if (ix->mode == 3)
-      hipLaunchKernelGGL(count_tail_kernel<PackPolicy>, tgrid, dim3(kBlockThreads), 0, stream,
-                         d, static_cast<const TailItem*>(S.tail.p), d.tail_count, d_plen, d_pats, d_starts,
-                         static_cast<const uint32_t*>(S.idx2.as<uint32_t>()), static_cast<const uint64_t*>(S.keys2.as<uint64_t>()), ix->dense_bits, 63 / ix->dense_bits, out, S.d_flags);
-    else
-      hipLaunchKernelGGL(count_tail_kernel<Pack2Policy>, tgrid, dim3(kBlockThreads), 0, stream,
-                         d, static_cast<const TailItem*>(S.tail.p), d.tail_count, d_plen, d_pats, d_starts,
-                         static_cast<const uint32_t*>(S.idx2.as<uint32_t>()), static_cast<const uint64_t*>(S.keys2.as<uint64_t>()), ix->dense_bits, 63 / ix->dense_bits, out, S.d_flags);
+    launch_tail(ix, d, tgrid, stream, static_cast<const TailItem*>(S.tail.p), d_plen, d_pats, d_starts, S.idx2.as<uint32_t>(), S.keys2.as<uint64_t>(),
+                ix->dense_bits, 63 / ix->dense_bits, out, S.d_flags);
   }
   HIP_TRY(hipGetLastError());
   timer_end(ix, ix->t_count, stream, e0, e1);
@@ -603,12 +632,21 @@ int launch_plan_rows(femto_amd_index* ix, Scratch& S, int64_t npats, const int32
   int* big_flag = S.d_flags + 1;
   HIP_TRY(hipMemsetAsync(big_flag, 0, sizeof(int), stream));
   const int64_t nblocks = (npats + kBlockThreads - 1) / kBlockThreads;
-  hipLaunchKernelGGL(plan_rows_kernel, dim3(uint32_t(nblocks)), dim3(kBlockThreads), 0, stream, npats, d_noccs, d_first,
-                     static_cast<const int64_t*>(S.bsums.as<int64_t>()), d_out_starts, d_offsets, capacity, big_flag);
-  if (d_offsets)
-    hipLaunchKernelGGL(plan_big_rows_kernel, dim3(uint32_t(std::min<int64_t>(nblocks, int64_t(ix->num_cus) * 8))), dim3(kBlockThreads), 0, stream, npats,
-                       d_first, static_cast<const int64_t*>(d_out_starts), static_cast<const int64_t*>(S.d_total), capacity, d_offsets, static_cast<const int*>(big_flag));
+  const dim3 grid{uint32_t(nblocks)}, bgrid{uint32_t(std::min<int64_t>(nblocks, int64_t(ix->num_cus) * 8))}, block{uint32_t(kBlockThreads)};
+  const int64_t* boffs = S.bsums.as<int64_t>();
+  const bool sa = d_offsets && ix->dev.sa_full;    // the offsets themselves, no walk afterwards
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (sa) timer_begin(ix, ix->t_locate, stream, &e0, &e1);
+  if (sa) hipLaunchKernelGGL(plan_rows_kernel<true>, grid, block, 0, stream, npats, d_noccs, d_first, boffs, d_out_starts, d_offsets, capacity, big_flag, ix->dev);
+  else hipLaunchKernelGGL(plan_rows_kernel<false>, grid, block, 0, stream, npats, d_noccs, d_first, boffs, d_out_starts, d_offsets, capacity, big_flag, ix->dev);
+  if (d_offsets) {
+    if (sa) hipLaunchKernelGGL(plan_big_rows_kernel<true>, bgrid, block, 0, stream, npats, d_first, static_cast<const int64_t*>(d_out_starts),
+                               static_cast<const int64_t*>(S.d_total), capacity, d_offsets, static_cast<const int*>(big_flag), ix->dev);
+    else hipLaunchKernelGGL(plan_big_rows_kernel<false>, bgrid, block, 0, stream, npats, d_first, static_cast<const int64_t*>(d_out_starts),
+                            static_cast<const int64_t*>(S.d_total), capacity, d_offsets, static_cast<const int*>(big_flag), ix->dev);
+  }
   HIP_TRY(hipGetLastError());
+  if (sa) timer_end(ix, ix->t_locate, stream, e0, e1);
   return 0;
 }
 
@@ -654,6 +692,9 @@ int launch_locate(femto_amd_index* ix, Scratch& S, int64_t npats, const int64_t*
     }
     hipLaunchKernelGGL(locate_kernel_flat, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_first,
                        d_out_starts, total, d_offsets);
+  } else if ((ix->mode == 3 || ix->mode == 4) && ix->dev.sa_full) {
+    const int64_t lblocks = (total + kBlockThreads - 1) / kBlockThreads;
+    hipLaunchKernelGGL(gather_sa_kernel, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, total, d_offsets);
   } else if (ix->mode == 4) {
     const int64_t lblocks = (total + kBlockThreads - 1) / kBlockThreads;
     hipLaunchKernelGGL(locate_kernel_pack2, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, total, d_offsets);
@@ -990,6 +1031,28 @@ int build_pack2(femto_amd_index* ix) {
                        scans.as<int64_t>(), stride2);
     HIP_TRY(hipGetLastError());
     d.p2_l2 = ix->d_p2_l2;
+    {  // per-character rank lines (ind_kernels.hip.hpp) while the symbols are at hand -- optional: a quarter of the free HBM
+      bool want = true;
+      if (const char* e = getenv("FEMTO_AMD_IND")) want = atoi(e) != 0;
+      const int64_t groups = (n + kIndRows - 1) / kIndRows, istride = groups + 1;
+      const size_t ibytes = size_t(sigma) * size_t(istride) * 128;
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+      if (want && ibytes <= free_b / 4 && hipMalloc(reinterpret_cast<void**>(&ix->d_ind), ibytes + 256) == hipSuccess) {
+        HIP_TRY(hipMemset(ix->d_ind, 0, ibytes + 256));
+        const int64_t gchunk = int64_t(1) << 22;
+        for (int64_t g0 = 0; g0 < groups; g0 += gchunk)
+          hipLaunchKernelGGL(ind_build_kernel, dim3(uint32_t(std::min(gchunk, groups - g0))), dim3(256), 0, nullptr, ix->dev, n, sym.as<uint16_t>(),
+                             ix->d_ind, istride, g0);
+        HIP_TRY(hipGetLastError());
+        d.ind = ix->d_ind;
+        d.ind_stride = istride;
+        ix->ind_bytes = int64_t(ibytes);
+        ix->table_bytes += ix->ind_bytes;
+      } else {
+        (void)hipGetLastError();
+      }
+    }
     int64_t sa_bytes = 0;
     const int every = derived_mark_every(h);
     int64_t nmarks = tot[16];
@@ -1051,15 +1114,31 @@ int build_pack2(femto_amd_index* ix) {
   return r;
 }
 
-// text + sampled inverse suffix array for the long-pattern tail (text_kernels.hip.hpp); optional (FEMTO_AMD_TEXT=0)
+// text + inverse suffix array for the long-pattern tail (text_kernels.hip.hpp); optional (FEMTO_AMD_TEXT=0).
+// When HBM allows (each at most a fifth of what is free; FEMTO_AMD_DENSE=0 declines) the inverse suffix array is kept for
+// EVERY text position instead of every 8th, and the suffix array itself for every row: locating a row is then one
+// 8-byte read instead of a walk of LF steps, the row of a text position one read instead of up to 7 LF steps.  This is
+// femto's own space/time knob -- mark_period (src/main/index.c:122-142) -- turned to 1 in HBM; the files stay as they are.
 int build_text(femto_amd_index* ix) {
   if (const char* e = getenv("FEMTO_AMD_TEXT")) if (atoi(e) == 0) return 0;
   const int64_t n = ix->host.total_length;
-  const size_t tb = size_t(n) + 64, ib = (size_t(n >> kIsaShift) + 2) * 8;
-  if (hipMalloc(reinterpret_cast<void**>(&ix->d_txt), tb) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&ix->d_isa8), ib) != hipSuccess) {
+  bool dense = true;
+  if (const char* e = getenv("FEMTO_AMD_DENSE")) dense = atoi(e) != 0;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+  int isa_shift = kIsaShift;
+  if (dense && size_t(n + 2) * 8 <= free_b / 5) {
+    isa_shift = 0;
+    free_b -= size_t(n + 2) * 8;
+  }
+  const bool want_sa = dense && size_t(n) * 8 <= free_b / 5;
+  const size_t tb = size_t(n) + 64, ib = (size_t(n >> isa_shift) + 2) * 8, sb = want_sa ? size_t(n) * 8 + 64 : 0;
+  if (hipMalloc(reinterpret_cast<void**>(&ix->d_txt), tb) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&ix->d_isa8), ib) != hipSuccess ||
+      (sb && hipMalloc(reinterpret_cast<void**>(&ix->d_sa_full), sb) != hipSuccess)) {
     (void)hipGetLastError();
     (void)hipFree(ix->d_txt); ix->d_txt = nullptr;
     (void)hipFree(ix->d_isa8); ix->d_isa8 = nullptr;
+    (void)hipFree(ix->d_sa_full); ix->d_sa_full = nullptr;
     return FEMTO_AMD_ERR_MEM;
   }
   HIP_TRY(hipMemset(ix->d_txt, 0xff, tb));
@@ -1067,16 +1146,22 @@ int build_text(femto_amd_index* ix) {
   const int64_t chunk = int64_t(1) << 30;
   for (int64_t r0 = 0; r0 < n; r0 += chunk) {
     const int64_t cn = std::min(chunk, n - r0);
-    if (ix->dev.pack)
-      hipLaunchKernelGGL(text_isa_build_kernel<PackPolicy>, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, r0, cn, ix->d_txt, ix->d_isa8);
-    else
-      hipLaunchKernelGGL(text_isa_build_kernel<Pack2Policy>, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, r0, cn, ix->d_txt, ix->d_isa8);
+    const dim3 grid{uint32_t((cn + 255) / 256)}, block{256};
+    if (ix->dev.pack) {
+      if (sb) hipLaunchKernelGGL((text_isa_build_kernel<PackPolicy, true>), grid, block, 0, nullptr, ix->dev, r0, cn, ix->d_txt, ix->d_isa8, isa_shift, ix->d_sa_full);
+      else hipLaunchKernelGGL((text_isa_build_kernel<PackPolicy, false>), grid, block, 0, nullptr, ix->dev, r0, cn, ix->d_txt, ix->d_isa8, isa_shift, ix->d_sa_full);
+    } else {
+      if (sb) hipLaunchKernelGGL((text_isa_build_kernel<Pack2Policy, true>), grid, block, 0, nullptr, ix->dev, r0, cn, ix->d_txt, ix->d_isa8, isa_shift, ix->d_sa_full);
+      else hipLaunchKernelGGL((text_isa_build_kernel<Pack2Policy, false>), grid, block, 0, nullptr, ix->dev, r0, cn, ix->d_txt, ix->d_isa8, isa_shift, ix->d_sa_full);
+    }
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   ix->dev.txt = ix->d_txt;
   ix->dev.isa8 = ix->d_isa8;
-  ix->text_bytes = int64_t(tb + ib);
+  ix->dev.isa_shift = isa_shift;
+  ix->dev.sa_full = ix->d_sa_full;
+  ix->text_bytes = int64_t(tb + ib + sb);
   ix->table_bytes += ix->text_bytes;
   return 0;
 }
@@ -1355,6 +1440,74 @@ int locate_host(femto_amd_index* ix, Scratch& S, const HostBatch& hb, int max_oc
 }
 
 }  // namespace
+namespace {
+
+// ---- multi-device handle: contiguous shards of a host-pointer batch, one host thread per replica --------------------
+// fn(child, lo, hi) runs the ordinary single-device call on patterns [lo, hi); the first failure is reported.
+template <class Fn>
+int multi_run(femto_amd_index* ix, int64_t npats, Fn fn) {
+  const int N = int(ix->children.size());
+  std::vector<int> rcs(size_t(N), 0);
+  std::vector<std::string> msgs((size_t(N)));
+  std::vector<std::thread> th;
+  for (int i = 0; i < N; i++)
+    th.emplace_back([&, i] {
+      const int64_t lo = npats * i / N, hi = npats * (i + 1) / N;
+      try {
+        rcs[size_t(i)] = fn(ix->children[size_t(i)], i, lo, hi);
+      } catch (...) {
+        rcs[size_t(i)] = FEMTO_AMD_ERR_INVALID;
+      }
+      if (rcs[size_t(i)]) msgs[size_t(i)] = g_last_error;   // thread-local message of the failing call
+    });
+  for (auto& t : th) t.join();
+  for (int i = 0; i < N; i++)
+    if (rcs[size_t(i)]) return set_err(rcs[size_t(i)], "device shard " + std::to_string(i) + ": " + msgs[size_t(i)]);
+  return 0;
+}
+
+// ---- RCCL, loaded on first use ---------------------------------------------------------------------------------------
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl* rccl() {
+  static Rccl R;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    R.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!R.lib) R.lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!R.lib) return;
+    R.GetUniqueId = reinterpret_cast<decltype(R.GetUniqueId)>(dlsym(R.lib, "ncclGetUniqueId"));
+    R.CommInitRank = reinterpret_cast<decltype(R.CommInitRank)>(dlsym(R.lib, "ncclCommInitRank"));
+    R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(dlsym(R.lib, "ncclCommDestroy"));
+    R.Send = reinterpret_cast<decltype(R.Send)>(dlsym(R.lib, "ncclSend"));
+    R.Recv = reinterpret_cast<decltype(R.Recv)>(dlsym(R.lib, "ncclRecv"));
+    R.GroupStart = reinterpret_cast<decltype(R.GroupStart)>(dlsym(R.lib, "ncclGroupStart"));
+    R.GroupEnd = reinterpret_cast<decltype(R.GroupEnd)>(dlsym(R.lib, "ncclGroupEnd"));
+    R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(dlsym(R.lib, "ncclGetErrorString"));
+  });
+  if (!R.lib || !R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.Send || !R.Recv || !R.GroupStart || !R.GroupEnd) return nullptr;
+  return &R;
+}
+
+#define RCCL_TRY(R, expr)                                                                                         \
+  do {                                                                                                            \
+    ncclResult_t r_ = (expr);                                                                                     \
+    if (r_ != ncclSuccess)                                                                                        \
+      return set_err(FEMTO_AMD_ERR_INVALID, std::string(#expr) + ": " + ((R)->GetErrorString ? (R)->GetErrorString(r_) : "rccl error")); \
+  } while (0)
+
+}  // namespace
+
 extern "C" {
 
 const char* femto_amd_last_error(void) { return g_last_error.c_str(); }
@@ -1502,9 +1655,7 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
       r = build_pack2(ix);
       if (r == FEMTO_AMD_ERR_MEM) {
         (void)hipGetLastError();
-        (void)hipFree(ix->d_txt);
-    (void)hipFree(ix->d_isa8);
-    (void)hipFree(ix->d_p2_l1); ix->d_p2_l1 = nullptr;
+        (void)hipFree(ix->d_p2_l1); ix->d_p2_l1 = nullptr;
         (void)hipFree(ix->d_p2_l2); ix->d_p2_l2 = nullptr;
         ix->dev.p2_l1 = nullptr;
         ix->dev.p2_l2 = nullptr;
@@ -1667,6 +1818,12 @@ int femto_amd_split_info(const femto_amd_index_t* ix, int* part, int* nparts, in
 
 void femto_amd_close(femto_amd_index_t* ix) {
   if (!ix) return;
+  for (femto_amd_index* c : ix->children) femto_amd_close(c);
+  ix->children.clear();
+  if (ix->comm) {
+    if (Rccl* R = rccl()) (void)R->CommDestroy(ix->comm);
+    ix->comm = nullptr;
+  }
   if (ix->device >= 0) {
     (void)hipSetDevice(ix->device);
     ix->t_count.destroy();
@@ -1709,6 +1866,8 @@ void femto_amd_close(femto_amd_index_t* ix) {
     (void)hipFree(ix->d_p2_code);
     (void)hipFree(ix->d_p2_alpha);
     (void)hipFree(ix->d_ktab2);
+    (void)hipFree(ix->d_sa_full);
+    (void)hipFree(ix->d_ind);
     for (DeviceBuffer& b : ix->open_scan) b.release();
   }
   delete ix;
@@ -1733,6 +1892,7 @@ int femto_amd_info(const femto_amd_index_t* ix, femto_amd_info_t* out) {
                              h.lnodes.size() * sizeof(LaneNode) + h.lseqs.size() * sizeof(LaneSeq) +
                              h.occ.size() * sizeof(OccEntry));
   if (ix->device >= 0) out->table_bytes = ix->table_bytes;   // what is actually resident, derived fast-path layouts included
+  if (!ix->children.empty()) out->table_bytes = ix->children[0]->table_bytes;   // per GPU
   return FEMTO_AMD_OK;
 }
 
@@ -1779,6 +1939,12 @@ int femto_amd_count_flat(femto_amd_index_t* ix, int64_t npats, const int32_t* pl
                          const int64_t* starts, int64_t* first, int64_t* last) {
   API_BEGIN
   if (!ix || (npats && !first)) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  if (!ix->children.empty()) {   // multi-device handle: contiguous shards, one host thread per GPU
+    if (npats < 0 || (npats && (!plen || !starts))) return set_err(FEMTO_AMD_ERR_PARAM, "null pattern arrays");
+    return multi_run(ix, npats, [&](femto_amd_index* c, int, int64_t lo, int64_t hi) {
+      return femto_amd_count_flat(c, hi - lo, plen + lo, pats, starts + lo, first + lo, last ? last + lo : nullptr);
+    });
+  }
   int rc = ensure_device(ix);
   if (rc) return rc;
   Lease L(ix);
@@ -1827,6 +1993,12 @@ int femto_amd_parallel_count(femto_amd_index_t* ix, int npats, const int* plen, 
                              int64_t* first, int64_t* last) {
   API_BEGIN
   if (npats < 0 || (npats && (!plen || !pats))) return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
+  if (ix && !ix->children.empty()) {
+    if (npats && !first) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+    return multi_run(ix, npats, [&](femto_amd_index* c, int, int64_t lo, int64_t hi) {
+      return femto_amd_parallel_count(c, int(hi - lo), plen + lo, pats + lo, first + lo, last ? last + lo : nullptr);
+    });
+  }
   if (ix && first && npats >= kPipeMin && ix->device >= 0) {  // large batches: gathered chunk by chunk into pinned memory
     int rc = ensure_device(ix);
     if (rc) return rc;
@@ -1905,7 +2077,7 @@ int femto_amd_locate_device(femto_amd_index_t* ix, int64_t npats, const int32_t*
   if ((rc = launch_count_plan(ix, S, npats, d_plen, d_pats, d_starts, d_first, d_last, &plan, stream))) return rc;
   if (plan.done) {   // direct pipeline: one stream-ordered chain, nothing returns to the host
     if ((rc = launch_plan_rows(ix, S, npats, d_noccs, d_first, d_out_starts, d_offsets, offsets_capacity, stream))) return rc;
-    if (offsets_capacity > 0 && d_offsets && (rc = launch_walk_device_total(ix, S, d_offsets, offsets_capacity, stream))) return rc;
+    if (offsets_capacity > 0 && d_offsets && !ix->dev.sa_full && (rc = launch_walk_device_total(ix, S, d_offsets, offsets_capacity, stream))) return rc;
   } else {           // other kernel families size the walk on the host
     int64_t tot[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(tot, S.d_total, sizeof tot, hipMemcpyDeviceToHost, stream));
@@ -1924,6 +2096,17 @@ int femto_amd_locate_flat(femto_amd_index_t* ix, int64_t npats, const int32_t* p
   API_BEGIN
   if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
   if (max_occs_each < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative max_occs_each");
+  if (!ix->children.empty()) {   // through the one-pass form, then into the caller's buffer
+    int64_t* all = nullptr;
+    int64_t tot = 0;
+    int rc = femto_amd_locate_flat_alloc(ix, npats, plen, pats, starts, max_occs_each, noccs, out_starts, &all, &tot);
+    if (rc) return rc;
+    if (total_out) *total_out = tot;
+    if (offsets && offsets_capacity < tot) { free(all); return set_err(FEMTO_AMD_ERR_PARAM, "offsets buffer too small"); }
+    if (offsets && tot) memcpy(offsets, all, size_t(tot) * 8);
+    free(all);
+    return FEMTO_AMD_OK;
+  }
   int rc = ensure_device(ix);
   if (rc) return rc;
   if (npats < 0 || (npats && (!plen || !starts))) return set_err(FEMTO_AMD_ERR_PARAM, "null pattern arrays");
@@ -1954,6 +2137,42 @@ int femto_amd_locate_flat_alloc(femto_amd_index_t* ix, int64_t npats, const int3
   API_BEGIN
   if (!ix || !offsets_out) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
   if (max_occs_each < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative max_occs_each");
+  if (!ix->children.empty()) {   // shards locate independently; their offsets are concatenated in batch order
+    if (npats < 0 || (npats && (!plen || !starts))) return set_err(FEMTO_AMD_ERR_PARAM, "null pattern arrays");
+    const int N = int(ix->children.size());
+    std::vector<int64_t*> part(size_t(N), nullptr);
+    std::vector<int64_t> ptotal(size_t(N), 0);
+    std::vector<std::vector<int64_t>> pstarts((size_t(N)));
+    std::vector<int32_t> tmp_noccs;
+    if (!noccs) { tmp_noccs.resize(size_t(npats) + 1); noccs = tmp_noccs.data(); }
+    int rc = multi_run(ix, npats, [&](femto_amd_index* c, int i, int64_t lo, int64_t hi) {
+      pstarts[size_t(i)].assign(size_t(hi - lo) + 1, 0);
+      return femto_amd_locate_flat_alloc(c, hi - lo, plen + lo, pats, starts + lo, max_occs_each, noccs + lo, pstarts[size_t(i)].data(),
+                                         &part[size_t(i)], &ptotal[size_t(i)]);
+    });
+    int64_t total = 0;
+    for (int i = 0; i < N; i++) total += ptotal[size_t(i)];
+    int64_t* all = nullptr;
+    if (!rc && total) {
+      all = static_cast<int64_t*>(malloc(size_t(total) * 8));
+      if (!all) rc = set_err(FEMTO_AMD_ERR_MEM, "malloc failed");
+    }
+    int64_t at = 0;
+    for (int i = 0; i < N; i++) {
+      const int64_t lo = npats * i / N, hi = npats * (i + 1) / N;
+      if (!rc) {
+        if (ptotal[size_t(i)]) memcpy(all + at, part[size_t(i)], size_t(ptotal[size_t(i)]) * 8);
+        if (out_starts) for (int64_t k = lo; k < hi; k++) out_starts[k] = at + pstarts[size_t(i)][size_t(k - lo)];
+      }
+      at += ptotal[size_t(i)];
+      free(part[size_t(i)]);
+    }
+    if (rc) return rc;
+    if (out_starts) out_starts[npats] = total;
+    *offsets_out = all;
+    if (total_out) *total_out = total;
+    return FEMTO_AMD_OK;
+  }
   int rc = ensure_device(ix);
   if (rc) return rc;
   if (npats < 0 || (npats && (!plen || !starts))) return set_err(FEMTO_AMD_ERR_PARAM, "null pattern arrays");
@@ -1974,6 +2193,10 @@ int femto_amd_parallel_locate(femto_amd_index_t* ix, int npats, const int* plen,
   if (npats < 0 || (npats && (!plen || !pats || !noccs || !offsets))) return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
   if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
   if (max_occs_each < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative max_occs_each");
+  if (!ix->children.empty())     // every pattern's offsets are its own malloc(): shards are independent
+    return multi_run(ix, npats, [&](femto_amd_index* c, int, int64_t lo, int64_t hi) {
+      return femto_amd_parallel_locate(c, int(hi - lo), plen + lo, pats + lo, max_occs_each, noccs + lo, offsets + lo);
+    });
   int rc = ensure_device(ix);
   if (rc) return rc;
   std::vector<int64_t> ostarts(size_t(npats) + 2);
@@ -2024,10 +2247,14 @@ int femto_amd_parallel_locate(femto_amd_index_t* ix, int npats, const int* plen,
 int femto_amd_parallel_locate_range(femto_amd_index_t* ix, int64_t first, int64_t last, int64_t* offsets) {
   API_BEGIN
   if (!ix || !offsets) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
-  int rc = ensure_device(ix);
-  if (rc) return rc;
   if (first < 0 || last < first || last >= ix->host.total_length)
     return set_err(FEMTO_AMD_ERR_PARAM, "row range outside the index");   // the reference has no query to set up (server.c:4061)
+  if (!ix->children.empty())
+    return multi_run(ix, last - first + 1, [&](femto_amd_index* c, int, int64_t lo, int64_t hi) {
+      return hi > lo ? femto_amd_parallel_locate_range(c, first + lo, first + hi - 1, offsets + lo) : 0;
+    });
+  int rc = ensure_device(ix);
+  if (rc) return rc;
   Lease L(ix);
   if (!L.s) return L.rc;
   Scratch& S = *L.s;
@@ -2050,6 +2277,7 @@ int femto_amd_block_requests(femto_amd_index_t* ix, int64_t n, const int64_t* ro
                              uint16_t* ch_out, int32_t* occ_out, int64_t* off_out) {
   API_BEGIN
   if (!ix || (n && !rows)) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  if (!ix->children.empty()) return femto_amd_block_requests(ix->children[0], n, rows, ch_in, ch_out, occ_out, off_out);
   int rc = ensure_device(ix);
   if (rc) return rc;
   const HostIndex& h = ix->host;
@@ -2114,6 +2342,7 @@ int femto_amd_forward_steps(femto_amd_index_t* ix, int64_t n, const int64_t* row
                             int64_t* off_out) {
   API_BEGIN
   if (!ix || (n && (!rows || !ch_out || !row_out || !off_out))) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  if (!ix->children.empty()) return femto_amd_forward_steps(ix->children[0], n, rows, ch_out, row_out, off_out);
   int rc = ensure_device(ix);
   if (rc) return rc;
   if (!ix->host.dir_regular) return set_err(FEMTO_AMD_ERR_INVALID, "forward steps need the derived mark-table directory");
@@ -2141,75 +2370,104 @@ int femto_amd_forward_steps(femto_amd_index_t* ix, int64_t n, const int64_t* row
   API_END
 }
 
-// Compulsory traffic of a batch: runs count (+ clamp + scan) and then the row expansion + locate walk with the line
-// trace switched on and reports, per traced array, how many DISTINCT 128-byte lines each phase loaded.
+// Compulsory traffic of a batch: runs count (+ clamp + scan) and then the row expansion + locate walk through the TRACED
+// twins of the direct pipeline's kernels (trace_kernels.hip) and reports, per traced array, how many DISTINCT 128-byte
+// lines each phase loaded.
 int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
-                          const int64_t* d_starts, int max_occs_each, int64_t* count_lines /* [8] */,
-                          int64_t* locate_lines /* [8] */, int64_t* rows_out) {
+                          const int64_t* d_starts, int max_occs_each, int64_t* count_lines /* [10] */,
+                          int64_t* locate_lines /* [10] */, int64_t* rows_out) {
   API_BEGIN
+  namespace ta = femto_amd_trace_api;
   if (!ix || !count_lines || !locate_lines) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
   int rc = ensure_device(ix);
   if (rc) return rc;
   if (npats <= 0 || npats >= (int64_t(1) << 31)) return set_err(FEMTO_AMD_ERR_PARAM, "trace: 1 .. 2^31-1 patterns");
+  if (!use_direct(ix)) return set_err(FEMTO_AMD_ERR_INVALID, "the line trace follows the direct pipeline (modes 3/4 with the level table)");
+  if (ta::traced_dev_index_bytes() != sizeof(DevIndex)) return set_err(FEMTO_AMD_ERR_INVALID, "traced kernels were built from different tables");
   Lease L(ix);
   if (!L.s) return L.rc;
   Scratch& S = *L.s;
   hipStream_t st = S.stream;
   const int64_t n = ix->host.total_length;
-  int64_t region_lines[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t region_lines[kTraceRegions] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  region_lines[kTraceInd] = ix->ind_bytes / 128;
   region_lines[kTracePack] = ix->dev.pack ? (n + kPackRows - 1) / kPackRows : 0;
   region_lines[kTraceKtab] = ix->ktab2_bytes / 128 + 1;
-  region_lines[kTraceSa] = ix->n_marks / 16 + 1;
+  region_lines[kTraceSa] = (ix->dev.sa_full ? n : ix->n_marks) / 16 + 1;
   region_lines[kTraceL1] = ix->p2_lines1;
   region_lines[kTraceL2] = ix->p2_lines2;
   region_lines[kTraceTxt] = ix->dev.txt ? (n + 64) / 128 + 1 : 0;
-  region_lines[kTraceIsa] = ix->dev.isa8 ? ((n >> kIsaShift) + 2) / 16 + 1 : 0;
+  region_lines[kTraceIsa] = ix->dev.isa8 ? ((n >> ix->dev.isa_shift) + 2) / 16 + 1 : 0;
   region_lines[kTraceKtab1] = ix->dev.ktab ? ((int64_t(1) << ix->dev.ktab_bits) * 16) / 128 + 1 : 0;
-  int64_t off[9];
+  int64_t off[kTraceRegions + 1];
   off[0] = 0;
-  for (int r = 0; r < 8; r++) off[r + 1] = (off[r] + region_lines[r] + 63) & ~int64_t(63);
+  for (int r = 0; r < kTraceRegions; r++) off[r + 1] = (off[r] + region_lines[r] + 63) & ~int64_t(63);
   DeviceBuffer bitmap, counts;
+  static_assert(kTraceRegions <= 16, "counts buffer");
   auto body = [&]() -> int {
     int r2;
-    if ((r2 = bitmap.reserve(size_t(off[8]) / 8 + 64))) return r2;
+    const size_t bm_bytes = size_t(off[kTraceRegions]) / 8 + 64;
+    const int64_t nblocks = (npats + kBlockThreads - 1) / kBlockThreads;
+    if ((r2 = bitmap.reserve(bm_bytes))) return r2;
     if ((r2 = counts.reserve(16 * 8))) return r2;
     if ((r2 = S.first.reserve(size_t(npats + 1) * 8))) return r2;
     if ((r2 = S.last.reserve(size_t(npats + 1) * 8))) return r2;
     if ((r2 = S.noccs.reserve(size_t(npats + 1) * 4))) return r2;
     if ((r2 = S.out_starts.reserve(size_t(npats + 2) * 8))) return r2;
-    DevIndex saved = ix->dev;
+    if ((r2 = S.bsums.reserve(size_t(nblocks + 1) * 8))) return r2;
+    DevIndex d = ix->dev;
+    ta::TraceArgs a{};
+    a.dev = &d;
+    a.mode = ix->mode;
+    a.num_cus = ix->num_cus;
+    a.npats = npats;
+    a.plen = d_plen;
+    a.pats = d_pats;
+    a.starts = d_starts;
+    a.max_occs = max_occs_each;
+    a.first = S.first.as<int64_t>();
+    a.last = S.last.as<int64_t>();
+    a.noccs = S.noccs.as<int32_t>();
+    a.out_starts = S.out_starts.as<int64_t>();
+    a.bsums = S.bsums.as<int64_t>();
+    a.tail_items = nullptr;
+    a.tail_min = ix->mode == 3 ? 12 : 10;
+    if (const char* tm = getenv("FEMTO_AMD_TAIL_MIN")) a.tail_min = std::max(2, atoi(tm));
+    if (d.txt && !(ix->mode == 3 && d.sa_full && d.isa8 && d.isa_shift == 0)) {
+      if ((r2 = tail_setup(ix, S, d, npats, st))) return r2;
+      a.tail_items = d.tail_items;
+      a.tail_min = d.tail_min;
+    }
+    a.flags = S.d_flags;
+    a.total = S.d_total;
+    a.bitmap = static_cast<uint32_t*>(bitmap.p);
+    a.trace_off = off;
+    a.stream = st;
     auto collect = [&](int64_t* out) -> int {
       HIP_TRY(hipMemsetAsync(counts.p, 0, 16 * 8, st));
-      for (int r = 0; r < 8; r++)
+      for (int r = 0; r < kTraceRegions; r++)
         if (region_lines[r])
-          hipLaunchKernelGGL(trace_popcount_kernel, dim3(1024), dim3(256), 0, st, static_cast<const uint32_t*>(bitmap.p), off[r] / 32,
-                             (off[r] + region_lines[r] + 31) / 32, reinterpret_cast<unsigned long long*>(counts.p) + r);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipMemcpyAsync(out, counts.p, 8 * 8, hipMemcpyDeviceToHost, st));
+          HIP_TRY(ta::traced_popcount(static_cast<const uint32_t*>(bitmap.p), off[r] / 32, (off[r] + region_lines[r] + 31) / 32,
+                                      reinterpret_cast<unsigned long long*>(counts.p) + r, st));
+      HIP_TRY(hipMemcpyAsync(out, counts.p, kTraceRegions * 8, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
       return 0;
     };
-    HIP_TRY(hipMemsetAsync(bitmap.p, 0, size_t(off[8]) / 8 + 64, st));
-    ix->dev.trace = static_cast<uint32_t*>(bitmap.p);
-    for (int r = 0; r < 8; r++) ix->dev.trace_off[r] = off[r];
-    Plan plan{max_occs_each, S.noccs.as<int32_t>(), S.out_starts.as<int64_t>(), INT64_MAX, false};
-    r2 = launch_count_plan(ix, S, npats, d_plen, d_pats, d_starts, S.first.as<int64_t>(), S.last.as<int64_t>(), &plan, st);
-    if (!r2) r2 = collect(count_lines);
+    HIP_TRY(hipMemsetAsync(bitmap.p, 0, bm_bytes, st));
+    HIP_TRY(ta::traced_count_plan(a));
+    if ((r2 = collect(count_lines))) return r2;
     int64_t total = 0;
-    if (!r2) {
-      HIP_TRY(hipMemsetAsync(bitmap.p, 0, size_t(off[8]) / 8 + 64, st));
-      if (plan.done) r2 = launch_plan_rows(ix, S, npats, S.noccs.as<int32_t>(), S.first.as<int64_t>(), S.out_starts.as<int64_t>(), nullptr, INT64_MAX, st);
-      if (!r2) {
-        HIP_TRY(hipMemcpyAsync(&total, S.out_starts.as<int64_t>() + npats, 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (total > 0 && !(r2 = S.offsets.reserve(size_t(total) * 8)))
-          r2 = launch_locate(ix, S, npats, S.first.as<int64_t>(), S.out_starts.as<int64_t>(), total, S.offsets.as<int64_t>(), st);
-      }
-      if (!r2) r2 = collect(locate_lines);
+    HIP_TRY(hipMemcpyAsync(&total, S.d_total, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemsetAsync(bitmap.p, 0, bm_bytes, st));
+    if (total > 0) {
+      if ((r2 = S.offsets.reserve(size_t(total) * 8))) return r2;
+      HIP_TRY(ta::traced_walk(a, S.offsets.as<int64_t>(), total));
     }
+    if ((r2 = collect(locate_lines))) return r2;
     if (rows_out) *rows_out = total;
-    ix->dev = saved;
-    return r2;
+    HIP_TRY(hipMemsetAsync(S.d_flags, 0, 4 * sizeof(int), st));
+    return 0;
   };
   rc = body();
   (void)hipStreamSynchronize(st);
@@ -2219,8 +2477,115 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
   API_END
 }
 
+// ---- several GPUs ------------------------------------------------------------------------------------------------------
+int femto_amd_open_multi(const char* index_path, int ndev, const int* devices, femto_amd_index_t** out) {
+  API_BEGIN
+  if (!index_path || !out || ndev < 1 || ndev > 64 || !devices) return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
+  *out = nullptr;
+  femto_amd_index_t* ix = nullptr;
+  int rc = femto_amd_open(index_path, -1, &ix);     // parse-only: facts, document table
+  if (rc) return rc;
+  ix->children.assign(size_t(ndev), nullptr);
+  std::vector<int> rcs(size_t(ndev), 0);
+  std::vector<std::string> msgs((size_t(ndev)));
+  std::vector<std::thread> th;
+  for (int i = 0; i < ndev; i++)
+    th.emplace_back([&, i] {
+      rcs[size_t(i)] = femto_amd_open(index_path, devices[i], &ix->children[size_t(i)]);
+      if (rcs[size_t(i)]) msgs[size_t(i)] = g_last_error;
+    });
+  for (auto& t : th) t.join();
+  for (int i = 0; i < ndev; i++)
+    if (rcs[size_t(i)]) {
+      const int code = rcs[size_t(i)];
+      const std::string m = "device " + std::to_string(devices[i]) + ": " + msgs[size_t(i)];
+      for (auto& c : ix->children) if (!c) c = nullptr;
+      std::vector<femto_amd_index*> kids;
+      for (femto_amd_index* c : ix->children) if (c) kids.push_back(c);
+      ix->children = kids;
+      femto_amd_close(ix);
+      return set_err(code, m);
+    }
+  *out = ix;
+  return FEMTO_AMD_OK;
+  API_END
+}
+
+int femto_amd_device_count(const femto_amd_index_t* ix) {
+  if (!ix) return 0;
+  return ix->children.empty() ? (ix->device >= 0 ? 1 : 0) : int(ix->children.size());
+}
+
+int femto_amd_comm_unique_id(void* id128) {
+  API_BEGIN
+  if (!id128) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  Rccl* R = rccl();
+  if (!R) return set_err(FEMTO_AMD_ERR_MISSING, "librccl.so could not be loaded");
+  static_assert(sizeof(ncclUniqueId) == 128, "id blob layout");
+  ncclUniqueId id;
+  RCCL_TRY(R, R->GetUniqueId(&id));
+  memcpy(id128, &id, sizeof id);
+  return FEMTO_AMD_OK;
+  API_END
+}
+
+int femto_amd_comm_init(femto_amd_index_t* ix, const void* id128, int nranks, int rank) {
+  API_BEGIN
+  if (!ix || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
+  int rc = ensure_device(ix);
+  if (rc) return rc;
+  Rccl* R = rccl();
+  if (!R) return set_err(FEMTO_AMD_ERR_MISSING, "librccl.so could not be loaded");
+  if (ix->comm) return set_err(FEMTO_AMD_ERR_INVALID, "communicator already initialised");
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof id);
+  RCCL_TRY(R, R->CommInitRank(&ix->comm, nranks, id, rank));
+  ix->comm_rank = rank;
+  ix->comm_size = nranks;
+  return FEMTO_AMD_OK;
+  API_END
+}
+
+// bytes_per_rank bytes of every rank land, in rank order, in d_recv on `root`: one grouped batch of point-to-point
+// transfers (xGMI is point to point: every peer's payload crosses its own link into the root)
+int femto_amd_comm_gather(femto_amd_index_t* ix, const void* d_send, void* d_recv, int64_t bytes_per_rank, int root, void* stream_) {
+  API_BEGIN
+  if (!ix || !ix->comm) return set_err(FEMTO_AMD_ERR_INVALID, "no communicator (femto_amd_comm_init)");
+  if (bytes_per_rank < 0 || root < 0 || root >= ix->comm_size || (bytes_per_rank && !d_send)) return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
+  if (ix->comm_rank == root && bytes_per_rank && !d_recv) return set_err(FEMTO_AMD_ERR_PARAM, "root needs a receive buffer");
+  int rc = ensure_device(ix);
+  if (rc) return rc;
+  Rccl* R = rccl();
+  if (!R) return set_err(FEMTO_AMD_ERR_MISSING, "librccl.so could not be loaded");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (bytes_per_rank == 0) return FEMTO_AMD_OK;
+  RCCL_TRY(R, R->GroupStart());
+  ncclResult_t r1 = ncclSuccess;
+  if (ix->comm_rank == root) {
+    for (int p = 0; p < ix->comm_size && r1 == ncclSuccess; p++) {
+      char* dst = static_cast<char*>(d_recv) + size_t(p) * size_t(bytes_per_rank);
+      if (p == root) {
+        if (hipMemcpyAsync(dst, d_send, size_t(bytes_per_rank), hipMemcpyDeviceToDevice, stream) != hipSuccess) r1 = ncclUnhandledCudaError;
+      } else {
+        r1 = R->Recv(dst, size_t(bytes_per_rank), ncclInt8, p, ix->comm, stream);
+      }
+    }
+  } else {
+    r1 = R->Send(d_send, size_t(bytes_per_rank), ncclInt8, root, ix->comm, stream);
+  }
+  ncclResult_t r2 = R->GroupEnd();
+  RCCL_TRY(R, r1);
+  RCCL_TRY(R, r2);
+  return FEMTO_AMD_OK;
+  API_END
+}
+
 int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode) {
   if (!ix || mode < 0 || mode > 4) return set_err(FEMTO_AMD_ERR_PARAM, "bad rank mode");
+  if (!ix->children.empty()) {
+    for (femto_amd_index* c : ix->children) { int rc = femto_amd_set_rank_mode(c, mode); if (rc) return rc; }
+    return FEMTO_AMD_OK;
+  }
   if (mode == 4 && !ix->dev.p2_l1)
     return set_err(FEMTO_AMD_ERR_INVALID, "two-level lines (mode 4) are built for indexes with 9..256 distinct characters (FEMTO_AMD_PACK2=1 forces them for fewer)");
   if (mode == 3 && !ix->dev.pack)
@@ -2233,10 +2598,14 @@ int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode) {
   return FEMTO_AMD_OK;
 }
 
-int femto_amd_get_rank_mode(const femto_amd_index_t* ix) { return ix ? ix->mode : -1; }
+int femto_amd_get_rank_mode(const femto_amd_index_t* ix) {
+  if (ix && !ix->children.empty()) return ix->children[0]->mode;
+  return ix ? ix->mode : -1;
+}
 
 int femto_amd_set_option(femto_amd_index_t* ix, const char* name, int value) {
   if (!ix || !name) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  for (femto_amd_index* c : ix->children) { int rc = femto_amd_set_option(c, name, value); if (rc) return rc; }
   std::lock_guard<std::mutex> lk(ix->mu);
   if (!strcmp(name, "direct")) ix->direct = value != 0;
   else if (!strcmp(name, "sort")) ix->sort_queries = value != 0;
@@ -2246,10 +2615,14 @@ int femto_amd_set_option(femto_amd_index_t* ix, const char* name, int value) {
 
 int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* bytes, double* build_ms, int* ktab_syms) {
   if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
+  if (!ix->children.empty()) return femto_amd_pack_info(ix->children[0], available, bytes, build_ms, ktab_syms);
   if (available) *available = ix->dev.pack != nullptr;
   if (ktab_syms) *ktab_syms = ix->dev.ktab2 ? ix->dev.kt2_syms : (ix->dev.ktab ? ix->dev.ktab_syms : 0);
   if (available && ix->dev.p2_l1) *available |= 2;   // bit 1: the two-level lines (mode 4) exist
   if (available && ix->dev.ktab2) *available |= 4;   // bit 2: the level table of the direct pipeline exists
+  if (available && ix->dev.ind) *available |= 32;     // bit 5: per-character rank lines (byte alphabets)
+  if (available && ix->dev.sa_full) *available |= 8;  // bit 3: the full suffix array is resident
+  if (available && ix->dev.isa8 && ix->dev.isa_shift == 0) *available |= 16;   // bit 4: the full inverse suffix array
   if (bytes) *bytes = ix->pack_bytes + ix->pack2_bytes;
   if (build_ms) *build_ms = ix->pack_build_ms + ix->pack2_build_ms;
   return FEMTO_AMD_OK;

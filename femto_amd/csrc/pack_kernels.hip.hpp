@@ -26,13 +26,16 @@ constexpr int kPackRows = 160;
 constexpr int kPackPlaneWords = 5;
 constexpr int kPackLineWords = 32;
 
-// compulsory-traffic trace (femto_amd_trace_lines): when ix.trace is set, every 128-byte line a query kernel loads from
-// a traced array sets its bit.  The branch is uniform (a kernel argument), so ordinary launches pay one scalar test.
+// compulsory-traffic trace (femto_amd_trace_lines): trace_kernels.hip compiles these same sources a second time with
+// FEMTO_AMD_TRACE defined, in a namespace of their own; there every 128-byte line loaded from a traced array sets its
+// bit.  The production kernels (this header compiled without the macro) contain no trace code at all.
 __device__ __forceinline__ void trace_touch(const DevIndex& ix, int region, uint64_t line) {
-  if (ix.trace) {
-    const uint64_t b = uint64_t(ix.trace_off[region]) + line;
-    atomicOr(ix.trace + (b >> 5), 1u << (b & 31u));
-  }
+#ifdef FEMTO_AMD_TRACE
+  const uint64_t b = uint64_t(ix.trace_off[region]) + line;
+  atomicOr(ix.trace + (b >> 5), 1u << (b & 31u));
+#else
+  (void)ix; (void)region; (void)line;
+#endif
 }
 
 __device__ __forceinline__ void pack_split(int64_t row, uint64_t* line, uint32_t* r) {

@@ -15,7 +15,7 @@
 
 namespace femto_amd {
 
-constexpr int kIsaShift = 3;          // isa8: every 8th text position
+constexpr int kIsaShift = 3;          // sampled isa8: every 8th text position (DevIndex::isa_shift; 0 = every position)
 
 struct TailItem {
   uint32_t slot;      // position in the sorted batch
@@ -24,6 +24,7 @@ struct TailItem {
 };
 
 struct PackPolicy {
+  static constexpr int kWaves = 8;     // waves per SIMD the count kernel is built for (64 VGPRs)
   static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
     pack_search_step(ix, ix.pack, j, code, f, l);
   }
@@ -49,6 +50,7 @@ struct PackPolicy {
 };
 
 struct Pack2Policy {
+  static constexpr int kWaves = 8;
   static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
     p2_search_step(ix, j, code, f, l);
   }
@@ -66,9 +68,24 @@ struct Pack2Policy {
   }
 };
 
-// SA[row] by the locate walk; false when the walk cannot finish (never for a well-formed index)
-template <class P>
+// byte alphabets with the per-character rank lines resident (ind_kernels.hip.hpp): search steps read one line per range
+// end; everything that does not know its character in advance (LF steps) stays on the two-level lines
+struct IndPolicy : Pack2Policy {
+  static constexpr int kWaves = 3;     // two whole lines in flight per lane (16 x 16-byte loads): up to 168 VGPRs
+  static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
+    ind_search_step(ix, j, code, f, l);
+  }
+};
+
+// SA[row]: one read of the full suffix array when it is resident (kSaFull), else the locate walk; false when the walk
+// cannot finish (never for a well-formed index)
+template <class P, bool kSaFull = false>
 __device__ __forceinline__ bool tail_locate(const DevIndex& ix, int64_t row, int64_t* pos, uint32_t* first_code) {
+  if (kSaFull) {
+    *pos = ix.sa_full[row];
+    trace_touch(ix, kTraceSa, uint64_t(row) >> 4);
+    return true;
+  }
   int64_t steps = 0;
   for (;;) {
     uint32_t code;
@@ -87,27 +104,32 @@ __device__ __forceinline__ bool tail_locate(const DevIndex& ix, int64_t row, int
   }
 }
 
-// build: txt[SA[row] - 1] = L[row] (position -1 wraps to the last one), isa8[SA[row] / 8] = row for SA[row] % 8 == 0
-template <class P>
+// build: txt[SA[row] - 1] = L[row] (position -1 wraps to the last one), isa[SA[row] >> shift] = row for the sampled
+// positions (shift 0: all of them) and, kSa, sa_full[row] = SA[row]
+template <class P, bool kSa>
 __global__ __launch_bounds__(256) void text_isa_build_kernel(const DevIndex ix, const int64_t row0, const int64_t n, uint8_t* __restrict__ txt,
-                                                             int64_t* __restrict__ isa8) {
+                                                             int64_t* __restrict__ isa, const int isa_shift, int64_t* __restrict__ sa_full) {
   const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (row >= row0 + n) return;
   int64_t pos;
   uint32_t code = 0;
-  if (!tail_locate<P>(ix, row, &pos, &code)) return;
+  if (!tail_locate<P>(ix, row, &pos, &code)) {
+    if (kSa) sa_full[row] = -1;    // what the walk reports for such a row (inconsistent index)
+    return;
+  }
   txt[pos == 0 ? ix.total_length - 1 : pos - 1] = uint8_t(code);
-  if ((pos & ((int64_t(1) << kIsaShift) - 1)) == 0) isa8[pos >> kIsaShift] = row;
+  if ((pos & ((int64_t(1) << isa_shift) - 1)) == 0) isa[pos >> isa_shift] = row;
+  if (kSa) sa_full[row] = pos;
 }
 
 // row of the suffix starting at text position x (sampled ISA + LF walk); false near the text end or a document end
 template <class P>
 __device__ __forceinline__ bool tail_row_of(const DevIndex& ix, int64_t x, int64_t* row_out) {
-  const int64_t K = int64_t(1) << kIsaShift;
+  const int64_t K = int64_t(1) << ix.isa_shift;
   const int64_t s = (x + K - 1) & ~(K - 1);
   if (s >= ix.total_length) return false;
-  int64_t row = ix.isa8[s >> kIsaShift];
-  trace_touch(ix, kTraceIsa, uint64_t(s >> kIsaShift) >> 4);
+  int64_t row = ix.isa8[s >> ix.isa_shift];
+  trace_touch(ix, kTraceIsa, uint64_t(s >> ix.isa_shift) >> 4);
   for (int64_t k = s; k > x; k--) {
     uint32_t code;
     bool marked;
@@ -168,7 +190,7 @@ struct TailOut {
   int max_occs;
 };
 
-template <class P>
+template <class P, bool kSaFull>
 __global__ __launch_bounds__(256) void count_tail_kernel(const DevIndex ix, const TailItem* __restrict__ items, const int* __restrict__ n_items,
                                                          const int32_t* __restrict__ plen, const uint16_t* __restrict__ pats,
                                                          const int64_t* __restrict__ starts, const uint32_t* __restrict__ perm,
@@ -193,7 +215,7 @@ __global__ __launch_bounds__(256) void count_tail_kernel(const DevIndex ix, cons
 
   // ---- the shortcut: position of the row, compare against the text, row of the last matching position
   int64_t p;
-  if (tail_locate<P>(ix, first, &p, nullptr) && p >= int64_t(len - j)) {
+  if (tail_locate<P, kSaFull>(ix, first, &p, nullptr) && p >= int64_t(len - j)) {
     const int remaining = len - j;
     int m = 0;                       // symbols matched
     uint64_t tw = 0;                 // aligned 8-byte word of txt holding the byte being compared

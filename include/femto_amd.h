@@ -188,6 +188,28 @@ int femto_amd_split_commit(femto_amd_index_t* ix);
 /* bytes of this part's own slices (segment lines, block images) */
 int femto_amd_split_info(const femto_amd_index_t* ix, int* part, int* nparts, int64_t* seg_bytes, int64_t* image_bytes);
 
+/* ---- several GPUs of one node ----------------------------------------------------------------------------------------
+ * Queries are independent (each string_query_t is its own state machine, src/main/server.c:3969-4001), so a batch shards
+ * with no exchange during the search.
+ *
+ * One process, several GPUs -- what the C caller of parallel_count (src/main/femto.c:275) needs: femto_amd_open_multi
+ * opens the index on every listed device (replicated) and returns an ordinary handle; the HOST-pointer batch calls
+ * (femto_amd_parallel_count / _parallel_locate / _count_flat / _locate_flat / _locate_flat_alloc /
+ * _parallel_locate_range) then split the batch into contiguous shards, one host thread per GPU, and every GPU returns
+ * its shard straight into the caller's arrays over its own PCIe link -- no gather at all.  Device-pointer calls are not
+ * available on such a handle (FEMTO_AMD_ERR_INVALID).  INTEGRATION.md: the shim opens one when FEMTO_AMD_DEVICES lists
+ * more than one device. */
+int femto_amd_open_multi(const char* index_path, int ndev, const int* devices, femto_amd_index_t** out);
+int femto_amd_device_count(const femto_amd_index_t* ix);
+/* One process per GPU, results resident on the devices: the only exchange is the final gather of the shards' results
+ * to one rank -- a grouped batch of ncclSend / ncclRecv over xGMI (RCCL is loaded on first use, it is not a link-time
+ * dependency).  Bootstrap as with NCCL: one rank makes the 128-byte id, every rank passes it to femto_amd_comm_init
+ * (any transport; bench.py --gather native broadcasts it through torch.distributed).  femto_amd_comm_gather enqueues on
+ * `stream`: rank r's bytes_per_rank bytes arrive at d_recv + r * bytes_per_rank on `root` (d_recv is ignored elsewhere). */
+int femto_amd_comm_unique_id(void* id128);
+int femto_amd_comm_init(femto_amd_index_t* ix, const void* id128, int nranks, int rank);
+int femto_amd_comm_gather(femto_amd_index_t* ix, const void* d_send, void* d_recv, int64_t bytes_per_rank, int root, void* stream);
+
 /* ---- kernel family ---------------------------------------------------------------------------- */
 /* Five kernel families, all bit-exact; the default at open is the fastest that applies (mode 3 for <= 8 distinct
  * characters, mode 4 for <= 256, else mode 1); FEMTO_AMD_RANK_MODE=pack|pack2|lane|flat|raw overrides it.
@@ -227,9 +249,10 @@ void femto_amd_kernel_time_reset(femto_amd_index_t* ix);
 void femto_amd_kernel_time_enable(femto_amd_index_t* ix, int on);
 
 /* Compulsory HBM traffic of a batch (bench.py's roofline): runs the batch once with a line trace and reports how many
- * DISTINCT 128-byte lines of each derived array the count phase (count_lines[8]) and the row expansion + locate walk
- * (locate_lines[8]) loaded; *rows_out = rows located.  Regions: 0 packed lines (mode 3), 1 level table, 2 offsets of
- * the marked rows, 3 / 4 level-1 / level-2 lines (mode 4), 5 text, 6 sampled inverse suffix array, 7 round-1 table.
+ * DISTINCT 128-byte lines of each derived array the count phase (count_lines[10]) and the row expansion + locate walk
+ * (locate_lines[10]) loaded; *rows_out = rows located.  Regions: 0 packed lines (mode 3), 1 level table, 2 suffix
+ * array / offsets of the marked rows, 3 / 4 level-1 / level-2 lines (mode 4), 5 text, 6 inverse suffix array, 7 round-1
+ * table, 8 per-character rank lines, 9 unused.
  * Device pointers as in femto_amd_count_device; blocking; not to be called while other calls use the handle. */
 int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
                           const int64_t* d_starts, int max_occs_each, int64_t* count_lines, int64_t* locate_lines,

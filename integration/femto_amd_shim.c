@@ -41,10 +41,30 @@ static error_t amd_err(int code)   /* err_code_t values are shared (src/utils/er
   return ERR_MAKE_STR((err_code_t) code, femto_amd_last_error());
 }
 
-static int shim_device(void)
+/* FEMTO_AMD_DEVICES="0,1,2,3": the index is opened on every listed GPU and each batch is sharded over them
+ * (femto_amd_open_multi); one entry, or FEMTO_AMD_DEVICE=n, or nothing (device 0): a single GPU. */
+static int shim_open(const char* path, femto_amd_index_t** out)
 {
-  const char* d = getenv("FEMTO_AMD_DEVICE");
-  return d ? atoi(d) : 0;
+  int devs[64];
+  int n = 0;
+  const char* list = getenv("FEMTO_AMD_DEVICES");
+  if( list ) {
+    const char* p = list;
+    while( *p && n < 64 ) {
+      char* end = NULL;
+      long v = strtol(p, &end, 10);
+      if( end == p ) break;
+      devs[n++] = (int) v;
+      p = end;
+      while( *p == ',' || *p == ' ' ) p++;
+    }
+  }
+  if( n == 0 ) {
+    const char* d = getenv("FEMTO_AMD_DEVICE");
+    devs[n++] = d ? atoi(d) : 0;
+  }
+  if( n == 1 ) return femto_amd_open(path, devs[0], out);
+  return femto_amd_open_multi(path, n, devs, out);
 }
 
 /* id -> path.  block_storage.h:62 declares path_translator_path_for_id() but block_storage.c never defines it (only the
@@ -93,7 +113,7 @@ static error_t amd_get(femto_server_t* srv, index_locator_t loc, femto_amd_index
     /* the path given to femto_loc_for_path_err (src/main/femto.c:269); directory or flattened file */
     err = shim_path_for_id(&srv->state->path_to_id, loc, &path);
     if( err ) goto done;
-    rc = femto_amd_open(path, shim_device(), &shim_slots[loc.id].ix);
+    rc = shim_open(path, &shim_slots[loc.id].ix);
     free(path);
     if( rc ) { shim_slots[loc.id].ix = NULL; err = amd_err(rc); goto done; }
     shim_slots[loc.id].owner = srv->state;

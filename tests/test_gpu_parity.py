@@ -176,6 +176,142 @@ def test_pointer_array_forms(fixtures, gpu_ok):
     assert np.array_equal(np.array(got, dtype=np.int64), fx.gold["loc7_offs"])
 
 
+@pytest.mark.parametrize("name", ["acgt48k", "eng2doc", "chunks2doc"])
+def test_multi_device_handle_shards_host_batches(fixtures, gpu_ok, name):
+    """femto_amd_open_multi: one handle over several GPUs of the process; every host-pointer batch call splits into
+    contiguous shards, one host thread per replica, results straight into the caller's arrays.  The box has one GPU, so
+    the three replicas share it -- the sharding, the merging of located offsets and the error path are what is tested."""
+    fx = fixtures(name)
+    g = fx.gold
+    ix = femto_amd.Index(fx.index, devices=[0, 0, 0])
+    assert femto_amd.lib().femto_amd_device_count(ix.handle) == 3
+    plen, flat, starts = fx.patterns
+    first, last = ix.count_flat(plen, flat, starts)
+    assert np.array_equal(first, g["count_first"]) and np.array_equal(last, g["count_last"])
+    for mo, g_noccs, g_offs in fx.locate_cases():
+        noccs, offs = ix.locate_flat(plen, flat, starts, mo)
+        assert np.array_equal(noccs, g_noccs) and np.array_equal(offs, g_offs), mo
+        noccs2, offs2 = ix.locate_flat_two_call(plen, flat, starts, mo)
+        assert np.array_equal(noccs2, g_noccs) and np.array_equal(offs2, g_offs), mo
+    # the reference's own calling convention (alpha_t**, callee-malloc'd offsets[i])
+    n = len(plen)
+    L = femto_amd.lib()
+    pats = [np.ascontiguousarray(flat[starts[i]:starts[i] + plen[i]]) for i in range(n)]
+    parr = (C.c_void_p * n)(*[p.ctypes.data if len(p) else None for p in pats])
+    pl = plen.astype(np.int32)
+    f2 = np.zeros(n, dtype=np.int64)
+    l2 = np.zeros(n, dtype=np.int64)
+    assert L.femto_amd_parallel_count(ix.handle, n, pl.ctypes.data, parr, f2.ctypes.data, l2.ctypes.data) == 0
+    assert np.array_equal(f2, g["count_first"]) and np.array_equal(l2, g["count_last"])
+    noccs = np.zeros(n, dtype=np.int32)
+    offs = (C.POINTER(C.c_int64) * n)()
+    assert L.femto_amd_parallel_locate(ix.handle, n, pl.ctypes.data, parr, 7, noccs.ctypes.data, offs) == 0
+    assert np.array_equal(noccs, g["loc7_noccs"])
+    got = []
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    for i in range(n):
+        if noccs[i]:
+            got.extend(offs[i][j] for j in range(noccs[i]))
+            libc.free(offs[i])
+    assert np.array_equal(np.array(got, dtype=np.int64), g["loc7_offs"])
+    rows = int(ix.info.total_length)
+    single = femto_amd.Index(fx.index, device=0)
+    assert np.array_equal(ix.locate_range(0, rows - 1), single.locate_range(0, rows - 1))
+    single.close()
+    # a device-pointer call has no meaning on such a handle
+    with pytest.raises(femto_amd.FemtoAmdError):
+        ix.count_device(1, 8, 8, 8, 8, 8)
+    # a bad pattern in one shard fails the whole call with that shard's error
+    bad = flat.copy()
+    bad[int(starts[n - 1])] = 300 if plen[n - 1] else bad[0]
+    if plen[n - 1]:
+        with pytest.raises(femto_amd.FemtoAmdError) as ei:
+            ix.count_flat(plen, bad, starts)
+        assert ei.value.code == 3
+    ix.close()
+
+
+def test_comm_gather_one_rank(fixtures, gpu_ok):
+    """femto_amd_comm_*: RCCL is loaded on first use; a communicator of one rank gathers to itself (the N > 1 exchange is
+    the same grouped ncclSend / ncclRecv batch, which needs N GPUs: bench.py --gather native on the multi-GPU node)."""
+    import torch
+    fx = fixtures("acgt48k")
+    ix = femto_amd.Index(fx.index, device=0)
+    ix.comm_init(femto_amd.Index.comm_unique_id(), 1, 0)
+    src = torch.arange(1000, dtype=torch.int64, device="cuda:0")
+    dst = torch.zeros(1000, dtype=torch.int64, device="cuda:0")
+    ix.comm_gather(src.data_ptr(), dst.data_ptr(), 8000, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(src, dst)
+    ix.close()
+
+
+def test_concurrent_callers_on_one_handle(tmp_path, gpu_ok):
+    """The reference accepts blocking calls from many threads at once (src/main/server.c:3732-3793): every call here
+    leases its own scratch (buffers, flags, stream), so four host threads issuing count / locate batches on ONE handle
+    overlap on the GPU and must each get exactly the answers of a serial run -- host-pointer and device-pointer forms."""
+    import threading
+    import torch
+    from femto_amd import textgen as tg
+    text = tg.t_acgt(1 << 20, 77)
+    path = str(tmp_path / "ix")
+    femto_amd.build_index(path, [text], infos=["t"])
+    ix = femto_amd.Index(path, device=0)
+    batches = []
+    for t in range(4):
+        plen, flat = tg.p_hit(6, 30, 300_000 + 1000 * t, 1000 + t, text)   # above the pipelined-staging threshold too
+        batches.append((plen, flat, tg.starts_of(plen)))
+    serial = [(ix.count_flat(*b), ix.locate_flat(*b, 5)) for b in batches]
+    results, errors = [None] * 4, []
+
+    def work(t):
+        try:
+            out = []
+            for _ in range(3):
+                out.append((ix.count_flat(*batches[t]), ix.locate_flat(*batches[t], 5)))
+            results[t] = out
+        except Exception as ex:      # noqa: BLE001
+            errors.append(repr(ex))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(4):
+        (sf, sl), (sn, so) = serial[t]
+        for (f, l), (n, o) in results[t]:
+            assert np.array_equal(f, sf) and np.array_equal(l, sl) and np.array_equal(n, sn) and np.array_equal(o, so)
+    # enqueue-only calls on four different streams at once (the scratch of one must not be reused by another in flight)
+    dev = torch.device("cuda", 0)
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    outs = []
+    for t, (plen, flat, starts) in enumerate(batches):
+        n = len(plen)
+        d = {"plen": torch.from_numpy(plen).to(dev), "flat": torch.from_numpy(flat.view(np.int16)).to(dev),
+             "starts": torch.from_numpy(starts).to(dev), "res": torch.empty((2, n), dtype=torch.int64, device=dev),
+             "noccs": torch.empty(n, dtype=torch.int32, device=dev), "ost": torch.empty(n + 1, dtype=torch.int64, device=dev),
+             "offs": torch.empty(len(serial[t][1][1]) + 16, dtype=torch.int64, device=dev), "tot": torch.zeros(2, dtype=torch.int64, device=dev)}
+        outs.append(d)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for t, d in enumerate(outs):
+            n = len(batches[t][0])
+            ix.locate_device(n, d["plen"].data_ptr(), d["flat"].data_ptr(), d["starts"].data_ptr(), 5, d["res"][0].data_ptr(),
+                             d["res"][1].data_ptr(), d["noccs"].data_ptr(), d["ost"].data_ptr(), d["offs"].data_ptr(), d["offs"].numel(),
+                             d["tot"].data_ptr(), streams[t].cuda_stream)
+    torch.cuda.synchronize()
+    for t, d in enumerate(outs):
+        (sf, sl), (sn, so) = serial[t]
+        tot = d["tot"].cpu().numpy()
+        assert tot[1] == 0 and tot[0] == len(so)
+        assert np.array_equal(d["res"][0].cpu().numpy(), sf) and np.array_equal(d["res"][1].cpu().numpy(), sl)
+        assert np.array_equal(d["noccs"].cpu().numpy(), sn) and np.array_equal(d["offs"][:len(so)].cpu().numpy(), so)
+    ix.close()
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_locate_range_matches_reference(fixtures, gpu_ok, mode):
     """parallel_locate_range (femto.c:481): every row's offset, against the per-row LOCATION answers captured from the
@@ -650,6 +786,80 @@ def test_full_size_text96_properties(tmp_path, gpu_ok):
     assert np.array_equal(of, first[:m]) and np.array_equal(ol, last[:m])
     on, oo = o.locate_flat(plen[:m], flat, starts[:m], 20, threads=16)
     assert np.array_equal(on, noccs[:m]) and np.array_equal(oo, offs[:int(noccs[:m].sum())])
+
+
+def test_full_size_8gib_properties(tmp_path, gpu_ok):
+    """BASELINE configs[4]'s index at FULL size: 8 GiB random-ACGT text (8 589 934 593 rows, 65 data blocks, 64-bit rows
+    everywhere), built here by the partitioned 64-bit suffix sorter, opened (a) replicated on the GPU and (b) range-split
+    in two parts.  Size-independent properties plus an oracle spot check:
+      * every sampled 20-mer is found and every located offset really is an occurrence;
+      * the packed lines (default) and the wavelet path (mode 1) agree; the two-part range-split handle agrees with both;
+      * 1 000 random + sampled patterns agree bit-for-bit with the oracle (count and locate)."""
+    import shutil
+    if shutil.disk_usage(str(tmp_path)).free < 12 * (1 << 30):
+        pytest.skip("needs ~10 GB of scratch disk for the 8 GiB index")
+    try:
+        import psutil
+        if psutil.virtual_memory().available < 200 * (1 << 30):
+            pytest.skip("needs ~200 GB of host memory for the 8 GiB text and its suffix array")
+    except ImportError:
+        pass
+    n = 1 << 33
+    text = tg.t_acgt(n, 808)
+    path = str(tmp_path / "acgt8g")
+    femto_amd.build_index(path, [text], params=None, infos=["full8"], device=0)
+    ix = femto_amd.Index(path, device=0)
+    assert ix.info.total_length == n + 1 and ix.info.number_of_blocks == 65 and ix.info.total_buckets == 8193
+    assert ix.info.text_size_bits == 34 and ix.rank_mode == 3
+    npat = 200_000
+    plen, flat = tg.p_hit(20, 20, npat, 21, text)
+    starts = tg.starts_of(plen)
+    first, last = ix.count_flat(plen, flat, starts)
+    cnt = last - first + 1
+    assert (cnt >= 1).all() and last.max() > (1 << 32)          # rows beyond 32 bits are really in play
+    noccs, offs = ix.locate_flat(plen, flat, starts, 100)
+    assert np.array_equal(noccs, np.minimum(cnt, np.where(cnt - 1 > 100, 100, cnt)))
+    assert offs.max() > (1 << 32)
+    owner = np.repeat(np.arange(npat), noccs)
+    pat_bytes = (flat.reshape(npat, 20) - 5).astype(np.uint8)
+    for k in range(20):
+        assert np.array_equal(text[offs + k], pat_bytes[owner, k]), k
+    # oracle spot check (random + sampled)
+    o = po.Oracle(path)
+    rp, rf = tg.p_rand(20, 500, 5)
+    p2 = np.concatenate([rp, plen[:500]])
+    f2 = np.concatenate([rf, flat[:500 * 20]])
+    s2 = tg.starts_of(p2)
+    gf, gl = ix.count_flat(p2, f2, s2)
+    of, ol = o.count_flat(p2, f2, s2, threads=16)
+    assert np.array_equal(gf, of) and np.array_equal(gl, ol)
+    gn, go = ix.locate_flat(p2, f2, s2, 100)
+    on, oo = o.locate_flat(p2, f2, s2, 100, threads=16)
+    assert np.array_equal(gn, on) and np.array_equal(go, oo)
+    # wavelet path on the same handle
+    m = 50_000
+    ix.set_rank_mode(1)
+    f1, l1 = ix.count_flat(plen[:m], flat, starts[:m])
+    assert np.array_equal(f1, first[:m]) and np.array_equal(l1, last[:m])
+    n1, o1 = ix.locate_flat(plen[:m], flat, starts[:m], 100)
+    assert np.array_equal(n1, noccs[:m]) and np.array_equal(o1, offs[:int(noccs[:m].sum())])
+    ix.close()
+    del text
+    # range-split in two parts (both on this GPU): part p keeps blocks [65p/2, 65(p+1)/2) and reads the rest from its peer
+    parts = [femto_amd.Index(path, device=0, part=p, nparts=2) for p in range(2)]
+    for a in parts:
+        for b in parts:
+            if a is not b:
+                a.split_attach_local(b)
+    for a in parts:
+        a.split_commit()
+    for a in parts:
+        fs, ls = a.count_flat(plen[:m], flat, starts[:m])
+        assert np.array_equal(fs, first[:m]) and np.array_equal(ls, last[:m])
+        ns, os_ = a.locate_flat(plen[:m], flat, starts[:m], 100)
+        assert np.array_equal(ns, noccs[:m]) and np.array_equal(os_, offs[:int(noccs[:m].sum())])
+    for a in parts:
+        a.close()
 
 
 def test_multiquery_cpp_tool(fixtures, tmp_path, gpu_ok):

@@ -69,8 +69,13 @@ def test_reference_caller_answers_from_gpu(fixtures, tmp_path, name):
         assert np.array_equal(noccs, g_noccs), mo
         assert np.array_equal(offs, g_offs), mo
     # the flattened container goes through the same path translator entry (isfile)
+    flat_path = fx.flat
+    if not os.path.exists(flat_path):      # only one fixture ships the reference's own flattened file
+        import femto_amd
+        flat_path = str(tmp_path / "index.flat")
+        femto_amd.flatten_index(fx.index, flat_path)
     out = str(tmp_path / "count_flat.bin")
-    subprocess.run([po.REF_TOOL_AMD, "count", fx.flat, pf, out], check=True, timeout=300)
+    subprocess.run([po.REF_TOOL_AMD, "count", flat_path, pf, out], check=True, timeout=300)
     r = np.fromfile(out, dtype=np.int64)
     assert np.array_equal(r[:n], fx.gold["count_first"]) and np.array_equal(r[n:], fx.gold["count_last"])
 
