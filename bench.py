@@ -32,16 +32,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# (rank mode, direct pipeline?) -> name of the search / walk kernel as rocprofv3 prints it
-KERNEL_NAMES = {(4, True): "count_direct_kernel<femto_amd::Pack2Policy, true>", (3, True): "count_direct_kernel<femto_amd::PackPolicy, true>",
-                (4, False): "count_kernel_pack2<true>", (3, False): "count_kernel_pack<true>",
-                (1, False): "count_kernel_lane", (2, False): "count_kernel_flat<1>", (0, False): "count_kernel<32>"}
-LOCATE_NAMES = {(4, True): "locate_walk_kernel<femto_amd::Pack2Policy>", (3, True): "locate_walk_kernel<femto_amd::PackPolicy>",
-                (4, False): "locate_kernel_pack2", (3, False): "locate_kernel_pack",
-                (1, False): "locate_kernel_lane", (2, False): "locate_kernel_flat", (0, False): "locate_kernel<32>"}
+# (rank mode, direct pipeline?) -> how rocprofv3 names the search / walk kernel (a prefix: template arguments follow)
+KERNEL_NAMES = {(4, True): "femto_amd::count_direct_kernel<femto_amd::Pack2Policy, true", (3, True): "femto_amd::count_direct_kernel<femto_amd::PackPolicy, true",
+                (4, False): "femto_amd::count_kernel_pack2<true>", (3, False): "femto_amd::count_kernel_pack<true>",
+                (1, False): "femto_amd::count_kernel_lane", (2, False): "femto_amd::count_kernel_flat<1>", (0, False): "femto_amd::count_kernel<32>"}
+LOCATE_NAMES = {(4, True): "femto_amd::locate_walk_kernel<femto_amd::Pack2Policy>", (3, True): "femto_amd::locate_walk_kernel<femto_amd::PackPolicy>",
+                (4, False): "femto_amd::locate_kernel_pack2", (3, False): "femto_amd::locate_kernel_pack",
+                (1, False): "femto_amd::locate_kernel_lane", (2, False): "femto_amd::locate_kernel_flat", (0, False): "femto_amd::locate_kernel<32>"}
 for _m in (0, 1, 2):
     KERNEL_NAMES[(_m, True)] = KERNEL_NAMES[(_m, False)]
     LOCATE_NAMES[(_m, True)] = LOCATE_NAMES[(_m, False)]
+
+
+def kernel_names(ix, direct):
+    """names (prefixes) of the kernels the count and the locate timers bracket for this handle"""
+    pi = ix.pack_info()
+    cn, ln = KERNEL_NAMES[(ix.rank_mode, direct)], LOCATE_NAMES[(ix.rank_mode, direct)]
+    if direct and ix.rank_mode == 4 and pi.get("char_rank_lines"):
+        cn = "femto_amd::count_direct_kernel<femto_amd::IndPolicy, true"
+    if direct and pi.get("sa_full"):
+        ln = "femto_amd::plan_rows_kernel<true>"      # the full suffix array is resident: locate is fused into the row expansion
+    return cn, ln
+
+
 PMC_REGEX = "count_direct_kernel|locate_walk_kernel|count_kernel|locate_kernel|count_tail_kernel"
 
 
@@ -78,7 +91,7 @@ def pmc_traffic(args, kname):
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for r in csv.DictReader(fh):
-                        if kname.split("<")[0] in r.get("Kernel_Name", "") and _same_kernel(kname, r.get("Kernel_Name", "")):
+                        if _same_kernel(kname, r.get("Kernel_Name", "")):
                             means.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     if "FETCH_SIZE" not in means or "WRITE_SIZE" not in means:
         return None, None
@@ -92,11 +105,9 @@ def pmc_traffic(args, kname):
 
 
 def _same_kernel(kname, full):
-    """template arguments must match too (count_direct_kernel<..., true> vs <..., false>)"""
-    if "<" not in kname:
-        return True
-    want = kname[kname.index("<"):].replace(" ", "")
-    return want in full.replace(" ", "")
+    """rocprofv3's kernel name starts (after an optional 'void ') with the wanted prefix"""
+    f = full[5:] if full.startswith("void ") else full
+    return f.replace(" ", "").startswith(kname.replace(" ", ""))
 
 
 def committed_traffic(args, kname, npats):
@@ -509,7 +520,7 @@ def main():
         dominant_is_count = cnt_ms >= loc_ms
         k_ms = cnt_ms if dominant_is_count else loc_ms
         comp = comp_count if dominant_is_count else comp_locate
-        kname = (KERNEL_NAMES if dominant_is_count else LOCATE_NAMES)[(ix.rank_mode, direct)]
+        kname = kernel_names(ix, direct)[0 if dominant_is_count else 1]
         achieved = comp / (k_ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
         if args.pmc != "off" and world == 1:

@@ -236,6 +236,7 @@ struct femto_amd_index {
   bool sort_queries = true;    // FEMTO_AMD_SORT=0 disables the suffix-order batch sort of the paths that use one
   bool direct = true;          // FEMTO_AMD_DIRECT=0: modes 3/4 go back to the sorted-batch kernels of round 1
   uint8_t* d_dense = nullptr;  // alpha code -> dense sort digit (characters present in the text)
+  std::vector<uint8_t> h_dense; // the same table on the host (key staging of host-pointer batches)
   int dense_bits = 8;
   double dense_sigma = 256;    // distinct characters of the indexed text
   int64_t sort_min = 4096;
@@ -422,10 +423,9 @@ int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const in
   const int64_t nblocks = (npats + kBlockThreads - 1) / kBlockThreads;
   DevIndex d = ix->dev;
   int rc;
-  // DNA (mode 3) with the full suffix array + inverse suffix array resident compares the tail inline: its lanes reach a
-  // one-row range at about the same step, so nothing diverges.  Byte alphabets (word-like text: 5.7 ms + 3.1 ms handed
-  // over vs 19 ms inline, measured) and the sampled arrays hand the pattern over to count_tail_kernel instead.
-  const bool inline_tail = d.txt && ix->mode == 3 && d.sa_full && d.isa8 && d.isa_shift == 0;
+  // full suffix array + inverse suffix array resident: the text tail is compared inline, after the wavefront's stepping
+  // loop (direct_kernels.hip.hpp); with the sampled arrays the pattern is handed over to count_tail_kernel instead
+  const bool inline_tail = d.txt && d.sa_full && d.isa8 && d.isa_shift == 0;
   const bool tail = d.txt != nullptr && !inline_tail;
   if (tail && (rc = tail_setup(ix, S, d, npats, stream))) return rc;
   if (d.txt && !tail) {
@@ -599,6 +599,21 @@ int device_scan(DeviceBuffer* scan, int64_t n, const int64_t* in, int64_t* out /
   }
   hipLaunchKernelGGL(set_total_kernel, dim3(1), dim3(64), 0, stream, n, out, in, out + n);
   HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// host-pointer key chunks (count_keys_kernel)
+int launch_count_keys(femto_amd_index* ix, int64_t n, const uint64_t* d_keys, int2* out32, int64_t* d_first, int64_t* d_last, hipStream_t stream) {
+  if (n <= 0) return 0;
+  const dim3 grid{uint32_t((n + kBlockThreads - 1) / kBlockThreads)}, block{uint32_t(kBlockThreads)};
+  const int bits = ix->dense_bits, nsym = 63 / bits;
+  hipEvent_t e0, e1;
+  timer_begin(ix, ix->t_count, stream, &e0, &e1);
+  if (ix->mode == 3) hipLaunchKernelGGL(count_keys_kernel<PackPolicy>, grid, block, 0, stream, ix->dev, n, d_keys, bits, nsym, out32, d_first, d_last);
+  else if (ix->dev.ind) hipLaunchKernelGGL(count_keys_kernel<IndPolicy>, grid, block, 0, stream, ix->dev, n, d_keys, bits, nsym, out32, d_first, d_last);
+  else hipLaunchKernelGGL(count_keys_kernel<Pack2Policy>, grid, block, 0, stream, ix->dev, n, d_keys, bits, nsym, out32, d_first, d_last);
+  HIP_TRY(hipGetLastError());
+  timer_end(ix, ix->t_count, stream, e0, e1);
   return 0;
 }
 
@@ -1177,9 +1192,11 @@ int pipe_init(femto_amd_index* ix, Scratch& S) {
   {
     std::lock_guard<std::mutex> lk(ix->workers_mu);
     if (!ix->workers) {
-      int nthreads = int(std::thread::hardware_concurrency());
+      // a quarter of the host's hardware threads, between 4 and 64 (packing 10 M patterns into keys is ~200 M table
+      // look-ups: 16 threads would be the bottleneck of the pipeline on the GPU box's 256-thread host)
+      int nthreads = std::max(4, int(std::thread::hardware_concurrency()) / 4);
       if (const char* e = getenv("FEMTO_AMD_HOST_THREADS")) nthreads = atoi(e);
-      nthreads = std::max(1, std::min(nthreads, 16));
+      nthreads = std::max(1, std::min(nthreads, 64));
       ix->workers.reset(new WorkerPool(nthreads));
     }
   }
@@ -1277,6 +1294,38 @@ int64_t pipe_stage(femto_amd_index* ix, const HostBatch& hb, int64_t a, int64_t 
   return nsym;
 }
 
+// Key staging (count_keys_kernel): every pattern of the chunk packed into 8 bytes.  Returns 1 when all of them are
+// described completely by their keys (written to h_in as u64[n]), 0 when some pattern is not (the chunk then travels as
+// symbols; malformed input is reported by that path).
+int pipe_stage_keys(femto_amd_index* ix, const HostBatch& hb, int64_t a, int64_t b, void* h_in) {
+  WorkerPool& pool = *ix->workers;
+  std::lock_guard<std::mutex> wl(ix->workers_mu);
+  const int64_t n = b - a;
+  uint64_t* o_key = static_cast<uint64_t*>(h_in);
+  const int bits = ix->dense_bits, nsym = 63 / bits;
+  const uint8_t* dense = ix->h_dense.data();
+  const int T = pool.size();
+  std::vector<int> partial(size_t(T), 0);
+  pool.run([&](int t, int nt) {
+    const int64_t i0 = a + n * t / nt, i1 = a + n * (t + 1) / nt;
+    for (int64_t i = i0; i < i1; i++) {
+      const int64_t l = hb.plen[i];
+      const uint16_t* pat = hb.ptrs ? hb.ptrs[i] : (hb.starts[i] >= 0 ? hb.flat + hb.starts[i] : nullptr);
+      if (l < 0 || l > nsym || (l && !pat)) { partial[size_t(t)] = 1; return; }
+      uint64_t key = 0;
+      for (int64_t s = l - 1; s >= 0; s--) {   // last symbol first: it lands in the top field
+        const uint32_t ch = pat[s];
+        const uint32_t c = ch < uint32_t(kAlphaSize) ? dense[ch] : 0u;
+        if (c == 0) { partial[size_t(t)] = 1; return; }
+        key = (key << bits) | c;
+      }
+      o_key[i - a] = l ? key << (64 - int(l) * bits) : 0;   // field j (from the top) = j-th symbol from the end; 0 = end
+    }
+  });
+  for (int t = 0; t < T; t++) if (partial[size_t(t)]) return 0;
+  return 1;
+}
+
 // returns 0, an error code, or -1: "not applicable, use the plain path"
 // With dev_first != nullptr the ranges stay on the device (whole-batch arrays dev_first / dev_last, the locate plan's
 // input) and nothing is copied back.
@@ -1289,6 +1338,10 @@ int count_host_pipelined(femto_amd_index* ix, Scratch& S, const HostBatch& hb, i
   auto& P = S.pipe;
   hipStream_t s_k = S.stream;
   const int64_t nchunks = (hb.npats + kPipeChunk - 1) / kPipeChunk;
+  bool keys_ok = use_direct(ix) && !ix->h_dense.empty();
+  if (const char* e = getenv("FEMTO_AMD_HOST_KEYS")) keys_ok = keys_ok && atoi(e) != 0;
+  const bool rows32 = ix->host.total_length < (int64_t(1) << 31) - 1;    // rows (and last + 1, -1) fit 32 bits
+  int kind[2] = {1, 1};   // what h_out[b] holds: 1 int64 arrays, 2 int32 (first,last) pairs, 3 int64 arrays of a key chunk (both present)
   // every exit leaves nothing in flight on the pinned buffers
   auto fail = [&](int code) {
     (void)hipStreamSynchronize(P.s_h2d);
@@ -1308,33 +1361,46 @@ int count_host_pipelined(femto_amd_index* ix, Scratch& S, const HostBatch& hb, i
       const int b = int(c & 1);
       const int64_t a = c * kPipeChunk, e = std::min(hb.npats, a + kPipeChunk), n = e - a;
       if (c >= 2) PIPE_TRY(hipEventSynchronize(P.k_done[b]));  // chunk c-2 no longer reads d_in[b] (and h_in[b] was uploaded)
-      const int64_t nsym = pipe_stage(ix, hb, a, e, P.h_in[b]);
-      if (nsym == -1) return fail(-1);
-      if (nsym < -1) return fail(set_err(int(-2 - nsym), "negative pattern length/start or null pattern"));
       char* din = static_cast<char*>(P.d_in[b]);
       const char* hin = static_cast<const char*>(P.h_in[b]);
-      PIPE_TRY(hipMemcpyAsync(din, hin, size_t(n) * 4, hipMemcpyHostToDevice, P.s_h2d));
-      PIPE_TRY(hipMemcpyAsync(din + size_t(kPipeChunk) * 4, hin + size_t(kPipeChunk) * 4, size_t(n) * 8, hipMemcpyHostToDevice, P.s_h2d));
-      if (nsym)
-        PIPE_TRY(hipMemcpyAsync(din + size_t(kPipeChunk) * 12, hin + size_t(kPipeChunk) * 12, size_t(nsym) * 2, hipMemcpyHostToDevice, P.s_h2d));
+      // keys when every pattern of the chunk fits one (8 B per pattern over PCIe), symbols otherwise
+      const bool as_keys = keys_ok && pipe_stage_keys(ix, hb, a, e, P.h_in[b]) == 1;
+      const bool out32 = as_keys && !dev_first && rows32;
+      kind[b] = out32 ? 2 : (as_keys ? 3 : 1);
+      if (as_keys) {
+        PIPE_TRY(hipMemcpyAsync(din, hin, size_t(n) * 8, hipMemcpyHostToDevice, P.s_h2d));
+      } else {
+        const int64_t nsym = pipe_stage(ix, hb, a, e, P.h_in[b]);
+        if (nsym == -1) return fail(-1);
+        if (nsym < -1) return fail(set_err(int(-2 - nsym), "negative pattern length/start or null pattern"));
+        PIPE_TRY(hipMemcpyAsync(din, hin, size_t(n) * 4, hipMemcpyHostToDevice, P.s_h2d));
+        PIPE_TRY(hipMemcpyAsync(din + size_t(kPipeChunk) * 4, hin + size_t(kPipeChunk) * 4, size_t(n) * 8, hipMemcpyHostToDevice, P.s_h2d));
+        if (nsym)
+          PIPE_TRY(hipMemcpyAsync(din + size_t(kPipeChunk) * 12, hin + size_t(kPipeChunk) * 12, size_t(nsym) * 2, hipMemcpyHostToDevice, P.s_h2d));
+      }
       PIPE_TRY(hipEventRecord(P.in_done[b], P.s_h2d));
       PIPE_TRY(hipStreamWaitEvent(s_k, P.in_done[b], 0));
       if (c >= 2) PIPE_TRY(hipStreamWaitEvent(s_k, P.out_done[b], 0));  // results of chunk c-2 have left d_out[b]
       int64_t* d_first = static_cast<int64_t*>(P.d_out[b]);
-      int64_t* d_last = last ? d_first + kPipeChunk : nullptr;
+      int64_t* d_last = (last || as_keys) ? d_first + kPipeChunk : nullptr;
       if (dev_first) {
         d_first = dev_first + a;
         d_last = dev_last + a;
       }
-      rc = launch_count(ix, S, n, reinterpret_cast<const int32_t*>(din), reinterpret_cast<const uint16_t*>(din + size_t(kPipeChunk) * 12),
-                        reinterpret_cast<const int64_t*>(din + size_t(kPipeChunk) * 4), d_first, d_last, s_k);
+      if (as_keys) rc = launch_count_keys(ix, n, reinterpret_cast<const uint64_t*>(din), out32 ? static_cast<int2*>(P.d_out[b]) : nullptr, d_first, d_last, s_k);
+      else rc = launch_count(ix, S, n, reinterpret_cast<const int32_t*>(din), reinterpret_cast<const uint16_t*>(din + size_t(kPipeChunk) * 12),
+                             reinterpret_cast<const int64_t*>(din + size_t(kPipeChunk) * 4), d_first, d_last, s_k);
       if (rc) return fail(rc);
       PIPE_TRY(hipEventRecord(P.k_done[b], s_k));
       if (dev_first) continue;
       PIPE_TRY(hipStreamWaitEvent(P.s_d2h, P.k_done[b], 0));
       char* hout = static_cast<char*>(P.h_out[b]);
-      PIPE_TRY(hipMemcpyAsync(hout, d_first, size_t(n) * 8, hipMemcpyDeviceToHost, P.s_d2h));
-      if (last) PIPE_TRY(hipMemcpyAsync(hout + size_t(kPipeChunk) * 8, d_last, size_t(n) * 8, hipMemcpyDeviceToHost, P.s_d2h));
+      if (out32) {
+        PIPE_TRY(hipMemcpyAsync(hout, P.d_out[b], size_t(n) * 8, hipMemcpyDeviceToHost, P.s_d2h));
+      } else {
+        PIPE_TRY(hipMemcpyAsync(hout, d_first, size_t(n) * 8, hipMemcpyDeviceToHost, P.s_d2h));
+        if (last || as_keys) PIPE_TRY(hipMemcpyAsync(hout + size_t(kPipeChunk) * 8, d_last, size_t(n) * 8, hipMemcpyDeviceToHost, P.s_d2h));
+      }
       PIPE_TRY(hipEventRecord(P.out_done[b], P.s_d2h));
     }
     if (c >= 1 && !dev_first) {  // hand chunk c-1 back while chunk c is on its way
@@ -1342,11 +1408,25 @@ int count_host_pipelined(femto_amd_index* ix, Scratch& S, const HostBatch& hb, i
       const int64_t a = (c - 1) * kPipeChunk, e = std::min(hb.npats, a + kPipeChunk), n = e - a;
       PIPE_TRY(hipEventSynchronize(P.out_done[b]));
       const char* hout = static_cast<const char*>(P.h_out[b]);
+      const int k = kind[b];      // still chunk c-1's: chunk c went into the other buffer
       std::lock_guard<std::mutex> wl(ix->workers_mu);
       ix->workers->run([&](int t, int nt) {
         const int64_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
-        memcpy(first + a + i0, hout + size_t(i0) * 8, size_t(i1 - i0) * 8);
-        if (last) memcpy(last + a + i0, hout + size_t(kPipeChunk) * 8 + size_t(i0) * 8, size_t(i1 - i0) * 8);
+        if (k == 2) {          // 32-bit (first,last) pairs: widened into the caller's arrays (or the counts, femto.c:313-318)
+          const int32_t* pr = reinterpret_cast<const int32_t*>(hout);
+          for (int64_t i = i0; i < i1; i++) {
+            const int64_t f = pr[2 * i], l = pr[2 * i + 1];
+            if (last) { first[a + i] = f; last[a + i] = l; }
+            else first[a + i] = l - f + 1;
+          }
+        } else if (!last && k == 3) {   // key chunk with 64-bit rows and no `last` array: counts from both
+          const int64_t* pf = reinterpret_cast<const int64_t*>(hout);
+          const int64_t* pl = reinterpret_cast<const int64_t*>(hout + size_t(kPipeChunk) * 8);
+          for (int64_t i = i0; i < i1; i++) first[a + i] = pl[i] - pf[i] + 1;
+        } else {
+          memcpy(first + a + i0, hout + size_t(i0) * 8, size_t(i1 - i0) * 8);
+          if (last) memcpy(last + a + i0, hout + size_t(kPipeChunk) * 8 + size_t(i0) * 8, size_t(i1 - i0) * 8);
+        }
       });
     }
   }
@@ -1610,6 +1690,7 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
         ix->dense_bits = bits;
         ix->dense_sigma = sigma < 2 ? 2 : sigma;
         if ((r = upload(&ix->d_dense, dense, &ix->table_bytes))) return r;
+        if (sigma <= 255) ix->h_dense = dense;    // keys need every character of the text to have a digit
       }
       DevIndex& d = ix->dev;
       d.image = ix->d_image;
@@ -2433,7 +2514,7 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
     a.tail_items = nullptr;
     a.tail_min = ix->mode == 3 ? 12 : 10;
     if (const char* tm = getenv("FEMTO_AMD_TAIL_MIN")) a.tail_min = std::max(2, atoi(tm));
-    if (d.txt && !(ix->mode == 3 && d.sa_full && d.isa8 && d.isa_shift == 0)) {
+    if (d.txt && !(d.sa_full && d.isa8 && d.isa_shift == 0)) {
       if ((r2 = tail_setup(ix, S, d, npats, st))) return r2;
       a.tail_items = d.tail_items;
       a.tail_min = d.tail_min;

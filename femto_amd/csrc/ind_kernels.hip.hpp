@@ -6,8 +6,9 @@
 // When HBM allows, open therefore also derives, for every character c of the text, the plain bit vector
 // B_c[row] = (L[row] == c) cut into 128-byte lines of 960 rows:
 //
-//   dword 0,1     C[c] + Occ(c, rows before this line)        (40 bits)
-//   dword 2..31   bit i of dword 2+k = B_c[960*line + 32k + i]
+//   qword 0       bits 0..39: C[c] + Occ(c, rows before this line); bits 40..49 / 50..59: set bits in qwords 1..5 /
+//                 1..10 of this line (two sub-block counts: a rank popcounts at most five words)
+//   qword 1..15   bit i of qword 1+k = B_c[960*line + 64k + i]
 //
 // sigma * rows / 7.5 bytes (13.7 GB for a 2^30-row text with 96 characters -- "size everything for 288 GB").  A search
 // step is then two INDEPENDENT line reads (one when both range ends fall into the same 960 rows): half the lines and half
@@ -20,28 +21,28 @@ namespace femto_amd {
 
 constexpr int kIndRows = 960;
 
-struct IndLine { uint32_t w[32]; };
-
-__device__ __forceinline__ void ind_load(const uint32_t* __restrict__ ind, uint64_t line, IndLine& L) {
-  const uint4* lp = reinterpret_cast<const uint4*>(ind + line * 32);
+// C[c] + Occ(c, row) for row = 960*line + b.  Only what the rank needs is loaded: the head word and the five words of
+// b's sub-block (the 128-byte line is one memory request either way, but 48 instead of 128 bytes reach the registers and a
+// rank costs ~45 VALU instructions instead of ~150 -- the round-2 profile showed the whole-line version VALU-bound).
+__device__ __forceinline__ int64_t ind_rank(const uint32_t* __restrict__ ind, uint64_t line, uint32_t b) {
+  const uint64_t* lp = reinterpret_cast<const uint64_t*>(ind + line * 32);
+  const uint64_t head = lp[0];
+  const uint32_t w = b >> 6;                 // data word 0..14
+  const uint32_t sblk = w / 5u;              // sub-block 0..2
+  const uint64_t* dp = lp + 1 + 5u * sblk;
+  uint64_t d[5];
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const uint4 v = lp[k];
-    L.w[4 * k] = v.x; L.w[4 * k + 1] = v.y; L.w[4 * k + 2] = v.z; L.w[4 * k + 3] = v.w;
-  }
-}
-
-// C[c] + Occ(c, row) for row = 960*line + b: the line's count + set bits among its first b+1
-__device__ __forceinline__ int64_t ind_rank(const IndLine& L, uint32_t b) {
+  for (int k = 0; k < 5; k++) d[k] = dp[k];
+  const int nb = int(b - 320u * sblk) + 1;   // bits of the sub-block to count: 1..320
   uint32_t cnt = 0;
-  const int nb = int(b) + 1;
 #pragma unroll
-  for (int k = 0; k < 30; k++) {
-    const int bits = nb - 32 * k;
-    const uint32_t m = bits >= 32 ? ~0u : (bits <= 0 ? 0u : ((1u << bits) - 1u));
-    cnt += uint32_t(__popc(L.w[2 + k] & m));
+  for (int k = 0; k < 5; k++) {
+    const int bits = nb - 64 * k;
+    const uint64_t m = bits >= 64 ? ~0ull : (bits <= 0 ? 0ull : ((1ull << bits) - 1ull));
+    cnt += uint32_t(__popcll(d[k] & m));
   }
-  return int64_t((uint64_t(L.w[1] & 0xffu) << 32) | L.w[0]) + int64_t(cnt);
+  const uint32_t sub = sblk == 0 ? 0u : (sblk == 1 ? uint32_t(head >> 40) & 0x3ffu : uint32_t(head >> 50) & 0x3ffu);
+  return int64_t(head & ((1ull << 40) - 1ull)) + int64_t(sub + cnt);
 }
 
 __device__ __forceinline__ void ind_split(int64_t row, uint64_t* line, uint32_t* b) {
@@ -64,20 +65,11 @@ __device__ __forceinline__ void ind_search_step(const DevIndex& ix, int j, uint3
   ind_split(last, &lineL, &bL);
   const bool haveF = first != 0;
   if (haveF) ind_split(first - 1, &lineF, &bF);
-  const bool other = haveF && lineF != lineL;
-  IndLine LL, LF;
-  ind_load(ix.ind, base + lineL, LL);
   trace_touch(ix, kTraceInd, base + lineL);
-  if (other) {
-    ind_load(ix.ind, base + lineF, LF);
-    trace_touch(ix, kTraceInd, base + lineF);
-  }
-  const int64_t nl = ind_rank(LL, bL);
-  int64_t nf;
-  if (!haveF) nf = ix.p2_c[code];
-  else if (other) nf = ind_rank(LF, bF);
-  else nf = ind_rank(LL, bF);
-  first = nf;
+  if (haveF && lineF != lineL) trace_touch(ix, kTraceInd, base + lineF);
+  const int64_t nl = ind_rank(ix.ind, base + lineL, bL);      // the two ranks are independent: their loads overlap
+  const int64_t rf = ind_rank(ix.ind, base + lineF, bF);      // (first == 0: line 0 of the character, result unused)
+  first = haveF ? rf : ix.p2_c[code];
   last = nl - 1;
 }
 
@@ -92,20 +84,20 @@ __global__ __launch_bounds__(256) void ind_build_kernel(const DevIndex ix, const
   __syncthreads();
   const uint32_t c = threadIdx.x;
   if (int(c) >= ix.p2_sigma) return;
-  uint32_t w[32];
   const int64_t before = row0 == 0 ? ix.p2_c[c] : p2_c_plus_occ(ix, c, row0 - 1);
-  w[0] = uint32_t(uint64_t(before));
-  w[1] = uint32_t(uint64_t(before) >> 32) & 0xffu;
+  uint64_t* dst = reinterpret_cast<uint64_t*>(ind + (uint64_t(c) * uint64_t(stride) + uint64_t(g)) * 32);
+  uint32_t sub1 = 0, sub2 = 0, run = 0;
 #pragma unroll 1
-  for (int k = 0; k < 30; k++) {
-    uint32_t v = 0;
+  for (int k = 0; k < 15; k++) {
+    uint64_t v = 0;
 #pragma unroll
-    for (int i = 0; i < 32; i++) v |= (uint32_t(s_sym[32 * k + i]) == c ? 1u : 0u) << i;
-    w[2 + k] = v;
+    for (int i = 0; i < 64; i++) v |= uint64_t(uint32_t(s_sym[64 * k + i]) == c ? 1u : 0u) << i;
+    dst[1 + k] = v;
+    run += uint32_t(__popcll(v));
+    if (k == 4) sub1 = run;
+    if (k == 9) sub2 = run;
   }
-  uint4* dst = reinterpret_cast<uint4*>(ind + (uint64_t(c) * uint64_t(stride) + uint64_t(g)) * 32);
-#pragma unroll
-  for (int k = 0; k < 8; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+  dst[0] = (uint64_t(before) & ((1ull << 40) - 1ull)) | (uint64_t(sub1) << 40) | (uint64_t(sub2) << 50);
 }
 
 }  // namespace femto_amd

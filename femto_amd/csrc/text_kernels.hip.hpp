@@ -71,7 +71,7 @@ struct Pack2Policy {
 // byte alphabets with the per-character rank lines resident (ind_kernels.hip.hpp): search steps read one line per range
 // end; everything that does not know its character in advance (LF steps) stays on the two-level lines
 struct IndPolicy : Pack2Policy {
-  static constexpr int kWaves = 3;     // two whole lines in flight per lane (16 x 16-byte loads): up to 168 VGPRs
+  static constexpr int kWaves = 8;
   static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
     ind_search_step(ix, j, code, f, l);
   }

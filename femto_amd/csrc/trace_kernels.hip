@@ -36,7 +36,7 @@ static DevIndex make_dev(const TraceArgs& a) {
   d.tail_items = a.tail_items;
   d.tail_count = a.flags + 2;
   d.tail_min = a.tail_min;
-  if (!a.tail_items && !(a.mode == 3 && d.sa_full && d.isa8 && d.isa_shift == 0)) d.txt = nullptr;
+  if (!a.tail_items && !(d.sa_full && d.isa8 && d.isa_shift == 0)) d.txt = nullptr;
   return d;
 }
 
@@ -47,7 +47,7 @@ hipError_t traced_count_plan(const TraceArgs& a) {
   const dim3 grid{uint32_t(nblocks)}, block{256};
   hipError_t e = hipMemsetAsync(a.flags, 0, 4 * sizeof(int), a.stream);
   if (e != hipSuccess) return e;
-  const bool dense = a.mode == 3 && d.txt && d.sa_full && d.isa8 && d.isa_shift == 0;   // as launch_count_direct decides
+  const bool dense = d.txt && d.sa_full && d.isa8 && d.isa_shift == 0;   // as launch_count_direct decides
 #define LAUNCH_COUNT_DIRECT(POLICY)                                                                                                     \
   do {                                                                                                                                  \
     if (dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, true, true>), grid, block, 0, a.stream, d, a.npats, a.plen, a.pats, a.starts, a.first, a.last, a.flags, a.max_occs, a.noccs, a.bsums); \
