@@ -77,6 +77,7 @@ def lib():
         L.femto_amd_locate_device.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, vp, vp]
         L.femto_amd_trace_lines.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, C.POINTER(i64)]
         L.femto_amd_open_multi.argtypes = [C.c_char_p, i32, vp, C.POINTER(vp)]
+        L.femto_amd_open_multi_striped.argtypes = [C.c_char_p, i32, vp, C.POINTER(vp)]
         L.femto_amd_device_count.argtypes = [vp]
         L.femto_amd_comm_unique_id.argtypes = [vp]
         L.femto_amd_comm_init.argtypes = [vp, vp, i32, i32]
@@ -135,12 +136,13 @@ def flatten(patterns):
 class Index:
     """A femto index resident in the HBM of one GPU.  device=-1 parses only (host logic tests)."""
 
-    def __init__(self, path, device=0, part=None, nparts=None, devices=None):
+    def __init__(self, path, device=0, part=None, nparts=None, devices=None, striped=False):
         self._h = C.c_void_p()
         self._peers = []   # range-split: the parts attached in-process must outlive this handle's use
         if devices is not None:     # one handle over several GPUs of this process (femto_amd_open_multi): host-pointer calls only
             arr = (C.c_int * len(devices))(*[int(d) for d in devices])
-            _check(lib().femto_amd_open_multi(os.fsencode(path), len(devices), arr, C.byref(self._h)))
+            fn = lib().femto_amd_open_multi_striped if striped else lib().femto_amd_open_multi
+            _check(fn(os.fsencode(path), len(devices), arr, C.byref(self._h)))
             device = list(devices)
         elif nparts is None:
             _check(lib().femto_amd_open(os.fsencode(path), device, C.byref(self._h)))

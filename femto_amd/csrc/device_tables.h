@@ -137,6 +137,8 @@ struct DevIndex {           // passed by value to kernels
   int32_t kt2_base;         // t = number of table characters (characters of the text that are not <= SEOF)
   int32_t kt2_nstop;        // dense codes below this are <= SEOF: digit = dense code - kt2_nstop
   int32_t kt2_pad;
+  const uint64_t* kt2_deep; // the deepest level, compact: first (40 bits) | rows in the range (24 bits; 0xffffff: see ktab2_lookup)
+  int64_t kt2_deep_off;     // heap position of the deepest level's first entry
   uint32_t* trace;          // NULL, or the line bitmaps of femto_amd_trace_lines: bit trace_off[region] + line index
   int64_t trace_off[kTraceRegions];   // first bit of every traced region (kTrace* above)
   uint16_t pack_alpha[8];   // dense code -> alpha code

@@ -23,8 +23,9 @@
 // occupies [ (t^m-1)/(t-1), (t^(m+1)-1)/(t-1) ) -- holds exactly the values do_string_query's loop
 // (src/main/server.c:832-936) holds after searching s, including an early death:  x = first,  y = (last + 1) | m << 48.
 // A pattern shorter than K, or one that meets a character outside the table, leaves the table at its level and
-// continues symbol by symbol.  K is chosen from a byte budget (FEMTO_AMD_KTAB_MB; default half a byte per row, so the
-// table stays a fraction of the packed lines: K = 12 for a 2^30-row DNA index = 358 MB).
+// continues symbol by symbol.  K: the deepest level has at most one entry per row (t^K <= rows; K = 15 for a 2^30-row DNA
+// index) and the table at most a quarter of the free HBM; the deepest level is stored in 8 bytes per entry (see
+// ktab2_deep_kernel): 5.7 + 8.6 GB there.  FEMTO_AMD_KTAB_SYMS / FEMTO_AMD_KTAB_MB override.
 #pragma once
 
 namespace femto_amd {
@@ -47,6 +48,55 @@ __global__ __launch_bounds__(256) void ktab2_level_kernel(const DevIndex ix, con
 
 __global__ void ktab2_root_kernel(const DevIndex ix, longlong2* __restrict__ tab) {
   if (threadIdx.x == 0 && blockIdx.x == 0) tab[0] = make_longlong2(0, ix.total_length);   // empty pattern: [0, n-1] (server.c:782-808)
+}
+
+// The deepest level holds three quarters of the entries and its ranges are short, so it is stored compactly: 8 bytes =
+// first (40 bits: the format's 2^39 rows) | number of rows (24 bits).  A dead range has last == first - 1 by construction
+// (first = C+Occ(c,first-1), last = C+Occ(c,last)-1 with equal Occs), i.e. 0 rows; a range of 2^24 - 1 rows or more
+// (highly repetitive text) stores 0xffffff and is recomputed from its parent with one ordinary step.
+constexpr uint64_t kDeepBig = 0xffffffu;
+constexpr uint64_t kDeepFirstMask = (uint64_t(1) << 40) - 1;
+
+template <class P>
+__global__ __launch_bounds__(256) void ktab2_deep_kernel(const DevIndex ix, const int level, const int64_t lo, const int64_t n,
+                                                         const longlong2* __restrict__ tab, uint64_t* __restrict__ deep) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t pos = lo + i;
+  const int64_t t = ix.kt2_base;
+  const int64_t parent = (pos - 1) / t;
+  const uint32_t digit = uint32_t((pos - 1) - parent * t);
+  const longlong2 e = tab[parent];
+  int64_t first = e.x, last = int64_t(uint64_t(e.y) & kKtabLastMask) - 1;
+  if (first <= last) P::search_step(ix, level - 1, digit + uint32_t(ix.kt2_nstop), first, last);
+  const uint64_t rows = first <= last ? uint64_t(last - first + 1) : 0;
+  deep[i] = (uint64_t(first) & kDeepFirstMask) | ((rows < kDeepBig ? rows : kDeepBig) << 40);
+}
+
+// the table entry of heap position `pos` at level m: the (first,last) after searching those m symbols
+template <class P>
+__device__ __forceinline__ void ktab2_lookup(const DevIndex& ix, int64_t pos, int m, int64_t& first, int64_t& last) {
+  if (ix.kt2_deep && m == ix.kt2_syms) {
+    const int64_t i = pos - ix.kt2_deep_off;
+    const uint64_t e = ix.kt2_deep[i];
+    trace_touch(ix, kTraceKtab, uint64_t(ix.kt2_deep_off >> 3) + 1 + (uint64_t(i) >> 4));
+    const uint64_t rows = e >> 40;
+    first = int64_t(e & kDeepFirstMask);
+    last = first + int64_t(rows) - 1;
+    if (rows != kDeepBig) return;
+    const int64_t t = ix.kt2_base;
+    const int64_t parent = (pos - 1) / t;
+    const longlong2 pe = reinterpret_cast<const longlong2*>(ix.ktab2)[parent];
+    trace_touch(ix, kTraceKtab, uint64_t(parent) >> 3);
+    first = pe.x;
+    last = int64_t(uint64_t(pe.y) & kKtabLastMask) - 1;
+    P::search_step(ix, m - 1, uint32_t((pos - 1) - parent * t) + uint32_t(ix.kt2_nstop), first, last);
+    return;
+  }
+  const longlong2 e = reinterpret_cast<const longlong2*>(ix.ktab2)[pos];
+  trace_touch(ix, kTraceKtab, uint64_t(pos) >> 3);
+  first = e.x;
+  last = int64_t(uint64_t(e.y) & kKtabLastMask) - 1;
 }
 
 // sum of `v` over the 256-thread block (all threads must call); valid in thread 0
@@ -109,10 +159,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, 
         if (code == 0xffffu || code < nstop) break;   // not a table character: the ordinary step below deals with it
         pos = pos * t + 1 + int64_t(code - nstop);
       }
-      const longlong2 e = reinterpret_cast<const longlong2*>(ix.ktab2)[pos];
-      trace_touch(ix, kTraceKtab, uint64_t(pos) >> 3);
-      first = e.x;
-      last = int64_t(uint64_t(e.y) & kKtabLastMask) - 1;
+      ktab2_lookup<P>(ix, pos, j, first, last);
       if (first > last) j = len;
     }
     bool handed = false;
@@ -233,10 +280,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, 
       if (f - 1 < nstop) break;          // a character <= SEOF: not a table character, stepped below
       pos = pos * t + 1 + int64_t(f - 1 - nstop);
     }
-    const longlong2 e = reinterpret_cast<const longlong2*>(ix.ktab2)[pos];
-    trace_touch(ix, kTraceKtab, uint64_t(pos) >> 3);
-    first = e.x;
-    last = int64_t(uint64_t(e.y) & kKtabLastMask) - 1;
+    ktab2_lookup<P>(ix, pos, j, first, last);
     if (first > last) ended = true;
   }
   if (!ended)

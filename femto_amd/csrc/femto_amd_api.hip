@@ -83,6 +83,15 @@ struct DeviceBuffer {
   template <class T> T* as() { return reinterpret_cast<T*>(p); }
 };
 
+// two timing events destroyed on every exit path (the derivations at open return early on any HIP error)
+struct EventPair {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ~EventPair() {
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+  }
+};
+
 struct KernelTimer {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // recorded, not yet read
   std::vector<hipEvent_t> free_list;                       // created once, reused
@@ -205,6 +214,7 @@ struct femto_amd_index {
   int64_t* d_pack_c = nullptr;
   int64_t* d_ktab = nullptr;
   int64_t* d_ktab2 = nullptr;
+  int64_t* d_ktab2_deep = nullptr;
   int64_t ktab2_bytes = 0;
   uint8_t* d_txt = nullptr;
   int64_t* d_isa8 = nullptr;
@@ -253,6 +263,14 @@ struct femto_amd_index {
   // multi-device handle (femto_amd_open_multi): no device of its own, one replica per GPU; host-pointer batches are
   // sharded over the replicas by host threads
   std::vector<femto_amd_index*> children;
+  // striped index (femto_amd_open_multi_striped): the big arrays are ONE address range each whose pages live in the HBM
+  // of all the listed GPUs (HIP virtual memory management); the small tables are copied to every GPU
+  std::vector<int> stripe_devices;           // non-empty while the builder handle allocates
+  struct Striped { void* va; size_t size, chunk; std::vector<hipMemGenericAllocationHandle_t> handles; };
+  std::vector<Striped> striped;
+  std::vector<std::pair<void*, size_t>> small_tables;   // every upload()ed table: what a view on another GPU copies
+  bool borrowed = false;                     // a view of another handle's arrays on a second GPU: owns only `owned_small`
+  std::vector<void*> owned_small;
   // RCCL communicator of the multi-process form (femto_amd_comm_init)
   ncclComm_t comm = nullptr;
   int comm_rank = 0, comm_size = 0;
@@ -324,6 +342,8 @@ struct Lease {
 // `slack` zero bytes follow the data: a damaged index (counts that disagree with the bits they summarise) can make a
 // kernel index a little past the end of the table it is walking -- at most one bucket's worth -- and must read
 // zeros there, not fault.  (Results for such an index are garbage either way, as they are in the reference.)
+thread_local std::vector<std::pair<void*, size_t>>* g_small_registry = nullptr;   // set while a handle is being opened
+
 template <class T>
 int upload(T** dst, const std::vector<T>& src, int64_t* bytes, size_t slack = 0) {
   size_t n = src.size() * sizeof(T);
@@ -331,7 +351,102 @@ int upload(T** dst, const std::vector<T>& src, int64_t* bytes, size_t slack = 0)
   if (n) HIP_TRY(hipMemcpy(*dst, src.data(), n, hipMemcpyHostToDevice));
   if (slack) HIP_TRY(hipMemset(reinterpret_cast<char*>(*dst) + n, 0, slack));
   if (bytes) *bytes += int64_t(n);
+  if (g_small_registry) g_small_registry->emplace_back(static_cast<void*>(*dst), (n + slack) ? n + slack : size_t(16));
   return 0;
+}
+
+// ---- big arrays: plain hipMalloc, or -- striped index -- one address range backed by the HBM of several GPUs ---------
+hipError_t big_malloc(femto_amd_index* ix, void** out, size_t bytes) {
+  if (ix->stripe_devices.empty()) return hipMalloc(out, bytes);
+  const int N = int(ix->stripe_devices.size());
+  hipMemAllocationProp prop{};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = ix->stripe_devices[0];
+  size_t gran = 0;
+  hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+  if (e != hipSuccess) return e;
+  if (gran == 0) gran = size_t(2) << 20;
+  femto_amd_index::Striped st;
+  st.chunk = ((bytes + size_t(N) - 1) / size_t(N) + gran - 1) / gran * gran;
+  st.size = st.chunk * size_t(N);
+  st.va = nullptr;
+  if ((e = hipMemAddressReserve(&st.va, st.size, gran, nullptr, 0)) != hipSuccess) return e;
+  for (int i = 0; i < N; i++) {
+    prop.location.id = ix->stripe_devices[size_t(i)];
+    hipMemGenericAllocationHandle_t h;
+    if ((e = hipMemCreate(&h, st.chunk, &prop, 0)) != hipSuccess) break;
+    st.handles.push_back(h);
+    if ((e = hipMemMap(static_cast<char*>(st.va) + size_t(i) * st.chunk, st.chunk, 0, h, 0)) != hipSuccess) break;
+  }
+  if (e == hipSuccess) {
+    std::vector<hipMemAccessDesc> acc;
+    std::vector<int> seen;
+    for (int d : ix->stripe_devices) {
+      if (std::find(seen.begin(), seen.end(), d) != seen.end()) continue;
+      seen.push_back(d);
+      hipMemAccessDesc a{};
+      a.location.type = hipMemLocationTypeDevice;
+      a.location.id = d;
+      a.flags = hipMemAccessFlagsProtReadWrite;
+      acc.push_back(a);
+    }
+    e = hipMemSetAccess(st.va, st.size, acc.data(), acc.size());
+  }
+  if (e != hipSuccess) {
+    for (size_t i = 0; i < st.handles.size(); i++) {
+      (void)hipMemUnmap(static_cast<char*>(st.va) + i * st.chunk, st.chunk);
+      (void)hipMemRelease(st.handles[i]);
+    }
+    (void)hipMemAddressFree(st.va, st.size);
+    return e;
+  }
+  ix->striped.push_back(st);
+  *out = st.va;
+  return hipSuccess;
+}
+
+void big_free(femto_amd_index* ix, void* p) {
+  if (!p) return;
+  for (size_t k = 0; k < ix->striped.size(); k++)
+    if (ix->striped[k].va == p) {
+      auto& st = ix->striped[k];
+      for (size_t i = 0; i < st.handles.size(); i++) {
+        (void)hipMemUnmap(static_cast<char*>(st.va) + i * st.chunk, st.chunk);
+        (void)hipMemRelease(st.handles[i]);
+      }
+      (void)hipMemAddressFree(st.va, st.size);
+      ix->striped.erase(ix->striped.begin() + long(k));
+      return;
+    }
+  (void)hipFree(p);
+}
+
+// memset / host-to-device copy that never crosses a stripe boundary in one call
+template <class Fn>
+hipError_t big_pieces(femto_amd_index* ix, void* p, size_t bytes, Fn fn) {
+  char* c = static_cast<char*>(p);
+  for (auto& st : ix->striped) {
+    char* va = static_cast<char*>(st.va);
+    if (c >= va && c < va + st.size) {
+      size_t done = 0;
+      while (done < bytes) {
+        const size_t off = size_t(c + done - va);
+        const size_t piece = std::min(bytes - done, st.chunk - off % st.chunk);
+        hipError_t e = fn(c + done, done, piece);
+        if (e != hipSuccess) return e;
+        done += piece;
+      }
+      return hipSuccess;
+    }
+  }
+  return fn(c, 0, bytes);
+}
+hipError_t big_memset(femto_amd_index* ix, void* p, int v, size_t bytes) {
+  return big_pieces(ix, p, bytes, [&](char* dst, size_t, size_t n) { return hipMemset(dst, v, n); });
+}
+hipError_t big_h2d(femto_amd_index* ix, void* p, const void* src, size_t bytes) {
+  return big_pieces(ix, p, bytes, [&](char* dst, size_t off, size_t n) { return hipMemcpy(dst, static_cast<const char*>(src) + off, n, hipMemcpyHostToDevice); });
 }
 
 int ensure_device(femto_amd_index* ix) {
@@ -777,17 +892,18 @@ int build_ktab(femto_amd_index* ix, Kernel kernel) {
 }
 
 // Level table of the direct pipeline (direct_kernels.hip.hpp): all strings of at most K table characters, heap-numbered.
-// K: the deepest level has at most one entry per four rows (t^K <= rows / 4, never fewer than 2^16 entries) -- deeper
-// levels would mostly hold one-row or empty ranges -- and the whole table takes at most a quarter of the free HBM.
-// For a 2^30-row DNA index: K = 14, 5.7 GB (bowtie-style "ftab", but of femto's own ranges: x = first, y = last + 1).
-// FEMTO_AMD_KTAB_MB bounds the bytes instead, FEMTO_AMD_KTAB_SYMS pins K, FEMTO_AMD_KTAB=0 disables the table.
+// K: the deepest level has at most one entry per row (t^K <= rows, never fewer than 2^16 entries) -- deeper levels would
+// mostly hold empty ranges -- and the whole table takes at most a quarter of the free HBM.  Levels 0..K-1 are 16-byte
+// entries, the deepest level 8-byte ones.  For a 2^30-row DNA index: K = 15, 5.7 + 8.6 GB (the "ftab" of DNA aligners,
+// but of femto's own ranges).  FEMTO_AMD_KTAB_MB bounds the bytes instead, FEMTO_AMD_KTAB_SYMS pins K, FEMTO_AMD_KTAB=0
+// disables the table.
 template <class P>
 int build_ktab2(femto_amd_index* ix, int sigma, int nstop) {
   if (ix->dev.ktab2) return 0;
   if (const char* kt = getenv("FEMTO_AMD_KTAB")) if (atoi(kt) == 0) return 0;
   const int64_t t = sigma - nstop;
   if (t < 1) return 0;
-  int64_t level_cap = std::max<int64_t>(int64_t(1) << 16, ix->host.total_length / 4);
+  int64_t level_cap = std::max<int64_t>(int64_t(1) << 16, ix->host.total_length);
   int64_t budget = INT64_MAX;
   {
     size_t free_b = 0, total_b = 0;
@@ -799,23 +915,28 @@ int build_ktab2(femto_amd_index* ix, int sigma, int nstop) {
   }
   int want = -1;
   if (const char* ks = getenv("FEMTO_AMD_KTAB_SYMS")) want = atoi(ks);
-  // level m holds t^m entries; entries(K) = 1 + t + ... + t^K
+  // level m holds t^m entries; bytes(K) = 16 * (1 + t + ... + t^(K-1)) + 8 * t^K
   int K = 0;
-  int64_t entries = 1, level = 1;
+  int64_t upper = 0, level = 1;       // entries of levels 0..K-1, entries of level K
   std::vector<int64_t> lo{0};
   for (;;) {
     if (K >= 24 || level > (int64_t(1) << 40) / t) break;
     const int64_t next_level = level * t;
-    if (want >= 0 ? K >= want : (next_level > level_cap || (entries + next_level) > budget / 16)) break;
-    lo.push_back(entries);
-    entries += next_level;
+    if (want >= 0 ? K >= want : (next_level > level_cap || ((upper + level) * 16 + next_level * 8) > budget)) break;
+    upper += level;
+    lo.push_back(upper);
     level = next_level;
     K++;
   }
   if (K < 1) return 0;
-  if (hipMalloc(reinterpret_cast<void**>(&ix->d_ktab2), size_t(entries) * 16) != hipSuccess) {
+  // upper = entries of levels 0..K-1 (16 bytes each), level = entries of level K (8 bytes each)
+  if (big_malloc(ix, reinterpret_cast<void**>(&ix->d_ktab2), size_t(upper) * 16) != hipSuccess ||
+      big_malloc(ix, reinterpret_cast<void**>(&ix->d_ktab2_deep), size_t(level) * 8 + 64) != hipSuccess) {
     (void)hipGetLastError();
+    big_free(ix, ix->d_ktab2);
     ix->d_ktab2 = nullptr;
+    big_free(ix, ix->d_ktab2_deep);
+    ix->d_ktab2_deep = nullptr;
     return FEMTO_AMD_ERR_MEM;
   }
   DevIndex d = ix->dev;
@@ -825,20 +946,26 @@ int build_ktab2(femto_amd_index* ix, int sigma, int nstop) {
   longlong2* tab = reinterpret_cast<longlong2*>(ix->d_ktab2);
   hipLaunchKernelGGL(ktab2_root_kernel, dim3(1), dim3(64), 0, nullptr, d, tab);
   int64_t cnt = 1;
+  const int64_t chunk = int64_t(1) << 30;
   for (int m = 1; m <= K; m++) {
     cnt *= t;
-    const int64_t chunk = int64_t(1) << 30;
     for (int64_t o = 0; o < cnt; o += chunk) {
       const int64_t cn = std::min(chunk, cnt - o);
-      hipLaunchKernelGGL(ktab2_level_kernel<P>, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, d, m, lo[size_t(m)] + o, cn, tab);
+      if (m < K)
+        hipLaunchKernelGGL(ktab2_level_kernel<P>, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, d, m, lo[size_t(m)] + o, cn, tab);
+      else
+        hipLaunchKernelGGL(ktab2_deep_kernel<P>, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, d, m, lo[size_t(m)] + o, cn,
+                           static_cast<const longlong2*>(tab), reinterpret_cast<uint64_t*>(ix->d_ktab2_deep) + o);
     }
   }
   if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return set_err(FEMTO_AMD_ERR_INVALID, "level table build failed");
   ix->dev.ktab2 = ix->d_ktab2;
+  ix->dev.kt2_deep = reinterpret_cast<const uint64_t*>(ix->d_ktab2_deep);
+  ix->dev.kt2_deep_off = lo[size_t(K)];
   ix->dev.kt2_syms = K;
   ix->dev.kt2_base = int32_t(t);
   ix->dev.kt2_nstop = nstop;
-  ix->ktab2_bytes = entries * 16;
+  ix->ktab2_bytes = upper * 16 + level * 8;
   ix->table_bytes += ix->ktab2_bytes;
   return 0;
 }
@@ -872,7 +999,8 @@ int build_pack(femto_amd_index* ix) {
     pc[8 + size_t(c)] = h.C[size_t(ix->dev.pack_alpha[c]) + 1] - 1;
   }
   ix->dev.pack_sigma = sigma;
-  hipEvent_t e0, e1;
+  EventPair ev;
+  hipEvent_t &e0 = ev.e0, &e1 = ev.e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
   HIP_TRY(hipEventRecord(e0, nullptr));
@@ -892,7 +1020,7 @@ int build_pack(femto_amd_index* ix) {
     if ((rc = counts.reserve(size_t(9 * stride) * 8))) return rc;
     if ((rc = scans.reserve(size_t(9 * stride) * 8))) return rc;
     HIP_TRY(hipMemset(sym.p, 0, size_t(nlines) * kPackRows));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_pack), size_t(nlines) * kPackLineWords * 4));
+    HIP_TRY(big_malloc(ix, reinterpret_cast<void**>(&ix->d_pack), size_t(nlines) * kPackLineWords * 4));
     const int64_t chunk = int64_t(1) << 30;
     for (int64_t r0 = 0; r0 < n; r0 += chunk) {
       const int64_t cn = std::min(chunk, n - r0);
@@ -923,7 +1051,7 @@ int build_pack(femto_amd_index* ix) {
     }
     int64_t nmarks = 0;
     HIP_TRY(hipMemcpy(&nmarks, scans.as<int64_t>() + 8 * stride + nlines, 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_pack_sa), size_t(nmarks > 0 ? nmarks : 1) * 8));
+    HIP_TRY(big_malloc(ix, reinterpret_cast<void**>(&ix->d_pack_sa), size_t(nmarks > 0 ? nmarks : 1) * 8));
     for (int64_t r0 = 0; r0 < n; r0 += chunk) {
       const int64_t cn = std::min(chunk, n - r0);
       if (every)
@@ -951,8 +1079,6 @@ int build_pack(femto_amd_index* ix) {
     ix->dev.pack_sa = ix->d_pack_sa;
     r = build_ktab(ix, ktab_build_kernel);
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   return r;
 }
 
@@ -976,7 +1102,8 @@ int build_pack2(femto_amd_index* ix) {
       if (ch <= kSEOF) stop_below = uint32_t(sigma) + 1;
       code[size_t(ch)] = uint16_t(sigma++);
     }
-  hipEvent_t e0, e1;
+  EventPair ev;
+  hipEvent_t &e0 = ev.e0, &e1 = ev.e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
   HIP_TRY(hipEventRecord(e0, nullptr));
@@ -999,7 +1126,7 @@ int build_pack2(femto_amd_index* ix) {
     if ((rc = sym.reserve(size_t(n) * 2))) return rc;
     if ((rc = counts.reserve(size_t(17 * stride1) * 8))) return rc;
     if ((rc = scans.reserve(size_t(17 * stride1) * 8))) return rc;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_p2_l1), size_t(nl1) * 128));
+    HIP_TRY(big_malloc(ix, reinterpret_cast<void**>(&ix->d_p2_l1), size_t(nl1) * 128));
     const int64_t chunk = int64_t(1) << 30;
     for (int64_t r0 = 0; r0 < n; r0 += chunk) {
       const int64_t cn = std::min(chunk, n - r0);
@@ -1033,7 +1160,7 @@ int build_pack2(femto_amd_index* ix) {
                          lo2.as<uint8_t>());
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_p2_l2), size_t(nl2) * 128));
+    HIP_TRY(big_malloc(ix, reinterpret_cast<void**>(&ix->d_p2_l2), size_t(nl2) * 128));
     // the level-1 scratch is free again: reuse it for the level-2 counts when it is large enough
     if ((rc = counts.reserve(size_t(16 * stride2) * 8))) return rc;
     if ((rc = scans.reserve(size_t(16 * stride2) * 8))) return rc;
@@ -1053,8 +1180,8 @@ int build_pack2(femto_amd_index* ix) {
       const size_t ibytes = size_t(sigma) * size_t(istride) * 128;
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-      if (want && ibytes <= free_b / 4 && hipMalloc(reinterpret_cast<void**>(&ix->d_ind), ibytes + 256) == hipSuccess) {
-        HIP_TRY(hipMemset(ix->d_ind, 0, ibytes + 256));
+      if (want && ibytes <= free_b / 4 && big_malloc(ix, reinterpret_cast<void**>(&ix->d_ind), ibytes + 256) == hipSuccess) {
+        HIP_TRY(big_memset(ix, ix->d_ind, 0, ibytes + 256));
         const int64_t gchunk = int64_t(1) << 22;
         for (int64_t g0 = 0; g0 < groups; g0 += gchunk)
           hipLaunchKernelGGL(ind_build_kernel, dim3(uint32_t(std::min(gchunk, groups - g0))), dim3(256), 0, nullptr, ix->dev, n, sym.as<uint16_t>(),
@@ -1087,7 +1214,7 @@ int build_pack2(femto_amd_index* ix) {
       HIP_TRY(hipMemcpy(&nmarks, counts.as<int64_t>() + stride1 + nl1, 8, hipMemcpyDeviceToHost));
     }
     if (!ix->d_pack_sa) {  // offsets of the marked rows (shared with the 3-bit lines when both exist)
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_pack_sa), size_t(nmarks > 0 ? nmarks : 1) * 8));
+      HIP_TRY(big_malloc(ix, reinterpret_cast<void**>(&ix->d_pack_sa), size_t(nmarks > 0 ? nmarks : 1) * 8));
       for (int64_t r0 = 0; r0 < n; r0 += chunk) {
         const int64_t cn = std::min(chunk, n - r0);
         if (every)
@@ -1124,8 +1251,6 @@ int build_pack2(femto_amd_index* ix) {
     d.p2_l1 = nullptr;
     d.p2_l2 = nullptr;
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   return r;
 }
 
@@ -1148,16 +1273,16 @@ int build_text(femto_amd_index* ix) {
   }
   const bool want_sa = dense && size_t(n) * 8 <= free_b / 5;
   const size_t tb = size_t(n) + 64, ib = (size_t(n >> isa_shift) + 2) * 8, sb = want_sa ? size_t(n) * 8 + 64 : 0;
-  if (hipMalloc(reinterpret_cast<void**>(&ix->d_txt), tb) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&ix->d_isa8), ib) != hipSuccess ||
-      (sb && hipMalloc(reinterpret_cast<void**>(&ix->d_sa_full), sb) != hipSuccess)) {
+  if (big_malloc(ix, reinterpret_cast<void**>(&ix->d_txt), tb) != hipSuccess || big_malloc(ix, reinterpret_cast<void**>(&ix->d_isa8), ib) != hipSuccess ||
+      (sb && big_malloc(ix, reinterpret_cast<void**>(&ix->d_sa_full), sb) != hipSuccess)) {
     (void)hipGetLastError();
-    (void)hipFree(ix->d_txt); ix->d_txt = nullptr;
-    (void)hipFree(ix->d_isa8); ix->d_isa8 = nullptr;
-    (void)hipFree(ix->d_sa_full); ix->d_sa_full = nullptr;
+    big_free(ix, ix->d_txt); ix->d_txt = nullptr;
+    big_free(ix, ix->d_isa8); ix->d_isa8 = nullptr;
+    big_free(ix, ix->d_sa_full); ix->d_sa_full = nullptr;
     return FEMTO_AMD_ERR_MEM;
   }
-  HIP_TRY(hipMemset(ix->d_txt, 0xff, tb));
-  HIP_TRY(hipMemset(ix->d_isa8, 0, ib));
+  HIP_TRY(big_memset(ix, ix->d_txt, 0xff, tb));
+  HIP_TRY(big_memset(ix, ix->d_isa8, 0, ib));
   const int64_t chunk = int64_t(1) << 30;
   for (int64_t r0 = 0; r0 < n; r0 += chunk) {
     const int64_t cn = std::min(chunk, n - r0);
@@ -1592,12 +1717,14 @@ extern "C" {
 
 const char* femto_amd_last_error(void) { return g_last_error.c_str(); }
 
-static int open_impl(const char* index_path, int device, int part, int nparts, femto_amd_index_t** out) {
+static int open_impl(const char* index_path, int device, int part, int nparts, femto_amd_index_t** out,
+                     const std::vector<int>* stripe = nullptr) {
   if (!index_path || !out) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
   *out = nullptr;
   const bool split = nparts > 0;
   femto_amd_index* ix = new (std::nothrow) femto_amd_index();
   if (!ix) return set_err(FEMTO_AMD_ERR_MEM, "out of memory");
+  if (stripe) ix->stripe_devices = *stripe;     // the big arrays of this handle are striped over these GPUs (big_malloc)
   Error err{0, ""};
   int rc;
   try {
@@ -1628,13 +1755,19 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
       int r;
       if (!split) {
         const size_t image_slack = size_t(h.b_size) * size_t(h.text_size_bits) / 8 + 64;   // a mark array read one bucket too far
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_image), h.image.size() + image_slack));
-        HIP_TRY(hipMemcpy(ix->d_image, h.image.data(), h.image.size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemset(ix->d_image + h.image.size(), 0, image_slack));
+        HIP_TRY(big_malloc(ix, reinterpret_cast<void**>(&ix->d_image), h.image.size() + image_slack));
+        HIP_TRY(big_h2d(ix, ix->d_image, h.image.data(), h.image.size()));
+        HIP_TRY(big_memset(ix, ix->d_image + h.image.size(), 0, image_slack));
         if ((r = upload(&ix->d_nodes, h.nodes, &ix->table_bytes))) return r;
         if ((r = upload(&ix->d_seqs, h.seqs, &ix->table_bytes))) return r;
         if ((r = upload(&ix->d_leaf_code, h.leaf_code, &ix->table_bytes))) return r;
-        if ((r = upload(&ix->d_segs, h.segs, &ix->table_bytes, (size_t(h.b_size) / 511 + 4) * 128))) return r;
+        {  // the segment lines: a big array (striped when the index is)
+          const size_t sb = h.segs.size() * 8, slack = (size_t(h.b_size) / 511 + 4) * 128;
+          HIP_TRY(big_malloc(ix, reinterpret_cast<void**>(&ix->d_segs), sb + slack));
+          if (sb) HIP_TRY(big_h2d(ix, ix->d_segs, h.segs.data(), sb));
+          HIP_TRY(big_memset(ix, reinterpret_cast<char*>(ix->d_segs) + sb, 0, slack));
+          ix->table_bytes += int64_t(sb);
+        }
         if ((r = upload(&ix->d_cum, h.cum, &ix->table_bytes))) return r;
         if ((r = upload(&ix->d_hint, h.hint, &ix->table_bytes))) return r;
         if ((r = upload(&ix->d_lnodes, h.lnodes, &ix->table_bytes))) return r;
@@ -1727,8 +1860,8 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
       r = build_pack(ix);
       if (r == FEMTO_AMD_ERR_MEM) {
         (void)hipGetLastError();
-        (void)hipFree(ix->d_pack); ix->d_pack = nullptr;
-        if (!ix->dev.pack_sa) { (void)hipFree(ix->d_pack_sa); ix->d_pack_sa = nullptr; }
+        big_free(ix, ix->d_pack); ix->d_pack = nullptr;
+        if (!ix->dev.pack_sa) { big_free(ix, ix->d_pack_sa); ix->d_pack_sa = nullptr; }
         ix->dev.pack = nullptr;
         r = 0;
       }
@@ -1736,8 +1869,8 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
       r = build_pack2(ix);
       if (r == FEMTO_AMD_ERR_MEM) {
         (void)hipGetLastError();
-        (void)hipFree(ix->d_p2_l1); ix->d_p2_l1 = nullptr;
-        (void)hipFree(ix->d_p2_l2); ix->d_p2_l2 = nullptr;
+        big_free(ix, ix->d_p2_l1); ix->d_p2_l1 = nullptr;
+        big_free(ix, ix->d_p2_l2); ix->d_p2_l2 = nullptr;
         ix->dev.p2_l1 = nullptr;
         ix->dev.p2_l2 = nullptr;
         r = 0;
@@ -1760,6 +1893,7 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
       }
       return 0;
     };
+    g_small_registry = &ix->small_tables;
     try {
       rc = up();
     } catch (const std::bad_alloc&) {
@@ -1767,6 +1901,7 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
     } catch (const std::exception& ex) {
       rc = set_err(FEMTO_AMD_ERR_FORMAT, std::string("damaged index: ") + ex.what());
     }
+    g_small_registry = nullptr;
     if (rc) {
       femto_amd_close(ix);
       return rc;
@@ -1899,7 +2034,7 @@ int femto_amd_split_info(const femto_amd_index_t* ix, int* part, int* nparts, in
 
 void femto_amd_close(femto_amd_index_t* ix) {
   if (!ix) return;
-  for (femto_amd_index* c : ix->children) femto_amd_close(c);
+  for (size_t c = ix->children.size(); c-- > 0;) femto_amd_close(ix->children[c]);   // views before the builder of a striped index
   ix->children.clear();
   if (ix->comm) {
     if (Rccl* R = rccl()) (void)R->CommDestroy(ix->comm);
@@ -1918,37 +2053,20 @@ void femto_amd_close(femto_amd_index_t* ix) {
         (void)hipIpcCloseMemHandle(ix->peer_segs[p]);
         (void)hipIpcCloseMemHandle(ix->peer_image[p]);
       }
-    (void)hipFree(ix->d_image);
-    (void)hipFree(ix->d_nodes);
-    (void)hipFree(ix->d_buckets);
-    (void)hipFree(ix->d_seqs);
-    (void)hipFree(ix->d_occ_base);
-    (void)hipFree(ix->d_leaf_code);
-    (void)hipFree(ix->d_C);
-    (void)hipFree(ix->d_segs);
-    (void)hipFree(ix->d_cum);
-    (void)hipFree(ix->d_hint);
-    (void)hipFree(ix->d_bdir);
-    (void)hipFree(ix->d_lnodes);
-    (void)hipFree(ix->d_lseqs);
-    (void)hipFree(ix->d_occ);
-    (void)hipFree(ix->d_dense);
-    (void)hipFree(ix->d_pack);
-    (void)hipFree(ix->d_pack_sa);
-    (void)hipFree(ix->d_pack_code);
-    (void)hipFree(ix->d_pack_c);
-    (void)hipFree(ix->d_ktab);
-    (void)hipFree(ix->d_txt);
-    (void)hipFree(ix->d_isa8);
-    (void)hipFree(ix->d_p2_l1);
-    (void)hipFree(ix->d_p2_l2);
-    (void)hipFree(ix->d_p2_base);
-    (void)hipFree(ix->d_p2_c);
-    (void)hipFree(ix->d_p2_code);
-    (void)hipFree(ix->d_p2_alpha);
-    (void)hipFree(ix->d_ktab2);
-    (void)hipFree(ix->d_sa_full);
-    (void)hipFree(ix->d_ind);
+    if (ix->borrowed) {      // a view on a second GPU: the arrays belong to the builder handle
+      for (void* q : ix->owned_small) (void)hipFree(q);
+    } else {
+      for (void* q : {static_cast<void*>(ix->d_image), static_cast<void*>(ix->d_segs), static_cast<void*>(ix->d_pack), static_cast<void*>(ix->d_pack_sa),
+                      static_cast<void*>(ix->d_txt), static_cast<void*>(ix->d_isa8), static_cast<void*>(ix->d_p2_l1), static_cast<void*>(ix->d_p2_l2),
+                      static_cast<void*>(ix->d_ktab2), static_cast<void*>(ix->d_ktab2_deep), static_cast<void*>(ix->d_sa_full), static_cast<void*>(ix->d_ind)})
+        big_free(ix, q);
+      for (void* q : {static_cast<void*>(ix->d_nodes), static_cast<void*>(ix->d_buckets), static_cast<void*>(ix->d_seqs), static_cast<void*>(ix->d_occ_base),
+                      static_cast<void*>(ix->d_leaf_code), static_cast<void*>(ix->d_C), static_cast<void*>(ix->d_cum), static_cast<void*>(ix->d_hint),
+                      static_cast<void*>(ix->d_bdir), static_cast<void*>(ix->d_lnodes), static_cast<void*>(ix->d_lseqs), static_cast<void*>(ix->d_occ),
+                      static_cast<void*>(ix->d_dense), static_cast<void*>(ix->d_pack_code), static_cast<void*>(ix->d_pack_c), static_cast<void*>(ix->d_ktab),
+                      static_cast<void*>(ix->d_p2_base), static_cast<void*>(ix->d_p2_c), static_cast<void*>(ix->d_p2_code), static_cast<void*>(ix->d_p2_alpha)})
+        (void)hipFree(q);
+    }
     for (DeviceBuffer& b : ix->open_scan) b.release();
   }
   delete ix;
@@ -2473,7 +2591,7 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
   int64_t region_lines[kTraceRegions] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   region_lines[kTraceInd] = ix->ind_bytes / 128;
   region_lines[kTracePack] = ix->dev.pack ? (n + kPackRows - 1) / kPackRows : 0;
-  region_lines[kTraceKtab] = ix->ktab2_bytes / 128 + 1;
+  region_lines[kTraceKtab] = ix->ktab2_bytes / 128 + 4;
   region_lines[kTraceSa] = (ix->dev.sa_full ? n : ix->n_marks) / 16 + 1;
   region_lines[kTraceL1] = ix->p2_lines1;
   region_lines[kTraceL2] = ix->p2_lines2;
@@ -2587,6 +2705,84 @@ int femto_amd_open_multi(const char* index_path, int ndev, const int* devices, f
       femto_amd_close(ix);
       return set_err(code, m);
     }
+  *out = ix;
+  return FEMTO_AMD_OK;
+  API_END
+}
+
+// A view of `b` (the builder of a striped index) for another GPU: the big arrays are the builder's own address ranges
+// (their pages are mapped for every listed GPU), the small tables are copied into the view's GPU.
+static int make_view(femto_amd_index* b, int device, femto_amd_index** out) {
+  femto_amd_index* v = new (std::nothrow) femto_amd_index();
+  if (!v) return set_err(FEMTO_AMD_ERR_MEM, "out of memory");
+  auto fail = [&](int code) { femto_amd_close(v); return code; };
+  v->borrowed = true;
+  v->device = device;
+  HostIndex& h = v->host;
+  const HostIndex& s = b->host;
+  h.total_length = s.total_length; h.number_of_blocks = s.number_of_blocks; h.number_of_documents = s.number_of_documents;
+  h.block_size = s.block_size; h.b_size = s.b_size; h.mark_period = s.mark_period; h.chunk_size = s.chunk_size;
+  h.text_size_bits = s.text_size_bits; h.buckets_per_block = s.buckets_per_block; h.total_buckets = s.total_buckets;
+  h.header = s.header; h.C = s.C; h.doc_ends = s.doc_ends; h.doc_info_off = s.doc_info_off; h.dir_regular = s.dir_regular;
+  h.block_off = s.block_off; h.block_len = s.block_len;
+  v->mode = b->mode; v->direct = b->direct; v->sort_queries = b->sort_queries; v->dense_bits = b->dense_bits;
+  v->dense_sigma = b->dense_sigma; v->sort_min = b->sort_min; v->h_dense = b->h_dense; v->table_bytes = b->table_bytes;
+  v->ktab2_bytes = b->ktab2_bytes; v->n_marks = b->n_marks; v->p2_lines1 = b->p2_lines1; v->p2_lines2 = b->p2_lines2;
+  v->ind_bytes = b->ind_bytes; v->text_bytes = b->text_bytes; v->pack_bytes = b->pack_bytes; v->pack2_bytes = b->pack2_bytes;
+  v->blocks_per_cu_override = b->blocks_per_cu_override;
+  if (hipSetDevice(device) != hipSuccess) return fail(set_err(FEMTO_AMD_ERR_INVALID, "no usable HIP device " + std::to_string(device)));
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) v->num_cus = prop.multiProcessorCount;
+  std::vector<std::pair<const void*, void*>> map;
+  for (auto& t : b->small_tables) {
+    void* q = nullptr;
+    if (hipMalloc(&q, t.second) != hipSuccess) return fail(set_err(FEMTO_AMD_ERR_MEM, "hipMalloc (small table copy)"));
+    v->owned_small.push_back(q);
+    if (hipMemcpyPeer(q, device, t.first, b->device, t.second) != hipSuccess)
+      return fail(set_err(FEMTO_AMD_ERR_INVALID, "hipMemcpyPeer (small table copy)"));
+    map.emplace_back(t.first, q);
+  }
+  auto remap = [&](auto*& ptr) {
+    for (auto& m : map)
+      if (m.first == static_cast<const void*>(ptr)) { ptr = static_cast<std::remove_reference_t<decltype(ptr)>>(m.second); return; }
+  };
+  v->dev = b->dev;
+  DevIndex& d = v->dev;
+  remap(d.nodes); remap(d.buckets); remap(d.seqs); remap(d.occ_base); remap(d.leaf_code); remap(d.C); remap(d.cum); remap(d.hint);
+  remap(d.bdir); remap(d.lnodes); remap(d.lseqs); remap(d.occ); remap(d.pack_code); remap(d.pack_c); remap(d.p2_base); remap(d.p2_c);
+  remap(d.p2_code); remap(d.p2_alpha);
+  v->d_dense = b->d_dense;
+  remap(v->d_dense);
+  *out = v;
+  return 0;
+}
+
+int femto_amd_open_multi_striped(const char* index_path, int ndev, const int* devices, femto_amd_index_t** out) {
+  API_BEGIN
+  if (!index_path || !out || ndev < 1 || ndev > 64 || !devices) return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
+  *out = nullptr;
+  femto_amd_index_t* ix = nullptr;
+  int rc = femto_amd_open(index_path, -1, &ix);     // parse-only: facts, document table
+  if (rc) return rc;
+  const std::vector<int> devs(devices, devices + ndev);
+  for (int a : devs)      // every GPU reads the others' stripes directly
+    for (int b : devs)
+      if (a != b) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) {
+          femto_amd_close(ix);
+          return set_err(FEMTO_AMD_ERR_INVALID, "no peer access between devices " + std::to_string(a) + " and " + std::to_string(b));
+        }
+      }
+  femto_amd_index* builder = nullptr;
+  rc = open_impl(index_path, devs[0], 0, 0, &builder, &devs);     // derives everything on the first GPU, into striped arrays
+  if (rc) { femto_amd_close(ix); return rc; }
+  ix->children.push_back(builder);
+  for (int i = 1; i < ndev; i++) {
+    femto_amd_index* v = nullptr;
+    if ((rc = make_view(builder, devs[size_t(i)], &v))) { femto_amd_close(ix); return rc; }
+    ix->children.push_back(v);
+  }
   *out = ix;
   return FEMTO_AMD_OK;
   API_END

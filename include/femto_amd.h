@@ -200,6 +200,14 @@ int femto_amd_split_info(const femto_amd_index_t* ix, int* part, int* nparts, in
  * available on such a handle (FEMTO_AMD_ERR_INVALID).  INTEGRATION.md: the shim opens one when FEMTO_AMD_DEVICES lists
  * more than one device. */
 int femto_amd_open_multi(const char* index_path, int ndev, const int* devices, femto_amd_index_t** out);
+/* The same handle for an index LARGER than one GPU's HBM (BASELINE configs[4]; the reference partitions by block,
+ * bsearch_block_rows src/main/index.c:1613-1617): every big array -- block images, segment lines, packed / two-level /
+ * per-character lines, level table, suffix arrays, text -- is ONE address range whose pages live in the HBM of all the
+ * listed GPUs in equal contiguous stripes (HIP virtual memory management: hipMemCreate per GPU, one hipMemMap'ed
+ * range, access granted to every GPU), the small tables are copied to every GPU.  The kernels are unchanged: a line in
+ * another GPU's stripe is an ordinary load that travels over xGMI -- the packed fast paths, unlike
+ * femto_amd_open_split's wavelet-path kernels, keep working.  Batches shard over the GPUs as with femto_amd_open_multi. */
+int femto_amd_open_multi_striped(const char* index_path, int ndev, const int* devices, femto_amd_index_t** out);
 int femto_amd_device_count(const femto_amd_index_t* ix);
 /* One process per GPU, results resident on the devices: the only exchange is the final gather of the shards' results
  * to one rank -- a grouped batch of ncclSend / ncclRecv over xGMI (RCCL is loaded on first use, it is not a link-time

@@ -232,6 +232,33 @@ def test_multi_device_handle_shards_host_batches(fixtures, gpu_ok, name):
     ix.close()
 
 
+@pytest.mark.parametrize("name", ["acgt48k", "eng2doc", "bytes256"])
+def test_striped_index_over_devices(fixtures, gpu_ok, name):
+    """femto_amd_open_multi_striped: every big array is one address range whose pages are spread over the listed GPUs
+    (HIP virtual memory management), the small tables are copied per GPU, the kernels are unchanged.  The box has one GPU,
+    so the three stripes and the two views live on it -- allocation, mapping, the per-stripe copies / fills and the views'
+    table copies are what is tested; every kernel family must still reproduce the goldens through views."""
+    fx = fixtures(name)
+    g = fx.gold
+    ix = femto_amd.Index(fx.index, devices=[0, 0, 0], striped=True)
+    plen, flat, starts = fx.patterns
+    for mode in (None, 1):
+        if mode is not None:
+            ix.set_rank_mode(mode)
+        first, last = ix.count_flat(plen, flat, starts)
+        assert np.array_equal(first, g["count_first"]) and np.array_equal(last, g["count_last"]), mode
+        for mo, g_noccs, g_offs in fx.locate_cases():
+            noccs, offs = ix.locate_flat(plen, flat, starts, mo)
+            assert np.array_equal(noccs, g_noccs) and np.array_equal(offs, g_offs), (mode, mo)
+    rows = int(ix.info.total_length)
+    single = femto_amd.Index(fx.index, device=0)
+    assert np.array_equal(ix.locate_range(0, rows - 1), single.locate_range(0, rows - 1))
+    ch, occ, off = ix.block_requests(np.arange(rows, dtype=np.int64))
+    assert np.array_equal(ch, g["L"]) and np.array_equal(occ, g["occ"]) and np.array_equal(off, g["off"])
+    single.close()
+    ix.close()
+
+
 def test_comm_gather_one_rank(fixtures, gpu_ok):
     """femto_amd_comm_*: RCCL is loaded on first use; a communicator of one rank gathers to itself (the N > 1 exchange is
     the same grouped ncclSend / ncclRecv batch, which needs N GPUs: bench.py --gather native on the multi-GPU node)."""
@@ -746,6 +773,14 @@ def test_full_size_1gib_properties(tmp_path, gpu_ok):
     leaf1 = ix.block_requests(rows2)
     for a, b in zip(leaf3, leaf1):
         assert np.array_equal(a, b)
+    ix.close()
+    # the same index with its big arrays striped over "three GPUs" (all stripes on this one): same kernels, same answers
+    sx = femto_amd.Index(path, devices=[0, 0, 0], striped=True)
+    fs, ls = sx.count_flat(plen, flat, starts)
+    assert np.array_equal(fs, first) and np.array_equal(ls, last)
+    ns, os_ = sx.locate_flat(plen, flat, starts, 100)
+    assert np.array_equal(ns, noccs) and np.array_equal(os_, offs)
+    sx.close()
 
 
 def test_full_size_text96_properties(tmp_path, gpu_ok):
