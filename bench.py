@@ -149,6 +149,7 @@ class Batch:
         self.d_res2 = [torch.empty((2, self.n), dtype=torch.int64, device=dev) for _ in range(2)]   # [first; last], double buffered
         self.d_res = self.d_res2[0]
         self.d_wire2 = None       # multi-GPU: the ranges as they travel to rank 0 (see wire())
+        self.w_res, self.w_cap, self.w_views, self.w_tmp = None, -1, None, None   # ... or match counts + offsets (wire_results())
         self.d_noccs = torch.empty(self.n, dtype=torch.int32, device=dev)
         self.d_ostarts = torch.empty(self.n + 1, dtype=torch.int64, device=dev)
         self.offsets = None
@@ -187,6 +188,35 @@ class Batch:
         self.d_wire2[buf].copy_(self.d_res)
         return self.d_wire2[buf]
 
+    def wire_results(self, rows, cap, buf=0):
+        """What north_star calls the results -- the match count of every pattern and the located text offsets -- as ONE
+        buffer for the gather: [total rows i64 | counts | offsets[:cap]], counts and offsets narrowed to int32 when the index
+        has fewer than 2^31 - 1 rows (lossless).  `cap` is the same on every rank (max of the ranks' totals + slack, agreed in
+        the untimed settle phase).  Half the bytes of the (first,last) form for a batch that locates few rows."""
+        t = self.torch
+        small = rows < (1 << 31) - 1
+        dt = t.int32 if small else t.int64
+        if self.w_res is None or self.w_cap != cap:
+            esz = 4 if small else 8
+            nbytes = 8 + esz * (self.n + cap)
+            self.w_res = [t.zeros(nbytes + 8, dtype=t.uint8, device=self.dev) for _ in range(2)]
+            self.w_cap = cap
+            self.w_tmp = t.empty(self.n, dtype=t.int64, device=self.dev)
+            self.w_views = []
+            for w in self.w_res:
+                tot = w[:8].view(t.int64)
+                cnt = w[8:8 + esz * self.n].view(dt)
+                off = w[8 + esz * self.n:8 + esz * (self.n + cap)].view(dt)
+                self.w_views.append((tot, cnt, off))
+        tot, cnt, off = self.w_views[buf]
+        t.sub(self.d_res[1], self.d_res[0], out=self.w_tmp)
+        self.w_tmp.add_(1).clamp_(min=0)                   # match count: last - first + 1, 0 when there is no match
+        cnt.copy_(self.w_tmp)
+        tot.copy_(self.d_total[:1])
+        k = min(cap, self.offsets.numel())
+        off[:k].copy_(self.offsets[:k])
+        return self.w_res[buf]
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -211,6 +241,9 @@ def main():
     ap.add_argument("--gather", default="torch", choices=["torch", "native"],
                     help="N > 1: torch = torch.distributed.gather (RCCL); native = the library's own grouped ncclSend/ncclRecv "
                          "(femto_amd_comm_gather), its id broadcast through torch.distributed")
+    ap.add_argument("--results", default="counts", choices=["counts", "ranges"],
+                    help="N > 1: what is gathered to rank 0 every step: counts = match count of every pattern + the located offsets "
+                         "(north_star's 'results'), ranges = the (first,last) row ranges of parallel_count")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary P_hit line (N=1 default workload only)")
     ap.add_argument("--workdir", default=os.environ.get("FEMTO_AMD_BENCH_DIR", "/tmp/femto_amd_bench"))
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "latest_pmc.json"))
@@ -296,9 +329,23 @@ def main():
         torch.cuda.synchronize()
         ix.close()
         return
+    cap = 0
+    if world > 1 and args.results == "counts":     # untimed: every rank's row total, the common capacity of the gathered offsets
+        batch.settle(ix, args.max_occs, torch.cuda.current_stream().cuda_stream)
+        tcap = torch.tensor([batch.total], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tcap, op=dist.ReduceOp.MAX)
+        cap = int(tcap.item() * 1.25) + 1024
+        if batch.offsets.numel() < cap:
+            batch.offsets = torch.empty(cap, dtype=torch.int64, device=dev)
+
+    def payload_of(b=0):
+        if args.results == "counts":
+            return batch.wire_results(info.total_length, cap, b)
+        return batch.wire(info.total_length, b)
+
     gather_lists = None
     if world > 1 and rank == 0:
-        gather_lists = [[torch.empty_like(batch.wire(info.total_length), device=None if backend == "nccl" else "cpu")
+        gather_lists = [[torch.empty_like(payload_of(), device=None if backend == "nccl" else "cpu")
                          for _ in range(world)] for _ in range(2)]
     native = world > 1 and args.gather == "native" and backend == "nccl"
     gstream, recv_native = None, None
@@ -307,7 +354,7 @@ def main():
         dist.broadcast_object_list(ids, src=0)
         ix.comm_init(ids[0], world, rank)
         gstream = torch.cuda.Stream()
-        w0 = batch.wire(info.total_length)
+        w0 = payload_of()
         if rank == 0:
             recv_native = [torch.empty((world,) + tuple(w0.shape), dtype=w0.dtype, device=dev) for _ in range(2)]
     stream = torch.cuda.current_stream().cuda_stream
@@ -324,7 +371,7 @@ def main():
             pending[b] = None
         batch.step(ix, args.max_occs, stream, b)
         if native:
-            payload = batch.wire(info.total_length, b)
+            payload = payload_of(b)
             ev = torch.cuda.Event()
             ev.record()
             gstream.wait_event(ev)
@@ -334,7 +381,7 @@ def main():
             done.record(gstream)
             pending[b] = _EventWork(done)
         elif world > 1:
-            payload = batch.wire(info.total_length, b)
+            payload = payload_of(b)
             if backend != "nccl":
                 payload = payload.cpu()
             pending[b] = dist.gather(payload, gather_lists[b] if rank == 0 else None, dst=0, async_op=True)
@@ -561,8 +608,9 @@ def main():
                    "rank_mode": {4: "pack2", 3: "pack", 1: "lane", 2: "flat", 0: "raw"}[ix.rank_mode], "index": {"rows": int(info.total_length), "blocks": int(info.number_of_blocks), "buckets": int(info.total_buckets),
                              "image_bytes": int(info.image_bytes), "table_bytes": int(info.table_bytes),
                              "packed_lines": ix.pack_info()},
-                   "parallelism": ("range-split index (1/N of the blocks per GPU, peer loads over xGMI)" if args.layout == "split" and world > 1 else "replicated index") + f", query shards x{world}" + ((", RCCL gather of (first,last) to rank 0 every step (int32 rows when the index has < 2^31 rows), overlapped with the next step's kernels"
-                                                                                  + ("; gather = femto_amd_comm_gather (grouped ncclSend/ncclRecv)" if native else "; gather = torch.distributed.gather")) if world > 1 else ""),
+                   "parallelism": ("range-split index (1/N of the blocks per GPU, peer loads over xGMI)" if args.layout == "split" and world > 1 else "replicated index") + f", query shards x{world}" + ((", RCCL gather of the results to rank 0 every step (32-bit when the index has < 2^31 rows), overlapped with the next step's kernels"
+                                                                                  + ("; gather = femto_amd_comm_gather (grouped ncclSend/ncclRecv)" if native else "; gather = torch.distributed.gather") + (
+                                                                                  "; payload = match counts + located offsets" if args.results == "counts" else "; payload = (first,last) ranges")) if world > 1 else ""),
                    "build_s": build_s, "open_s": open_s},
         "roofline": roof, "cpu_baseline": cpu,
         "gpu_vs_cpu": (value / cpu["value"]) if cpu else None,

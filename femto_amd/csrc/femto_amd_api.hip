@@ -1317,11 +1317,11 @@ int pipe_init(femto_amd_index* ix, Scratch& S) {
   {
     std::lock_guard<std::mutex> lk(ix->workers_mu);
     if (!ix->workers) {
-      // a quarter of the host's hardware threads, between 4 and 64 (packing 10 M patterns into keys is ~200 M table
+      // a quarter of the host's hardware threads, at least 4, at most 128 (packing 10 M patterns into keys is ~200 M table
       // look-ups: 16 threads would be the bottleneck of the pipeline on the GPU box's 256-thread host)
       int nthreads = std::max(4, int(std::thread::hardware_concurrency()) / 4);
       if (const char* e = getenv("FEMTO_AMD_HOST_THREADS")) nthreads = atoi(e);
-      nthreads = std::max(1, std::min(nthreads, 64));
+      nthreads = std::max(1, std::min(nthreads, 128));
       ix->workers.reset(new WorkerPool(nthreads));
     }
   }
@@ -1462,7 +1462,9 @@ int count_host_pipelined(femto_amd_index* ix, Scratch& S, const HostBatch& hb, i
   if (rc) return rc;
   auto& P = S.pipe;
   hipStream_t s_k = S.stream;
-  const int64_t nchunks = (hb.npats + kPipeChunk - 1) / kPipeChunk;
+  int64_t chunk = kPipeChunk;          // patterns per pipeline stage (the buffers are laid out for kPipeChunk)
+  if (const char* e = getenv("FEMTO_AMD_PIPE_CHUNK_LOG2")) chunk = std::min<int64_t>(kPipeChunk, int64_t(1) << std::max(12, std::min(30, atoi(e))));
+  const int64_t nchunks = (hb.npats + chunk - 1) / chunk;
   bool keys_ok = use_direct(ix) && !ix->h_dense.empty();
   if (const char* e = getenv("FEMTO_AMD_HOST_KEYS")) keys_ok = keys_ok && atoi(e) != 0;
   const bool rows32 = ix->host.total_length < (int64_t(1) << 31) - 1;    // rows (and last + 1, -1) fit 32 bits
@@ -1484,7 +1486,7 @@ int count_host_pipelined(femto_amd_index* ix, Scratch& S, const HostBatch& hb, i
   for (int64_t c = 0; c <= nchunks; c++) {
     if (c < nchunks) {
       const int b = int(c & 1);
-      const int64_t a = c * kPipeChunk, e = std::min(hb.npats, a + kPipeChunk), n = e - a;
+      const int64_t a = c * chunk, e = std::min(hb.npats, a + chunk), n = e - a;
       if (c >= 2) PIPE_TRY(hipEventSynchronize(P.k_done[b]));  // chunk c-2 no longer reads d_in[b] (and h_in[b] was uploaded)
       char* din = static_cast<char*>(P.d_in[b]);
       const char* hin = static_cast<const char*>(P.h_in[b]);
@@ -1530,7 +1532,7 @@ int count_host_pipelined(femto_amd_index* ix, Scratch& S, const HostBatch& hb, i
     }
     if (c >= 1 && !dev_first) {  // hand chunk c-1 back while chunk c is on its way
       const int b = int((c - 1) & 1);
-      const int64_t a = (c - 1) * kPipeChunk, e = std::min(hb.npats, a + kPipeChunk), n = e - a;
+      const int64_t a = (c - 1) * chunk, e = std::min(hb.npats, a + chunk), n = e - a;
       PIPE_TRY(hipEventSynchronize(P.out_done[b]));
       const char* hout = static_cast<const char*>(P.h_out[b]);
       const int k = kind[b];      // still chunk c-1's: chunk c went into the other buffer

@@ -93,6 +93,14 @@ def _wire_worker(rank, world, port, q):
     out = [torch.empty_like(small) for _ in range(world)] if rank == 0 else None
     w = dist.gather(small, out, dst=0, async_op=True)
     w.wait()
+    # the default payload: match counts + located offsets in one buffer (wire_results), same on every rank in size
+    cap = 64
+    b.offsets = torch.arange(100 * rank, 100 * rank + cap, dtype=torch.int64)
+    b.d_total = torch.tensor([40 + rank, 0], dtype=torch.int64)
+    res = b.wire_results((1 << 30) + 1, cap, 1)
+    assert res.dtype == torch.uint8 and res.numel() == 8 + 4 * (n + cap) + 8
+    out2 = [torch.empty_like(res) for _ in range(world)] if rank == 0 else None
+    dist.gather(res, out2, dst=0, async_op=True).wait()
     if rank == 0:
         ok = True
         for r in range(world):
@@ -101,6 +109,11 @@ def _wire_worker(rank, world, port, q):
             l_ = f + g.integers(-1, 50, n)
             f[0], l_[0] = 0, -1
             ok = ok and np.array_equal(out[r][0].numpy(), f) and np.array_equal(out[r][1].numpy(), l_)
+            raw = out2[r].numpy()
+            tot = raw[:8].view(np.int64)[0]
+            cnt = raw[8:8 + 4 * n].view(np.int32)
+            off = raw[8 + 4 * n:8 + 4 * (n + cap)].view(np.int32)
+            ok = ok and tot == 40 + r and np.array_equal(cnt, np.maximum(l_ - f + 1, 0)) and np.array_equal(off, np.arange(100 * r, 100 * r + cap))
         q.put(bool(ok))
     dist.barrier()
     dist.destroy_process_group()
