@@ -82,6 +82,8 @@ def lib():
         L.femto_amd_comm_unique_id.argtypes = [vp]
         L.femto_amd_comm_init.argtypes = [vp, vp, i32, i32]
         L.femto_amd_comm_gather.argtypes = [vp, vp, vp, i64, i32, vp]
+        L.femto_amd_regexp_search.argtypes = [vp, vp, i64, i64, vp, vp, vp, C.POINTER(i64)]
+        L.femto_amd_regexp_match.argtypes = [vp, i64, vp, i64]
         L.femto_amd_set_option.argtypes = [vp, C.c_char_p, i32]
         L.femto_amd_block_requests.argtypes = [vp, i64, vp, vp, vp, vp, vp]
         L.femto_amd_kernel_time_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]
@@ -332,6 +334,20 @@ class Index:
     def comm_gather(self, d_send, d_recv, bytes_per_rank, root=0, stream=0):
         _check(lib().femto_amd_comm_gather(self._h, d_send, d_recv or None, int(bytes_per_rank), int(root), stream or None))
 
+    def regexp_search(self, regex, max_results=1 << 20):
+        """row ranges of every string of the index the byte regular expression matches in full:
+        (first int64[], last int64[], match_len int32[]) sorted by first ascending, last descending"""
+        rx = np.frombuffer(bytes(regex) + b"\0", dtype=np.uint8)
+        n = C.c_int64(0)
+        _check(lib().femto_amd_regexp_search(self._h, _ptr(rx), len(regex), 0, None, None, None, C.byref(n)))
+        if n.value > max_results:
+            raise FemtoAmdError(3, f"{n.value} results > max_results {max_results}")
+        first = np.zeros(max(1, n.value), dtype=np.int64)
+        last = np.zeros(max(1, n.value), dtype=np.int64)
+        mlen = np.zeros(max(1, n.value), dtype=np.int32)
+        _check(lib().femto_amd_regexp_search(self._h, _ptr(rx), len(regex), max(1, n.value), _ptr(first), _ptr(last), _ptr(mlen), C.byref(n)))
+        return first[:n.value], last[:n.value], mlen[:n.value]
+
     def set_option(self, name, value):
         """'direct' (modes 3/4: caller-order pipeline, default 1) / 'sort' (suffix-order batches of the other paths)"""
         _check(lib().femto_amd_set_option(self._h, name.encode(), int(value)))
@@ -354,6 +370,14 @@ class Index:
 
     def kernel_time_reset(self):
         lib().femto_amd_kernel_time_reset(self._h)
+
+
+def regexp_match(regex, s):
+    """test hook: the automaton built from `regex` accepts exactly the byte string s (None: syntax error)"""
+    rx = np.frombuffer(bytes(regex) + b"\0", dtype=np.uint8)
+    sb = np.frombuffer(bytes(s) + b"\0", dtype=np.uint8)
+    r = lib().femto_amd_regexp_match(_ptr(rx), len(regex), _ptr(sb), len(s))
+    return None if r < 0 else bool(r)
 
 
 def bseq_encode(raw_bytes, bitlen, force_type=0):

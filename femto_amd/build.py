@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("FEMTO_AMD_LIB") or os.path.join(HERE, "libfemto_amd.so")
 SOURCES = ["femto_amd_api.hip", "trace_kernels.hip", "host_index.cpp", "index_builder.cpp", "suffix_sort.hip", "query_sort.hip"]
-HEADERS = ["device_tables.h", "host_index.hpp", "host_pipeline.hpp", "kernels.hip.hpp", "pack_kernels.hip.hpp", "pack2_kernels.hip.hpp", "text_kernels.hip.hpp", "direct_kernels.hip.hpp", "ind_kernels.hip.hpp", "trace_api.hpp", "index_builder.hpp",
+HEADERS = ["regexp_nfa.hpp", "device_tables.h", "host_index.hpp", "host_pipeline.hpp", "kernels.hip.hpp", "pack_kernels.hip.hpp", "pack2_kernels.hip.hpp", "text_kernels.hip.hpp", "direct_kernels.hip.hpp", "ind_kernels.hip.hpp", "trace_api.hpp", "index_builder.hpp",
            os.path.join("..", "..", "include", "femto_amd.h")]
 
 

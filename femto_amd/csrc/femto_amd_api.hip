@@ -28,6 +28,7 @@
 #include "text_kernels.hip.hpp"
 #include "direct_kernels.hip.hpp"
 #include "trace_api.hpp"
+#include "regexp_nfa.hpp"
 
 using namespace femto_amd;
 
@@ -1317,9 +1318,10 @@ int pipe_init(femto_amd_index* ix, Scratch& S) {
   {
     std::lock_guard<std::mutex> lk(ix->workers_mu);
     if (!ix->workers) {
-      // a quarter of the host's hardware threads, at least 4, at most 128 (packing 10 M patterns into keys is ~200 M table
-      // look-ups: 16 threads would be the bottleneck of the pipeline on the GPU box's 256-thread host)
-      int nthreads = std::max(4, int(std::thread::hardware_concurrency()) / 4);
+      // half of the host's hardware threads, at least 4, at most 128: packing 10 M patterns into keys is ~200 M table
+      // look-ups, and the staging threads -- not PCIe, not the GPU -- bound this path (measured on the GPU box's
+      // 256-thread host, 10 M 20-mers: 16 threads 12.7 ms, 32 9.2 ms, 64 6-9 ms, 128 5.6 ms)
+      int nthreads = std::max(4, int(std::thread::hardware_concurrency()) / 2);
       if (const char* e = getenv("FEMTO_AMD_HOST_THREADS")) nthreads = atoi(e);
       nthreads = std::max(1, std::min(nthreads, 128));
       ix->workers.reset(new WorkerPool(nthreads));
@@ -2676,6 +2678,129 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
   counts.release();
   return rc;
   API_END
+}
+
+// ---- regular expressions ---------------------------------------------------------------------------------
+// Backward search of every string the pattern matches (do_regexp_query, src/main/server.c:1656): level by level, every
+// (row range, NFA state set) in flight fans out over the characters its states can be entered through; the ranges of one
+// level are stepped by ONE launch of ranges_step_kernel.  A result is a string that reaches the automaton's start state
+// (the whole pattern read, right to left): its row range, sorted as regexp_result_list_sort does (first ascending, last
+// descending, server.c:1528).
+int femto_amd_regexp_search(femto_amd_index_t* ix, const uint8_t* regex, int64_t regex_len, int64_t max_results, int64_t* first_out,
+                            int64_t* last_out, int32_t* len_out, int64_t* n_out) {
+  API_BEGIN
+  if (!ix || (regex_len && !regex) || regex_len < 0 || max_results < 0 || !n_out || (max_results && (!first_out || !last_out)))
+    return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
+  if (!ix->children.empty()) return femto_amd_regexp_search(ix->children[0], regex, regex_len, max_results, first_out, last_out, len_out, n_out);
+  int rc = ensure_device(ix);
+  if (rc) return rc;
+  if (!ix->host.dir_regular) return set_err(FEMTO_AMD_ERR_INVALID, "regular-expression search needs the derived segment lines");
+  RegexNfa nfa;
+  {
+    std::string perr;
+    RegexParser parser(regex, regex_len, &nfa);
+    if (!parser.parse(&perr)) return set_err(FEMTO_AMD_ERR_PARAM, "regular expression: " + perr);
+  }
+  const HostIndex& h = ix->host;
+  CharClass in_text;                      // characters of the text that are real bytes (codes <= SEOF never match a class)
+  for (int c = FEMTO_AMD_CHARACTER_OFFSET; c < kAlphaSize; c++)
+    if (h.C[size_t(c) + 1] > h.C[size_t(c)]) in_text.set(c);
+  struct Item { StateSet s; int64_t first, last; int32_t len; };
+  struct Result { int64_t first, last; int32_t len; };
+  std::vector<Result> results;
+  std::vector<Item> frontier, next;
+  const size_t words = size_t(nfa.size() + 63) / 64;
+  {
+    Item it{StateSet(words, 0), 0, h.total_length - 1, 0};
+    ss_set(it.s, nfa.accept);
+    closure_rev(nfa, it.s);
+    if (ss_get(it.s, nfa.start)) results.push_back({it.first, it.last, 0});   // the pattern matches the empty string
+    frontier.push_back(std::move(it));
+  }
+  Lease L(ix);
+  if (!L.s) return L.rc;
+  Scratch& S = *L.s;
+  hipStream_t st = S.stream;
+  const int64_t work_limit = int64_t(1) << 24;     // (range, character) pairs per level and results: beyond it the pattern is too general
+  int64_t total_work = 0;
+  std::vector<int64_t> wf, wl, nf, nl;
+  std::vector<uint16_t> wc;
+  std::vector<uint32_t> wi;
+  while (!frontier.empty()) {
+    wf.clear(); wl.clear(); wc.clear(); wi.clear();
+    for (size_t i = 0; i < frontier.size(); i++) {
+      CharClass cc = incoming_chars(nfa, frontier[i].s);
+      for (int k = 0; k < 5; k++) cc.w[k] &= in_text.w[k];
+      for (int c = FEMTO_AMD_CHARACTER_OFFSET; c < kAlphaSize; c++)
+        if (cc.get(c)) {
+          wf.push_back(frontier[i].first);
+          wl.push_back(frontier[i].last);
+          wc.push_back(uint16_t(c));
+          wi.push_back(uint32_t(i));
+        }
+    }
+    const int64_t n = int64_t(wf.size());
+    if (n == 0) break;
+    total_work += n;
+    if (n > work_limit || total_work > 16 * work_limit)
+      return set_err(FEMTO_AMD_ERR_PARAM, "regular expression matches too many different strings of this index");
+    if ((rc = S.first.reserve(size_t(n) * 8)) || (rc = S.last.reserve(size_t(n) * 8)) || (rc = S.ch.reserve(size_t(n) * 2)) ||
+        (rc = S.occ.reserve(size_t(n) * 8)) || (rc = S.off.reserve(size_t(n) * 8)))
+      return rc;
+    HIP_TRY(hipMemcpyAsync(S.first.p, wf.data(), size_t(n) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(S.last.p, wl.data(), size_t(n) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(S.ch.p, wc.data(), size_t(n) * 2, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(ranges_step_kernel, dim3(uint32_t((n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, st, ix->dev, n,
+                       static_cast<const int64_t*>(S.first.as<int64_t>()), static_cast<const int64_t*>(S.last.as<int64_t>()),
+                       static_cast<const uint16_t*>(S.ch.as<uint16_t>()), S.occ.as<int64_t>(), S.off.as<int64_t>());
+    HIP_TRY(hipGetLastError());
+    nf.resize(size_t(n));
+    nl.resize(size_t(n));
+    HIP_TRY(hipMemcpyAsync(nf.data(), S.occ.p, size_t(n) * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(nl.data(), S.off.p, size_t(n) * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    next.clear();
+    for (int64_t k = 0; k < n; k++) {
+      if (nf[size_t(k)] > nl[size_t(k)]) continue;            // the extended string does not occur
+      const Item& it = frontier[wi[size_t(k)]];
+      Item ni{step_rev(nfa, it.s, wc[size_t(k)]), nf[size_t(k)], nl[size_t(k)], it.len + 1};
+      if (ss_get(ni.s, nfa.start)) {
+        results.push_back({ni.first, ni.last, ni.len});
+        if (int64_t(results.size()) > max_results && max_results > 0)
+          return set_err(FEMTO_AMD_ERR_PARAM, "more results than max_results");
+      }
+      if (!incoming_chars(nfa, ni.s).empty()) next.push_back(std::move(ni));
+    }
+    frontier.swap(next);
+  }
+  std::sort(results.begin(), results.end(), [](const Result& a, const Result& b) {
+    if (a.first != b.first) return a.first < b.first;
+    if (a.last != b.last) return a.last > b.last;
+    return a.len < b.len;
+  });
+  *n_out = int64_t(results.size());
+  if (int64_t(results.size()) > max_results) return max_results ? set_err(FEMTO_AMD_ERR_PARAM, "more results than max_results") : FEMTO_AMD_OK;
+  for (size_t i = 0; i < results.size(); i++) {
+    first_out[i] = results[i].first;
+    last_out[i] = results[i].last;
+    if (len_out) len_out[i] = results[i].len;
+  }
+  return FEMTO_AMD_OK;
+  API_END
+}
+
+/* test hook: does the automaton built from `regex` accept exactly the byte string s?  1 yes, 0 no, -1 syntax error */
+int femto_amd_regexp_match(const uint8_t* regex, int64_t regex_len, const uint8_t* s, int64_t len) {
+  try {
+    if ((regex_len && !regex) || (len && !s) || regex_len < 0 || len < 0) return -1;
+    RegexNfa nfa;
+    std::string perr;
+    RegexParser parser(regex, regex_len, &nfa);
+    if (!parser.parse(&perr)) { set_err(FEMTO_AMD_ERR_PARAM, "regular expression: " + perr); return -1; }
+    return nfa_full_match(nfa, s, len) ? 1 : 0;
+  } catch (...) {
+    return -1;
+  }
 }
 
 // ---- several GPUs ------------------------------------------------------------------------------------------------------

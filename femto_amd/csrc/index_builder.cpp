@@ -212,6 +212,12 @@ struct BseqEncoder {
 
 // ---------------------------------------------------------------- Huffman (bzip2's length-limited scheme)
 
+// The algorithm below follows bzip2's BZ2_hbMakeCodeLengths, which the reference vendors (src/main/huffman.c:63-148):
+//   bzip2/libbzip2 version 1.0.6 of 6 September 2010, Copyright (C) 1996-2010 Julian Seward <jseward@bzip.org>,
+//   released under the terms of the bzip2 licence (a BSD-style licence: redistribution in source and binary forms
+//   permitted provided the copyright notice, the conditions and the disclaimer are retained; "THIS SOFTWARE IS PROVIDED
+//   BY THE AUTHOR ``AS IS'' AND ANY EXPRESS OR IMPLIED WARRANTIES ... ARE DISCLAIMED").
+// Byte-identical index files depend on reproducing its tie-breaking exactly, hence the close correspondence.
 // BZ2_hbMakeCodeLengths (src/main/huffman.c:63-148): repeated Huffman construction on
 // weights = freq<<8 | depth with a 1-based binary min-heap; on overflow of maxLen the
 // frequencies are halved (1 + f/2) and the construction is repeated.  The heap discipline

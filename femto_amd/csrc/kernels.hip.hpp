@@ -695,6 +695,20 @@ __device__ __forceinline__ int64_t c_plus_occ_lane(const DevIndex& ix, uint32_t 
   return oe.base + int64_t(occ);
 }
 
+// One backward-search step for MANY (row range, character) pairs: the fan-out of do_regexp_query (src/main/server.c:1656,
+// states 0x200-0x411: "first = C[ch] + Occ(ch, first-1); last = C[ch] + Occ(ch, last) - 1" for every reachable character
+// of every range in flight), one lane per pair on femto's own wavelet tree.
+__global__ __launch_bounds__(256) void ranges_step_kernel(const DevIndex ix, const int64_t n, const int64_t* __restrict__ first,
+                                                          const int64_t* __restrict__ last, const uint16_t* __restrict__ ch,
+                                                          int64_t* __restrict__ first_out, int64_t* __restrict__ last_out) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t f = first[i], l = last[i];
+  const uint32_t c = ch[i];
+  first_out[i] = f == 0 ? ix.C[c] : c_plus_occ_lane(ix, c, f - 1);
+  last_out[i] = c_plus_occ_lane(ix, c, l) - 1;
+}
+
 // do_string_query (src/main/server.c:713-946): one LANE per pattern
 // `perm` (optional): lane j processes pattern perm[j] -- the batch ordered by pattern suffix
 // (query_sort.hip) so that neighbouring lanes share the rows of their first steps.

@@ -188,6 +188,21 @@ int femto_amd_split_commit(femto_amd_index_t* ix);
 /* bytes of this part's own slices (segment lines, block images) */
 int femto_amd_split_info(const femto_amd_index_t* ix, int* part, int* nparts, int64_t* seg_bytes, int64_t* image_bytes);
 
+/* ---- regular expressions (do_regexp_query src/main/server.c:1656, nfa.c, compile_regexp.c) -------------
+ * Every string of the index that matches `regex` IN FULL, as row ranges: result i is one matched string of len_out[i]
+ * symbols and the rows [first_out[i], last_out[i]] of the suffixes that start with it (locate them with
+ * femto_amd_parallel_locate_range); sorted by first ascending, last descending (regexp_result_list_sort, server.c:1528).
+ * Pattern language: the byte-regular-expression part of src/main/QUERY_FORMAT.txt -- literal bytes, `.`, `[a-z]` /
+ * `[^...]`, `( )`, `|`, `*`, `+`, `?`, backslash escapes (\n \t \xNN ...), "double" and 'single' quotes; unescaped
+ * whitespace separates terms and is ignored; no boolean / APPROX keywords.  Call with max_results == 0 to count the
+ * results (*n_out) only; more than max_results results, or a pattern that matches too many different strings (`.*`),
+ * is FEMTO_AMD_ERR_PARAM.  The reference's regular-expression front end needs flex/bison and cannot be built in this
+ * image, so this entry point is checked against brute force over the texts, not against reference vectors. */
+int femto_amd_regexp_search(femto_amd_index_t* ix, const uint8_t* regex, int64_t regex_len, int64_t max_results,
+                            int64_t* first_out, int64_t* last_out, int32_t* len_out, int64_t* n_out);
+/* test hook: does the automaton built from `regex` accept exactly the byte string s?  1 yes, 0 no, -1 syntax error */
+int femto_amd_regexp_match(const uint8_t* regex, int64_t regex_len, const uint8_t* s, int64_t len);
+
 /* ---- several GPUs of one node ----------------------------------------------------------------------------------------
  * Queries are independent (each string_query_t is its own state machine, src/main/server.c:3969-4001), so a batch shards
  * with no exchange during the search.

@@ -711,6 +711,42 @@ def test_large_text_suffix_sorter_path(tmp_path, gpu_ok, kind, monkeypatch):
     assert np.array_equal(offs, sa)
 
 
+def test_config0_16mib_vs_genuine_reference(tmp_path, gpu_ok):
+    """BASELINE configs[0], the reference's own CPU-runnable case: 16 MiB random-ACGT text, default index parameters,
+    100 k 20-mers (half sampled from the text, half random -- the mix BASELINE.md measured).  The index is built by this
+    repo's builder; count and locate on the GPU must equal the GENUINE reference's parallel_count / parallel_locate on
+    the same files (oracle/_ref/ref_tool, prebuilt where /root/reference exists) and the oracle port."""
+    n = 1 << 24
+    text = tg.t_acgt(n, 160)
+    path = str(tmp_path / "acgt16m")
+    femto_amd.build_index(path, [text], params=None, infos=["cfg0"], device=0)
+    ix = femto_amd.Index(path, device=0)
+    assert ix.info.total_length == n + 1 and ix.info.number_of_blocks == 1 and ix.info.total_buckets == 17
+    hp, hf = tg.p_hit(20, 20, 50_000, 5, text)
+    rp, rf = tg.p_rand(20, 50_000, 6)
+    plen = np.concatenate([hp, rp])
+    flat = np.concatenate([hf, rf])
+    starts = tg.starts_of(plen)
+    first, last = ix.count_flat(plen, flat, starts)
+    assert (last[:50_000] >= first[:50_000]).all()
+    noccs, offs = ix.locate_flat(plen, flat, starts, 100)
+    o = po.Oracle(path)
+    of, ol = o.count_flat(plen, flat, starts, threads=16)
+    on, oo = o.locate_flat(plen, flat, starts, 100, threads=16)
+    assert np.array_equal(first, of) and np.array_equal(last, ol) and np.array_equal(noccs, on) and np.array_equal(offs, oo)
+    if po.have_ref():
+        pf = str(tmp_path / "p.fpat")
+        po.write_fpat_flat(pf, plen, flat)
+        po.ref_tool("count", path, pf, str(tmp_path / "c.bin"), capture=False)
+        r = np.fromfile(str(tmp_path / "c.bin"), dtype=np.int64)
+        assert np.array_equal(r[:len(plen)], first) and np.array_equal(r[len(plen):], last)
+        po.ref_tool("locate", path, pf, 100, str(tmp_path / "l.bin"), capture=False)
+        raw = np.fromfile(str(tmp_path / "l.bin"), dtype=np.uint8)
+        assert np.array_equal(raw[:4 * len(plen)].view(np.int32), noccs)
+        assert np.array_equal(raw[4 * len(plen):].view(np.int64), offs)
+    ix.close()
+
+
 def test_full_size_1gib_properties(tmp_path, gpu_ok):
     """BASELINE configs[1] at FULL size (1 GiB random-ACGT text, reference default parameters), checked through
     size-independent properties plus an oracle spot check:

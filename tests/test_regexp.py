@@ -1,0 +1,100 @@
+"""Regular-expression search (do_regexp_query src/main/server.c:1656).
+
+The reference's regex front end (flex/bison) cannot be built in this image, so there are no reference vectors for
+this entry point (DESIGN.md says so: parity UNPINNED).  What is checked instead:
+  * CPU: the parser + Thompson construction + the REVERSED simulation the index search runs (femto_amd_regexp_match)
+    against Python's `re.fullmatch` on random patterns and strings;
+  * GPU: femto_amd_regexp_search on reference-built fixture indexes against brute force over the documents -- the set of
+    text offsets at which SOME match starts (the method of index_test.c:351-434 applied to patterns)."""
+import re
+
+import numpy as np
+import pytest
+
+import femto_amd
+
+
+def _rand_regex(rng, depth=0):
+    """a random pattern over {a,b,c} in the common subset of femto's syntax and Python's"""
+    r = rng.random()
+    if depth > 3 or r < 0.35:
+        k = rng.integers(0, 6)
+        return [b"a", b"b", b"c", b".", b"[ab]", b"[^a]"][k]
+    if r < 0.55:
+        return _rand_regex(rng, depth + 1) + _rand_regex(rng, depth + 1)
+    if r < 0.75:
+        return b"(" + _rand_regex(rng, depth + 1) + b"|" + _rand_regex(rng, depth + 1) + b")"
+    op = [b"*", b"+", b"?"][rng.integers(0, 3)]
+    return b"(" + _rand_regex(rng, depth + 1) + b")" + op
+
+
+def test_nfa_matches_like_a_regex_library():
+    rng = np.random.Generator(np.random.PCG64(7))
+    checked = 0
+    for _ in range(300):
+        rx = _rand_regex(rng)
+        py = re.compile(b"(?s)" + rx)
+        for _ in range(40):
+            s = bytes(rng.choice(np.frombuffer(b"abc", dtype=np.uint8), size=int(rng.integers(0, 7))))
+            got = femto_amd.regexp_match(rx, s)
+            assert got is not None, rx
+            assert got == (py.fullmatch(s) is not None), (rx, s)
+            checked += 1
+    assert checked == 12000
+
+
+def test_pattern_syntax_of_query_format_txt():
+    m = femto_amd.regexp_match
+    assert m(rb"black sheep", b"blacksheep") is True          # unescaped whitespace separates terms (QUERY_FORMAT.txt)
+    assert m(rb"black\ sheep", b"black sheep") is True
+    assert m(rb'"a b"c', b"a bc") is True and m(rb"'a\n'", b"a\\n") is True
+    assert m(rb"\x41\n", b"A\n") is True and m(rb"\.", b".") is True and m(rb"\.", b"x") is False
+    assert m(rb"[a-c]+x?", b"abca") is True and m(rb"[]a]", b"]") is True and m(rb"[^\n]", b"\n") is False
+    assert m(rb"a|", b"") is True and m(rb"(ab)*", b"ababab") is True and m(rb"(ab)*", b"aba") is False
+    for bad in (rb"(a", rb"a)", rb"[a", rb"*a", rb"a\x4", b'"a'):
+        assert m(bad, b"a") is None, bad
+
+
+def _brute_force_starts(docs, rx):
+    """offsets (in the prepared text: documents separated by one SEOF each) where some match of rx starts"""
+    py = re.compile(b"(?s)" + rx)
+    out, base = [], 0
+    for d in docs:
+        b = d.tobytes()
+        out.extend(base + i for i in range(len(b) + 1) if py.match(b, i) and py.match(b, i).end() > i)
+        base += len(b) + 1
+    return np.array(sorted(out), dtype=np.int64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,patterns", [
+    ("acgt48k", [rb"ACGTACG", rb"AC(GT|TG)+A", rb"G[AC]T[^A]GG", rb"TTT.TTT", rb"(ACG|TGCA)A?C", rb"GATTACA|TACAGAT"]),
+    ("eng2doc", [rb"the", rb"th[aeiou]+", rb"(and|or)\ [a-z]+", rb"[A-Z][a-z]+ing", rb"e\. ", rb"q.", rb"wor(d|k)s?"]),
+    ("bytes256", [rb"\x00.", rb"[\x80-\xff][\x00-\x10]", rb"\xfe|\xff\xff?"]),
+])
+def test_regexp_search_equals_brute_force(fixtures, name, patterns):
+    import torch
+    assert torch.cuda.is_available()
+    fx = fixtures(name)
+    ix = femto_amd.Index(fx.index, device=0)
+    for rx in patterns:
+        first, last, mlen = ix.regexp_search(rx)
+        # sorted as regexp_result_list_sort does: first ascending, last descending
+        key = list(zip(first.tolist(), (-last).tolist()))
+        assert key == sorted(key), rx
+        assert (last >= first).all() and (mlen >= 1).all()
+        offs = [ix.locate_range(int(f), int(l)) for f, l in zip(first, last)]
+        got = np.unique(np.concatenate(offs)) if offs else np.zeros(0, dtype=np.int64)
+        want = _brute_force_starts(fx.docs, rx)
+        assert np.array_equal(got, want), (name, rx, len(got), len(want))
+        # every result is a distinct matched string: its length and its range size must agree with the text
+        py = re.compile(b"(?s)" + rx)
+        text = b"\x00".join(d.tobytes() for d in fx.docs)     # same offsets as the prepared text (one separator per document)
+        for f, l, m, o in list(zip(first, last, mlen, offs))[:50]:
+            s = text[int(o[0]):int(o[0]) + int(m)]
+            assert py.fullmatch(s) is not None, (rx, s)
+            assert all(text[int(p):int(p) + int(m)] == s for p in o[:20])
+    # a pattern that matches every substring is refused, not run for ever
+    with pytest.raises(femto_amd.FemtoAmdError):
+        ix.regexp_search(rb".*")
+    ix.close()
