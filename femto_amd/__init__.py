@@ -83,6 +83,7 @@ def lib():
         L.femto_amd_comm_init.argtypes = [vp, vp, i32, i32]
         L.femto_amd_comm_gather.argtypes = [vp, vp, vp, i64, i32, vp]
         L.femto_amd_regexp_search.argtypes = [vp, vp, i64, i64, vp, vp, vp, C.POINTER(i64)]
+        L.femto_amd_regexp_search_approx.argtypes = [vp, vp, i64, i32, i32, i32, i32, i64, vp, vp, vp, vp, C.POINTER(i64)]
         L.femto_amd_regexp_match.argtypes = [vp, i64, vp, i64]
         L.femto_amd_set_option.argtypes = [vp, C.c_char_p, i32]
         L.femto_amd_block_requests.argtypes = [vp, i64, vp, vp, vp, vp, vp]
@@ -334,19 +335,24 @@ class Index:
     def comm_gather(self, d_send, d_recv, bytes_per_rank, root=0, stream=0):
         _check(lib().femto_amd_comm_gather(self._h, d_send, d_recv or None, int(bytes_per_rank), int(root), stream or None))
 
-    def regexp_search(self, regex, max_results=1 << 20):
-        """row ranges of every string of the index the byte regular expression matches in full:
-        (first int64[], last int64[], match_len int32[]) sorted by first ascending, last descending"""
+    def regexp_search(self, regex, max_results=1 << 20, approx=None):
+        """row ranges of every string of the index the byte regular expression matches in full -- or, approx=(max_cost,
+        subst, delete, insert), within that weighted edit distance of such a string:
+        (first int64[], last int64[], match_len int32[][, cost int32[]]) sorted by first ascending, last descending"""
         rx = np.frombuffer(bytes(regex) + b"\0", dtype=np.uint8)
+        k = (0, 1, 1, 1) if approx is None else tuple(int(v) for v in approx)
         n = C.c_int64(0)
-        _check(lib().femto_amd_regexp_search(self._h, _ptr(rx), len(regex), 0, None, None, None, C.byref(n)))
+        _check(lib().femto_amd_regexp_search_approx(self._h, _ptr(rx), len(regex), k[0], k[1], k[2], k[3], 0, None, None, None, None, C.byref(n)))
         if n.value > max_results:
             raise FemtoAmdError(3, f"{n.value} results > max_results {max_results}")
-        first = np.zeros(max(1, n.value), dtype=np.int64)
-        last = np.zeros(max(1, n.value), dtype=np.int64)
-        mlen = np.zeros(max(1, n.value), dtype=np.int32)
-        _check(lib().femto_amd_regexp_search(self._h, _ptr(rx), len(regex), max(1, n.value), _ptr(first), _ptr(last), _ptr(mlen), C.byref(n)))
-        return first[:n.value], last[:n.value], mlen[:n.value]
+        m = max(1, n.value)
+        first, last = np.zeros(m, dtype=np.int64), np.zeros(m, dtype=np.int64)
+        mlen, cost = np.zeros(m, dtype=np.int32), np.zeros(m, dtype=np.int32)
+        _check(lib().femto_amd_regexp_search_approx(self._h, _ptr(rx), len(regex), k[0], k[1], k[2], k[3], m, _ptr(first), _ptr(last),
+                                                    _ptr(mlen), _ptr(cost), C.byref(n)))
+        if approx is None:
+            return first[:n.value], last[:n.value], mlen[:n.value]
+        return first[:n.value], last[:n.value], mlen[:n.value], cost[:n.value]
 
     def set_option(self, name, value):
         """'direct' (modes 3/4: caller-order pipeline, default 1) / 'sort' (suffix-order batches of the other paths)"""

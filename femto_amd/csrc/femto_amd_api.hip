@@ -545,7 +545,9 @@ int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const in
   const bool tail = d.txt != nullptr && !inline_tail;
   if (tail && (rc = tail_setup(ix, S, d, npats, stream))) return rc;
   if (d.txt && !tail) {
-    d.tail_min = ix->mode == 3 ? 12 : 10;
+    // inline: SA read + text compare + ISA read = three dependent lines, so it pays from four symbols to go
+    // (measured: P_hit 1.93 -> 1.69 ms, cfg 3 5.22 -> 5.08 ms against the hand-over thresholds 12 / 10)
+    d.tail_min = 4;
     if (const char* tm = getenv("FEMTO_AMD_TAIL_MIN")) d.tail_min = std::max(2, atoi(tm));
   }
   int64_t* bsums = nullptr;
@@ -2634,7 +2636,7 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
     a.out_starts = S.out_starts.as<int64_t>();
     a.bsums = S.bsums.as<int64_t>();
     a.tail_items = nullptr;
-    a.tail_min = ix->mode == 3 ? 12 : 10;
+    a.tail_min = 4;     // the inline threshold of launch_count_direct (the hand-over case takes tail_setup's below)
     if (const char* tm = getenv("FEMTO_AMD_TAIL_MIN")) a.tail_min = std::max(2, atoi(tm));
     if (d.txt && !(d.sa_full && d.isa8 && d.isa_shift == 0)) {
       if ((r2 = tail_setup(ix, S, d, npats, st))) return r2;
@@ -2686,12 +2688,17 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
 // level are stepped by ONE launch of ranges_step_kernel.  A result is a string that reaches the automaton's start state
 // (the whole pattern read, right to left): its row range, sorted as regexp_result_list_sort does (first ascending, last
 // descending, server.c:1528).
-int femto_amd_regexp_search(femto_amd_index_t* ix, const uint8_t* regex, int64_t regex_len, int64_t max_results, int64_t* first_out,
-                            int64_t* last_out, int32_t* len_out, int64_t* n_out) {
+int femto_amd_regexp_search_approx(femto_amd_index_t* ix, const uint8_t* regex, int64_t regex_len, int max_cost, int subst_cost,
+                                   int delete_cost, int insert_cost, int64_t max_results, int64_t* first_out, int64_t* last_out,
+                                   int32_t* len_out, int32_t* cost_out, int64_t* n_out) {
   API_BEGIN
   if (!ix || (regex_len && !regex) || regex_len < 0 || max_results < 0 || !n_out || (max_results && (!first_out || !last_out)))
     return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
-  if (!ix->children.empty()) return femto_amd_regexp_search(ix->children[0], regex, regex_len, max_results, first_out, last_out, len_out, n_out);
+  if (max_cost < 0 || max_cost > 8 || subst_cost < 1 || delete_cost < 1 || insert_cost < 1)
+    return set_err(FEMTO_AMD_ERR_PARAM, "approximate search: 0 <= max_cost <= 8, costs >= 1");
+  if (!ix->children.empty())
+    return femto_amd_regexp_search_approx(ix->children[0], regex, regex_len, max_cost, subst_cost, delete_cost, insert_cost, max_results,
+                                          first_out, last_out, len_out, cost_out, n_out);
   int rc = ensure_device(ix);
   if (rc) return rc;
   if (!ix->host.dir_regular) return set_err(FEMTO_AMD_ERR_INVALID, "regular-expression search needs the derived segment lines");
@@ -2701,27 +2708,27 @@ int femto_amd_regexp_search(femto_amd_index_t* ix, const uint8_t* regex, int64_t
     RegexParser parser(regex, regex_len, &nfa);
     if (!parser.parse(&perr)) return set_err(FEMTO_AMD_ERR_PARAM, "regular expression: " + perr);
   }
+  const ApproxCosts K{max_cost, subst_cost, delete_cost, insert_cost};
   const HostIndex& h = ix->host;
   CharClass in_text;                      // characters of the text that are real bytes (codes <= SEOF never match a class)
   for (int c = FEMTO_AMD_CHARACTER_OFFSET; c < kAlphaSize; c++)
     if (h.C[size_t(c) + 1] > h.C[size_t(c)]) in_text.set(c);
-  struct Item { StateSet s; int64_t first, last; int32_t len; };
-  struct Result { int64_t first, last; int32_t len; };
+  struct Item { CostVec s; int64_t first, last; int32_t len; };
+  struct Result { int64_t first, last; int32_t len, cost; };
   std::vector<Result> results;
   std::vector<Item> frontier, next;
-  const size_t words = size_t(nfa.size() + 63) / 64;
   {
-    Item it{StateSet(words, 0), 0, h.total_length - 1, 0};
-    ss_set(it.s, nfa.accept);
-    closure_rev(nfa, it.s);
-    if (ss_get(it.s, nfa.start)) results.push_back({it.first, it.last, 0});   // the pattern matches the empty string
+    Item it{CostVec(size_t(nfa.size()), kNoCost), 0, h.total_length - 1, 0};
+    it.s[size_t(nfa.accept)] = 0;
+    closure_cost(nfa, K, it.s);
+    if (it.s[size_t(nfa.start)] != kNoCost) results.push_back({it.first, it.last, 0, it.s[size_t(nfa.start)]});   // matches the empty string
     frontier.push_back(std::move(it));
   }
   Lease L(ix);
   if (!L.s) return L.rc;
   Scratch& S = *L.s;
   hipStream_t st = S.stream;
-  const int64_t work_limit = int64_t(1) << 24;     // (range, character) pairs per level and results: beyond it the pattern is too general
+  const int64_t work_limit = int64_t(1) << 24;     // (range, character) pairs per level: beyond it the pattern is too general
   int64_t total_work = 0;
   std::vector<int64_t> wf, wl, nf, nl;
   std::vector<uint16_t> wc;
@@ -2729,7 +2736,7 @@ int femto_amd_regexp_search(femto_amd_index_t* ix, const uint8_t* regex, int64_t
   while (!frontier.empty()) {
     wf.clear(); wl.clear(); wc.clear(); wi.clear();
     for (size_t i = 0; i < frontier.size(); i++) {
-      CharClass cc = incoming_chars(nfa, frontier[i].s);
+      CharClass cc = incoming_chars_cost(nfa, K, frontier[i].s, frontier[i].len == 0, in_text);
       for (int k = 0; k < 5; k++) cc.w[k] &= in_text.w[k];
       for (int c = FEMTO_AMD_CHARACTER_OFFSET; c < kAlphaSize; c++)
         if (cc.get(c)) {
@@ -2763,13 +2770,14 @@ int femto_amd_regexp_search(femto_amd_index_t* ix, const uint8_t* regex, int64_t
     for (int64_t k = 0; k < n; k++) {
       if (nf[size_t(k)] > nl[size_t(k)]) continue;            // the extended string does not occur
       const Item& it = frontier[wi[size_t(k)]];
-      Item ni{step_rev(nfa, it.s, wc[size_t(k)]), nf[size_t(k)], nl[size_t(k)], it.len + 1};
-      if (ss_get(ni.s, nfa.start)) {
-        results.push_back({ni.first, ni.last, ni.len});
+      Item ni{step_cost(nfa, K, it.s, wc[size_t(k)], it.len == 0), nf[size_t(k)], nl[size_t(k)], it.len + 1};
+      if (!any_alive(ni.s)) continue;
+      if (ni.s[size_t(nfa.start)] != kNoCost) {
+        results.push_back({ni.first, ni.last, ni.len, ni.s[size_t(nfa.start)]});
         if (int64_t(results.size()) > max_results && max_results > 0)
           return set_err(FEMTO_AMD_ERR_PARAM, "more results than max_results");
       }
-      if (!incoming_chars(nfa, ni.s).empty()) next.push_back(std::move(ni));
+      next.push_back(std::move(ni));
     }
     frontier.swap(next);
   }
@@ -2784,9 +2792,15 @@ int femto_amd_regexp_search(femto_amd_index_t* ix, const uint8_t* regex, int64_t
     first_out[i] = results[i].first;
     last_out[i] = results[i].last;
     if (len_out) len_out[i] = results[i].len;
+    if (cost_out) cost_out[i] = results[i].cost;
   }
   return FEMTO_AMD_OK;
   API_END
+}
+
+int femto_amd_regexp_search(femto_amd_index_t* ix, const uint8_t* regex, int64_t regex_len, int64_t max_results, int64_t* first_out,
+                            int64_t* last_out, int32_t* len_out, int64_t* n_out) {
+  return femto_amd_regexp_search_approx(ix, regex, regex_len, 0, 1, 1, 1, max_results, first_out, last_out, len_out, nullptr, n_out);
 }
 
 /* test hook: does the automaton built from `regex` accept exactly the byte string s?  1 yes, 0 no, -1 syntax error */

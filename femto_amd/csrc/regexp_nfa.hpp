@@ -282,6 +282,64 @@ inline CharClass incoming_chars(const RegexNfa& n, const StateSet& s) {
         for (int k = 0; k < 5; k++) r.w[k] |= n.cls[size_t(u)].w[k];
   return r;
 }
+// ---- approximate matching (QUERY_FORMAT.txt "APPROXIMATE SEARCH"; the error-counting states of src/main/nfa.c) -------
+// A cost vector holds, per state, the least cost at which the string read so far (right to left) can have brought the
+// reversed automaton there (kNoCost: not at all).  Costs: a substitution, a character missing from the data ("delete":
+// the pattern's character is skipped), an extra character in the data ("insert": read without moving).
+constexpr uint8_t kNoCost = 255;
+struct ApproxCosts { int max_cost = 0, subst = 1, del = 1, ins = 1; };
+using CostVec = std::vector<uint8_t>;
+
+// closure: reversed epsilon edges cost nothing, skipping a class edge costs `del` (relaxed until stable; costs are small)
+inline void closure_cost(const RegexNfa& n, const ApproxCosts& k, CostVec& c) {
+  std::vector<int> stack;
+  for (int i = 0; i < n.size(); i++) if (c[size_t(i)] != kNoCost) stack.push_back(i);
+  while (!stack.empty()) {
+    const int v = stack.back();
+    stack.pop_back();
+    const int cv = c[size_t(v)];
+    for (int u : n.r_eps[size_t(v)])
+      if (cv < c[size_t(u)]) { c[size_t(u)] = uint8_t(cv); stack.push_back(u); }
+    if (k.max_cost > 0 && cv + k.del <= k.max_cost)
+      for (int u : n.r_in[size_t(v)])
+        if (cv + k.del < c[size_t(u)]) { c[size_t(u)] = uint8_t(cv + k.del); stack.push_back(u); }
+  }
+}
+// read alpha code x; `at_end`: this is the pattern's last character -- no substitution and no extra character there
+// (QUERY_FORMAT.txt: "The approximate search will never allow substitutions at the last character")
+inline CostVec step_cost(const RegexNfa& n, const ApproxCosts& k, const CostVec& c, int x, bool at_end) {
+  CostVec r(c.size(), kNoCost);
+  for (int v = 0; v < n.size(); v++) {
+    const int cv = c[size_t(v)];
+    if (cv == kNoCost) continue;
+    for (int u : n.r_in[size_t(v)]) {
+      const int cu = n.cls[size_t(u)].get(x) ? cv : (at_end ? int(kNoCost) : cv + k.subst);
+      if (cu <= k.max_cost && cu < r[size_t(u)]) r[size_t(u)] = uint8_t(cu);
+    }
+    if (!at_end && cv + k.ins <= k.max_cost && cv + k.ins < r[size_t(v)]) r[size_t(v)] = uint8_t(cv + k.ins);
+  }
+  closure_cost(n, k, r);
+  return r;
+}
+inline bool any_alive(const CostVec& c) {
+  for (uint8_t v : c) if (v != kNoCost) return true;
+  return false;
+}
+// characters worth prepending: with errors left every character of the text can be an error; otherwise the class edges
+inline CharClass incoming_chars_cost(const RegexNfa& n, const ApproxCosts& k, const CostVec& c, bool at_end, const CharClass& all) {
+  CharClass r;
+  bool errors_left = false;
+  for (int v = 0; v < n.size(); v++) {
+    const int cv = c[size_t(v)];
+    if (cv == kNoCost) continue;
+    if (!at_end && (cv + k.ins <= k.max_cost || (cv + k.subst <= k.max_cost && !n.r_in[size_t(v)].empty()))) errors_left = true;
+    for (int u : n.r_in[size_t(v)])
+      for (int w = 0; w < 5; w++) r.w[w] |= n.cls[size_t(u)].w[w];
+  }
+  if (errors_left) for (int w = 0; w < 5; w++) r.w[w] |= all.w[w];
+  return r;
+}
+
 // does the automaton accept exactly this byte string?  (tests: the parser and the construction against a regex library)
 inline bool nfa_full_match(const RegexNfa& n, const uint8_t* s, int64_t len) {
   StateSet cur(size_t(n.size() + 63) / 64, 0);

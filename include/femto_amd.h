@@ -200,6 +200,15 @@ int femto_amd_split_info(const femto_amd_index_t* ix, int* part, int* nparts, in
  * image, so this entry point is checked against brute force over the texts, not against reference vectors. */
 int femto_amd_regexp_search(femto_amd_index_t* ix, const uint8_t* regex, int64_t regex_len, int64_t max_results,
                             int64_t* first_out, int64_t* last_out, int32_t* len_out, int64_t* n_out);
+/* Approximate form (QUERY_FORMAT.txt "APPROXIMATE SEARCH": APPROX <max_cost>:<subst_cost>:<delete_cost>:<insert_cost>; the
+ * error-counting states of src/main/nfa.c): every string of the index within weighted edit distance max_cost of a string
+ * the pattern matches -- a substitution costs subst_cost, a character of the pattern missing from the data delete_cost,
+ * an extra character in the data insert_cost; as in the reference, no substitution (and no extra character) at the
+ * pattern's LAST character.  cost_out[i] (may be NULL) = the least cost of result i.  max_cost = 0 is the exact search. */
+int femto_amd_regexp_search_approx(femto_amd_index_t* ix, const uint8_t* regex, int64_t regex_len, int max_cost,
+                                   int subst_cost, int delete_cost, int insert_cost, int64_t max_results,
+                                   int64_t* first_out, int64_t* last_out, int32_t* len_out, int32_t* cost_out,
+                                   int64_t* n_out);
 /* test hook: does the automaton built from `regex` accept exactly the byte string s?  1 yes, 0 no, -1 syntax error */
 int femto_amd_regexp_match(const uint8_t* regex, int64_t regex_len, const uint8_t* s, int64_t len);
 

@@ -98,3 +98,56 @@ def test_regexp_search_equals_brute_force(fixtures, name, patterns):
     with pytest.raises(femto_amd.FemtoAmdError):
         ix.regexp_search(rb".*")
     ix.close()
+
+
+def _edit_distance_prefix_min(pat, txt, k):
+    """min over L of the unit-cost edit distance between pat and txt[:L] (Sellers' column DP), cut at k + 1"""
+    m = len(pat)
+    prev = list(range(m + 1))          # distance of pat[:j] to the empty text prefix
+    best = prev[m]
+    for ch in txt:
+        cur = [prev[0] + 1] + [0] * m
+        for j in range(1, m + 1):
+            cur[j] = min(prev[j - 1] + (pat[j - 1] != ch), prev[j] + 1, cur[j - 1] + 1)
+        prev = cur
+        best = min(best, prev[m])
+        if min(prev) > k:
+            break
+    return best
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 2])
+def test_approximate_search_equals_brute_force(fixtures, k):
+    """APPROX k (unit costs) of literal patterns on the ACGT fixture: the set of offsets where some string within edit
+    distance k of the pattern starts must equal Sellers' dynamic programme over the document; every reported cost is the
+    true distance of its string (bounded below by the DP, above by k)."""
+    import torch
+    assert torch.cuda.is_available()
+    fx = fixtures("acgt48k")
+    ix = femto_amd.Index(fx.index, device=0)
+    doc = fx.docs[0].tobytes()
+    rng = np.random.Generator(np.random.PCG64(11 + k))
+    for trial in range(3):
+        m = int(rng.integers(9, 13))
+        at = int(rng.integers(0, len(doc) - m))
+        pat = bytearray(doc[at:at + m])
+        if trial:                                   # a pattern that is not in the text verbatim
+            pat[int(rng.integers(1, m - 1))] = ord("ACGT"[int(rng.integers(0, 4))])
+        pat = bytes(pat)
+        first, last, mlen, cost = ix.regexp_search(pat, approx=(k, 1, 1, 1))
+        assert (cost >= 0).all() and (cost <= k).all() and (mlen >= m - k).all() and (mlen <= m + k).all()
+        offs = [ix.locate_range(int(f), int(l)) for f, l in zip(first, last)]
+        got = np.unique(np.concatenate(offs)) if offs else np.zeros(0, dtype=np.int64)
+        want = np.array([i for i in range(len(doc)) if _edit_distance_prefix_min(pat, doc[i:i + m + k], k) <= k], dtype=np.int64)
+        assert np.array_equal(got, want), (pat, k, len(got), len(want))
+        for o, ln, c in list(zip(offs, mlen, cost))[:200]:
+            s = doc[int(o[0]):int(o[0]) + int(ln)]
+            prev = list(range(len(pat) + 1))        # full edit distance of s to pat
+            for ch in s:
+                cur = [prev[0] + 1] + [0] * len(pat)
+                for j in range(1, len(pat) + 1):
+                    cur[j] = min(prev[j - 1] + (pat[j - 1] != ch), prev[j] + 1, cur[j - 1] + 1)
+                prev = cur
+            assert prev[len(pat)] <= int(c) <= k, (pat, s, prev[len(pat)], int(c))
+    ix.close()
