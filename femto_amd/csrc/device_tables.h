@@ -164,6 +164,7 @@ struct DevIndex {           // passed by value to kernels
   void* tail_items;         // TailItem work list of the current count launch
   int* tail_count;
   int32_t tail_min;         // hand a one-row range over when at least this many symbols remain
+  int32_t tail_ones;        // ... and, inline tail only, the range has been one row for this many steps
   int64_t total_length;
   int64_t total_buckets;
   int32_t b_size;

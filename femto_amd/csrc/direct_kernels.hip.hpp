@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, 
     const int max_occs, int32_t* __restrict__ noccs, int64_t* __restrict__ block_sums) {
   __shared__ uint16_t s_code[264];
   __shared__ int64_t s_w[4];
+  __shared__ uint32_t s_chunk[16 * 256];     // 64 bytes of pattern per lane (see symbol() below)
   for (int i = threadIdx.x; i < kAlphaSize; i += blockDim.x) s_code[i] = uint16_t(P::code_of(ix, uint32_t(i)));
   __syncthreads();
   const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -134,16 +135,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, 
   if (q < npats) {
     const int len = plen[q];
     const uint16_t* pat = pats + starts[q];
-    uint64_t word = 0;           // aligned 8-byte word of the pattern holding the symbol being read (4 symbols per load);
-    uintptr_t word_addr = 0;     // a word never crosses a page, so the bytes around the pattern inside it are safe to touch
+    // The lane's window on its pattern: the aligned 64-byte chunk holding the symbol being read, kept in LDS (dword w of
+    // lane t at s_chunk[w * 256 + t]: bank = t mod 32, the minimum for 64 lanes).  A chunk never crosses a page, so the
+    // bytes around the pattern inside it are safe to touch.  Reading 8-byte words instead (round 2's first version) touched
+    // every 128-byte line of the pattern 16 times, iterations apart, and with 32 wavefronts per CU doing the same the line
+    // had left the caches in between: 5-6x the compulsory traffic on 100-mers, measured (profiles/README.md).
+    uintptr_t chunk_addr = 1;    // no chunk yet (chunk addresses are multiples of 64)
     auto symbol = [&](int j) -> uint32_t {   // j-th symbol from the end
       const uintptr_t sa = reinterpret_cast<uintptr_t>(pat + (len - 1 - j));
-      const uintptr_t wa = sa & ~uintptr_t(7);
-      if (wa != word_addr) {
-        word = *reinterpret_cast<const uint64_t*>(wa);
-        word_addr = wa;
+      const uintptr_t ca = sa & ~uintptr_t(63);
+      if (ca != chunk_addr) {
+        const uint4* g = reinterpret_cast<const uint4*>(ca);
+        const uint4 c0 = g[0], c1 = g[1], c2 = g[2], c3 = g[3];
+        uint32_t* s = s_chunk + threadIdx.x;
+        s[0 * 256] = c0.x; s[1 * 256] = c0.y; s[2 * 256] = c0.z; s[3 * 256] = c0.w;
+        s[4 * 256] = c1.x; s[5 * 256] = c1.y; s[6 * 256] = c1.z; s[7 * 256] = c1.w;
+        s[8 * 256] = c2.x; s[9 * 256] = c2.y; s[10 * 256] = c2.z; s[11 * 256] = c2.w;
+        s[12 * 256] = c3.x; s[13 * 256] = c3.y; s[14 * 256] = c3.z; s[15 * 256] = c3.w;
+        chunk_addr = ca;
       }
-      return uint32_t(word >> (8 * (sa - wa))) & 0xffffu;
+      const uint32_t off = uint32_t(sa - ca);
+      const uint32_t w = s_chunk[(off >> 2) * 256 + threadIdx.x];
+      return (off & 2u) ? w >> 16 : w & 0xffffu;
     };
     int64_t first = 0, last = ix.total_length - 1;
     int j = 0;
@@ -168,10 +181,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, 
     // others have finished (taking the shortcut inside the stepping loop would serialise it lane by lane: 19 ms instead
     // of 5.7 + 2.8 ms handed over, measured on the sigma~96 workload).
     bool tried = false, finished = false;
+    int ones = 0;      // consecutive steps that left exactly one row
     for (;;) {
       for (; j < len; j++) {
         if (kDense) {
-          if (!tried && first == last && j > 0 && len - j >= ix.tail_min) break;     // tail-ready
+          // tail-ready.  ix.tail_ones: a small alphabet's RANDOM pattern often has one row left after the table and dies
+          // on the next step or two (one line each), which is cheaper than the three dependent lines of the tail; a row
+          // that survived tail_ones steps belongs to a pattern that occurs (measured on 10 M random DNA 20-mers: 0.86 ms
+          // jumping at once, 0.65 ms stepping on).
+          if (!tried && first == last && j > 0 && ones >= ix.tail_ones && len - j >= ix.tail_min) break;
         } else if (ix.txt && first == last && j > 0 && len - j >= ix.tail_min) {
           tail_append(ix, q, j, first);   // one row left, a long tail to go: count_tail_kernel compares it with the text
           handed = true;
@@ -196,6 +214,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, 
         P::search_step(ix, j, code, first, last);
         if (first > last) { finished = true; break; }
         tried = false;
+        ones = first == last ? ones + 1 : 0;
       }
       if (!kDense || finished || j >= len) break;
       // ---- tail-ready: position of the row, compare with the text, row of the last matching position
@@ -203,23 +222,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, 
       const int64_t p = ix.sa_full[first];
       trace_touch(ix, kTraceSa, uint64_t(first) >> 4);
       const int remaining = len - j;
-      if (p >= int64_t(remaining)) {
+      if (p >= int64_t(remaining) && p < ix.total_length) {   // (p = -1: the row could not be located, see text_isa_build_kernel)
         int m = 0;                       // symbols matched
-        uint64_t tw = 0;                 // aligned 8-byte word of txt holding the byte being compared
-        uintptr_t tw_addr = 0;
+        uint4 tw = make_uint4(0, 0, 0, 0);   // aligned 16-byte piece of txt holding the byte being compared
+        uintptr_t tw_addr = 1;
         for (; m < remaining; m++) {
           const uint32_t ch = symbol(j + m);
           if (ch >= uint32_t(kAlphaSize)) break;          // anything unusual is left to the ordinary step
           const uint32_t code = s_code[ch];
           if (code == 0xffffu || P::is_stop(ix, code)) break;
           const uintptr_t ta = reinterpret_cast<uintptr_t>(ix.txt + (p - 1 - m));
-          const uintptr_t wa = ta & ~uintptr_t(7);
+          const uintptr_t wa = ta & ~uintptr_t(15);
           if (wa != tw_addr) {
-            tw = *reinterpret_cast<const uint64_t*>(wa);
+            tw = *reinterpret_cast<const uint4*>(wa);
             tw_addr = wa;
             trace_touch(ix, kTraceTxt, uint64_t(wa - reinterpret_cast<uintptr_t>(ix.txt)) >> 7);
           }
-          if ((uint32_t(tw >> (8 * (ta - wa))) & 0xffu) != code) break;
+          const uint32_t bo = uint32_t(ta - wa);
+          const uint32_t dw = (bo & 8u) ? ((bo & 4u) ? tw.w : tw.z) : ((bo & 4u) ? tw.y : tw.x);
+          if (((dw >> (8u * (bo & 3u))) & 0xffu) != code) break;
         }
         if (m > 0) {
           first = last = ix.isa8[p - m];   // isa_shift == 0: the row of every text position

@@ -147,7 +147,9 @@ struct Scratch {
   DeviceBuffer plen, pats, starts, first, last, noccs, noccs64, out_starts, offsets, scan[3];
   DeviceBuffer rows, ch, occ, off;
   DeviceBuffer keys, keys2, idx, idx2, sorttmp, pairs, tail, bsums;
-  int* d_flags = nullptr;       // [0] error flag, [1] "long ranges" flag of the row expansion, [2] tail item count
+  int* d_flags = nullptr;       // [0] error flag, [1] "long ranges" flag of the row expansion, [2] tail item count, [3] see err
+  int* err = nullptr;           // where kernels raise "symbol >= ALPHA_SIZE": d_flags (host-pointer calls check and clear it) or,
+                                // for enqueue-only calls, d_flags + 3 (nobody reads it: such a pattern just has the empty range)
   int64_t* d_total = nullptr;   // [0] rows to locate, [1] 1 = more rows than the caller's buffer holds
   hipStream_t stream = nullptr; // host-pointer calls launch here (non-blocking stream: calls of different threads overlap)
   hipEvent_t done = nullptr;
@@ -155,12 +157,17 @@ struct Scratch {
   HostPipe pipe;
 
   int init() {
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_flags), 8 * sizeof(int)));
-    HIP_TRY(hipMemset(d_flags, 0, 8 * sizeof(int)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_total), 4 * sizeof(int64_t)));
-    HIP_TRY(hipMemset(d_total, 0, 4 * sizeof(int64_t)));
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_flags), 8 * sizeof(int)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_total), 4 * sizeof(int64_t)));
+    // cleared ON the scratch's stream and waited for: a null-stream hipMemset is not ordered with a non-blocking stream,
+    // and the memory may be a closed handle's flag word that was still set (seen once as a spurious "character code >=
+    // ALPHA_SIZE" on a fresh handle)
+    HIP_TRY(hipMemsetAsync(d_flags, 0, 8 * sizeof(int), stream));
+    HIP_TRY(hipMemsetAsync(d_total, 0, 4 * sizeof(int64_t), stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    err = d_flags;
     return 0;
   }
   void release() {
@@ -336,7 +343,17 @@ struct Lease {
   hipStream_t stream = nullptr;
   int rc = 0;
   explicit Lease(femto_amd_index* i) : ix(i) { s = scratch_acquire(ix, &rc); }
-  ~Lease() { scratch_release(ix, s, async, stream); }
+  ~Lease() {
+    if (s) s->err = s->d_flags;
+    scratch_release(ix, s, async, stream);
+  }
+  // enqueue-only call on the caller's stream: nothing of it is checked on the host, so its kernels raise the error flag
+  // in a word of their own (a later host-pointer call on this scratch must not inherit it)
+  void enqueue_only(hipStream_t st) {
+    async = true;
+    stream = st;
+    s->err = s->d_flags + 3;
+  }
   Lease(const Lease&) = delete;
   Lease& operator=(const Lease&) = delete;
 };
@@ -533,6 +550,18 @@ void launch_tail(femto_amd_index* ix, const DevIndex& d, dim3 grid, hipStream_t 
   }
 }
 
+// Thresholds of the inline text tail (count_direct_kernel<.., kDense = true>): SA read + text compare + ISA read are
+// three dependent lines, so it pays from four symbols to go (measured: cfg 3 5.22 -> 5.08 ms against the hand-over
+// thresholds 12 / 10).  Packed lines (<= 8 characters): only once the row has survived two steps -- a random pattern's
+// last row usually dies on the next step, one line, and 10 M random DNA 20-mers ran 0.86 instead of 0.65 ms when they
+// jumped at once; a pattern that occurs pays two lines more.
+void inline_tail_setup(const femto_amd_index* ix, DevIndex& d) {
+  d.tail_min = 4;
+  d.tail_ones = ix->mode == 3 ? 2 : 0;
+  if (const char* tm = getenv("FEMTO_AMD_TAIL_MIN")) d.tail_min = std::max(2, atoi(tm));
+  if (const char* to = getenv("FEMTO_AMD_TAIL_ONES")) d.tail_ones = std::max(0, atoi(to));
+}
+
 // modes 3/4, caller order, no sort (direct_kernels.hip.hpp)
 int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
                         const int64_t* d_starts, int64_t* d_first, int64_t* d_last, hipStream_t stream, Plan* plan) {
@@ -544,12 +573,7 @@ int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const in
   const bool inline_tail = d.txt && d.sa_full && d.isa8 && d.isa_shift == 0;
   const bool tail = d.txt != nullptr && !inline_tail;
   if (tail && (rc = tail_setup(ix, S, d, npats, stream))) return rc;
-  if (d.txt && !tail) {
-    // inline: SA read + text compare + ISA read = three dependent lines, so it pays from four symbols to go
-    // (measured: P_hit 1.93 -> 1.69 ms, cfg 3 5.22 -> 5.08 ms against the hand-over thresholds 12 / 10)
-    d.tail_min = 4;
-    if (const char* tm = getenv("FEMTO_AMD_TAIL_MIN")) d.tail_min = std::max(2, atoi(tm));
-  }
+  if (d.txt && !tail) inline_tail_setup(ix, d);
   int64_t* bsums = nullptr;
   if (plan) {
     if ((rc = S.bsums.reserve(size_t(nblocks + 1) * 8))) return rc;
@@ -563,10 +587,10 @@ int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const in
   const bool dense = inline_tail;
 #define LAUNCH_COUNT_DIRECT(POLICY)                                                                                                        \
   do {                                                                                                                                     \
-    if (plan && dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, true, true>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.d_flags, mo, noccs, bsums); \
-    else if (plan) hipLaunchKernelGGL((count_direct_kernel<POLICY, true, false>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.d_flags, mo, noccs, bsums);       \
-    else if (dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, false, true>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.d_flags, mo, noccs, bsums);     \
-    else hipLaunchKernelGGL((count_direct_kernel<POLICY, false, false>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.d_flags, mo, noccs, bsums);              \
+    if (plan && dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, true, true>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, bsums); \
+    else if (plan) hipLaunchKernelGGL((count_direct_kernel<POLICY, true, false>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, bsums);       \
+    else if (dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, false, true>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, bsums);     \
+    else hipLaunchKernelGGL((count_direct_kernel<POLICY, false, false>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, bsums);              \
   } while (0)
   if (ix->mode == 3) LAUNCH_COUNT_DIRECT(PackPolicy);
   else if (d.ind) LAUNCH_COUNT_DIRECT(IndPolicy);     // per-character rank lines: one line per range end and step
@@ -576,7 +600,7 @@ int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const in
   if (tail) {   // persistent grid: the number of handed-over patterns is only known on the device
     const TailOut out{nullptr, d_first, d_last, noccs, bsums, mo};
     const dim3 tgrid{uint32_t(std::min<int64_t>(nblocks, int64_t(ix->num_cus) * 8))};
-    launch_tail(ix, d, tgrid, stream, static_cast<const TailItem*>(S.tail.p), d_plen, d_pats, d_starts, nullptr, nullptr, 1, 0, out, S.d_flags);
+    launch_tail(ix, d, tgrid, stream, static_cast<const TailItem*>(S.tail.p), d_plen, d_pats, d_starts, nullptr, nullptr, 1, 0, out, S.err);
     HIP_TRY(hipGetLastError());
   }
   timer_end(ix, ix->t_count, stream, e0, e1);
@@ -611,7 +635,7 @@ int launch_count_chunk(femto_amd_index* ix, Scratch& S, int64_t npats, const int
       if (lblocks > cap) lblocks = cap;
     }
     hipLaunchKernelGGL((count_kernel_flat<1>), dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, d, npats,
-                         d_plen, d_pats, d_starts, d_first, d_last, S.d_flags);
+                         d_plen, d_pats, d_starts, d_first, d_last, S.err);
   } else if (ix->mode == 1 || ix->mode == 3 || ix->mode == 4) {
     const int64_t lblocks = (npats + kBlockThreads - 1) / kBlockThreads;
     const uint32_t* perm = nullptr;
@@ -642,7 +666,7 @@ int launch_count_chunk(femto_amd_index* ix, Scratch& S, int64_t npats, const int
       int rc2 = S.pairs.reserve(size_t(npats) * 16);
       if (rc2) return rc2;
       hipLaunchKernelGGL(count_kernel_pack<true>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, d, npats, d_plen,
-                         d_pats, d_starts, d_first, d_last, S.d_flags, perm, S.keys2.as<uint64_t>(), ix->dense_bits,
+                         d_pats, d_starts, d_first, d_last, S.err, perm, S.keys2.as<uint64_t>(), ix->dense_bits,
                          63 / ix->dense_bits, S.pairs.as<longlong2>());
       split_pairs = true;
       tail_launch = tail;
@@ -650,29 +674,29 @@ int launch_count_chunk(femto_amd_index* ix, Scratch& S, int64_t npats, const int
       int rc2 = S.pairs.reserve(size_t(npats) * 16);
       if (rc2) return rc2;
       hipLaunchKernelGGL(count_kernel_pack2<true>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, d, npats, d_plen,
-                         d_pats, d_starts, d_first, d_last, S.d_flags, perm, S.keys2.as<uint64_t>(), ix->dense_bits,
+                         d_pats, d_starts, d_first, d_last, S.err, perm, S.keys2.as<uint64_t>(), ix->dense_bits,
                          63 / ix->dense_bits, S.pairs.as<longlong2>());
       split_pairs = true;
       tail_launch = tail;
     } else if (ix->mode == 4)
       hipLaunchKernelGGL(count_kernel_pack2<false>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, d, npats, d_plen,
-                         d_pats, d_starts, d_first, d_last, S.d_flags, perm, nullptr, 1, 0, nullptr);
+                         d_pats, d_starts, d_first, d_last, S.err, perm, nullptr, 1, 0, nullptr);
     else if (ix->mode == 3)
       hipLaunchKernelGGL(count_kernel_pack<false>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, d, npats, d_plen,
-                         d_pats, d_starts, d_first, d_last, S.d_flags, perm, nullptr, 1, 0, nullptr);
+                         d_pats, d_starts, d_first, d_last, S.err, perm, nullptr, 1, 0, nullptr);
     else
       hipLaunchKernelGGL(count_kernel_lane, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, d, npats, d_plen,
-                         d_pats, d_starts, d_first, d_last, S.d_flags, perm);
+                         d_pats, d_starts, d_first, d_last, S.err, perm);
   } else {
     timer_begin(ix, ix->t_count, stream, &e0, &e1);
     hipLaunchKernelGGL((count_kernel<kGroupW>), dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, stream, d, npats,
-                       d_plen, d_pats, d_starts, d_first, d_last, S.d_flags);
+                       d_plen, d_pats, d_starts, d_first, d_last, S.err);
   }
   if (tail_launch) {
     const TailOut out{S.pairs.as<longlong2>(), nullptr, nullptr, nullptr, nullptr, 0};
     const dim3 tgrid{uint32_t(std::min<int64_t>((npats + kBlockThreads - 1) / kBlockThreads, int64_t(ix->num_cus) * 8))};
     launch_tail(ix, d, tgrid, stream, static_cast<const TailItem*>(S.tail.p), d_plen, d_pats, d_starts, S.idx2.as<uint32_t>(), S.keys2.as<uint64_t>(),
-                ix->dense_bits, 63 / ix->dense_bits, out, S.d_flags);
+                ix->dense_bits, 63 / ix->dense_bits, out, S.err);
   }
   HIP_TRY(hipGetLastError());
   timer_end(ix, ix->t_count, stream, e0, e1);
@@ -1269,12 +1293,18 @@ int build_text(femto_amd_index* ix) {
   if (const char* e = getenv("FEMTO_AMD_DENSE")) dense = atoi(e) != 0;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+  // Dense arrays -- SA of every row and ISA of every position, 8 B each per row -- when the pair takes at most 55 % of
+  // the free HBM (the level table, built next, takes at most a quarter of what is left): 17 GB of 288 at 1 GiB of text,
+  // 137 GB at 8 GiB (BASELINE configs[4]: a located row is then one read instead of up to four LF steps).  Failing that
+  // the suffix array alone when it fits 30 %; the ISA is then sampled.
   int isa_shift = kIsaShift;
-  if (dense && size_t(n + 2) * 8 <= free_b / 5) {
+  bool want_sa = false;
+  if (dense && double(n + 2) * 16.0 <= 0.55 * double(free_b)) {
     isa_shift = 0;
-    free_b -= size_t(n + 2) * 8;
+    want_sa = true;
+  } else if (dense && double(n) * 8.0 <= 0.30 * double(free_b)) {
+    want_sa = true;
   }
-  const bool want_sa = dense && size_t(n) * 8 <= free_b / 5;
   const size_t tb = size_t(n) + 64, ib = (size_t(n >> isa_shift) + 2) * 8, sb = want_sa ? size_t(n) * 8 + 64 : 0;
   if (big_malloc(ix, reinterpret_cast<void**>(&ix->d_txt), tb) != hipSuccess || big_malloc(ix, reinterpret_cast<void**>(&ix->d_isa8), ib) != hipSuccess ||
       (sb && big_malloc(ix, reinterpret_cast<void**>(&ix->d_sa_full), sb) != hipSuccess)) {
@@ -1466,7 +1496,10 @@ int count_host_pipelined(femto_amd_index* ix, Scratch& S, const HostBatch& hb, i
   if (rc) return rc;
   auto& P = S.pipe;
   hipStream_t s_k = S.stream;
-  int64_t chunk = kPipeChunk;          // patterns per pipeline stage (the buffers are laid out for kPipeChunk)
+  // patterns per pipeline stage (the buffers are laid out for kPipeChunk).  Default 2^20: the first chunk's staging and
+  // the last chunk's return trip are not overlapped with anything, so smaller stages shorten the call until the per-stage
+  // costs take over (10 M 20-mers, 128 staging threads: 2^21 5.5 ms, 2^20 4.0 ms, 2^19 4.6 ms)
+  int64_t chunk = kPipeChunk / 2;
   if (const char* e = getenv("FEMTO_AMD_PIPE_CHUNK_LOG2")) chunk = std::min<int64_t>(kPipeChunk, int64_t(1) << std::max(12, std::min(30, atoi(e))));
   const int64_t nchunks = (hb.npats + chunk - 1) / chunk;
   bool keys_ok = use_direct(ix) && !ix->h_dense.empty();
@@ -2134,8 +2167,7 @@ int femto_amd_count_device(femto_amd_index_t* ix, int64_t npats, const int32_t* 
   if (rc) return rc;
   Lease L(ix);
   if (!L.s) return L.rc;
-  L.async = true;
-  L.stream = static_cast<hipStream_t>(stream);
+  L.enqueue_only(static_cast<hipStream_t>(stream));
   return launch_count(ix, *L.s, npats, d_plen, d_pats, d_starts, d_first, d_last, L.stream);
   API_END
 }
@@ -2239,8 +2271,7 @@ int femto_amd_locate_plan_device(femto_amd_index_t* ix, int64_t npats, const int
   if (rc) return rc;
   Lease L(ix);
   if (!L.s) return L.rc;
-  L.async = true;
-  L.stream = static_cast<hipStream_t>(stream_);
+  L.enqueue_only(static_cast<hipStream_t>(stream_));
   Plan plan{max_occs_each, d_noccs, d_out_starts, INT64_MAX, false};
   if ((rc = launch_count_plan(ix, *L.s, npats, d_plen, d_pats, d_starts, d_first, d_last, &plan, L.stream))) return rc;
   if (plan.done) rc = launch_plan_rows(ix, *L.s, npats, d_noccs, d_first, d_out_starts, nullptr, INT64_MAX, L.stream);
@@ -2256,8 +2287,7 @@ int femto_amd_locate_walk_device(femto_amd_index_t* ix, int64_t npats, const int
   if (rc) return rc;
   Lease L(ix);
   if (!L.s) return L.rc;
-  L.async = true;
-  L.stream = static_cast<hipStream_t>(stream);
+  L.enqueue_only(static_cast<hipStream_t>(stream));
   return launch_locate(ix, *L.s, npats, d_first, d_out_starts, total, d_offsets, L.stream);
   API_END
 }
@@ -2276,8 +2306,7 @@ int femto_amd_locate_device(femto_amd_index_t* ix, int64_t npats, const int32_t*
   if (!L.s) return L.rc;
   Scratch& S = *L.s;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  L.async = true;
-  L.stream = stream;
+  L.enqueue_only(stream);
   Plan plan{max_occs_each, d_noccs, d_out_starts, offsets_capacity, false};
   if ((rc = launch_count_plan(ix, S, npats, d_plen, d_pats, d_starts, d_first, d_last, &plan, stream))) return rc;
   if (plan.done) {   // direct pipeline: one stream-ordered chain, nothing returns to the host
@@ -2636,8 +2665,8 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
     a.out_starts = S.out_starts.as<int64_t>();
     a.bsums = S.bsums.as<int64_t>();
     a.tail_items = nullptr;
-    a.tail_min = 4;     // the inline threshold of launch_count_direct (the hand-over case takes tail_setup's below)
-    if (const char* tm = getenv("FEMTO_AMD_TAIL_MIN")) a.tail_min = std::max(2, atoi(tm));
+    inline_tail_setup(ix, d);     // as launch_count_direct does (the hand-over case takes tail_setup's below)
+    a.tail_min = d.tail_min;
     if (d.txt && !(d.sa_full && d.isa8 && d.isa_shift == 0)) {
       if ((r2 = tail_setup(ix, S, d, npats, st))) return r2;
       a.tail_items = d.tail_items;

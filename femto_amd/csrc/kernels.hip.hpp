@@ -412,6 +412,19 @@ __device__ __forceinline__ uint64_t read_bits_ptr(const uint8_t* p, uint64_t bit
   return v >> (64 - bits);
 }
 
+// Record number of a marked row in its character's mark array: o1 - 1, at most one bucket's worth (the zero slack behind
+// the image covers exactly that; a damaged mark table can report any count).
+__device__ __forceinline__ uint64_t mark_rec(const DevIndex& ix, uint32_t o1) {
+  const uint64_t rec = uint64_t(o1) - 1;
+  return rec < uint64_t(ix.b_size) ? rec : uint64_t(ix.b_size);
+}
+
+// A damaged index can leave the tree walk without a leaf (seq = -1) or at a leaf number its bucket does not have: the
+// result is garbage either way (as in the reference), but the table read stays inside the bucket's sequences.
+__device__ __forceinline__ uint32_t seq_in_bucket(const DevBucket& bk, int seq) {
+  return uint32_t(seq) < bk.n_in_use ? uint32_t(seq) : 0u;
+}
+
 // One row per group: walk LF backwards until a marked row (do_back_query, src/main/server.c:2228-2359,
 // driven as do_context_query does with LOCATE_STRONG, :2627-2795).  offset = mark + steps (server.c:2718).
 template <int W>
@@ -437,10 +450,10 @@ __global__ __launch_bounds__(256) void locate_kernel(const DevIndex ix, const in
     uint32_t cnt;
     wt_rank<W>(ix, bk, idx1, &seq, &cnt);
     if (seq < 0 || uint32_t(seq) >= bk.n_in_use) break;  // corrupt data guard
-    const DevSeq sq = ix.seqs[bk.seq_base + uint32_t(seq)];
+    const DevSeq sq = ix.seqs[bk.seq_base + seq_in_bucket(bk, seq)];
     const RankResult m = bseq_rank<W>(ix.image, sq.mark_table, cnt);  // index.c:2102-2140
     if (m.bit) {
-      const uint64_t rec = uint64_t(m.o1) - 1;
+      const uint64_t rec = mark_rec(ix, m.o1);
       result = int64_t(read_bits(ix.image, sq.mark_array * 8 + rec * uint64_t(ix.text_size_bits), ix.text_size_bits)) + steps;
       break;
     }
@@ -469,10 +482,10 @@ __global__ __launch_bounds__(256) void block_request_kernel(const DevIndex ix, c
   int seq;
   uint32_t cnt;
   wt_rank<W>(ix, bk, idx1, &seq, &cnt);
-  const DevSeq sq = ix.seqs[bk.seq_base + uint32_t(seq)];
+  const DevSeq sq = ix.seqs[bk.seq_base + seq_in_bucket(bk, seq)];
   int64_t off = -1;
   const RankResult m = bseq_rank<W>(ix.image, sq.mark_table, cnt);
-  if (m.bit) off = int64_t(read_bits(ix.image, sq.mark_array * 8 + (uint64_t(m.o1) - 1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
+  if (m.bit) off = int64_t(read_bits(ix.image, sq.mark_array * 8 + mark_rec(ix, m.o1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
   int64_t occ;
   uint32_t ch = sq.ch;
   if (ch_in) {
@@ -781,10 +794,10 @@ __global__ __launch_bounds__(256) void locate_kernel_lane(const DevIndex ix, con
     uint32_t cnt;
     wt_rank_lane(ix, bk.node_base, idx1, &seq, &cnt);
     if (seq < 0 || uint32_t(seq) >= bk.n_in_use) break;
-    const LaneSeq sq = ix.lseqs[bk.seq_base + uint32_t(seq)];
+    const LaneSeq sq = ix.lseqs[bk.seq_base + seq_in_bucket(bk, seq)];
     const RankResult m = bseq_rank_lane(ix, sq.mark_table, cnt);
     if (m.bit) {
-      const uint64_t rec = uint64_t(m.o1) - 1;
+      const uint64_t rec = mark_rec(ix, m.o1);
       result = int64_t(read_bits_ptr(wrap_ptr(ix.image, sq.mark_array), rec * uint64_t(ix.text_size_bits), ix.text_size_bits)) + steps;
       break;
     }
@@ -810,10 +823,10 @@ __global__ __launch_bounds__(256) void block_request_kernel_lane(const DevIndex 
   int seq;
   uint32_t cnt;
   wt_rank_lane(ix, bk.node_base, idx1, &seq, &cnt);
-  const LaneSeq sq = ix.lseqs[bk.seq_base + uint32_t(seq)];
+  const LaneSeq sq = ix.lseqs[bk.seq_base + seq_in_bucket(bk, seq)];
   int64_t off = -1;
   const RankResult m = bseq_rank_lane(ix, sq.mark_table, cnt);
-  if (m.bit) off = int64_t(read_bits_ptr(wrap_ptr(ix.image, sq.mark_array), (uint64_t(m.o1) - 1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
+  if (m.bit) off = int64_t(read_bits_ptr(wrap_ptr(ix.image, sq.mark_array), mark_rec(ix, m.o1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
   int64_t occ;
   uint32_t ch = sq.ch;
   if (ch_in) {
@@ -1061,7 +1074,7 @@ __global__ __launch_bounds__(256) void locate_kernel_flat(const DevIndex ix, con
     } else if (st == LT_MARK) {  // mark table rank at Occ-in-bucket(L[row], row) (index.c:2102-2140)
       const RankResult m = bseq_rank_lane(ix, mbs, idx);
       if (m.bit) {
-        const uint64_t rec = uint64_t(m.o1) - 1;
+        const uint64_t rec = mark_rec(ix, m.o1);
         offsets[item] = int64_t(read_bits_ptr(wrap_ptr(ix.image, marr), rec * uint64_t(ix.text_size_bits), ix.text_size_bits)) + steps;
         item += stride;
         st = LT_ITEM;
@@ -1236,10 +1249,10 @@ __global__ __launch_bounds__(256) void forward_kernel(const DevIndex ix, const i
       }
       new_row = gb * int64_t(ix.b_size) + int64_t(rank) - 1;
       if (seq >= 0 && uint32_t(seq) < bk.n_in_use) {  // BLOCK_REQUEST_LOCATION at the row found
-        const LaneSeq sq = ix.lseqs[bk.seq_base + uint32_t(seq)];
+        const LaneSeq sq = ix.lseqs[bk.seq_base + seq_in_bucket(bk, seq)];
         const RankResult m = bseq_rank_lane(ix, sq.mark_table, count);
         if (m.bit)
-          off = int64_t(read_bits(ix.image, sq.mark_array * 8 + (uint64_t(m.o1) - 1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
+          off = int64_t(read_bits(ix.image, sq.mark_array * 8 + mark_rec(ix, m.o1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
       }
     }
   }

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void p2_extract_kernel(const DevIndex ix, cons
   int seq;
   uint32_t cnt;
   wt_rank_lane(ix, bk.node_base, idx1, &seq, &cnt);
-  const LaneSeq sq = ix.lseqs[bk.seq_base + uint32_t(seq)];
+  const LaneSeq sq = ix.lseqs[bk.seq_base + seq_in_bucket(bk, seq)];
   const RankResult m = bseq_rank_lane(ix, sq.mark_table, cnt);
   sym[row] = uint16_t(ix.p2_code[sq.ch] | (m.bit ? 0x8000u : 0u));
 }
@@ -528,9 +528,9 @@ __global__ __launch_bounds__(256) void p2_sa_kernel(const DevIndex ix, const int
   int seq;
   uint32_t cnt;
   wt_rank_lane(ix, bk.node_base, idx1, &seq, &cnt);
-  const LaneSeq sq = ix.lseqs[bk.seq_base + uint32_t(seq)];
+  const LaneSeq sq = ix.lseqs[bk.seq_base + seq_in_bucket(bk, seq)];
   const RankResult m = bseq_rank_lane(ix, sq.mark_table, cnt);
-  const int64_t off = int64_t(read_bits_ptr(wrap_ptr(ix.image, sq.mark_array), (uint64_t(m.o1) - 1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
+  const int64_t off = int64_t(read_bits_ptr(wrap_ptr(ix.image, sq.mark_array), mark_rec(ix, m.o1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
   const uint32_t* lp = ix.p2_l1 + (uint64_t(row) >> 6) * 32;
   const uint32_t r = uint32_t(row) & 63u;
   const uint64_t pm = (uint64_t(lp[9]) << 32) | lp[8];

@@ -380,10 +380,10 @@ __device__ __forceinline__ int64_t lane_mark_offset(const DevIndex& ix, int64_t 
   int seq;
   uint32_t cnt;
   wt_rank_lane(ix, bk.node_base, idx1, &seq, &cnt);
-  const LaneSeq sq = ix.lseqs[bk.seq_base + uint32_t(seq)];
+  const LaneSeq sq = ix.lseqs[bk.seq_base + seq_in_bucket(bk, seq)];
   const RankResult m = bseq_rank_lane(ix, sq.mark_table, cnt);
   if (!m.bit) return -1;
-  return int64_t(read_bits_ptr(wrap_ptr(ix.image, sq.mark_array), (uint64_t(m.o1) - 1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
+  return int64_t(read_bits_ptr(wrap_ptr(ix.image, sq.mark_array), mark_rec(ix, m.o1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
 }
 
 // leaf requests (block_request CHAR|OCCS|LOCATION, src/main/index.c:1973-2144) from the packed lines
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void pack_extract_kernel(const DevIndex ix, co
   int seq;
   uint32_t cnt;
   wt_rank_lane(ix, bk.node_base, idx1, &seq, &cnt);
-  const LaneSeq sq = ix.lseqs[bk.seq_base + uint32_t(seq)];
+  const LaneSeq sq = ix.lseqs[bk.seq_base + seq_in_bucket(bk, seq)];
   const RankResult m = bseq_rank_lane(ix, sq.mark_table, cnt);
   sym[row] = uint8_t(ix.pack_code[sq.ch] | (m.bit ? 0x80u : 0u));
 }
@@ -519,9 +519,9 @@ __global__ __launch_bounds__(256) void pack_sa_kernel(const DevIndex ix, const i
   int seq;
   uint32_t cnt;
   wt_rank_lane(ix, bk.node_base, idx1, &seq, &cnt);
-  const LaneSeq sq = ix.lseqs[bk.seq_base + uint32_t(seq)];
+  const LaneSeq sq = ix.lseqs[bk.seq_base + seq_in_bucket(bk, seq)];
   const RankResult m = bseq_rank_lane(ix, sq.mark_table, cnt);
-  const int64_t off = int64_t(read_bits_ptr(wrap_ptr(ix.image, sq.mark_array), (uint64_t(m.o1) - 1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
+  const int64_t off = int64_t(read_bits_ptr(wrap_ptr(ix.image, sq.mark_array), mark_rec(ix, m.o1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
   uint64_t line;
   uint32_t r;
   pack_split(row, &line, &r);
@@ -572,9 +572,9 @@ __global__ __launch_bounds__(256) void pack_densify_kernel(const DevIndex ix, ui
     int seq;
     uint32_t cnt;
     wt_rank_lane(ix, bk.node_base, idx1, &seq, &cnt);
-    const LaneSeq sq = ix.lseqs[bk.seq_base + uint32_t(seq)];
+    const LaneSeq sq = ix.lseqs[bk.seq_base + seq_in_bucket(bk, seq)];
     const RankResult m = bseq_rank_lane(ix, sq.mark_table, cnt);
-    off = int64_t(read_bits_ptr(wrap_ptr(ix.image, sq.mark_array), (uint64_t(m.o1) - 1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
+    off = int64_t(read_bits_ptr(wrap_ptr(ix.image, sq.mark_array), mark_rec(ix, m.o1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
     sa[pack_mark_rank(pack, row)] = off;
   }
   int64_t r = row;

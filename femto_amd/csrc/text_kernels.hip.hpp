@@ -113,8 +113,10 @@ __global__ __launch_bounds__(256) void text_isa_build_kernel(const DevIndex ix, 
   if (row >= row0 + n) return;
   int64_t pos;
   uint32_t code = 0;
-  if (!tail_locate<P>(ix, row, &pos, &code)) {
-    if (kSa) sa_full[row] = -1;    // what the walk reports for such a row (inconsistent index)
+  if (!tail_locate<P>(ix, row, &pos, &code) || pos < 0 || pos >= ix.total_length) {
+    // an inconsistent index (an LF cycle without marks, a damaged mark array holding an offset outside the text): the row
+    // reports -1 as the walk does, and nothing is written outside the arrays
+    if (kSa) sa_full[row] = -1;
     return;
   }
   txt[pos == 0 ? ix.total_length - 1 : pos - 1] = uint8_t(code);
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void count_tail_kernel(const DevIndex ix, cons
 
   // ---- the shortcut: position of the row, compare against the text, row of the last matching position
   int64_t p;
-  if (tail_locate<P, kSaFull>(ix, first, &p, nullptr) && p >= int64_t(len - j)) {
+  if (tail_locate<P, kSaFull>(ix, first, &p, nullptr) && p >= int64_t(len - j) && p < ix.total_length) {
     const int remaining = len - j;
     int m = 0;                       // symbols matched
     uint64_t tw = 0;                 // aligned 8-byte word of txt holding the byte being compared

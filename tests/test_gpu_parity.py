@@ -367,6 +367,24 @@ def test_invalid_pattern_character_is_param_error(fixtures, gpu_ok):
     # the handle stays usable
     f, l = ix.count([np.array([70], dtype=np.uint16)])
     assert l[0] >= f[0]
+    # enqueue-only calls report nothing to the host: the bad pattern has the empty range there, and a host-pointer call
+    # that follows on the same scratch does not inherit the flag its kernels raised
+    import torch
+    for mode in MODES:
+        if mode == 4:
+            continue
+        ix.set_rank_mode(mode)
+        plen = torch.tensor([2, 1], dtype=torch.int32, device="cuda:0")
+        flat = torch.tensor([70, 300, 70], dtype=torch.int16, device="cuda:0")
+        starts = torch.tensor([0, 2], dtype=torch.int64, device="cuda:0")
+        res = torch.full((2, 2), 7, dtype=torch.int64, device="cuda:0")
+        ix.count_device(2, plen.data_ptr(), flat.data_ptr(), starts.data_ptr(), res[0].data_ptr(), res[1].data_ptr(),
+                        torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        r = res.cpu().numpy()
+        assert r[0][0] > r[1][0] and (r[0][1], r[1][1]) == (f[0], l[0]), (mode, r)
+        f2, l2 = ix.count([np.array([70], dtype=np.uint16)])
+        assert (f2[0], l2[0]) == (f[0], l[0]), mode
 
 
 def test_max_occs_zero_mirrors_reference(fixtures, gpu_ok):

@@ -1,4 +1,4 @@
-"""Damaged-index fuzz on the GPU box: python tools/fuzz_gpu.py [seed] [trials]
+"""Damaged-index fuzz on the GPU box: python tools/fuzz_gpu.py [seed] [trials] [only_trial]
 Mutates block files of the committed fixtures (random bytes, extreme header words, truncation) and, when the loader
 still accepts the index, runs count / locate / leaf requests in a child process under a time limit.  Expected: an
 error code or (garbage) results -- never a hang, and no GPU fault."""
@@ -17,13 +17,15 @@ except femto_amd.FemtoAmdError as e:
 n = ix.info.total_length
 rng = np.random.Generator(np.random.PCG64(1))
 pats = [rng.integers(5, 261, int(rng.integers(0, 12))).astype(np.uint16) for _ in range(300)]
+def stage(*a):
+    print("stage", *a, file=sys.stderr, flush=True)
 try:
     for mode in (ix.rank_mode, 1, 0):
         ix.set_rank_mode(mode)
-        ix.count(pats)
-        ix.locate(pats, 5)
-        ix.block_requests(rng.integers(0, max(1, n), 500).astype(np.int64))
-        ix.locate([np.zeros(0, dtype=np.uint16)], min(n, 20000))
+        stage(mode, "count"); ix.count(pats)
+        stage(mode, "locate"); ix.locate(pats, 5)
+        stage(mode, "block_requests"); ix.block_requests(rng.integers(0, max(1, n), 500).astype(np.int64))
+        stage(mode, "locate_all"); ix.locate([np.zeros(0, dtype=np.uint16)], min(n, 20000))
     print("RAN")
 except femto_amd.FemtoAmdError as e:
     print("ERR_RUN", e.code)
@@ -32,6 +34,8 @@ def main():
     from conftest import Fixture
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     trials = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+    only = int(sys.argv[3]) if len(sys.argv) > 3 else -1      # reproduce one trial (the mutations depend on the seed alone)
+    keep = os.environ.get("FUZZ_KEEP")                          # directory that receives the mutated index of a bad trial
     names = ["acgt48k", "eng2doc", "runs3doc", "chunks2doc", "b1000", "bytes256", "counter400_small"]
     root = tempfile.mkdtemp()
     open(root + "/child.py", "w").write(CHILD)
@@ -58,6 +62,12 @@ def main():
             pos = int(rng.integers(0, max(1, len(data) - 4))) & ~3
             data[pos:pos + 4] = int(rng.integers(0, 2**32)).to_bytes(4, "big")
         open(os.path.join(dst, f), "wb").write(data)
+        if only >= 0 and t != only:
+            continue
+        if only >= 0 and keep and not os.environ.get("FUZZ_RUN"):
+            shutil.copytree(dst, os.path.join(keep, f"fuzz_s{seed}_t{t}"), dirs_exist_ok=True)
+            print("kept", name, f, "kind", kind)
+            continue
         try:
             r = subprocess.run([sys.executable, root + "/child.py", dst, ROOT], capture_output=True, text=True, timeout=60)
             out = r.stdout.strip().split()[0] if r.stdout.strip() else f"DIED_rc{r.returncode}"
@@ -66,7 +76,10 @@ def main():
         stats[out] = stats.get(out, 0) + 1
         if out.startswith("DIED") or out == "TIMEOUT":
             bad += 1
-            print("BAD", out, name, f, "kind", kind, (r.stderr[-300:].replace("\n", " | ") if out != "TIMEOUT" else ""), flush=True)
+            stages = [l for l in (r.stderr.splitlines() if out != "TIMEOUT" else []) if l.startswith("stage")]
+            print("BAD trial", t, out, name, f, "kind", kind, "last", stages[-1:] , (r.stderr[-300:].replace("\n", " | ") if out != "TIMEOUT" else ""), flush=True)
+            if keep:
+                shutil.copytree(dst, os.path.join(keep, f"fuzz_s{seed}_t{t}"), dirs_exist_ok=True)
     print("stats", stats, "bad", bad)
 if __name__ == "__main__":
     main()
