@@ -257,7 +257,8 @@ class Index:
         a, b, ms, k = C.c_int(0), C.c_int64(0), C.c_double(0), C.c_int(0)
         _check(lib().femto_amd_pack_info(self._h, C.byref(a), C.byref(b), C.byref(ms), C.byref(k)))
         return {"available": bool(a.value & 1), "available2": bool(a.value & 2), "level_table": bool(a.value & 4),
-                "sa_full": bool(a.value & 8), "isa_full": bool(a.value & 16), "char_rank_lines": bool(a.value & 32),
+                "sa_full": bool(a.value & 8), "isa_full": bool(a.value & 16), "char_rank_lines": bool(a.value & 32), "context_table": bool(a.value & 64),
+                "context_syms": (a.value >> 8) & 15,
                 "bytes": b.value, "build_ms": ms.value, "ktab_syms": k.value}
 
     def document_info(self, doc):
@@ -312,7 +313,7 @@ class Index:
                                              d_out_starts, d_offsets, capacity, d_total, stream or None))
 
     TRACE_REGIONS = ("pack_lines", "level_table", "suffix_array", "level1_lines", "level2_lines", "text", "isa", "ktab_r1", "char_rank_lines",
-                     "unused")
+                     "context_table")
 
     def trace_lines(self, npats, d_plen, d_pats, d_starts, max_occs):
         """distinct 128-byte lines per derived array loaded by the count phase and by the locate phase of this batch"""

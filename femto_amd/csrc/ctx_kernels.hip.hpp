@@ -1,0 +1,138 @@
+// ctx_kernels.hip.hpp -- the CONTEXT TABLE of byte alphabets (mode 4): the first H backward-search steps as ONE hashed read.
+//
+// The level table (direct_kernels.hip.hpp) is a full t-ary heap, so with t ~ 96 table characters it stops at K = 4
+// symbols (96^5 entries would not fit); an English-like 1 GiB text then needs ~8 more steps of two rank lines each before
+// a sampled pattern's range is down to one row.  But only the strings that OCCUR matter: the rows whose suffixes share
+// their first H characters are contiguous in suffix order, so one pass over the resident suffix array + text (both dense
+// arrays of build_text) finds every distinct H-gram of the text with its row range, and a pattern's last H symbols are
+// then looked up in an open-addressing hash table instead of being stepped:
+//
+//   key   = H fields of `bits` bits, first character in the top field: 1 + the character's rank among the table characters
+//           (bits = ceil(log2(t + 1)), H <= min(12, 64 / bits): 9 symbols for t ~ 96; no character <= SEOF: such windows
+//           are not keys)
+//   value = first row (40 bits) | rows (24 bits; 0xffffff = "too many": the pattern takes the level table instead)
+//   slot  = 16 bytes {key, value}, key 0 = empty (every field of a key is >= 1);
+//           slots = power of two >= 2 x distinct H-grams; linear probing.
+//
+// The table is COMPLETE for windows without stop characters, so a miss means the range is empty -- exactly what
+// do_string_query (src/main/server.c:832-936) finds after those H steps.  H is the largest of 12, 11, ... whose table fits
+// the budget (a quarter of the free HBM at most); FEMTO_AMD_CTX=0 disables, FEMTO_AMD_CTX_SYMS=h forces.
+#pragma once
+
+namespace femto_amd {
+
+constexpr uint64_t kCtxBig = 0xffffffu;
+constexpr uint64_t kCtxFirstMask = (uint64_t(1) << 40) - 1;
+
+__device__ __forceinline__ uint64_t ctx_hash(uint64_t key, int log2_slots) {
+  return (key * 0x9E3779B97F4A7C15ull) >> (64 - log2_slots);
+}
+
+// H-gram starting at text position p as a key (0: not a key -- it runs past the text or holds a stop character)
+__device__ __forceinline__ uint64_t ctx_gram(const DevIndex& ix, int64_t p, int H, uint32_t nstop) {
+  if (p < 0 || p + H > ix.total_length) return 0;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(ix.txt + p);
+  const uintptr_t al = a & ~uintptr_t(7);
+  const uint64_t w0 = *reinterpret_cast<const uint64_t*>(al);            // txt has 64 bytes of slack behind it
+  const uint64_t w1 = *reinterpret_cast<const uint64_t*>(al + 8);
+  const uint64_t w2 = H > 9 ? *reinterpret_cast<const uint64_t*>(al + 16) : 0;
+  const uint32_t sh = uint32_t(a - al) * 8u;
+  const uint64_t lo = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;         // bytes p .. p+7, p in the low byte
+  const uint64_t hi = sh ? (w1 >> sh) | (w2 << (64u - sh)) : w1;         // bytes p+8 .. p+15
+  const int bits = ix.ctx_bits;
+  uint64_t key = 0;
+  for (int i = 0; i < H; i++) {
+    const uint32_t c = uint32_t((i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8))) & 0xffu);
+    if (c < nstop) return 0;
+    key = (key << bits) | uint64_t(c - nstop + 1u);
+  }
+  return key;
+}
+
+__device__ __forceinline__ uint64_t ctx_gram_of_row(const DevIndex& ix, int64_t row, int H, uint32_t nstop) {
+  if (row < 0 || row >= ix.total_length) return 0;
+  return ctx_gram(ix, ix.sa_full[row], H, nstop);
+}
+
+// number of rows that start a group of equal keys (= distinct H-grams), added to *count
+__global__ __launch_bounds__(256) void ctx_count_kernel(const DevIndex ix, const int64_t row0, const int64_t n, const int H, const uint32_t nstop,
+                                                        unsigned long long* __restrict__ count) {
+  const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool in = row < row0 + n;
+  const uint64_t g = in ? ctx_gram_of_row(ix, row, H, nstop) : 0;
+  uint32_t plo = uint32_t(__shfl_up(int(uint32_t(g)), 1, 64)), phi = uint32_t(__shfl_up(int(uint32_t(g >> 32)), 1, 64));
+  uint64_t prev = (uint64_t(phi) << 32) | plo;
+  if ((threadIdx.x & 63u) == 0) prev = in ? ctx_gram_of_row(ix, row - 1, H, nstop) : 0;
+  const bool start = in && g != 0 && g != prev;
+  const unsigned long long b = __ballot(start);
+  if ((threadIdx.x & 63u) == 0 && b) atomicAdd(count, static_cast<unsigned long long>(__popcll(b)));
+}
+
+// every group start claims a slot and stores its first row
+__global__ __launch_bounds__(256) void ctx_insert_kernel(const DevIndex ix, const int64_t row0, const int64_t n, const int H, const uint32_t nstop,
+                                                         unsigned long long* __restrict__ slots, const int log2_slots) {
+  const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool in = row < row0 + n;
+  const uint64_t g = in ? ctx_gram_of_row(ix, row, H, nstop) : 0;
+  uint32_t plo = uint32_t(__shfl_up(int(uint32_t(g)), 1, 64)), phi = uint32_t(__shfl_up(int(uint32_t(g >> 32)), 1, 64));
+  uint64_t prev = (uint64_t(phi) << 32) | plo;
+  if ((threadIdx.x & 63u) == 0) prev = in ? ctx_gram_of_row(ix, row - 1, H, nstop) : 0;
+  if (!in || g == 0 || g == prev) return;
+  const uint64_t mask = (uint64_t(1) << log2_slots) - 1;
+  uint64_t s = ctx_hash(g, log2_slots);
+  for (uint64_t probes = 0; probes <= mask; probes++, s = (s + 1) & mask) {
+    const unsigned long long old = atomicCAS(slots + 2 * s, 0ull, static_cast<unsigned long long>(g));
+    if (old == 0ull) {
+      slots[2 * s + 1] = uint64_t(row) & kCtxFirstMask;      // rows are added by ctx_ends_kernel
+      return;
+    }
+    // (old == g cannot happen for a well-formed index: equal keys are contiguous; on a damaged one the later group is lost)
+    if (old == g) return;
+  }
+}
+
+// every group end finds its slot and completes the value
+__global__ __launch_bounds__(256) void ctx_ends_kernel(const DevIndex ix, const int64_t row0, const int64_t n, const int H, const uint32_t nstop,
+                                                       unsigned long long* __restrict__ slots, const int log2_slots) {
+  const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool in = row < row0 + n;
+  const uint64_t g = in ? ctx_gram_of_row(ix, row, H, nstop) : 0;
+  uint32_t nlo = uint32_t(__shfl_down(int(uint32_t(g)), 1, 64)), nhi = uint32_t(__shfl_down(int(uint32_t(g >> 32)), 1, 64));
+  uint64_t next = (uint64_t(nhi) << 32) | nlo;
+  if ((threadIdx.x & 63u) == 63u || row + 1 >= row0 + n) next = in ? ctx_gram_of_row(ix, row + 1, H, nstop) : 0;
+  if (!in || g == 0 || g == next) return;
+  const uint64_t mask = (uint64_t(1) << log2_slots) - 1;
+  uint64_t s = ctx_hash(g, log2_slots);
+  for (uint64_t probes = 0; probes <= mask; probes++, s = (s + 1) & mask) {
+    const uint64_t k = slots[2 * s];
+    if (k == g) {
+      const uint64_t first = slots[2 * s + 1] & kCtxFirstMask;
+      const uint64_t rows = uint64_t(row) >= first ? uint64_t(row) - first + 1 : 0;   // (0 only on a damaged index)
+      slots[2 * s + 1] = first | ((rows < kCtxBig ? rows : kCtxBig) << 40);
+      return;
+    }
+    if (k == 0) return;
+  }
+}
+
+// 1: found (first, last set); 0: the H-gram does not occur (range empty); -1: too many rows for the value field
+__device__ __forceinline__ int ctx_lookup(const DevIndex& ix, uint64_t key, int64_t& first, int64_t& last) {
+  const int lg = ix.ctx_log2;
+  const uint64_t mask = (uint64_t(1) << lg) - 1;
+  uint64_t s = ctx_hash(key, lg);
+  for (uint64_t probes = 0; probes <= mask; probes++, s = (s + 1) & mask) {
+    const ulonglong2 e = reinterpret_cast<const ulonglong2*>(ix.ctx)[s];
+    trace_touch(ix, kTraceCtx, s >> 3);
+    if (e.x == key) {
+      const uint64_t rows = e.y >> 40;
+      if (rows == kCtxBig) return -1;
+      first = int64_t(e.y & kCtxFirstMask);
+      last = first + int64_t(rows) - 1;
+      return 1;
+    }
+    if (e.x == 0) return 0;
+  }
+  return 0;
+}
+
+}  // namespace femto_amd

@@ -108,7 +108,7 @@ struct DevBucket {          // 16 bytes
 // regions of the compulsory-traffic trace (femto_amd_trace_lines): every 128-byte line a query kernel loads from one
 // of these arrays sets one bit; the number of set bits x 128 B is what the launch MUST move from HBM at least once
 enum { kTracePack = 0, kTraceKtab = 1, kTraceSa = 2, kTraceL1 = 3, kTraceL2 = 4, kTraceTxt = 5, kTraceIsa = 6, kTraceKtab1 = 7, kTraceInd = 8,
-       kTraceRegions = 10 };
+       kTraceCtx = 9, kTraceRegions = 10 };
 
 struct DevIndex {           // passed by value to kernels
   const uint8_t* image;
@@ -158,6 +158,11 @@ struct DevIndex {           // passed by value to kernels
   const int64_t* isa8;      // row of the suffix at every (1 << isa_shift)-th text position
   const uint32_t* ind;      // per-character rank lines for byte alphabets (ind_kernels.hip.hpp), or NULL
   int64_t ind_stride;       // lines per character
+  const uint64_t* ctx;      // context table (ctx_kernels.hip.hpp): {key, value} slots, or NULL
+  int32_t ctx_log2;         // log2(slots)
+  int32_t ctx_syms;         // H: symbols per key
+  int32_t ctx_nstop;        // dense codes below this are characters <= SEOF
+  int32_t ctx_bits;         // bits per key field
   const int64_t* sa_full;   // SA[row] of EVERY row when HBM allows (8 B/row), else NULL: locate is then one read, no walk
   int32_t isa_shift;        // 0: full inverse suffix array (8 B/row), 3: every 8th position
   int32_t dense_pad;

@@ -23,9 +23,9 @@
 // occupies [ (t^m-1)/(t-1), (t^(m+1)-1)/(t-1) ) -- holds exactly the values do_string_query's loop
 // (src/main/server.c:832-936) holds after searching s, including an early death:  x = first,  y = (last + 1) | m << 48.
 // A pattern shorter than K, or one that meets a character outside the table, leaves the table at its level and
-// continues symbol by symbol.  K: the deepest level has at most one entry per row (t^K <= rows; K = 15 for a 2^30-row DNA
-// index) and the table at most a quarter of the free HBM; the deepest level is stored in 8 bytes per entry (see
-// ktab2_deep_kernel): 5.7 + 8.6 GB there.  FEMTO_AMD_KTAB_SYMS / FEMTO_AMD_KTAB_MB override.
+// continues symbol by symbol.  K: the deepest level has at most four entries per row (t^K <= 4 rows; K = 16 for a 2^30-row
+// DNA index) and the table at most a quarter of the free HBM; the deepest level is stored in 8 bytes per entry (see
+// ktab2_deep_kernel): 22.9 + 34.4 GB there.  FEMTO_AMD_KTAB_SYMS / FEMTO_AMD_KTAB_MB override.
 #pragma once
 
 namespace femto_amd {
@@ -160,7 +160,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, 
     };
     int64_t first = 0, last = ix.total_length - 1;
     int j = 0;
-    if (ix.ktab2) {
+    if (ix.ctx && len >= ix.ctx_syms) {     // byte alphabets: the last H symbols as one hashed read (ctx_kernels.hip.hpp)
+      const int H = ix.ctx_syms;
+      const uint32_t nstop = uint32_t(ix.ctx_nstop);
+      uint64_t key = 0;
+      bool ok = true;
+      for (int i = 0; i < H; i++) {
+        const uint32_t ch = symbol(i);
+        const uint32_t code = ch < uint32_t(kAlphaSize) ? uint32_t(s_code[ch]) : 0xffffu;
+        if (code == 0xffffu || code < nstop) { ok = false; break; }
+        key |= uint64_t(code - nstop + 1u) << (ix.ctx_bits * i);
+      }
+      // a miss means the range dies within these H steps; the level table / the steps below then find where, because the
+      // reference's (first, last) of an empty range are those of the step that emptied it
+      if (ok && ctx_lookup(ix, key, first, last) == 1) j = H;
+    }
+    if (j == 0 && ix.ktab2) {
       const int kmax = len < ix.kt2_syms ? len : ix.kt2_syms;
       const uint32_t nstop = uint32_t(ix.kt2_nstop);
       const int64_t t = ix.kt2_base;
@@ -319,31 +334,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, 
   }
 }
 
-// exclusive scan of n block sums in place (one 1024-thread workgroup); total -> total_out[0]; total_out[1] = 1 when the
-// total exceeds `capacity` rows (the rows beyond it are not located).  Every thread keeps a contiguous chunk of up to 16
-// sums in registers (all loads in flight at once: this kernel sits on the step's critical path), the 1024 chunk totals
-// are scanned with wavefront shuffles; batches of more than 2^14 blocks take further passes.
+// Two-level scan of the n block sums (one 1024-thread workgroup; this kernel sits on the step's critical path).
+//   phase 1  super[s] = sum of sums[64 s .. 64 s + 64): one coalesced 512-byte read per wavefront and super block,
+//            eight super blocks in flight per wavefront;
+//   phase 2  exclusive scan of the super sums in place (611 for 10 M patterns: one pass, one element per thread).
+// The block sums themselves stay as they are: plan_rows_kernel adds the sums of the blocks before it inside its super
+// block (one more 512-byte read).  super[] lives behind sums[] (plan_super()).  total -> total_out[0]; total_out[1] = 1
+// when the total exceeds `capacity` rows (the rows beyond it are not located); *big_flag is cleared for plan_rows_kernel.
+// (Round 2's first version scanned all n sums in place, a thread per 16 consecutive sums: 42 us for 39 k sums.)
+__device__ __forceinline__ int64_t* plan_super(int64_t* sums, int64_t n) { return sums + ((n + 63) & ~int64_t(63)); }
+__device__ __forceinline__ const int64_t* plan_super(const int64_t* sums, int64_t n) { return sums + ((n + 63) & ~int64_t(63)); }
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t lo = uint32_t(__shfl_down(int(uint32_t(v)), d, 64)), hi = uint32_t(__shfl_down(int(uint32_t(v >> 32)), d, 64));
+    v += (uint64_t(hi) << 32) | lo;
+  }
+  return v;   // valid in lane 0
+}
+
 __global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t n, int64_t* __restrict__ sums, int64_t* __restrict__ total_out,
-                                                         const int64_t capacity, int64_t* __restrict__ out_starts_end) {
-  constexpr int kPer = 16;
+                                                         const int64_t capacity, int64_t* __restrict__ out_starts_end, int* __restrict__ big_flag) {
   __shared__ int64_t s_wave[16];
   __shared__ int64_t s_carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) s_carry = 0;
-  __syncthreads();
-  for (int64_t base = 0; base < n; base += int64_t(1024) * kPer) {
-    const int64_t left = n - base < int64_t(1024) * kPer ? n - base : int64_t(1024) * kPer;
-    const int per = int((left + 1023) / 1024);
-    const int64_t a = base + int64_t(tid) * per;
-    int64_t v[kPer];
-    int64_t sum = 0;
+  int64_t* super = plan_super(sums, n);
+  const int64_t ns = (n + 63) >> 6;
+  if (tid == 0) {
+    s_carry = 0;
+    if (big_flag) *big_flag = 0;
+  }
+  constexpr int kFly = 8;
+  for (int64_t s0 = int64_t(wave) * kFly; s0 < ns; s0 += 16 * kFly) {
+    uint64_t v[kFly];
 #pragma unroll
-    for (int k = 0; k < kPer; k++) {
-      v[k] = (k < per && a + k < base + left) ? sums[a + k] : 0;
-      sum += v[k];
+    for (int k = 0; k < kFly; k++) {
+      const int64_t i = (s0 + k) * 64 + lane;
+      v[k] = (s0 + k < ns && i < n) ? uint64_t(sums[i]) : 0;
     }
-    // inclusive scan of the per-thread totals: within the wavefront, then across the 16 wavefronts
-    uint64_t x = uint64_t(sum);
+#pragma unroll
+    for (int k = 0; k < kFly; k++) {
+      const uint64_t t = wave_sum_u64(v[k]);
+      if (lane == 0 && s0 + k < ns) super[s0 + k] = int64_t(t);
+    }
+  }
+  __syncthreads();
+  for (int64_t base = 0; base < ns; base += 1024) {
+    const int64_t i = base + tid;
+    const int64_t v = i < ns ? super[i] : 0;
+    uint64_t x = uint64_t(v);      // inclusive scan within the wavefront, then across the 16 wavefronts
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const uint32_t lo = uint32_t(__shfl_up(int(uint32_t(x)), d, 64)), hi = uint32_t(__shfl_up(int(uint32_t(x >> 32)), d, 64));
@@ -353,14 +393,9 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t n, int64_
     __syncthreads();
     int64_t woff = s_carry;
     for (int k = 0; k < wave; k++) woff += s_wave[k];
-    int64_t run = woff + int64_t(x) - sum;
-#pragma unroll
-    for (int k = 0; k < kPer; k++) {
-      if (k < per && a + k < base + left) sums[a + k] = run;
-      run += v[k];
-    }
+    if (i < ns) super[i] = woff + int64_t(x) - v;
     __syncthreads();
-    if (tid == 1023) s_carry = run;    // the last thread's running value = everything so far
+    if (tid == 1023) s_carry = woff + int64_t(x);    // the last thread's inclusive value = everything so far
     __syncthreads();
   }
   if (tid == 0) {
@@ -395,15 +430,21 @@ __global__ void copy_total_kernel(const int64_t* __restrict__ src, int64_t* __re
 // reads) and no walk follows.
 template <bool kSa>
 __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npats, const int32_t* __restrict__ noccs, const int64_t* __restrict__ first,
-                                                        const int64_t* __restrict__ block_offs, int64_t* __restrict__ out_starts,
+                                                        const int64_t* __restrict__ block_sums, int64_t* __restrict__ out_starts,
                                                         int64_t* __restrict__ offsets, const int64_t capacity, int* __restrict__ big_flag,
                                                         const DevIndex ix) {
   __shared__ int64_t s_w[4];
+  __shared__ int64_t s_boff;
   const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const int64_t n = q < npats ? int64_t(noccs[q]) : 0;
   // inclusive scan inside the wavefront, then across the four wavefronts (a block's rows: <= 256 * (2^31 - 1): 64 bits)
   uint64_t incl = uint64_t(n);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave == 0) {   // rows before this block: its super block's scanned sum + the blocks before it inside the super block
+    const int64_t nblocks = (npats + 255) >> 8, b = int64_t(blockIdx.x);
+    const uint64_t part = wave_sum_u64(lane < int(b & 63) ? uint64_t(block_sums[(b & ~int64_t(63)) + lane]) : 0);
+    if (lane == 0) s_boff = plan_super(block_sums, nblocks)[b >> 6] + int64_t(part);
+  }
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const uint32_t lo = uint32_t(__shfl_up(int(uint32_t(incl)), d, 64)), hi = uint32_t(__shfl_up(int(uint32_t(incl >> 32)), d, 64));
@@ -413,7 +454,7 @@ __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npats, con
   __syncthreads();
   int64_t woff = 0;
   for (int k = 0; k < wave; k++) woff += s_w[k];
-  const int64_t base = q < npats ? block_offs[blockIdx.x] + woff + int64_t(incl) - n : 0;
+  const int64_t base = q < npats ? s_boff + woff + int64_t(incl) - n : 0;
   if (q < npats) out_starts[q] = base;
   if (!offsets) return;
   if (kSa) {
@@ -432,7 +473,7 @@ __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npats, con
       if (lane >= d) inc += y;
     }
     s_incl[wave][lane] = inc;
-    s_first[wave][lane] = q < npats ? first[q] : 0;
+    s_first[wave][lane] = mine ? first[q] : 0;      // (only ranges with rows: most lines of first[] are never touched on a random batch)
     s_lbase[wave][lane] = base;      // slots are addressed per lane: a long range keeps its slots but is not written here
     const uint32_t total = uint32_t(__shfl(int(inc), 63, 64));
     __syncthreads();

@@ -26,6 +26,7 @@
 #include "pack2_kernels.hip.hpp"
 #include "ind_kernels.hip.hpp"
 #include "text_kernels.hip.hpp"
+#include "ctx_kernels.hip.hpp"
 #include "direct_kernels.hip.hpp"
 #include "trace_api.hpp"
 #include "regexp_nfa.hpp"
@@ -224,6 +225,9 @@ struct femto_amd_index {
   int64_t* d_ktab2 = nullptr;
   int64_t* d_ktab2_deep = nullptr;
   int64_t ktab2_bytes = 0;
+  uint64_t* d_ctx = nullptr;     // context table of byte alphabets (ctx_kernels.hip.hpp)
+  int64_t ctx_bytes = 0, ctx_entries = 0;
+  double ctx_build_ms = 0;
   uint8_t* d_txt = nullptr;
   int64_t* d_isa8 = nullptr;
   int64_t* d_sa_full = nullptr;
@@ -550,6 +554,9 @@ void launch_tail(femto_amd_index* ix, const DevIndex& d, dim3 grid, hipStream_t 
   }
 }
 
+// block sums + their super sums (plan_scan_kernel)
+size_t plan_sums_bytes(int64_t nblocks) { return size_t(((nblocks + 63) & ~int64_t(63)) + (nblocks + 63) / 64 + 8) * 8; }
+
 // Thresholds of the inline text tail (count_direct_kernel<.., kDense = true>): SA read + text compare + ISA read are
 // three dependent lines, so it pays from four symbols to go (measured: cfg 3 5.22 -> 5.08 ms against the hand-over
 // thresholds 12 / 10).  Packed lines (<= 8 characters): only once the row has survived two steps -- a random pattern's
@@ -576,7 +583,7 @@ int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const in
   if (d.txt && !tail) inline_tail_setup(ix, d);
   int64_t* bsums = nullptr;
   if (plan) {
-    if ((rc = S.bsums.reserve(size_t(nblocks + 1) * 8))) return rc;
+    if ((rc = S.bsums.reserve(plan_sums_bytes(nblocks)))) return rc;
     bsums = S.bsums.as<int64_t>();
   }
   hipEvent_t e0, e1;
@@ -605,7 +612,7 @@ int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const in
   }
   timer_end(ix, ix->t_count, stream, e0, e1);
   if (plan) {
-    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, stream, nblocks, bsums, S.d_total, plan->capacity, plan->out_starts + npats);
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, stream, nblocks, bsums, S.d_total, plan->capacity, plan->out_starts + npats, S.d_flags + 1);
     HIP_TRY(hipGetLastError());
     plan->done = true;
   }
@@ -786,8 +793,7 @@ int launch_count_plan(femto_amd_index* ix, Scratch& S, int64_t npats, const int3
 int launch_plan_rows(femto_amd_index* ix, Scratch& S, int64_t npats, const int32_t* d_noccs, const int64_t* d_first,
                      int64_t* d_out_starts, int64_t* d_offsets, int64_t capacity, hipStream_t stream) {
   if (npats <= 0) return 0;
-  int* big_flag = S.d_flags + 1;
-  HIP_TRY(hipMemsetAsync(big_flag, 0, sizeof(int), stream));
+  int* big_flag = S.d_flags + 1;      // cleared by plan_scan_kernel
   const int64_t nblocks = (npats + kBlockThreads - 1) / kBlockThreads;
   const dim3 grid{uint32_t(nblocks)}, bgrid{uint32_t(std::min<int64_t>(nblocks, int64_t(ix->num_cus) * 8))}, block{uint32_t(kBlockThreads)};
   const int64_t* boffs = S.bsums.as<int64_t>();
@@ -930,7 +936,10 @@ int build_ktab2(femto_amd_index* ix, int sigma, int nstop) {
   if (const char* kt = getenv("FEMTO_AMD_KTAB")) if (atoi(kt) == 0) return 0;
   const int64_t t = sigma - nstop;
   if (t < 1) return 0;
-  int64_t level_cap = std::max<int64_t>(int64_t(1) << 16, ix->host.total_length);
+  // the deepest level may hold up to four entries per row (measured on 10 M random DNA 20-mers over 2^30 rows: K = 15
+  // 0.645 ms, K = 16 0.489 ms per count launch -- 78 % of random patterns then end at their table entry; 57 instead of
+  // 14 GB), the whole table at most a quarter of the free HBM
+  int64_t level_cap = std::max<int64_t>(int64_t(1) << 16, ix->host.total_length * 4);
   int64_t budget = INT64_MAX;
   {
     size_t free_b = 0, total_b = 0;
@@ -994,6 +1003,82 @@ int build_ktab2(femto_amd_index* ix, int sigma, int nstop) {
   ix->dev.kt2_nstop = nstop;
   ix->ktab2_bytes = upper * 16 + level * 8;
   ix->table_bytes += ix->ktab2_bytes;
+  return 0;
+}
+
+// Context table of a byte alphabet (ctx_kernels.hip.hpp): needs the dense arrays (suffix array of every row + text).
+// H = the largest of min(12, 64 / bits) .. K+2 whose table (16-byte slots, twice the distinct H-grams, a power of two) fits a quarter of
+// the free HBM; not built when even that does not fit, or when it would not save at least two steps over the level table.
+int build_ctx(femto_amd_index* ix, int nstop) {
+  if (ix->dev.ctx || !ix->dev.sa_full || !ix->dev.txt || nstop < 1) return 0;   // (nstop >= 1: key 0 stays "empty")
+  if (const char* e = getenv("FEMTO_AMD_CTX")) if (atoi(e) == 0) return 0;
+  const int64_t n = ix->host.total_length;
+  const int kmin = (ix->dev.ktab2 ? ix->dev.kt2_syms : 0) + 2;
+  const int t = int(ix->dev.p2_sigma) - nstop;      // table characters
+  if (t < 1) return 0;
+  int bits = 1;
+  while ((1 << bits) < t + 1) bits++;
+  int hmax = std::min(12, 64 / bits), hmin = kmin;
+  if (const char* e = getenv("FEMTO_AMD_CTX_SYMS")) hmax = hmin = std::max(1, std::min(hmax, atoi(e)));
+  if (hmin > hmax) return 0;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+  const int64_t budget = int64_t(free_b / 4);
+  DeviceBuffer cnt;
+  int rc = cnt.reserve(8);
+  if (rc) return rc;
+  const int64_t chunk = int64_t(1) << 30;
+  DevIndex d = ix->dev;
+  d.ctx_bits = bits;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  EventPair ep{e0, e1};
+  HIP_TRY(hipEventRecord(e0, nullptr));
+  for (int H = hmax; H >= hmin; H--) {
+    HIP_TRY(hipMemsetAsync(cnt.p, 0, 8, nullptr));
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+      const int64_t cn = std::min(chunk, n - r0);
+      hipLaunchKernelGGL(ctx_count_kernel, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, d, r0, cn, H, uint32_t(nstop),
+                         static_cast<unsigned long long*>(cnt.p));
+    }
+    HIP_TRY(hipGetLastError());
+    unsigned long long distinct = 0;
+    HIP_TRY(hipMemcpy(&distinct, cnt.p, 8, hipMemcpyDeviceToHost));
+    if (distinct == 0) continue;
+    int lg = 4;
+    while ((uint64_t(1) << lg) < 2 * distinct) lg++;
+    const int64_t bytes = (int64_t(1) << lg) * 16;
+    if (bytes > budget || lg > 40) continue;
+    if (big_malloc(ix, reinterpret_cast<void**>(&ix->d_ctx), size_t(bytes)) != hipSuccess) {
+      (void)hipGetLastError();
+      ix->d_ctx = nullptr;
+      continue;
+    }
+    HIP_TRY(big_memset(ix, ix->d_ctx, 0, size_t(bytes)));
+    for (int pass = 0; pass < 2; pass++)
+      for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+        const int64_t cn = std::min(chunk, n - r0);
+        const dim3 grid{uint32_t((cn + 255) / 256)}, block{256};
+        if (pass == 0) hipLaunchKernelGGL(ctx_insert_kernel, grid, block, 0, nullptr, d, r0, cn, H, uint32_t(nstop), reinterpret_cast<unsigned long long*>(ix->d_ctx), lg);
+        else hipLaunchKernelGGL(ctx_ends_kernel, grid, block, 0, nullptr, d, r0, cn, H, uint32_t(nstop), reinterpret_cast<unsigned long long*>(ix->d_ctx), lg);
+      }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    ix->dev.ctx = ix->d_ctx;
+    ix->dev.ctx_log2 = lg;
+    ix->dev.ctx_syms = H;
+    ix->dev.ctx_nstop = nstop;
+    ix->dev.ctx_bits = bits;
+    ix->ctx_bytes = bytes;
+    ix->ctx_entries = int64_t(distinct);
+    ix->ctx_build_ms = ms;
+    ix->table_bytes += bytes;
+    return 0;
+  }
   return 0;
 }
 
@@ -1922,6 +2007,7 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
       if (ix->dev.pack) r = build_ktab2<PackPolicy>(ix, ix->dev.pack_sigma, __builtin_popcount(ix->dev.pack_stop));
       else if (ix->dev.p2_l1) r = build_ktab2<Pack2Policy>(ix, ix->dev.p2_sigma, int(ix->dev.p2_stop_below));
       if (r && r != FEMTO_AMD_ERR_MEM) return r;
+      if (ix->dev.p2_l1 && !ix->dev.pack && (r = build_ctx(ix, int(ix->dev.p2_stop_below))) && r != FEMTO_AMD_ERR_MEM) return r;
       for (DeviceBuffer& b : ix->open_scan) b.release();
       if (const char* m = getenv("FEMTO_AMD_RANK_MODE")) {
         if (!strcmp(m, "raw")) ix->mode = 0;
@@ -2097,7 +2183,8 @@ void femto_amd_close(femto_amd_index_t* ix) {
     } else {
       for (void* q : {static_cast<void*>(ix->d_image), static_cast<void*>(ix->d_segs), static_cast<void*>(ix->d_pack), static_cast<void*>(ix->d_pack_sa),
                       static_cast<void*>(ix->d_txt), static_cast<void*>(ix->d_isa8), static_cast<void*>(ix->d_p2_l1), static_cast<void*>(ix->d_p2_l2),
-                      static_cast<void*>(ix->d_ktab2), static_cast<void*>(ix->d_ktab2_deep), static_cast<void*>(ix->d_sa_full), static_cast<void*>(ix->d_ind)})
+                      static_cast<void*>(ix->d_ktab2), static_cast<void*>(ix->d_ktab2_deep), static_cast<void*>(ix->d_sa_full), static_cast<void*>(ix->d_ind),
+                      static_cast<void*>(ix->d_ctx)})
         big_free(ix, q);
       for (void* q : {static_cast<void*>(ix->d_nodes), static_cast<void*>(ix->d_buckets), static_cast<void*>(ix->d_seqs), static_cast<void*>(ix->d_occ_base),
                       static_cast<void*>(ix->d_leaf_code), static_cast<void*>(ix->d_C), static_cast<void*>(ix->d_cum), static_cast<void*>(ix->d_hint),
@@ -2632,6 +2719,7 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
   region_lines[kTraceL2] = ix->p2_lines2;
   region_lines[kTraceTxt] = ix->dev.txt ? (n + 64) / 128 + 1 : 0;
   region_lines[kTraceIsa] = ix->dev.isa8 ? ((n >> ix->dev.isa_shift) + 2) / 16 + 1 : 0;
+  region_lines[kTraceCtx] = ix->ctx_bytes / 128;
   region_lines[kTraceKtab1] = ix->dev.ktab ? ((int64_t(1) << ix->dev.ktab_bits) * 16) / 128 + 1 : 0;
   int64_t off[kTraceRegions + 1];
   off[0] = 0;
@@ -2648,7 +2736,7 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
     if ((r2 = S.last.reserve(size_t(npats + 1) * 8))) return r2;
     if ((r2 = S.noccs.reserve(size_t(npats + 1) * 4))) return r2;
     if ((r2 = S.out_starts.reserve(size_t(npats + 2) * 8))) return r2;
-    if ((r2 = S.bsums.reserve(size_t(nblocks + 1) * 8))) return r2;
+    if ((r2 = S.bsums.reserve(plan_sums_bytes(nblocks)))) return r2;
     DevIndex d = ix->dev;
     ta::TraceArgs a{};
     a.dev = &d;
@@ -2897,7 +2985,7 @@ static int make_view(femto_amd_index* b, int device, femto_amd_index** out) {
   h.block_off = s.block_off; h.block_len = s.block_len;
   v->mode = b->mode; v->direct = b->direct; v->sort_queries = b->sort_queries; v->dense_bits = b->dense_bits;
   v->dense_sigma = b->dense_sigma; v->sort_min = b->sort_min; v->h_dense = b->h_dense; v->table_bytes = b->table_bytes;
-  v->ktab2_bytes = b->ktab2_bytes; v->n_marks = b->n_marks; v->p2_lines1 = b->p2_lines1; v->p2_lines2 = b->p2_lines2;
+  v->ktab2_bytes = b->ktab2_bytes; v->ctx_bytes = b->ctx_bytes; v->n_marks = b->n_marks; v->p2_lines1 = b->p2_lines1; v->p2_lines2 = b->p2_lines2;
   v->ind_bytes = b->ind_bytes; v->text_bytes = b->text_bytes; v->pack_bytes = b->pack_bytes; v->pack2_bytes = b->pack2_bytes;
   v->blocks_per_cu_override = b->blocks_per_cu_override;
   if (hipSetDevice(device) != hipSuccess) return fail(set_err(FEMTO_AMD_ERR_INVALID, "no usable HIP device " + std::to_string(device)));
@@ -3068,6 +3156,7 @@ int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* by
   if (available && ix->dev.p2_l1) *available |= 2;   // bit 1: the two-level lines (mode 4) exist
   if (available && ix->dev.ktab2) *available |= 4;   // bit 2: the level table of the direct pipeline exists
   if (available && ix->dev.ind) *available |= 32;     // bit 5: per-character rank lines (byte alphabets)
+  if (available && ix->dev.ctx) *available |= 64 | (ix->dev.ctx_syms << 8);   // bit 6: context table; bits 8-11: its H
   if (available && ix->dev.sa_full) *available |= 8;  // bit 3: the full suffix array is resident
   if (available && ix->dev.isa8 && ix->dev.isa_shift == 0) *available |= 16;   // bit 4: the full inverse suffix array
   if (bytes) *bytes = ix->pack_bytes + ix->pack2_bytes;

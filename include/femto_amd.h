@@ -284,7 +284,7 @@ void femto_amd_kernel_time_enable(femto_amd_index_t* ix, int on);
  * DISTINCT 128-byte lines of each derived array the count phase (count_lines[10]) and the row expansion + locate walk
  * (locate_lines[10]) loaded; *rows_out = rows located.  Regions: 0 packed lines (mode 3), 1 level table, 2 suffix
  * array / offsets of the marked rows, 3 / 4 level-1 / level-2 lines (mode 4), 5 text, 6 inverse suffix array, 7 round-1
- * table, 8 per-character rank lines, 9 unused.
+ * table, 8 per-character rank lines, 9 context table.
  * Device pointers as in femto_amd_count_device; blocking; not to be called while other calls use the handle. */
 int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
                           const int64_t* d_starts, int max_occs_each, int64_t* count_lines, int64_t* locate_lines,

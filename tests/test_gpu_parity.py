@@ -576,6 +576,59 @@ def test_gpu_built_english_like_vs_oracle(tmp_path, gpu_ok, mode):
     assert np.array_equal(noccs, on) and np.array_equal(offs, oo)
 
 
+def test_context_table_matches_steps(tmp_path, gpu_ok, monkeypatch):
+    """Byte alphabets: the hashed H-gram table (ctx_kernels.hip.hpp) answers the first H steps; the same handle opened
+    with FEMTO_AMD_CTX=0 steps through them.  Identical (first, last) -- including those of EMPTY ranges, which are the
+    values of the step that emptied them -- for sampled substrings, random strings, patterns shorter than H, patterns
+    crossing a document end and patterns holding a character the text lacks; both against the oracle."""
+    text = tg.t_eng(2 << 20, 7)
+    docs = [text[:700000], text[700000:]]
+    path = str(tmp_path / "ctx2doc")
+    femto_amd.build_index(path, docs, params="block_size=1048576,bucket_size=131072,mark_period=16", infos=["a", "b"], device=0)
+    ix = femto_amd.Index(path, device=0)
+    pi = ix.pack_info()
+    assert ix.rank_mode == 4 and pi["sa_full"] and pi["context_table"] and 5 <= pi["context_syms"] <= 12, pi
+    H = pi["context_syms"]
+    rng = np.random.Generator(np.random.PCG64(77))
+    plen, flat = tg.p_hit(1, 40, 30000, 9, text)
+    pats = [flat[s:s + l] for s, l in zip(tg.starts_of(plen), plen)]
+    alphabet = np.unique(text)
+    for _ in range(8000):                              # random strings over the text's alphabet: most die inside the H steps
+        pats.append(tg.to_alpha(alphabet[rng.integers(0, len(alphabet), int(rng.integers(1, 20)))]))
+    for _ in range(2000):                              # a sampled substring with one symbol replaced
+        l = int(rng.integers(H, 30))
+        s0 = int(rng.integers(0, len(text) - l))
+        q = text[s0:s0 + l].copy()
+        q[int(rng.integers(0, l))] = alphabet[int(rng.integers(0, len(alphabet)))]
+        pats.append(tg.to_alpha(q))
+    missing = [c for c in range(256) if c not in set(alphabet.tolist())][:3]
+    for c in missing:                                  # a character the text lacks, inside and outside the last H symbols
+        for pos in (0, 3, 12):
+            q = text[5000:5020].copy()
+            q[pos] = c
+            pats.append(tg.to_alpha(q))
+    for cut in (699990, 699995):                       # across the document end: SEOF (alpha code 2) inside the pattern
+        q = np.concatenate([tg.to_alpha(text[cut:700000]), np.array([2], dtype=np.uint16), tg.to_alpha(text[700000:700000 + 12])])
+        pats.append(q)
+    plen, flat, starts = femto_amd.flatten(pats)
+    first, last = ix.count_flat(plen, flat, starts)
+    noccs, offs = ix.locate_flat(plen, flat, starts, 10)
+    ix.close()
+    monkeypatch.setenv("FEMTO_AMD_CTX", "0")
+    ix0 = femto_amd.Index(path, device=0)
+    assert not ix0.pack_info()["context_table"]
+    f0, l0 = ix0.count_flat(plen, flat, starts)
+    n0, o0 = ix0.locate_flat(plen, flat, starts, 10)
+    ix0.close()
+    assert np.array_equal(first, f0) and np.array_equal(last, l0)
+    assert np.array_equal(noccs, n0) and np.array_equal(offs, o0)
+    o = po.Oracle(path)
+    of, ol = o.count_flat(plen, flat, starts, threads=8)
+    assert np.array_equal(first, of) and np.array_equal(last, ol)
+    # (a sampled substring misses only when it straddles the cut between the two documents)
+    assert (last[:30000] >= first[:30000]).sum() > 29900 and (last[30000:38000] < first[30000:38000]).sum() > 4000
+
+
 def test_full_text_lf_walk_recovers_every_offset(tmp_path, gpu_ok):
     """Size-independent property: locating the range of the EMPTY pattern (all rows) returns a
     permutation of 0..n-1, i.e. the whole suffix array, and L[row] == text[SA[row]-1]."""
