@@ -69,7 +69,7 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(args, kname):
+def pmc_traffic(args, kname, pack_info):
     """HBM-side bytes per launch of kernel `kname`, measured NOW: two separate `rocprofv3 --pmc` passes over a short child
     run of this script (FETCH_SIZE; WRITE_SIZE + request counters -- never combined with any trace domain).  Per the
     guide (MI355X_MICROARCH.md, HBM): on gfx950 FETCH_SIZE tallies a 128-byte request as 64 bytes -> x2; both are KiB."""
@@ -82,8 +82,16 @@ def pmc_traffic(args, kname):
             "--npats", str(args.npats), "--plen", str(args.plen), "--seed", str(args.seed), "--max-occs", str(args.max_occs),
             "--workload", args.workload, "--workdir", args.workdir]
     means = {}
+    child_info = None
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
-        env = dict(os.environ, TMPDIR="/tmp")
+        # The child opens the index while this process still holds its own, so it sees less free HBM: the depths this
+        # process chose for the level table / context table are forced, and the child reports what it built.
+        env = dict(os.environ, TMPDIR="/tmp", FEMTO_AMD_BENCH_CHILD_INFO=os.path.join(td, "child.json"))
+        if pack_info.get("level_table"):
+            env["FEMTO_AMD_KTAB_SYMS"] = str(pack_info["ktab_syms"])
+        env["FEMTO_AMD_CTX"] = "1" if pack_info.get("context_table") else "0"
+        if pack_info.get("context_table"):
+            env["FEMTO_AMD_CTX_SYMS"] = str(pack_info["context_syms"])
         for i, ctrs in enumerate((["FETCH_SIZE"], ["WRITE_SIZE", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_128B_sum"])):
             out = os.path.join(td, f"p{i}")
             cmd = ["rocprofv3", "--pmc"] + ctrs + ["--kernel-include-regex", PMC_REGEX, "-f", "csv", "-d", out, "-o", "pmc", "--"] + base
@@ -93,6 +101,14 @@ def pmc_traffic(args, kname):
                     for r in csv.DictReader(fh):
                         if _same_kernel(kname, r.get("Kernel_Name", "")):
                             means.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            try:
+                child_info = json.load(open(env["FEMTO_AMD_BENCH_CHILD_INFO"]))
+            except Exception:      # noqa: BLE001
+                child_info = None
+    keys = ("level_table", "ktab_syms", "sa_full", "isa_full", "char_rank_lines", "context_table", "context_syms")
+    if child_info is None or any(child_info.get(k) != pack_info.get(k) for k in keys):
+        log("pmc child built different structures, traffic not used:", child_info)
+        return None, None
     if "FETCH_SIZE" not in means or "WRITE_SIZE" not in means:
         return None, None
     m = {k: sum(v) / len(v) for k, v in means.items()}
@@ -100,6 +116,7 @@ def pmc_traffic(args, kname):
     src = {"how": "live: 2 separate rocprofv3 --pmc passes over a 2-step child run of this script in this very run",
            "FETCH_SIZE_KiB": m["FETCH_SIZE"], "WRITE_SIZE_KiB": m["WRITE_SIZE"], "TCC_EA0_RDREQ": m.get("TCC_EA0_RDREQ_sum"),
            "TCC_EA0_RDREQ_128B": m.get("TCC_EA0_RDREQ_128B_sum"), "dispatches": len(means["FETCH_SIZE"]), "source_hash": source_hash(),
+           "child_index": {k: child_info.get(k) for k in keys},
            "formula": "2 x FETCH_SIZE KiB x 1024 (gfx950 tallies 128-B requests as 64 B) + WRITE_SIZE KiB x 1024"}
     return traffic, src
 
@@ -322,6 +339,9 @@ def main():
     batch = Batch(torch, dev, plen, flat)
     direct = bool(ix.pack_info().get("level_table")) and os.environ.get("FEMTO_AMD_DIRECT", "1") != "0" and ix.rank_mode in (3, 4)
     if args.pmc_child:      # the short run the PMC passes of pmc_traffic() profile: same index, same batch, a few steps
+        if os.environ.get("FEMTO_AMD_BENCH_CHILD_INFO"):
+            with open(os.environ["FEMTO_AMD_BENCH_CHILD_INFO"], "w") as fh:
+                json.dump(ix.pack_info(), fh)
         st = torch.cuda.current_stream().cuda_stream
         batch.settle(ix, args.max_occs, st)
         for _ in range(args.warmup + args.steps):
@@ -572,7 +592,7 @@ def main():
         traffic, traffic_src = None, None
         if args.pmc != "off" and world == 1:
             try:
-                traffic, traffic_src = pmc_traffic(args, kname)
+                traffic, traffic_src = pmc_traffic(args, kname, ix.pack_info())
             except Exception as ex:      # noqa: BLE001
                 log("pmc pass failed:", repr(ex))
         if traffic is None:

@@ -170,6 +170,8 @@ struct DevIndex {           // passed by value to kernels
   int* tail_count;
   int32_t tail_min;         // hand a one-row range over when at least this many symbols remain
   int32_t tail_ones;        // ... and, inline tail only, the range has been one row for this many steps
+  int32_t tail_rows;        // inline tail: ranges of up to this many rows ...
+  int32_t tail_row_cost;    // ... when tail_min + tail_row_cost x (rows - 1) symbols remain
   int64_t total_length;
   int64_t total_buckets;
   int32_t b_size;

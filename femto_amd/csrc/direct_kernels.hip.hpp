@@ -204,7 +204,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, 
           // on the next step or two (one line each), which is cheaper than the three dependent lines of the tail; a row
           // that survived tail_ones steps belongs to a pattern that occurs (measured on 10 M random DNA 20-mers: 0.86 ms
           // jumping at once, 0.65 ms stepping on).
-          if (!tried && first == last && j > 0 && ones >= ix.tail_ones && len - j >= ix.tail_min) break;
+          if (!tried && last - first < int64_t(P::kTailRows) && last - first < int64_t(ix.tail_rows) && j > 0 && ones >= ix.tail_ones &&
+              len - j >= ix.tail_min + ix.tail_row_cost * int(last - first)) break;
         } else if (ix.txt && first == last && j > 0 && len - j >= ix.tail_min) {
           tail_append(ix, q, j, first);   // one row left, a long tail to go: count_tail_kernel compares it with the text
           handed = true;
@@ -234,14 +235,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, 
       if (!kDense || finished || j >= len) break;
       // ---- tail-ready: position of the row, compare with the text, row of the last matching position
       tried = true;
-      const int64_t p = ix.sa_full[first];
-      trace_touch(ix, kTraceSa, uint64_t(first) >> 4);
       const int remaining = len - j;
-      if (p >= int64_t(remaining) && p < ix.total_length) {   // (p = -1: the row could not be located, see text_isa_build_kernel)
+      int best = 0;                      // most symbols any row of the range matches; [qmin, qmax] = the rows of those that do
+      int64_t qmin = 0, qmax = -1;
+      for (int64_t row = first; row <= last; row++) {
+        const int64_t p = ix.sa_full[row];
+        trace_touch(ix, kTraceSa, uint64_t(row) >> 4);
+        if (p <= 0 || p >= ix.total_length) continue;   // (p = -1: the row could not be located, see text_isa_build_kernel)
+        const int lim = p < int64_t(remaining) ? int(p) : remaining;
         int m = 0;                       // symbols matched
         uint4 tw = make_uint4(0, 0, 0, 0);   // aligned 16-byte piece of txt holding the byte being compared
         uintptr_t tw_addr = 1;
-        for (; m < remaining; m++) {
+        for (; m < lim; m++) {
           const uint32_t ch = symbol(j + m);
           if (ch >= uint32_t(kAlphaSize)) break;          // anything unusual is left to the ordinary step
           const uint32_t code = s_code[ch];
@@ -257,11 +262,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, 
           const uint32_t dw = (bo & 8u) ? ((bo & 4u) ? tw.w : tw.z) : ((bo & 4u) ? tw.y : tw.x);
           if (((dw >> (8u * (bo & 3u))) & 0xffu) != code) break;
         }
-        if (m > 0) {
-          first = last = ix.isa8[p - m];   // isa_shift == 0: the row of every text position
+        if (m > 0 && m >= best) {
+          const int64_t q2 = ix.isa8[p - m];   // isa_shift == 0: the row of every text position
           trace_touch(ix, kTraceIsa, uint64_t(p - m) >> 4);
-          j += m;
+          if (m > best) {
+            best = m;
+            qmin = qmax = q2;
+          } else {
+            qmin = q2 < qmin ? q2 : qmin;
+            qmax = q2 > qmax ? q2 : qmax;
+          }
         }
+      }
+      if (best > 0) {      // the rows whose text goes on with `best` more pattern symbols: one contiguous range again
+        first = qmin;
+        last = qmax;
+        j += best;
       }
       if (j >= len) break;
     }
@@ -355,7 +371,8 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 }
 
 __global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t n, int64_t* __restrict__ sums, int64_t* __restrict__ total_out,
-                                                         const int64_t capacity, int64_t* __restrict__ out_starts_end, int* __restrict__ big_flag) {
+                                                         const int64_t capacity, int64_t* __restrict__ out_starts_end, int* __restrict__ big_flag,
+                                                         int64_t* __restrict__ total_user) {
   __shared__ int64_t s_wave[16];
   __shared__ int64_t s_carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -402,6 +419,10 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t n, int64_
     const int64_t total = s_carry;
     total_out[0] = total;
     total_out[1] = total > capacity ? 1 : 0;
+    if (total_user) {
+      total_user[0] = total;
+      total_user[1] = total > capacity ? 1 : 0;
+    }
     if (out_starts_end) *out_starts_end = total;
   }
 }

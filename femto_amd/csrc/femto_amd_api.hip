@@ -155,6 +155,7 @@ struct Scratch {
   hipStream_t stream = nullptr; // host-pointer calls launch here (non-blocking stream: calls of different threads overlap)
   hipEvent_t done = nullptr;
   bool busy = false, in_flight = false;
+  hipStream_t flight_stream = nullptr;   // the stream of the enqueue-only call that used this scratch last
   HostPipe pipe;
 
   int init() {
@@ -291,10 +292,20 @@ struct femto_amd_index {
 namespace {
 
 // lease of one Scratch for the duration of a call
-Scratch* scratch_acquire(femto_amd_index* ix, int* rc) {
+// `same_stream`: the call only enqueues work on that stream.  A scratch whose previous use was enqueued on the SAME stream
+// can be taken at once -- stream order keeps the two uses apart -- so a caller issuing step after step on one stream keeps
+// ONE warm scratch instead of cycling through the pool (creating a scratch allocates its buffers, which synchronises the
+// device: 0.2 ms per step of a 10-step run, measured).
+Scratch* scratch_acquire(femto_amd_index* ix, int* rc, bool enqueue_only = false, hipStream_t same_stream = nullptr) {
   std::unique_lock<std::mutex> lk(ix->pool_mu);
   for (;;) {
     Scratch* waiting = nullptr;
+    if (enqueue_only)
+      for (auto& s : ix->pool)
+        if (!s->busy && s->in_flight && s->flight_stream == same_stream) {
+          s->busy = true;      // still in flight: the event is re-recorded when this lease ends
+          return s.get();
+        }
     for (auto& s : ix->pool) {
       if (s->busy) continue;
       if (s->in_flight) {
@@ -336,6 +347,7 @@ void scratch_release(femto_amd_index* ix, Scratch* s, bool async, hipStream_t st
     std::lock_guard<std::mutex> lk(ix->pool_mu);
     s->busy = false;
     s->in_flight = flying;
+    s->flight_stream = stream;
   }
   ix->pool_cv.notify_one();
 }
@@ -347,6 +359,10 @@ struct Lease {
   hipStream_t stream = nullptr;
   int rc = 0;
   explicit Lease(femto_amd_index* i) : ix(i) { s = scratch_acquire(ix, &rc); }
+  Lease(femto_amd_index* i, hipStream_t st) : ix(i) {     // enqueue-only call on the caller's stream `st`
+    s = scratch_acquire(ix, &rc, true, st);
+    if (s) enqueue_only(st);
+  }
   ~Lease() {
     if (s) s->err = s->d_flags;
     scratch_release(ix, s, async, stream);
@@ -522,6 +538,7 @@ struct Plan {
   int64_t* out_starts;   // device, npats + 1
   int64_t capacity;      // rows the caller's offsets buffer holds (INT64_MAX when it is sized afterwards)
   bool done;
+  int64_t* total_user = nullptr;   // device, 2 words: the caller's copy of S.d_total, written by plan_scan_kernel itself
 };
 
 bool use_direct(const femto_amd_index* ix) {
@@ -567,6 +584,13 @@ void inline_tail_setup(const femto_amd_index* ix, DevIndex& d) {
   d.tail_ones = ix->mode == 3 ? 2 : 0;
   if (const char* tm = getenv("FEMTO_AMD_TAIL_MIN")) d.tail_min = std::max(2, atoi(tm));
   if (const char* to = getenv("FEMTO_AMD_TAIL_ONES")) d.tail_ones = std::max(0, atoi(to));
+  // Ranges of 2-4 rows can take the tail too (each row compared, the survivors' rows from the inverse suffix array), but on
+  // the sigma~96 workload that loses: the lanes of a wavefront then serialise up to 3 x rows dependent reads while the
+  // others wait (10 M sampled patterns: rows = 1 3.48 ms, 2 3.63 ms, 4 3.87-4.08 ms).  Default 1; FEMTO_AMD_TAIL_ROWS <= 4.
+  d.tail_rows = 1;
+  d.tail_row_cost = 8;
+  if (const char* tr = getenv("FEMTO_AMD_TAIL_ROWS")) d.tail_rows = std::max(1, atoi(tr));
+  if (const char* tc = getenv("FEMTO_AMD_TAIL_ROW_COST")) d.tail_row_cost = std::max(0, atoi(tc));
 }
 
 // modes 3/4, caller order, no sort (direct_kernels.hip.hpp)
@@ -612,7 +636,7 @@ int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const in
   }
   timer_end(ix, ix->t_count, stream, e0, e1);
   if (plan) {
-    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, stream, nblocks, bsums, S.d_total, plan->capacity, plan->out_starts + npats, S.d_flags + 1);
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, stream, nblocks, bsums, S.d_total, plan->capacity, plan->out_starts + npats, S.d_flags + 1, plan->total_user);
     HIP_TRY(hipGetLastError());
     plan->done = true;
   }
@@ -2252,9 +2276,8 @@ int femto_amd_count_device(femto_amd_index_t* ix, int64_t npats, const int32_t* 
   if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
   int rc = ensure_device(ix);
   if (rc) return rc;
-  Lease L(ix);
+  Lease L(ix, static_cast<hipStream_t>(stream));
   if (!L.s) return L.rc;
-  L.enqueue_only(static_cast<hipStream_t>(stream));
   return launch_count(ix, *L.s, npats, d_plen, d_pats, d_starts, d_first, d_last, L.stream);
   API_END
 }
@@ -2356,9 +2379,8 @@ int femto_amd_locate_plan_device(femto_amd_index_t* ix, int64_t npats, const int
   if (max_occs_each < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative max_occs_each");
   int rc = ensure_device(ix);
   if (rc) return rc;
-  Lease L(ix);
+  Lease L(ix, static_cast<hipStream_t>(stream_));
   if (!L.s) return L.rc;
-  L.enqueue_only(static_cast<hipStream_t>(stream_));
   Plan plan{max_occs_each, d_noccs, d_out_starts, INT64_MAX, false};
   if ((rc = launch_count_plan(ix, *L.s, npats, d_plen, d_pats, d_starts, d_first, d_last, &plan, L.stream))) return rc;
   if (plan.done) rc = launch_plan_rows(ix, *L.s, npats, d_noccs, d_first, d_out_starts, nullptr, INT64_MAX, L.stream);
@@ -2372,9 +2394,8 @@ int femto_amd_locate_walk_device(femto_amd_index_t* ix, int64_t npats, const int
   if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
   int rc = ensure_device(ix);
   if (rc) return rc;
-  Lease L(ix);
+  Lease L(ix, static_cast<hipStream_t>(stream));
   if (!L.s) return L.rc;
-  L.enqueue_only(static_cast<hipStream_t>(stream));
   return launch_locate(ix, *L.s, npats, d_first, d_out_starts, total, d_offsets, L.stream);
   API_END
 }
@@ -2389,14 +2410,13 @@ int femto_amd_locate_device(femto_amd_index_t* ix, int64_t npats, const int32_t*
   if (npats && (!d_first || !d_last || !d_noccs || !d_out_starts || !d_total)) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
   int rc = ensure_device(ix);
   if (rc) return rc;
-  Lease L(ix);
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  Lease L(ix, stream);
   if (!L.s) return L.rc;
   Scratch& S = *L.s;
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  L.enqueue_only(stream);
-  Plan plan{max_occs_each, d_noccs, d_out_starts, offsets_capacity, false};
+  Plan plan{max_occs_each, d_noccs, d_out_starts, offsets_capacity, false, d_total};
   if ((rc = launch_count_plan(ix, S, npats, d_plen, d_pats, d_starts, d_first, d_last, &plan, stream))) return rc;
-  if (plan.done) {   // direct pipeline: one stream-ordered chain, nothing returns to the host
+  if (plan.done) {   // direct pipeline: one stream-ordered chain, nothing returns to the host (d_total: plan_scan_kernel)
     if ((rc = launch_plan_rows(ix, S, npats, d_noccs, d_first, d_out_starts, d_offsets, offsets_capacity, stream))) return rc;
     if (offsets_capacity > 0 && d_offsets && !ix->dev.sa_full && (rc = launch_walk_device_total(ix, S, d_offsets, offsets_capacity, stream))) return rc;
   } else {           // other kernel families size the walk on the host
@@ -2405,8 +2425,8 @@ int femto_amd_locate_device(femto_amd_index_t* ix, int64_t npats, const int32_t*
     HIP_TRY(hipStreamSynchronize(stream));
     const int64_t walk = std::min(tot[0], offsets_capacity);
     if (walk == tot[0] && d_offsets && (rc = launch_locate(ix, S, npats, d_first, d_out_starts, walk, d_offsets, stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_total, S.d_total, 2 * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
   }
-  HIP_TRY(hipMemcpyAsync(d_total, S.d_total, 2 * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
   return FEMTO_AMD_OK;
   API_END
 }

@@ -73,7 +73,7 @@ hipError_t traced_count_plan(const TraceArgs& a) {
       else hipLaunchKernelGGL((count_tail_kernel<Pack2Policy, false>), tgrid, block, 0, a.stream, d, items, n_items, a.plen, a.pats, a.starts, perm, keys, 1, 0, out, a.flags);
     }
   }
-  hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, a.stream, nblocks, a.bsums, a.total, INT64_MAX, a.out_starts + a.npats, static_cast<int*>(nullptr));
+  hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, a.stream, nblocks, a.bsums, a.total, INT64_MAX, a.out_starts + a.npats, static_cast<int*>(nullptr), static_cast<int64_t*>(nullptr));
   hipLaunchKernelGGL(plan_rows_kernel<false>, grid, block, 0, a.stream, a.npats, static_cast<const int32_t*>(a.noccs), static_cast<const int64_t*>(a.first),
                      static_cast<const int64_t*>(a.bsums), a.out_starts, static_cast<int64_t*>(nullptr), INT64_MAX, a.flags + 1, d);
   return hipGetLastError();

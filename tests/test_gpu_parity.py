@@ -615,6 +615,8 @@ def test_context_table_matches_steps(tmp_path, gpu_ok, monkeypatch):
     noccs, offs = ix.locate_flat(plen, flat, starts, 10)
     ix.close()
     monkeypatch.setenv("FEMTO_AMD_CTX", "0")
+    monkeypatch.setenv("FEMTO_AMD_TAIL_ROWS", "4")     # ... and the text tail taken by ranges of up to four rows
+    monkeypatch.setenv("FEMTO_AMD_TAIL_ROW_COST", "1")
     ix0 = femto_amd.Index(path, device=0)
     assert not ix0.pack_info()["context_table"]
     f0, l0 = ix0.count_flat(plen, flat, starts)

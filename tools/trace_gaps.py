@@ -5,7 +5,10 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)
 rows = list(csv.DictReader(open(f[0])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-tail = rows[-int(sys.argv[2]) if len(sys.argv) > 2 else -24:]
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+steps = [i for i, r in enumerate(rows) if "femto_amd::count_direct_kernel" in r["Kernel_Name"] or "femto_amd::count_kernel" in r["Kernel_Name"]]
+lo = steps[-n] if len(steps) >= n else 0
+tail = rows[max(0, lo - 2):steps[-1] + 5] if steps else rows[-24:]     # the last n timed steps
 prev_end = None
 for r in tail:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
