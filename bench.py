@@ -92,6 +92,9 @@ def pmc_traffic(args, kname, pack_info):
         env["FEMTO_AMD_CTX"] = "1" if pack_info.get("context_table") else "0"
         if pack_info.get("context_table"):
             env["FEMTO_AMD_CTX_SYMS"] = str(pack_info["context_syms"])
+        env["FEMTO_AMD_CTX2"] = "1" if pack_info.get("context2_syms") else "0"
+        if pack_info.get("context2_syms"):
+            env["FEMTO_AMD_CTX2_SYMS"] = str(pack_info["context2_syms"])
         for i, ctrs in enumerate((["FETCH_SIZE"], ["WRITE_SIZE", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_128B_sum"])):
             out = os.path.join(td, f"p{i}")
             cmd = ["rocprofv3", "--pmc"] + ctrs + ["--kernel-include-regex", PMC_REGEX, "-f", "csv", "-d", out, "-o", "pmc", "--"] + base
@@ -105,7 +108,7 @@ def pmc_traffic(args, kname, pack_info):
                 child_info = json.load(open(env["FEMTO_AMD_BENCH_CHILD_INFO"]))
             except Exception:      # noqa: BLE001
                 child_info = None
-    keys = ("level_table", "ktab_syms", "sa_full", "isa_full", "char_rank_lines", "context_table", "context_syms")
+    keys = ("level_table", "ktab_syms", "sa_full", "isa_full", "char_rank_lines", "context_table", "context_syms", "context2_syms")
     if child_info is None or any(child_info.get(k) != pack_info.get(k) for k in keys):
         log("pmc child built different structures, traffic not used:", child_info)
         return None, None

@@ -258,7 +258,7 @@ class Index:
         _check(lib().femto_amd_pack_info(self._h, C.byref(a), C.byref(b), C.byref(ms), C.byref(k)))
         return {"available": bool(a.value & 1), "available2": bool(a.value & 2), "level_table": bool(a.value & 4),
                 "sa_full": bool(a.value & 8), "isa_full": bool(a.value & 16), "char_rank_lines": bool(a.value & 32), "context_table": bool(a.value & 64),
-                "context_syms": (a.value >> 8) & 15,
+                "context_syms": (a.value >> 8) & 15, "context2_syms": (a.value >> 12) & 31,
                 "bytes": b.value, "build_ms": ms.value, "ktab_syms": k.value}
 
     def document_info(self, doc):

@@ -14,6 +14,10 @@
 //   slot  = 16 bytes {key, value}, key 0 = empty (every field of a key is >= 1);
 //           slots = power of two >= 2 x distinct H-grams; linear probing.
 //
+// A second, WIDE table of the same kind (two-word keys, 32-byte slots {key lo, key hi, value, 0}, H2 <= min(16, 128 / bits))
+// answers patterns of at least H2 symbols: 12 symbols for t ~ 96, after which most sampled patterns of an English-like
+// 1 GiB text are down to a row or two.  A pattern tries the wide table, then the narrow one, then the level table.
+//
 // The table is COMPLETE for windows without stop characters, so a miss means the range is empty -- exactly what
 // do_string_query (src/main/server.c:832-936) finds after those H steps.  H is the largest of 12, 11, ... whose table fits
 // the budget (a quarter of the free HBM at most); FEMTO_AMD_CTX=0 disables, FEMTO_AMD_CTX_SYMS=h forces.
@@ -131,6 +135,135 @@ __device__ __forceinline__ int ctx_lookup(const DevIndex& ix, uint64_t key, int6
       return 1;
     }
     if (e.x == 0) return 0;
+  }
+  return 0;
+}
+
+// ---- the wide table -------------------------------------------------------------------------------------------------
+struct CtxKey2 {
+  uint64_t lo, hi;
+};
+__device__ __forceinline__ bool operator==(const CtxKey2& a, const CtxKey2& b) { return a.lo == b.lo && a.hi == b.hi; }
+__device__ __forceinline__ bool operator!=(const CtxKey2& a, const CtxKey2& b) { return !(a == b); }
+
+// key |= field << sh  (0 <= sh < 128, the field may straddle the two words)
+__device__ __forceinline__ void ctx_key2_or(CtxKey2& k, uint64_t field, int sh) {
+  if (sh < 64) {
+    k.lo |= field << sh;
+    if (sh) k.hi |= field >> (64 - sh);
+  } else {
+    k.hi |= field << (sh - 64);
+  }
+}
+
+__device__ __forceinline__ uint64_t ctx_hash2(const CtxKey2& k, int log2_slots) {
+  return ((k.lo * 0x9E3779B97F4A7C15ull) ^ (k.hi * 0xC2B2AE3D27D4EB4Full)) * 0xD6E8FEB86659FD93ull >> (64 - log2_slots);
+}
+
+// H-gram (H <= 16) starting at text position p as a wide key ({0,0}: not a key); field i (text order) at bits * (H-1-i)
+__device__ __forceinline__ CtxKey2 ctx_gram2(const DevIndex& ix, int64_t p, int H, uint32_t nstop) {
+  CtxKey2 key{0, 0};
+  if (p < 0 || p + H > ix.total_length) return key;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(ix.txt + p);
+  const uintptr_t al = a & ~uintptr_t(7);
+  const uint64_t w0 = *reinterpret_cast<const uint64_t*>(al);            // txt has 64 bytes of slack behind it
+  const uint64_t w1 = *reinterpret_cast<const uint64_t*>(al + 8);
+  const uint64_t w2 = *reinterpret_cast<const uint64_t*>(al + 16);
+  const uint32_t sh = uint32_t(a - al) * 8u;
+  const uint64_t lo = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;         // bytes p .. p+7, p in the low byte
+  const uint64_t hi = sh ? (w1 >> sh) | (w2 << (64u - sh)) : w1;         // bytes p+8 .. p+15
+  const int bits = ix.ctx_bits;
+  for (int i = 0; i < H; i++) {
+    const uint32_t c = uint32_t((i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8))) & 0xffu);
+    if (c < nstop) return CtxKey2{0, 0};
+    ctx_key2_or(key, uint64_t(c - nstop + 1u), bits * (H - 1 - i));
+  }
+  return key;
+}
+
+__device__ __forceinline__ CtxKey2 ctx_gram2_of_row(const DevIndex& ix, int64_t row, int H, uint32_t nstop) {
+  if (row < 0 || row >= ix.total_length) return CtxKey2{0, 0};
+  return ctx_gram2(ix, ix.sa_full[row], H, nstop);
+}
+
+__device__ __forceinline__ CtxKey2 ctx_shfl2(const CtxKey2& g, int delta, bool up) {
+  CtxKey2 r;
+  uint32_t a = uint32_t(g.lo), b = uint32_t(g.lo >> 32), c = uint32_t(g.hi), d = uint32_t(g.hi >> 32);
+  if (up) {
+    a = uint32_t(__shfl_up(int(a), delta, 64)); b = uint32_t(__shfl_up(int(b), delta, 64));
+    c = uint32_t(__shfl_up(int(c), delta, 64)); d = uint32_t(__shfl_up(int(d), delta, 64));
+  } else {
+    a = uint32_t(__shfl_down(int(a), delta, 64)); b = uint32_t(__shfl_down(int(b), delta, 64));
+    c = uint32_t(__shfl_down(int(c), delta, 64)); d = uint32_t(__shfl_down(int(d), delta, 64));
+  }
+  r.lo = (uint64_t(b) << 32) | a;
+  r.hi = (uint64_t(d) << 32) | c;
+  return r;
+}
+
+// pass 0: count the group starts; pass 1: every group start claims a slot; pass 2: every group end completes its value
+__global__ __launch_bounds__(256) void ctx2_build_kernel(const DevIndex ix, const int64_t row0, const int64_t n, const int H, const uint32_t nstop,
+                                                         const int pass, unsigned long long* __restrict__ count,
+                                                         unsigned long long* __restrict__ slots, const int log2_slots) {
+  const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool in = row < row0 + n;
+  const CtxKey2 zero{0, 0};
+  const CtxKey2 g = in ? ctx_gram2_of_row(ix, row, H, nstop) : zero;
+  const uint64_t mask = (uint64_t(1) << log2_slots) - 1;
+  if (pass < 2) {
+    CtxKey2 prev = ctx_shfl2(g, 1, true);
+    if ((threadIdx.x & 63u) == 0) prev = in ? ctx_gram2_of_row(ix, row - 1, H, nstop) : zero;
+    const bool start = in && g != zero && g != prev;
+    if (pass == 0) {
+      const unsigned long long b = __ballot(start);
+      if ((threadIdx.x & 63u) == 0 && b) atomicAdd(count, static_cast<unsigned long long>(__popcll(b)));
+      return;
+    }
+    if (!start) return;
+    uint64_t s = ctx_hash2(g, log2_slots);
+    for (uint64_t probes = 0; probes <= mask; probes++, s = (s + 1) & mask) {
+      // every distinct key is inserted exactly once (equal keys are contiguous), so a taken slot is simply passed over
+      if (atomicCAS(slots + 4 * s, 0ull, static_cast<unsigned long long>(g.lo)) == 0ull) {
+        slots[4 * s + 1] = g.hi;
+        slots[4 * s + 2] = uint64_t(row) & kCtxFirstMask;
+        return;
+      }
+    }
+    return;
+  }
+  CtxKey2 next = ctx_shfl2(g, 1, false);
+  if ((threadIdx.x & 63u) == 63u || row + 1 >= row0 + n) next = in ? ctx_gram2_of_row(ix, row + 1, H, nstop) : zero;
+  if (!in || g == zero || g == next) return;
+  uint64_t s = ctx_hash2(g, log2_slots);
+  for (uint64_t probes = 0; probes <= mask; probes++, s = (s + 1) & mask) {
+    const uint64_t klo = slots[4 * s];
+    if (klo == 0) return;
+    if (klo == g.lo && slots[4 * s + 1] == g.hi) {
+      const uint64_t first = slots[4 * s + 2] & kCtxFirstMask;
+      const uint64_t rows = uint64_t(row) >= first ? uint64_t(row) - first + 1 : 0;   // (0 only on a damaged index)
+      slots[4 * s + 2] = first | ((rows < kCtxBig ? rows : kCtxBig) << 40);
+      return;
+    }
+  }
+}
+
+// 1: found (first, last set); 0: the H-gram does not occur; -1: too many rows for the value field
+__device__ __forceinline__ int ctx2_lookup(const DevIndex& ix, const CtxKey2& key, int64_t& first, int64_t& last) {
+  const int lg = ix.ctx2_log2;
+  const uint64_t mask = (uint64_t(1) << lg) - 1;
+  uint64_t s = ctx_hash2(key, lg);
+  for (uint64_t probes = 0; probes <= mask; probes++, s = (s + 1) & mask) {
+    const ulonglong2 e = reinterpret_cast<const ulonglong2*>(ix.ctx2)[2 * s];
+    trace_touch(ix, kTraceCtx, uint64_t(ix.ctx2_trace_off) + (s >> 2));
+    if (e.x == 0) return 0;
+    if (e.x == key.lo && e.y == key.hi) {
+      const uint64_t v = ix.ctx2[4 * s + 2];
+      const uint64_t rows = v >> 40;
+      if (rows == kCtxBig) return -1;
+      first = int64_t(v & kCtxFirstMask);
+      last = first + int64_t(rows) - 1;
+      return 1;
+    }
   }
   return 0;
 }

@@ -161,19 +161,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, 
     int64_t first = 0, last = ix.total_length - 1;
     int j = 0;
     if (ix.ctx && len >= ix.ctx_syms) {     // byte alphabets: the last H symbols as one hashed read (ctx_kernels.hip.hpp)
-      const int H = ix.ctx_syms;
+      const int H1 = ix.ctx_syms, H2 = (ix.ctx2 && len >= ix.ctx2_syms) ? ix.ctx2_syms : 0;
+      const int HH = H2 ? H2 : H1;
       const uint32_t nstop = uint32_t(ix.ctx_nstop);
-      uint64_t key = 0;
-      bool ok = true;
-      for (int i = 0; i < H; i++) {
-        const uint32_t ch = symbol(i);
+      const int bits = ix.ctx_bits;
+      uint64_t key1 = 0;
+      CtxKey2 key2{0, 0};
+      int okn = 0;                           // leading symbols (from the end) that are table characters
+      for (; okn < HH; okn++) {
+        const uint32_t ch = symbol(okn);
         const uint32_t code = ch < uint32_t(kAlphaSize) ? uint32_t(s_code[ch]) : 0xffffu;
-        if (code == 0xffffu || code < nstop) { ok = false; break; }
-        key |= uint64_t(code - nstop + 1u) << (ix.ctx_bits * i);
+        if (code == 0xffffu || code < nstop) break;
+        const uint64_t field = uint64_t(code - nstop + 1u);
+        if (okn < H1) key1 |= field << (bits * okn);
+        if (H2) ctx_key2_or(key2, field, bits * okn);
       }
-      // a miss means the range dies within these H steps; the level table / the steps below then find where, because the
-      // reference's (first, last) of an empty range are those of the step that emptied it
-      if (ok && ctx_lookup(ix, key, first, last) == 1) j = H;
+      // A miss means the range dies within these symbols; the shorter table / the level table / the steps below then find
+      // where, because the reference's (first, last) of an empty range are those of the step that emptied it.
+      if (H2 && okn == H2 && ctx2_lookup(ix, key2, first, last) == 1) j = H2;
+      else if (okn >= H1 && ctx_lookup(ix, key1, first, last) == 1) j = H1;
     }
     if (j == 0 && ix.ktab2) {
       const int kmax = len < ix.kt2_syms ? len : ix.kt2_syms;

@@ -226,8 +226,9 @@ struct femto_amd_index {
   int64_t* d_ktab2 = nullptr;
   int64_t* d_ktab2_deep = nullptr;
   int64_t ktab2_bytes = 0;
-  uint64_t* d_ctx = nullptr;     // context table of byte alphabets (ctx_kernels.hip.hpp)
-  int64_t ctx_bytes = 0, ctx_entries = 0;
+  uint64_t* d_ctx = nullptr;     // context tables of byte alphabets (ctx_kernels.hip.hpp)
+  uint64_t* d_ctx2 = nullptr;
+  int64_t ctx_bytes = 0, ctx_entries = 0, ctx2_bytes = 0;
   double ctx_build_ms = 0;
   uint8_t* d_txt = nullptr;
   int64_t* d_isa8 = nullptr;
@@ -1100,6 +1101,72 @@ int build_ctx(femto_amd_index* ix, int nstop) {
     ix->ctx_bytes = bytes;
     ix->ctx_entries = int64_t(distinct);
     ix->ctx_build_ms = ms;
+    ix->table_bytes += bytes;
+    return 0;
+  }
+  return 0;
+}
+
+// The wide context table (two-word keys): H2 = the largest of min(16, 128 / bits, 12) .. H1 + 2 whose table (32-byte
+// slots, twice the distinct H2-grams) fits a quarter of the free HBM.  FEMTO_AMD_CTX2=0 disables, FEMTO_AMD_CTX2_SYMS=h forces.
+int build_ctx2(femto_amd_index* ix, int nstop) {
+  if (ix->dev.ctx2 || !ix->dev.ctx) return 0;
+  if (const char* e = getenv("FEMTO_AMD_CTX2")) if (atoi(e) == 0) return 0;
+  const int64_t n = ix->host.total_length;
+  const int bits = ix->dev.ctx_bits;
+  int hmax = std::min(12, std::min(16, 128 / bits)), hmin = ix->dev.ctx_syms + 2;
+  if (const char* e = getenv("FEMTO_AMD_CTX2_SYMS")) hmax = hmin = std::max(ix->dev.ctx_syms + 1, std::min(std::min(16, 128 / bits), atoi(e)));
+  if (hmin > hmax) return 0;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+  const int64_t budget = int64_t(free_b / 4);
+  DeviceBuffer cnt;
+  int rc = cnt.reserve(8);
+  if (rc) return rc;
+  const int64_t chunk = int64_t(1) << 30;
+  const DevIndex d = ix->dev;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  EventPair ep{e0, e1};
+  HIP_TRY(hipEventRecord(e0, nullptr));
+  auto pass = [&](int H, int which, unsigned long long* slots, int lg) {
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+      const int64_t cn = std::min(chunk, n - r0);
+      hipLaunchKernelGGL(ctx2_build_kernel, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, d, r0, cn, H, uint32_t(nstop), which,
+                         static_cast<unsigned long long*>(cnt.p), slots, lg);
+    }
+  };
+  for (int H = hmax; H >= hmin; H--) {
+    HIP_TRY(hipMemsetAsync(cnt.p, 0, 8, nullptr));
+    pass(H, 0, nullptr, 4);
+    HIP_TRY(hipGetLastError());
+    unsigned long long distinct = 0;
+    HIP_TRY(hipMemcpy(&distinct, cnt.p, 8, hipMemcpyDeviceToHost));
+    if (distinct == 0) continue;
+    int lg = 4;
+    while ((uint64_t(1) << lg) < 2 * distinct) lg++;
+    const int64_t bytes = (int64_t(1) << lg) * 32;
+    if (bytes > budget || lg > 40) continue;
+    if (big_malloc(ix, reinterpret_cast<void**>(&ix->d_ctx2), size_t(bytes)) != hipSuccess) {
+      (void)hipGetLastError();
+      ix->d_ctx2 = nullptr;
+      continue;
+    }
+    HIP_TRY(big_memset(ix, ix->d_ctx2, 0, size_t(bytes)));
+    pass(H, 1, reinterpret_cast<unsigned long long*>(ix->d_ctx2), lg);
+    pass(H, 2, reinterpret_cast<unsigned long long*>(ix->d_ctx2), lg);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    ix->dev.ctx2 = ix->d_ctx2;
+    ix->dev.ctx2_log2 = lg;
+    ix->dev.ctx2_syms = H;
+    ix->dev.ctx2_trace_off = ix->ctx_bytes / 128;
+    ix->ctx2_bytes = bytes;
+    ix->ctx_build_ms += ms;
     ix->table_bytes += bytes;
     return 0;
   }
@@ -2032,6 +2099,7 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
       else if (ix->dev.p2_l1) r = build_ktab2<Pack2Policy>(ix, ix->dev.p2_sigma, int(ix->dev.p2_stop_below));
       if (r && r != FEMTO_AMD_ERR_MEM) return r;
       if (ix->dev.p2_l1 && !ix->dev.pack && (r = build_ctx(ix, int(ix->dev.p2_stop_below))) && r != FEMTO_AMD_ERR_MEM) return r;
+      if (ix->dev.ctx && (r = build_ctx2(ix, int(ix->dev.p2_stop_below))) && r != FEMTO_AMD_ERR_MEM) return r;
       for (DeviceBuffer& b : ix->open_scan) b.release();
       if (const char* m = getenv("FEMTO_AMD_RANK_MODE")) {
         if (!strcmp(m, "raw")) ix->mode = 0;
@@ -2208,7 +2276,7 @@ void femto_amd_close(femto_amd_index_t* ix) {
       for (void* q : {static_cast<void*>(ix->d_image), static_cast<void*>(ix->d_segs), static_cast<void*>(ix->d_pack), static_cast<void*>(ix->d_pack_sa),
                       static_cast<void*>(ix->d_txt), static_cast<void*>(ix->d_isa8), static_cast<void*>(ix->d_p2_l1), static_cast<void*>(ix->d_p2_l2),
                       static_cast<void*>(ix->d_ktab2), static_cast<void*>(ix->d_ktab2_deep), static_cast<void*>(ix->d_sa_full), static_cast<void*>(ix->d_ind),
-                      static_cast<void*>(ix->d_ctx)})
+                      static_cast<void*>(ix->d_ctx), static_cast<void*>(ix->d_ctx2)})
         big_free(ix, q);
       for (void* q : {static_cast<void*>(ix->d_nodes), static_cast<void*>(ix->d_buckets), static_cast<void*>(ix->d_seqs), static_cast<void*>(ix->d_occ_base),
                       static_cast<void*>(ix->d_leaf_code), static_cast<void*>(ix->d_C), static_cast<void*>(ix->d_cum), static_cast<void*>(ix->d_hint),
@@ -2739,7 +2807,7 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
   region_lines[kTraceL2] = ix->p2_lines2;
   region_lines[kTraceTxt] = ix->dev.txt ? (n + 64) / 128 + 1 : 0;
   region_lines[kTraceIsa] = ix->dev.isa8 ? ((n >> ix->dev.isa_shift) + 2) / 16 + 1 : 0;
-  region_lines[kTraceCtx] = ix->ctx_bytes / 128;
+  region_lines[kTraceCtx] = ix->ctx_bytes / 128 + ix->ctx2_bytes / 128;
   region_lines[kTraceKtab1] = ix->dev.ktab ? ((int64_t(1) << ix->dev.ktab_bits) * 16) / 128 + 1 : 0;
   int64_t off[kTraceRegions + 1];
   off[0] = 0;
@@ -3005,7 +3073,7 @@ static int make_view(femto_amd_index* b, int device, femto_amd_index** out) {
   h.block_off = s.block_off; h.block_len = s.block_len;
   v->mode = b->mode; v->direct = b->direct; v->sort_queries = b->sort_queries; v->dense_bits = b->dense_bits;
   v->dense_sigma = b->dense_sigma; v->sort_min = b->sort_min; v->h_dense = b->h_dense; v->table_bytes = b->table_bytes;
-  v->ktab2_bytes = b->ktab2_bytes; v->ctx_bytes = b->ctx_bytes; v->n_marks = b->n_marks; v->p2_lines1 = b->p2_lines1; v->p2_lines2 = b->p2_lines2;
+  v->ktab2_bytes = b->ktab2_bytes; v->ctx_bytes = b->ctx_bytes; v->ctx2_bytes = b->ctx2_bytes; v->n_marks = b->n_marks; v->p2_lines1 = b->p2_lines1; v->p2_lines2 = b->p2_lines2;
   v->ind_bytes = b->ind_bytes; v->text_bytes = b->text_bytes; v->pack_bytes = b->pack_bytes; v->pack2_bytes = b->pack2_bytes;
   v->blocks_per_cu_override = b->blocks_per_cu_override;
   if (hipSetDevice(device) != hipSuccess) return fail(set_err(FEMTO_AMD_ERR_INVALID, "no usable HIP device " + std::to_string(device)));
@@ -3177,6 +3245,7 @@ int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* by
   if (available && ix->dev.ktab2) *available |= 4;   // bit 2: the level table of the direct pipeline exists
   if (available && ix->dev.ind) *available |= 32;     // bit 5: per-character rank lines (byte alphabets)
   if (available && ix->dev.ctx) *available |= 64 | (ix->dev.ctx_syms << 8);   // bit 6: context table; bits 8-11: its H
+  if (available && ix->dev.ctx2) *available |= ix->dev.ctx2_syms << 12;        // bits 12-16: H2 of the wide context table
   if (available && ix->dev.sa_full) *available |= 8;  // bit 3: the full suffix array is resident
   if (available && ix->dev.isa8 && ix->dev.isa_shift == 0) *available |= 16;   // bit 4: the full inverse suffix array
   if (bytes) *bytes = ix->pack_bytes + ix->pack2_bytes;

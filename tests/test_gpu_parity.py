@@ -588,7 +588,8 @@ def test_context_table_matches_steps(tmp_path, gpu_ok, monkeypatch):
     ix = femto_amd.Index(path, device=0)
     pi = ix.pack_info()
     assert ix.rank_mode == 4 and pi["sa_full"] and pi["context_table"] and 5 <= pi["context_syms"] <= 12, pi
-    H = pi["context_syms"]
+    assert pi["context_syms"] < pi["context2_syms"] <= 16, pi      # ... and the wide table behind it
+    H = pi["context2_syms"]
     rng = np.random.Generator(np.random.PCG64(77))
     plen, flat = tg.p_hit(1, 40, 30000, 9, text)
     pats = [flat[s:s + l] for s, l in zip(tg.starts_of(plen), plen)]
