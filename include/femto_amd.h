@@ -123,7 +123,9 @@ int femto_amd_document_info(const femto_amd_index_t* ix, int64_t doc, const char
 
 /* ---- device-pointer batch API (inputs and outputs already resident in HBM) ---------------- */
 /* All pointers are device pointers on the index's device; `stream` is a hipStream_t passed as
- * void* (NULL = default stream).  Calls only enqueue work and return; the caller synchronises. */
+ * void* (NULL = default stream).  Calls only enqueue work and return; the caller synchronises.
+ * Nothing is reported to the host afterwards: a pattern holding a symbol >= 261 (which the host-pointer
+ * calls reject with FEMTO_AMD_ERR_PARAM) has the empty range first = 0, last = -1. */
 int femto_amd_count_device(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen,
                            const uint16_t* d_pats, const int64_t* d_starts,
                            int64_t* d_first, int64_t* d_last, void* stream);
