@@ -208,34 +208,63 @@ class Batch:
         self.d_wire2[buf].copy_(self.d_res)
         return self.d_wire2[buf]
 
-    def wire_results(self, rows, cap, buf=0):
+    def wire_layout(self, rows, cap, bigcap):
+        """byte offsets of the gathered buffer: [rows located i64 | n_big i64 | (pattern, count) i64 pairs x bigcap |
+        offsets (i32 below 2^31 - 1 rows, else i64) x cap | counts u8 x n | pad to 8]"""
+        esz = 4 if rows < (1 << 31) - 1 else 8
+        o_big = 16
+        o_off = o_big + 16 * bigcap
+        o_cnt = o_off + esz * cap
+        nbytes = (o_cnt + self.n + 7) & ~7
+        return esz, o_big, o_off, o_cnt, nbytes
+
+    def wire_results(self, rows, cap, buf=0, bigcap=1024, ix=None, stream=0):
         """What north_star calls the results -- the match count of every pattern and the located text offsets -- as ONE
-        buffer for the gather: [total rows i64 | counts | offsets[:cap]], counts and offsets narrowed to int32 when the index
-        has fewer than 2^31 - 1 rows (lossless).  `cap` is the same on every rank (max of the ranks' totals + slack, agreed in
-        the untimed settle phase).  Half the bytes of the (first,last) form for a batch that locates few rows."""
+        buffer for the gather.  Match counts travel as one byte each (255 = see the list of (pattern, count) pairs for the
+        patterns with 255 matches or more: femto_amd_pack_counts_device), offsets as int32 when the index has fewer than
+        2^31 - 1 rows; all lossless.  `cap` / `bigcap` are the same on every rank (max over the ranks + slack, agreed in the
+        untimed settle phase).  10 MB per 10 M patterns + 4 B per located row, against 160 MB for the (first,last) ranges."""
         t = self.torch
-        small = rows < (1 << 31) - 1
-        dt = t.int32 if small else t.int64
-        if self.w_res is None or self.w_cap != cap:
-            esz = 4 if small else 8
-            nbytes = 8 + esz * (self.n + cap)
-            self.w_res = [t.zeros(nbytes + 8, dtype=t.uint8, device=self.dev) for _ in range(2)]
-            self.w_cap = cap
-            self.w_tmp = t.empty(self.n, dtype=t.int64, device=self.dev)
+        esz, o_big, o_off, o_cnt, nbytes = self.wire_layout(rows, cap, bigcap)
+        dt = t.int32 if esz == 4 else t.int64
+        if self.w_res is None or self.w_cap != (cap, bigcap):
+            self.w_res = [t.zeros(nbytes, dtype=t.uint8, device=self.dev) for _ in range(2)]
+            self.w_cap = (cap, bigcap)
             self.w_views = []
             for w in self.w_res:
-                tot = w[:8].view(t.int64)
-                cnt = w[8:8 + esz * self.n].view(dt)
-                off = w[8 + esz * self.n:8 + esz * (self.n + cap)].view(dt)
-                self.w_views.append((tot, cnt, off))
-        tot, cnt, off = self.w_views[buf]
-        t.sub(self.d_res[1], self.d_res[0], out=self.w_tmp)
-        self.w_tmp.add_(1).clamp_(min=0)                   # match count: last - first + 1, 0 when there is no match
-        cnt.copy_(self.w_tmp)
+                self.w_views.append((w[:8].view(t.int64), w[8:16].view(t.int64), w[o_big:o_off].view(t.int64),
+                                     w[o_off:o_cnt].view(dt), w[o_cnt:o_cnt + self.n]))
+        tot, nbig, big, off, cnt = self.w_views[buf]
+        if ix is not None and cnt.is_cuda:
+            ix.pack_counts_device(self.n, self.d_res[0].data_ptr(), self.d_res[1].data_ptr(), cnt.data_ptr(), big.data_ptr(), bigcap,
+                                  nbig.data_ptr(), stream)
+        else:      # the same format with torch operators (CPU tensors: the gloo tests)
+            c = (self.d_res[1] - self.d_res[0] + 1).clamp_(min=0)
+            cnt.copy_(c.clamp(max=255))
+            idx = t.nonzero(c >= 255).flatten()
+            nbig.fill_(int(idx.numel()))
+            k = min(int(idx.numel()), bigcap)
+            if k:
+                big[0:2 * k:2] = idx[:k]
+                big[1:2 * k:2] = c[idx[:k]]
         tot.copy_(self.d_total[:1])
         k = min(cap, self.offsets.numel())
         off[:k].copy_(self.offsets[:k])
         return self.w_res[buf]
+
+    def unwire_results(self, raw, rows, cap, bigcap):
+        """(rows located, match counts int64[n], offsets int64[min(rows located, cap)]) from one rank's gathered buffer"""
+        esz, o_big, o_off, o_cnt, nbytes = self.wire_layout(rows, cap, bigcap)
+        raw = np.ascontiguousarray(raw)
+        assert raw.dtype == np.uint8 and raw.size == nbytes
+        tot = int(raw[:8].view(np.int64)[0])
+        nbig = int(raw[8:16].view(np.int64)[0])
+        assert nbig <= bigcap, "more patterns with >= 255 matches than the agreed list holds"
+        cnt = raw[o_cnt:o_cnt + self.n].astype(np.int64)
+        pairs = raw[o_big:o_big + 16 * nbig].view(np.int64).reshape(-1, 2)
+        cnt[pairs[:, 0]] = pairs[:, 1]
+        off = raw[o_off:o_cnt].view(np.int32 if esz == 4 else np.int64)[:min(tot, cap)].astype(np.int64)
+        return tot, cnt, off
 
 
 def main():
@@ -352,7 +381,7 @@ def main():
         torch.cuda.synchronize()
         ix.close()
         return
-    cap = 0
+    cap, bigcap = 0, 1024
     if world > 1 and args.results == "counts":     # untimed: every rank's row total, the common capacity of the gathered offsets
         batch.settle(ix, args.max_occs, torch.cuda.current_stream().cuda_stream)
         tcap = torch.tensor([batch.total], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
@@ -360,10 +389,13 @@ def main():
         cap = int(tcap.item() * 1.25) + 1024
         if batch.offsets.numel() < cap:
             batch.offsets = torch.empty(cap, dtype=torch.int64, device=dev)
+        nbig = ((batch.d_res[1] - batch.d_res[0]) >= 254).sum().to(tcap.device).reshape(1)
+        dist.all_reduce(nbig, op=dist.ReduceOp.MAX)
+        bigcap = int(nbig.item() * 1.25) + 1024
 
     def payload_of(b=0):
         if args.results == "counts":
-            return batch.wire_results(info.total_length, cap, b)
+            return batch.wire_results(info.total_length, cap, b, bigcap, ix, torch.cuda.current_stream().cuda_stream)
         return batch.wire(info.total_length, b)
 
     gather_lists = None
@@ -453,6 +485,19 @@ def main():
     g_ost = batch.d_ostarts.cpu().numpy()
     g_offs = batch.offsets[:batch.total].cpu().numpy()
     value = world * npats * args.steps / elapsed
+    gathered_ok = None
+    if world > 1 and args.results == "counts" and counter["k"]:
+        # what arrived on rank 0 in the last step: every rank's buffer decodes, and rank 0's own slot equals its local results
+        b_last = (counter["k"] - 1) & 1
+        slots = recv_native[b_last] if native else gather_lists[b_last]
+        gathered_ok = True
+        for r in range(world):
+            tot_r, cnt_r, off_r = batch.unwire_results(slots[r].cpu().numpy(), info.total_length, cap, bigcap)
+            gathered_ok = gathered_ok and tot_r >= 0 and int(cnt_r.min()) >= 0
+            if r == 0:
+                gathered_ok = (gathered_ok and tot_r == batch.total and np.array_equal(cnt_r, np.maximum(last - first + 1, 0))
+                               and np.array_equal(off_r, g_offs[:len(off_r)]))
+        assert gathered_ok, "the gathered results do not decode to rank 0's own results"
 
     # ---- secondary line: every pattern occurs and is located (same index, P_hit 20-mers)
     extra = None
@@ -627,7 +672,7 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int64", "data": "synthetic",
         "config": {"workload": wl, "text_bytes": n_text, "patterns_per_gpu": npats, "pattern_len": args.plen, "seed": args.seed,
-                   "located_rows_per_gpu": batch.total, "matched_patterns_frac": float(np.mean(last >= first)),
+                   "located_rows_per_gpu": batch.total, "gathered_results_verified": gathered_ok, "matched_patterns_frac": float(np.mean(last >= first)),
                    "rank_mode": {4: "pack2", 3: "pack", 1: "lane", 2: "flat", 0: "raw"}[ix.rank_mode], "index": {"rows": int(info.total_length), "blocks": int(info.number_of_blocks), "buckets": int(info.total_buckets),
                              "image_bytes": int(info.image_bytes), "table_bytes": int(info.table_bytes),
                              "packed_lines": ix.pack_info()},

@@ -75,6 +75,7 @@ def lib():
         L.femto_amd_locate_plan_device.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, vp, vp, vp]
         L.femto_amd_locate_walk_device.argtypes = [vp, i64, vp, vp, i64, vp, vp]
         L.femto_amd_locate_device.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, vp, vp]
+        L.femto_amd_pack_counts_device.argtypes = [vp, i64, vp, vp, vp, vp, i64, vp, vp]
         L.femto_amd_trace_lines.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, C.POINTER(i64)]
         L.femto_amd_open_multi.argtypes = [C.c_char_p, i32, vp, C.POINTER(vp)]
         L.femto_amd_open_multi_striped.argtypes = [C.c_char_p, i32, vp, C.POINTER(vp)]
@@ -301,6 +302,11 @@ class Index:
                            stream=0):
         _check(lib().femto_amd_locate_plan_device(self._h, npats, d_plen, d_pats, d_starts, max_occs, d_first, d_last,
                                                   d_noccs, d_out_starts, stream or None))
+
+    def pack_counts_device(self, npats, d_first, d_last, d_counts8, d_big, big_capacity, d_big_n, stream=0):
+        """match counts as one byte per pattern + (pattern, count) pairs for counts >= 255 (femto_amd_pack_counts_device)"""
+        _check(lib().femto_amd_pack_counts_device(self._h, npats, d_first, d_last, d_counts8, d_big or None, big_capacity, d_big_n,
+                                                  stream or None))
 
     def locate_walk_device(self, npats, d_first, d_out_starts, total, d_offsets, stream=0):
         _check(lib().femto_amd_locate_walk_device(self._h, npats, d_first, d_out_starts, total, d_offsets,

@@ -433,6 +433,27 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t n, int64_
   }
 }
 
+// The match counts of a batch in the form they travel to another GPU (the result gather of a multi-GPU run): ONE byte per
+// pattern -- last - first + 1, 0 when there is no match, 255 = "255 or more: see the list" -- and the patterns with 255
+// matches or more appended to a list of (pattern, count) pairs (order unspecified; *big_n counts them even beyond
+// big_cap, so the receiver sees an overflow).  Lossless, 1 byte instead of 16 per pattern on the links.
+__global__ __launch_bounds__(256) void pack_counts_kernel(const int64_t n, const int64_t* __restrict__ first, const int64_t* __restrict__ last,
+                                                          uint8_t* __restrict__ counts8, int64_t* __restrict__ big, const int64_t big_cap,
+                                                          unsigned long long* __restrict__ big_n) {
+  const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  int64_t c = last[q] - first[q] + 1;
+  if (c < 0) c = 0;
+  counts8[q] = uint8_t(c < 255 ? c : 255);
+  if (c >= 255) {
+    const unsigned long long k = atomicAdd(big_n, 1ull);
+    if (int64_t(k) < big_cap) {
+      big[2 * k] = q;
+      big[2 * k + 1] = c;
+    }
+  }
+}
+
 // set bits of trace words [w0, w1) added to *out (femto_amd_trace_lines)
 __global__ __launch_bounds__(256) void trace_popcount_kernel(const uint32_t* __restrict__ bitmap, const int64_t w0, const int64_t w1,
                                                              unsigned long long* __restrict__ out) {

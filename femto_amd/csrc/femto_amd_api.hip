@@ -2499,6 +2499,25 @@ int femto_amd_locate_device(femto_amd_index_t* ix, int64_t npats, const int32_t*
   API_END
 }
 
+int femto_amd_pack_counts_device(femto_amd_index_t* ix, int64_t npats, const int64_t* d_first, const int64_t* d_last, uint8_t* d_counts8,
+                                 int64_t* d_big, int64_t big_capacity, int64_t* d_big_n, void* stream_) {
+  API_BEGIN
+  if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
+  if (npats < 0 || big_capacity < 0 || !d_big_n || (npats && (!d_first || !d_last || !d_counts8)) || (big_capacity && !d_big))
+    return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
+  int rc = ensure_device(ix);
+  if (rc) return rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  HIP_TRY(hipMemsetAsync(d_big_n, 0, sizeof(int64_t), stream));
+  if (npats) {
+    hipLaunchKernelGGL(pack_counts_kernel, dim3(uint32_t((npats + 255) / 256)), dim3(256), 0, stream, npats, d_first, d_last, d_counts8, d_big,
+                       big_capacity, reinterpret_cast<unsigned long long*>(d_big_n));
+    HIP_TRY(hipGetLastError());
+  }
+  return FEMTO_AMD_OK;
+  API_END
+}
+
 int femto_amd_locate_flat(femto_amd_index_t* ix, int64_t npats, const int32_t* plen, const uint16_t* pats,
                           const int64_t* starts, int max_occs_each, int32_t* noccs, int64_t* out_starts,
                           int64_t* offsets, int64_t offsets_capacity, int64_t* total_out) {

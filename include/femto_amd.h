@@ -244,6 +244,14 @@ int femto_amd_comm_unique_id(void* id128);
 int femto_amd_comm_init(femto_amd_index_t* ix, const void* id128, int nranks, int rank);
 int femto_amd_comm_gather(femto_amd_index_t* ix, const void* d_send, void* d_recv, int64_t bytes_per_rank, int root, void* stream);
 
+/* The match counts of a batch in the form a result gather sends ("one RCCL collective for results";
+ * parallel_count's last == NULL form, src/main/femto.c:313-318, narrowed): d_counts8[i] = min(last[i] - first[i] + 1, 255),
+ * 0 when there is no match; every pattern with 255 matches or more is appended to d_big as a pair (pattern index, count),
+ * in no particular order, and *d_big_n receives how many there are (pairs beyond big_capacity are not written).  Lossless;
+ * one byte per pattern on the links.  Enqueue-only, device pointers. */
+int femto_amd_pack_counts_device(femto_amd_index_t* ix, int64_t npats, const int64_t* d_first, const int64_t* d_last,
+                                 uint8_t* d_counts8, int64_t* d_big, int64_t big_capacity, int64_t* d_big_n, void* stream);
+
 /* ---- kernel family ---------------------------------------------------------------------------- */
 /* Five kernel families, all bit-exact; the default at open is the fastest that applies (mode 3 for <= 8 distinct
  * characters, mode 4 for <= 256, else mode 1); FEMTO_AMD_RANK_MODE=pack|pack2|lane|flat|raw overrides it.

@@ -84,6 +84,7 @@ def _wire_worker(rank, world, port, q):
     first = rng.integers(0, 1 << 30, n)
     last = first + rng.integers(-1, 50, n)
     first[0], last[0] = 0, -1                      # the "no match / error" encoding must survive the narrowing
+    last[5], last[77] = first[5] + 254, first[77] + 123456789      # 255 matches and more: the (pattern, count) list
     b.d_res = b.d_res2[1]
     b.d_res.copy_(torch.from_numpy(np.stack([first, last])))
     small = b.wire((1 << 30) + 1, 1)
@@ -97,8 +98,9 @@ def _wire_worker(rank, world, port, q):
     cap = 64
     b.offsets = torch.arange(100 * rank, 100 * rank + cap, dtype=torch.int64)
     b.d_total = torch.tensor([40 + rank, 0], dtype=torch.int64)
-    res = b.wire_results((1 << 30) + 1, cap, 1)
-    assert res.dtype == torch.uint8 and res.numel() == 8 + 4 * (n + cap) + 8
+    bigcap = 8
+    res = b.wire_results((1 << 30) + 1, cap, 1, bigcap)
+    assert res.dtype == torch.uint8 and res.numel() == 16 + 16 * bigcap + 4 * cap + n      # one byte per match count
     out2 = [torch.empty_like(res) for _ in range(world)] if rank == 0 else None
     dist.gather(res, out2, dst=0, async_op=True).wait()
     if rank == 0:
@@ -108,12 +110,11 @@ def _wire_worker(rank, world, port, q):
             f = g.integers(0, 1 << 30, n)
             l_ = f + g.integers(-1, 50, n)
             f[0], l_[0] = 0, -1
+            l_[5], l_[77] = f[5] + 254, f[77] + 123456789
             ok = ok and np.array_equal(out[r][0].numpy(), f) and np.array_equal(out[r][1].numpy(), l_)
-            raw = out2[r].numpy()
-            tot = raw[:8].view(np.int64)[0]
-            cnt = raw[8:8 + 4 * n].view(np.int32)
-            off = raw[8 + 4 * n:8 + 4 * (n + cap)].view(np.int32)
-            ok = ok and tot == 40 + r and np.array_equal(cnt, np.maximum(l_ - f + 1, 0)) and np.array_equal(off, np.arange(100 * r, 100 * r + cap))
+            tot, cnt, off = b.unwire_results(out2[r].numpy(), (1 << 30) + 1, cap, bigcap)
+            ok = ok and tot == 40 + r and np.array_equal(cnt, np.maximum(l_ - f + 1, 0)) and cnt[5] == 255 and cnt[77] == 123456790
+            ok = ok and np.array_equal(off, np.arange(100 * r, 100 * r + min(cap, 40 + r)))
         q.put(bool(ok))
     dist.barrier()
     dist.destroy_process_group()

@@ -1156,10 +1156,39 @@ def test_search_cli(fixtures, tmp_path, gpu_ok):
     assert r.returncode != 0 and b"regular expressions are not supported" in r.stderr
 
 
+def test_pack_counts_device(fixtures, gpu_ok):
+    """femto_amd_pack_counts_device: one byte per match count, (pattern, count) pairs for 255 and more, overflow reported"""
+    import torch
+    fx = fixtures("acgt48k")
+    ix = femto_amd.Index(fx.index, device=0)
+    rng = np.random.Generator(np.random.PCG64(5))
+    n = 100_000
+    first = rng.integers(0, 1 << 40, n)
+    cnt = rng.integers(0, 300, n)
+    cnt[rng.integers(0, n, 50)] = rng.integers(1 << 20, 1 << 39, 50)
+    last = first + cnt - 1
+    last[cnt == 0] = first[cnt == 0] - rng.integers(1, 9, int((cnt == 0).sum()))      # first > last by any amount: no match
+    d_f, d_l = torch.from_numpy(first).cuda(), torch.from_numpy(last).cuda()
+    c8 = torch.full((n,), 7, dtype=torch.uint8, device="cuda:0")
+    nbig = int((cnt >= 255).sum())
+    for cap in (nbig + 10, nbig // 2):
+        big = torch.zeros(2 * max(cap, 1), dtype=torch.int64, device="cuda:0")
+        bn = torch.full((1,), -1, dtype=torch.int64, device="cuda:0")
+        ix.pack_counts_device(n, d_f.data_ptr(), d_l.data_ptr(), c8.data_ptr(), big.data_ptr(), cap, bn.data_ptr(),
+                              torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert int(bn.item()) == nbig                                   # counted even beyond the capacity
+        assert np.array_equal(c8.cpu().numpy(), np.minimum(cnt, 255).astype(np.uint8))
+        pairs = big.cpu().numpy().reshape(-1, 2)[:min(cap, nbig)]
+        assert len(set(pairs[:, 0].tolist())) == len(pairs) and (cnt[pairs[:, 0]] == pairs[:, 1]).all() and (pairs[:, 1] >= 255).all()
+    ix.close()
+
+
 def test_bench_two_ranks_control_flow(tmp_path, gpu_ok):
     """bench.py's N > 1 path (rank 0 builds, everybody opens, sharded steps, double-buffered gather of the narrowed
     ranges, max-over-ranks timing, one JSON line from rank 0) with two ranks sharing this box's GPU and the gather routed
-    through gloo -- the control flow the driver runs with RCCL on 2/4/8 GPUs."""
+    through gloo -- the control flow the driver runs with RCCL on 2/4/8 GPUs.  (Random 20-mers match next to nothing, so
+    the list of patterns with 255 matches or more stays empty here; tests/test_distributed.py fills it.)"""
     import json
     root = os.path.join(os.path.dirname(__file__), "..")
     env = dict(os.environ, FEMTO_AMD_BENCH_BACKEND="gloo", FEMTO_AMD_BENCH_DIR=str(tmp_path), MASTER_ADDR="127.0.0.1")
@@ -1170,3 +1199,6 @@ def test_bench_two_ranks_control_flow(tmp_path, gpu_ok):
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
     assert line["value"] > 0 and line["cpu_baseline"]["bit_exact_vs_gpu"] is True
     assert line["config"]["patterns_per_gpu"] == 200000
+    # the buffers that arrived on rank 0 (one byte per match count + offsets, femto_amd_pack_counts_device) decoded, and rank
+    # 0's own slot equalled its local results
+    assert line["config"]["gathered_results_verified"] is True
