@@ -536,7 +536,7 @@ def main():
                                         hf_.ctypes.data, hl_.ctypes.data)
             hs = time.perf_counter() - t0
             assert rc == 0
-        extra["host_pointer_count"] = {"what": "femto_amd_count_flat on the same 10M-pattern batch, pageable host arrays in and out (staging threads + PCIe + kernels, pipelined in 2M-pattern chunks)",
+        extra["host_pointer_count"] = {"what": "femto_amd_count_flat on the same 10M-pattern batch, pageable host arrays in and out (staging threads + PCIe + kernels, pipelined in 1M-pattern stages)",
                                        "value": npats / hs, "unit": "patterns/s", "ms": 1e3 * hs,
                                        "equal_to_device_path": bool(np.array_equal(hf_, first) and np.array_equal(hl_, last))}
         del hf_, hl_
@@ -568,7 +568,7 @@ def main():
                 "rank_mode": {4: "pack2", 3: "pack", 1: "lane", 2: "flat", 0: "raw"}[eix.rank_mode],
                 "value": npats * 3 / ee, "unit": "patterns/s", "ms_per_step": 1e3 * ee / 3, "located_rows": eb.total,
                 "count_kernel_ms": eix.kernel_time("count")[0], "locate_kernel_ms": eix.kernel_time("locate")[0],
-                "parity": "tests/test_gpu_parity.py (oracle, all modes); profiles/r01_cfg3_eng_1GiB_pack2_bench.json has the run with the reference timed beside it"}
+                "parity": "tests/test_gpu_parity.py (oracle, all modes); profiles/r02_eng_bench.json has the run with the reference timed beside it"}
             del eb
             eix.close()
         except Exception as ex:      # noqa: BLE001

@@ -247,3 +247,33 @@ int main(int argc, char** argv) {
         tf.extractall(fx_index)
     out = subprocess.run([str(exe), os.path.join(fx_index, "index")], capture_output=True, text=True, check=True).stdout
     assert "rc=0" in out and "docs=2" in out and "count rc=6" in out     # ERR_INVALID: no device behind this handle
+
+
+def test_worker_pool_runs_every_job_on_every_worker(tmp_path):
+    """host_pipeline.hpp's staging pool (spin, then sleep): 20 000 back-to-back jobs with pauses long enough for the workers
+    to fall asleep in between -- every worker runs every job exactly once, none is lost across the spin / sleep hand-over."""
+    src = tmp_path / "pool.cpp"
+    src.write_text('''
+#include "host_pipeline.hpp"
+#include <cstdio>
+int main() {
+  const int T = 4;
+  femto_amd::WorkerPool pool(T);
+  std::vector<long> acc(T, 0);
+  long want = 0;
+  for (int rep = 0; rep < 20000; rep++) {
+    pool.run([&](int t, int nt) { acc[size_t(t)] += t + rep % 3 + nt; });
+    for (int t = 0; t < T; t++) want += t + rep % 3 + T;
+    if (rep % 4000 == 0) std::this_thread::sleep_for(std::chrono::milliseconds(3));
+  }
+  long total = 0;
+  for (long v : acc) total += v;
+  std::printf("%s\\n", total == want ? "ok" : "MISMATCH");
+  return total != want;
+}
+''')
+    exe = tmp_path / "pool"
+    import subprocess
+    subprocess.run(["g++", "-std=c++17", "-O2", "-pthread", "-I", os.path.join(ROOT, "femto_amd", "csrc"), "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ok" in out.stdout
