@@ -281,9 +281,11 @@ def main():
     ap.add_argument("--workload", default="acgt", choices=["acgt", "acgt_hit", "eng"],
                     help="acgt = configs[1] (default, headline): random 20-mers; acgt_hit = same index, 20-mers sampled "
                          "from the text (every pattern is located); eng = configs[2]: sigma~96 text, sampled lengths 8..64")
-    ap.add_argument("--layout", default="replicated", choices=["replicated", "split"],
-                    help="split: range-split index (BASELINE configs[4]) -- every rank keeps 1/N of the blocks and reads the "
-                         "rest from its peers' HBM over xGMI (femto_amd.parallel.open_range_split)")
+    ap.add_argument("--layout", default="replicated", choices=["replicated", "striped", "split"],
+                    help="striped: ONE index spread over the HBM of the N GPUs (BASELINE configs[4]) -- rank 0 derives it, every "
+                         "big array one address range with 1/N of its pages per GPU, the other ranks map the stripes "
+                         "(femto_amd.parallel.open_striped_shared); all fast paths, remote lines over xGMI.  split: the round-1 "
+                         "form, 1/N of the blocks per rank through hipIpc handles, wavelet-path kernels (open_range_split)")
     ap.add_argument("--ref-sample", type=int, default=100_000, help="patterns per timed pass of the genuine reference (3 passes + warm-up)")
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"], help="auto: roofline.traffic from live rocprofv3 --pmc passes (N=1)")
     ap.add_argument("--pmc-child", action="store_true", help="internal: the short run the PMC passes profile")
@@ -351,9 +353,15 @@ def main():
     if world > 1:
         dist.barrier()
     t0 = time.time()
+    ix_keep = None
     if args.layout == "split" and world > 1:
         from femto_amd import parallel as fpar
         ix = fpar.open_range_split(index_path, local_rank)
+    elif args.layout == "striped" and world > 1:
+        from femto_amd import parallel as fpar
+        ndev = torch.cuda.device_count()
+        ix, ix_keep = fpar.open_striped_shared(index_path, local_rank, os.path.join(args.workdir, "stripes.sock"),
+                                               devices=[r % ndev for r in range(world)])
     else:
         ix = femto_amd.Index(index_path, device=local_rank)
     open_s = time.time() - t0
@@ -676,7 +684,9 @@ def main():
                    "rank_mode": {4: "pack2", 3: "pack", 1: "lane", 2: "flat", 0: "raw"}[ix.rank_mode], "index": {"rows": int(info.total_length), "blocks": int(info.number_of_blocks), "buckets": int(info.total_buckets),
                              "image_bytes": int(info.image_bytes), "table_bytes": int(info.table_bytes),
                              "packed_lines": ix.pack_info()},
-                   "parallelism": ("range-split index (1/N of the blocks per GPU, peer loads over xGMI)" if args.layout == "split" and world > 1 else "replicated index") + f", query shards x{world}" + ((", RCCL gather of the results to rank 0 every step (32-bit when the index has < 2^31 rows), overlapped with the next step's kernels"
+                   "parallelism": ("range-split index (1/N of the blocks per GPU, peer loads over xGMI)" if args.layout == "split" and world > 1 else
+                                   "striped index (every big array 1/N per GPU, one address range, shared between the ranks; remote lines over xGMI)"
+                                   if args.layout == "striped" and world > 1 else "replicated index") + f", query shards x{world}" + ((", RCCL gather of the results to rank 0 every step (32-bit when the index has < 2^31 rows), overlapped with the next step's kernels"
                                                                                   + ("; gather = femto_amd_comm_gather (grouped ncclSend/ncclRecv)" if native else "; gather = torch.distributed.gather") + (
                                                                                   "; payload = match counts + located offsets" if args.results == "counts" else "; payload = (first,last) ranges")) if world > 1 else ""),
                    "build_s": build_s, "open_s": open_s},

@@ -79,6 +79,9 @@ def lib():
         L.femto_amd_trace_lines.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, C.POINTER(i64)]
         L.femto_amd_open_multi.argtypes = [C.c_char_p, i32, vp, C.POINTER(vp)]
         L.femto_amd_open_multi_striped.argtypes = [C.c_char_p, i32, vp, C.POINTER(vp)]
+        L.femto_amd_striped_serve.argtypes = [vp, C.c_char_p, i32]
+        L.femto_amd_open_striped_client.argtypes = [C.c_char_p, C.c_char_p, i32, i32, C.POINTER(vp)]
+        L.femto_amd_multi_child.argtypes = [vp, i32, C.POINTER(vp)]
         L.femto_amd_device_count.argtypes = [vp]
         L.femto_amd_comm_unique_id.argtypes = [vp]
         L.femto_amd_comm_init.argtypes = [vp, vp, i32, i32]
@@ -140,10 +143,17 @@ def flatten(patterns):
 class Index:
     """A femto index resident in the HBM of one GPU.  device=-1 parses only (host logic tests)."""
 
-    def __init__(self, path, device=0, part=None, nparts=None, devices=None, striped=False):
+    def __init__(self, path, device=0, part=None, nparts=None, devices=None, striped=False, striped_socket=None, timeout_s=600,
+                 _borrowed=None):
         self._h = C.c_void_p()
         self._peers = []   # range-split: the parts attached in-process must outlive this handle's use
-        if devices is not None:     # one handle over several GPUs of this process (femto_amd_open_multi): host-pointer calls only
+        self._owner = None
+        if _borrowed is not None:   # replica of a multi-device handle (femto_amd_multi_child): closed with its parent
+            self._owner, self._h = _borrowed
+        elif striped_socket is not None:   # striped index built by ANOTHER process (femto_amd_open_striped_client)
+            _check(lib().femto_amd_open_striped_client(os.fsencode(path), os.fsencode(striped_socket), int(device), int(timeout_s),
+                                                       C.byref(self._h)))
+        elif devices is not None:     # one handle over several GPUs of this process (femto_amd_open_multi): host-pointer calls only
             arr = (C.c_int * len(devices))(*[int(d) for d in devices])
             fn = lib().femto_amd_open_multi_striped if striped else lib().femto_amd_open_multi
             _check(fn(os.fsencode(path), len(devices), arr, C.byref(self._h)))
@@ -180,7 +190,23 @@ class Index:
         _check(lib().femto_amd_split_info(self._h, C.byref(part), C.byref(nparts), C.byref(sb), C.byref(ib)))
         return {"part": part.value, "nparts": nparts.value, "seg_bytes": sb.value, "image_bytes": ib.value}
 
+    def striped_serve(self, socket_path, nclients):
+        """striped handle (devices=[...], striped=True): hand the stripes to `nclients` other processes (blocks until all
+        have attached; femto_amd_striped_serve)"""
+        _check(lib().femto_amd_striped_serve(self._h, os.fsencode(socket_path), int(nclients)))
+
+    def child(self, i):
+        """replica i of a multi-device handle as a single-GPU Index (borrowed: valid until this handle is closed)"""
+        h = C.c_void_p()
+        _check(lib().femto_amd_multi_child(self._h, int(i), C.byref(h)))
+        dev = self.device[i] if isinstance(self.device, (list, tuple)) else self.device
+        return Index(None, device=dev, _borrowed=(self, h))
+
     def close(self):
+        if self._owner is not None:
+            self._h = C.c_void_p()
+            self._owner = None
+            return
         if self._h:
             lib().femto_amd_close(self._h)
             self._h = C.c_void_p()

@@ -119,3 +119,28 @@ def open_range_split(path, device, group=None):
     ix.split_commit()
     dist.barrier(group=group)   # nobody queries before every owner's slices are mapped everywhere
     return ix
+
+
+def open_striped_shared(path, device, socket_path, group=None, devices=None):
+    """Open `path` STRIPED over the GPUs of the ranks of `group` (one process per GPU): rank 0 derives the index once,
+    every big array one address range whose pages are spread over all the GPUs (femto_amd_open_multi_striped), and hands
+    the stripes to the other ranks as file descriptors over the Unix socket `socket_path`; every rank gets a single-GPU
+    handle on its own device with all kernel families and fast paths -- remote lines travel over xGMI, no collective runs
+    during a query.  `devices`: the GPU of every rank, in rank order (default: rank r uses GPU r).
+    Returns (index, keepalive): keep `keepalive` referenced as long as the index is used (rank 0: the multi handle)."""
+    import femto_amd
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if devices is None:
+        devices = list(range(world))
+    if rank == 0:
+        multi = femto_amd.Index(path, devices=devices, striped=True)
+        multi.striped_serve(socket_path, world - 1)
+        ix = multi.child(0)
+        keep = multi
+    else:
+        ix = femto_amd.Index(path, device=device, striped_socket=socket_path)
+        keep = None
+    dist.barrier(group=group)
+    return ix, keep
+

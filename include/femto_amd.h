@@ -244,6 +244,19 @@ int femto_amd_comm_unique_id(void* id128);
 int femto_amd_comm_init(femto_amd_index_t* ix, const void* id128, int nranks, int rank);
 int femto_amd_comm_gather(femto_amd_index_t* ix, const void* d_send, void* d_recv, int64_t bytes_per_rank, int root, void* stream);
 
+/* A striped index shared between PROCESSES (one process per GPU; BASELINE.json configs[4], "index range-split across 8
+ * GPUs"; the owner of a stripe is position / chunk as the owner of a row is row / block_size in bsearch_block_rows,
+ * src/main/index.c:1613).  The process that called femto_amd_open_multi_striped serves `nclients` other processes: every
+ * physical stripe travels as a POSIX file descriptor over the Unix-domain socket `socket_path` (SCM_RIGHTS), with a
+ * description of the handle.  femto_amd_open_striped_client (index_path: the same index, for its header and document
+ * table) maps the stripes at the builder's addresses, copies the small tables to `device` and returns an ordinary
+ * single-GPU handle -- every kernel family and fast path, remote lines over xGMI; it waits up to timeout_s seconds for the
+ * builder's socket.  femto_amd_multi_child returns replica i of a multi-device handle (a borrowed single-GPU handle, valid
+ * until the parent is closed): replica 0 of a striped handle is the builder's own. */
+int femto_amd_striped_serve(femto_amd_index_t* ix, const char* socket_path, int nclients);
+int femto_amd_open_striped_client(const char* index_path, const char* socket_path, int device, int timeout_s, femto_amd_index_t** out);
+int femto_amd_multi_child(femto_amd_index_t* ix, int i, femto_amd_index_t** child);
+
 /* The match counts of a batch in the form a result gather sends ("one RCCL collective for results";
  * parallel_count's last == NULL form, src/main/femto.c:313-318, narrowed): d_counts8[i] = min(last[i] - first[i] + 1, 255),
  * 0 when there is no match; every pattern with 255 matches or more is appended to d_big as a pair (pattern index, count),

@@ -1114,6 +1114,24 @@ def test_range_split_across_processes(fixtures, gpu_ok, tmp_path):
         assert (tmp_path / f"ok{r}").exists()
 
 
+def test_striped_index_across_processes(fixtures, gpu_ok, tmp_path):
+    """Two PROCESSES (both on this box's single GPU) share ONE striped index: rank 0 derives it
+    (femto_amd_open_multi_striped, two stripes) and serves every stripe as a file descriptor over a Unix socket
+    (femto_amd_striped_serve); rank 1 maps them at the same addresses (femto_amd_open_striped_client) and answers the
+    golden batches on the packed lines (DNA fixture) and on the two-level lines + context tables (byte fixture) -- the
+    fast paths, not the wavelet path of the IPC range-split -- and through the enqueue-only device chain."""
+    script = os.path.join(os.path.dirname(__file__), "striped_worker.py")
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    args = [str(tmp_path)]
+    for name, mode in (("acgt48k", 3), ("eng2doc", 4)):
+        args += [fixtures(name).index, os.path.join(gold, f"{name}.npz"), str(mode)]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = _torchrun(2, [script] + args, env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    for r in range(2):
+        assert (tmp_path / f"ok{r}").exists()
+
+
 def test_search_cli(fixtures, tmp_path, gpu_ok):
     """femto_amd_search (femto_search's counterpart for literal patterns, search_tool.cc:1082-1113): --count,
     --matches, document list and --offsets; expected text derived from the document bytes themselves."""
@@ -1184,7 +1202,8 @@ def test_pack_counts_device(fixtures, gpu_ok):
     ix.close()
 
 
-def test_bench_two_ranks_control_flow(tmp_path, gpu_ok):
+@pytest.mark.parametrize("layout", ["replicated", "striped"])
+def test_bench_two_ranks_control_flow(tmp_path, gpu_ok, layout):
     """bench.py's N > 1 path (rank 0 builds, everybody opens, sharded steps, double-buffered gather of the narrowed
     ranges, max-over-ranks timing, one JSON line from rank 0) with two ranks sharing this box's GPU and the gather routed
     through gloo -- the control flow the driver runs with RCCL on 2/4/8 GPUs.  (Random 20-mers match next to nothing, so
@@ -1193,7 +1212,7 @@ def test_bench_two_ranks_control_flow(tmp_path, gpu_ok):
     root = os.path.join(os.path.dirname(__file__), "..")
     env = dict(os.environ, FEMTO_AMD_BENCH_BACKEND="gloo", FEMTO_AMD_BENCH_DIR=str(tmp_path), MASTER_ADDR="127.0.0.1")
     out = _torchrun(2, [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--text-log2", "22",
-                        "--npats", "200000", "--cpu-sample", "2000"], env, cwd=root)
+                        "--npats", "200000", "--cpu-sample", "2000", "--layout", layout], env, cwd=root)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
@@ -1202,3 +1221,4 @@ def test_bench_two_ranks_control_flow(tmp_path, gpu_ok):
     # the buffers that arrived on rank 0 (one byte per match count + offsets, femto_amd_pack_counts_device) decoded, and rank
     # 0's own slot equalled its local results
     assert line["config"]["gathered_results_verified"] is True
+    assert line["config"]["parallelism"].startswith("striped index" if layout == "striped" else "replicated index")
