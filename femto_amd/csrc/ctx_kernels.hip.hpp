@@ -47,7 +47,7 @@ __device__ __forceinline__ uint64_t ctx_gram(const DevIndex& ix, int64_t p, int 
   uint64_t key = 0;
   for (int i = 0; i < H; i++) {
     const uint32_t c = uint32_t((i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8))) & 0xffu);
-    if (c < nstop) return 0;
+    if (c < nstop || c - nstop + 1u >= (1u << bits)) return 0;     // (a code beyond the alphabet: an unwritten byte of a damaged index)
     key = (key << bits) | uint64_t(c - nstop + 1u);
   }
   return key;
@@ -175,7 +175,7 @@ __device__ __forceinline__ CtxKey2 ctx_gram2(const DevIndex& ix, int64_t p, int 
   const int bits = ix.ctx_bits;
   for (int i = 0; i < H; i++) {
     const uint32_t c = uint32_t((i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8))) & 0xffu);
-    if (c < nstop) return CtxKey2{0, 0};
+    if (c < nstop || c - nstop + 1u >= (1u << bits)) return CtxKey2{0, 0};
     ctx_key2_or(key, uint64_t(c - nstop + 1u), bits * (H - 1 - i));
   }
   return key;
