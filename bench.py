@@ -603,13 +603,12 @@ def main():
         # (the restatement's deterministic counters on a small single-thread sample), scaled to the measured rate
         csub = min(sample, 20_000)
         ctr = po.Counters()
-        o.count_flat(s_plen[:csub], s_flat, s_starts[:csub], threads=1, counters=ctr)
         o.locate_flat(s_plen[:csub], s_flat, s_starts[:csub], args.max_occs, threads=1, counters=ctr)
         cd = ctr.asdict()
         ref_work = {"sample": csub, "occ_per_pattern": cd["n_occ"] / csub, "bseq_rank_per_pattern": cd["n_rank"] / csub,
                     "lf_steps_per_pattern": cd["n_lf"] / csub, "mark_reads_per_pattern": cd["n_mark"] / csub,
                     "occ_per_s": value * cd["n_occ"] / csub,
-                    "what": "Occ / bseq_rank / LF-step / mark-read counts of femto's own algorithm (count + locate) for this batch, from "
+                    "what": "Occ / bseq_rank / LF-step / mark-read counts of femto's own algorithm (parallel_locate: search + locate walk) for this batch, from "
                             "oracle/femto_oracle.c's counters; occ_per_s = value x occ_per_pattern -- the reference-equivalent Occ rate, "
                             "not the number of lines this engine reads (see roofline)"}
         if po.have_ref():

@@ -971,15 +971,20 @@ int build_ktab2(femto_amd_index* ix, int sigma, int nstop) {
   if (t < 1) return 0;
   // the deepest level may hold up to four entries per row (measured on 10 M random DNA 20-mers over 2^30 rows: K = 15
   // 0.645 ms, K = 16 0.489 ms per count launch -- 78 % of random patterns then end at their table entry; 57 instead of
-  // 14 GB), the whole table at most a quarter of the free HBM
+  // 14 GB), the whole table at most a quarter of the free HBM ...
   int64_t level_cap = std::max<int64_t>(int64_t(1) << 16, ix->host.total_length * 4);
-  int64_t budget = INT64_MAX;
+  // ... except that the depths with at most ONE entry per row may take 60 % of it: on an 8 GiB DNA text (2^33 rows, 137 GB of
+  // dense arrays already resident) a quarter stops at K = 15, 60 % admits K = 16 (57 GB): 10 M sampled 20-mers 3.91 -> 3.22 ms
+  int64_t budget = INT64_MAX, budget_row = INT64_MAX;
   {
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = int64_t(free_b / 4);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      budget = int64_t(free_b / 4);
+      budget_row = int64_t(double(free_b) * 0.6);
+    }
   }
   if (const char* mb = getenv("FEMTO_AMD_KTAB_MB")) {
-    budget = std::max<int64_t>(1, atoll(mb)) << 20;
+    budget = budget_row = std::max<int64_t>(1, atoll(mb)) << 20;
     level_cap = INT64_MAX;
   }
   int want = -1;
@@ -991,7 +996,8 @@ int build_ktab2(femto_amd_index* ix, int sigma, int nstop) {
   for (;;) {
     if (K >= 24 || level > (int64_t(1) << 40) / t) break;
     const int64_t next_level = level * t;
-    if (want >= 0 ? K >= want : (next_level > level_cap || ((upper + level) * 16 + next_level * 8) > budget)) break;
+    const int64_t allowed = next_level <= ix->host.total_length ? budget_row : budget;
+    if (want >= 0 ? K >= want : (next_level > level_cap || ((upper + level) * 16 + next_level * 8) > allowed)) break;
     upper += level;
     lo.push_back(upper);
     level = next_level;
