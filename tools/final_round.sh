@@ -1,3 +1,5 @@
+# tools/final_round.sh -- on the GPU box (gpurun): the whole -m gpu suite, then the profile rounds that profiles/ is promoted from
+# (tools/promote_profiles.py r02_default r02_eng r02_hit; the reads100 / cfg5 bench lines are copied as they are).
 timeout 2700 python -m pytest tests -m gpu -x -q -rs 2>&1 | grep -E "passed|failed|Error|error|assert|SKIPPED" | tail -12 | cut -c1-200
 bash tools/profile_round.sh r02_default --steps 20 --warmup 5 > gpurun_out/r02_default.log 2>&1; tail -2 gpurun_out/r02_default.log | cut -c1-200
 bash tools/profile_round.sh r02_eng --steps 10 --warmup 3 --workload eng --no-extra > gpurun_out/r02_eng.log 2>&1; tail -2 gpurun_out/r02_eng.log | cut -c1-200
