@@ -1840,14 +1840,59 @@ int plan_host(femto_amd_index* ix, Scratch& S, const HostBatch& hb, int max_occs
   return 0;
 }
 
+// Results of a large host-pointer batch back into the caller's PAGEABLE memory: a plain hipMemcpy stages through the
+// runtime's own bounce buffer on one thread (~10 GB/s, and a freshly malloc()ed destination faults its pages in on that
+// thread); here the copy runs in 32 MB pieces into the call's two pinned buffers while the staging threads move the
+// previous piece into place (parallel_locate's offsets of 10 M located rows: 80 MB).  Everything enqueued on S.stream so
+// far is waited for; blocking.
+int d2h_staged(femto_amd_index* ix, Scratch& S, void* dst, const void* d_src, size_t bytes) {
+  auto& P = S.pipe;
+  const size_t piece = size_t(kPipeChunk) * 16;
+  bool staged = P.ready && ix->workers && bytes >= (size_t(4) << 20);
+  if (const char* e = getenv("FEMTO_AMD_D2H_STAGED")) staged = staged && atoi(e) != 0;
+  if (!staged) {
+    HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, S.stream));
+    HIP_TRY(hipStreamSynchronize(S.stream));
+    return 0;
+  }
+  HIP_TRY(hipEventRecord(P.k_done[0], S.stream));
+  HIP_TRY(hipStreamWaitEvent(P.s_d2h, P.k_done[0], 0));
+  const size_t npieces = (bytes + piece - 1) / piece;
+  auto fail = [&](hipError_t e) {
+    (void)hipStreamSynchronize(P.s_d2h);
+    return set_err(FEMTO_AMD_ERR_INVALID, std::string("staged copy to the host: ") + hipGetErrorString(e));
+  };
+  for (size_t c = 0; c <= npieces; c++) {
+    if (c < npieces) {
+      const int b = int(c & 1);
+      const size_t off = c * piece, len = std::min(piece, bytes - off);
+      hipError_t e = hipMemcpyAsync(P.h_out[b], static_cast<const char*>(d_src) + off, len, hipMemcpyDeviceToHost, P.s_d2h);
+      if (e == hipSuccess) e = hipEventRecord(P.out_done[b], P.s_d2h);
+      if (e != hipSuccess) return fail(e);
+    }
+    if (c >= 1) {      // piece c-1 into the caller's memory while piece c is on its way
+      const int b = int((c - 1) & 1);
+      const size_t off = (c - 1) * piece, len = std::min(piece, bytes - off);
+      const hipError_t e = hipEventSynchronize(P.out_done[b]);
+      if (e != hipSuccess) return fail(e);
+      const char* src = static_cast<const char*>(P.h_out[b]);
+      char* out = static_cast<char*>(dst) + off;
+      std::lock_guard<std::mutex> wl(ix->workers_mu);
+      ix->workers->run([&](int t, int nt) {
+        const size_t i0 = (len * size_t(t) / size_t(nt)) & ~size_t(63), i1 = t + 1 == nt ? len : (len * size_t(t + 1) / size_t(nt)) & ~size_t(63);
+        if (i1 > i0) memcpy(out + i0, src + i0, i1 - i0);
+      });
+    }
+  }
+  return 0;
+}
+
 // plan, walk, offsets copied to `dst` (host, room for the total) -- shared by the flat and the malloc forms
 int walk_to_host(femto_amd_index* ix, Scratch& S, int64_t npats, int64_t total, int64_t* dst) {
   int rc;
   if ((rc = S.offsets.reserve(size_t(total) * 8))) return rc;
   if ((rc = launch_locate(ix, S, npats, S.first.as<int64_t>(), S.out_starts.as<int64_t>(), total, S.offsets.as<int64_t>(), S.stream))) return rc;
-  HIP_TRY(hipMemcpyAsync(dst, S.offsets.p, size_t(total) * 8, hipMemcpyDeviceToHost, S.stream));
-  HIP_TRY(hipStreamSynchronize(S.stream));
-  return 0;
+  return d2h_staged(ix, S, dst, S.offsets.p, size_t(total) * 8);
 }
 
 // one pass: plan, walk, offsets returned in one malloc()ed array (caller frees); noccs / out_starts optional
@@ -1859,8 +1904,8 @@ int locate_host(femto_amd_index* ix, Scratch& S, const HostBatch& hb, int max_oc
   if (rc) return rc;
   const int64_t npats = hb.npats;
   if (total_out) *total_out = total;
-  if (noccs && npats) HIP_TRY(hipMemcpy(noccs, S.noccs.p, size_t(npats) * 4, hipMemcpyDeviceToHost));
-  if (out_starts) HIP_TRY(hipMemcpy(out_starts, S.out_starts.p, size_t(npats + 1) * 8, hipMemcpyDeviceToHost));
+  if (noccs && npats && (rc = d2h_staged(ix, S, noccs, S.noccs.p, size_t(npats) * 4))) return rc;
+  if (out_starts && (rc = d2h_staged(ix, S, out_starts, S.out_starts.p, size_t(npats + 1) * 8))) return rc;
   *offsets_out = nullptr;
   if (total == 0) return 0;
   int64_t* buf = static_cast<int64_t*>(malloc(size_t(total) * 8));
