@@ -36,6 +36,53 @@ class Info(C.Structure):
                 ("image_bytes", C.c_int64), ("table_bytes", C.c_int64)]
 
 
+class NfaStruct(C.Structure):
+    """femto_amd_nfa_t (include/femto_amd.h): the reference's nfa_description_t, flat"""
+    _fields_ = [("num_nodes", C.c_int32), ("num_transitions", C.c_int32), ("trans_start", C.c_void_p),
+                ("trans_char", C.c_void_p), ("trans_dest", C.c_void_p), ("is_start", C.c_void_p), ("is_final", C.c_void_p),
+                ("cost_bound", C.c_int32), ("subst_cost", C.c_int32), ("delete_cost", C.c_int32), ("insert_cost", C.c_int32)]
+
+
+class Nfa:
+    """An epsilon-free automaton of the REVERSED pattern, as do_regexp_query simulates it (src/main/nfa.h:62-88): node i's
+    transitions are entries trans_start[i] .. trans_start[i+1]-1 of trans_char (alpha codes) / trans_dest; settings =
+    (cost_bound, subst_cost, delete_cost, insert_cost), cost_bound 1 = exact."""
+
+    def __init__(self, trans_start, trans_char, trans_dest, is_start, is_final, settings=(1, 1, 1, 1)):
+        self.trans_start = np.ascontiguousarray(trans_start, dtype=np.int32)
+        self.trans_char = np.ascontiguousarray(trans_char, dtype=np.int32)
+        self.trans_dest = np.ascontiguousarray(trans_dest, dtype=np.int32)
+        self.is_start = np.ascontiguousarray(is_start, dtype=np.uint8)
+        self.is_final = np.ascontiguousarray(is_final, dtype=np.uint8)
+        self.settings = tuple(int(v) for v in settings)
+        self.num_nodes = len(self.is_start)
+
+    @classmethod
+    def from_regex(cls, regex, approx=None):
+        """femto_amd_regexp_compile: pattern text -> the position automaton of the reversed pattern; approx = (max_cost,
+        subst_cost, delete_cost, insert_cost) as in QUERY_FORMAT.txt's APPROX"""
+        rx = np.frombuffer(bytes(regex) + b"\0", dtype=np.uint8)
+        k = (0, 1, 1, 1) if approx is None else tuple(int(v) for v in approx)
+        h = C.c_void_p()
+        _check(lib().femto_amd_regexp_compile(_ptr(rx), len(regex), k[0], k[1], k[2], k[3], C.byref(h)))
+        try:
+            v = lib().femto_amd_regexp_nfa(h).contents
+            n, t = v.num_nodes, v.num_transitions
+
+            def arr(p, count, ct):
+                return np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(count,)).copy() if count else np.zeros(0, dtype=ct)
+
+            return cls(arr(v.trans_start, n + 1, C.c_int32), arr(v.trans_char, t, C.c_int32), arr(v.trans_dest, t, C.c_int32),
+                       arr(v.is_start, n, C.c_uint8), arr(v.is_final, n, C.c_uint8),
+                       (v.cost_bound, v.subst_cost, v.delete_cost, v.insert_cost))
+        finally:
+            lib().femto_amd_regexp_free(h)
+
+    def struct(self):
+        return NfaStruct(self.num_nodes, len(self.trans_char), self.trans_start.ctypes.data, self.trans_char.ctypes.data,
+                         self.trans_dest.ctypes.data, self.is_start.ctypes.data, self.is_final.ctypes.data, *self.settings)
+
+
 _lib = None
 
 
@@ -89,6 +136,12 @@ def lib():
         L.femto_amd_regexp_search.argtypes = [vp, vp, i64, i64, vp, vp, vp, C.POINTER(i64)]
         L.femto_amd_regexp_search_approx.argtypes = [vp, vp, i64, i32, i32, i32, i32, i64, vp, vp, vp, vp, C.POINTER(i64)]
         L.femto_amd_regexp_match.argtypes = [vp, i64, vp, i64]
+        L.femto_amd_regexp_compile.argtypes = [vp, i64, i32, i32, i32, i32, C.POINTER(vp)]
+        L.femto_amd_regexp_nfa.argtypes = [vp]
+        L.femto_amd_regexp_nfa.restype = C.POINTER(NfaStruct)
+        L.femto_amd_regexp_free.argtypes = [vp]
+        L.femto_amd_regexp_free.restype = None
+        L.femto_amd_nfa_search_batch.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]
         L.femto_amd_set_option.argtypes = [vp, C.c_char_p, i32]
         L.femto_amd_block_requests.argtypes = [vp, i64, vp, vp, vp, vp, vp]
         L.femto_amd_kernel_time_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]
@@ -368,17 +421,36 @@ class Index:
     def comm_gather(self, d_send, d_recv, bytes_per_rank, root=0, stream=0):
         _check(lib().femto_amd_comm_gather(self._h, d_send, d_recv or None, int(bytes_per_rank), int(root), stream or None))
 
+    def nfa_search_batch(self, nfas, max_results=1 << 20):
+        """femto_amd_nfa_search_batch: do_regexp_query (src/main/server.c:1656) for a batch of automata on the GPU.
+        Returns (result_start int64[n+1], first, last, match_len, cost, status int32[n]): automaton q's results are entries
+        result_start[q] .. result_start[q+1]-1, in the order of the reference's sorted result list."""
+        nfas = list(nfas)
+        n = len(nfas)
+        arr = (NfaStruct * max(1, n))(*[a.struct() for a in nfas])
+        start = np.zeros(n + 1, dtype=np.int64)
+        status = np.zeros(max(1, n), dtype=np.int32)
+        m = max(1, int(max_results))
+        first, last = np.zeros(m, dtype=np.int64), np.zeros(m, dtype=np.int64)
+        mlen, cost = np.zeros(m, dtype=np.int32), np.zeros(m, dtype=np.int32)
+        tot = C.c_int64(0)
+        _check(lib().femto_amd_nfa_search_batch(self._h, n, C.cast(arr, C.c_void_p), m, _ptr(start), _ptr(first), _ptr(last), _ptr(mlen),
+                                                _ptr(cost), _ptr(status), C.byref(tot)))
+        k = tot.value
+        return start, first[:k], last[:k], mlen[:k], cost[:k], status[:n]
+
+    def regexp_search_batch(self, regexes, max_results=1 << 20, approx=None):
+        """compile every pattern (Nfa.from_regex) and search them as one batch"""
+        return self.nfa_search_batch([Nfa.from_regex(r, approx) for r in regexes], max_results)
+
     def regexp_search(self, regex, max_results=1 << 20, approx=None):
-        """row ranges of every string of the index the byte regular expression matches in full -- or, approx=(max_cost,
-        subst, delete, insert), within that weighted edit distance of such a string:
-        (first int64[], last int64[], match_len int32[][, cost int32[]]) sorted by first ascending, last descending"""
+        """the sorted result list of do_regexp_query for one byte regular expression -- or, approx=(max_cost, subst, delete,
+        insert), its APPROX form: (first int64[], last int64[], match_len int32[][, cost int32[]]); a range whose string
+        matches is a result and is not extended (the reference's rule), ranges inside another result are dropped"""
         rx = np.frombuffer(bytes(regex) + b"\0", dtype=np.uint8)
         k = (0, 1, 1, 1) if approx is None else tuple(int(v) for v in approx)
         n = C.c_int64(0)
-        _check(lib().femto_amd_regexp_search_approx(self._h, _ptr(rx), len(regex), k[0], k[1], k[2], k[3], 0, None, None, None, None, C.byref(n)))
-        if n.value > max_results:
-            raise FemtoAmdError(3, f"{n.value} results > max_results {max_results}")
-        m = max(1, n.value)
+        m = max(1, int(max_results))
         first, last = np.zeros(m, dtype=np.int64), np.zeros(m, dtype=np.int64)
         mlen, cost = np.zeros(m, dtype=np.int32), np.zeros(m, dtype=np.int32)
         _check(lib().femto_amd_regexp_search_approx(self._h, _ptr(rx), len(regex), k[0], k[1], k[2], k[3], m, _ptr(first), _ptr(last),

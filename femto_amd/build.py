@@ -1,35 +1,70 @@
-"""Build the in-tree HIP extension (femto_amd/libfemto_amd.so) with hipcc for gfx950."""
+"""Build the in-tree HIP extension (femto_amd/libfemto_amd.so) with hipcc for gfx950.
+
+Every translation unit is compiled to an object under femto_amd/_obj/ (in parallel, only when it or a header changed) and
+the objects are linked into the shared library."""
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_obj")
 LIB = os.environ.get("FEMTO_AMD_LIB") or os.path.join(HERE, "libfemto_amd.so")
-SOURCES = ["femto_amd_api.hip", "trace_kernels.hip", "host_index.cpp", "index_builder.cpp", "suffix_sort.hip", "query_sort.hip"]
-HEADERS = ["regexp_nfa.hpp", "device_tables.h", "host_index.hpp", "host_pipeline.hpp", "kernels.hip.hpp", "pack_kernels.hip.hpp", "pack2_kernels.hip.hpp", "text_kernels.hip.hpp", "direct_kernels.hip.hpp", "ind_kernels.hip.hpp", "trace_api.hpp", "index_builder.hpp",
-           os.path.join("..", "..", "include", "femto_amd.h")]
+SOURCES = ["femto_amd_api.hip", "regexp_search.hip", "trace_kernels.hip", "host_index.cpp", "index_builder.cpp", "suffix_sort.hip",
+           "query_sort.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-Wno-unused-result", "-Wno-cuda-compat"]
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
+    hs.append(os.path.join(os.path.dirname(HERE), "include", "femto_amd.h"))
+    return hs
+
+
+def _newest_header():
+    return max(os.path.getmtime(h) for h in _headers())
+
+
+def _obj(src):
+    return os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+
+
+def _stale(src, hdr_time):
+    o = _obj(src)
+    if not os.path.exists(o):
+        return True
+    t = os.path.getmtime(o)
+    return os.path.getmtime(os.path.join(CSRC, src)) > t or hdr_time > t
 
 
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    for f in SOURCES + HEADERS:
-        p = os.path.join(CSRC, f)
-        if os.path.exists(p) and os.path.getmtime(p) > t:
-            return True
-    return False
+    if _newest_header() > t:
+        return True
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES)
 
 
 def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
     if not force and not needs_build():
         return LIB
-    srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-           "-Wno-unused-result", "-o", LIB] + srcs
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_time = _newest_header()
+    todo = [s for s in SOURCES if force or _stale(s, hdr_time)]
+
+    def compile_one(src):
+        cmd = ["hipcc"] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", _obj(src)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(todo)))) as ex:
+        list(ex.map(compile_one, todo))
+    cmd = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-pthread", "-o", LIB] + [_obj(s) for s in SOURCES]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     return LIB
 

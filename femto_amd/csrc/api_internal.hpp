@@ -1,0 +1,340 @@
+// api_internal.hpp -- what the translation units of the C ABI share: the handle (femto_amd_index), the per-call scratch and its
+// lease, device buffers, error reporting.  The C ABI is split by concern: femto_amd_api.hip (open / derive / batch pipeline / multi-device),
+// regexp_search.hip (NFA search).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types only: the library is loaded on first use (femto_amd_comm_*), never at link time
+
+#include <condition_variable>
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/femto_amd.h"
+#include "device_tables.h"
+#include "host_index.hpp"
+#include "host_pipeline.hpp"
+
+namespace femto_amd {
+
+int set_err(int code, const std::string& msg);   // thread-local last error (femto_amd_last_error)
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return set_err(e_ == hipErrorOutOfMemory ? FEMTO_AMD_ERR_MEM : FEMTO_AMD_ERR_INVALID,        \
+                     std::string(#expr) + ": " + hipGetErrorString(e_));                           \
+  } while (0)
+
+constexpr int kGroupW = 32;          // lanes per rank group; a count query uses one wavefront
+constexpr int kBlockThreads = 256;
+
+struct DeviceBuffer {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return set_err(FEMTO_AMD_ERR_MEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    cap = want;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+// two timing events destroyed on every exit path (the derivations at open return early on any HIP error)
+struct EventPair {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ~EventPair() {
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+  }
+};
+
+struct KernelTimer {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // recorded, not yet read
+  std::vector<hipEvent_t> free_list;                       // created once, reused
+  double total_ms = 0;
+  int64_t launches = 0;
+  bool take(hipEvent_t* e0, hipEvent_t* e1) {
+    while (free_list.size() < 2) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreate(&e) != hipSuccess) return false;
+      free_list.push_back(e);
+    }
+    *e0 = free_list.back(); free_list.pop_back();
+    *e1 = free_list.back(); free_list.pop_back();
+    return true;
+  }
+  void give(hipEvent_t e0, hipEvent_t e1) { free_list.push_back(e0); free_list.push_back(e1); }
+  void drain() {
+    for (auto& pr : events) {
+      float ms = 0;
+      if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+        total_ms += ms;
+        launches++;
+      }
+      give(pr.first, pr.second);
+    }
+    events.clear();
+  }
+  void destroy() {
+    drain();
+    for (hipEvent_t e : free_list) (void)hipEventDestroy(e);
+    free_list.clear();
+  }
+};
+
+// ---- per-call scratch ----------------------------------------------------------------------------------------------
+// The reference accepts blocking calls from many threads at once (each request has its own mutex and condition variable,
+// src/main/server.c:3732-3793).  Here every call leases a Scratch -- all the device buffers, flags and (for host-pointer
+// batches) the stream and pinned staging a call writes -- from a small pool owned by the handle, so concurrent calls
+// on one handle never share mutable device state and overlap on the GPU.  An enqueue-only (device-pointer) call
+// returns its lease with an event recorded on the caller's stream; the scratch is reused once that event is done.
+struct HostPipe {
+  void* h_in[2] = {nullptr, nullptr};    // [plen i32 x chunk | starts i64 x chunk | symbols u16 x sym_cap]
+  void* h_out[2] = {nullptr, nullptr};   // [first i64 x chunk | last i64 x chunk]
+  void* d_in[2] = {nullptr, nullptr};
+  void* d_out[2] = {nullptr, nullptr};
+  hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+  hipEvent_t in_done[2] = {nullptr, nullptr}, k_done[2] = {nullptr, nullptr}, out_done[2] = {nullptr, nullptr};
+  bool ready = false;
+};
+
+struct Scratch {
+  DeviceBuffer plen, pats, starts, first, last, noccs, noccs64, out_starts, offsets, scan[3];
+  DeviceBuffer rows, ch, occ, off;
+  DeviceBuffer keys, keys2, idx, idx2, sorttmp, pairs, tail, bsums;
+  int* d_flags = nullptr;       // [0] error flag, [1] "long ranges" flag of the row expansion, [2] tail item count, [3] see err
+  int* err = nullptr;           // where kernels raise "symbol >= ALPHA_SIZE": d_flags (host-pointer calls check and clear it) or,
+                                // for enqueue-only calls, d_flags + 3 (nobody reads it: such a pattern just has the empty range)
+  int64_t* d_total = nullptr;   // [0] rows to locate, [1] 1 = more rows than the caller's buffer holds
+  hipStream_t stream = nullptr; // host-pointer calls launch here (non-blocking stream: calls of different threads overlap)
+  hipEvent_t done = nullptr;
+  bool busy = false, in_flight = false;
+  hipStream_t flight_stream = nullptr;   // the stream of the enqueue-only call that used this scratch last
+  HostPipe pipe;
+
+  int init() {
+    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_flags), 8 * sizeof(int)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_total), 4 * sizeof(int64_t)));
+    // cleared ON the scratch's stream and waited for: a null-stream hipMemset is not ordered with a non-blocking stream,
+    // and the memory may be a closed handle's flag word that was still set (seen once as a spurious "character code >=
+    // ALPHA_SIZE" on a fresh handle)
+    HIP_TRY(hipMemsetAsync(d_flags, 0, 8 * sizeof(int), stream));
+    HIP_TRY(hipMemsetAsync(d_total, 0, 4 * sizeof(int64_t), stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    err = d_flags;
+    return 0;
+  }
+  void release() {
+    for (DeviceBuffer* b : {&plen, &pats, &starts, &first, &last, &noccs, &noccs64, &out_starts, &offsets, &scan[0], &scan[1], &scan[2],
+                            &rows, &ch, &occ, &off, &keys, &keys2, &idx, &idx2, &sorttmp, &pairs, &tail, &bsums})
+      b->release();
+    for (int b = 0; b < 2; b++) {
+      if (pipe.h_in[b]) (void)hipHostFree(pipe.h_in[b]);
+      if (pipe.h_out[b]) (void)hipHostFree(pipe.h_out[b]);
+      if (pipe.d_in[b]) (void)hipFree(pipe.d_in[b]);
+      if (pipe.d_out[b]) (void)hipFree(pipe.d_out[b]);
+      if (pipe.in_done[b]) (void)hipEventDestroy(pipe.in_done[b]);
+      if (pipe.k_done[b]) (void)hipEventDestroy(pipe.k_done[b]);
+      if (pipe.out_done[b]) (void)hipEventDestroy(pipe.out_done[b]);
+    }
+    if (pipe.s_h2d) (void)hipStreamDestroy(pipe.s_h2d);
+    if (pipe.s_d2h) (void)hipStreamDestroy(pipe.s_d2h);
+    if (d_flags) (void)hipFree(d_flags);
+    if (d_total) (void)hipFree(d_total);
+    if (stream) (void)hipStreamDestroy(stream);
+    if (done) (void)hipEventDestroy(done);
+  }
+};
+
+}  // namespace femto_amd
+
+using namespace femto_amd;   // internal header: only the C ABI's own translation units include it
+
+struct femto_amd_index {
+  HostIndex host;
+  int device = -1;
+  std::mutex mu;   // mode switches, timers
+  // device-resident index
+  uint8_t* d_image = nullptr;
+  DevNode* d_nodes = nullptr;
+  DevBucket* d_buckets = nullptr;
+  DevSeq* d_seqs = nullptr;
+  int64_t* d_occ_base = nullptr;
+  uint32_t* d_leaf_code = nullptr;
+  int64_t* d_C = nullptr;
+  uint64_t* d_segs = nullptr;
+  CumEntry* d_cum = nullptr;
+  uint32_t* d_hint = nullptr;
+  BlockDir* d_bdir = nullptr;
+  LaneNode* d_lnodes = nullptr;
+  LaneSeq* d_lseqs = nullptr;
+  OccEntry* d_occ = nullptr;
+  int mode = 1;  // 3: packed small-alphabet lines (default when the index has <= 8 characters); 4: two-level lines (<= 256
+                 // characters); 1: lane-per-query kernels on femto's wavelet tree (default otherwise); 2: flattened
+                 // persistent-lane kernels; 0: wavefront-cooperative raw A/S/D walk
+  uint32_t* d_pack = nullptr;
+  int64_t* d_pack_sa = nullptr;
+  uint8_t* d_pack_code = nullptr;
+  int64_t* d_pack_c = nullptr;
+  int64_t* d_ktab = nullptr;
+  int64_t* d_ktab2 = nullptr;
+  int64_t* d_ktab2_deep = nullptr;
+  int64_t ktab2_bytes = 0;
+  uint64_t* d_ctx = nullptr;     // context tables of byte alphabets (ctx_kernels.hip.hpp)
+  uint64_t* d_ctx2 = nullptr;
+  int64_t ctx_bytes = 0, ctx_entries = 0, ctx2_bytes = 0;
+  double ctx_build_ms = 0;
+  uint8_t* d_txt = nullptr;
+  int64_t* d_isa8 = nullptr;
+  int64_t* d_sa_full = nullptr;
+  uint32_t* d_ind = nullptr;
+  int64_t ind_bytes = 0;
+  int64_t text_bytes = 0;
+  int64_t n_marks = 0;         // entries of pack_sa
+  int64_t p2_lines1 = 0, p2_lines2 = 0;
+  uint32_t *d_p2_l1 = nullptr, *d_p2_l2 = nullptr;
+  int64_t *d_p2_base = nullptr, *d_p2_c = nullptr;
+  uint16_t *d_p2_code = nullptr, *d_p2_alpha = nullptr;
+  int64_t pack2_bytes = 0;
+  double pack2_build_ms = 0;
+  int64_t pack_bytes = 0;
+  double pack_build_ms = 0;
+  int num_cus = 256;
+  int blocks_per_cu_override = 0;
+  DevIndex dev{};
+  int64_t table_bytes = 0;
+  DeviceBuffer open_scan[3];   // scan scratch of the derivations at open
+  // scratch pool (see Scratch)
+  std::mutex pool_mu;
+  std::condition_variable pool_cv;
+  std::vector<std::unique_ptr<Scratch>> pool;
+  int pool_max = 8;
+  std::unique_ptr<WorkerPool> workers;   // staging threads of host-pointer batches, created on first use
+  std::mutex workers_mu;                 // one staged batch at a time uses the worker pool
+  bool sort_queries = true;    // FEMTO_AMD_SORT=0 disables the suffix-order batch sort of the paths that use one
+  bool direct = true;          // FEMTO_AMD_DIRECT=0: modes 3/4 go back to the sorted-batch kernels of round 1
+  uint8_t* d_dense = nullptr;  // alpha code -> dense sort digit (characters present in the text)
+  std::vector<uint8_t> h_dense; // the same table on the host (key staging of host-pointer batches)
+  int dense_bits = 8;
+  double dense_sigma = 256;    // distinct characters of the indexed text
+  int64_t sort_min = 4096;
+  int64_t regexp_max_iterations = 1000000;   // MAX_REGEXP_ITERATIONS (src/main/server.c:40); option "regexp_max_iterations"
+  int64_t regexp_stack_cap = int64_t(1) << 22; // pending ranges one search may hold (option "regexp_stack_cap")
+  bool timing = false;
+  KernelTimer t_count, t_locate;
+  // range-split index (femto_amd_open_split): this handle holds the segment lines and the block images of
+  // data blocks [split_blo[part], split_blo[part+1]); the other parts' slices are mapped from their owners
+  int split_parts = 0, split_part = 0;
+  bool split_ready = false;
+  std::vector<int64_t> split_blo;        // nparts + 1 block boundaries
+  std::vector<void*> peer_segs, peer_image;  // per part: base of that part's slices as seen from this process
+  std::vector<char> peer_ipc;            // per part: 1 if opened with hipIpcOpenMemHandle (close on release)
+  int64_t split_seg_bytes = 0, split_image_bytes = 0;
+  // multi-device handle (femto_amd_open_multi): no device of its own, one replica per GPU; host-pointer batches are
+  // sharded over the replicas by host threads
+  std::vector<femto_amd_index*> children;
+  // striped index (femto_amd_open_multi_striped): the big arrays are ONE address range each whose pages live in the HBM
+  // of all the listed GPUs (HIP virtual memory management); the small tables are copied to every GPU
+  std::vector<int> stripe_devices;           // non-empty while the builder handle allocates
+  struct Striped { void* va; size_t size, chunk; std::vector<hipMemGenericAllocationHandle_t> handles; };
+  std::vector<Striped> striped;
+  std::vector<std::pair<void*, size_t>> small_tables;   // every upload()ed table: what a view on another GPU copies
+  bool borrowed = false;                     // a view of another handle's arrays on a second GPU: owns only `owned_small`
+  bool imported = false;                     // ... of another PROCESS's arrays: also owns its mappings of them (`striped`)
+  std::vector<void*> owned_small;
+  // RCCL communicator of the multi-process form (femto_amd_comm_init)
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_size = 0;
+};
+
+namespace femto_amd {
+
+Scratch* scratch_acquire(femto_amd_index* ix, int* rc, bool enqueue_only = false, hipStream_t same_stream = nullptr);
+void scratch_release(femto_amd_index* ix, Scratch* s, bool async, hipStream_t stream);
+
+struct Lease {
+  femto_amd_index* ix;
+  Scratch* s = nullptr;
+  bool async = false;           // enqueue-only call: the work is still running when the lease ends
+  hipStream_t stream = nullptr;
+  int rc = 0;
+  explicit Lease(femto_amd_index* i) : ix(i) { s = scratch_acquire(ix, &rc); }
+  Lease(femto_amd_index* i, hipStream_t st) : ix(i) {     // enqueue-only call on the caller's stream `st`
+    s = scratch_acquire(ix, &rc, true, st);
+    if (s) enqueue_only(st);
+  }
+  ~Lease() {
+    if (s) s->err = s->d_flags;
+    scratch_release(ix, s, async, stream);
+  }
+  // enqueue-only call on the caller's stream: nothing of it is checked on the host, so its kernels raise the error flag
+  // in a word of their own (a later host-pointer call on this scratch must not inherit it)
+  void enqueue_only(hipStream_t st) {
+    async = true;
+    stream = st;
+    s->err = s->d_flags + 3;
+  }
+  Lease(const Lease&) = delete;
+  Lease& operator=(const Lease&) = delete;
+};
+// `slack` zero bytes follow the data: a damaged index (counts that disagree with the bits they summarise) can make a
+// kernel index a little past the end of the table it is walking -- at most one bucket's worth -- and must read
+// zeros there, not fault.  (Results for such an index are garbage either way, as they are in the reference.)
+extern thread_local std::vector<std::pair<void*, size_t>>* g_small_registry;   // set while a handle is being opened
+
+template <class T>
+int upload(T** dst, const std::vector<T>& src, int64_t* bytes, size_t slack = 0) {
+  size_t n = src.size() * sizeof(T);
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(dst), n + slack ? n + slack : 16));
+  if (n) HIP_TRY(hipMemcpy(*dst, src.data(), n, hipMemcpyHostToDevice));
+  if (slack) HIP_TRY(hipMemset(reinterpret_cast<char*>(*dst) + n, 0, slack));
+  if (bytes) *bytes += int64_t(n);
+  if (g_small_registry) g_small_registry->emplace_back(static_cast<void*>(*dst), (n + slack) ? n + slack : size_t(16));
+  return 0;
+}
+
+
+hipError_t big_malloc(femto_amd_index* ix, void** out, size_t bytes);
+void big_free(femto_amd_index* ix, void* p);
+hipError_t big_memset(femto_amd_index* ix, void* p, int v, size_t bytes);
+hipError_t big_h2d(femto_amd_index* ix, void* p, const void* src, size_t bytes);
+int ensure_device(femto_amd_index* ix);
+int check_err_flag(Scratch& S, hipStream_t stream);
+bool timer_begin(femto_amd_index* ix, KernelTimer& t, hipStream_t stream, hipEvent_t* e0, hipEvent_t* e1);
+void timer_end(femto_amd_index* ix, KernelTimer& t, hipStream_t stream, hipEvent_t e0, hipEvent_t e1);
+
+}  // namespace femto_amd
+
+// no exception crosses the C boundary
+#define API_BEGIN try {
+#define API_END                                                                            \
+  } catch (const std::bad_alloc&) {                                                        \
+    return set_err(FEMTO_AMD_ERR_MEM, "out of memory");                                    \
+  } catch (const std::exception& ex) {                                                     \
+    return set_err(FEMTO_AMD_ERR_INVALID, std::string("internal error: ") + ex.what());    \
+  } catch (...) {                                                                          \
+    return set_err(FEMTO_AMD_ERR_INVALID, "internal error");                               \
+  }

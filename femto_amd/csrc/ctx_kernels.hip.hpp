@@ -59,7 +59,7 @@ __device__ __forceinline__ uint64_t ctx_gram_of_row(const DevIndex& ix, int64_t 
 }
 
 // number of rows that start a group of equal keys (= distinct H-grams), added to *count
-__global__ __launch_bounds__(256) void ctx_count_kernel(const DevIndex ix, const int64_t row0, const int64_t n, const int H, const uint32_t nstop,
+inline __global__ __launch_bounds__(256) void ctx_count_kernel(const DevIndex ix, const int64_t row0, const int64_t n, const int H, const uint32_t nstop,
                                                         unsigned long long* __restrict__ count) {
   const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const bool in = row < row0 + n;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void ctx_count_kernel(const DevIndex ix, const
 }
 
 // every group start claims a slot and stores its first row
-__global__ __launch_bounds__(256) void ctx_insert_kernel(const DevIndex ix, const int64_t row0, const int64_t n, const int H, const uint32_t nstop,
+inline __global__ __launch_bounds__(256) void ctx_insert_kernel(const DevIndex ix, const int64_t row0, const int64_t n, const int H, const uint32_t nstop,
                                                          unsigned long long* __restrict__ slots, const int log2_slots) {
   const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const bool in = row < row0 + n;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void ctx_insert_kernel(const DevIndex ix, cons
 }
 
 // every group end finds its slot and completes the value
-__global__ __launch_bounds__(256) void ctx_ends_kernel(const DevIndex ix, const int64_t row0, const int64_t n, const int H, const uint32_t nstop,
+inline __global__ __launch_bounds__(256) void ctx_ends_kernel(const DevIndex ix, const int64_t row0, const int64_t n, const int H, const uint32_t nstop,
                                                        unsigned long long* __restrict__ slots, const int log2_slots) {
   const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const bool in = row < row0 + n;
@@ -202,7 +202,7 @@ __device__ __forceinline__ CtxKey2 ctx_shfl2(const CtxKey2& g, int delta, bool u
 }
 
 // pass 0: count the group starts; pass 1: every group start claims a slot; pass 2: every group end completes its value
-__global__ __launch_bounds__(256) void ctx2_build_kernel(const DevIndex ix, const int64_t row0, const int64_t n, const int H, const uint32_t nstop,
+inline __global__ __launch_bounds__(256) void ctx2_build_kernel(const DevIndex ix, const int64_t row0, const int64_t n, const int H, const uint32_t nstop,
                                                          const int pass, unsigned long long* __restrict__ count,
                                                          unsigned long long* __restrict__ slots, const int log2_slots) {
   const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;

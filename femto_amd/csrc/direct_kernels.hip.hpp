@@ -32,7 +32,7 @@ namespace femto_amd {
 
 // ---- level table construction: one launch per level, entries of level m+1 from their parents in level m -----------
 template <class P>
-__global__ __launch_bounds__(256) void ktab2_level_kernel(const DevIndex ix, const int level /* m+1 >= 1 */, const int64_t lo, const int64_t n,
+inline __global__ __launch_bounds__(256) void ktab2_level_kernel(const DevIndex ix, const int level /* m+1 >= 1 */, const int64_t lo, const int64_t n,
                                                           longlong2* __restrict__ tab) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void ktab2_level_kernel(const DevIndex ix, con
   tab[pos] = make_longlong2(first, int64_t(uint64_t(last + 1) | (uint64_t(level) << 48)));
 }
 
-__global__ void ktab2_root_kernel(const DevIndex ix, longlong2* __restrict__ tab) {
+inline __global__ void ktab2_root_kernel(const DevIndex ix, longlong2* __restrict__ tab) {
   if (threadIdx.x == 0 && blockIdx.x == 0) tab[0] = make_longlong2(0, ix.total_length);   // empty pattern: [0, n-1] (server.c:782-808)
 }
 
@@ -58,7 +58,7 @@ constexpr uint64_t kDeepBig = 0xffffffu;
 constexpr uint64_t kDeepFirstMask = (uint64_t(1) << 40) - 1;
 
 template <class P>
-__global__ __launch_bounds__(256) void ktab2_deep_kernel(const DevIndex ix, const int level, const int64_t lo, const int64_t n,
+inline __global__ __launch_bounds__(256) void ktab2_deep_kernel(const DevIndex ix, const int level, const int64_t lo, const int64_t n,
                                                          const longlong2* __restrict__ tab, uint64_t* __restrict__ deep) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -121,7 +121,7 @@ __device__ __forceinline__ int64_t block_sum_256(int64_t v, int64_t* s_w /* [4] 
 // last matching position = ISA[..] (one read) -- instead of being handed to count_tail_kernel (whose LF walks only
 // exist because the sampled arrays need them).  Same result as stepping on: see text_kernels.hip.hpp.
 template <class P, bool kPlan, bool kDense>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, P::kWaves))) void count_direct_kernel(
+inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, P::kWaves))) void count_direct_kernel(
     const DevIndex ix, const int64_t npats, const int32_t* __restrict__ plen, const uint16_t* __restrict__ pats,
     const int64_t* __restrict__ starts, int64_t* __restrict__ first_out, int64_t* __restrict__ last_out, int* __restrict__ err_flag,
     const int max_occs, int32_t* __restrict__ noccs, int64_t* __restrict__ block_sums) {
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, 
 // pairs when the index has fewer than 2^31 - 1 rows: 16 instead of 68 bytes per 20-mer over PCIe.  Same search, same
 // results; a chunk holding any pattern a key cannot describe (longer, or a character outside the text) travels as symbols.
 template <class P>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, P::kWaves))) void count_keys_kernel(
+inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, P::kWaves))) void count_keys_kernel(
     const DevIndex ix, const int64_t npats, const uint64_t* __restrict__ keys, const int bits, const int nsym,
     int2* __restrict__ out32, int64_t* __restrict__ first_out, int64_t* __restrict__ last_out) {
   const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -384,7 +384,7 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
   return v;   // valid in lane 0
 }
 
-__global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t n, int64_t* __restrict__ sums, int64_t* __restrict__ total_out,
+inline __global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t n, int64_t* __restrict__ sums, int64_t* __restrict__ total_out,
                                                          const int64_t capacity, int64_t* __restrict__ out_starts_end, int* __restrict__ big_flag,
                                                          int64_t* __restrict__ total_user) {
   __shared__ int64_t s_wave[16];
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t n, int64_
 // pattern -- last - first + 1, 0 when there is no match, 255 = "255 or more: see the list" -- and the patterns with 255
 // matches or more appended to a list of (pattern, count) pairs (order unspecified; *big_n counts them even beyond
 // big_cap, so the receiver sees an overflow).  Lossless, 1 byte instead of 16 per pattern on the links.
-__global__ __launch_bounds__(256) void pack_counts_kernel(const int64_t n, const int64_t* __restrict__ first, const int64_t* __restrict__ last,
+inline __global__ __launch_bounds__(256) void pack_counts_kernel(const int64_t n, const int64_t* __restrict__ first, const int64_t* __restrict__ last,
                                                           uint8_t* __restrict__ counts8, int64_t* __restrict__ big, const int64_t big_cap,
                                                           unsigned long long* __restrict__ big_n) {
   const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void pack_counts_kernel(const int64_t n, const
 }
 
 // set bits of trace words [w0, w1) added to *out (femto_amd_trace_lines)
-__global__ __launch_bounds__(256) void trace_popcount_kernel(const uint32_t* __restrict__ bitmap, const int64_t w0, const int64_t w1,
+inline __global__ __launch_bounds__(256) void trace_popcount_kernel(const uint32_t* __restrict__ bitmap, const int64_t w0, const int64_t w1,
                                                              unsigned long long* __restrict__ out) {
   unsigned long long c = 0;
   for (int64_t i = w0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < w1; i += int64_t(gridDim.x) * blockDim.x) c += uint32_t(__popc(bitmap[i]));
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void trace_popcount_kernel(const uint32_t* __r
 }
 
 // paths that scanned the row counts themselves: publish the total the same way plan_scan_kernel does
-__global__ void copy_total_kernel(const int64_t* __restrict__ src, int64_t* __restrict__ total_out, const int64_t capacity) {
+inline __global__ void copy_total_kernel(const int64_t* __restrict__ src, int64_t* __restrict__ total_out, const int64_t capacity) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     total_out[0] = *src;
     total_out[1] = *src > capacity ? 1 : 0;
@@ -485,7 +485,7 @@ __global__ void copy_total_kernel(const int64_t* __restrict__ src, int64_t* __re
 // kSa: the full suffix array is resident -- the offsets themselves are written (offsets[..] = SA[first + k], consecutive
 // reads) and no walk follows.
 template <bool kSa>
-__global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npats, const int32_t* __restrict__ noccs, const int64_t* __restrict__ first,
+inline __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npats, const int32_t* __restrict__ noccs, const int64_t* __restrict__ first,
                                                         const int64_t* __restrict__ block_sums, int64_t* __restrict__ out_starts,
                                                         int64_t* __restrict__ offsets, const int64_t capacity, int* __restrict__ big_flag,
                                                         const DevIndex ix) {
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npats, con
 
 // the long ranges left over by plan_rows_kernel: grid-stride, one thread per output slot (idle unless the flag is set)
 template <bool kSa>
-__global__ __launch_bounds__(256) void plan_big_rows_kernel(const int64_t npats, const int64_t* __restrict__ first,
+inline __global__ __launch_bounds__(256) void plan_big_rows_kernel(const int64_t npats, const int64_t* __restrict__ first,
                                                             const int64_t* __restrict__ out_starts, const int64_t* __restrict__ total_ptr,
                                                             const int64_t capacity, int64_t* __restrict__ offsets, const int* __restrict__ big_flag,
                                                             const DevIndex ix) {
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(256) void plan_big_rows_kernel(const int64_t npats,
 }
 
 // the other row expansions (two-call API, host paths): rows already in offsets[] -> their text offsets, full suffix array
-__global__ __launch_bounds__(256) void gather_sa_kernel(const DevIndex ix, const int64_t total, int64_t* __restrict__ offsets) {
+inline __global__ __launch_bounds__(256) void gather_sa_kernel(const DevIndex ix, const int64_t total, int64_t* __restrict__ offsets) {
   const int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (item >= total) return;
   const int64_t row = offsets[item];
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256) void gather_sa_kernel(const DevIndex ix, const
 // of rows is read from the device word the plan wrote, so count -> plan -> walk is one stream-ordered chain.
 // offsets[item] holds the row on entry and the row's text offset on return.
 template <class P>
-__global__ __launch_bounds__(256) void locate_walk_kernel(const DevIndex ix, const int64_t* __restrict__ total_ptr, const int64_t capacity,
+inline __global__ __launch_bounds__(256) void locate_walk_kernel(const DevIndex ix, const int64_t* __restrict__ total_ptr, const int64_t capacity,
                                                           int64_t* __restrict__ offsets) {
   const int64_t total = *total_ptr < capacity ? *total_ptr : capacity;
   for (int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; item < total; item += int64_t(gridDim.x) * blockDim.x) {

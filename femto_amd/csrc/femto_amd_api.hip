@@ -23,6 +23,7 @@
 #include <thread>
 #include <vector>
 
+#include "api_internal.hpp"
 #include "../../include/femto_amd.h"
 #include "host_index.hpp"
 #include "host_pipeline.hpp"
@@ -35,7 +36,6 @@
 #include "ctx_kernels.hip.hpp"
 #include "direct_kernels.hip.hpp"
 #include "trace_api.hpp"
-#include "regexp_nfa.hpp"
 
 using namespace femto_amd;
 
@@ -47,264 +47,24 @@ hipError_t query_sort(int64_t npats, const int32_t* d_plen, const uint16_t* d_pa
 }
 
 namespace {
-
 thread_local std::string g_last_error;
+}  // namespace
+
+namespace femto_amd {
 
 int set_err(int code, const std::string& msg) {
   g_last_error = msg;
   return code;
 }
 
-#define HIP_TRY(expr)                                                                              \
-  do {                                                                                             \
-    hipError_t e_ = (expr);                                                                        \
-    if (e_ != hipSuccess)                                                                          \
-      return set_err(e_ == hipErrorOutOfMemory ? FEMTO_AMD_ERR_MEM : FEMTO_AMD_ERR_INVALID,        \
-                     std::string(#expr) + ": " + hipGetErrorString(e_));                           \
-  } while (0)
-
-constexpr int kGroupW = 32;          // lanes per rank group; a count query uses one wavefront
-constexpr int kBlockThreads = 256;
-
-struct DeviceBuffer {
-  void* p = nullptr;
-  size_t cap = 0;
-  int reserve(size_t bytes) {
-    if (bytes <= cap) return 0;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-    size_t want = bytes + bytes / 4 + 256;
-    hipError_t e = hipMalloc(&p, want);
-    if (e != hipSuccess) {
-      p = nullptr;
-      return set_err(FEMTO_AMD_ERR_MEM, std::string("hipMalloc: ") + hipGetErrorString(e));
-    }
-    cap = want;
-    return 0;
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-  }
-  template <class T> T* as() { return reinterpret_cast<T*>(p); }
-};
-
-// two timing events destroyed on every exit path (the derivations at open return early on any HIP error)
-struct EventPair {
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  ~EventPair() {
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-  }
-};
-
-struct KernelTimer {
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // recorded, not yet read
-  std::vector<hipEvent_t> free_list;                       // created once, reused
-  double total_ms = 0;
-  int64_t launches = 0;
-  bool take(hipEvent_t* e0, hipEvent_t* e1) {
-    while (free_list.size() < 2) {
-      hipEvent_t e = nullptr;
-      if (hipEventCreate(&e) != hipSuccess) return false;
-      free_list.push_back(e);
-    }
-    *e0 = free_list.back(); free_list.pop_back();
-    *e1 = free_list.back(); free_list.pop_back();
-    return true;
-  }
-  void give(hipEvent_t e0, hipEvent_t e1) { free_list.push_back(e0); free_list.push_back(e1); }
-  void drain() {
-    for (auto& pr : events) {
-      float ms = 0;
-      if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
-        total_ms += ms;
-        launches++;
-      }
-      give(pr.first, pr.second);
-    }
-    events.clear();
-  }
-  void destroy() {
-    drain();
-    for (hipEvent_t e : free_list) (void)hipEventDestroy(e);
-    free_list.clear();
-  }
-};
-
-// ---- per-call scratch ----------------------------------------------------------------------------------------------
-// The reference accepts blocking calls from many threads at once (each request has its own mutex and condition variable,
-// src/main/server.c:3732-3793).  Here every call leases a Scratch -- all the device buffers, flags and (for host-pointer
-// batches) the stream and pinned staging a call writes -- from a small pool owned by the handle, so concurrent calls
-// on one handle never share mutable device state and overlap on the GPU.  An enqueue-only (device-pointer) call
-// returns its lease with an event recorded on the caller's stream; the scratch is reused once that event is done.
-struct HostPipe {
-  void* h_in[2] = {nullptr, nullptr};    // [plen i32 x chunk | starts i64 x chunk | symbols u16 x sym_cap]
-  void* h_out[2] = {nullptr, nullptr};   // [first i64 x chunk | last i64 x chunk]
-  void* d_in[2] = {nullptr, nullptr};
-  void* d_out[2] = {nullptr, nullptr};
-  hipStream_t s_h2d = nullptr, s_d2h = nullptr;
-  hipEvent_t in_done[2] = {nullptr, nullptr}, k_done[2] = {nullptr, nullptr}, out_done[2] = {nullptr, nullptr};
-  bool ready = false;
-};
-
-struct Scratch {
-  DeviceBuffer plen, pats, starts, first, last, noccs, noccs64, out_starts, offsets, scan[3];
-  DeviceBuffer rows, ch, occ, off;
-  DeviceBuffer keys, keys2, idx, idx2, sorttmp, pairs, tail, bsums;
-  int* d_flags = nullptr;       // [0] error flag, [1] "long ranges" flag of the row expansion, [2] tail item count, [3] see err
-  int* err = nullptr;           // where kernels raise "symbol >= ALPHA_SIZE": d_flags (host-pointer calls check and clear it) or,
-                                // for enqueue-only calls, d_flags + 3 (nobody reads it: such a pattern just has the empty range)
-  int64_t* d_total = nullptr;   // [0] rows to locate, [1] 1 = more rows than the caller's buffer holds
-  hipStream_t stream = nullptr; // host-pointer calls launch here (non-blocking stream: calls of different threads overlap)
-  hipEvent_t done = nullptr;
-  bool busy = false, in_flight = false;
-  hipStream_t flight_stream = nullptr;   // the stream of the enqueue-only call that used this scratch last
-  HostPipe pipe;
-
-  int init() {
-    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_flags), 8 * sizeof(int)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_total), 4 * sizeof(int64_t)));
-    // cleared ON the scratch's stream and waited for: a null-stream hipMemset is not ordered with a non-blocking stream,
-    // and the memory may be a closed handle's flag word that was still set (seen once as a spurious "character code >=
-    // ALPHA_SIZE" on a fresh handle)
-    HIP_TRY(hipMemsetAsync(d_flags, 0, 8 * sizeof(int), stream));
-    HIP_TRY(hipMemsetAsync(d_total, 0, 4 * sizeof(int64_t), stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    err = d_flags;
-    return 0;
-  }
-  void release() {
-    for (DeviceBuffer* b : {&plen, &pats, &starts, &first, &last, &noccs, &noccs64, &out_starts, &offsets, &scan[0], &scan[1], &scan[2],
-                            &rows, &ch, &occ, &off, &keys, &keys2, &idx, &idx2, &sorttmp, &pairs, &tail, &bsums})
-      b->release();
-    for (int b = 0; b < 2; b++) {
-      if (pipe.h_in[b]) (void)hipHostFree(pipe.h_in[b]);
-      if (pipe.h_out[b]) (void)hipHostFree(pipe.h_out[b]);
-      if (pipe.d_in[b]) (void)hipFree(pipe.d_in[b]);
-      if (pipe.d_out[b]) (void)hipFree(pipe.d_out[b]);
-      if (pipe.in_done[b]) (void)hipEventDestroy(pipe.in_done[b]);
-      if (pipe.k_done[b]) (void)hipEventDestroy(pipe.k_done[b]);
-      if (pipe.out_done[b]) (void)hipEventDestroy(pipe.out_done[b]);
-    }
-    if (pipe.s_h2d) (void)hipStreamDestroy(pipe.s_h2d);
-    if (pipe.s_d2h) (void)hipStreamDestroy(pipe.s_d2h);
-    if (d_flags) (void)hipFree(d_flags);
-    if (d_total) (void)hipFree(d_total);
-    if (stream) (void)hipStreamDestroy(stream);
-    if (done) (void)hipEventDestroy(done);
-  }
-};
-
-}  // namespace
-
-struct femto_amd_index {
-  HostIndex host;
-  int device = -1;
-  std::mutex mu;   // mode switches, timers
-  // device-resident index
-  uint8_t* d_image = nullptr;
-  DevNode* d_nodes = nullptr;
-  DevBucket* d_buckets = nullptr;
-  DevSeq* d_seqs = nullptr;
-  int64_t* d_occ_base = nullptr;
-  uint32_t* d_leaf_code = nullptr;
-  int64_t* d_C = nullptr;
-  uint64_t* d_segs = nullptr;
-  CumEntry* d_cum = nullptr;
-  uint32_t* d_hint = nullptr;
-  BlockDir* d_bdir = nullptr;
-  LaneNode* d_lnodes = nullptr;
-  LaneSeq* d_lseqs = nullptr;
-  OccEntry* d_occ = nullptr;
-  int mode = 1;  // 3: packed small-alphabet lines (default when the index has <= 8 characters); 4: two-level lines (<= 256
-                 // characters); 1: lane-per-query kernels on femto's wavelet tree (default otherwise); 2: flattened
-                 // persistent-lane kernels; 0: wavefront-cooperative raw A/S/D walk
-  uint32_t* d_pack = nullptr;
-  int64_t* d_pack_sa = nullptr;
-  uint8_t* d_pack_code = nullptr;
-  int64_t* d_pack_c = nullptr;
-  int64_t* d_ktab = nullptr;
-  int64_t* d_ktab2 = nullptr;
-  int64_t* d_ktab2_deep = nullptr;
-  int64_t ktab2_bytes = 0;
-  uint64_t* d_ctx = nullptr;     // context tables of byte alphabets (ctx_kernels.hip.hpp)
-  uint64_t* d_ctx2 = nullptr;
-  int64_t ctx_bytes = 0, ctx_entries = 0, ctx2_bytes = 0;
-  double ctx_build_ms = 0;
-  uint8_t* d_txt = nullptr;
-  int64_t* d_isa8 = nullptr;
-  int64_t* d_sa_full = nullptr;
-  uint32_t* d_ind = nullptr;
-  int64_t ind_bytes = 0;
-  int64_t text_bytes = 0;
-  int64_t n_marks = 0;         // entries of pack_sa
-  int64_t p2_lines1 = 0, p2_lines2 = 0;
-  uint32_t *d_p2_l1 = nullptr, *d_p2_l2 = nullptr;
-  int64_t *d_p2_base = nullptr, *d_p2_c = nullptr;
-  uint16_t *d_p2_code = nullptr, *d_p2_alpha = nullptr;
-  int64_t pack2_bytes = 0;
-  double pack2_build_ms = 0;
-  int64_t pack_bytes = 0;
-  double pack_build_ms = 0;
-  int num_cus = 256;
-  int blocks_per_cu_override = 0;
-  DevIndex dev{};
-  int64_t table_bytes = 0;
-  DeviceBuffer open_scan[3];   // scan scratch of the derivations at open
-  // scratch pool (see Scratch)
-  std::mutex pool_mu;
-  std::condition_variable pool_cv;
-  std::vector<std::unique_ptr<Scratch>> pool;
-  int pool_max = 8;
-  std::unique_ptr<WorkerPool> workers;   // staging threads of host-pointer batches, created on first use
-  std::mutex workers_mu;                 // one staged batch at a time uses the worker pool
-  bool sort_queries = true;    // FEMTO_AMD_SORT=0 disables the suffix-order batch sort of the paths that use one
-  bool direct = true;          // FEMTO_AMD_DIRECT=0: modes 3/4 go back to the sorted-batch kernels of round 1
-  uint8_t* d_dense = nullptr;  // alpha code -> dense sort digit (characters present in the text)
-  std::vector<uint8_t> h_dense; // the same table on the host (key staging of host-pointer batches)
-  int dense_bits = 8;
-  double dense_sigma = 256;    // distinct characters of the indexed text
-  int64_t sort_min = 4096;
-  bool timing = false;
-  KernelTimer t_count, t_locate;
-  // range-split index (femto_amd_open_split): this handle holds the segment lines and the block images of
-  // data blocks [split_blo[part], split_blo[part+1]); the other parts' slices are mapped from their owners
-  int split_parts = 0, split_part = 0;
-  bool split_ready = false;
-  std::vector<int64_t> split_blo;        // nparts + 1 block boundaries
-  std::vector<void*> peer_segs, peer_image;  // per part: base of that part's slices as seen from this process
-  std::vector<char> peer_ipc;            // per part: 1 if opened with hipIpcOpenMemHandle (close on release)
-  int64_t split_seg_bytes = 0, split_image_bytes = 0;
-  // multi-device handle (femto_amd_open_multi): no device of its own, one replica per GPU; host-pointer batches are
-  // sharded over the replicas by host threads
-  std::vector<femto_amd_index*> children;
-  // striped index (femto_amd_open_multi_striped): the big arrays are ONE address range each whose pages live in the HBM
-  // of all the listed GPUs (HIP virtual memory management); the small tables are copied to every GPU
-  std::vector<int> stripe_devices;           // non-empty while the builder handle allocates
-  struct Striped { void* va; size_t size, chunk; std::vector<hipMemGenericAllocationHandle_t> handles; };
-  std::vector<Striped> striped;
-  std::vector<std::pair<void*, size_t>> small_tables;   // every upload()ed table: what a view on another GPU copies
-  bool borrowed = false;                     // a view of another handle's arrays on a second GPU: owns only `owned_small`
-  bool imported = false;                     // ... of another PROCESS's arrays: also owns its mappings of them (`striped`)
-  std::vector<void*> owned_small;
-  // RCCL communicator of the multi-process form (femto_amd_comm_init)
-  ncclComm_t comm = nullptr;
-  int comm_rank = 0, comm_size = 0;
-};
-
-namespace {
+thread_local std::vector<std::pair<void*, size_t>>* g_small_registry = nullptr;   // set while a handle is being opened
 
 // lease of one Scratch for the duration of a call
 // `same_stream`: the call only enqueues work on that stream.  A scratch whose previous use was enqueued on the SAME stream
 // can be taken at once -- stream order keeps the two uses apart -- so a caller issuing step after step on one stream keeps
 // ONE warm scratch instead of cycling through the pool (creating a scratch allocates its buffers, which synchronises the
 // device: 0.2 ms per step of a 10-step run, measured).
-Scratch* scratch_acquire(femto_amd_index* ix, int* rc, bool enqueue_only = false, hipStream_t same_stream = nullptr) {
+Scratch* scratch_acquire(femto_amd_index* ix, int* rc, bool enqueue_only, hipStream_t same_stream) {
   std::unique_lock<std::mutex> lk(ix->pool_mu);
   for (;;) {
     Scratch* waiting = nullptr;
@@ -358,47 +118,6 @@ void scratch_release(femto_amd_index* ix, Scratch* s, bool async, hipStream_t st
     s->flight_stream = stream;
   }
   ix->pool_cv.notify_one();
-}
-
-struct Lease {
-  femto_amd_index* ix;
-  Scratch* s = nullptr;
-  bool async = false;           // enqueue-only call: the work is still running when the lease ends
-  hipStream_t stream = nullptr;
-  int rc = 0;
-  explicit Lease(femto_amd_index* i) : ix(i) { s = scratch_acquire(ix, &rc); }
-  Lease(femto_amd_index* i, hipStream_t st) : ix(i) {     // enqueue-only call on the caller's stream `st`
-    s = scratch_acquire(ix, &rc, true, st);
-    if (s) enqueue_only(st);
-  }
-  ~Lease() {
-    if (s) s->err = s->d_flags;
-    scratch_release(ix, s, async, stream);
-  }
-  // enqueue-only call on the caller's stream: nothing of it is checked on the host, so its kernels raise the error flag
-  // in a word of their own (a later host-pointer call on this scratch must not inherit it)
-  void enqueue_only(hipStream_t st) {
-    async = true;
-    stream = st;
-    s->err = s->d_flags + 3;
-  }
-  Lease(const Lease&) = delete;
-  Lease& operator=(const Lease&) = delete;
-};
-// `slack` zero bytes follow the data: a damaged index (counts that disagree with the bits they summarise) can make a
-// kernel index a little past the end of the table it is walking -- at most one bucket's worth -- and must read
-// zeros there, not fault.  (Results for such an index are garbage either way, as they are in the reference.)
-thread_local std::vector<std::pair<void*, size_t>>* g_small_registry = nullptr;   // set while a handle is being opened
-
-template <class T>
-int upload(T** dst, const std::vector<T>& src, int64_t* bytes, size_t slack = 0) {
-  size_t n = src.size() * sizeof(T);
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(dst), n + slack ? n + slack : 16));
-  if (n) HIP_TRY(hipMemcpy(*dst, src.data(), n, hipMemcpyHostToDevice));
-  if (slack) HIP_TRY(hipMemset(reinterpret_cast<char*>(*dst) + n, 0, slack));
-  if (bytes) *bytes += int64_t(n);
-  if (g_small_registry) g_small_registry->emplace_back(static_cast<void*>(*dst), (n + slack) ? n + slack : size_t(16));
-  return 0;
 }
 
 // ---- big arrays: plain hipMalloc, or -- striped index -- one address range backed by the HBM of several GPUs ---------
@@ -537,6 +256,11 @@ void timer_end(femto_amd_index* ix, KernelTimer& t, hipStream_t stream, hipEvent
   std::lock_guard<std::mutex> lk(ix->mu);
   t.events.emplace_back(e0, e1);
 }
+
+
+}  // namespace femto_amd
+
+namespace {
 
 // The locate plan that can ride along with a count: do_locate_query's clamp (src/main/server.c:4405-4415) and the
 // exclusive prefix sum of the row counts.  `done` is set when the count path produced noccs[], the block offsets in
@@ -2388,17 +2112,6 @@ int femto_amd_document_info(const femto_amd_index_t* ix, int64_t doc, const char
   return FEMTO_AMD_OK;
 }
 
-// Exceptions never cross the C boundary: bad_alloc -> ERR_MEM, anything else -> ERR_INVALID.
-#define API_BEGIN try {
-#define API_END                                                                            \
-  } catch (const std::bad_alloc&) {                                                        \
-    return set_err(FEMTO_AMD_ERR_MEM, "out of memory");                                    \
-  } catch (const std::exception& ex) {                                                     \
-    return set_err(FEMTO_AMD_ERR_INVALID, std::string("internal error: ") + ex.what());    \
-  } catch (...) {                                                                          \
-    return set_err(FEMTO_AMD_ERR_INVALID, "internal error");                               \
-  }
-
 int femto_amd_count_device(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
                            const int64_t* d_starts, int64_t* d_first, int64_t* d_last, void* stream) {
   API_BEGIN
@@ -2967,141 +2680,6 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
   API_END
 }
 
-// ---- regular expressions ---------------------------------------------------------------------------------
-// Backward search of every string the pattern matches (do_regexp_query, src/main/server.c:1656): level by level, every
-// (row range, NFA state set) in flight fans out over the characters its states can be entered through; the ranges of one
-// level are stepped by ONE launch of ranges_step_kernel.  A result is a string that reaches the automaton's start state
-// (the whole pattern read, right to left): its row range, sorted as regexp_result_list_sort does (first ascending, last
-// descending, server.c:1528).
-int femto_amd_regexp_search_approx(femto_amd_index_t* ix, const uint8_t* regex, int64_t regex_len, int max_cost, int subst_cost,
-                                   int delete_cost, int insert_cost, int64_t max_results, int64_t* first_out, int64_t* last_out,
-                                   int32_t* len_out, int32_t* cost_out, int64_t* n_out) {
-  API_BEGIN
-  if (!ix || (regex_len && !regex) || regex_len < 0 || max_results < 0 || !n_out || (max_results && (!first_out || !last_out)))
-    return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
-  if (max_cost < 0 || max_cost > 8 || subst_cost < 1 || delete_cost < 1 || insert_cost < 1)
-    return set_err(FEMTO_AMD_ERR_PARAM, "approximate search: 0 <= max_cost <= 8, costs >= 1");
-  if (!ix->children.empty())
-    return femto_amd_regexp_search_approx(ix->children[0], regex, regex_len, max_cost, subst_cost, delete_cost, insert_cost, max_results,
-                                          first_out, last_out, len_out, cost_out, n_out);
-  int rc = ensure_device(ix);
-  if (rc) return rc;
-  if (!ix->host.dir_regular) return set_err(FEMTO_AMD_ERR_INVALID, "regular-expression search needs the derived segment lines");
-  RegexNfa nfa;
-  {
-    std::string perr;
-    RegexParser parser(regex, regex_len, &nfa);
-    if (!parser.parse(&perr)) return set_err(FEMTO_AMD_ERR_PARAM, "regular expression: " + perr);
-  }
-  const ApproxCosts K{max_cost, subst_cost, delete_cost, insert_cost};
-  const HostIndex& h = ix->host;
-  CharClass in_text;                      // characters of the text that are real bytes (codes <= SEOF never match a class)
-  for (int c = FEMTO_AMD_CHARACTER_OFFSET; c < kAlphaSize; c++)
-    if (h.C[size_t(c) + 1] > h.C[size_t(c)]) in_text.set(c);
-  struct Item { CostVec s; int64_t first, last; int32_t len; };
-  struct Result { int64_t first, last; int32_t len, cost; };
-  std::vector<Result> results;
-  std::vector<Item> frontier, next;
-  {
-    Item it{CostVec(size_t(nfa.size()), kNoCost), 0, h.total_length - 1, 0};
-    it.s[size_t(nfa.accept)] = 0;
-    closure_cost(nfa, K, it.s);
-    if (it.s[size_t(nfa.start)] != kNoCost) results.push_back({it.first, it.last, 0, it.s[size_t(nfa.start)]});   // matches the empty string
-    frontier.push_back(std::move(it));
-  }
-  Lease L(ix);
-  if (!L.s) return L.rc;
-  Scratch& S = *L.s;
-  hipStream_t st = S.stream;
-  const int64_t work_limit = int64_t(1) << 24;     // (range, character) pairs per level: beyond it the pattern is too general
-  int64_t total_work = 0;
-  std::vector<int64_t> wf, wl, nf, nl;
-  std::vector<uint16_t> wc;
-  std::vector<uint32_t> wi;
-  while (!frontier.empty()) {
-    wf.clear(); wl.clear(); wc.clear(); wi.clear();
-    for (size_t i = 0; i < frontier.size(); i++) {
-      CharClass cc = incoming_chars_cost(nfa, K, frontier[i].s, frontier[i].len == 0, in_text);
-      for (int k = 0; k < 5; k++) cc.w[k] &= in_text.w[k];
-      for (int c = FEMTO_AMD_CHARACTER_OFFSET; c < kAlphaSize; c++)
-        if (cc.get(c)) {
-          wf.push_back(frontier[i].first);
-          wl.push_back(frontier[i].last);
-          wc.push_back(uint16_t(c));
-          wi.push_back(uint32_t(i));
-        }
-    }
-    const int64_t n = int64_t(wf.size());
-    if (n == 0) break;
-    total_work += n;
-    if (n > work_limit || total_work > 16 * work_limit)
-      return set_err(FEMTO_AMD_ERR_PARAM, "regular expression matches too many different strings of this index");
-    if ((rc = S.first.reserve(size_t(n) * 8)) || (rc = S.last.reserve(size_t(n) * 8)) || (rc = S.ch.reserve(size_t(n) * 2)) ||
-        (rc = S.occ.reserve(size_t(n) * 8)) || (rc = S.off.reserve(size_t(n) * 8)))
-      return rc;
-    HIP_TRY(hipMemcpyAsync(S.first.p, wf.data(), size_t(n) * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(S.last.p, wl.data(), size_t(n) * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(S.ch.p, wc.data(), size_t(n) * 2, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(ranges_step_kernel, dim3(uint32_t((n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, st, ix->dev, n,
-                       static_cast<const int64_t*>(S.first.as<int64_t>()), static_cast<const int64_t*>(S.last.as<int64_t>()),
-                       static_cast<const uint16_t*>(S.ch.as<uint16_t>()), S.occ.as<int64_t>(), S.off.as<int64_t>());
-    HIP_TRY(hipGetLastError());
-    nf.resize(size_t(n));
-    nl.resize(size_t(n));
-    HIP_TRY(hipMemcpyAsync(nf.data(), S.occ.p, size_t(n) * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(nl.data(), S.off.p, size_t(n) * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    next.clear();
-    for (int64_t k = 0; k < n; k++) {
-      if (nf[size_t(k)] > nl[size_t(k)]) continue;            // the extended string does not occur
-      const Item& it = frontier[wi[size_t(k)]];
-      Item ni{step_cost(nfa, K, it.s, wc[size_t(k)], it.len == 0), nf[size_t(k)], nl[size_t(k)], it.len + 1};
-      if (!any_alive(ni.s)) continue;
-      if (ni.s[size_t(nfa.start)] != kNoCost) {
-        results.push_back({ni.first, ni.last, ni.len, ni.s[size_t(nfa.start)]});
-        if (int64_t(results.size()) > max_results && max_results > 0)
-          return set_err(FEMTO_AMD_ERR_PARAM, "more results than max_results");
-      }
-      next.push_back(std::move(ni));
-    }
-    frontier.swap(next);
-  }
-  std::sort(results.begin(), results.end(), [](const Result& a, const Result& b) {
-    if (a.first != b.first) return a.first < b.first;
-    if (a.last != b.last) return a.last > b.last;
-    return a.len < b.len;
-  });
-  *n_out = int64_t(results.size());
-  if (int64_t(results.size()) > max_results) return max_results ? set_err(FEMTO_AMD_ERR_PARAM, "more results than max_results") : FEMTO_AMD_OK;
-  for (size_t i = 0; i < results.size(); i++) {
-    first_out[i] = results[i].first;
-    last_out[i] = results[i].last;
-    if (len_out) len_out[i] = results[i].len;
-    if (cost_out) cost_out[i] = results[i].cost;
-  }
-  return FEMTO_AMD_OK;
-  API_END
-}
-
-int femto_amd_regexp_search(femto_amd_index_t* ix, const uint8_t* regex, int64_t regex_len, int64_t max_results, int64_t* first_out,
-                            int64_t* last_out, int32_t* len_out, int64_t* n_out) {
-  return femto_amd_regexp_search_approx(ix, regex, regex_len, 0, 1, 1, 1, max_results, first_out, last_out, len_out, nullptr, n_out);
-}
-
-/* test hook: does the automaton built from `regex` accept exactly the byte string s?  1 yes, 0 no, -1 syntax error */
-int femto_amd_regexp_match(const uint8_t* regex, int64_t regex_len, const uint8_t* s, int64_t len) {
-  try {
-    if ((regex_len && !regex) || (len && !s) || regex_len < 0 || len < 0) return -1;
-    RegexNfa nfa;
-    std::string perr;
-    RegexParser parser(regex, regex_len, &nfa);
-    if (!parser.parse(&perr)) { set_err(FEMTO_AMD_ERR_PARAM, "regular expression: " + perr); return -1; }
-    return nfa_full_match(nfa, s, len) ? 1 : 0;
-  } catch (...) {
-    return -1;
-  }
-}
-
 // ---- several GPUs ------------------------------------------------------------------------------------------------------
 int femto_amd_open_multi(const char* index_path, int ndev, const int* devices, femto_amd_index_t** out) {
   API_BEGIN
@@ -3624,6 +3202,8 @@ int femto_amd_set_option(femto_amd_index_t* ix, const char* name, int value) {
   std::lock_guard<std::mutex> lk(ix->mu);
   if (!strcmp(name, "direct")) ix->direct = value != 0;
   else if (!strcmp(name, "sort")) ix->sort_queries = value != 0;
+  else if (!strcmp(name, "regexp_max_iterations")) ix->regexp_max_iterations = value;
+  else if (!strcmp(name, "regexp_stack_cap")) ix->regexp_stack_cap = std::max(16, value);
   else return set_err(FEMTO_AMD_ERR_PARAM, "unknown option");
   return FEMTO_AMD_OK;
 }

@@ -75,7 +75,7 @@ __device__ __forceinline__ void ind_search_step(const DevIndex& ix, int j, uint3
 
 // construction: one block per 960 rows; thread c builds character c's line from the block's symbols (LDS) and takes
 // the count before the line from the two-level lines
-__global__ __launch_bounds__(256) void ind_build_kernel(const DevIndex ix, const int64_t nrows, const uint16_t* __restrict__ sym,
+inline __global__ __launch_bounds__(256) void ind_build_kernel(const DevIndex ix, const int64_t nrows, const uint16_t* __restrict__ sym,
                                                         uint32_t* __restrict__ ind, const int64_t stride, const int64_t group0) {
   __shared__ uint16_t s_sym[kIndRows];
   const int64_t g = group0 + int64_t(blockIdx.x);

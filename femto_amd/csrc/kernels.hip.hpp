@@ -248,7 +248,7 @@ __device__ __forceinline__ int64_t bucket_of(const DevIndex& ix, int64_t row, ui
 
 // One backward-search job per pair of groups (do_string_query, src/main/server.c:713-946).
 template <int W>
-__global__ __launch_bounds__(256) void count_kernel(const DevIndex ix, const int64_t npats,
+inline __global__ __launch_bounds__(256) void count_kernel(const DevIndex ix, const int64_t npats,
                                                     const int32_t* __restrict__ plen,
                                                     const uint16_t* __restrict__ pats,
                                                     const int64_t* __restrict__ starts,
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void count_kernel(const DevIndex ix, const int
 }
 
 // do_locate_query clamp (src/main/server.c:4405-4415): note `last-first > max_occs`.
-__global__ void clamp_kernel(const int64_t npats, const int64_t* __restrict__ first, const int64_t* __restrict__ last,
+inline __global__ void clamp_kernel(const int64_t npats, const int64_t* __restrict__ first, const int64_t* __restrict__ last,
                              const int max_occs, int32_t* __restrict__ noccs, int64_t* __restrict__ noccs64) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= npats) return;
@@ -339,7 +339,7 @@ constexpr int kScanBlock = 256;
 constexpr int kScanItems = 8;  // per thread
 constexpr int kScanTile = kScanBlock * kScanItems;
 
-__global__ __launch_bounds__(kScanBlock) void scan_tile_kernel(const int64_t n, const int64_t* __restrict__ in,
+inline __global__ __launch_bounds__(kScanBlock) void scan_tile_kernel(const int64_t n, const int64_t* __restrict__ in,
                                                               int64_t* __restrict__ out, int64_t* __restrict__ tile_sums) {
   __shared__ int64_t warp_tot[kScanBlock / 64];
   const int64_t base = int64_t(blockIdx.x) * kScanTile + int64_t(threadIdx.x) * kScanItems;
@@ -373,12 +373,12 @@ __global__ __launch_bounds__(kScanBlock) void scan_tile_kernel(const int64_t n, 
   if (threadIdx.x == kScanBlock - 1) tile_sums[blockIdx.x] = woff + x;
 }
 
-__global__ void scan_add_kernel(const int64_t n, int64_t* __restrict__ out, const int64_t* __restrict__ tile_offs) {
+inline __global__ void scan_add_kernel(const int64_t n, int64_t* __restrict__ out, const int64_t* __restrict__ tile_offs) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < n) out[i] += tile_offs[i / kScanTile];
 }
 
-__global__ void set_total_kernel(const int64_t n, const int64_t* __restrict__ excl, const int64_t* __restrict__ in, int64_t* __restrict__ out_n) {
+inline __global__ void set_total_kernel(const int64_t n, const int64_t* __restrict__ excl, const int64_t* __restrict__ in, int64_t* __restrict__ out_n) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *out_n = n ? excl[n - 1] + in[n - 1] : 0;
 }
 
@@ -428,7 +428,7 @@ __device__ __forceinline__ uint32_t seq_in_bucket(const DevBucket& bk, int seq) 
 // One row per group: walk LF backwards until a marked row (do_back_query, src/main/server.c:2228-2359,
 // driven as do_context_query does with LOCATE_STRONG, :2627-2795).  offset = mark + steps (server.c:2718).
 template <int W>
-__global__ __launch_bounds__(256) void locate_kernel(const DevIndex ix, const int64_t npats,
+inline __global__ __launch_bounds__(256) void locate_kernel(const DevIndex ix, const int64_t npats,
                                                      const int64_t* __restrict__ first,
                                                      const int64_t* __restrict__ out_starts, const int64_t total,
                                                      int64_t* __restrict__ offsets) {
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void locate_kernel(const DevIndex ix, const in
 // Leaf requests for parity tests (block_request CHAR|OCCS|LOCATION, src/main/index.c:1973-2144).
 // occ_out = C[ch] + block_occs + Occ-in-block (the host subtracts the header part).
 template <int W>
-__global__ __launch_bounds__(256) void block_request_kernel(const DevIndex ix, const int64_t n,
+inline __global__ __launch_bounds__(256) void block_request_kernel(const DevIndex ix, const int64_t n,
                                                             const int64_t* __restrict__ rows,
                                                             const uint16_t* __restrict__ ch_in,
                                                             uint16_t* __restrict__ ch_out,
@@ -711,7 +711,7 @@ __device__ __forceinline__ int64_t c_plus_occ_lane(const DevIndex& ix, uint32_t 
 // One backward-search step for MANY (row range, character) pairs: the fan-out of do_regexp_query (src/main/server.c:1656,
 // states 0x200-0x411: "first = C[ch] + Occ(ch, first-1); last = C[ch] + Occ(ch, last) - 1" for every reachable character
 // of every range in flight), one lane per pair on femto's own wavelet tree.
-__global__ __launch_bounds__(256) void ranges_step_kernel(const DevIndex ix, const int64_t n, const int64_t* __restrict__ first,
+inline __global__ __launch_bounds__(256) void ranges_step_kernel(const DevIndex ix, const int64_t n, const int64_t* __restrict__ first,
                                                           const int64_t* __restrict__ last, const uint16_t* __restrict__ ch,
                                                           int64_t* __restrict__ first_out, int64_t* __restrict__ last_out) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(256) void ranges_step_kernel(const DevIndex ix, con
 // do_string_query (src/main/server.c:713-946): one LANE per pattern
 // `perm` (optional): lane j processes pattern perm[j] -- the batch ordered by pattern suffix
 // (query_sort.hip) so that neighbouring lanes share the rows of their first steps.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void count_kernel_lane(const DevIndex ix, const int64_t npats,
+inline __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void count_kernel_lane(const DevIndex ix, const int64_t npats,
                                                          const int32_t* __restrict__ plen,
                                                          const uint16_t* __restrict__ pats,
                                                          const int64_t* __restrict__ starts,
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void coun
 }
 
 // locate walk (do_back_query / do_context_query), one LANE per located row
-__global__ __launch_bounds__(256) void locate_kernel_lane(const DevIndex ix, const int64_t npats,
+inline __global__ __launch_bounds__(256) void locate_kernel_lane(const DevIndex ix, const int64_t npats,
                                                           const int64_t* __restrict__ first,
                                                           const int64_t* __restrict__ out_starts, const int64_t total,
                                                           int64_t* __restrict__ offsets) {
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256) void locate_kernel_lane(const DevIndex ix, con
   offsets[item] = result;
 }
 
-__global__ __launch_bounds__(256) void block_request_kernel_lane(const DevIndex ix, const int64_t n,
+inline __global__ __launch_bounds__(256) void block_request_kernel_lane(const DevIndex ix, const int64_t n,
                                                                  const int64_t* __restrict__ rows,
                                                                  const uint16_t* __restrict__ ch_in,
                                                                  uint16_t* __restrict__ ch_out,
@@ -858,7 +858,7 @@ enum : int { ST_QUERY = 0, ST_STEP = 1, ST_WALK = 2, ST_DONE = 3 };
 // do_string_query (src/main/server.c:713-946), flattened: every lane owns NQ patterns at a time and
 // advances the two walks (rows first-1 and last) of each by ONE wavelet level per loop iteration.
 template <int NQ>
-__global__ __launch_bounds__(256) void count_kernel_flat(const DevIndex ix, const int64_t npats,
+inline __global__ __launch_bounds__(256) void count_kernel_flat(const DevIndex ix, const int64_t npats,
                                                          const int32_t* __restrict__ plen,
                                                          const uint16_t* __restrict__ pats,
                                                          const int64_t* __restrict__ starts,
@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(256) void count_kernel_flat(const DevIndex ix, cons
 enum : int { LT_ITEM = 0, LT_ROW = 1, LT_WT = 2, LT_MARK = 3 };
 
 // locate walk (do_back_query / do_context_query), flattened: one rank per loop iteration
-__global__ __launch_bounds__(256) void locate_kernel_flat(const DevIndex ix, const int64_t npats,
+inline __global__ __launch_bounds__(256) void locate_kernel_flat(const DevIndex ix, const int64_t npats,
                                                           const int64_t* __restrict__ first,
                                                           const int64_t* __restrict__ out_starts, const int64_t total,
                                                           int64_t* __restrict__ offsets) {
@@ -1202,7 +1202,7 @@ __device__ __forceinline__ void bseq_select_lane(const uint8_t* __restrict__ ima
 // do_forward_query for one row per lane: chr = F[row] (bsearch_C, index.c:1522), the bucket holding the
 // (row+1-C[chr])'th occurrence of chr (bsearch_block_occs + bsearch_bucket_occs, index.c:1571,1847, here one
 // search over the combined Occ bases), wtree_select (wtree.c:1150-1178) and the mark lookup at the row found.
-__global__ __launch_bounds__(256) void forward_kernel(const DevIndex ix, const int64_t n, const int64_t* __restrict__ rows,
+inline __global__ __launch_bounds__(256) void forward_kernel(const DevIndex ix, const int64_t n, const int64_t* __restrict__ rows,
                                                       uint16_t* __restrict__ ch_out, int64_t* __restrict__ row_out,
                                                       int64_t* __restrict__ off_out) {
   const int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;

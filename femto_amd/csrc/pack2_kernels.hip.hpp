@@ -164,7 +164,7 @@ __device__ __forceinline__ void p2_search_step(const DevIndex& ix, int j, uint32
   last = nl - 1;
 }
 
-__global__ __launch_bounds__(256) void ktab_build_kernel2(const DevIndex ix, const int bits, const int syms, longlong2* __restrict__ tab) {
+inline __global__ __launch_bounds__(256) void ktab_build_kernel2(const DevIndex ix, const int bits, const int syms, longlong2* __restrict__ tab) {
   const uint64_t f = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (f >= (uint64_t(1) << (bits * syms))) return;
   int64_t first = 0, last = ix.total_length - 1;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void ktab_build_kernel2(const DevIndex ix, con
 // do_string_query (src/main/server.c:713-946), one lane per pattern; see count_kernel_pack for the key / table /
 // pair-store conventions.  Symbols the key does not hold are read from the pattern four at a time (aligned words).
 template <bool kKeys>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void count_kernel_pack2(const DevIndex ix, const int64_t npats, const int32_t* __restrict__ plen,
+inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void count_kernel_pack2(const DevIndex ix, const int64_t npats, const int32_t* __restrict__ plen,
                                                           const uint16_t* __restrict__ pats, const int64_t* __restrict__ starts,
                                                           int64_t* __restrict__ first_out, int64_t* __restrict__ last_out,
                                                           int* __restrict__ err_flag, const uint32_t* __restrict__ perm,
@@ -322,7 +322,7 @@ __device__ __forceinline__ P2Step p2_step(const DevIndex& ix, int64_t row) {
   return s;
 }
 
-__global__ __launch_bounds__(256) void locate_kernel_pack2(const DevIndex ix, const int64_t total, int64_t* __restrict__ offsets) {
+inline __global__ __launch_bounds__(256) void locate_kernel_pack2(const DevIndex ix, const int64_t total, int64_t* __restrict__ offsets) {
   const int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (item >= total) return;
   int64_t row = offsets[item];
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void locate_kernel_pack2(const DevIndex ix, co
   offsets[item] = result;
 }
 
-__global__ __launch_bounds__(256) void block_request_kernel_pack2(const DevIndex ix, const int64_t n, const int64_t* __restrict__ rows,
+inline __global__ __launch_bounds__(256) void block_request_kernel_pack2(const DevIndex ix, const int64_t n, const int64_t* __restrict__ rows,
                                                                   const uint16_t* __restrict__ ch_in, uint16_t* __restrict__ ch_out,
                                                                   int64_t* __restrict__ occ_out, int64_t* __restrict__ off_out) {
   const int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void block_request_kernel_pack2(const DevIndex
 // ---- construction (at open, on the GPU, from the lane tables) -------------------------------------------------------
 
 // phase A: sym[row] = dense code | 0x8000 if the row is marked
-__global__ __launch_bounds__(256) void p2_extract_kernel(const DevIndex ix, const int64_t row0, const int64_t n, uint16_t* __restrict__ sym) {
+inline __global__ __launch_bounds__(256) void p2_extract_kernel(const DevIndex ix, const int64_t row0, const int64_t n, uint16_t* __restrict__ sym) {
   const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (row >= row0 + n) return;
   uint32_t idx1;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void p2_extract_kernel(const DevIndex ix, cons
 }
 
 // phase B1: level-1 planes of one line (64 rows) + its 16 h-counts and mark count (SoA counts[k*stride + line], k=16: marks)
-__global__ __launch_bounds__(256) void p2_l1_planes_kernel(const int64_t nlines, const int64_t nrows, const uint16_t* __restrict__ sym,
+inline __global__ __launch_bounds__(256) void p2_l1_planes_kernel(const int64_t nlines, const int64_t nrows, const uint16_t* __restrict__ sym,
                                                            uint32_t* __restrict__ l1, int64_t* __restrict__ counts, const int64_t stride) {
   const int64_t line = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (line >= nlines) return;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void p2_l1_planes_kernel(const int64_t nlines,
 }
 
 // phase B3: counts before every line -> dwords 10..31
-__global__ __launch_bounds__(256) void p2_l1_counts_kernel(const int64_t nlines, uint32_t* __restrict__ l1, const int64_t* __restrict__ scans,
+inline __global__ __launch_bounds__(256) void p2_l1_counts_kernel(const int64_t nlines, uint32_t* __restrict__ l1, const int64_t* __restrict__ scans,
                                                            const int64_t stride) {
   const int64_t line = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (line >= nlines) return;
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void p2_l1_counts_kernel(const int64_t nlines,
 }
 
 // phase C: scatter every row's l digit to its level-2 position: lo2[p2_base[h]*96 + rank_h(row) - 1]
-__global__ __launch_bounds__(256) void p2_scatter_kernel(const DevIndex ix, const int64_t row0, const int64_t n, const uint16_t* __restrict__ sym,
+inline __global__ __launch_bounds__(256) void p2_scatter_kernel(const DevIndex ix, const int64_t row0, const int64_t n, const uint16_t* __restrict__ sym,
                                                          uint8_t* __restrict__ lo2) {
   const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (row >= row0 + n) return;
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void p2_scatter_kernel(const DevIndex ix, cons
 }
 
 // phase D1: level-2 planes of one line (96 positions) + its 16 l-counts
-__global__ __launch_bounds__(256) void p2_l2_planes_kernel(const int64_t nlines, const uint8_t* __restrict__ lo2, uint32_t* __restrict__ l2,
+inline __global__ __launch_bounds__(256) void p2_l2_planes_kernel(const int64_t nlines, const uint8_t* __restrict__ lo2, uint32_t* __restrict__ l2,
                                                            int64_t* __restrict__ counts, const int64_t stride) {
   const int64_t line = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (line >= nlines) return;
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void p2_l2_planes_kernel(const int64_t nlines,
 // phase D3: C[ch(16h+k)] + earlier positions of the same h with l == k -> dwords 12..31.  Padding positions (value 0)
 // sit at the end of an h's last line, i.e. after every real position of that h, and the next h subtracts the scan
 // value at its own first line, so they are never counted.
-__global__ __launch_bounds__(256) void p2_l2_counts_kernel(const DevIndex ix, const int64_t nlines, uint32_t* __restrict__ l2,
+inline __global__ __launch_bounds__(256) void p2_l2_counts_kernel(const DevIndex ix, const int64_t nlines, uint32_t* __restrict__ l2,
                                                            const int64_t* __restrict__ scans, const int64_t stride) {
   const int64_t line = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (line >= nlines) return;
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void p2_l2_counts_kernel(const DevIndex ix, co
 }
 
 // phase E: offsets of the marked rows in row order
-__global__ __launch_bounds__(256) void p2_sa_kernel(const DevIndex ix, const int64_t row0, const int64_t n, const uint16_t* __restrict__ sym,
+inline __global__ __launch_bounds__(256) void p2_sa_kernel(const DevIndex ix, const int64_t row0, const int64_t n, const uint16_t* __restrict__ sym,
                                                     int64_t* __restrict__ sa) {
   const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (row >= row0 + n) return;
@@ -548,7 +548,7 @@ __device__ __forceinline__ int64_t p2_mark_rank(const uint32_t* __restrict__ l1,
 }
 
 template <bool kStore>
-__global__ __launch_bounds__(256) void p2_densify_kernel(const DevIndex ix, uint32_t* __restrict__ l1, const int64_t row0, const int64_t n,
+inline __global__ __launch_bounds__(256) void p2_densify_kernel(const DevIndex ix, uint32_t* __restrict__ l1, const int64_t row0, const int64_t n,
                                                          const uint16_t* __restrict__ sym, const int every, const int period,
                                                          int64_t* __restrict__ sa) {
   const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -571,13 +571,13 @@ __global__ __launch_bounds__(256) void p2_densify_kernel(const DevIndex ix, uint
   }
 }
 
-__global__ __launch_bounds__(256) void p2_recount_marks_kernel(const int64_t nlines, const uint32_t* __restrict__ l1, int64_t* __restrict__ counts) {
+inline __global__ __launch_bounds__(256) void p2_recount_marks_kernel(const int64_t nlines, const uint32_t* __restrict__ l1, int64_t* __restrict__ counts) {
   const int64_t line = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (line >= nlines) return;
   counts[line] = int64_t(__popc(l1[line * 32 + 8]) + __popc(l1[line * 32 + 9]));
 }
 
-__global__ __launch_bounds__(256) void p2_markcount_kernel(const int64_t nlines, uint32_t* __restrict__ l1, const int64_t* __restrict__ scan) {
+inline __global__ __launch_bounds__(256) void p2_markcount_kernel(const int64_t nlines, uint32_t* __restrict__ l1, const int64_t* __restrict__ scan) {
   const int64_t line = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (line >= nlines) return;
   const uint64_t m = uint64_t(scan[line]);

@@ -120,7 +120,7 @@ __device__ __forceinline__ void pack_search_step(const DevIndex& ix, const uint3
 //   x = first,  y = (last + 1) | fields_consumed << 48.
 constexpr uint64_t kKtabLastMask = (uint64_t(1) << 48) - 1;
 
-__global__ __launch_bounds__(256) void ktab_build_kernel(const DevIndex ix, const int bits, const int syms, longlong2* __restrict__ tab) {
+inline __global__ __launch_bounds__(256) void ktab_build_kernel(const DevIndex ix, const int bits, const int syms, longlong2* __restrict__ tab) {
   const uint64_t f = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (f >= (uint64_t(1) << (bits * syms))) return;
   int64_t first = 0, last = ix.total_length - 1;
@@ -155,7 +155,7 @@ __device__ __forceinline__ void tail_append(const DevIndex& ix, int64_t slot, in
 // scattered over the batch (a 128-byte memory line per symbol once the batch is processed out of order); plen /
 // starts / the pattern are only touched for patterns the key does not describe completely.
 template <bool kKeys>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void count_kernel_pack(const DevIndex ix, const int64_t npats, const int32_t* __restrict__ plen,
+inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void count_kernel_pack(const DevIndex ix, const int64_t npats, const int32_t* __restrict__ plen,
                                                          const uint16_t* __restrict__ pats, const int64_t* __restrict__ starts,
                                                          int64_t* __restrict__ first_out, int64_t* __restrict__ last_out,
                                                          int* __restrict__ err_flag, const uint32_t* __restrict__ perm,
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 }
 
 // split + the locate clamp of do_locate_query (src/main/server.c:4405-4415, note `last-first > max_occs`) in one pass
-__global__ __launch_bounds__(256) void split_clamp_kernel(const int64_t n, const longlong2* __restrict__ pairs, int64_t* __restrict__ first_out,
+inline __global__ __launch_bounds__(256) void split_clamp_kernel(const int64_t n, const longlong2* __restrict__ pairs, int64_t* __restrict__ first_out,
                                                           int64_t* __restrict__ last_out, const int max_occs, int32_t* __restrict__ noccs,
                                                           int64_t* __restrict__ noccs64) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void split_clamp_kernel(const int64_t n, const
 }
 
 // (first,last) pairs -> the API's separate arrays (coalesced); last_out == NULL: first_out receives the counts
-__global__ __launch_bounds__(256) void split_pairs_kernel(const int64_t n, const longlong2* __restrict__ pairs, int64_t* __restrict__ first_out,
+inline __global__ __launch_bounds__(256) void split_pairs_kernel(const int64_t n, const longlong2* __restrict__ pairs, int64_t* __restrict__ first_out,
                                                           int64_t* __restrict__ last_out) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -314,7 +314,7 @@ __device__ __forceinline__ PackStep pack_step(const PackLine& L, uint32_t r) {
 // then needs no search for "which pattern owns output slot i".
 constexpr int64_t kExpandSerialMax = 4096;   // a longer range (e.g. the empty pattern's) is filled by one thread per row
 
-__global__ __launch_bounds__(256) void expand_rows_kernel(const int64_t npats, const int64_t* __restrict__ first,
+inline __global__ __launch_bounds__(256) void expand_rows_kernel(const int64_t npats, const int64_t* __restrict__ first,
                                                           const int64_t* __restrict__ out_starts, int64_t* __restrict__ offsets,
                                                           int* __restrict__ big_flag) {
   const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void expand_rows_kernel(const int64_t npats, c
 }
 
 // the long ranges left over by expand_rows_kernel: one thread per output slot (idle unless the flag is set)
-__global__ __launch_bounds__(256) void expand_big_rows_kernel(const int64_t npats, const int64_t* __restrict__ first,
+inline __global__ __launch_bounds__(256) void expand_big_rows_kernel(const int64_t npats, const int64_t* __restrict__ first,
                                                               const int64_t* __restrict__ out_starts, const int64_t total,
                                                               int64_t* __restrict__ offsets, const int* __restrict__ big_flag) {
   if (!*big_flag) return;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void expand_big_rows_kernel(const int64_t npat
 // (A persistent-lane variant -- finished lanes pull the next row instead of idling until the slowest lane of the
 // wavefront is done -- and the removal of the per-row owner search both measured neutral: 105 M random line
 // fetches per 10 M rows run at 30 G lines/s = 4 TB/s either way, the rate of purely random 128-byte reads.)
-__global__ __launch_bounds__(256) void locate_kernel_pack(const DevIndex ix, const int64_t total, int64_t* __restrict__ offsets) {
+inline __global__ __launch_bounds__(256) void locate_kernel_pack(const DevIndex ix, const int64_t total, int64_t* __restrict__ offsets) {
   const int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (item >= total) return;
   int64_t row = offsets[item];
@@ -387,7 +387,7 @@ __device__ __forceinline__ int64_t lane_mark_offset(const DevIndex& ix, int64_t 
 }
 
 // leaf requests (block_request CHAR|OCCS|LOCATION, src/main/index.c:1973-2144) from the packed lines
-__global__ __launch_bounds__(256) void block_request_kernel_pack(const DevIndex ix, const int64_t n, const int64_t* __restrict__ rows,
+inline __global__ __launch_bounds__(256) void block_request_kernel_pack(const DevIndex ix, const int64_t n, const int64_t* __restrict__ rows,
                                                                  const uint16_t* __restrict__ ch_in, uint16_t* __restrict__ ch_out,
                                                                  int64_t* __restrict__ occ_out, int64_t* __restrict__ off_out) {
   const int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void block_request_kernel_pack(const DevIndex 
 // ---- construction of the packed lines (at open, on the GPU, from the lane tables) ------------------------------
 
 // phase A: sym[row] = dense code of L[row] | 0x80 if the row is marked
-__global__ __launch_bounds__(256) void pack_extract_kernel(const DevIndex ix, const int64_t row0, const int64_t n, uint8_t* __restrict__ sym) {
+inline __global__ __launch_bounds__(256) void pack_extract_kernel(const DevIndex ix, const int64_t row0, const int64_t n, uint8_t* __restrict__ sym) {
   const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (row >= row0 + n) return;
   uint32_t idx1;
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void pack_extract_kernel(const DevIndex ix, co
 }
 
 // phase B1: one thread per line: planes from 160 sym bytes, per-line counts (SoA: counts[c * stride + line], c = 8: marks)
-__global__ __launch_bounds__(256) void pack_planes_kernel(const int64_t nlines, const uint8_t* __restrict__ sym, uint32_t* __restrict__ pack,
+inline __global__ __launch_bounds__(256) void pack_planes_kernel(const int64_t nlines, const uint8_t* __restrict__ sym, uint32_t* __restrict__ pack,
                                                           int64_t* __restrict__ counts, const int64_t stride) {
   const int64_t line = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (line >= nlines) return;
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void pack_planes_kernel(const int64_t nlines, 
 
 // phase B3: counts before every line (exclusive scans, SoA) + C[ch] -> dwords 20..31
 // NOTE: padding rows past total_length carry code 0; they lie after every real row, so no count that is ever read includes them.
-__global__ __launch_bounds__(256) void pack_counts_kernel(const DevIndex ix, const int64_t nlines, uint32_t* __restrict__ pack,
+inline __global__ __launch_bounds__(256) void pack_counts_kernel(const DevIndex ix, const int64_t nlines, uint32_t* __restrict__ pack,
                                                           const int64_t* __restrict__ scans, const int64_t stride) {
   const int64_t line = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (line >= nlines) return;
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void pack_counts_kernel(const DevIndex ix, con
 }
 
 // phase C: the offsets of the marked rows, in row order
-__global__ __launch_bounds__(256) void pack_sa_kernel(const DevIndex ix, const int64_t row0, const int64_t n, const uint8_t* __restrict__ sym,
+inline __global__ __launch_bounds__(256) void pack_sa_kernel(const DevIndex ix, const int64_t row0, const int64_t n, const uint8_t* __restrict__ sym,
                                                       const uint32_t* __restrict__ pack, int64_t* __restrict__ sa) {
   const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (row >= row0 + n) return;
@@ -558,7 +558,7 @@ __device__ __forceinline__ int64_t pack_mark_rank(const uint32_t* __restrict__ p
 }
 
 template <bool kStore>
-__global__ __launch_bounds__(256) void pack_densify_kernel(const DevIndex ix, uint32_t* __restrict__ pack, const int64_t row0, const int64_t n,
+inline __global__ __launch_bounds__(256) void pack_densify_kernel(const DevIndex ix, uint32_t* __restrict__ pack, const int64_t row0, const int64_t n,
                                                            const uint8_t* __restrict__ sym, const int every, const int period,
                                                            int64_t* __restrict__ sa) {
   const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256) void pack_densify_kernel(const DevIndex ix, ui
   }
 }
 
-__global__ __launch_bounds__(256) void pack_recount_marks_kernel(const int64_t nlines, const uint32_t* __restrict__ pack, int64_t* __restrict__ counts) {
+inline __global__ __launch_bounds__(256) void pack_recount_marks_kernel(const int64_t nlines, const uint32_t* __restrict__ pack, int64_t* __restrict__ counts) {
   const int64_t line = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (line >= nlines) return;
   const uint32_t* lp = pack + line * kPackLineWords;
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256) void pack_recount_marks_kernel(const int64_t n
   counts[line] = int64_t(c);
 }
 
-__global__ __launch_bounds__(256) void pack_markcount_kernel(const int64_t nlines, uint32_t* __restrict__ pack, const int64_t* __restrict__ scan) {
+inline __global__ __launch_bounds__(256) void pack_markcount_kernel(const int64_t nlines, uint32_t* __restrict__ pack, const int64_t* __restrict__ scan) {
   const int64_t line = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (line >= nlines) return;
   const uint64_t m = uint64_t(scan[line]);

@@ -1,16 +1,16 @@
-// regexp_nfa.hpp -- host side of regular-expression search: pattern -> Thompson NFA -> the REVERSED
-// automaton the backward search simulates.
+// regexp_nfa.hpp -- host side of regular-expression search: pattern -> Thompson NFA -> the epsilon-free
+// automaton of the REVERSED pattern in the reference's own form (nfa_description_t, src/main/nfa.h:62-88).
 //
-// The reference parses a query with a flex/bison grammar into an AST, compiles it to a Thompson NFA
-// (src/main/compile_regexp.c, src/main/nfa.c) and walks the index backwards with the set of NFA states each searched
-// string reaches (do_regexp_query, src/main/server.c:1656): for every (row range, state set) it asks Occ for EVERY
-// character the states can read next -- a 261-way fan-out of the same leaf requests a literal search issues.  Here
-// the pattern language is the byte-regular-expression part of src/main/QUERY_FORMAT.txt (literals, `.`, `[...]`
-// classes, `( )`, `|`, `*`, `+`, `?`, backslash escapes, quotes; unescaped whitespace separates terms and is ignored),
-// without the boolean / APPROX keywords; the fan-out runs as one batched GPU kernel per string length
-// (ranges_step_kernel).  The reference's regular-expression front end cannot be built in this image (no flex/bison), so
-// this path has NO reference golden vectors: it is checked against brute force over the fixture texts (the method
-// of index_test.c:351-434) -- parity with the reference's result lists is UNPINNED and says so in DESIGN.md.
+// The reference parses a query with a flex/bison grammar into an AST, reverses it (reverse_regexp), compiles it to a
+// Thompson NFA and removes the epsilon edges (src/main/compile_regexp.c:658-705); do_regexp_query (src/main/server.c:1656)
+// then walks the index backwards simulating that automaton.  Here the pattern language is the byte-regular-expression part
+// of src/main/QUERY_FORMAT.txt (literals, `.`, `[...]` classes, `( )`, `|`, `*`, `+`, `?`, backslash escapes, quotes;
+// unescaped whitespace separates terms and is ignored), without the boolean keywords; the automaton handed to the search is
+// the Glushkov (position) automaton of the reversed pattern -- epsilon-free by construction, one node per character
+// position plus the start node.  The reference's front end cannot be generated in this image (no flex/bison), so parity is
+// pinned one level below it: the SAME nfa_description_t is fed to the genuine do_regexp_query through
+// setup_regexp_query_take_nfa (server.h:838; oracle/ref_tool.c regexp_nfa) and to femto_amd_nfa_search_batch
+// (regexp_search.hip), and the result lists must be identical (tests/golden/*_regexp.npz, tests/test_regexp.py).
 #pragma once
 #include <cstdint>
 #include <string>
@@ -20,6 +20,8 @@ namespace femto_amd {
 
 constexpr int kRegexAlpha = 261;          // ALPHA_SIZE: class bits are alpha codes (byte + 5)
 constexpr int kRegexMaxStates = 4096;
+constexpr int kRegexMaxDepth = 256;       // nesting of ( ): the recursive-descent parser's stack is bounded by it
+constexpr int64_t kRegexMaxLen = 1 << 20; // bytes of pattern text accepted at all
 
 struct CharClass {
   uint64_t w[5] = {0, 0, 0, 0, 0};
@@ -41,7 +43,9 @@ struct RegexNfa {
   // reversed view: r_eps[v] = states with an epsilon edge INTO v; r_in[v] = states whose class edge leads INTO v
   std::vector<std::vector<int>> r_eps, r_in;
   int size() const { return int(to.size()); }
+  bool too_large = false;      // add() refuses to grow past kRegexMaxStates: the parser fails early (no multi-MB automata)
   int add() {
+    if (size() >= kRegexMaxStates) { too_large = true; return size() - 1; }
     eps.emplace_back();
     cls.emplace_back();
     to.push_back(-1);
@@ -67,8 +71,10 @@ class RegexParser {
   RegexParser(const uint8_t* p, int64_t n, RegexNfa* nfa) : p_(p), n_(n), nfa_(nfa) {}
   // returns false with *err set on a syntax error
   bool parse(std::string* err) {
+    if (n_ > kRegexMaxLen) { *err = "pattern text too long"; return false; }
     Frag f;
     if (!alt(&f)) { *err = err_; return false; }
+    if (nfa_->too_large) { *err = "regular expression too large"; return false; }
     skip_ws();
     if (at_ < n_) { *err = "unexpected '" + std::string(1, char(p_[at_])) + "'"; return false; }
     nfa_->start = f.in;
@@ -83,6 +89,7 @@ class RegexParser {
   const uint8_t* p_;
   int64_t n_, at_ = 0;
   RegexNfa* nfa_;
+  int depth_ = 0;
   std::string err_;
   bool fail(const std::string& m) { err_ = m; return false; }
   void skip_ws() { while (at_ < n_ && (p_[at_] == ' ' || p_[at_] == '\t' || p_[at_] == '\n' || p_[at_] == '\r')) at_++; }
@@ -155,6 +162,7 @@ class RegexParser {
     Frag f = empty();
     for (;;) {
       if (at_ >= n_) return fail("unterminated quote");
+      if (nfa_->too_large) return fail("regular expression too large");
       int c = p_[at_++];
       if (c == q) break;
       if (q == '"' && c == '\\' && !escape(&c)) return false;
@@ -173,7 +181,10 @@ class RegexParser {
     const uint8_t c = p_[at_];
     if (c == '(') {
       at_++;
-      if (!alt(out)) return false;
+      if (++depth_ > kRegexMaxDepth) return fail("parentheses nested too deeply");   // the descent recurses per '(': bound the stack
+      const bool ok = alt(out);
+      depth_--;
+      if (!ok) return false;
       skip_ws();
       if (at_ >= n_ || p_[at_] != ')') return fail("missing )");
       at_++;
@@ -222,6 +233,7 @@ class RegexParser {
     for (;;) {
       skip_ws();
       if (at_ >= n_ || p_[at_] == '|' || p_[at_] == ')') break;
+      if (nfa_->too_large) return fail("regular expression too large");
       Frag g;
       if (!repeat(&g)) return false;
       nfa_->eps[size_t(f.out)].push_back(g.in);
@@ -282,62 +294,81 @@ inline CharClass incoming_chars(const RegexNfa& n, const StateSet& s) {
         for (int k = 0; k < 5; k++) r.w[k] |= n.cls[size_t(u)].w[k];
   return r;
 }
-// ---- approximate matching (QUERY_FORMAT.txt "APPROXIMATE SEARCH"; the error-counting states of src/main/nfa.c) -------
-// A cost vector holds, per state, the least cost at which the string read so far (right to left) can have brought the
-// reversed automaton there (kNoCost: not at all).  Costs: a substitution, a character missing from the data ("delete":
-// the pattern's character is skipped), an extra character in the data ("insert": read without moving).
-constexpr uint8_t kNoCost = 255;
-struct ApproxCosts { int max_cost = 0, subst = 1, del = 1, ins = 1; };
-using CostVec = std::vector<uint8_t>;
+// ---- the automaton the search simulates: the reference's nfa_description_t, flat -----------------------------------------
+// Nodes with (character, destination) transitions, a set of start nodes, a set of final nodes, the approximate-search
+// settings (src/main/nfa.h:62-88, regexp_settings_t src/main/index_types.h:147-162).  The search reads the matched string
+// from its LAST character to its first, so this is an automaton of the reversed pattern.
+struct NfaDesc {
+  int32_t num_nodes = 0;
+  std::vector<int32_t> trans_start;   // [num_nodes + 1]
+  std::vector<int32_t> trans_char;    // alpha codes (byte + 5)
+  std::vector<int32_t> trans_dest;
+  std::vector<uint8_t> is_start, is_final;
+  int32_t cost_bound = 1, subst_cost = 1, delete_cost = 1, insert_cost = 1;   // set_default_regexp_settings: exact matching
+};
+constexpr int64_t kNfaMaxTransitions = int64_t(1) << 22;
 
-// closure: reversed epsilon edges cost nothing, skipping a class edge costs `del` (relaxed until stable; costs are small)
-inline void closure_cost(const RegexNfa& n, const ApproxCosts& k, CostVec& c) {
+// Glushkov automaton of the reversed pattern: node 0 = nothing read yet; node 1 + k = the k-th class edge ("position") of the
+// Thompson automaton has just been read.  Reading backwards, position p' may follow position p when p' can PRECEDE p in a
+// match (to[p'] reaches p over epsilon edges); the first character read must be able to END a match; a node is final when
+// its position can START a match.  false: more than kNfaMaxTransitions transitions.
+inline bool build_reversed_nfa(const RegexNfa& n, NfaDesc* out) {
+  const int S = n.size();
+  std::vector<int> pos_of(size_t(S), -1), positions;
+  for (int s = 0; s < S; s++)
+    if (n.to[size_t(s)] >= 0) { pos_of[size_t(s)] = int(positions.size()); positions.push_back(s); }
+  const int P = int(positions.size());
+  // forward epsilon closure of one state
+  std::vector<char> seen(static_cast<size_t>(S));
   std::vector<int> stack;
-  for (int i = 0; i < n.size(); i++) if (c[size_t(i)] != kNoCost) stack.push_back(i);
-  while (!stack.empty()) {
-    const int v = stack.back();
-    stack.pop_back();
-    const int cv = c[size_t(v)];
-    for (int u : n.r_eps[size_t(v)])
-      if (cv < c[size_t(u)]) { c[size_t(u)] = uint8_t(cv); stack.push_back(u); }
-    if (k.max_cost > 0 && cv + k.del <= k.max_cost)
-      for (int u : n.r_in[size_t(v)])
-        if (cv + k.del < c[size_t(u)]) { c[size_t(u)] = uint8_t(cv + k.del); stack.push_back(u); }
-  }
-}
-// read alpha code x; `at_end`: this is the pattern's last character -- no substitution and no extra character there
-// (QUERY_FORMAT.txt: "The approximate search will never allow substitutions at the last character")
-inline CostVec step_cost(const RegexNfa& n, const ApproxCosts& k, const CostVec& c, int x, bool at_end) {
-  CostVec r(c.size(), kNoCost);
-  for (int v = 0; v < n.size(); v++) {
-    const int cv = c[size_t(v)];
-    if (cv == kNoCost) continue;
-    for (int u : n.r_in[size_t(v)]) {
-      const int cu = n.cls[size_t(u)].get(x) ? cv : (at_end ? int(kNoCost) : cv + k.subst);
-      if (cu <= k.max_cost && cu < r[size_t(u)]) r[size_t(u)] = uint8_t(cu);
+  auto closure = [&](int from) {
+    std::fill(seen.begin(), seen.end(), 0);
+    stack.assign(1, from);
+    seen[size_t(from)] = 1;
+    while (!stack.empty()) {
+      const int v = stack.back();
+      stack.pop_back();
+      for (int u : n.eps[size_t(v)])
+        if (!seen[size_t(u)]) { seen[size_t(u)] = 1; stack.push_back(u); }
     }
-    if (!at_end && cv + k.ins <= k.max_cost && cv + k.ins < r[size_t(v)]) r[size_t(v)] = uint8_t(cv + k.ins);
+  };
+  // preds[p] = positions p' whose edge target reaches position p; ends = positions whose edge target reaches accept
+  std::vector<std::vector<int>> preds(static_cast<size_t>(P));
+  std::vector<int> ends;
+  for (int k = 0; k < P; k++) {
+    closure(n.to[size_t(positions[size_t(k)])]);
+    if (seen[size_t(n.accept)]) ends.push_back(k);
+    for (int j = 0; j < P; j++)
+      if (seen[size_t(positions[size_t(j)])]) preds[size_t(j)].push_back(k);
   }
-  closure_cost(n, k, r);
-  return r;
-}
-inline bool any_alive(const CostVec& c) {
-  for (uint8_t v : c) if (v != kNoCost) return true;
-  return false;
-}
-// characters worth prepending: with errors left every character of the text can be an error; otherwise the class edges
-inline CharClass incoming_chars_cost(const RegexNfa& n, const ApproxCosts& k, const CostVec& c, bool at_end, const CharClass& all) {
-  CharClass r;
-  bool errors_left = false;
-  for (int v = 0; v < n.size(); v++) {
-    const int cv = c[size_t(v)];
-    if (cv == kNoCost) continue;
-    if (!at_end && (cv + k.ins <= k.max_cost || (cv + k.subst <= k.max_cost && !n.r_in[size_t(v)].empty()))) errors_left = true;
-    for (int u : n.r_in[size_t(v)])
-      for (int w = 0; w < 5; w++) r.w[w] |= n.cls[size_t(u)].w[w];
-  }
-  if (errors_left) for (int w = 0; w < 5; w++) r.w[w] |= all.w[w];
-  return r;
+  closure(n.start);
+  out->num_nodes = P + 1;
+  out->is_start.assign(size_t(P) + 1, 0);
+  out->is_final.assign(size_t(P) + 1, 0);
+  out->is_start[0] = 1;
+  if (seen[size_t(n.accept)]) out->is_final[0] = 1;            // the pattern matches the empty string
+  for (int k = 0; k < P; k++)
+    if (seen[size_t(positions[size_t(k)])]) out->is_final[size_t(k) + 1] = 1;
+  out->trans_start.assign(1, 0);
+  out->trans_char.clear();
+  out->trans_dest.clear();
+  auto emit = [&](const std::vector<int>& targets) -> bool {
+    for (int k : targets) {
+      const CharClass& cc = n.cls[size_t(positions[size_t(k)])];
+      for (int c = 0; c < kRegexAlpha; c++)
+        if (cc.get(c)) {
+          out->trans_char.push_back(c);
+          out->trans_dest.push_back(k + 1);
+        }
+      if (int64_t(out->trans_char.size()) > kNfaMaxTransitions) return false;
+    }
+    out->trans_start.push_back(int32_t(out->trans_char.size()));
+    return true;
+  };
+  if (!emit(ends)) return false;
+  for (int k = 0; k < P; k++)
+    if (!emit(preds[size_t(k)])) return false;
+  return true;
 }
 
 // does the automaton accept exactly this byte string?  (tests: the parser and the construction against a regex library)

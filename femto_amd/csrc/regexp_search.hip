@@ -1,0 +1,648 @@
+// regexp_search.hip -- batched NFA search over the index: do_regexp_query (src/main/server.c:1656-2163) for
+// MANY automata at once, entirely on the GPU.
+//
+// The reference simulates one nfa_description_t (src/main/nfa.h:62-88) backwards over the index: a map from row range
+// [first,last] to the set of NFA states (one error count per state) the strings with that range have reached, kept in a
+// STACK with a hash on the range (queue_map, src/utils/queue_map.c -- "THIS ... IS NOT ACTUALLY A QUEUE; IT IS A STACK").
+// Pop an entry; if a final state is alive it is a result and is not extended; otherwise, for every character some alive
+// state can read (every character of the alphabet while errors are left), new_first = C[ch] + Occ(ch, first-1),
+// new_last = C[ch] + Occ(ch, last) - 1 -- the 261-way fan-out -- and the child (new range -> states after reading ch,
+// merged with the substitution and insertion states) is pushed, or min-merged into the pending entry that already has
+// that range (add_mapping, server.c:1558-1652).  The results are sorted, de-duplicated and ranges inside other ranges
+// dropped (regexp_result_list_sort, server.c:1528-1573).
+//
+// Here ONE 64-lane workgroup runs one automaton's whole search, and a batch of automata fills the GPU:
+//   * the stack (ranges, match lengths, one cost byte per node and entry) lives in a per-workgroup arena in HBM;
+//   * the popped entry's cost vector, the per-character transition lists (the automaton's transitions sorted by
+//     character at upload: reading character ch touches exactly its own entries) and the children live in LDS;
+//   * lane k computes the k-th reachable character's new range -- the fan-out is one wavefront-wide step on the index's
+//     fastest rank layout (packed lines / per-character rank lines / femto's wavelet tree);
+//   * the lanes stride over transition entries (LDS atomicMin), over the nodes of a cost vector, and over the pending
+//     entries when a child looks for an entry with its range.
+// The order of every push, merge and pop is the reference's (it decides which match length and cost a merged entry
+// reports), so the result lists are IDENTICAL to do_regexp_query's for the same nfa_description_t: pinned by
+// tests/golden/*_regexp.npz (generated through setup_regexp_query_take_nfa, oracle/ref_tool.c) and tests/test_regexp.py.
+#include <algorithm>
+#include <climits>
+#include <cstring>
+
+#include "api_internal.hpp"
+#include "kernels.hip.hpp"
+#include "pack_kernels.hip.hpp"
+#include "pack2_kernels.hip.hpp"
+#include "ind_kernels.hip.hpp"
+#include "text_kernels.hip.hpp"
+#include "regexp_nfa.hpp"
+
+using namespace femto_amd;
+
+namespace femto_amd {
+
+constexpr int kNfaMaxNodes = 2048;        // cost vectors of one automaton live in LDS
+constexpr int kNfaOffset = 5;             // CHARACTER_OFFSET (src/main/index_types.h): alpha codes below it are EOF/SEOF/...
+constexpr int kNfaDead = 255;             // MAX_NFA_ERRCNT (src/main/nfa.h:75)
+constexpr int kNfaStatusFull = FEMTO_AMD_ERR_FULL;
+constexpr int kNfaStatusOverworked = FEMTO_AMD_ERR_OVERWORKED;
+
+struct NfaQueryDev {
+  int64_t node_off;       // first node's flag byte (bit 0: start node, bit 1: final node)
+  int64_t ent_off;        // first transition entry (sorted by character)
+  int64_t bychar_off;     // this automaton's 262 by-character starts
+  int32_t num_nodes, num_ents;
+  int32_t cost_bound, subst, del, ins;
+};
+struct NfaResultDev {
+  int64_t first, last;
+  int32_t query, len, cost, pass;   // pass: the attempt that produced it (a search that ran out of stack is run again)
+};
+struct NfaBatchDev {
+  const NfaQueryDev* queries;
+  const int32_t* order;      // queries[order[i]] is the i-th to be taken (NULL: identity)
+  int32_t nq;
+  const uint8_t* node_flags;
+  const uint32_t* ent_sd;    // source node | destination node << 16
+  const uint16_t* ent_ch;    // the entry's character
+  const int32_t* bychar;
+  uint8_t* arena;            // per workgroup: first[cap] i64 | last[cap] i64 | len[cap] i32 | cost[cap][cost_stride] u8
+  int64_t arena_bytes;
+  int32_t cap, cost_stride;
+  int32_t* next;             // work counter
+  NfaResultDev* results;
+  int64_t result_cap;
+  unsigned long long* result_count;
+  int32_t* status;           // per query
+  int64_t max_iterations;    // MAX_REGEXP_ITERATIONS (src/main/server.c:40)
+  int32_t pass;
+};
+
+// mode 1: femto's own wavelet tree through the derived segment lines (alphabets of more than 256 characters, range-split
+// indexes); "code" is the alpha code itself
+struct WavePolicy {
+  static __device__ __forceinline__ void search_step(const DevIndex& ix, int, uint32_t ch, int64_t& f, int64_t& l) {
+    const int64_t nf = f == 0 ? ix.C[ch] : c_plus_occ_lane(ix, ch, f - 1);
+    const int64_t nl = c_plus_occ_lane(ix, ch, l) - 1;
+    f = nf;
+    l = nl;
+  }
+  static __device__ __forceinline__ uint32_t code_of(const DevIndex& ix, uint32_t ch) { return ix.C[ch + 1] > ix.C[ch] ? ch : 0xffffu; }
+};
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const int o = __shfl_xor(v, d, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+template <class P>
+__global__ __launch_bounds__(64) void nfa_search_kernel(const DevIndex ix, const NfaBatchDev B) {
+  __shared__ uint8_t s_cur[kNfaMaxNodes];       // nfa_states: the popped entry's costs, deletions merged in
+  __shared__ uint8_t s_sub[kNfaMaxNodes];       // states after one substitution error (any character)
+  __shared__ uint32_t s_tmp[kNfaMaxNodes];      // tmp_states being accumulated (atomicMin)
+  __shared__ int32_t s_bychar[264];
+  __shared__ uint32_t s_rc[9];                  // r_c: reachable characters
+  __shared__ uint16_t s_child_ch[264];
+  __shared__ int64_t s_child_f[264], s_child_l[264];
+  __shared__ int32_t s_child_found[264];
+  __shared__ int32_t s_q;
+  const int t = threadIdx.x;
+  uint8_t* const arena = B.arena + size_t(blockIdx.x) * size_t(B.arena_bytes);
+  const int cap = B.cap;
+  const size_t stride = size_t(B.cost_stride);
+  int64_t* const e_first = reinterpret_cast<int64_t*>(arena);
+  int64_t* const e_last = e_first + cap;
+  int32_t* const e_len = reinterpret_cast<int32_t*>(e_last + cap);
+  uint8_t* const e_cost = reinterpret_cast<uint8_t*>(e_len + cap);
+  for (;;) {
+    if (t == 0) s_q = atomicAdd(B.next, 1);
+    __syncthreads();
+    const int qi = s_q;
+    __syncthreads();
+    if (qi >= B.nq) break;
+    const int q = B.order ? B.order[qi] : qi;
+    const NfaQueryDev Q = B.queries[q];
+    const int N = Q.num_nodes, T = Q.num_ents, bound = Q.cost_bound;
+    const bool approx = bound > 1;
+    const uint8_t* const flags = B.node_flags + Q.node_off;
+    const uint32_t* const ent_sd = B.ent_sd + Q.ent_off;
+    const uint16_t* const ent_ch = B.ent_ch + Q.ent_off;
+    for (int i = t; i < 262; i += 64) s_bychar[i] = B.bychar[Q.bychar_off + i];
+    // the initial mapping: the whole index -> the start states (server.c:1786-1812)
+    for (int i = t; i < N; i += 64) e_cost[i] = (flags[i] & 1u) ? 0 : kNfaDead;
+    if (t == 0) {
+      e_first[0] = 0;
+      e_last[0] = ix.total_length - 1;
+      e_len[0] = 0;
+    }
+    int sp = 1, status = 0;
+    int64_t iters = 0;
+    __syncthreads();
+    for (;;) {
+      if (iters > B.max_iterations) { status = kNfaStatusOverworked; break; }   // server.c:1821
+      if (sp == 0) break;
+      sp--;
+      const int64_t first = e_first[sp], last = e_last[sp];
+      const int len = e_len[sp];
+      // ---- a final state alive: a result, not extended (approx_is_final_state: the first such node's cost)
+      int fin = INT_MAX;
+      for (int i = t; i < N; i += 64) {
+        const uint8_t c = e_cost[size_t(sp) * stride + i];
+        s_cur[i] = c;
+        if (int(c) < bound && (flags[i] & 2u) && i < fin) fin = i;
+      }
+      fin = wave_min_i32(fin);
+      __syncthreads();
+      if (fin != INT_MAX) {
+        if (t == 0) {
+          const unsigned long long slot = atomicAdd(B.result_count, 1ull);
+          if (int64_t(slot) < B.result_cap) B.results[slot] = NfaResultDev{first, last, q, len, int(s_cur[fin]), B.pass};
+        }
+        __syncthreads();
+        continue;
+      }
+      const int base5 = s_bychar[kNfaOffset];    // entries of characters >= CHARACTER_OFFSET start here
+      // ---- deletions: states after reading ANY character at delete_cost, merged in (server.c:1854-1863)
+      if (approx) {
+        for (int i = t; i < N; i += 64) s_tmp[i] = kNfaDead;
+        __syncthreads();
+        for (int e = base5 + t; e < T; e += 64) {
+          const uint32_t sd = ent_sd[e];
+          const int c = int(s_cur[sd & 0xffffu]) + Q.del;
+          if (c < bound) atomicMin(&s_tmp[sd >> 16], uint32_t(c));
+        }
+        __syncthreads();
+        for (int i = t; i < N; i += 64) {
+          const uint32_t v = s_tmp[i];
+          if (v < uint32_t(s_cur[i])) s_cur[i] = uint8_t(v);
+        }
+        __syncthreads();
+      }
+      // ---- may any character be an error from here?  (nfa_errcnt_t arithmetic: one byte, as the reference computes it)
+      int m = bound;
+      for (int i = t; i < N; i += 64) m = int(s_cur[i]) < m ? int(s_cur[i]) : m;
+      m = wave_min_i32(m);
+      const int ms = m + Q.subst, mi = m + Q.ins;
+      const int min_err = (ms < mi ? ms : mi) & 0xff;
+      const bool allchars = min_err < bound && iters > 0;
+      // ---- r_c: the characters an alive state can read
+      if (t < 9) s_rc[t] = 0;
+      __syncthreads();
+      for (int e = t; e < T; e += 64)
+        if (int(s_cur[ent_sd[e] & 0xffffu]) < bound) {
+          const uint32_t ch = ent_ch[e];
+          atomicOr(&s_rc[ch >> 5], 1u << (ch & 31u));
+        }
+      __syncthreads();
+      if (allchars && t < 9) {      // CHARACTER_OFFSET .. ALPHA_SIZE - 1
+        uint32_t mask = ~0u;
+        if (t == 0) mask = ~0u << kNfaOffset;
+        if (t == 8) mask = (1u << (kAlphaSize - 256)) - 1u;
+        s_rc[t] |= mask;
+      }
+      __syncthreads();
+      // ---- the children in push order: characters >= CHARACTER_OFFSET ascending (the substitution loop creates their
+      // entries first, server.c:2114-2120), then the characters below it (regular loop, :2123-2130)
+      int n_all = 0, n_low;
+      {
+        const uint32_t w = t < 9 ? s_rc[t] : 0u;
+        n_all = wave_sum_i32(__popc(w));
+        n_low = __popc(s_rc[0] & ((1u << kNfaOffset) - 1u));
+      }
+      const int nchild = n_all;
+      for (int c = t; c < kAlphaSize; c += 64) {
+        if (!((s_rc[c >> 5] >> (c & 31)) & 1u)) continue;
+        int rank = __popc(s_rc[c >> 5] & ((1u << (c & 31)) - 1u));
+        for (int w = 0; w < (c >> 5); w++) rank += __popc(s_rc[w]);
+        const int pos = c >= kNfaOffset ? rank - n_low : (n_all - n_low) + rank;
+        s_child_ch[pos] = uint16_t(c);
+      }
+      __syncthreads();
+      // ---- the fan-out: lane k steps the range with the k-th character (server.c:1954-2060)
+      for (int k = t; k < nchild; k += 64) {
+        const uint32_t ch = s_child_ch[k];
+        const uint32_t code = P::code_of(ix, ch);
+        int64_t f = first, l = last;
+        if (code == 0xffffu) {         // the character does not occur in the text: Occ == 0, an empty range
+          f = 1;
+          l = 0;
+        } else {
+          P::search_step(ix, 1, code, f, l);
+        }
+        s_child_f[k] = f;
+        s_child_l[k] = l;
+        s_child_found[k] = -1;
+      }
+      __syncthreads();
+      // ---- add_mapping's lookup: a pending entry with a child's range?  (children of one pop have disjoint ranges)
+      for (int s = t; s < sp; s += 64) {
+        const int64_t ef = e_first[s], el = e_last[s];
+        for (int k = 0; k < nchild; k++)
+          if (s_child_f[k] == ef && s_child_l[k] == el) s_child_found[k] = s;
+      }
+      // ---- substitutions: states after reading any character at subst_cost (server.c:2107-2110)
+      if (approx) {
+        for (int i = t; i < N; i += 64) s_tmp[i] = kNfaDead;
+        __syncthreads();
+        for (int e = base5 + t; e < T; e += 64) {
+          const uint32_t sd = ent_sd[e];
+          const int c = int(s_cur[sd & 0xffffu]) + Q.subst;
+          if (c < bound) atomicMin(&s_tmp[sd >> 16], uint32_t(c));
+        }
+        __syncthreads();
+        for (int i = t; i < N; i += 64) s_sub[i] = uint8_t(s_tmp[i]);
+      }
+      __syncthreads();
+      for (int k = 0; k < nchild; k++) {
+        const int64_t cf = s_child_f[k], cl = s_child_l[k];
+        if (cl < cf) continue;                      // add_mapping ignores empty ranges (server.c:1565)
+        const int ch = s_child_ch[k];
+        for (int i = t; i < N; i += 64) s_tmp[i] = kNfaDead;
+        __syncthreads();
+        for (int e = s_bychar[ch] + t; e < s_bychar[ch + 1]; e += 64) {    // approx_get_reachable_states(ch)
+          const uint32_t sd = ent_sd[e];
+          const uint32_t c = s_cur[sd & 0xffffu];
+          if (int(c) < bound) atomicMin(&s_tmp[sd >> 16], c);
+        }
+        __syncthreads();
+        const int found = s_child_found[k];
+        if (found < 0 && sp >= cap) { status = kNfaStatusFull; break; }
+        const int slot = found < 0 ? sp : found;
+        uint8_t* const dst = e_cost + size_t(slot) * stride;
+        for (int i = t; i < N; i += 64) {
+          uint32_t v = s_tmp[i];
+          if (approx) {
+            const uint32_t ins = uint32_t(s_cur[i]) + uint32_t(Q.ins);          // approx_add_error_allchars (nfa.c:305)
+            v = ins < v ? ins : v;
+            if (ch >= kNfaOffset && uint32_t(s_sub[i]) < v) v = s_sub[i];
+          }
+          if (int(v) >= bound) v = kNfaDead;                                    // beyond the bound is dead, whatever the number
+          if (found >= 0) {
+            const uint32_t old = dst[i];
+            v = old < v ? old : v;                                              // nfa_states_union
+          }
+          dst[i] = uint8_t(v);
+        }
+        if (t == 0) {
+          if (found < 0) {
+            e_first[slot] = cf;
+            e_last[slot] = cl;
+            e_len[slot] = len + 1;
+          } else if (len + 1 > e_len[slot]) {
+            e_len[slot] = len + 1;                                              // the longer match is kept (server.c:1611-1619)
+          }
+        }
+        if (found < 0) sp++;
+        __syncthreads();
+      }
+      if (status) break;
+      iters++;
+    }
+    if (t == 0) B.status[q] = status;
+    __syncthreads();
+  }
+}
+
+}  // namespace femto_amd
+
+namespace {
+
+struct NfaHostResult { int64_t first, last; int32_t len, cost; int64_t seq; };
+
+int validate_nfa(const femto_amd_nfa_t& a, int64_t qi) {
+  auto bad = [&](const char* what) { return set_err(FEMTO_AMD_ERR_PARAM, "automaton " + std::to_string(qi) + ": " + what); };
+  if (a.num_nodes < 1 || a.num_nodes > kNfaMaxNodes) return bad("1 <= num_nodes <= 2048");
+  if (a.num_transitions < 0 || int64_t(a.num_transitions) > kNfaMaxTransitions) return bad("too many transitions");
+  if (!a.trans_start || !a.is_start || !a.is_final || (a.num_transitions && (!a.trans_char || !a.trans_dest))) return bad("null array");
+  // regexp_settings_t as compile_regexp_from_ast accepts them (src/main/compile_regexp.c:673-685); errors are counted in one byte
+  if (a.cost_bound < 1 || a.cost_bound > kNfaDead) return bad("1 <= cost_bound <= 255");
+  if (a.subst_cost < 1 || a.subst_cost > kNfaDead || a.delete_cost < 1 || a.delete_cost > kNfaDead || a.insert_cost < 1 || a.insert_cost > kNfaDead)
+    return bad("1 <= subst_cost, delete_cost, insert_cost <= 255");
+  if (a.trans_start[0] != 0 || a.trans_start[a.num_nodes] != a.num_transitions) return bad("trans_start does not span the transitions");
+  for (int i = 0; i < a.num_nodes; i++)
+    if (a.trans_start[i + 1] < a.trans_start[i]) return bad("trans_start is not monotone");
+  for (int e = 0; e < a.num_transitions; e++) {
+    if (a.trans_char[e] < 0 || a.trans_char[e] >= kAlphaSize) return bad("transition character >= ALPHA_SIZE (261)");
+    if (a.trans_dest[e] < 0 || a.trans_dest[e] >= a.num_nodes) return bad("transition destination out of range");
+  }
+  return 0;
+}
+
+template <class P>
+void launch_nfa(const DevIndex& d, const NfaBatchDev& B, int blocks, hipStream_t st) {
+  hipLaunchKernelGGL((nfa_search_kernel<P>), dim3(uint32_t(blocks)), dim3(64), 0, st, d, B);
+}
+
+}  // namespace
+
+// regexp_result_list_sort (src/main/server.c:1528-1573): sort by first ascending, last descending; drop equal ranges (the one
+// appended first stays: glibc's qsort is a stable merge sort) and ranges inside the last kept one
+static void sort_results(std::vector<NfaHostResult>& r) {
+  std::stable_sort(r.begin(), r.end(), [](const NfaHostResult& a, const NfaHostResult& b) {
+    if (a.first != b.first) return a.first < b.first;
+    if (a.last != b.last) return a.last > b.last;
+    return a.seq < b.seq;
+  });
+  size_t n = 0;
+  for (size_t k = 0; k < r.size(); k++) {
+    if (n && r[k].first == r[n - 1].first && r[k].last == r[n - 1].last) continue;
+    r[n++] = r[k];
+  }
+  r.resize(n);
+  if (r.empty()) return;
+  int64_t first = r[0].first, last = r[0].last;
+  size_t i = 1;
+  for (size_t k = 1; k < r.size(); k++) {
+    if (r[k].first >= first && r[k].last <= last) continue;
+    first = r[k].first;
+    last = r[k].last;
+    r[i++] = r[k];
+  }
+  r.resize(i);
+}
+
+int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_amd_nfa_t* nfas, int64_t max_results,
+                               int64_t* result_start, int64_t* first_out, int64_t* last_out, int32_t* len_out, int32_t* cost_out,
+                               int32_t* status_out, int64_t* n_out) {
+  API_BEGIN
+  if (!ix || nq < 0 || nq > INT_MAX / 2 || (nq && (!nfas || !result_start)) || max_results < 0 || !n_out ||
+      (max_results && (!first_out || !last_out)))
+    return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
+  if (!ix->children.empty())
+    return femto_amd_nfa_search_batch(ix->children[0], nq, nfas, max_results, result_start, first_out, last_out, len_out, cost_out, status_out, n_out);
+  int rc = ensure_device(ix);
+  if (rc) return rc;
+  *n_out = 0;
+  if (nq == 0) return FEMTO_AMD_OK;
+  const int mode = ix->mode;
+  if (mode != 3 && mode != 4 && !ix->host.dir_regular)
+    return set_err(FEMTO_AMD_ERR_INVALID, "regular-expression search needs the derived segment lines");
+  // ---- the automata, flat: transitions sorted by character (reading ch touches only its own entries)
+  std::vector<NfaQueryDev> hq(static_cast<size_t>(nq));
+  std::vector<uint8_t> h_flags;
+  std::vector<uint32_t> h_sd;
+  std::vector<uint16_t> h_ch;
+  std::vector<int32_t> h_bychar(size_t(nq) * 262);
+  int max_nodes = 1;
+  for (int64_t qi = 0; qi < nq; qi++) {
+    const femto_amd_nfa_t& a = nfas[qi];
+    if ((rc = validate_nfa(a, qi))) return rc;
+    NfaQueryDev& Q = hq[size_t(qi)];
+    Q.node_off = int64_t(h_flags.size());
+    Q.ent_off = int64_t(h_sd.size());
+    Q.bychar_off = qi * 262;
+    Q.num_nodes = a.num_nodes;
+    Q.num_ents = a.num_transitions;
+    Q.cost_bound = a.cost_bound;
+    Q.subst = a.subst_cost;
+    Q.del = a.delete_cost;
+    Q.ins = a.insert_cost;
+    max_nodes = std::max(max_nodes, int(a.num_nodes));
+    for (int i = 0; i < a.num_nodes; i++) h_flags.push_back(uint8_t((a.is_start[i] ? 1 : 0) | (a.is_final[i] ? 2 : 0)));
+    int32_t* bc = h_bychar.data() + qi * 262;
+    std::fill(bc, bc + 262, 0);
+    for (int e = 0; e < a.num_transitions; e++) bc[a.trans_char[e] + 1]++;
+    for (int c = 0; c < 261; c++) bc[c + 1] += bc[c];
+    std::vector<int32_t> fill(bc, bc + 261);
+    const size_t base = h_sd.size();
+    h_sd.resize(base + size_t(a.num_transitions));
+    h_ch.resize(base + size_t(a.num_transitions));
+    for (int i = 0; i < a.num_nodes; i++)
+      for (int e = a.trans_start[i]; e < a.trans_start[i + 1]; e++) {
+        const int c = a.trans_char[e];
+        const size_t at = base + size_t(fill[size_t(c)]++);
+        h_sd[at] = uint32_t(i) | (uint32_t(a.trans_dest[e]) << 16);
+        h_ch[at] = uint16_t(c);
+      }
+  }
+  Lease L(ix);
+  if (!L.s) return L.rc;
+  hipStream_t st = L.s->stream;
+  DeviceBuffer d_q, d_flags, d_sd, d_ch, d_bychar, d_arena, d_results, d_misc, d_order;
+  struct Free {
+    std::vector<DeviceBuffer*> b;
+    ~Free() { for (DeviceBuffer* x : b) x->release(); }
+  } guard{{&d_q, &d_flags, &d_sd, &d_ch, &d_bychar, &d_arena, &d_results, &d_misc, &d_order}};
+  const int64_t result_cap = std::max<int64_t>(max_results, 1);
+  if ((rc = d_q.reserve(hq.size() * sizeof(NfaQueryDev))) || (rc = d_flags.reserve(h_flags.size() + 16)) ||
+      (rc = d_sd.reserve(h_sd.size() * 4 + 16)) || (rc = d_ch.reserve(h_ch.size() * 2 + 16)) || (rc = d_bychar.reserve(h_bychar.size() * 4)) ||
+      (rc = d_results.reserve(size_t(result_cap) * sizeof(NfaResultDev))) || (rc = d_misc.reserve(64 + size_t(nq) * 4)) ||
+      (rc = d_order.reserve(size_t(nq) * 4)))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(d_q.p, hq.data(), hq.size() * sizeof(NfaQueryDev), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_flags.p, h_flags.data(), h_flags.size(), hipMemcpyHostToDevice, st));
+  if (!h_sd.empty()) {
+    HIP_TRY(hipMemcpyAsync(d_sd.p, h_sd.data(), h_sd.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_ch.p, h_ch.data(), h_ch.size() * 2, hipMemcpyHostToDevice, st));
+  }
+  HIP_TRY(hipMemcpyAsync(d_bychar.p, h_bychar.data(), h_bychar.size() * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(d_misc.p, 0, 64 + size_t(nq) * 4, st));
+  // d_misc: [0] work counter (i32), [8] result count (u64), [64...] status per query
+  int32_t* d_next = d_misc.as<int32_t>();
+  unsigned long long* d_count = reinterpret_cast<unsigned long long*>(static_cast<char*>(d_misc.p) + 8);
+  int32_t* d_status = reinterpret_cast<int32_t*>(static_cast<char*>(d_misc.p) + 64);
+  NfaBatchDev B{};
+  B.queries = d_q.as<NfaQueryDev>();
+  B.node_flags = d_flags.as<uint8_t>();
+  B.ent_sd = d_sd.as<uint32_t>();
+  B.ent_ch = d_ch.as<uint16_t>();
+  B.bychar = d_bychar.as<int32_t>();
+  B.next = d_next;
+  B.results = d_results.as<NfaResultDev>();
+  B.result_cap = result_cap;
+  B.result_count = d_count;
+  B.status = d_status;
+  B.max_iterations = ix->regexp_max_iterations;
+  B.cost_stride = (max_nodes + 3) & ~3;
+  // Stack capacity: most searches keep a few dozen pending entries; the ones that run out (status FULL) are run again
+  // with a larger arena and fewer workgroups, up to regexp_stack_cap entries.
+  const size_t entry_bytes = 20 + size_t(B.cost_stride);
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  const size_t budget = std::min<size_t>(free_b / 2, size_t(16) << 30);
+  std::vector<int32_t> todo(static_cast<size_t>(nq)), status(static_cast<size_t>(nq), 0), last_pass(static_cast<size_t>(nq), 0);
+  for (int64_t i = 0; i < nq; i++) todo[size_t(i)] = int32_t(i);
+  int64_t cap = std::min<int64_t>(1024, ix->regexp_stack_cap);
+  for (int pass = 0;; pass++) {
+    int blocks = int(std::min<int64_t>(int64_t(todo.size()), int64_t(ix->num_cus) * 8));
+    const size_t per_block = (size_t(cap) * entry_bytes + 255) & ~size_t(255);
+    if (size_t(blocks) * per_block > budget) blocks = int(std::max<size_t>(1, budget / per_block));
+    if ((rc = d_arena.reserve(size_t(blocks) * per_block))) return rc;
+    B.arena = d_arena.as<uint8_t>();
+    B.arena_bytes = int64_t(per_block);
+    B.cap = int32_t(cap);
+    B.nq = int32_t(todo.size());
+    B.order = d_order.as<int32_t>();
+    B.pass = pass;
+    for (int32_t q : todo) last_pass[size_t(q)] = pass;
+    HIP_TRY(hipMemcpyAsync(d_order.p, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d_next, 0, 4, st));
+    if (mode == 3) launch_nfa<PackPolicy>(ix->dev, B, blocks, st);
+    else if (mode == 4 && ix->dev.ind) launch_nfa<IndPolicy>(ix->dev, B, blocks, st);
+    else if (mode == 4) launch_nfa<Pack2Policy>(ix->dev, B, blocks, st);
+    else launch_nfa<WavePolicy>(ix->dev, B, blocks, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(status.data(), d_status, size_t(nq) * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<int32_t> again;
+    for (int32_t q : todo)
+      if (status[size_t(q)] == kNfaStatusFull) again.push_back(q);
+    if (again.empty() || cap >= ix->regexp_stack_cap) break;
+    cap = std::min<int64_t>(cap * 64, ix->regexp_stack_cap);
+    todo.swap(again);
+  }
+  unsigned long long count = 0;
+  HIP_TRY(hipMemcpy(&count, d_count, 8, hipMemcpyDeviceToHost));
+  if (int64_t(count) > result_cap) {
+    *n_out = int64_t(count);
+    return set_err(FEMTO_AMD_ERR_FULL, "more results than max_results (before sorting: " + std::to_string(count) + ")");
+  }
+  std::vector<NfaResultDev> raw(static_cast<size_t>(count));
+  if (count) HIP_TRY(hipMemcpy(raw.data(), d_results.p, size_t(count) * sizeof(NfaResultDev), hipMemcpyDeviceToHost));
+  // a search that was run again appended its earlier attempts' results too: only the last attempt's count
+  std::vector<std::vector<NfaHostResult>> per(static_cast<size_t>(nq));
+  for (size_t k = 0; k < raw.size(); k++)
+    if (raw[k].pass == last_pass[size_t(raw[k].query)])
+      per[size_t(raw[k].query)].push_back({raw[k].first, raw[k].last, raw[k].len, raw[k].cost, int64_t(k)});
+  int64_t n = 0;
+  for (int64_t qi = 0; qi < nq; qi++) {
+    std::vector<NfaHostResult>& r = per[size_t(qi)];
+    if (status[size_t(qi)] != 0) r.clear();        // the reference returns an error and no results (RETURN_ERROR)
+    sort_results(r);
+    result_start[qi] = n;
+    n += int64_t(r.size());
+  }
+  result_start[nq] = n;
+  *n_out = n;
+  if (status_out) std::memcpy(status_out, status.data(), size_t(nq) * 4);
+  if (max_results == 0) return FEMTO_AMD_OK;        // count only
+  if (n > max_results) return set_err(FEMTO_AMD_ERR_FULL, "more results than max_results");
+  for (int64_t qi = 0; qi < nq; qi++) {
+    const std::vector<NfaHostResult>& r = per[size_t(qi)];
+    int64_t at = result_start[qi];
+    for (const NfaHostResult& x : r) {
+      first_out[at] = x.first;
+      last_out[at] = x.last;
+      if (len_out) len_out[at] = x.len;
+      if (cost_out) cost_out[at] = x.cost;
+      at++;
+    }
+  }
+  return FEMTO_AMD_OK;
+  API_END
+}
+
+// ---- regular expressions: pattern text -> automaton (regexp_nfa.hpp) --------------------------------------------------------
+struct femto_amd_regexp {
+  NfaDesc desc;
+  femto_amd_nfa_t view;
+};
+
+static int settings_check(int max_cost, int subst_cost, int delete_cost, int insert_cost) {
+  // compile_regexp_from_ast (src/main/compile_regexp.c:673-685): cost_bound = max_cost + 1 (approx_node_new, ast.c:168-191)
+  const int bound = max_cost + 1;
+  if (max_cost < 0 || bound > kNfaDead || subst_cost < 1 || delete_cost < 1 || insert_cost < 1)
+    return set_err(FEMTO_AMD_ERR_PARAM, "approximate search: 0 <= max_cost <= 254, costs >= 1");
+  if (3 * std::min(subst_cost, kNfaDead) < bound || 3 * std::min(insert_cost, kNfaDead) < bound)
+    return set_err(FEMTO_AMD_ERR_PARAM, "approximate search: three substitutions or insertions are not allowed (3 * cost >= max_cost + 1)");
+  return 0;
+}
+
+int femto_amd_regexp_compile(const uint8_t* regex, int64_t regex_len, int max_cost, int subst_cost, int delete_cost, int insert_cost,
+                             femto_amd_regexp_t** out) {
+  API_BEGIN
+  if (!out || (regex_len && !regex) || regex_len < 0) return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
+  *out = nullptr;
+  int rc = settings_check(max_cost, subst_cost, delete_cost, insert_cost);
+  if (rc) return rc;
+  RegexNfa nfa;
+  std::string perr;
+  RegexParser parser(regex, regex_len, &nfa);
+  if (!parser.parse(&perr)) return set_err(FEMTO_AMD_ERR_PARAM, "regular expression: " + perr);
+  std::unique_ptr<femto_amd_regexp> r(new femto_amd_regexp());
+  if (!build_reversed_nfa(nfa, &r->desc)) return set_err(FEMTO_AMD_ERR_PARAM, "regular expression: too many transitions");
+  if (r->desc.num_nodes > kNfaMaxNodes) return set_err(FEMTO_AMD_ERR_PARAM, "regular expression too large");
+  r->desc.cost_bound = max_cost + 1;
+  r->desc.subst_cost = std::min(subst_cost, kNfaDead);
+  r->desc.delete_cost = std::min(delete_cost, kNfaDead);
+  r->desc.insert_cost = std::min(insert_cost, kNfaDead);
+  femto_amd_nfa_t& v = r->view;
+  v.num_nodes = r->desc.num_nodes;
+  v.num_transitions = int32_t(r->desc.trans_char.size());
+  v.trans_start = r->desc.trans_start.data();
+  v.trans_char = r->desc.trans_char.data();
+  v.trans_dest = r->desc.trans_dest.data();
+  v.is_start = r->desc.is_start.data();
+  v.is_final = r->desc.is_final.data();
+  v.cost_bound = r->desc.cost_bound;
+  v.subst_cost = r->desc.subst_cost;
+  v.delete_cost = r->desc.delete_cost;
+  v.insert_cost = r->desc.insert_cost;
+  *out = r.release();
+  return FEMTO_AMD_OK;
+  API_END
+}
+
+const femto_amd_nfa_t* femto_amd_regexp_nfa(const femto_amd_regexp_t* r) { return r ? &r->view : nullptr; }
+
+void femto_amd_regexp_free(femto_amd_regexp_t* r) { delete r; }
+
+int femto_amd_regexp_search_batch(femto_amd_index_t* ix, int64_t nq, const uint8_t* const* regex, const int64_t* regex_len, int max_cost,
+                                  int subst_cost, int delete_cost, int insert_cost, int64_t max_results, int64_t* result_start,
+                                  int64_t* first_out, int64_t* last_out, int32_t* len_out, int32_t* cost_out, int32_t* status_out,
+                                  int64_t* n_out) {
+  API_BEGIN
+  if (nq < 0 || (nq && (!regex || !regex_len))) return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
+  struct Owner {
+    std::vector<femto_amd_regexp_t*> v;
+    ~Owner() { for (auto* r : v) femto_amd_regexp_free(r); }
+  } own;
+  std::vector<femto_amd_nfa_t> views;
+  for (int64_t qi = 0; qi < nq; qi++) {
+    femto_amd_regexp_t* r = nullptr;
+    int rc = femto_amd_regexp_compile(regex[qi], regex_len[qi], max_cost, subst_cost, delete_cost, insert_cost, &r);
+    if (rc) return rc;
+    own.v.push_back(r);
+    views.push_back(r->view);
+  }
+  return femto_amd_nfa_search_batch(ix, nq, views.data(), max_results, result_start, first_out, last_out, len_out, cost_out, status_out, n_out);
+  API_END
+}
+
+int femto_amd_regexp_search_approx(femto_amd_index_t* ix, const uint8_t* regex, int64_t regex_len, int max_cost, int subst_cost,
+                                   int delete_cost, int insert_cost, int64_t max_results, int64_t* first_out, int64_t* last_out,
+                                   int32_t* len_out, int32_t* cost_out, int64_t* n_out) {
+  int64_t start[2] = {0, 0};
+  int32_t status = 0;
+  const int rc = femto_amd_regexp_search_batch(ix, 1, &regex, &regex_len, max_cost, subst_cost, delete_cost, insert_cost, max_results, start,
+                                               first_out, last_out, len_out, cost_out, &status, n_out);
+  if (rc) return rc;
+  if (status == kNfaStatusOverworked) return set_err(FEMTO_AMD_ERR_OVERWORKED, "regular expression: too much work (more than MAX_REGEXP_ITERATIONS steps)");
+  if (status == kNfaStatusFull) return set_err(FEMTO_AMD_ERR_FULL, "regular expression: more pending ranges than the search stack holds");
+  return FEMTO_AMD_OK;
+}
+
+int femto_amd_regexp_search(femto_amd_index_t* ix, const uint8_t* regex, int64_t regex_len, int64_t max_results, int64_t* first_out,
+                            int64_t* last_out, int32_t* len_out, int64_t* n_out) {
+  return femto_amd_regexp_search_approx(ix, regex, regex_len, 0, 1, 1, 1, max_results, first_out, last_out, len_out, nullptr, n_out);
+}
+
+/* test hook: does the automaton built from `regex` accept exactly the byte string s?  1 yes, 0 no, -1 syntax error */
+int femto_amd_regexp_match(const uint8_t* regex, int64_t regex_len, const uint8_t* s, int64_t len) {
+  try {
+    if ((regex_len && !regex) || (len && !s) || regex_len < 0 || len < 0) return -1;
+    RegexNfa nfa;
+    std::string perr;
+    RegexParser parser(regex, regex_len, &nfa);
+    if (!parser.parse(&perr)) { set_err(FEMTO_AMD_ERR_PARAM, "regular expression: " + perr); return -1; }
+    return nfa_full_match(nfa, s, len) ? 1 : 0;
+  } catch (...) {
+    return -1;
+  }
+}

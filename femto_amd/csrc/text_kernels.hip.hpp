@@ -109,7 +109,7 @@ __device__ __forceinline__ bool tail_locate(const DevIndex& ix, int64_t row, int
 // build: txt[SA[row] - 1] = L[row] (position -1 wraps to the last one), isa[SA[row] >> shift] = row for the sampled
 // positions (shift 0: all of them) and, kSa, sa_full[row] = SA[row]
 template <class P, bool kSa>
-__global__ __launch_bounds__(256) void text_isa_build_kernel(const DevIndex ix, const int64_t row0, const int64_t n, uint8_t* __restrict__ txt,
+inline __global__ __launch_bounds__(256) void text_isa_build_kernel(const DevIndex ix, const int64_t row0, const int64_t n, uint8_t* __restrict__ txt,
                                                              int64_t* __restrict__ isa, const int isa_shift, int64_t* __restrict__ sa_full) {
   const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (row >= row0 + n) return;
@@ -195,7 +195,7 @@ struct TailOut {
 };
 
 template <class P, bool kSaFull>
-__global__ __launch_bounds__(256) void count_tail_kernel(const DevIndex ix, const TailItem* __restrict__ items, const int* __restrict__ n_items,
+inline __global__ __launch_bounds__(256) void count_tail_kernel(const DevIndex ix, const TailItem* __restrict__ items, const int* __restrict__ n_items,
                                                          const int32_t* __restrict__ plen, const uint16_t* __restrict__ pats,
                                                          const int64_t* __restrict__ starts, const uint32_t* __restrict__ perm,
                                                          const uint64_t* __restrict__ keys, const int bits, const int nsym,

@@ -37,6 +37,8 @@ enum {
   FEMTO_AMD_ERR_BZ_DATA = 5,
   FEMTO_AMD_ERR_INVALID = 6,
   FEMTO_AMD_ERR_MISSING = 8,
+  FEMTO_AMD_ERR_FULL = 10,
+  FEMTO_AMD_ERR_OVERWORKED = 11,
   FEMTO_AMD_ERR_UNKNOWN = 12
 };
 
@@ -190,23 +192,61 @@ int femto_amd_split_commit(femto_amd_index_t* ix);
 /* bytes of this part's own slices (segment lines, block images) */
 int femto_amd_split_info(const femto_amd_index_t* ix, int* part, int* nparts, int64_t* seg_bytes, int64_t* image_bytes);
 
-/* ---- regular expressions (do_regexp_query src/main/server.c:1656, nfa.c, compile_regexp.c) -------------
- * Every string of the index that matches `regex` IN FULL, as row ranges: result i is one matched string of len_out[i]
- * symbols and the rows [first_out[i], last_out[i]] of the suffixes that start with it (locate them with
- * femto_amd_parallel_locate_range); sorted by first ascending, last descending (regexp_result_list_sort, server.c:1528).
- * Pattern language: the byte-regular-expression part of src/main/QUERY_FORMAT.txt -- literal bytes, `.`, `[a-z]` /
- * `[^...]`, `( )`, `|`, `*`, `+`, `?`, backslash escapes (\n \t \xNN ...), "double" and 'single' quotes; unescaped
- * whitespace separates terms and is ignored; no boolean / APPROX keywords.  Call with max_results == 0 to count the
- * results (*n_out) only; more than max_results results, or a pattern that matches too many different strings (`.*`),
- * is FEMTO_AMD_ERR_PARAM.  The reference's regular-expression front end needs flex/bison and cannot be built in this
- * image, so this entry point is checked against brute force over the texts, not against reference vectors. */
+/* ---- regular expressions and automata (do_regexp_query src/main/server.c:1656, nfa.c, compile_regexp.c) ----
+ * The reference searches a regular expression by simulating an EPSILON-FREE automaton of the REVERSED pattern backwards over
+ * the index (do_regexp_query): femto_amd_nfa_t is that automaton, field for field the reference's nfa_description_t
+ * (src/main/nfa.h:62-88) with the arrays flattened -- node i's transitions are entries trans_start[i] .. trans_start[i+1]-1 of
+ * trans_char[] (alpha codes, byte + 5) / trans_dest[]; is_start / is_final are the two bit sets; the four costs are
+ * regexp_settings_t (src/main/index_types.h:147-162: cost_bound = largest allowed total cost + 1, 1 = exact matching).
+ *
+ * femto_amd_nfa_search_batch replaces setup_regexp_query_take_nfa (src/main/server.h:838) + do_regexp_query for nq automata at
+ * once, each searched by one GPU workgroup (regexp_search.hip): for automaton q the results are entries
+ * result_start[q] .. result_start[q+1]-1 of first_out / last_out (row range of a matched string: locate its rows with
+ * femto_amd_parallel_locate_range), len_out (match_len: symbols of the matched string) and cost_out (errors), in the order
+ * of the reference's sorted result list (regexp_result_list_sort, server.c:1528: first ascending, last descending, equal
+ * ranges and ranges inside another result dropped) -- IDENTICAL to the reference's list for the same automaton, quirks
+ * included (a range with a final state alive is a result and is NOT extended; a pending range reached again is merged).
+ * status_out[q] (may be NULL): 0, FEMTO_AMD_ERR_OVERWORKED (more than MAX_REGEXP_ITERATIONS = 10^6 steps, server.c:40,1821:
+ * the reference returns ERR_OVERWORKED and no results) or FEMTO_AMD_ERR_FULL (more pending ranges than option
+ * "regexp_stack_cap", default 2^22; the reference has no such bound).  The out arrays hold max_results entries for ALL
+ * automata together; *n_out = results in total; max_results == 0 only counts; more results than max_results is
+ * FEMTO_AMD_ERR_FULL with *n_out = the number needed (before de-duplication).  Limits: 2048 nodes, 2^22 transitions per
+ * automaton, costs and cost_bound 1..255 (errors are counted in one byte, nfa.h:74-76). */
+typedef struct femto_amd_nfa {
+  int32_t num_nodes;
+  int32_t num_transitions;
+  const int32_t* trans_start;   /* [num_nodes + 1] */
+  const int32_t* trans_char;    /* [num_transitions] alpha codes */
+  const int32_t* trans_dest;    /* [num_transitions] */
+  const uint8_t* is_start;      /* [num_nodes] */
+  const uint8_t* is_final;      /* [num_nodes] */
+  int32_t cost_bound, subst_cost, delete_cost, insert_cost;
+} femto_amd_nfa_t;
+int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_amd_nfa_t* nfas, int64_t max_results,
+                               int64_t* result_start /* nq + 1 */, int64_t* first_out, int64_t* last_out, int32_t* len_out,
+                               int32_t* cost_out, int32_t* status_out, int64_t* n_out);
+/* Pattern text -> automaton.  Pattern language: the byte-regular-expression part of src/main/QUERY_FORMAT.txt -- literal
+ * bytes, `.`, `[a-z]` / `[^...]`, `( )`, `|`, `*`, `+`, `?`, backslash escapes (\n \t \xNN ...), "double" and 'single'
+ * quotes; unescaped whitespace separates terms and is ignored; no boolean keywords.  The automaton is the position
+ * (Glushkov) automaton of the reversed pattern.  (The reference's own front end -- flex/bison grammar, compile_regexp.c --
+ * cannot be generated in this image; parity is pinned at the automaton: the same femto_amd_nfa_t goes to the genuine
+ * do_regexp_query and to femto_amd_nfa_search_batch.)  APPROX (QUERY_FORMAT.txt "APPROXIMATE SEARCH",
+ * max_cost:subst_cost:delete_cost:insert_cost): cost_bound = max_cost + 1, validated as compile_regexp_from_ast does
+ * (compile_regexp.c:673-685: three substitutions or insertions are refused).  Limits: 2^20 bytes of pattern text,
+ * parentheses nested 256 deep, 4096 Thompson states: beyond them FEMTO_AMD_ERR_PARAM, never a crash. */
+typedef struct femto_amd_regexp femto_amd_regexp_t;
+int femto_amd_regexp_compile(const uint8_t* regex, int64_t regex_len, int max_cost, int subst_cost, int delete_cost,
+                             int insert_cost, femto_amd_regexp_t** out);
+const femto_amd_nfa_t* femto_amd_regexp_nfa(const femto_amd_regexp_t* r);   /* valid until femto_amd_regexp_free */
+void femto_amd_regexp_free(femto_amd_regexp_t* r);
+/* compile + search, a batch of patterns with the same costs (max_cost = 0, costs 1: exact) */
+int femto_amd_regexp_search_batch(femto_amd_index_t* ix, int64_t nq, const uint8_t* const* regex, const int64_t* regex_len,
+                                  int max_cost, int subst_cost, int delete_cost, int insert_cost, int64_t max_results,
+                                  int64_t* result_start, int64_t* first_out, int64_t* last_out, int32_t* len_out,
+                                  int32_t* cost_out, int32_t* status_out, int64_t* n_out);
+/* one pattern; a search that ends OVERWORKED / FULL returns that code */
 int femto_amd_regexp_search(femto_amd_index_t* ix, const uint8_t* regex, int64_t regex_len, int64_t max_results,
                             int64_t* first_out, int64_t* last_out, int32_t* len_out, int64_t* n_out);
-/* Approximate form (QUERY_FORMAT.txt "APPROXIMATE SEARCH": APPROX <max_cost>:<subst_cost>:<delete_cost>:<insert_cost>; the
- * error-counting states of src/main/nfa.c): every string of the index within weighted edit distance max_cost of a string
- * the pattern matches -- a substitution costs subst_cost, a character of the pattern missing from the data delete_cost,
- * an extra character in the data insert_cost; as in the reference, no substitution (and no extra character) at the
- * pattern's LAST character.  cost_out[i] (may be NULL) = the least cost of result i.  max_cost = 0 is the exact search. */
 int femto_amd_regexp_search_approx(femto_amd_index_t* ix, const uint8_t* regex, int64_t regex_len, int max_cost,
                                    int subst_cost, int delete_cost, int insert_cost, int64_t max_results,
                                    int64_t* first_out, int64_t* last_out, int32_t* len_out, int32_t* cost_out,

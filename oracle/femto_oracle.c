@@ -816,3 +816,141 @@ done:
   free(first); free(last); free(out_starts);
   return rc;
 }
+
+/* ---- do_regexp_query (src/main/server.c:1656-2163) ---------------------------------------------------------------------- */
+typedef struct {
+  int64_t first, last;
+  int32_t len, cost;
+  uint8_t* states;          /* one error count per node (nfa_errcnt_t) */
+  int64_t seq;
+} rx_entry_t;
+
+static int rx_result_cmp(const void* ap, const void* bp)   /* regexp_result_cmp, server.c:1485; ties: append order (stable qsort) */
+{
+  const rx_entry_t* a = ap; const rx_entry_t* b = bp;
+  if (a->first < b->first) return -1;
+  if (a->first > b->first) return 1;
+  if (a->last < b->last) return 1;
+  if (a->last > b->last) return -1;
+  return a->seq < b->seq ? -1 : (a->seq > b->seq ? 1 : 0);
+}
+
+int64_t fo_nfa_search(fo_index_t* ix, int nn, const int32_t* tstart, const int32_t* tchar, const int32_t* tdest,
+                      const uint8_t* is_start, const uint8_t* is_final, const int32_t* settings, int64_t max_iterations,
+                      int64_t cap, int64_t* first_out, int64_t* last_out, int32_t* len_out, int32_t* cost_out)
+{
+  const int bound = settings[0], subst = settings[1], del = settings[2], ins = settings[3];
+  rx_entry_t* stack = NULL; int64_t sp = 0, scap = 0;      /* queue_map: a stack ... */
+  rx_entry_t* res = NULL; int64_t nres = 0, rcap = 0;
+  uint8_t* cur = malloc(nn), *tmp = malloc(nn), *sub = malloc(nn), *child = malloc(nn);
+  int64_t iters = 0, rc = 0, seq = 0;
+#define RX_PUSH(arr, n, c, e) do { if (n == c) { c = c ? 2 * c : 64; arr = realloc(arr, c * sizeof(rx_entry_t)); } arr[n++] = (e); } while (0)
+  {
+    rx_entry_t e = { 0, ix->total_length - 1, 0, 0, malloc(nn), 0 };
+    for (int i = 0; i < nn; i++) e.states[i] = is_start[i] ? 0 : 255;          /* approx_get_start_states, nfa.c:220 */
+    RX_PUSH(stack, sp, scap, e);
+  }
+  for (;;) {
+    if (iters > max_iterations) { rc = -FO_ERR_OVERWORKED; break; }            /* server.c:1821 */
+    if (sp == 0) break;
+    rx_entry_t var = stack[--sp];
+    int fin = -1;
+    for (int i = 0; i < nn; i++)                                               /* approx_is_final_state, nfa.c:205 */
+      if (var.states[i] < bound && is_final[i]) { fin = i; break; }
+    if (fin >= 0) {
+      var.cost = var.states[fin];
+      var.seq = seq++;
+      free(var.states); var.states = NULL;
+      RX_PUSH(res, nres, rcap, var);
+      continue;
+    }
+    /* deletions (approx_get_reachable_states_allchars, nfa.c:234, with delete_cost), merged in */
+    memset(tmp, 255, nn);
+    if (bound > 1)
+      for (int i = 0; i < nn; i++)
+        if (var.states[i] + del < bound)
+          for (int j = tstart[i]; j < tstart[i + 1]; j++)
+            if (tchar[j] >= FO_CHARACTER_OFFSET && tchar[j] < FO_ALPHA_SIZE && var.states[i] + del < tmp[tdest[j]]) tmp[tdest[j]] = var.states[i] + del;
+    for (int i = 0; i < nn; i++) cur[i] = var.states[i] < tmp[i] ? var.states[i] : tmp[i];
+    free(var.states);
+    uint8_t min_err = (uint8_t) bound;                                         /* nfa_errcnt_t arithmetic, server.c:1868-1873 */
+    for (int i = 0; i < nn; i++) if (cur[i] < min_err) min_err = cur[i];
+    min_err = (uint8_t) ((min_err + subst) < (min_err + ins) ? (min_err + subst) : (min_err + ins));
+    uint8_t rc_set[FO_ALPHA_SIZE];                                             /* approx_get_reachable_characters, nfa.c:165 */
+    memset(rc_set, 0, sizeof rc_set);
+    for (int i = 0; i < nn; i++)
+      if (cur[i] < bound)
+        for (int j = tstart[i]; j < tstart[i + 1]; j++) rc_set[tchar[j]] = 1;
+    if (min_err < bound && iters > 0)
+      for (int c = FO_CHARACTER_OFFSET; c < FO_ALPHA_SIZE; c++) rc_set[c] = 1;
+    int64_t nf[FO_ALPHA_SIZE], nl[FO_ALPHA_SIZE];
+    for (int c = 0; c < FO_ALPHA_SIZE; c++) {
+      if (!rc_set[c]) continue;
+      int64_t a, b;                                                            /* server.c:2050-2056 */
+      if (var.first == 0) a = fo_get_C(ix, c);
+      else if (c_plus_occ(ix, c, var.first - 1, &a, NULL)) { rc = -FO_ERR_FORMAT; goto done; }
+      if (c_plus_occ(ix, c, var.last, &b, NULL)) { rc = -FO_ERR_FORMAT; goto done; }
+      nf[c] = a; nl[c] = b - 1;
+    }
+    memset(sub, 255, nn);                                                      /* substitutions, server.c:2107-2110 */
+    if (bound > 1)
+      for (int i = 0; i < nn; i++)
+        if (cur[i] + subst < bound)
+          for (int j = tstart[i]; j < tstart[i + 1]; j++)
+            if (tchar[j] >= FO_CHARACTER_OFFSET && tchar[j] < FO_ALPHA_SIZE && cur[i] + subst < sub[tdest[j]]) sub[tdest[j]] = cur[i] + subst;
+    /* the three add_mapping loops (server.c:2114-2141): pass 0 substitution states for characters >= CHARACTER_OFFSET,
+       pass 1 the states after reading ch, pass 2 the insertion states */
+    for (int pass = 0; pass < 3; pass++)
+      for (int c = pass == 0 ? FO_CHARACTER_OFFSET : 0; c < FO_ALPHA_SIZE; c++) {
+        if (!rc_set[c] || nl[c] < nf[c]) continue;                             /* add_mapping ignores empty ranges */
+        if (pass == 0) memcpy(child, sub, nn);
+        else if (pass == 1) {                                                  /* approx_get_reachable_states, nfa.c:273 */
+          memset(child, 255, nn);
+          for (int i = 0; i < nn; i++)
+            if (cur[i] < bound)
+              for (int j = tstart[i]; j < tstart[i + 1]; j++)
+                if (tchar[j] == c && cur[i] < child[tdest[j]]) child[tdest[j]] = cur[i];
+        } else {                                                               /* approx_add_error_allchars, nfa.c:305 */
+          for (int i = 0; i < nn; i++) child[i] = (uint8_t) (cur[i] + ins < 255 ? cur[i] + ins : 255);
+        }
+        int64_t k;
+        for (k = 0; k < sp; k++) if (stack[k].first == nf[c] && stack[k].last == nl[c]) break;
+        if (k < sp) {                                                          /* found: union the states, keep the longer match */
+          for (int i = 0; i < nn; i++) if (child[i] < stack[k].states[i]) stack[k].states[i] = child[i];
+          if (var.len + 1 > stack[k].len) stack[k].len = var.len + 1;
+        } else {
+          rx_entry_t e = { nf[c], nl[c], var.len + 1, 0, malloc(nn), 0 };
+          memcpy(e.states, child, nn);
+          RX_PUSH(stack, sp, scap, e);
+        }
+      }
+    iters++;
+  }
+done:
+  for (int64_t k = 0; k < sp; k++) free(stack[k].states);
+  if (rc == 0) {                                                               /* regexp_result_list_sort, server.c:1528-1573 */
+    qsort(res, nres, sizeof(rx_entry_t), rx_result_cmp);
+    int64_t n = 0;
+    for (int64_t k = 0; k < nres; k++) {
+      if (n && res[k].first == res[n - 1].first && res[k].last == res[n - 1].last) continue;
+      res[n++] = res[k];
+    }
+    nres = n;
+    if (nres > 0) {
+      int64_t f = res[0].first, l = res[0].last, i = 1;
+      for (int64_t k = 1; k < nres; k++) {
+        if (res[k].first >= f && res[k].last <= l) continue;
+        f = res[k].first; l = res[k].last;
+        res[i++] = res[k];
+      }
+      nres = i;
+    }
+    for (int64_t k = 0; k < nres && k < cap; k++) {
+      first_out[k] = res[k].first; last_out[k] = res[k].last; len_out[k] = res[k].len; cost_out[k] = res[k].cost;
+    }
+    rc = nres;
+  }
+  free(stack); free(res); free(cur); free(tmp); free(sub); free(child);
+  return rc;
+#undef RX_PUSH
+}

@@ -29,7 +29,7 @@ extern "C" {
 
 /* err_code_t values of src/utils/error.h:25-39 */
 enum { FO_OK = 0, FO_ERR_MEM = 1, FO_ERR_IO = 2, FO_ERR_PARAM = 3, FO_ERR_FORMAT = 4,
-       FO_ERR_BZ_DATA = 5, FO_ERR_INVALID = 6 };
+       FO_ERR_BZ_DATA = 5, FO_ERR_INVALID = 6, FO_ERR_OVERWORKED = 11 };
 
 typedef struct fo_index fo_index_t;
 
@@ -83,6 +83,16 @@ int  fo_wtree_select(const unsigned char* wt, int leaf, int count);
 /* single LF^-1 step with mark lookup: do_forward_query, src/main/server.c:2424 */
 int  fo_forward_step(fo_index_t* ix, int64_t row, int64_t* new_row, int* ch, int64_t* offset, fo_counters_t* c);
 int  fo_back_step(fo_index_t* ix, int64_t row, int64_t* new_row, int* ch, int64_t* offset, fo_counters_t* c);
+
+/* do_regexp_query (src/main/server.c:1656-2163): backward simulation of one nfa_description_t (src/main/nfa.h:62-88, given
+   flat: node i's transitions are entries trans_start[i] .. trans_start[i+1]-1; settings[4] = cost_bound, subst_cost,
+   delete_cost, insert_cost) with the reference's stack-with-a-hash discipline (src/utils/queue_map.c), add_mapping
+   (server.c:1558), the approx_* state functions (src/main/nfa.c:165-322) and regexp_result_list_sort (server.c:1528).
+   out: up to cap results {first, last, match_len, cost}; returns the number of results, or -FO_ERR_* (OVERWORKED after
+   max_iterations pops, server.c:40,1821).  Pinned against the genuine do_regexp_query: tests/golden/NAME_regexp.npz. */
+int64_t fo_nfa_search(fo_index_t* ix, int num_nodes, const int32_t* trans_start, const int32_t* trans_char,
+                      const int32_t* trans_dest, const uint8_t* is_start, const uint8_t* is_final, const int32_t* settings,
+                      int64_t max_iterations, int64_t cap, int64_t* first, int64_t* last, int32_t* match_len, int32_t* cost);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,8 @@ def lib():
         L.fo_resolve_location.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.fo_wtree_occs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.fo_wtree_rank.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]
+        L.fo_nfa_search.restype = C.c_int64
+        L.fo_nfa_search.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int64, C.c_int64] + [C.c_void_p] * 4
         _lib = L
     return _lib
 
@@ -180,6 +182,20 @@ class Oracle:
     def locate(self, patterns, max_occs, threads=1, counters=None):
         return self.locate_flat(*_flat(patterns), max_occs, threads=threads, counters=counters)
 
+    def nfa_search(self, nfa, max_iterations=1000000, cap=1 << 20):
+        """do_regexp_query restated (fo_nfa_search): (err_code, first, last, match_len, cost) for one automaton (an object
+        with trans_start / trans_char / trans_dest int32, is_start / is_final uint8 and settings, e.g. femto_amd.Nfa)"""
+        first, last = np.zeros(cap, dtype=np.int64), np.zeros(cap, dtype=np.int64)
+        mlen, cost = np.zeros(cap, dtype=np.int32), np.zeros(cap, dtype=np.int32)
+        st = np.array(nfa.settings, dtype=np.int32)
+        n = lib().fo_nfa_search(self.h, nfa.num_nodes, nfa.trans_start.ctypes.data, nfa.trans_char.ctypes.data, nfa.trans_dest.ctypes.data,
+                                nfa.is_start.ctypes.data, nfa.is_final.ctypes.data, st.ctypes.data, max_iterations, cap,
+                                first.ctypes.data, last.ctypes.data, mlen.ctypes.data, cost.ctypes.data)
+        if n < 0:
+            return -n, first[:0], last[:0], mlen[:0], cost[:0]
+        assert n <= cap
+        return 0, first[:n], last[:n], mlen[:n], cost[:n]
+
 
 def bseq_rank(image, index):
     """(occs0, occs1, bit) of one encoded binary sequence at 1-based index"""
@@ -218,9 +234,9 @@ def write_fpat_flat(path, plen, flat):
         f.write(np.ascontiguousarray(flat, dtype=np.uint16).tobytes())
 
 
-def ref_tool(*args, capture=True):
+def ref_tool(*args, capture=True, timeout=None):
     r = subprocess.run([REF_TOOL] + [str(a) for a in args], check=True,
-                       stdout=subprocess.PIPE if capture else None)
+                       stdout=subprocess.PIPE if capture else None, timeout=timeout)
     return r.stdout.decode() if capture else ""
 
 
@@ -270,3 +286,39 @@ def ref_locate(index_path, patterns, max_occs, tmpdir):
     noccs = np.frombuffer(raw, dtype=np.int32, count=n).copy()
     offs = np.frombuffer(raw, dtype=np.int64, offset=4 * n, count=int(noccs.sum())).copy()
     return noccs, offs
+
+
+FNFA_MAGIC = 0x41464E46
+
+
+def write_fnfa(path, nfas):
+    """the automaton file ref_tool regexp_nfa reads (oracle/ref_tool.c)"""
+    with open(path, "wb") as f:
+        f.write(np.array([FNFA_MAGIC, len(nfas)], dtype=np.uint32).tobytes())
+        for a in nfas:
+            f.write(np.array([a.num_nodes, len(a.trans_char)] + list(a.settings), dtype=np.int32).tobytes())
+            f.write(np.ascontiguousarray(a.trans_start, dtype=np.int32).tobytes())
+            f.write(np.ascontiguousarray(a.trans_char, dtype=np.int32).tobytes())
+            f.write(np.ascontiguousarray(a.trans_dest, dtype=np.int32).tobytes())
+            f.write(np.ascontiguousarray(a.is_start, dtype=np.uint8).tobytes())
+            f.write(np.ascontiguousarray(a.is_final, dtype=np.uint8).tobytes())
+
+
+def ref_regexp_nfa(index_path, nfas, tmpdir, timeout=600):
+    """the GENUINE do_regexp_query (setup_regexp_query_take_nfa, src/main/server.h:838) on hand-fed automata:
+    one (err_code, first, last, match_len, cost) per automaton, in the order of the reference's sorted result list"""
+    nf, of = os.path.join(tmpdir, "q.fnfa"), os.path.join(tmpdir, "regexp.bin")
+    write_fnfa(nf, nfas)
+    # (do_regexp_query never returns when a pending range's alive states can read NOTHING: it then schedules zero
+    # requests and waits for them, server.c:1954-1990 -- hence the timeout; automata from a pattern have no such state)
+    ref_tool("regexp_nfa", index_path, nf, of, timeout=timeout)
+    raw = open(of, "rb").read()
+    out, o = [], 0
+    rec = np.dtype([("first", "<i8"), ("last", "<i8"), ("len", "<i4"), ("cost", "<i4")])
+    for _ in nfas:
+        code, n = np.frombuffer(raw, dtype=np.int32, count=2, offset=o)
+        o += 8
+        r = np.frombuffer(raw, dtype=rec, count=int(n), offset=o)
+        o += int(n) * rec.itemsize
+        out.append((int(code), r["first"].copy(), r["last"].copy(), r["len"].copy(), r["cost"].copy()))
+    return out

@@ -15,6 +15,9 @@
  *   forward : the leaf requests of do_forward_query (src/main/server.c:2424) for every row
  *   bseq    : bseq_construct_forcetype (src/main/wtree.c:365) -> encoded image
  *   flatten : flatten_index (src/main/index.c:2260)
+ *   regexp_nfa : setup_regexp_query_take_nfa (src/main/server.h:838, server.c:1342) + femto_run_query: do_regexp_query
+ *             (server.c:1656) on hand-fed nfa_description_t automata (filled as nfa_test.c:57-80 fills them); the
+ *             reference's regex FRONT END (flex/bison) is not needed for this, and is not built
  *
  * Nothing here is part of the product; the product never links or executes this file.
  *
@@ -37,6 +40,8 @@
 #include "server.h"
 #include "timing.h"
 #include "wtree_funcs.h"
+#include "nfa.h"
+#include "bit_array.h"
 
 #define FPAT_MAGIC 0x54415046u
 
@@ -443,6 +448,81 @@ static int cmd_flatten(int argc, char** argv)
   return 0;
 }
 
+/* regexp_nfa <index> <nfas.bin> <out.bin>
+   nfas.bin ("FNFA", native little-endian): u32 magic 0x41464e46, u32 nq, then per automaton
+     i32 num_nodes, num_trans, cost_bound, subst_cost, delete_cost, insert_cost;
+     i32 trans_start[num_nodes + 1]; i32 trans_char[num_trans] (alpha codes); i32 trans_dest[num_trans];
+     u8 is_start[num_nodes]; u8 is_final[num_nodes]
+   out.bin: per automaton i32 err_code (0 = ok), i32 nresults, then nresults x { i64 first, i64 last, i32 match_len,
+   i32 cost } in the order of the query's sorted result list (regexp_result_list_sort, server.c:1528). */
+static int cmd_regexp_nfa(int argc, char** argv)
+{
+  if (argc < 3) return 2;
+  femto_server_t srv = start_srv(0);
+  index_locator_t loc;
+  error_t err = femto_loc_for_path_err(&srv, argv[0], &loc);
+  if (err) die("femto_loc_for_path_err", err);
+  int64_t flen;
+  unsigned char* fb = slurp(argv[1], &flen);
+  const unsigned char* p = fb;
+  uint32_t magic, nq;
+  memcpy(&magic, p, 4); p += 4;
+  memcpy(&nq, p, 4); p += 4;
+  if (magic != 0x41464e46u) { fprintf(stderr, "bad FNFA magic\n"); return 2; }
+  FILE* out = fopen(argv[2], "wb");
+  if (!out) { perror(argv[2]); return 2; }
+  for (uint32_t qi = 0; qi < nq; qi++) {
+    int32_t hd[6];
+    memcpy(hd, p, 24); p += 24;
+    const int nn = hd[0], nt = hd[1];
+    const int32_t* tstart = (const int32_t*) p; p += 4 * (size_t)(nn + 1);
+    const int32_t* tchar = (const int32_t*) p; p += 4 * (size_t) nt;
+    const int32_t* tdest = (const int32_t*) p; p += 4 * (size_t) nt;
+    const unsigned char* is_start = p; p += nn;
+    const unsigned char* is_final = p; p += nn;
+    nfa_description_t* nfa = malloc(sizeof(nfa_description_t));   /* freed by cleanup_regexp_query */
+    err = init_nfa_description(nfa, nn);
+    if (err) die("init_nfa_description", err);
+    for (int i = 0; i < nn; i++) {
+      const int k = tstart[i + 1] - tstart[i];
+      nfa->nodes[i].num_transitions = k;
+      nfa->nodes[i].transitions = k ? malloc(k * sizeof(nfa_transition_t)) : NULL;
+      for (int j = 0; j < k; j++) {
+        nfa->nodes[i].transitions[j].character = (alpha_t) tchar[tstart[i] + j];
+        nfa->nodes[i].transitions[j].destination = tdest[tstart[i] + j];
+      }
+      if (is_start[i]) set_bit(nfa->bit_array_len, nfa->start_states_set, i);
+      if (is_final[i]) set_bit(nfa->bit_array_len, nfa->final_states_set, i);
+    }
+    nfa->settings.cost_bound = hd[2];
+    nfa->settings.subst_cost = hd[3];
+    nfa->settings.delete_cost = hd[4];
+    nfa->settings.insert_cost = hd[5];
+    regexp_query_t* q = malloc(sizeof(regexp_query_t));
+    err = setup_regexp_query_take_nfa(q, NULL, loc, nfa, 0);
+    if (err) die("setup_regexp_query_take_nfa", err);
+    err = femto_run_query(&srv, (query_entry_t*) q);
+    if (err) die("femto_run_query", err);
+    int32_t code = q->proc.entry.err_code, nres = code ? 0 : q->results.num_results;
+    fwrite(&code, 4, 1, out);
+    fwrite(&nres, 4, 1, out);
+    for (int i = 0; i < nres; i++) {
+      const regexp_result_t* r = &q->results.results[i];
+      int32_t ml = r->match_len, cost = r->cost;
+      fwrite(&r->first, 8, 1, out);
+      fwrite(&r->last, 8, 1, out);
+      fwrite(&ml, 4, 1, out);
+      fwrite(&cost, 4, 1, out);
+    }
+    cleanup_regexp_query(q);
+    free(q);
+  }
+  fclose(out);
+  free(fb);
+  femto_stop_server(&srv);
+  return 0;
+}
+
 int main(int argc, char** argv)
 {
   if (argc < 2) {
@@ -459,6 +539,7 @@ int main(int argc, char** argv)
   if (!strcmp(c, "forward")) return cmd_forward(argc - 2, argv + 2);
   if (!strcmp(c, "bseq")) return cmd_bseq(argc - 2, argv + 2);
   if (!strcmp(c, "flatten")) return cmd_flatten(argc - 2, argv + 2);
+  if (!strcmp(c, "regexp_nfa")) return cmd_regexp_nfa(argc - 2, argv + 2);
   fprintf(stderr, "unknown command %s\n", c);
   return 2;
 }
