@@ -20,7 +20,8 @@ __all__ = ["Index", "FemtoAmdError", "lib", "ALPHA_SIZE", "CHARACTER_OFFSET", "I
 ALPHA_SIZE = 261
 CHARACTER_OFFSET = 5
 ERR_NAMES = {0: "NOERR", 1: "MEM", 2: "IO", 3: "PARAM", 4: "FORMAT", 5: "BZ_DATA", 6: "INVALID",
-             8: "MISSING", 12: "UNKNOWN"}
+             8: "MISSING", 10: "FULL", 11: "OVERWORKED", 12: "UNKNOWN"}
+ERR_PARAM, ERR_INVALID, ERR_FULL, ERR_OVERWORKED = 3, 6, 10, 11
 
 
 class FemtoAmdError(RuntimeError):
