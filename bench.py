@@ -34,14 +34,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # (rank mode, direct pipeline?) -> how rocprofv3 names the search / walk kernel (a prefix: template arguments follow)
 KERNEL_NAMES = {(4, True): "femto_amd::count_direct_kernel<femto_amd::Pack2Policy, true", (3, True): "femto_amd::count_direct_kernel<femto_amd::PackPolicy, true",
-                (4, False): "femto_amd::count_kernel_pack2<true>", (3, False): "femto_amd::count_kernel_pack<true>",
-                (1, False): "femto_amd::count_kernel_lane", (2, False): "femto_amd::count_kernel_flat<1>", (0, False): "femto_amd::count_kernel<32>"}
+                (1, False): "femto_amd::count_kernel_lane", (0, False): "femto_amd::count_kernel<32>"}
 LOCATE_NAMES = {(4, True): "femto_amd::locate_walk_kernel<femto_amd::Pack2Policy>", (3, True): "femto_amd::locate_walk_kernel<femto_amd::PackPolicy>",
-                (4, False): "femto_amd::locate_kernel_pack2", (3, False): "femto_amd::locate_kernel_pack",
-                (1, False): "femto_amd::locate_kernel_lane", (2, False): "femto_amd::locate_kernel_flat", (0, False): "femto_amd::locate_kernel<32>"}
-for _m in (0, 1, 2):
-    KERNEL_NAMES[(_m, True)] = KERNEL_NAMES[(_m, False)]
-    LOCATE_NAMES[(_m, True)] = LOCATE_NAMES[(_m, False)]
+                (1, False): "femto_amd::locate_kernel_lane", (0, False): "femto_amd::locate_kernel<32>"}
 
 
 def kernel_names(ix, direct):
@@ -377,7 +372,7 @@ def main():
     else:
         plen, flat = tg.p_rand(args.plen, npats, args.seed + 1000 + rank)
     batch = Batch(torch, dev, plen, flat)
-    direct = bool(ix.pack_info().get("level_table")) and os.environ.get("FEMTO_AMD_DIRECT", "1") != "0" and ix.rank_mode in (3, 4)
+    direct = ix.rank_mode in (3, 4)      # the caller-order pipeline (direct_kernels.hip.hpp)
     if args.pmc_child:      # the short run the PMC passes of pmc_traffic() profile: same index, same batch, a few steps
         if os.environ.get("FEMTO_AMD_BENCH_CHILD_INFO"):
             with open(os.environ["FEMTO_AMD_BENCH_CHILD_INFO"], "w") as fh:

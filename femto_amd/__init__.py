@@ -461,11 +461,12 @@ class Index:
         return first[:n.value], last[:n.value], mlen[:n.value], cost[:n.value]
 
     def set_option(self, name, value):
-        """'direct' (modes 3/4: caller-order pipeline, default 1) / 'sort' (suffix-order batches of the other paths)"""
+        """'sort' (suffix-order batches of the wavelet-path kernels), 'regexp_max_iterations', 'regexp_stack_cap'"""
         _check(lib().femto_amd_set_option(self._h, name.encode(), int(value)))
 
     def set_rank_mode(self, mode):
-        """1 = lane per query (default), 2 = flattened persistent lanes, 0 = wavefront-per-query raw walk"""
+        """3 / 4 = packed / two-level lines (the defaults where they exist), 1 = lane per query on femto's wavelet tree,
+        0 = wavefront-per-query walk of femto's raw tables"""
         _check(lib().femto_amd_set_rank_mode(self._h, mode))
 
     @property

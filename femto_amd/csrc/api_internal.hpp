@@ -193,13 +193,12 @@ struct femto_amd_index {
   LaneSeq* d_lseqs = nullptr;
   OccEntry* d_occ = nullptr;
   int mode = 1;  // 3: packed small-alphabet lines (default when the index has <= 8 characters); 4: two-level lines (<= 256
-                 // characters); 1: lane-per-query kernels on femto's wavelet tree (default otherwise); 2: flattened
-                 // persistent-lane kernels; 0: wavefront-cooperative raw A/S/D walk
+                 // characters); 1: lane-per-query kernels on femto's wavelet tree (default otherwise); 0: wavefront-cooperative
+                 // walk of femto's raw A/S/D tables
   uint32_t* d_pack = nullptr;
   int64_t* d_pack_sa = nullptr;
   uint8_t* d_pack_code = nullptr;
   int64_t* d_pack_c = nullptr;
-  int64_t* d_ktab = nullptr;
   int64_t* d_ktab2 = nullptr;
   int64_t* d_ktab2_deep = nullptr;
   int64_t ktab2_bytes = 0;
@@ -223,7 +222,6 @@ struct femto_amd_index {
   int64_t pack_bytes = 0;
   double pack_build_ms = 0;
   int num_cus = 256;
-  int blocks_per_cu_override = 0;
   DevIndex dev{};
   int64_t table_bytes = 0;
   DeviceBuffer open_scan[3];   // scan scratch of the derivations at open
@@ -235,7 +233,6 @@ struct femto_amd_index {
   std::unique_ptr<WorkerPool> workers;   // staging threads of host-pointer batches, created on first use
   std::mutex workers_mu;                 // one staged batch at a time uses the worker pool
   bool sort_queries = true;    // FEMTO_AMD_SORT=0 disables the suffix-order batch sort of the paths that use one
-  bool direct = true;          // FEMTO_AMD_DIRECT=0: modes 3/4 go back to the sorted-batch kernels of round 1
   uint8_t* d_dense = nullptr;  // alpha code -> dense sort digit (characters present in the text)
   std::vector<uint8_t> h_dense; // the same table on the host (key staging of host-pointer batches)
   int dense_bits = 8;

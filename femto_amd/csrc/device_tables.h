@@ -130,8 +130,6 @@ struct DevIndex {           // passed by value to kernels
   const int64_t* pack_sa;   // offsets of the marked rows, row order
   const uint8_t* pack_code; // [261] alpha code -> dense code 0..7, 0xff: not in the text
   const int64_t* pack_c;    // [16]: C[ch(code)] for code 0..7, then C[ch(code)+1]-1
-  const int64_t* ktab;      // [2^ktab_bits][2]: backward search of the first ktab_syms key fields, precomputed (pack_kernels.hip.hpp)
-  int32_t ktab_bits, ktab_syms;
   const int64_t* ktab2;     // level table of the first steps, heap-numbered over the table characters (direct_kernels.hip.hpp)
   int32_t kt2_syms;         // deepest level K
   int32_t kt2_base;         // t = number of table characters (characters of the text that are not <= SEOF)

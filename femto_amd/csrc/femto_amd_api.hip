@@ -274,9 +274,8 @@ struct Plan {
   int64_t* total_user = nullptr;   // device, 2 words: the caller's copy of S.d_total, written by plan_scan_kernel itself
 };
 
-bool use_direct(const femto_amd_index* ix) {
-  return ix->direct && (ix->mode == 3 || ix->mode == 4) && ix->dev.ktab2 != nullptr;
-}
+// modes 3 / 4: the caller-order pipeline of direct_kernels.hip.hpp (with or without a level table)
+bool use_direct(const femto_amd_index* ix) { return ix->mode == 3 || ix->mode == 4; }
 
 int tail_setup(femto_amd_index* ix, Scratch& S, DevIndex& d, int64_t npats, hipStream_t stream) {
   int rc = S.tail.reserve(size_t(npats) * sizeof(TailItem));
@@ -384,27 +383,15 @@ int launch_count_chunk(femto_amd_index* ix, Scratch& S, int64_t npats, const int
   const int64_t threads = npats * lanes_per_query;
   const int64_t blocks = (threads + kBlockThreads - 1) / kBlockThreads;
   if (blocks > 0x7fffffffLL) return set_err(FEMTO_AMD_ERR_PARAM, "batch too large for one launch");
-  bool split_pairs = false, tail_launch = false;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  DevIndex d = ix->dev;
-  if (ix->mode == 2) {
-    timer_begin(ix, ix->t_count, stream, &e0, &e1);
-    int64_t lblocks = (npats + kBlockThreads - 1) / kBlockThreads;
-    {  // persistent grid: exactly the resident blocks, lanes stride over the batch
-      int per_cu = 0;
-      hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, count_kernel_flat<1>, kBlockThreads, 0);
-      if (oe != hipSuccess || per_cu < 1) per_cu = 1;
-      int64_t cap = int64_t(ix->num_cus) * per_cu;
-      if (ix->blocks_per_cu_override > 0) cap = int64_t(ix->num_cus) * ix->blocks_per_cu_override;
-      if (lblocks > cap) lblocks = cap;
-    }
-    hipLaunchKernelGGL((count_kernel_flat<1>), dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, d, npats,
-                         d_plen, d_pats, d_starts, d_first, d_last, S.err);
-  } else if (ix->mode == 1 || ix->mode == 3 || ix->mode == 4) {
+  const DevIndex& d = ix->dev;
+  if (ix->mode == 1) {
+    // femto's own wavelet tree, one lane per pattern (alphabets of more than 256 characters, range-split indexes)
     const int64_t lblocks = (npats + kBlockThreads - 1) / kBlockThreads;
     const uint32_t* perm = nullptr;
     if (ix->sort_queries && npats >= ix->sort_min && npats < (int64_t(1) << 32)) {
-      // order the batch by pattern suffix (query_sort.hip); results still land at the caller's indexes
+      // order the batch by pattern suffix (query_sort.hip: the reference's "sort requests by block and row",
+      // server.h:930-971); results still land at the caller's indexes
       int rc;
       if ((rc = S.keys.reserve(size_t(npats) * 8))) return rc;
       if ((rc = S.keys2.reserve(size_t(npats) * 8))) return rc;
@@ -419,56 +406,17 @@ int launch_count_chunk(femto_amd_index* ix, Scratch& S, int64_t npats, const int
                          S.keys2.as<uint64_t>(), S.idx.as<uint32_t>(), S.idx2.as<uint32_t>(), S.sorttmp.p, tb, stream));
       perm = S.idx2.as<uint32_t>();
     }
-    bool tail = false;
-    if ((ix->mode == 3 || ix->mode == 4) && perm && d.txt) {   // long patterns may be handed to count_tail_kernel
-      int rc2 = tail_setup(ix, S, d, npats, stream);
-      if (rc2) return rc2;
-      tail = true;
-    }
     timer_begin(ix, ix->t_count, stream, &e0, &e1);   // events bracket the search kernel itself (the sort is separate)
-    if (ix->mode == 3 && perm) {
-      int rc2 = S.pairs.reserve(size_t(npats) * 16);
-      if (rc2) return rc2;
-      hipLaunchKernelGGL(count_kernel_pack<true>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, d, npats, d_plen,
-                         d_pats, d_starts, d_first, d_last, S.err, perm, S.keys2.as<uint64_t>(), ix->dense_bits,
-                         63 / ix->dense_bits, S.pairs.as<longlong2>());
-      split_pairs = true;
-      tail_launch = tail;
-    } else if (ix->mode == 4 && perm) {
-      int rc2 = S.pairs.reserve(size_t(npats) * 16);
-      if (rc2) return rc2;
-      hipLaunchKernelGGL(count_kernel_pack2<true>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, d, npats, d_plen,
-                         d_pats, d_starts, d_first, d_last, S.err, perm, S.keys2.as<uint64_t>(), ix->dense_bits,
-                         63 / ix->dense_bits, S.pairs.as<longlong2>());
-      split_pairs = true;
-      tail_launch = tail;
-    } else if (ix->mode == 4)
-      hipLaunchKernelGGL(count_kernel_pack2<false>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, d, npats, d_plen,
-                         d_pats, d_starts, d_first, d_last, S.err, perm, nullptr, 1, 0, nullptr);
-    else if (ix->mode == 3)
-      hipLaunchKernelGGL(count_kernel_pack<false>, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, d, npats, d_plen,
-                         d_pats, d_starts, d_first, d_last, S.err, perm, nullptr, 1, 0, nullptr);
-    else
-      hipLaunchKernelGGL(count_kernel_lane, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, d, npats, d_plen,
-                         d_pats, d_starts, d_first, d_last, S.err, perm);
+    hipLaunchKernelGGL(count_kernel_lane, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, d, npats, d_plen,
+                       d_pats, d_starts, d_first, d_last, S.err, perm);
   } else {
+    // mode 0: the wavefront-cooperative walk of femto's raw tables (north_star's sketch; the documented reference kernel)
     timer_begin(ix, ix->t_count, stream, &e0, &e1);
     hipLaunchKernelGGL((count_kernel<kGroupW>), dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, stream, d, npats,
                        d_plen, d_pats, d_starts, d_first, d_last, S.err);
   }
-  if (tail_launch) {
-    const TailOut out{S.pairs.as<longlong2>(), nullptr, nullptr, nullptr, nullptr, 0};
-    const dim3 tgrid{uint32_t(std::min<int64_t>((npats + kBlockThreads - 1) / kBlockThreads, int64_t(ix->num_cus) * 8))};
-    launch_tail(ix, d, tgrid, stream, static_cast<const TailItem*>(S.tail.p), d_plen, d_pats, d_starts, S.idx2.as<uint32_t>(), S.keys2.as<uint64_t>(),
-                ix->dense_bits, 63 / ix->dense_bits, out, S.err);
-  }
   HIP_TRY(hipGetLastError());
   timer_end(ix, ix->t_count, stream, e0, e1);
-  if (split_pairs) {
-    hipLaunchKernelGGL(split_pairs_kernel, dim3(uint32_t((npats + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, stream,
-                       npats, S.pairs.as<longlong2>(), d_first, d_last);
-    HIP_TRY(hipGetLastError());
-  }
   return 0;
 }
 
@@ -601,18 +549,7 @@ int launch_locate(femto_amd_index* ix, Scratch& S, int64_t npats, const int64_t*
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   timer_begin(ix, ix->t_locate, stream, &e0, &e1);
-  if (ix->mode == 2) {
-    int64_t lblocks = (total + kBlockThreads - 1) / kBlockThreads;
-    {
-      int per_cu = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, locate_kernel_flat, kBlockThreads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-      int64_t cap = int64_t(ix->num_cus) * per_cu;
-      if (ix->blocks_per_cu_override > 0) cap = int64_t(ix->num_cus) * ix->blocks_per_cu_override;
-      if (lblocks > cap) lblocks = cap;
-    }
-    hipLaunchKernelGGL(locate_kernel_flat, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, npats, d_first,
-                       d_out_starts, total, d_offsets);
-  } else if ((ix->mode == 3 || ix->mode == 4) && ix->dev.sa_full) {
+  if ((ix->mode == 3 || ix->mode == 4) && ix->dev.sa_full) {
     const int64_t lblocks = (total + kBlockThreads - 1) / kBlockThreads;
     hipLaunchKernelGGL(gather_sa_kernel, dim3(uint32_t(lblocks)), dim3(kBlockThreads), 0, stream, ix->dev, total, d_offsets);
   } else if (ix->mode == 4) {
@@ -657,27 +594,6 @@ int stage_patterns(Scratch& S, int64_t npats, const int32_t* plen, const uint16_
     HIP_TRY(hipMemcpyAsync(S.starts.p, starts, size_t(npats) * 8, hipMemcpyHostToDevice, S.stream));
   }
   if (total) HIP_TRY(hipMemcpyAsync(S.pats.p, pats, size_t(total) * 2, hipMemcpyHostToDevice, S.stream));
-  return 0;
-}
-
-// first-steps table (ktab): as many key fields as give at most 2^21 entries; the ranges do not depend on which
-// layout computes them, so pack and pack2 share it
-template <class Kernel>
-int build_ktab(femto_amd_index* ix, Kernel kernel) {
-  if (ix->dev.ktab) return 0;
-  const char* kt = getenv("FEMTO_AMD_KTAB");
-  if (kt && atoi(kt) == 0) return 0;
-  const int bits = ix->dense_bits;
-  const int syms = std::min(21 / bits, 63 / bits);
-  const size_t entries = size_t(1) << (bits * syms);
-  if (hipMalloc(reinterpret_cast<void**>(&ix->d_ktab), entries * 16) != hipSuccess) return set_err(FEMTO_AMD_ERR_MEM, "hipMalloc ktab");
-  hipLaunchKernelGGL(kernel, dim3(uint32_t((entries + 255) / 256)), dim3(256), 0, nullptr, ix->dev, bits, syms,
-                     reinterpret_cast<longlong2*>(ix->d_ktab));
-  if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return set_err(FEMTO_AMD_ERR_INVALID, "ktab build failed");
-  ix->dev.ktab = ix->d_ktab;
-  ix->dev.ktab_bits = bits * syms;
-  ix->dev.ktab_syms = syms;
-  ix->table_bytes += int64_t(entries * 16);
   return 0;
 }
 
@@ -1018,7 +934,6 @@ int build_pack(femto_amd_index* ix) {
     ix->pack_build_ms = ms;
     ix->dev.pack = ix->d_pack;
     ix->dev.pack_sa = ix->d_pack_sa;
-    r = build_ktab(ix, ktab_build_kernel);
   }
   return r;
 }
@@ -1187,7 +1102,6 @@ int build_pack2(femto_amd_index* ix) {
     (void)hipEventElapsedTime(&ms, e0, e1);
     ix->pack2_build_ms = ms;
     ix->pack2_bytes = ix->table_bytes - bytes0;
-    r = build_ktab(ix, ktab_build_kernel2);
   } else {
     d.p2_l1 = nullptr;
     d.p2_l2 = nullptr;
@@ -1849,7 +1763,6 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         ix->num_cus = prop.multiProcessorCount;
         if (const char* so = getenv("FEMTO_AMD_SORT")) ix->sort_queries = atoi(so) != 0;
-        if (const char* pb = getenv("FEMTO_AMD_BLOCKS_PER_CU")) ix->blocks_per_cu_override = atoi(pb);
       }
       ix->mode = h.dir_regular ? 1 : 0;
       if (split) return 0;  // lane kernels only
@@ -1877,7 +1790,6 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
       if ((ix->dev.pack || ix->dev.p2_l1) && (r = build_text(ix)) && r != FEMTO_AMD_ERR_MEM) return r;
       if (ix->dev.pack) ix->mode = 3;
       else if (ix->dev.p2_l1) ix->mode = 4;
-      if (const char* dm = getenv("FEMTO_AMD_DIRECT")) ix->direct = atoi(dm) != 0;
       if (ix->dev.pack) r = build_ktab2<PackPolicy>(ix, ix->dev.pack_sigma, __builtin_popcount(ix->dev.pack_stop));
       else if (ix->dev.p2_l1) r = build_ktab2<Pack2Policy>(ix, ix->dev.p2_sigma, int(ix->dev.p2_stop_below));
       if (r && r != FEMTO_AMD_ERR_MEM) return r;
@@ -1887,7 +1799,6 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
       if (const char* m = getenv("FEMTO_AMD_RANK_MODE")) {
         if (!strcmp(m, "raw")) ix->mode = 0;
         else if (!strcmp(m, "lane") && h.dir_regular) ix->mode = 1;
-        else if (!strcmp(m, "flat") && h.dir_regular) ix->mode = 2;
         else if (!strcmp(m, "pack") && ix->dev.pack) ix->mode = 3;
         else if (!strcmp(m, "pack2") && ix->dev.p2_l1) ix->mode = 4;
       }
@@ -2066,7 +1977,7 @@ void femto_amd_close(femto_amd_index_t* ix) {
       for (void* q : {static_cast<void*>(ix->d_nodes), static_cast<void*>(ix->d_buckets), static_cast<void*>(ix->d_seqs), static_cast<void*>(ix->d_occ_base),
                       static_cast<void*>(ix->d_leaf_code), static_cast<void*>(ix->d_C), static_cast<void*>(ix->d_cum), static_cast<void*>(ix->d_hint),
                       static_cast<void*>(ix->d_bdir), static_cast<void*>(ix->d_lnodes), static_cast<void*>(ix->d_lseqs), static_cast<void*>(ix->d_occ),
-                      static_cast<void*>(ix->d_dense), static_cast<void*>(ix->d_pack_code), static_cast<void*>(ix->d_pack_c), static_cast<void*>(ix->d_ktab),
+                      static_cast<void*>(ix->d_dense), static_cast<void*>(ix->d_pack_code), static_cast<void*>(ix->d_pack_c),
                       static_cast<void*>(ix->d_p2_base), static_cast<void*>(ix->d_p2_c), static_cast<void*>(ix->d_p2_code), static_cast<void*>(ix->d_p2_alpha)})
         (void)hipFree(q);
     }
@@ -2601,7 +2512,7 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
   region_lines[kTraceTxt] = ix->dev.txt ? (n + 64) / 128 + 1 : 0;
   region_lines[kTraceIsa] = ix->dev.isa8 ? ((n >> ix->dev.isa_shift) + 2) / 16 + 1 : 0;
   region_lines[kTraceCtx] = ix->ctx_bytes / 128 + ix->ctx2_bytes / 128;
-  region_lines[kTraceKtab1] = ix->dev.ktab ? ((int64_t(1) << ix->dev.ktab_bits) * 16) / 128 + 1 : 0;
+  region_lines[kTraceKtab1] = 0;
   int64_t off[kTraceRegions + 1];
   off[0] = 0;
   for (int r = 0; r < kTraceRegions; r++) off[r + 1] = (off[r] + region_lines[r] + 63) & ~int64_t(63);
@@ -2742,11 +2653,10 @@ static int make_view(femto_amd_index* b, int device, femto_amd_index** out) {
   h.text_size_bits = s.text_size_bits; h.buckets_per_block = s.buckets_per_block; h.total_buckets = s.total_buckets;
   h.header = s.header; h.C = s.C; h.doc_ends = s.doc_ends; h.doc_info_off = s.doc_info_off; h.dir_regular = s.dir_regular;
   h.block_off = s.block_off; h.block_len = s.block_len;
-  v->mode = b->mode; v->direct = b->direct; v->sort_queries = b->sort_queries; v->dense_bits = b->dense_bits;
+  v->mode = b->mode; v->sort_queries = b->sort_queries; v->dense_bits = b->dense_bits;
   v->dense_sigma = b->dense_sigma; v->sort_min = b->sort_min; v->h_dense = b->h_dense; v->table_bytes = b->table_bytes;
   v->ktab2_bytes = b->ktab2_bytes; v->ctx_bytes = b->ctx_bytes; v->ctx2_bytes = b->ctx2_bytes; v->n_marks = b->n_marks; v->p2_lines1 = b->p2_lines1; v->p2_lines2 = b->p2_lines2;
   v->ind_bytes = b->ind_bytes; v->text_bytes = b->text_bytes; v->pack_bytes = b->pack_bytes; v->pack2_bytes = b->pack2_bytes;
-  v->blocks_per_cu_override = b->blocks_per_cu_override;
   if (hipSetDevice(device) != hipSuccess) return fail(set_err(FEMTO_AMD_ERR_INVALID, "no usable HIP device " + std::to_string(device)));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) v->num_cus = prop.multiProcessorCount;
@@ -2812,7 +2722,7 @@ extern "C++" {
 namespace {
 
 struct SharedFacts {       // what make_view copies from the builder, as plain data
-  int32_t mode, direct, sort_queries, dense_bits, blocks_per_cu_override;
+  int32_t mode, sort_queries, dense_bits;
   double dense_sigma;
   int64_t sort_min, table_bytes, ktab2_bytes, ctx_bytes, ctx2_bytes, n_marks, p2_lines1, p2_lines2, ind_bytes, text_bytes, pack_bytes, pack2_bytes;
   uint64_t d_dense;
@@ -2921,8 +2831,8 @@ int femto_amd_striped_serve(femto_amd_index_t* ix, const char* socket_path, int 
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipDeviceSynchronize());
   SharedFacts f{};
-  f.mode = b->mode; f.direct = b->direct; f.sort_queries = b->sort_queries; f.dense_bits = b->dense_bits;
-  f.blocks_per_cu_override = b->blocks_per_cu_override; f.dense_sigma = b->dense_sigma; f.sort_min = b->sort_min;
+  f.mode = b->mode; f.sort_queries = b->sort_queries; f.dense_bits = b->dense_bits;
+  f.dense_sigma = b->dense_sigma; f.sort_min = b->sort_min;
   f.table_bytes = b->table_bytes; f.ktab2_bytes = b->ktab2_bytes; f.ctx_bytes = b->ctx_bytes; f.ctx2_bytes = b->ctx2_bytes;
   f.n_marks = b->n_marks; f.p2_lines1 = b->p2_lines1; f.p2_lines2 = b->p2_lines2; f.ind_bytes = b->ind_bytes;
   f.text_bytes = b->text_bytes; f.pack_bytes = b->pack_bytes; f.pack2_bytes = b->pack2_bytes;
@@ -3040,8 +2950,8 @@ int femto_amd_open_striped_client(const char* index_path, const char* socket_pat
   if (!R.get(&v->dev, sizeof(DevIndex))) return bail(set_err(FEMTO_AMD_ERR_FORMAT, "short description"));
   v->h_dense.resize(size_t(f.n_dense));
   if (f.n_dense && !R.get(v->h_dense.data(), size_t(f.n_dense))) return bail(set_err(FEMTO_AMD_ERR_FORMAT, "short description"));
-  v->mode = f.mode; v->direct = f.direct != 0; v->sort_queries = f.sort_queries != 0; v->dense_bits = f.dense_bits;
-  v->blocks_per_cu_override = f.blocks_per_cu_override; v->dense_sigma = f.dense_sigma; v->sort_min = f.sort_min;
+  v->mode = f.mode; v->sort_queries = f.sort_queries != 0; v->dense_bits = f.dense_bits;
+  v->dense_sigma = f.dense_sigma; v->sort_min = f.sort_min;
   v->table_bytes = f.table_bytes; v->ktab2_bytes = f.ktab2_bytes; v->ctx_bytes = f.ctx_bytes; v->ctx2_bytes = f.ctx2_bytes;
   v->n_marks = f.n_marks; v->p2_lines1 = f.p2_lines1; v->p2_lines2 = f.p2_lines2; v->ind_bytes = f.ind_bytes;
   v->text_bytes = f.text_bytes; v->pack_bytes = f.pack_bytes; v->pack2_bytes = f.pack2_bytes;
@@ -3174,7 +3084,7 @@ int femto_amd_comm_gather(femto_amd_index_t* ix, const void* d_send, void* d_rec
 }
 
 int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode) {
-  if (!ix || mode < 0 || mode > 4) return set_err(FEMTO_AMD_ERR_PARAM, "bad rank mode");
+  if (!ix || mode < 0 || mode > 4 || mode == 2) return set_err(FEMTO_AMD_ERR_PARAM, "bad rank mode (0, 1, 3, 4)");
   if (!ix->children.empty()) {
     for (femto_amd_index* c : ix->children) { int rc = femto_amd_set_rank_mode(c, mode); if (rc) return rc; }
     return FEMTO_AMD_OK;
@@ -3200,8 +3110,7 @@ int femto_amd_set_option(femto_amd_index_t* ix, const char* name, int value) {
   if (!ix || !name) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
   for (femto_amd_index* c : ix->children) { int rc = femto_amd_set_option(c, name, value); if (rc) return rc; }
   std::lock_guard<std::mutex> lk(ix->mu);
-  if (!strcmp(name, "direct")) ix->direct = value != 0;
-  else if (!strcmp(name, "sort")) ix->sort_queries = value != 0;
+  if (!strcmp(name, "sort")) ix->sort_queries = value != 0;
   else if (!strcmp(name, "regexp_max_iterations")) ix->regexp_max_iterations = value;
   else if (!strcmp(name, "regexp_stack_cap")) ix->regexp_stack_cap = std::max(16, value);
   else return set_err(FEMTO_AMD_ERR_PARAM, "unknown option");
@@ -3212,7 +3121,7 @@ int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* by
   if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
   if (!ix->children.empty()) return femto_amd_pack_info(ix->children[0], available, bytes, build_ms, ktab_syms);
   if (available) *available = ix->dev.pack != nullptr;
-  if (ktab_syms) *ktab_syms = ix->dev.ktab2 ? ix->dev.kt2_syms : (ix->dev.ktab ? ix->dev.ktab_syms : 0);
+  if (ktab_syms) *ktab_syms = ix->dev.ktab2 ? ix->dev.kt2_syms : 0;
   if (available && ix->dev.p2_l1) *available |= 2;   // bit 1: the two-level lines (mode 4) exist
   if (available && ix->dev.ktab2) *available |= 4;   // bit 2: the level table of the direct pipeline exists
   if (available && ix->dev.ind) *available |= 32;     // bit 5: per-character rank lines (byte alphabets)

@@ -840,258 +840,6 @@ inline __global__ __launch_bounds__(256) void block_request_kernel_lane(const De
   if (off_out) off_out[item] = off;
 }
 
-
-// =====================================================================================
-// Flattened persistent-lane kernels (mode 2, selectable).
-//
-// The nested loops of the lane kernels above (pattern steps x two rows x wavelet levels x gamma
-// codes) diverge multiplicatively inside a wavefront: on a sigma~96 index (code lengths 1..20,
-// 74 % RLE ranks, ~67 gamma codes each) rocprofv3 showed 1.4e11 VALU wave-instructions per 2 M
-// patterns, ~10 % lane utilisation.  Here every lane runs ONE flat loop whose body performs exactly
-// one bseq_rank for whatever (query, row, level) the lane is at, then advances a small state
-// machine; finished lanes pull their next query (grid-stride), so a wavefront's 64 lanes always
-// rank together and only the rank itself (literal popcount vs gamma runs) can diverge.
-// =====================================================================================
-
-enum : int { ST_QUERY = 0, ST_STEP = 1, ST_WALK = 2, ST_DONE = 3 };
-
-// do_string_query (src/main/server.c:713-946), flattened: every lane owns NQ patterns at a time and
-// advances the two walks (rows first-1 and last) of each by ONE wavelet level per loop iteration.
-template <int NQ>
-inline __global__ __launch_bounds__(256) void count_kernel_flat(const DevIndex ix, const int64_t npats,
-                                                         const int32_t* __restrict__ plen,
-                                                         const uint16_t* __restrict__ pats,
-                                                         const int64_t* __restrict__ starts,
-                                                         int64_t* __restrict__ first_out,
-                                                         int64_t* __restrict__ last_out, int* __restrict__ err_flag) {
-  constexpr int NW = 2 * NQ;  // walks per lane
-  const int64_t T = int64_t(gridDim.x) * blockDim.x;
-  const int64_t tid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  int64_t q[NQ];
-  int st[NQ];
-  const uint16_t* pat[NQ];
-  int i[NQ];
-  int64_t first[NQ], last[NQ];
-  // per walk (w = 2*slot + side)
-  bool walking[NW];
-  int64_t base[NW];
-  uint32_t code[NW], idx[NW], nodei[NW], node_base[NW];
-  int rem[NW];
-#pragma unroll
-  for (int s = 0; s < NQ; s++) {
-    q[s] = tid + int64_t(s) * T;
-    st[s] = ST_QUERY;
-    pat[s] = nullptr;
-    i[s] = 0;
-    first[s] = 0;
-    last[s] = -1;
-  }
-#pragma unroll
-  for (int w = 0; w < NW; w++) {
-    walking[w] = false;
-    base[w] = 0;
-    code[w] = idx[w] = nodei[w] = node_base[w] = 0;
-    rem[w] = 0;
-  }
-
-  for (;;) {
-    // ---- transitions (cheap, divergent): make every live slot either walking or finished
-    bool any_live = false;
-#pragma unroll
-    for (int s = 0; s < NQ; s++) {
-      if (st[s] == ST_QUERY) {
-        if (q[s] >= npats) {
-          st[s] = ST_DONE;
-        } else {
-          const int len = plen[q[s]];
-          pat[s] = pats + starts[q[s]];
-          st[s] = ST_STEP;
-          if (len == 0) {  // server.c:782-808
-            first[s] = 0;
-            last[s] = ix.total_length - 1;
-            i[s] = 0;
-          } else {
-            i[s] = len - 1;
-            const uint32_t c0 = pat[s][i[s]];
-            if (c0 >= uint32_t(kAlphaSize)) {
-              atomicOr(err_flag, 1);
-              first[s] = 0;
-              last[s] = -1;
-            } else {
-              first[s] = ix.C[c0];       // server.c:795-829
-              last[s] = ix.C[c0 + 1] - 1;
-            }
-          }
-        }
-      }
-      if (st[s] == ST_STEP) {
-        if (first[s] > last[s] || i[s] == 0) {  // server.c:832
-          first_out[q[s]] = last_out ? first[s] : last[s] - first[s] + 1;
-          if (last_out) last_out[q[s]] = last[s];
-          q[s] += int64_t(NQ) * T;
-          st[s] = ST_QUERY;  // refilled at the top of the next iteration
-        } else {
-          const uint32_t ch = pat[s][i[s] - 1];
-          if (ch >= uint32_t(kAlphaSize)) {
-            atomicOr(err_flag, 1);
-            first[s] = 0;
-            last[s] = -1;
-          } else {
-            // both rows of the step: first-1 (skipped when first == 0: only C[ch], server.c:838-843) and last
-            uint32_t ia = 1, ib;
-            const int64_t ga = first[s] > 0 ? bucket_of(ix, first[s] - 1, &ia) : 0;
-            const int64_t gbk = bucket_of(ix, last[s], &ib);
-            const OccEntry ea = ix.occ[ga * kAlphaSize + ch];
-            const OccEntry eb = ix.occ[gbk * kAlphaSize + ch];
-            const int wa = 2 * s, wb = 2 * s + 1;
-            if (first[s] == 0) {
-              base[wa] = ix.C[ch];
-              idx[wa] = 0;
-              walking[wa] = false;
-            } else {
-              base[wa] = ea.base;
-              idx[wa] = ea.code ? ia : 0;   // absent character: Occ adds 0 (index.c:2080-2089)
-              walking[wa] = ea.code != 0;
-              code[wa] = ea.code;
-              rem[wa] = 31 - __clz(int(ea.code | 1u));
-              node_base[wa] = ea.node_base;
-              nodei[wa] = ea.node_base;
-            }
-            base[wb] = eb.base;
-            idx[wb] = eb.code ? ib : 0;
-            walking[wb] = eb.code != 0;
-            code[wb] = eb.code;
-            rem[wb] = 31 - __clz(int(eb.code | 1u));
-            node_base[wb] = eb.node_base;
-            nodei[wb] = eb.node_base;
-            st[s] = ST_WALK;
-          }
-        }
-      }
-      if (st[s] == ST_WALK && !walking[2 * s] && !walking[2 * s + 1]) {
-        // first = C+Occ(ch, first-1); last = C+Occ(ch, last) - 1 (server.c:909-936)
-        first[s] = base[2 * s] + int64_t(idx[2 * s]);
-        last[s] = base[2 * s + 1] + int64_t(idx[2 * s + 1]) - 1;
-        i[s]--;
-        st[s] = ST_STEP;
-      }
-      any_live = any_live || st[s] != ST_DONE;
-    }
-    if (!any_live) break;
-
-    // ---- one wavelet level for every active walk, loads issued stage by stage
-    LaneNode nd[NW];
-    RankJob job[NW];
-    uint64_t words[NW][kSegmentWords];
-#pragma unroll
-    for (int w = 0; w < NW; w++)
-      if (walking[w]) nd[w] = ix.lnodes[nodei[w]];
-#pragma unroll
-    for (int w = 0; w < NW; w++)
-      if (walking[w]) rank_locate_segment(ix, nd[w].bs, idx[w], job[w]);
-#pragma unroll
-    for (int w = 0; w < NW; w++)
-      if (walking[w]) rank_load_segment(ix, job[w], words[w]);
-#pragma unroll
-    for (int w = 0; w < NW; w++) {
-      if (walking[w]) {  // one level of wtree_occs (src/main/wtree.c:1081-1115)
-        const RankResult r = rank_finish(ix, job[w], words[w]);
-        rem[w]--;
-        const uint32_t b = (code[w] >> rem[w]) & 1u;
-        idx[w] -= b ? r.o0 : r.o1;
-        const int child = b ? nd[w].child[1] : nd[w].child[0];
-        if (idx[w] == 0 || rem[w] == 0 || child < 0) walking[w] = false;
-        else nodei[w] = node_base[w] + uint32_t(child);
-      }
-    }
-  }
-}
-
-enum : int { LT_ITEM = 0, LT_ROW = 1, LT_WT = 2, LT_MARK = 3 };
-
-// locate walk (do_back_query / do_context_query), flattened: one rank per loop iteration
-inline __global__ __launch_bounds__(256) void locate_kernel_flat(const DevIndex ix, const int64_t npats,
-                                                          const int64_t* __restrict__ first,
-                                                          const int64_t* __restrict__ out_starts, const int64_t total,
-                                                          int64_t* __restrict__ offsets) {
-  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
-  int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  int st = LT_ITEM;
-  int64_t row = 0, steps = 0, gb = 0;
-  uint32_t idx = 0, node_base = 0, nodei = 0, seq_base = 0, n_in_use = 0, mch = 0;
-  LaneBseq mbs{0, 0, 0};
-  uint64_t marr = 0;
-
-  for (;;) {
-    if (st == LT_ITEM) {
-      if (item >= total) break;
-      int64_t lo = 0, hi = npats;  // largest q with out_starts[q] <= item
-      while (hi - lo > 1) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (out_starts[mid] <= item) lo = mid; else hi = mid;
-      }
-      row = first[lo] + (item - out_starts[lo]);
-      steps = 0;
-      st = LT_ROW;
-    }
-    if (st == LT_ROW) {
-      if (row < 0) {  // walked past a document start without meeting a mark
-        offsets[item] = -1;
-        item += stride;
-        st = LT_ITEM;
-        continue;
-      }
-      uint32_t idx1;
-      gb = bucket_of(ix, row, &idx1);
-      const DevBucket bk = ix.buckets[gb];
-      idx = idx1;
-      node_base = bk.node_base;
-      nodei = node_base;
-      seq_base = bk.seq_base;
-      n_in_use = bk.n_in_use;
-      st = LT_WT;
-    }
-    if (st == LT_WT) {  // one level of wtree_rank (src/main/wtree.c:1117-1148)
-      const LaneNode nd = ix.lnodes[nodei];
-      const RankResult r = bseq_rank_lane(ix, nd.bs, idx);
-      idx -= r.bit ? r.o0 : r.o1;
-      const int child = r.bit ? nd.child[1] : nd.child[0];
-      if (child >= 0) {
-        nodei = node_base + uint32_t(child);
-      } else {
-        const uint32_t seq = uint32_t(-1 - child);
-        if (seq >= n_in_use) {  // corrupt data guard
-          row = -1;
-          st = LT_ROW;
-        } else {
-          const LaneSeq sq = ix.lseqs[seq_base + seq];
-          mbs = sq.mark_table;
-          marr = sq.mark_array;
-          mch = sq.ch;
-          st = LT_MARK;
-        }
-      }
-    } else if (st == LT_MARK) {  // mark table rank at Occ-in-bucket(L[row], row) (index.c:2102-2140)
-      const RankResult m = bseq_rank_lane(ix, mbs, idx);
-      if (m.bit) {
-        const uint64_t rec = mark_rec(ix, m.o1);
-        offsets[item] = int64_t(read_bits_ptr(wrap_ptr(ix.image, marr), rec * uint64_t(ix.text_size_bits), ix.text_size_bits)) + steps;
-        item += stride;
-        st = LT_ITEM;
-      } else if (mch <= uint32_t(kSEOF)) {
-        row = -1;  // server.c:2336-2342
-        st = LT_ROW;
-      } else {
-        row = ix.occ[gb * kAlphaSize + mch].base + int64_t(idx) - 1;  // LF (server.c:2279-2282)
-        steps++;
-        if (steps > int64_t(ix.walk_limit)) row = -1;   // inconsistent index: give up on this row (-1)
-        st = LT_ROW;
-      }
-    }
-  }
-}
-
-
 // =====================================================================================
 // LF^-1 (do_forward_query, src/main/server.c:2424-2565): not needed for exact locate results (the
 // backward walk always meets a mark first) but part of the reference's leaf interface

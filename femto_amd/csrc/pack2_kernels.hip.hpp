@@ -164,91 +164,6 @@ __device__ __forceinline__ void p2_search_step(const DevIndex& ix, int j, uint32
   last = nl - 1;
 }
 
-inline __global__ __launch_bounds__(256) void ktab_build_kernel2(const DevIndex ix, const int bits, const int syms, longlong2* __restrict__ tab) {
-  const uint64_t f = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (f >= (uint64_t(1) << (bits * syms))) return;
-  int64_t first = 0, last = ix.total_length - 1;
-  int j = 0;
-  for (; j < syms; j++) {
-    const uint32_t c = uint32_t(f >> (bits * (syms - 1 - j))) & ((1u << bits) - 1u);
-    if (c == 0 || int(c) > ix.p2_sigma) break;
-    p2_search_step(ix, j, c - 1, first, last);
-    if (first > last) { j++; break; }
-  }
-  tab[f] = make_longlong2(first, int64_t(uint64_t(last + 1) | (uint64_t(j) << 48)));
-}
-
-// do_string_query (src/main/server.c:713-946), one lane per pattern; see count_kernel_pack for the key / table /
-// pair-store conventions.  Symbols the key does not hold are read from the pattern four at a time (aligned words).
-template <bool kKeys>
-inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void count_kernel_pack2(const DevIndex ix, const int64_t npats, const int32_t* __restrict__ plen,
-                                                          const uint16_t* __restrict__ pats, const int64_t* __restrict__ starts,
-                                                          int64_t* __restrict__ first_out, int64_t* __restrict__ last_out,
-                                                          int* __restrict__ err_flag, const uint32_t* __restrict__ perm,
-                                                          const uint64_t* __restrict__ keys, const int bits, const int nsym,
-                                                          longlong2* __restrict__ pair_out) {
-  const int64_t slot = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (slot >= npats) return;
-  const int64_t q = perm ? int64_t(perm[slot]) : slot;
-  const uint64_t key = kKeys ? keys[slot] : 0;
-  const bool whole = kKeys && (key & 1u);
-  const int len = whole ? nsym : plen[q];
-  const uint16_t* pat = whole ? pats : pats + starts[q];
-  int64_t first = 0, last = ix.total_length - 1;
-  int j = 0;
-  if (kKeys && ix.ktab) {
-    const longlong2 e = reinterpret_cast<const longlong2*>(ix.ktab)[key >> (64 - ix.ktab_bits)];
-    trace_touch(ix, kTraceKtab1, (key >> (64 - ix.ktab_bits)) >> 3);
-    first = e.x;
-    last = int64_t(uint64_t(e.y) & kKtabLastMask) - 1;
-    j = int(uint64_t(e.y) >> 48);
-    if (first > last) j = len;
-  }
-  uint64_t word = 0;           // the aligned 8-byte word of the pattern that holds symbol index `word_at`..+3
-  uintptr_t word_addr = 0;
-  for (; j < len; j++) {
-    if (kKeys && !whole && ix.txt && first == last && j > 0 && len - j >= ix.tail_min) {
-      tail_append(ix, slot, j, first);   // one row left, a long tail to go: compare it with the text instead
-      return;
-    }
-    uint32_t code = 0;
-    if (kKeys && j < nsym) code = uint32_t(key >> (64 - bits * (j + 1))) & ((1u << bits) - 1u);
-    if (code != 0) {
-      code -= 1;
-    } else {
-      if (whole) break;
-      const uintptr_t sa = reinterpret_cast<uintptr_t>(pat + (len - 1 - j));
-      const uintptr_t wa = sa & ~uintptr_t(7);
-      if (wa != word_addr) {
-        word = *reinterpret_cast<const uint64_t*>(wa);
-        word_addr = wa;
-      }
-      const uint32_t ch = uint32_t(word >> (8 * (sa - wa))) & 0xffffu;
-      if (ch >= uint32_t(kAlphaSize)) {
-        atomicOr(err_flag, 1);
-        first = 0;
-        last = -1;
-        break;
-      }
-      code = ix.p2_code[ch];
-      if (code > 255u) {  // the character does not occur in the text: Occ == 0 (index.c:2080-2089)
-        first = ix.C[ch];
-        last = first - 1;
-        break;
-      }
-    }
-    p2_search_step(ix, j, code, first, last);
-    if (first > last) break;
-  }
-  if (pair_out) {
-    pair_out[q] = make_longlong2(first, last);
-    return;
-  }
-  first_out[q] = first;
-  if (last_out) last_out[q] = last;
-  else first_out[q] = last - first + 1;
-}
-
 // what an LF step / leaf request needs from a row: its character, C+Occ of it, the mark test
 struct P2Step {
   uint32_t code;

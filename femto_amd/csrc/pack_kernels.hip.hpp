@@ -113,26 +113,8 @@ __device__ __forceinline__ void pack_search_step(const DevIndex& ix, const uint3
   last = nl - 1;
 }
 
-// The first steps of every search are shared by huge numbers of patterns (a batch of 10 M 20-mers over ACGT holds
-// every 7-mer 600 times), so they are precomputed: ktab[f] for f = the top ktab_syms key fields (dense codes, last
-// pattern symbol first) holds the range after searching the leading non-empty fields of f -- exactly the values the
-// stepping loop would hold at that point, including an early death -- and how many fields that were:
-//   x = first,  y = (last + 1) | fields_consumed << 48.
+// level-table entries (direct_kernels.hip.hpp): x = first, y = (last + 1) | level << 48
 constexpr uint64_t kKtabLastMask = (uint64_t(1) << 48) - 1;
-
-inline __global__ __launch_bounds__(256) void ktab_build_kernel(const DevIndex ix, const int bits, const int syms, longlong2* __restrict__ tab) {
-  const uint64_t f = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (f >= (uint64_t(1) << (bits * syms))) return;
-  int64_t first = 0, last = ix.total_length - 1;
-  int j = 0;
-  for (; j < syms; j++) {
-    const uint32_t c = uint32_t(f >> (bits * (syms - 1 - j))) & ((1u << bits) - 1u);
-    if (c == 0 || int(c) > ix.pack_sigma) break;
-    pack_search_step(ix, ix.pack, j, c - 1, first, last);
-    if (first > last) { j++; break; }
-  }
-  tab[f] = make_longlong2(first, int64_t(uint64_t(last + 1) | (uint64_t(j) << 48)));
-}
 
 // hand a pattern whose range is down to one row, with many symbols to go, over to count_tail_kernel
 // (text_kernels.hip.hpp): one atomic per wavefront, entries {slot, symbols done, row}
@@ -146,114 +128,6 @@ __device__ __forceinline__ void tail_append(const DevIndex& ix, int64_t slot, in
   const int at = base + __popcll(m & ((1ull << lane) - 1ull));
   int4* dst = reinterpret_cast<int4*>(ix.tail_items) + at;
   *dst = make_int4(int(uint32_t(slot)), done, int(uint32_t(uint64_t(row))), int(uint32_t(uint64_t(row) >> 32)));
-}
-
-// do_string_query (src/main/server.c:713-946): one lane per pattern, one line per Occ.
-// kKeys: the batch was suffix-sorted (query_sort.hip) and keys[slot] holds the dense codes (1 + pack code, 0 = none)
-// of the pattern's last `nsym` symbols, last symbol in the top field, and in bit 0 "the key is the whole pattern".
-// The symbols are then taken from the key -- one coalesced 8-byte read per pattern -- instead of 2-byte reads
-// scattered over the batch (a 128-byte memory line per symbol once the batch is processed out of order); plen /
-// starts / the pattern are only touched for patterns the key does not describe completely.
-template <bool kKeys>
-inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void count_kernel_pack(const DevIndex ix, const int64_t npats, const int32_t* __restrict__ plen,
-                                                         const uint16_t* __restrict__ pats, const int64_t* __restrict__ starts,
-                                                         int64_t* __restrict__ first_out, int64_t* __restrict__ last_out,
-                                                         int* __restrict__ err_flag, const uint32_t* __restrict__ perm,
-                                                         const uint64_t* __restrict__ keys, const int bits, const int nsym,
-                                                         longlong2* __restrict__ pair_out) {
-  const int64_t slot = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (slot >= npats) return;
-  const int64_t q = perm ? int64_t(perm[slot]) : slot;
-  const uint64_t key = kKeys ? keys[slot] : 0;
-  const bool whole = kKeys && (key & 1u);
-  const int len = whole ? nsym : plen[q];   // whole: the first empty field ends the pattern
-  const uint16_t* pat = whole ? pats : pats + starts[q];
-  const uint32_t* __restrict__ pack = ix.pack;
-  int64_t first = 0, last = ix.total_length - 1;
-  int j = 0;
-  if (kKeys && ix.ktab) {
-    const longlong2 e = reinterpret_cast<const longlong2*>(ix.ktab)[key >> (64 - ix.ktab_bits)];
-    trace_touch(ix, kTraceKtab1, (key >> (64 - ix.ktab_bits)) >> 3);
-    first = e.x;
-    last = int64_t(uint64_t(e.y) & kKtabLastMask) - 1;
-    j = int(uint64_t(e.y) >> 48);   // fields consumed; a pattern that ends (or leaves the alphabet) there goes on below
-    if (first > last) j = len;
-  }
-  uint64_t word = 0;           // aligned 8-byte word of the pattern holding the symbol being read (4 symbols per load:
-  uintptr_t word_addr = 0;     // reads longer than a key -- 100-150 bp -- would otherwise cost a memory line per symbol)
-  for (; j < len; j++) {  // j-th symbol from the end
-    if (kKeys && !whole && ix.txt && first == last && j > 0 && len - j >= ix.tail_min) {
-      tail_append(ix, slot, j, first);   // one row left, a long tail to go: compare it with the text instead
-      return;
-    }
-    uint32_t code = 0;
-    if (kKeys && j < nsym) code = uint32_t(key >> (64 - bits * (j + 1))) & ((1u << bits) - 1u);
-    if (code != 0) {
-      code -= 1;
-    } else {
-      if (whole) break;  // pattern exhausted
-      // not covered by the key, or a character outside the indexed alphabet: read it
-      const uintptr_t sa = reinterpret_cast<uintptr_t>(pat + (len - 1 - j));
-      const uintptr_t wa = sa & ~uintptr_t(7);
-      if (wa != word_addr) {
-        word = *reinterpret_cast<const uint64_t*>(wa);
-        word_addr = wa;
-      }
-      const uint32_t ch = uint32_t(word >> (8 * (sa - wa))) & 0xffffu;
-      if (ch >= uint32_t(kAlphaSize)) {
-        atomicOr(err_flag, 1);
-        first = 0;
-        last = -1;
-        break;
-      }
-      code = ix.pack_code[ch];
-      if (code > 7u) {  // the character does not occur in the text: Occ == 0 (index.c:2080-2089)
-        first = ix.C[ch];
-        last = first - 1;
-        break;
-      }
-    }
-    pack_search_step(ix, pack, j, code, first, last);
-    if (first > last) break;
-  }
-  if (pair_out) {  // sorted batch: ONE scattered 16-byte store per pattern; split_pairs_kernel restores the two arrays
-    pair_out[q] = make_longlong2(first, last);
-    return;
-  }
-  first_out[q] = first;
-  if (last_out) last_out[q] = last;
-  else first_out[q] = last - first + 1;
-}
-
-// split + the locate clamp of do_locate_query (src/main/server.c:4405-4415, note `last-first > max_occs`) in one pass
-inline __global__ __launch_bounds__(256) void split_clamp_kernel(const int64_t n, const longlong2* __restrict__ pairs, int64_t* __restrict__ first_out,
-                                                          int64_t* __restrict__ last_out, const int max_occs, int32_t* __restrict__ noccs,
-                                                          int64_t* __restrict__ noccs64) {
-  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const longlong2 p = pairs[i];
-  first_out[i] = p.x;
-  last_out[i] = p.y;
-  int64_t c;
-  if (p.x > p.y) c = 0;
-  else if (p.y - p.x > int64_t(max_occs)) c = max_occs;
-  else c = p.y - p.x + 1;
-  noccs[i] = int32_t(c);
-  noccs64[i] = c;
-}
-
-// (first,last) pairs -> the API's separate arrays (coalesced); last_out == NULL: first_out receives the counts
-inline __global__ __launch_bounds__(256) void split_pairs_kernel(const int64_t n, const longlong2* __restrict__ pairs, int64_t* __restrict__ first_out,
-                                                          int64_t* __restrict__ last_out) {
-  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const longlong2 p = pairs[i];
-  if (last_out) {
-    first_out[i] = p.x;
-    last_out[i] = p.y;
-  } else {
-    first_out[i] = p.y - p.x + 1;
-  }
 }
 
 struct PackLine { uint32_t w[kPackLineWords]; };

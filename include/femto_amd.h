@@ -306,32 +306,29 @@ int femto_amd_pack_counts_device(femto_amd_index_t* ix, int64_t npats, const int
                                  uint8_t* d_counts8, int64_t* d_big, int64_t big_capacity, int64_t* d_big_n, void* stream);
 
 /* ---- kernel family ---------------------------------------------------------------------------- */
-/* Five kernel families, all bit-exact; the default at open is the fastest that applies (mode 3 for <= 8 distinct
- * characters, mode 4 for <= 256, else mode 1); FEMTO_AMD_RANK_MODE=pack|pack2|lane|flat|raw overrides it.
- * mode 1: one LANE per query on femto's own wavelet tree; a rank reads one 128-byte line per segment (segment + the
- * counts before it) from tables derived at load time (RLE segments also a 64-byte skip table).
- * mode 2: the same per-lane rank inside one flat loop on a persistent grid (one wavelet level per
- * iteration, lanes refill with the next query).  mode 0: one WAVEFRONT per query walking femto's own
- * A0/A1/AP group tables and varbyte S sums with __ballot/ds_bpermute (no derived rank tables). */
+/* Four kernel families, all bit-exact; the default at open is the fastest that applies (mode 3 for <= 8 distinct
+ * characters, mode 4 for <= 256, else mode 1); FEMTO_AMD_RANK_MODE=pack|pack2|lane|raw overrides it.
+ * mode 3 ("pack"): for indexes with at most 8 distinct characters (DNA) the loader derives, on the GPU, one self-contained
+ *   128-byte line per 160 rows -- three bit planes of the dense character code, a "row is marked" plane, and C[ch]+Occ
+ *   before the line for each character -- so that an Occ and a whole locate step each read ONE memory line
+ *   (femto_amd/csrc/pack_kernels.hip.hpp).
+ * mode 4 ("pack2"): 9..256 distinct characters -- a two-level 16-ary decomposition of the dense character code, one
+ *   128-byte line per level (pack2_kernels.hip.hpp), plus per-character rank lines for the search steps
+ *   (ind_kernels.hip.hpp) and hashed context tables of the text's H-grams (ctx_kernels.hip.hpp) when HBM allows.
+ *   Modes 3 and 4 process a batch in the CALLER's order, one lane per pattern, the first steps from a level table
+ *   precomputed at open (direct_kernels.hip.hpp); they also derive the full suffix array / inverse suffix array / text
+ *   (HBM allowing) so that locate is one read and a long pattern's tail is compared with the text.
+ * mode 1 ("lane"): one LANE per query on femto's own wavelet tree; a rank reads one 128-byte line per segment (segment +
+ *   the counts before it) from tables derived at load time.  Alphabets of more than 256 characters, range-split indexes.
+ * mode 0 ("raw"): one WAVEFRONT per query walking femto's own A0/A1/AP group tables and varbyte S sums with
+ *   __ballot / ds_bpermute, no derived tables at all -- BASELINE.json north_star's sketch, kept as the documented
+ *   reference kernel (5 % of the HBM roofline) and for indexes whose segments the derived tables cannot
+ *   describe.
+ * (Rounds 1-2 also carried a persistent-grid variant of mode 1 and suffix-sorted variants of modes 3/4; both measured
+ * slower than what replaced them and were removed.) */
 int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode);
-/* mode 3 ("pack", the default when it applies): for indexes with at most 8 distinct characters (DNA) the
- * loader derives, on the GPU, one self-contained 128-byte line per 160 rows -- three bit planes of the dense
- * character code, a "row is marked" plane, and C[ch]+Occ before the line for each character -- plus the
- * marked rows' offsets in row order, so that an Occ and a whole locate step each read ONE memory line instead of
- * 2-5 (femto_amd/csrc/pack_kernels.hip.hpp).  Batches large enough to be suffix-sorted are searched from their
- * sort keys (dense codes, no scattered pattern reads), and the first ktab_syms steps of every search -- shared by
- * huge numbers of patterns -- come from a table precomputed at open (FEMTO_AMD_KTAB=0 disables it).  Same results,
- * bit for bit.  FEMTO_AMD_PACK=0 skips the derivation. */
-/* mode 4 ("pack2", the default for 9..256 distinct characters): the same idea for byte alphabets -- a two-level
- * 16-ary decomposition of the dense character code, one 128-byte line per level (femto_amd/csrc/pack2_kernels.hip.hpp):
- * an Occ or a locate step reads TWO lines and decodes no Elias-gamma runs.  FEMTO_AMD_PACK2=0 skips it, =1 also builds
- * it for small alphabets.  *available: bit 0 = mode 3 lines exist, bit 1 = mode 4 lines exist.
- * Both modes also derive: marks every FEMTO_AMD_MARK_EVERY-th text position (default 5; a locate walk then ends within
- * 4 steps -- leaf requests still answer from femto's own marks), and the text + a sampled inverse suffix array
- * (FEMTO_AMD_TEXT=0 skips them) against which the tail of a long pattern is compared once its range is one row. */
-/* Runtime switches of an open handle: "direct" (default 1: modes 3/4 process a batch in the caller's order with the
- * level table of femto_amd/csrc/direct_kernels.hip.hpp; 0: the suffix-sorted kernels of round 1), "sort" (default 1:
- * suffix-order batches for the paths that use them).  Results are identical either way. */
+/* Runtime switches of an open handle: "sort" (default 1: mode 1 orders large batches by pattern suffix),
+ * "regexp_max_iterations" (default 10^6 = MAX_REGEXP_ITERATIONS), "regexp_stack_cap" (default 2^22). */
 int femto_amd_set_option(femto_amd_index_t* ix, const char* name, int value);
 int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* bytes, double* build_ms, int* ktab_syms);
 int femto_amd_get_rank_mode(const femto_amd_index_t* ix);

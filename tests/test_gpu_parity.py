@@ -24,7 +24,7 @@ def gpu_ok():
 # 3: packed small-alphabet lines (default when the index has <= 8 characters); 4: two-level 16-ary lines (default for
 # 9..256 characters); 1: lane per query on femto's wavelet tree (default otherwise); 2: flattened persistent lanes;
 # 0: wavefront-per-query raw walk
-MODES = [3, 4, 1, 2, 0]
+MODES = [3, 4, 1, 0]
 
 
 def _torchrun(nproc, script_and_args, env, cwd=None, attempts=2):

@@ -65,7 +65,7 @@ def one(seed, root):
     rows = rng.integers(0, ix.info.total_length, 2000).astype(np.int64)
     want = [o.block_request(int(r), 7) for r in rows]
     info = ix.pack_info()
-    modes = [m for m in (3, 4, 1, 2, 0) if not (m == 3 and not info["available"]) and not (m == 4 and not info["available2"])]
+    modes = [m for m in (3, 4, 1, 0) if not (m == 3 and not info["available"]) and not (m == 4 and not info["available2"])]
     for mode in modes:
         ix.set_rank_mode(mode)
         f, l_ = ix.count_flat(plen, flat, starts)
