@@ -526,6 +526,49 @@ def main():
                                         "located_rows": hb.total, "count_kernel_ms": ix.kernel_time("count")[0],
                                         "locate_kernel_ms": ix.kernel_time("locate")[0]}}
         del hb
+        # The headline batch once more as 64-bit KEYS (femto_amd_pack_keys_device: 3 bits per DNA symbol, packed once, untimed --
+        # the form a caller that keeps its patterns in HBM would hold them in) with the ranges returned as int32 pairs:
+        # 28 instead of 80 bytes streamed per pattern around the same search.  Same results, checked below; an `extra`
+        # line, never the headline (whose input is the reference's own alpha_t symbols).
+        try:
+            d_keys = torch.empty(npats, dtype=torch.int64, device=dev)
+            d_bad = torch.zeros(1, dtype=torch.int64, device=dev)
+            ix.pack_keys_device(npats, batch.d_plen.data_ptr(), batch.d_flat.data_ptr(), batch.d_starts.data_ptr(), d_keys.data_ptr(),
+                                d_bad.data_ptr(), stream)
+            torch.cuda.synchronize()
+            assert int(d_bad.item()) == 0, "a pattern of the batch does not fit a key"
+            k_r32 = torch.empty(2 * npats, dtype=torch.int32, device=dev)
+            k_noccs = torch.empty(npats, dtype=torch.int32, device=dev)
+            k_ost = torch.empty(npats + 1, dtype=torch.int64, device=dev)
+            k_offs = torch.empty(batch.offsets.numel(), dtype=torch.int64, device=dev)
+            k_total = torch.zeros(2, dtype=torch.int64, device=dev)
+
+            def kstep():
+                ix.locate_keys_device(npats, d_keys.data_ptr(), args.max_occs, k_r32.data_ptr(), 0, 0, k_noccs.data_ptr(), k_ost.data_ptr(),
+                                      k_offs.data_ptr(), k_offs.numel(), k_total.data_ptr(), stream)
+            for _ in range(3):
+                kstep()
+            torch.cuda.synchronize()
+            ix.kernel_time_reset()
+            ix.kernel_time_enable(True)
+            ksteps = max(3, args.steps)
+            t0 = time.perf_counter()
+            for _ in range(ksteps):
+                kstep()
+            torch.cuda.synchronize()
+            ke = time.perf_counter() - t0
+            ix.kernel_time_enable(False)
+            pairs = k_r32.cpu().numpy().reshape(npats, 2)
+            same = bool(np.array_equal(pairs[:, 0], first) and np.array_equal(pairs[:, 1], last) and np.array_equal(k_noccs.cpu().numpy(), g_noccs)
+                        and np.array_equal(k_ost.cpu().numpy(), g_ost) and np.array_equal(k_offs[:batch.total].cpu().numpy(), g_offs))
+            assert same, "the key path's results differ from the symbol path's"
+            extra["compact_keys_count_locate"] = {
+                "what": "the headline batch as 64-bit keys in, int32 (first,last) pairs + row counts + located offsets out (femto_amd_locate_keys_device)",
+                "value": npats * ksteps / ke, "unit": "patterns/s", "ms_per_step": 1e3 * ke / ksteps, "steps": ksteps,
+                "count_kernel_ms": ix.kernel_time("count")[0], "streamed_bytes_per_pattern": 28, "equal_to_symbol_path": same}
+            del d_keys, k_r32, k_noccs, k_ost, k_offs
+        except Exception as ex:      # noqa: BLE001
+            extra["compact_keys_count_locate"] = {"error": repr(ex)}
         # PCIe-inclusive rate of the host-pointer entry point (patterns and results in pageable host memory):
         # never the headline value, reported for the drop-in caller's benefit
         hf_ = np.zeros(npats, dtype=np.int64) + 1      # touched: the call is timed, not the first-touch page faults

@@ -137,6 +137,9 @@ def lib():
         L.femto_amd_regexp_search.argtypes = [vp, vp, i64, i64, vp, vp, vp, C.POINTER(i64)]
         L.femto_amd_regexp_search_approx.argtypes = [vp, vp, i64, i32, i32, i32, i32, i64, vp, vp, vp, vp, C.POINTER(i64)]
         L.femto_amd_regexp_match.argtypes = [vp, i64, vp, i64]
+        L.femto_amd_key_format.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), vp]
+        L.femto_amd_pack_keys_device.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
+        L.femto_amd_locate_keys_device.argtypes = [vp, i64, vp, i32, vp, vp, vp, vp, vp, vp, i64, vp, vp]
         L.femto_amd_regexp_compile.argtypes = [vp, i64, i32, i32, i32, i32, C.POINTER(vp)]
         L.femto_amd_regexp_nfa.argtypes = [vp]
         L.femto_amd_regexp_nfa.restype = C.POINTER(NfaStruct)
@@ -421,6 +424,23 @@ class Index:
 
     def comm_gather(self, d_send, d_recv, bytes_per_rank, root=0, stream=0):
         _check(lib().femto_amd_comm_gather(self._h, d_send, d_recv or None, int(bytes_per_rank), int(root), stream or None))
+
+    def key_format(self):
+        """(bits per field, symbols per key, field_of_alpha uint8[261]) of femto_amd_key_format"""
+        bits, syms = C.c_int32(), C.c_int32()
+        table = np.zeros(261, dtype=np.uint8)
+        _check(lib().femto_amd_key_format(self._h, C.byref(bits), C.byref(syms), _ptr(table)))
+        return bits.value, syms.value, table
+
+    def pack_keys_device(self, npats, d_plen, d_pats, d_starts, d_keys, d_bad, stream=0):
+        _check(lib().femto_amd_pack_keys_device(self._h, int(npats), d_plen, d_pats, d_starts, d_keys, d_bad, stream or None))
+
+    def locate_keys_device(self, npats, d_keys, max_occs, d_ranges32, d_first, d_last, d_noccs, d_out_starts, d_offsets, capacity, d_total,
+                           stream=0):
+        """femto_amd_locate_keys_device on raw device addresses (0 / None = NULL)"""
+        _check(lib().femto_amd_locate_keys_device(self._h, int(npats), d_keys, int(max_occs), d_ranges32 or None, d_first or None,
+                                                  d_last or None, d_noccs or None, d_out_starts or None, d_offsets or None,
+                                                  int(capacity), d_total or None, stream or None))
 
     def nfa_search_batch(self, nfas, max_results=1 << 20):
         """femto_amd_nfa_search_batch: do_regexp_query (src/main/server.c:1656) for a batch of automata on the GPU.

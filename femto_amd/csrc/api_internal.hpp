@@ -127,6 +127,10 @@ struct Scratch {
   int* err = nullptr;           // where kernels raise "symbol >= ALPHA_SIZE": d_flags (host-pointer calls check and clear it) or,
                                 // for enqueue-only calls, d_flags + 3 (nobody reads it: such a pattern just has the empty range)
   int64_t* d_total = nullptr;   // [0] rows to locate, [1] 1 = more rows than the caller's buffer holds
+  int64_t* total_user = nullptr;   // the caller's copy of d_total (enqueue-only locate): written by plan_rows_kernel
+  int64_t bsums_nblocks = -1;      // the batch size `bsums` is laid out for (PlanSums, direct_kernels.hip.hpp)
+  int bsums_parity = 0;            // which set of group sums the current launch accumulates into
+  bool bsums_clean = false;        // the other set has been cleared by plan_rows_kernel
   hipStream_t stream = nullptr; // host-pointer calls launch here (non-blocking stream: calls of different threads overlap)
   hipEvent_t done = nullptr;
   bool busy = false, in_flight = false;

@@ -10,10 +10,12 @@
 //                         the first steps come from the LEVEL TABLE below; the remaining steps walk the packed lines;
 //                         (first,last) and the clamped row count are stored coalesced, and the block's row-count sum
 //                         goes to block_sums[] (do_locate_query's clamp, src/main/server.c:4405-4415, fused);
+//                         every block also adds its sum to its group-of-64's word (PlanSums::super, one atomic): there is
+//                         no scan kernel on the step's critical path;
 //   count_tail_kernel     (text_kernels.hip.hpp) long patterns whose range is one row: compared against the text;
-//   plan_scan_kernel      exclusive scan of the block sums (one workgroup), total -> device word;
-//   plan_rows_kernel      out_starts[] = block offset + in-block scan; the rows to locate are written where their
-//                         offsets will go (setup_locate_range, src/main/server.c:4047);
+//   plan_rows_kernel      block offset = the group sums before the block's group + the block sums before it inside the
+//                         group; out_starts[] = block offset + in-block scan; the rows to locate are written where their
+//                         offsets will go (setup_locate_range, src/main/server.c:4047); the last block publishes the total;
 //   locate_walk_kernel    persistent grid, reads the total from the device word: no host round trip inside a step.
 //
 // LEVEL TABLE (ktab2).  The first steps of a backward search depend only on the pattern's last symbols and are shared by
@@ -114,6 +116,49 @@ __device__ __forceinline__ int64_t block_sum_256(int64_t v, int64_t* s_w /* [4] 
   return s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t lo = uint32_t(__shfl_down(int(uint32_t(v)), d, 64)), hi = uint32_t(__shfl_down(int(uint32_t(v >> 32)), d, 64));
+    v += (uint64_t(hi) << 32) | lo;
+  }
+  return v;   // valid in lane 0
+}
+
+// The row counts of a count launch, summed per 256-pattern block, per group of 64 blocks (super) and per 64 groups
+// (super2).  Every block with rows adds its sum to its group's two words with device-scope atomics (64 / 4096 blocks per
+// word: no contention to speak of), so no scan kernel sits between the count and the row expansion; plan_rows_kernel
+// adds up at most 63 words of each level.  The words must be zero when the count kernel starts: the two (super, super2)
+// sets alternate between launches and plan_rows_kernel clears the set the NEXT launch will use.
+// (A "last block of the group adds the 64 sums up" scheme needs a __threadfence() per block, which on this part -- eight
+// XCDs, one L2 each -- writes the XCD's L2 back: the count kernel ran 5x slower, measured.)
+// acc == 0: the sums are not final when the count kernel ends (count_tail_kernel still adds to them) and
+// plan_super_kernel computes the group sums afterwards.
+struct PlanSums {
+  int64_t* sums;        // [nblocks]
+  int64_t* super;       // [ns = ceil(nblocks / 64)]
+  int64_t* super2;      // [ceil(ns / 64)]
+  int64_t* next_super;  // the other set: super and super2 contiguous, cleared by plan_rows_kernel
+  int64_t next_words;
+  int64_t nblocks;
+  int32_t acc;          // 1: the count kernel accumulates super / super2
+};
+__host__ __device__ inline int64_t plan_set_words(int64_t nblocks) {
+  const int64_t ns = (nblocks + 63) / 64;
+  return ((ns + (ns + 63) / 64 + 7) & ~int64_t(7)) + 8;
+}
+__host__ __device__ inline size_t plan_sums_bytes(int64_t nblocks) {
+  return size_t(((nblocks + 63) & ~int64_t(63)) + 2 * plan_set_words(nblocks)) * 8;
+}
+// `parity` selects the set this launch accumulates into
+__host__ __device__ inline PlanSums plan_sums_at(void* base, int64_t nblocks, bool fold, int parity) {
+  const int64_t ns = (nblocks + 63) / 64, w = plan_set_words(nblocks);
+  int64_t* sums = static_cast<int64_t*>(base);
+  int64_t* sets = sums + ((nblocks + 63) & ~int64_t(63));
+  int64_t* mine = sets + (parity & 1) * w;
+  return PlanSums{sums, mine, mine + ns, sets + ((parity & 1) ^ 1) * w, w, nblocks, fold ? 1 : 0};
+}
+
 // do_string_query (src/main/server.c:713-946), one lane per pattern in the caller's order.
 // kPlan: also do_locate_query's clamp (server.c:4405-4415): noccs[q] and the block's sum of them.
 // kDense: the full suffix array and the full inverse suffix array are resident: once the range is ONE row with a long
@@ -124,7 +169,7 @@ template <class P, bool kPlan, bool kDense>
 inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, P::kWaves))) void count_direct_kernel(
     const DevIndex ix, const int64_t npats, const int32_t* __restrict__ plen, const uint16_t* __restrict__ pats,
     const int64_t* __restrict__ starts, int64_t* __restrict__ first_out, int64_t* __restrict__ last_out, int* __restrict__ err_flag,
-    const int max_occs, int32_t* __restrict__ noccs, int64_t* __restrict__ block_sums) {
+    const int max_occs, int32_t* __restrict__ noccs, const PlanSums ps, int* __restrict__ big_flag) {
   __shared__ uint16_t s_code[264];
   __shared__ int64_t s_w[4];
   __shared__ uint32_t s_chunk[16 * 256];     // 64 bytes of pattern per lane (see symbol() below)
@@ -314,7 +359,14 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
   }
   if (kPlan) {
     const int64_t s = block_sum_256(nocc, s_w);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = s;
+    if (threadIdx.x == 0) {
+      ps.sums[blockIdx.x] = s;
+      if (ps.acc && s) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(&ps.super[blockIdx.x >> 6]), static_cast<unsigned long long>(s));
+        atomicAdd(reinterpret_cast<unsigned long long*>(&ps.super2[blockIdx.x >> 12]), static_cast<unsigned long long>(s));
+      }
+      if (blockIdx.x == 0 && big_flag) *big_flag = 0;      // plan_rows_kernel's "long ranges" flag
+    }
   }
 }
 
@@ -323,121 +375,106 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
 // of pattern) into 8 bytes instead of 2 bytes per symbol + 12 bytes of length / start, and the ranges come back as 32-bit
 // pairs when the index has fewer than 2^31 - 1 rows: 16 instead of 68 bytes per 20-mer over PCIe.  Same search, same
 // results; a chunk holding any pattern a key cannot describe (longer, or a character outside the text) travels as symbols.
-template <class P>
+// kPlan: also the clamped row counts and their block / group sums, as count_direct_kernel<.., kPlan = true> leaves them:
+// the device-pointer form (femto_amd_locate_keys_device) then runs plan_rows_kernel on 28 bytes per pattern all told.
+template <class P, bool kPlan>
 inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, P::kWaves))) void count_keys_kernel(
     const DevIndex ix, const int64_t npats, const uint64_t* __restrict__ keys, const int bits, const int nsym,
-    int2* __restrict__ out32, int64_t* __restrict__ first_out, int64_t* __restrict__ last_out) {
+    int2* __restrict__ out32, int64_t* __restrict__ first_out, int64_t* __restrict__ last_out, const int max_occs,
+    int32_t* __restrict__ noccs, const PlanSums ps, int* __restrict__ big_flag) {
+  __shared__ int64_t s_w[4];
+  const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  int64_t nocc = 0;
+  if (q < npats) {
+    const uint64_t key = keys[q];
+    const uint32_t fmask = (1u << bits) - 1u;
+    auto field = [&](int j) -> uint32_t { return uint32_t(key >> (64 - bits * (j + 1))) & fmask; };
+    int64_t first = 0, last = ix.total_length - 1;
+    int j = 0;
+    bool ended = false;
+    if (ix.ktab2) {
+      const int kmax = nsym < ix.kt2_syms ? nsym : ix.kt2_syms;
+      const uint32_t nstop = uint32_t(ix.kt2_nstop);
+      const int64_t t = ix.kt2_base;
+      int64_t pos = 0;
+      for (; j < kmax; j++) {
+        const uint32_t f = field(j);
+        if (f == 0) { ended = true; break; }
+        if (f - 1 < nstop) break;          // a character <= SEOF: not a table character, stepped below
+        pos = pos * t + 1 + int64_t(f - 1 - nstop);
+      }
+      ktab2_lookup<P>(ix, pos, j, first, last);
+      if (first > last) ended = true;
+    }
+    if (!ended)
+      for (; j < nsym; j++) {
+        const uint32_t f = field(j);
+        if (f == 0) break;
+        P::search_step(ix, j, f - 1, first, last);
+        if (first > last) break;
+      }
+    if (out32) {
+      out32[q] = make_int2(int(first), int(last));
+    } else {
+      first_out[q] = first;
+      last_out[q] = last;
+    }
+    if (kPlan) {
+      if (first > last) nocc = 0;
+      else if (last - first > int64_t(max_occs)) nocc = max_occs;      // server.c:4411 (">": see Appendix C of SURVEY.md)
+      else nocc = last - first + 1;
+      noccs[q] = int32_t(nocc);
+    }
+  }
+  if (kPlan) {
+    const int64_t s = block_sum_256(nocc, s_w);
+    if (threadIdx.x == 0) {
+      ps.sums[blockIdx.x] = s;
+      if (s) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(&ps.super[blockIdx.x >> 6]), static_cast<unsigned long long>(s));
+        atomicAdd(reinterpret_cast<unsigned long long*>(&ps.super2[blockIdx.x >> 12]), static_cast<unsigned long long>(s));
+      }
+      if (blockIdx.x == 0 && big_flag) *big_flag = 0;
+    }
+  }
+}
+
+// u16 symbols -> keys on the device (femto_amd_pack_keys_device): key 0 and *bad += 1 for a pattern a key cannot describe
+// (longer than nsym symbols, or a character that does not occur in the text -- its empty range has values of its own)
+inline __global__ __launch_bounds__(256) void pack_keys_kernel(const int64_t npats, const int32_t* __restrict__ plen, const uint16_t* __restrict__ pats,
+                                                        const int64_t* __restrict__ starts, const uint8_t* __restrict__ dense, const int bits,
+                                                        const int nsym, uint64_t* __restrict__ keys, unsigned long long* __restrict__ bad) {
   const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (q >= npats) return;
-  const uint64_t key = keys[q];
-  const uint32_t fmask = (1u << bits) - 1u;
-  auto field = [&](int j) -> uint32_t { return uint32_t(key >> (64 - bits * (j + 1))) & fmask; };
-  int64_t first = 0, last = ix.total_length - 1;
-  int j = 0;
-  bool ended = false;
-  if (ix.ktab2) {
-    const int kmax = nsym < ix.kt2_syms ? nsym : ix.kt2_syms;
-    const uint32_t nstop = uint32_t(ix.kt2_nstop);
-    const int64_t t = ix.kt2_base;
-    int64_t pos = 0;
-    for (; j < kmax; j++) {
-      const uint32_t f = field(j);
-      if (f == 0) { ended = true; break; }
-      if (f - 1 < nstop) break;          // a character <= SEOF: not a table character, stepped below
-      pos = pos * t + 1 + int64_t(f - 1 - nstop);
+  const int l = plen[q];
+  uint64_t key = 0;
+  bool ok = l >= 0 && l <= nsym;
+  if (ok && l) {
+    const uint16_t* pat = pats + starts[q];
+    for (int s = l - 1; s >= 0; s--) {       // last symbol first: it lands in the top field
+      const uint32_t ch = pat[s];
+      const uint32_t c = ch < uint32_t(kAlphaSize) ? dense[ch] : 0u;
+      if (c == 0) { ok = false; break; }
+      key = (key << bits) | c;
     }
-    ktab2_lookup<P>(ix, pos, j, first, last);
-    if (first > last) ended = true;
+    key = ok ? key << (64 - l * bits) : 0;
   }
-  if (!ended)
-    for (; j < nsym; j++) {
-      const uint32_t f = field(j);
-      if (f == 0) break;
-      P::search_step(ix, j, f - 1, first, last);
-      if (first > last) break;
-    }
-  if (out32) {
-    out32[q] = make_int2(int(first), int(last));
-  } else {
-    first_out[q] = first;
-    last_out[q] = last;
-  }
+  keys[q] = ok ? key : 0;
+  if (!ok) atomicAdd(bad, 1ull);
 }
 
-// Two-level scan of the n block sums (one 1024-thread workgroup; this kernel sits on the step's critical path).
-//   phase 1  super[s] = sum of sums[64 s .. 64 s + 64): one coalesced 512-byte read per wavefront and super block,
-//            eight super blocks in flight per wavefront;
-//   phase 2  exclusive scan of the super sums in place (611 for 10 M patterns: one pass, one element per thread).
-// The block sums themselves stay as they are: plan_rows_kernel adds the sums of the blocks before it inside its super
-// block (one more 512-byte read).  super[] lives behind sums[] (plan_super()).  total -> total_out[0]; total_out[1] = 1
-// when the total exceeds `capacity` rows (the rows beyond it are not located); *big_flag is cleared for plan_rows_kernel.
-// (Round 2's first version scanned all n sums in place, a thread per 16 consecutive sums: 42 us for 39 k sums.)
-__device__ __forceinline__ int64_t* plan_super(int64_t* sums, int64_t n) { return sums + ((n + 63) & ~int64_t(63)); }
-__device__ __forceinline__ const int64_t* plan_super(const int64_t* sums, int64_t n) { return sums + ((n + 63) & ~int64_t(63)); }
-
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    const uint32_t lo = uint32_t(__shfl_down(int(uint32_t(v)), d, 64)), hi = uint32_t(__shfl_down(int(uint32_t(v >> 32)), d, 64));
-    v += (uint64_t(hi) << 32) | lo;
-  }
-  return v;   // valid in lane 0
-}
-
-inline __global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t n, int64_t* __restrict__ sums, int64_t* __restrict__ total_out,
-                                                         const int64_t capacity, int64_t* __restrict__ out_starts_end, int* __restrict__ big_flag,
-                                                         int64_t* __restrict__ total_user) {
-  __shared__ int64_t s_wave[16];
-  __shared__ int64_t s_carry;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int64_t* super = plan_super(sums, n);
-  const int64_t ns = (n + 63) >> 6;
-  if (tid == 0) {
-    s_carry = 0;
-    if (big_flag) *big_flag = 0;
-  }
-  constexpr int kFly = 8;
-  for (int64_t s0 = int64_t(wave) * kFly; s0 < ns; s0 += 16 * kFly) {
-    uint64_t v[kFly];
-#pragma unroll
-    for (int k = 0; k < kFly; k++) {
-      const int64_t i = (s0 + k) * 64 + lane;
-      v[k] = (s0 + k < ns && i < n) ? uint64_t(sums[i]) : 0;
-    }
-#pragma unroll
-    for (int k = 0; k < kFly; k++) {
-      const uint64_t t = wave_sum_u64(v[k]);
-      if (lane == 0 && s0 + k < ns) super[s0 + k] = int64_t(t);
-    }
-  }
-  __syncthreads();
-  for (int64_t base = 0; base < ns; base += 1024) {
-    const int64_t i = base + tid;
-    const int64_t v = i < ns ? super[i] : 0;
-    uint64_t x = uint64_t(v);      // inclusive scan within the wavefront, then across the 16 wavefronts
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t lo = uint32_t(__shfl_up(int(uint32_t(x)), d, 64)), hi = uint32_t(__shfl_up(int(uint32_t(x >> 32)), d, 64));
-      if (lane >= d) x += (uint64_t(hi) << 32) | lo;
-    }
-    if (lane == 63) s_wave[wave] = int64_t(x);
-    __syncthreads();
-    int64_t woff = s_carry;
-    for (int k = 0; k < wave; k++) woff += s_wave[k];
-    if (i < ns) super[i] = woff + int64_t(x) - v;
-    __syncthreads();
-    if (tid == 1023) s_carry = woff + int64_t(x);    // the last thread's inclusive value = everything so far
-    __syncthreads();
-  }
-  if (tid == 0) {
-    const int64_t total = s_carry;
-    total_out[0] = total;
-    total_out[1] = total > capacity ? 1 : 0;
-    if (total_user) {
-      total_user[0] = total;
-      total_user[1] = total > capacity ? 1 : 0;
-    }
-    if (out_starts_end) *out_starts_end = total;
+// super[g] = sum of the block sums of group g, for count launches whose sums are only final after count_tail_kernel
+// (sampled suffix arrays): one wavefront per group.  Launches with the dense arrays never run this -- the count kernel's
+// blocks have accumulated the group sums already.
+inline __global__ __launch_bounds__(256) void plan_super_kernel(const PlanSums ps) {
+  const int64_t g = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t ns = (ps.nblocks + 63) >> 6;
+  if (g >= ns) return;
+  const int64_t b = (g << 6) + int64_t(threadIdx.x & 63u);
+  const uint64_t t = wave_sum_u64(b < ps.nblocks ? uint64_t(ps.sums[b]) : 0);
+  if ((threadIdx.x & 63u) == 0) {
+    ps.super[g] = int64_t(t);
+    if (t) atomicAdd(reinterpret_cast<unsigned long long*>(&ps.super2[g >> 6]), static_cast<unsigned long long>(t));   // cleared by the host
   }
 }
 
@@ -486,9 +523,10 @@ inline __global__ void copy_total_kernel(const int64_t* __restrict__ src, int64_
 // reads) and no walk follows.
 template <bool kSa>
 inline __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npats, const int32_t* __restrict__ noccs, const int64_t* __restrict__ first,
-                                                        const int64_t* __restrict__ block_sums, int64_t* __restrict__ out_starts,
+                                                        const int2* __restrict__ first32 /* or NULL: (first,last) pairs instead of first[] */,
+                                                        const PlanSums ps, int64_t* __restrict__ out_starts,
                                                         int64_t* __restrict__ offsets, const int64_t capacity, int* __restrict__ big_flag,
-                                                        const DevIndex ix) {
+                                                        const DevIndex ix, int64_t* __restrict__ total_out, int64_t* __restrict__ total_user) {
   __shared__ int64_t s_w[4];
   __shared__ int64_t s_boff;
   const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -496,10 +534,28 @@ inline __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npa
   // inclusive scan inside the wavefront, then across the four wavefronts (a block's rows: <= 256 * (2^31 - 1): 64 bits)
   uint64_t incl = uint64_t(n);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (wave == 0) {   // rows before this block: its super block's scanned sum + the blocks before it inside the super block
-    const int64_t nblocks = (npats + 255) >> 8, b = int64_t(blockIdx.x);
-    const uint64_t part = wave_sum_u64(lane < int(b & 63) ? uint64_t(block_sums[(b & ~int64_t(63)) + lane]) : 0);
-    if (lane == 0) s_boff = plan_super(block_sums, nblocks)[b >> 6] + int64_t(part);
+  if (wave == 0) {   // rows before this block: the groups before its group + the blocks before it inside the group
+    const int64_t b = int64_t(blockIdx.x), g = b >> 6;
+    // three independent loads per lane: blocks before b in its group, groups before g in its group of groups, and those
+    uint64_t acc = lane < int(b & 63) ? uint64_t(ps.sums[(b & ~int64_t(63)) + lane]) : 0;
+    if (lane < int(g & 63)) acc += uint64_t(ps.super[(g & ~int64_t(63)) + lane]);
+    for (int64_t k = lane; k < (g >> 6); k += 64) acc += uint64_t(ps.super2[k]);    // (one round up to 2^18 blocks = 67 M patterns)
+    const uint64_t part = wave_sum_u64(acc);
+    // the set of group sums the NEXT launch accumulates into starts at zero
+    for (int64_t k = int64_t(blockIdx.x) * 64 + lane; k < ps.next_words; k += int64_t(gridDim.x) * 64) ps.next_super[k] = 0;
+    if (lane == 0) {
+      s_boff = int64_t(part);
+      if (b == ps.nblocks - 1) {      // the last block knows the total: everything before it + its own rows
+        const int64_t total = int64_t(part) + ps.sums[b];
+        total_out[0] = total;
+        total_out[1] = total > capacity ? 1 : 0;
+        if (total_user) {
+          total_user[0] = total;
+          total_user[1] = total > capacity ? 1 : 0;
+        }
+        out_starts[npats] = total;
+      }
+    }
   }
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -529,7 +585,7 @@ inline __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npa
       if (lane >= d) inc += y;
     }
     s_incl[wave][lane] = inc;
-    s_first[wave][lane] = mine ? first[q] : 0;      // (only ranges with rows: most lines of first[] are never touched on a random batch)
+    s_first[wave][lane] = mine ? (first32 ? int64_t(first32[q].x) : first[q]) : 0;      // (only ranges with rows: most lines of first[] are never touched on a random batch)
     s_lbase[wave][lane] = base;      // slots are addressed per lane: a long range keeps its slots but is not written here
     const uint32_t total = uint32_t(__shfl(int(inc), 63, 64));
     __syncthreads();
@@ -558,14 +614,14 @@ inline __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npa
     atomicOr(big_flag, 1);
     return;
   }
-  const int64_t f = first[q];
+  const int64_t f = first32 ? int64_t(first32[q].x) : first[q];
   const int64_t lim = base + n <= capacity ? n : (capacity > base ? capacity - base : 0);
   for (int64_t k = 0; k < lim; k++) offsets[base + k] = f + k;
 }
 
 // the long ranges left over by plan_rows_kernel: grid-stride, one thread per output slot (idle unless the flag is set)
 template <bool kSa>
-inline __global__ __launch_bounds__(256) void plan_big_rows_kernel(const int64_t npats, const int64_t* __restrict__ first,
+inline __global__ __launch_bounds__(256) void plan_big_rows_kernel(const int64_t npats, const int64_t* __restrict__ first, const int2* __restrict__ first32,
                                                             const int64_t* __restrict__ out_starts, const int64_t* __restrict__ total_ptr,
                                                             const int64_t capacity, int64_t* __restrict__ offsets, const int* __restrict__ big_flag,
                                                             const DevIndex ix) {
@@ -579,7 +635,7 @@ inline __global__ __launch_bounds__(256) void plan_big_rows_kernel(const int64_t
     }
     const int64_t end = lo + 1 < npats ? out_starts[lo + 1] : *total_ptr;
     if (end - out_starts[lo] > kExpandSerialMax) {
-      const int64_t row = first[lo] + (item - out_starts[lo]);
+      const int64_t row = (first32 ? int64_t(first32[lo].x) : first[lo]) + (item - out_starts[lo]);
       if (kSa) {
         offsets[item] = ix.sa_full[row];
         trace_touch(ix, kTraceSa, uint64_t(row) >> 4);

@@ -271,7 +271,7 @@ struct Plan {
   int64_t* out_starts;   // device, npats + 1
   int64_t capacity;      // rows the caller's offsets buffer holds (INT64_MAX when it is sized afterwards)
   bool done;
-  int64_t* total_user = nullptr;   // device, 2 words: the caller's copy of S.d_total, written by plan_scan_kernel itself
+  int64_t* total_user = nullptr;   // device, 2 words: the caller's copy of S.d_total, written by plan_rows_kernel itself
 };
 
 // modes 3 / 4: the caller-order pipeline of direct_kernels.hip.hpp (with or without a level table)
@@ -303,8 +303,22 @@ void launch_tail(femto_amd_index* ix, const DevIndex& d, dim3 grid, hipStream_t 
   }
 }
 
-// block sums + their super sums (plan_scan_kernel)
-size_t plan_sums_bytes(int64_t nblocks) { return size_t(((nblocks + 63) & ~int64_t(63)) + (nblocks + 63) / 64 + 8) * 8; }
+// S.bsums holds a PlanSums (direct_kernels.hip.hpp): block sums + two alternating sets of group sums.  The kernels keep
+// the set the next launch uses cleared; the host only clears when the buffer is new or the batch size (= the layout) changes,
+// or when the group sums are computed by plan_super_kernel (which accumulates the second level).
+int reserve_plan_sums(Scratch& S, int64_t nblocks, bool fold, hipStream_t stream) {
+  const void* before = S.bsums.p;
+  int rc = S.bsums.reserve(plan_sums_bytes(nblocks));
+  if (rc) return rc;
+  S.bsums_parity ^= 1;
+  if (S.bsums.p != before || S.bsums_nblocks != nblocks || !fold || !S.bsums_clean) {
+    int64_t* sets = S.bsums.as<int64_t>() + ((nblocks + 63) & ~int64_t(63));
+    HIP_TRY(hipMemsetAsync(sets, 0, size_t(2 * plan_set_words(nblocks)) * 8, stream));
+  }
+  S.bsums_nblocks = nblocks;
+  S.bsums_clean = false;       // true again once launch_plan_rows has run for this launch (it clears the other set)
+  return 0;
+}
 
 // Thresholds of the inline text tail (count_direct_kernel<.., kDense = true>): SA read + text compare + ISA read are
 // three dependent lines, so it pays from four symbols to go (measured: cfg 3 5.22 -> 5.08 ms against the hand-over
@@ -337,11 +351,14 @@ int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const in
   const bool tail = d.txt != nullptr && !inline_tail;
   if (tail && (rc = tail_setup(ix, S, d, npats, stream))) return rc;
   if (d.txt && !tail) inline_tail_setup(ix, d);
-  int64_t* bsums = nullptr;
+  PlanSums ps{nullptr, nullptr, nullptr, nullptr, 0, nblocks, 0};
+  int* big_flag = nullptr;
   if (plan) {
-    if ((rc = S.bsums.reserve(plan_sums_bytes(nblocks)))) return rc;
-    bsums = S.bsums.as<int64_t>();
+    if ((rc = reserve_plan_sums(S, nblocks, !tail, stream))) return rc;
+    ps = plan_sums_at(S.bsums.p, nblocks, /*fold=*/!tail, S.bsums_parity);     // (count_tail_kernel still adds to the sums: see plan_super_kernel)
+    big_flag = S.d_flags + 1;
   }
+  int64_t* bsums = ps.sums;
   hipEvent_t e0, e1;
   timer_begin(ix, ix->t_count, stream, &e0, &e1);
   const dim3 grid{uint32_t(nblocks)}, block{uint32_t(kBlockThreads)};
@@ -350,10 +367,10 @@ int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const in
   const bool dense = inline_tail;
 #define LAUNCH_COUNT_DIRECT(POLICY)                                                                                                        \
   do {                                                                                                                                     \
-    if (plan && dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, true, true>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, bsums); \
-    else if (plan) hipLaunchKernelGGL((count_direct_kernel<POLICY, true, false>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, bsums);       \
-    else if (dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, false, true>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, bsums);     \
-    else hipLaunchKernelGGL((count_direct_kernel<POLICY, false, false>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, bsums);              \
+    if (plan && dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, true, true>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, ps, big_flag); \
+    else if (plan) hipLaunchKernelGGL((count_direct_kernel<POLICY, true, false>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, ps, big_flag);       \
+    else if (dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, false, true>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, ps, big_flag);     \
+    else hipLaunchKernelGGL((count_direct_kernel<POLICY, false, false>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, ps, big_flag);              \
   } while (0)
   if (ix->mode == 3) LAUNCH_COUNT_DIRECT(PackPolicy);
   else if (d.ind) LAUNCH_COUNT_DIRECT(IndPolicy);     // per-character rank lines: one line per range end and step
@@ -368,8 +385,11 @@ int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const in
   }
   timer_end(ix, ix->t_count, stream, e0, e1);
   if (plan) {
-    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, stream, nblocks, bsums, S.d_total, plan->capacity, plan->out_starts + npats, S.d_flags + 1, plan->total_user);
-    HIP_TRY(hipGetLastError());
+    if (tail) {     // the sums became final in count_tail_kernel: the group sums in a launch of their own
+      hipLaunchKernelGGL(plan_super_kernel, dim3(uint32_t(((nblocks + 63) / 64 + 3) / 4)), dim3(256), 0, stream, ps);
+      HIP_TRY(hipGetLastError());
+    }
+    S.total_user = plan->total_user;
     plan->done = true;
   }
   return 0;
@@ -456,18 +476,40 @@ int device_scan(DeviceBuffer* scan, int64_t n, const int64_t* in, int64_t* out /
   return 0;
 }
 
-// host-pointer key chunks (count_keys_kernel)
-int launch_count_keys(femto_amd_index* ix, int64_t n, const uint64_t* d_keys, int2* out32, int64_t* d_first, int64_t* d_last, hipStream_t stream) {
+// key batches (count_keys_kernel): host-pointer key chunks, and -- with a plan -- femto_amd_locate_keys_device
+int launch_count_keys(femto_amd_index* ix, int64_t n, const uint64_t* d_keys, int2* out32, int64_t* d_first, int64_t* d_last, hipStream_t stream,
+                      Scratch* S = nullptr, Plan* plan = nullptr) {
   if (n <= 0) return 0;
-  const dim3 grid{uint32_t((n + kBlockThreads - 1) / kBlockThreads)}, block{uint32_t(kBlockThreads)};
+  const int64_t nblocks = (n + kBlockThreads - 1) / kBlockThreads;
+  const dim3 grid{uint32_t(nblocks)}, block{uint32_t(kBlockThreads)};
   const int bits = ix->dense_bits, nsym = 63 / bits;
+  PlanSums ps{nullptr, nullptr, nullptr, nullptr, 0, nblocks, 0};
+  int* big_flag = nullptr;
+  int rc;
+  if (plan) {
+    if ((rc = reserve_plan_sums(*S, nblocks, true, stream))) return rc;
+    ps = plan_sums_at(S->bsums.p, nblocks, true, S->bsums_parity);
+    big_flag = S->d_flags + 1;
+  }
+  const int mo = plan ? plan->max_occs : 0;
+  int32_t* noccs = plan ? plan->noccs : nullptr;
   hipEvent_t e0, e1;
   timer_begin(ix, ix->t_count, stream, &e0, &e1);
-  if (ix->mode == 3) hipLaunchKernelGGL(count_keys_kernel<PackPolicy>, grid, block, 0, stream, ix->dev, n, d_keys, bits, nsym, out32, d_first, d_last);
-  else if (ix->dev.ind) hipLaunchKernelGGL(count_keys_kernel<IndPolicy>, grid, block, 0, stream, ix->dev, n, d_keys, bits, nsym, out32, d_first, d_last);
-  else hipLaunchKernelGGL(count_keys_kernel<Pack2Policy>, grid, block, 0, stream, ix->dev, n, d_keys, bits, nsym, out32, d_first, d_last);
+#define LAUNCH_KEYS(POLICY)                                                                                                                                  \
+  do {                                                                                                                                                       \
+    if (plan) hipLaunchKernelGGL((count_keys_kernel<POLICY, true>), grid, block, 0, stream, ix->dev, n, d_keys, bits, nsym, out32, d_first, d_last, mo, noccs, ps, big_flag); \
+    else hipLaunchKernelGGL((count_keys_kernel<POLICY, false>), grid, block, 0, stream, ix->dev, n, d_keys, bits, nsym, out32, d_first, d_last, mo, noccs, ps, big_flag);     \
+  } while (0)
+  if (ix->mode == 3) LAUNCH_KEYS(PackPolicy);
+  else if (ix->dev.ind) LAUNCH_KEYS(IndPolicy);
+  else LAUNCH_KEYS(Pack2Policy);
+#undef LAUNCH_KEYS
   HIP_TRY(hipGetLastError());
   timer_end(ix, ix->t_count, stream, e0, e1);
+  if (plan) {
+    S->total_user = plan->total_user;
+    plan->done = true;
+  }
   return 0;
 }
 
@@ -496,21 +538,22 @@ int launch_count_plan(femto_amd_index* ix, Scratch& S, int64_t npats, const int3
 
 // direct pipeline, after launch_count_plan: out_starts[] and -- when d_offsets is given -- the rows to locate
 int launch_plan_rows(femto_amd_index* ix, Scratch& S, int64_t npats, const int32_t* d_noccs, const int64_t* d_first,
-                     int64_t* d_out_starts, int64_t* d_offsets, int64_t capacity, hipStream_t stream) {
+                     int64_t* d_out_starts, int64_t* d_offsets, int64_t capacity, hipStream_t stream, const int2* d_first32 = nullptr) {
   if (npats <= 0) return 0;
-  int* big_flag = S.d_flags + 1;      // cleared by plan_scan_kernel
+  int* big_flag = S.d_flags + 1;      // cleared by the count kernel
   const int64_t nblocks = (npats + kBlockThreads - 1) / kBlockThreads;
   const dim3 grid{uint32_t(nblocks)}, bgrid{uint32_t(std::min<int64_t>(nblocks, int64_t(ix->num_cus) * 8))}, block{uint32_t(kBlockThreads)};
-  const int64_t* boffs = S.bsums.as<int64_t>();
+  const PlanSums ps = plan_sums_at(S.bsums.p, nblocks, false, S.bsums_parity);
+  S.bsums_clean = true;
   const bool sa = d_offsets && ix->dev.sa_full;    // the offsets themselves, no walk afterwards
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (sa) timer_begin(ix, ix->t_locate, stream, &e0, &e1);
-  if (sa) hipLaunchKernelGGL(plan_rows_kernel<true>, grid, block, 0, stream, npats, d_noccs, d_first, boffs, d_out_starts, d_offsets, capacity, big_flag, ix->dev);
-  else hipLaunchKernelGGL(plan_rows_kernel<false>, grid, block, 0, stream, npats, d_noccs, d_first, boffs, d_out_starts, d_offsets, capacity, big_flag, ix->dev);
+  if (sa) hipLaunchKernelGGL(plan_rows_kernel<true>, grid, block, 0, stream, npats, d_noccs, d_first, d_first32, ps, d_out_starts, d_offsets, capacity, big_flag, ix->dev, S.d_total, S.total_user);
+  else hipLaunchKernelGGL(plan_rows_kernel<false>, grid, block, 0, stream, npats, d_noccs, d_first, d_first32, ps, d_out_starts, d_offsets, capacity, big_flag, ix->dev, S.d_total, S.total_user);
   if (d_offsets) {
-    if (sa) hipLaunchKernelGGL(plan_big_rows_kernel<true>, bgrid, block, 0, stream, npats, d_first, static_cast<const int64_t*>(d_out_starts),
+    if (sa) hipLaunchKernelGGL(plan_big_rows_kernel<true>, bgrid, block, 0, stream, npats, d_first, d_first32, static_cast<const int64_t*>(d_out_starts),
                                static_cast<const int64_t*>(S.d_total), capacity, d_offsets, static_cast<const int*>(big_flag), ix->dev);
-    else hipLaunchKernelGGL(plan_big_rows_kernel<false>, bgrid, block, 0, stream, npats, d_first, static_cast<const int64_t*>(d_out_starts),
+    else hipLaunchKernelGGL(plan_big_rows_kernel<false>, bgrid, block, 0, stream, npats, d_first, d_first32, static_cast<const int64_t*>(d_out_starts),
                             static_cast<const int64_t*>(S.d_total), capacity, d_offsets, static_cast<const int*>(big_flag), ix->dev);
   }
   HIP_TRY(hipGetLastError());
@@ -773,7 +816,8 @@ int build_ctx2(femto_amd_index* ix, int nstop) {
   if (hmin > hmax) return 0;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
-  const int64_t budget = int64_t(free_b / 4);
+  int64_t budget = int64_t(free_b / 4);
+  if (const char* e = getenv("FEMTO_AMD_CTX2_MB")) budget = std::max<int64_t>(1, atoll(e)) << 20;
   DeviceBuffer cnt;
   int rc = cnt.reserve(8);
   if (rc) return rc;
@@ -2169,7 +2213,7 @@ int femto_amd_locate_device(femto_amd_index_t* ix, int64_t npats, const int32_t*
   Scratch& S = *L.s;
   Plan plan{max_occs_each, d_noccs, d_out_starts, offsets_capacity, false, d_total};
   if ((rc = launch_count_plan(ix, S, npats, d_plen, d_pats, d_starts, d_first, d_last, &plan, stream))) return rc;
-  if (plan.done) {   // direct pipeline: one stream-ordered chain, nothing returns to the host (d_total: plan_scan_kernel)
+  if (plan.done) {   // direct pipeline: one stream-ordered chain, nothing returns to the host (d_total: plan_rows_kernel's last block)
     if ((rc = launch_plan_rows(ix, S, npats, d_noccs, d_first, d_out_starts, d_offsets, offsets_capacity, stream))) return rc;
     if (offsets_capacity > 0 && d_offsets && !ix->dev.sa_full && (rc = launch_walk_device_total(ix, S, d_offsets, offsets_capacity, stream))) return rc;
   } else {           // other kernel families size the walk on the host
@@ -2180,6 +2224,69 @@ int femto_amd_locate_device(femto_amd_index_t* ix, int64_t npats, const int32_t*
     if (walk == tot[0] && d_offsets && (rc = launch_locate(ix, S, npats, d_first, d_out_starts, walk, d_offsets, stream))) return rc;
     HIP_TRY(hipMemcpyAsync(d_total, S.d_total, 2 * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
   }
+  return FEMTO_AMD_OK;
+  API_END
+}
+
+int femto_amd_key_format(const femto_amd_index_t* ix, int* bits, int* max_syms, uint8_t* field_of_alpha /* [261] or NULL */) {
+  if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
+  if (!ix->children.empty()) return femto_amd_key_format(ix->children[0], bits, max_syms, field_of_alpha);
+  if (!use_direct(ix) || ix->h_dense.empty())
+    return set_err(FEMTO_AMD_ERR_INVALID, "keys need the packed layouts (modes 3 / 4) and at most 255 distinct characters");
+  if (bits) *bits = ix->dense_bits;
+  if (max_syms) *max_syms = 63 / ix->dense_bits;
+  if (field_of_alpha) memcpy(field_of_alpha, ix->h_dense.data(), std::min<size_t>(ix->h_dense.size(), size_t(kAlphaSize)));
+  return FEMTO_AMD_OK;
+}
+
+int femto_amd_pack_keys_device(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats, const int64_t* d_starts,
+                               uint64_t* d_keys, int64_t* d_bad, void* stream_) {
+  API_BEGIN
+  if (!ix || npats < 0 || !d_bad || (npats && (!d_plen || !d_starts || !d_keys))) return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
+  int rc = ensure_device(ix);
+  if (rc) return rc;
+  if (!use_direct(ix) || ix->h_dense.empty())
+    return set_err(FEMTO_AMD_ERR_INVALID, "keys need the packed layouts (modes 3 / 4) and at most 255 distinct characters");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  HIP_TRY(hipMemsetAsync(d_bad, 0, sizeof(int64_t), stream));
+  if (npats) {
+    hipLaunchKernelGGL(pack_keys_kernel, dim3(uint32_t((npats + 255) / 256)), dim3(256), 0, stream, npats, d_plen, d_pats, d_starts,
+                       static_cast<const uint8_t*>(ix->d_dense), ix->dense_bits, 63 / ix->dense_bits, d_keys,
+                       reinterpret_cast<unsigned long long*>(d_bad));
+    HIP_TRY(hipGetLastError());
+  }
+  return FEMTO_AMD_OK;
+  API_END
+}
+
+int femto_amd_locate_keys_device(femto_amd_index_t* ix, int64_t npats, const uint64_t* d_keys, int max_occs_each, int32_t* d_ranges32,
+                                 int64_t* d_first, int64_t* d_last, int32_t* d_noccs, int64_t* d_out_starts, int64_t* d_offsets,
+                                 int64_t offsets_capacity, int64_t* d_total, void* stream_) {
+  API_BEGIN
+  if (!ix || npats < 0 || max_occs_each < 0 || offsets_capacity < 0) return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
+  if (npats && (!d_keys || (!d_ranges32 && (!d_first || !d_last)))) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  if (d_noccs && (!d_out_starts || !d_total)) return set_err(FEMTO_AMD_ERR_PARAM, "a locate plan needs d_out_starts and d_total");
+  int rc = ensure_device(ix);
+  if (rc) return rc;
+  if (!use_direct(ix) || ix->h_dense.empty())
+    return set_err(FEMTO_AMD_ERR_INVALID, "keys need the packed layouts (modes 3 / 4) and at most 255 distinct characters");
+  if (d_ranges32 && ix->host.total_length >= int64_t(INT32_MAX)) return set_err(FEMTO_AMD_ERR_PARAM, "32-bit ranges need an index of fewer than 2^31 - 1 rows");
+  if (npats > (int64_t(1) << 31)) return set_err(FEMTO_AMD_ERR_PARAM, "at most 2^31 keys per call");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  Lease L(ix, stream);
+  if (!L.s) return L.rc;
+  Scratch& S = *L.s;
+  int2* r32 = reinterpret_cast<int2*>(d_ranges32);
+  if (!d_noccs) return launch_count_keys(ix, npats, d_keys, r32, d_first, d_last, stream);
+  if (npats == 0) {
+    HIP_TRY(hipMemsetAsync(d_out_starts, 0, sizeof(int64_t), stream));
+    HIP_TRY(hipMemsetAsync(d_total, 0, 2 * sizeof(int64_t), stream));
+    return FEMTO_AMD_OK;
+  }
+  Plan plan{max_occs_each, d_noccs, d_out_starts, offsets_capacity, false, d_total};
+  if ((rc = launch_count_keys(ix, npats, d_keys, r32, d_first, d_last, stream, &S, &plan))) return rc;
+  if ((rc = launch_plan_rows(ix, S, npats, d_noccs, d_first, d_out_starts, d_offsets, offsets_capacity, stream, r32))) return rc;
+  if (offsets_capacity > 0 && d_offsets && !ix->dev.sa_full && (rc = launch_walk_device_total(ix, S, d_offsets, offsets_capacity, stream))) return rc;
   return FEMTO_AMD_OK;
   API_END
 }
@@ -2528,7 +2635,7 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
     if ((r2 = S.last.reserve(size_t(npats + 1) * 8))) return r2;
     if ((r2 = S.noccs.reserve(size_t(npats + 1) * 4))) return r2;
     if ((r2 = S.out_starts.reserve(size_t(npats + 2) * 8))) return r2;
-    if ((r2 = S.bsums.reserve(plan_sums_bytes(nblocks)))) return r2;
+    if ((r2 = reserve_plan_sums(S, nblocks, true, st))) return r2;
     DevIndex d = ix->dev;
     ta::TraceArgs a{};
     a.dev = &d;
@@ -2544,6 +2651,8 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
     a.noccs = S.noccs.as<int32_t>();
     a.out_starts = S.out_starts.as<int64_t>();
     a.bsums = S.bsums.as<int64_t>();
+    a.parity = S.bsums_parity;
+    S.bsums_clean = false;    // (the traced twins run plan_rows twice: simply clear before the next real launch)
     a.tail_items = nullptr;
     inline_tail_setup(ix, d);     // as launch_count_direct does (the hand-over case takes tail_setup's below)
     a.tail_min = d.tail_min;

@@ -16,6 +16,7 @@ struct TraceArgs {
   int64_t *first, *last;
   int32_t* noccs;
   int64_t *out_starts, *bsums;
+  int parity;               // which set of group sums of bsums this launch uses (PlanSums)
   void* tail_items;         // NULL: no text tail
   int tail_min;
   int* flags;               // [0] error, [1] long ranges, [2] tail item count

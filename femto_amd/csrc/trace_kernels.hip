@@ -41,7 +41,7 @@ static DevIndex make_dev(const TraceArgs& a) {
   return d;
 }
 
-// count_direct_kernel + count_tail_kernel + plan_scan_kernel + plan_rows_kernel (out_starts only)
+// count_direct_kernel + count_tail_kernel (+ plan_super_kernel) + plan_rows_kernel (out_starts only)
 hipError_t traced_count_plan(const TraceArgs& a) {
   const DevIndex d = make_dev(a);
   const int64_t nblocks = (a.npats + 255) / 256;
@@ -49,16 +49,19 @@ hipError_t traced_count_plan(const TraceArgs& a) {
   hipError_t e = hipMemsetAsync(a.flags, 0, 4 * sizeof(int), a.stream);
   if (e != hipSuccess) return e;
   const bool dense = d.txt && d.sa_full && d.isa8 && d.isa_shift == 0;   // as launch_count_direct decides
+  const bool tail = d.txt && !dense;
+  const PlanSums ps = plan_sums_at(a.bsums, nblocks, !tail, a.parity);
+  int* big_flag = a.flags + 1;
 #define LAUNCH_COUNT_DIRECT(POLICY)                                                                                                     \
   do {                                                                                                                                  \
-    if (dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, true, true>), grid, block, 0, a.stream, d, a.npats, a.plen, a.pats, a.starts, a.first, a.last, a.flags, a.max_occs, a.noccs, a.bsums); \
-    else hipLaunchKernelGGL((count_direct_kernel<POLICY, true, false>), grid, block, 0, a.stream, d, a.npats, a.plen, a.pats, a.starts, a.first, a.last, a.flags, a.max_occs, a.noccs, a.bsums);     \
+    if (dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, true, true>), grid, block, 0, a.stream, d, a.npats, a.plen, a.pats, a.starts, a.first, a.last, a.flags, a.max_occs, a.noccs, ps, big_flag); \
+    else hipLaunchKernelGGL((count_direct_kernel<POLICY, true, false>), grid, block, 0, a.stream, d, a.npats, a.plen, a.pats, a.starts, a.first, a.last, a.flags, a.max_occs, a.noccs, ps, big_flag);     \
   } while (0)
   if (a.mode == 3) LAUNCH_COUNT_DIRECT(PackPolicy);
   else if (d.ind) LAUNCH_COUNT_DIRECT(IndPolicy);
   else LAUNCH_COUNT_DIRECT(Pack2Policy);
 #undef LAUNCH_COUNT_DIRECT
-  if (d.txt && !dense) {
+  if (tail) {
     const TailOut out{nullptr, a.first, a.last, a.noccs, a.bsums, a.max_occs};
     const dim3 tgrid{uint32_t(std::min<int64_t>(nblocks, int64_t(a.num_cus) * 8))};
     const TailItem* items = static_cast<const TailItem*>(a.tail_items);
@@ -73,9 +76,9 @@ hipError_t traced_count_plan(const TraceArgs& a) {
       else hipLaunchKernelGGL((count_tail_kernel<Pack2Policy, false>), tgrid, block, 0, a.stream, d, items, n_items, a.plen, a.pats, a.starts, perm, keys, 1, 0, out, a.flags);
     }
   }
-  hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, a.stream, nblocks, a.bsums, a.total, INT64_MAX, a.out_starts + a.npats, static_cast<int*>(nullptr), static_cast<int64_t*>(nullptr));
-  hipLaunchKernelGGL(plan_rows_kernel<false>, grid, block, 0, a.stream, a.npats, static_cast<const int32_t*>(a.noccs), static_cast<const int64_t*>(a.first),
-                     static_cast<const int64_t*>(a.bsums), a.out_starts, static_cast<int64_t*>(nullptr), INT64_MAX, a.flags + 1, d);
+  if (tail) hipLaunchKernelGGL(plan_super_kernel, dim3(uint32_t(((nblocks + 63) / 64 + 3) / 4)), block, 0, a.stream, ps);
+  hipLaunchKernelGGL(plan_rows_kernel<false>, grid, block, 0, a.stream, a.npats, static_cast<const int32_t*>(a.noccs), static_cast<const int64_t*>(a.first), static_cast<const int2*>(nullptr),
+                     ps, a.out_starts, static_cast<int64_t*>(nullptr), INT64_MAX, a.flags + 1, d, a.total, static_cast<int64_t*>(nullptr));
   return hipGetLastError();
 }
 
@@ -88,15 +91,16 @@ hipError_t traced_walk(const TraceArgs& a, int64_t* offsets, int64_t capacity) {
   if (e != hipSuccess) return e;
   const dim3 wgrid{uint32_t(std::max<int64_t>(1, std::min<int64_t>((capacity + 255) / 256, int64_t(a.num_cus) * 8)))};
   const int32_t* noccs = a.noccs;
-  const int64_t *first = a.first, *boffs = a.bsums, *ostarts = a.out_starts, *total = a.total;
+  const int64_t *first = a.first, *ostarts = a.out_starts, *total = a.total;
+  const PlanSums boffs = plan_sums_at(a.bsums, nblocks, false, a.parity);
   const int* big = a.flags + 1;
   if (d.sa_full) {   // the offsets themselves, no walk
-    hipLaunchKernelGGL(plan_rows_kernel<true>, grid, block, 0, a.stream, a.npats, noccs, first, boffs, a.out_starts, offsets, capacity, a.flags + 1, d);
-    hipLaunchKernelGGL(plan_big_rows_kernel<true>, wgrid, block, 0, a.stream, a.npats, first, ostarts, total, capacity, offsets, big, d);
+    hipLaunchKernelGGL(plan_rows_kernel<true>, grid, block, 0, a.stream, a.npats, noccs, first, static_cast<const int2*>(nullptr), boffs, a.out_starts, offsets, capacity, a.flags + 1, d, a.total, static_cast<int64_t*>(nullptr));
+    hipLaunchKernelGGL(plan_big_rows_kernel<true>, wgrid, block, 0, a.stream, a.npats, first, static_cast<const int2*>(nullptr), ostarts, total, capacity, offsets, big, d);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(plan_rows_kernel<false>, grid, block, 0, a.stream, a.npats, noccs, first, boffs, a.out_starts, offsets, capacity, a.flags + 1, d);
-  hipLaunchKernelGGL(plan_big_rows_kernel<false>, wgrid, block, 0, a.stream, a.npats, first, ostarts, total, capacity, offsets, big, d);
+  hipLaunchKernelGGL(plan_rows_kernel<false>, grid, block, 0, a.stream, a.npats, noccs, first, static_cast<const int2*>(nullptr), boffs, a.out_starts, offsets, capacity, a.flags + 1, d, a.total, static_cast<int64_t*>(nullptr));
+  hipLaunchKernelGGL(plan_big_rows_kernel<false>, wgrid, block, 0, a.stream, a.npats, first, static_cast<const int2*>(nullptr), ostarts, total, capacity, offsets, big, d);
   if (a.mode == 3)
     hipLaunchKernelGGL(locate_walk_kernel<PackPolicy>, wgrid, block, 0, a.stream, d, total, capacity, offsets);
   else

@@ -297,6 +297,25 @@ int femto_amd_striped_serve(femto_amd_index_t* ix, const char* socket_path, int 
 int femto_amd_open_striped_client(const char* index_path, const char* socket_path, int device, int timeout_s, femto_amd_index_t** out);
 int femto_amd_multi_child(femto_amd_index_t* ix, int i, femto_amd_index_t** child);
 
+/* ---- patterns as keys (device pointers) ---------------------------------------------------------------------------------
+ * A pattern of at most max_syms symbols whose characters all occur in the text fits ONE 64-bit word: `bits`-bit fields, the
+ * pattern's LAST symbol in the top field, field = field_of_alpha[alpha code] (1 + the character's rank among the text's
+ * characters), 0 = end of pattern.  femto_amd_key_format reports bits / max_syms (3 bits, 21 symbols for DNA; 7 bits, 9
+ * symbols for a 96-character text) and the field table; femto_amd_pack_keys_device packs a (plen, pats, starts) batch that
+ * is already in HBM (*d_bad = patterns no key describes: they get key 0 = the empty pattern; such a batch belongs to the
+ * symbol entry points).  femto_amd_locate_keys_device is femto_amd_count_device / femto_amd_locate_device on keys: the
+ * same search (parallel_count / parallel_locate, src/main/femto.c:275,331), bit-identical results, 8 bytes of input per
+ * pattern instead of 12 + 2 per symbol, and -- d_ranges32 != NULL, an index of fewer than 2^31 - 1 rows -- the ranges as
+ * int32 (first, last) pairs instead of two int64 arrays.  d_noccs == NULL: count only (d_out_starts / d_offsets / d_total
+ * unused).  Enqueue-only, like the calls it mirrors. */
+int femto_amd_key_format(const femto_amd_index_t* ix, int* bits, int* max_syms, uint8_t* field_of_alpha /* [261] or NULL */);
+int femto_amd_pack_keys_device(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
+                               const int64_t* d_starts, uint64_t* d_keys, int64_t* d_bad, void* stream);
+int femto_amd_locate_keys_device(femto_amd_index_t* ix, int64_t npats, const uint64_t* d_keys, int max_occs_each,
+                                 int32_t* d_ranges32 /* [2 * npats] or NULL */, int64_t* d_first, int64_t* d_last,
+                                 int32_t* d_noccs, int64_t* d_out_starts /* npats + 1 */, int64_t* d_offsets,
+                                 int64_t offsets_capacity, int64_t* d_total /* 2 */, void* stream);
+
 /* The match counts of a batch in the form a result gather sends ("one RCCL collective for results";
  * parallel_count's last == NULL form, src/main/femto.c:313-318, narrowed): d_counts8[i] = min(last[i] - first[i] + 1, 255),
  * 0 when there is no match; every pattern with 255 matches or more is appended to d_big as a pair (pattern index, count),

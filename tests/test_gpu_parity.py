@@ -1222,3 +1222,69 @@ def test_bench_two_ranks_control_flow(tmp_path, gpu_ok, layout):
     # 0's own slot equalled its local results
     assert line["config"]["gathered_results_verified"] is True
     assert line["config"]["parallelism"].startswith("striped index" if layout == "striped" else "replicated index")
+
+
+@pytest.mark.parametrize("name", ["acgt48k", "eng2doc", "runs3doc"])
+def test_keys_device_path_equals_symbol_path(fixtures, gpu_ok, name):
+    """femto_amd_pack_keys_device + femto_amd_locate_keys_device: patterns as 64-bit keys, ranges as int32 pairs -- the same
+    (first, last), clamped row counts, out_starts and located offsets as the symbol entry points and the reference's goldens,
+    for every pattern a key describes; the others are counted in *d_bad"""
+    import torch
+    fx = fixtures(name)
+    g = fx.gold
+    ix = femto_amd.Index(fx.index, device=0)
+    bits, max_syms, table = ix.key_format()
+    assert 63 // bits == max_syms and table.max() < (1 << bits)
+    plen, flat, starts = fx.patterns
+    n = len(plen)
+    in_text = table[np.minimum(flat, 260)] != 0
+    in_text[flat > 260] = False
+    ok = np.array([plen[i] <= max_syms and bool(in_text[starts[i]:starts[i] + plen[i]].all()) for i in range(n)])
+    assert ok.sum() >= 20
+    dev = "cuda:0"
+    d_plen, d_flat, d_starts = torch.from_numpy(plen).to(dev), torch.from_numpy(flat.view(np.int16)).to(dev), torch.from_numpy(starts).to(dev)
+    d_keys = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_bad = torch.zeros(1, dtype=torch.int64, device=dev)
+    ix.pack_keys_device(n, d_plen.data_ptr(), d_flat.data_ptr(), d_starts.data_ptr(), d_keys.data_ptr(), d_bad.data_ptr())
+    torch.cuda.synchronize()
+    assert int(d_bad.item()) == int((~ok).sum())
+    # the keys of the host-side definition: field j from the top = the j-th symbol from the end
+    keys = d_keys.cpu().numpy().view(np.uint64)
+    for i in np.flatnonzero(ok)[:50]:
+        k = 0
+        for s in range(plen[i] - 1, -1, -1):
+            k = (k << bits) | int(table[flat[starts[i] + s]])
+        want = (k << (64 - int(plen[i]) * bits)) & 0xFFFFFFFFFFFFFFFF if plen[i] else 0
+        assert int(keys[i]) == want, i
+    sel = torch.from_numpy(np.flatnonzero(ok)).to(dev)
+    kk = d_keys[sel].contiguous()
+    m = int(ok.sum())
+    want_first, want_last = g["count_first"][ok], g["count_last"][ok]
+    # count only, 32-bit pairs and 64-bit arrays
+    r32 = torch.zeros(2 * m, dtype=torch.int32, device=dev)
+    ix.locate_keys_device(m, kk.data_ptr(), 0, r32.data_ptr(), 0, 0, 0, 0, 0, 0, 0)
+    f64, l64 = torch.zeros(m, dtype=torch.int64, device=dev), torch.zeros(m, dtype=torch.int64, device=dev)
+    ix.locate_keys_device(m, kk.data_ptr(), 0, 0, f64.data_ptr(), l64.data_ptr(), 0, 0, 0, 0, 0)
+    torch.cuda.synchronize()
+    pairs = r32.cpu().numpy().reshape(m, 2)
+    assert np.array_equal(pairs[:, 0], want_first) and np.array_equal(pairs[:, 1], want_last)
+    assert np.array_equal(f64.cpu().numpy(), want_first) and np.array_equal(l64.cpu().numpy(), want_last)
+    # the whole locate chain on keys against the symbol path on the same patterns
+    for mo, _, _ in fx.locate_cases():
+        sub_plen, sub_starts = plen[ok], starts[ok]
+        noccs_ref, offs_ref = ix.locate_flat(sub_plen, flat, sub_starts, mo)
+        cap = int(noccs_ref.sum()) + 8
+        noccs = torch.zeros(m, dtype=torch.int32, device=dev)
+        ostarts = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+        offs = torch.full((cap,), -7, dtype=torch.int64, device=dev)
+        total = torch.zeros(2, dtype=torch.int64, device=dev)
+        for rep in range(3):     # (the group sums alternate between two sets: several launches in a row must agree)
+            ix.locate_keys_device(m, kk.data_ptr(), mo, r32.data_ptr(), 0, 0, noccs.data_ptr(), ostarts.data_ptr(), offs.data_ptr(), cap,
+                                  total.data_ptr())
+            torch.cuda.synchronize()
+            assert total.cpu().tolist() == [int(noccs_ref.sum()), 0], (mo, rep)
+            assert np.array_equal(noccs.cpu().numpy(), noccs_ref)
+            want_starts = np.concatenate([[0], np.cumsum(noccs_ref.astype(np.int64))])
+            assert np.array_equal(ostarts.cpu().numpy(), want_starts)
+            assert np.array_equal(offs.cpu().numpy()[:int(noccs_ref.sum())], offs_ref), (mo, rep)
+    ix.close()
