@@ -172,7 +172,7 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
     const int max_occs, int32_t* __restrict__ noccs, const PlanSums ps, int* __restrict__ big_flag) {
   __shared__ uint16_t s_code[264];
   __shared__ int64_t s_w[4];
-  __shared__ uint32_t s_chunk[16 * 256];     // 64 bytes of pattern per lane (see symbol() below)
+  __shared__ uint32_t s_win[16 * 256];       // 64 dense pattern codes per lane (see fill() below)
   for (int i = threadIdx.x; i < kAlphaSize; i += blockDim.x) s_code[i] = uint16_t(P::code_of(ix, uint32_t(i)));
   __syncthreads();
   const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -180,29 +180,50 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
   if (q < npats) {
     const int len = plen[q];
     const uint16_t* pat = pats + starts[q];
-    // The lane's window on its pattern: the aligned 64-byte chunk holding the symbol being read, kept in LDS (dword w of
-    // lane t at s_chunk[w * 256 + t]: bank = t mod 32, the minimum for 64 lanes).  A chunk never crosses a page, so the
-    // bytes around the pattern inside it are safe to touch.  Reading 8-byte words instead (round 2's first version) touched
-    // every 128-byte line of the pattern 16 times, iterations apart, and with 32 wavefronts per CU doing the same the line
-    // had left the caches in between: 5-6x the compulsory traffic on 100-mers, measured (profiles/README.md).
-    uintptr_t chunk_addr = 1;    // no chunk yet (chunk addresses are multiples of 64)
-    auto symbol = [&](int j) -> uint32_t {   // j-th symbol from the end
-      const uintptr_t sa = reinterpret_cast<uintptr_t>(pat + (len - 1 - j));
-      const uintptr_t ca = sa & ~uintptr_t(63);
-      if (ca != chunk_addr) {
-        const uint4* g = reinterpret_cast<const uint4*>(ca);
-        const uint4 c0 = g[0], c1 = g[1], c2 = g[2], c3 = g[3];
-        uint32_t* s = s_chunk + threadIdx.x;
-        s[0 * 256] = c0.x; s[1 * 256] = c0.y; s[2 * 256] = c0.z; s[3 * 256] = c0.w;
-        s[4 * 256] = c1.x; s[5 * 256] = c1.y; s[6 * 256] = c1.z; s[7 * 256] = c1.w;
-        s[8 * 256] = c2.x; s[9 * 256] = c2.y; s[10 * 256] = c2.z; s[11 * 256] = c2.w;
-        s[12 * 256] = c3.x; s[13 * 256] = c3.y; s[14 * 256] = c3.z; s[15 * 256] = c3.w;
-        chunk_addr = ca;
+    // The lane's window on its pattern: the DENSE codes of symbols j = w0 .. w0 + 63 (j counts from the pattern's END, the
+    // order a backward search reads them in), one byte each, in LDS (byte k of lane t in dword (k >> 2) * 256 + t: bank =
+    // t mod 32, the minimum for 64 lanes).  Filled from aligned 64-byte chunks of the caller's symbols, each symbol translated ONCE
+    // (alpha code -> dense code through s_code); 0xFF = "look at the alpha symbol": a code >= ALPHA_SIZE, a character the
+    // text lacks, a character <= SEOF, or dense code 255 -- the fast paths stop there and the ordinary step below reads the
+    // symbol itself.  Every later use -- table digits, context keys, search steps, the comparison with the text, four symbols
+    // per iteration -- reads bytes of the window.  (Round 2 kept the raw 64-byte chunk and translated every symbol at every
+    // use: 5 800 VALU wave-instructions per wavefront on the sigma~96 workload, half of them in the byte-by-byte text
+    // comparison -- the kernel was issue-bound, not memory-bound.)  The aligned 64-byte chunks reach at most 62 bytes before /
+    // behind the pattern and never cross a page (include/femto_amd.h says so).
+    int w0 = -(1 << 30);         // no window yet
+    uint8_t* const win = reinterpret_cast<uint8_t*>(s_win);
+    auto waddr = [&](uint32_t k) -> uint32_t { return (((k >> 2) * 256u + threadIdx.x) << 2) + (k & 3u); };
+    auto fill = [&](int base) {  // base: a multiple of 4
+      w0 = base;
+      const int jmax = (len < base + 64 ? len : base + 64) - 1;
+      if (jmax < base) return;
+      const uintptr_t a_hi = reinterpret_cast<uintptr_t>(pat + (len - 1 - base));   // symbol j = base (the highest address)
+      const uintptr_t a_lo = reinterpret_cast<uintptr_t>(pat + (len - 1 - jmax));
+      // aligned 32-byte pieces, both halves loaded together (a 20-mer is two of them)
+      for (uintptr_t piece = a_hi & ~uintptr_t(31); piece + 31 >= a_lo; piece -= 32) {
+        const uint4 va = reinterpret_cast<const uint4*>(piece)[0], vb = reinterpret_cast<const uint4*>(piece)[1];
+#pragma unroll
+        for (int sl = 15; sl >= 0; sl--) {
+          const uintptr_t a = piece + 2u * uint32_t(sl);
+          if (a > a_hi || a < a_lo) continue;
+          const uint4& v = sl < 8 ? va : vb;
+          const int s8 = sl & 7;
+          const uint32_t w = s8 < 2 ? v.x : (s8 < 4 ? v.y : (s8 < 6 ? v.z : v.w));
+          const uint32_t ch = (sl & 1) ? w >> 16 : w & 0xffffu;
+          uint32_t b = 0xFFu;
+          if (ch < uint32_t(kAlphaSize)) {
+            const uint32_t c = s_code[ch];
+            if (c < 255u && !P::is_stop(ix, c)) b = c;
+          }
+          win[waddr(uint32_t((a_hi - a) >> 1))] = uint8_t(b);
+        }
       }
-      const uint32_t off = uint32_t(sa - ca);
-      const uint32_t w = s_chunk[(off >> 2) * 256 + threadIdx.x];
-      return (off & 2u) ? w >> 16 : w & 0xffffu;
     };
+    auto wcode = [&](int j) -> uint32_t {    // dense code of the j-th symbol from the end, or 0xFF
+      if (j < w0 || j >= w0 + 64) fill(j & ~3);
+      return win[waddr(uint32_t(j - w0))];
+    };
+    auto alpha = [&](int j) -> uint32_t { return pat[len - 1 - j]; };     // the symbol itself (0xFF cases only)
     int64_t first = 0, last = ix.total_length - 1;
     int j = 0;
     if (ix.ctx && len >= ix.ctx_syms) {     // byte alphabets: the last H symbols as one hashed read (ctx_kernels.hip.hpp)
@@ -214,9 +235,8 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
       CtxKey2 key2{0, 0};
       int okn = 0;                           // leading symbols (from the end) that are table characters
       for (; okn < HH; okn++) {
-        const uint32_t ch = symbol(okn);
-        const uint32_t code = ch < uint32_t(kAlphaSize) ? uint32_t(s_code[ch]) : 0xffffu;
-        if (code == 0xffffu || code < nstop) break;
+        const uint32_t code = wcode(okn);
+        if (code == 0xFFu) break;
         const uint64_t field = uint64_t(code - nstop + 1u);
         if (okn < H1) key1 |= field << (bits * okn);
         if (H2) ctx_key2_or(key2, field, bits * okn);
@@ -232,10 +252,8 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
       const int64_t t = ix.kt2_base;
       int64_t pos = 0;
       for (; j < kmax; j++) {
-        const uint32_t ch = symbol(j);
-        if (ch >= uint32_t(kAlphaSize)) break;
-        const uint32_t code = s_code[ch];
-        if (code == 0xffffu || code < nstop) break;   // not a table character: the ordinary step below deals with it
+        const uint32_t code = wcode(j);
+        if (code == 0xFFu) break;            // not a table character: the ordinary step below deals with it
         pos = pos * t + 1 + int64_t(code - nstop);
       }
       ktab2_lookup<P>(ix, pos, j, first, last);
@@ -256,6 +274,7 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
       const unsigned long long act = __ballot(1), alive = __ballot(first <= last && j < len);
       if (__popcll(alive) * 4 >= __popcll(act) * 3) need_ones = 0;
     }
+    const bool fast_cmp = P::max_code(ix) < 255u;     // a text byte is never 0xFF: four symbols compare as one word
     for (;;) {
       for (; j < len; j++) {
         if (kDense) {
@@ -271,20 +290,23 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
           finished = true;
           break;
         }
-        const uint32_t ch = symbol(j);
-        if (ch >= uint32_t(kAlphaSize)) {
-          atomicOr(err_flag, 1);
-          first = 0;
-          last = -1;
-          finished = true;
-          break;
-        }
-        const uint32_t code = s_code[ch];
-        if (code == 0xffffu) {  // the character does not occur in the text: Occ == 0 (index.c:2080-2089)
-          first = ix.C[ch];
-          last = first - 1;
-          finished = true;
-          break;
+        uint32_t code = wcode(j);
+        if (code == 0xFFu) {            // the alpha symbol decides (server.c:832-936 on the symbol itself)
+          const uint32_t ch = alpha(j);
+          if (ch >= uint32_t(kAlphaSize)) {
+            atomicOr(err_flag, 1);
+            first = 0;
+            last = -1;
+            finished = true;
+            break;
+          }
+          code = s_code[ch];
+          if (code == 0xffffu) {  // the character does not occur in the text: Occ == 0 (index.c:2080-2089)
+            first = ix.C[ch];
+            last = first - 1;
+            finished = true;
+            break;
+          }
         }
         P::search_step(ix, j, code, first, last);
         if (first > last) { finished = true; break; }
@@ -302,25 +324,37 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
         trace_touch(ix, kTraceSa, uint64_t(row) >> 4);
         if (p <= 0 || p >= ix.total_length) continue;   // (p = -1: the row could not be located, see text_isa_build_kernel)
         const int lim = p < int64_t(remaining) ? int(p) : remaining;
+        const uint8_t* const tp = ix.txt + (p - 1);       // txt[p - 1 - m] = tp[-m]
         int m = 0;                       // symbols matched
-        uint4 tw = make_uint4(0, 0, 0, 0);   // aligned 16-byte piece of txt holding the byte being compared
-        uintptr_t tw_addr = 1;
-        for (; m < lim; m++) {
-          const uint32_t ch = symbol(j + m);
-          if (ch >= uint32_t(kAlphaSize)) break;          // anything unusual is left to the ordinary step
-          const uint32_t code = s_code[ch];
-          if (code == 0xffffu || P::is_stop(ix, code)) break;
-          const uintptr_t ta = reinterpret_cast<uintptr_t>(ix.txt + (p - 1 - m));
-          const uintptr_t wa = ta & ~uintptr_t(15);
-          if (wa != tw_addr) {
-            tw = *reinterpret_cast<const uint4*>(wa);
-            tw_addr = wa;
-            trace_touch(ix, kTraceTxt, uint64_t(wa - reinterpret_cast<uintptr_t>(ix.txt)) >> 7);
+        bool stopped = false;
+        if (fast_cmp) {
+          while (m + 4 <= lim) {
+            const int jj = j + m;
+            if (jj < w0 || jj + 4 > w0 + 64) fill(jj & ~3);
+            const uint32_t k = uint32_t(jj - w0), d = k >> 2, sh = k & 3u;
+            const uint32_t lo = s_win[d * 256u + threadIdx.x];
+            const uint32_t hi = sh ? s_win[(d + 1u) * 256u + threadIdx.x] : 0u;
+            const uint32_t pw = __builtin_amdgcn_alignbyte(hi, lo, sh);           // window bytes k .. k+3, k in the low byte
+            uint32_t tw;
+            __builtin_memcpy(&tw, tp - m - 3, 4);                                  // txt[p-4-m .. p-1-m]
+            trace_touch(ix, kTraceTxt, uint64_t(tp - m - 3 - ix.txt) >> 7);
+            trace_touch(ix, kTraceTxt, uint64_t(tp - m - ix.txt) >> 7);
+            const uint32_t x = pw ^ __builtin_bswap32(tw);                          // byte 0: symbol j+m against txt[p-1-m]
+            if (x) {
+              m += (__ffs(int(x)) - 1) >> 3;
+              stopped = true;
+              break;
+            }
+            m += 4;
           }
-          const uint32_t bo = uint32_t(ta - wa);
-          const uint32_t dw = (bo & 8u) ? ((bo & 4u) ? tw.w : tw.z) : ((bo & 4u) ? tw.y : tw.x);
-          if (((dw >> (8u * (bo & 3u))) & 0xffu) != code) break;
         }
+        if (!stopped)
+          for (; m < lim; m++) {
+            const uint32_t code = wcode(j + m);
+            if (code == 0xFFu) break;                       // anything unusual is left to the ordinary step
+            trace_touch(ix, kTraceTxt, uint64_t(tp - m - ix.txt) >> 7);
+            if (uint32_t(tp[-m]) != code) break;
+          }
         if (m > 0 && m >= best) {
           const int64_t q2 = ix.isa8[p - m];   // isa_shift == 0: the row of every text position
           trace_touch(ix, kTraceIsa, uint64_t(p - m) >> 4);

@@ -44,6 +44,9 @@ struct PackPolicy {
     next = s.c_plus_occ - 1;
   }
   static __device__ __forceinline__ bool is_stop(const DevIndex& ix, uint32_t code) { return (ix.pack_stop >> code) & 1u; }
+  static __device__ __forceinline__ uint32_t max_code(const DevIndex&) { return 7u; }
+  static __device__ __forceinline__ uint32_t stop_info(const DevIndex& ix) { return ix.pack_stop; }
+  static __device__ __forceinline__ bool is_stop_by(uint32_t info, uint32_t code) { return (info >> code) & 1u; }
   static __device__ __forceinline__ uint32_t code_of(const DevIndex& ix, uint32_t ch) {
     const uint32_t c = ix.pack_code[ch];
     return c > 7u ? 0xffffu : c;
@@ -64,6 +67,9 @@ struct Pack2Policy {
     next = s.c_plus_occ - 1;
   }
   static __device__ __forceinline__ bool is_stop(const DevIndex& ix, uint32_t code) { return code < ix.p2_stop_below; }
+  static __device__ __forceinline__ uint32_t max_code(const DevIndex& ix) { return uint32_t(ix.p2_sigma) - 1u; }
+  static __device__ __forceinline__ uint32_t stop_info(const DevIndex& ix) { return ix.p2_stop_below; }
+  static __device__ __forceinline__ bool is_stop_by(uint32_t info, uint32_t code) { return code < info; }
   static __device__ __forceinline__ uint32_t code_of(const DevIndex& ix, uint32_t ch) {
     const uint32_t c = ix.p2_code[ch];
     return c > 255u ? 0xffffu : c;

@@ -127,7 +127,13 @@ int femto_amd_document_info(const femto_amd_index_t* ix, int64_t doc, const char
 /* All pointers are device pointers on the index's device; `stream` is a hipStream_t passed as
  * void* (NULL = default stream).  Calls only enqueue work and return; the caller synchronises.
  * Nothing is reported to the host afterwards: a pattern holding a symbol >= 261 (which the host-pointer
- * calls reject with FEMTO_AMD_ERR_PARAM) has the empty range first = 0, last = -1. */
+ * calls reject with FEMTO_AMD_ERR_PARAM) has the empty range first = 0, last = -1.
+ * READS AROUND THE SYMBOLS: the kernels fetch the patterns in aligned 64-byte chunks, so up to 62 bytes before the first and
+ * behind the last symbol of d_pats[] are LOADED (never used, never written).  An aligned chunk cannot cross a page, so this
+ * cannot fault -- but a memory checker, or a sub-allocator with poisoned guard bytes next to d_pats, will see the reads:
+ * give d_pats 64 bytes of slack on either side, or align its ends to 64 bytes, if that matters.  (femto_amd_locate_device
+ * falls back to a host-synchronising path -- it reads the row total back on `stream` -- for rank modes 0 and 1; the
+ * packed modes 3 / 4 are enqueue-only as stated.) */
 int femto_amd_count_device(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen,
                            const uint16_t* d_pats, const int64_t* d_starts,
                            int64_t* d_first, int64_t* d_last, void* stream);
