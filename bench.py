@@ -141,6 +141,47 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+ENTRY_BYTES = {"level_table": 8, "context_table": 16, "suffix_array": 8, "isa": 8}     # bytes a lookup USES of the 128-byte line it loads
+
+
+def roofline_block(ix, direct, b, npats, plen, max_occs, cnt_ms, loc_ms, cnt_n):
+    """roofline of the dominant kernel of a timed run (without the PMC traffic): see the comment at its call site"""
+    cl, ll, trows = ix.trace_lines(npats, b.d_plen.data_ptr(), b.d_flat.data_ptr(), b.d_starts.data_ptr(), max_occs)
+    n_sym = int(plen.astype(np.int64).sum())
+    stream_count = npats * (4 + 8) + 2 * n_sym + npats * (8 + 8 + 4) + 8 * ((npats + 255) // 256)
+    stream_locate = trows * (8 + 8)                    # the row in, its text offset out
+    comp_count = 128 * sum(cl.values()) + stream_count
+    comp_locate = 128 * sum(ll.values()) + stream_locate
+    dominant_is_count = cnt_ms >= loc_ms
+    k_ms = cnt_ms if dominant_is_count else loc_ms
+    comp = comp_count if dominant_is_count else comp_locate
+    lines = cl if dominant_is_count else ll
+    # what the kernel USES of those lines: a table / array lookup uses one entry of its line, not 128 bytes
+    useful = comp - sum((128 - eb) * lines.get(k, 0) for k, eb in ENTRY_BYTES.items())
+    kname = kernel_names(ix, direct)[0 if dominant_is_count else 1]
+    achieved = comp / (k_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "traffic_source": None, "traffic_GBs": None, "traffic_over_compulsory": None,
+            "useful": {"bytes": useful, "GBs": useful / (k_ms * 1e-3) / 1e9, "frac": useful / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "model": "compulsory bytes with every level-table / context-table / suffix-array / inverse-suffix-array line counted as the "
+                                "entry it is loaded for (8 / 16 / 8 / 8 bytes) instead of 128: line-granular fetches are what the memory moves, "
+                                "entry bytes are what the search needs"},
+            "kernel": kname, "kernel_ms": k_ms, "launches_timed": cnt_n, "count_kernel_ms": cnt_ms, "locate_kernel_ms": loc_ms,
+            "compulsory_bytes_per_launch": comp,
+            "compulsory": {"count": {"distinct_lines": cl, "streamed_bytes": stream_count, "bytes": comp_count},
+                           "locate": {"distinct_lines": ll, "streamed_bytes": stream_locate, "bytes": comp_locate, "rows": trows}},
+            "per_pattern_bytes": comp / npats,
+            "bytes_model": "compulsory bytes: 128 B x distinct lines loaded from each derived array (GPU line trace of the same "
+                           "batch, femto_amd_trace_lines) + arrays streamed once (count: 12 B/pattern + 2 B/symbol in, 20 B/pattern "
+                           "out; locate: 16 B/row); kernel time from HIP events on the launch stream"}, kname, k_ms, comp, comp_count + comp_locate
+
+
+def add_traffic(roof, traffic, traffic_src, k_ms, comp):
+    roof["traffic"], roof["traffic_source"] = traffic, traffic_src
+    roof["traffic_GBs"] = (traffic / (k_ms * 1e-3) / 1e9) if traffic else None
+    roof["traffic_over_compulsory"] = (traffic / comp) if traffic else None
+
+
 class _EventWork:
     """the .wait() of a gather enqueued on a side stream (same shape as torch's async work handle)"""
 
@@ -614,9 +655,26 @@ def main():
                 "rank_mode": {4: "pack2", 3: "pack", 1: "lane", 2: "flat", 0: "raw"}[eix.rank_mode],
                 "value": npats * 3 / ee, "unit": "patterns/s", "ms_per_step": 1e3 * ee / 3, "located_rows": eb.total,
                 "count_kernel_ms": eix.kernel_time("count")[0], "locate_kernel_ms": eix.kernel_time("locate")[0],
-                "parity": "tests/test_gpu_parity.py (oracle, all modes); profiles/r02_eng_bench.json has the run with the reference timed beside it"}
+                "parity": "tests/test_gpu_parity.py (oracle, all modes); profiles/ holds the run with the reference timed beside it"}
+            # its own roofline block: the compulsory lines of THIS batch on THIS index (traced twins of the kernels) and, unless
+            # --pmc off, the memory-side traffic from live rocprofv3 --pmc passes over a child run of the same workload
+            e_cnt, e_n = eix.kernel_time("count")
+            e_loc, _ = eix.kernel_time("locate")
+            e_roof, e_kname, e_kms, e_comp, _ = roofline_block(eix, eix.rank_mode in (3, 4), eb, npats, ep, args.max_occs, e_cnt, e_loc, e_n)
+            e_info = eix.pack_info()
             del eb
             eix.close()
+            eix = None
+            if args.pmc != "off" and world == 1:
+                try:
+                    e_args = argparse.Namespace(**vars(args))
+                    e_args.workload = "eng"
+                    tr, trs = pmc_traffic(e_args, e_kname, e_info)
+                    add_traffic(e_roof, tr, trs, e_kms, e_comp)
+                except Exception as ex:      # noqa: BLE001
+                    log("cfg3 pmc pass failed:", repr(ex))
+            extra["cfg3_text96_count_locate"]["roofline"] = e_roof
+            extra["cfg3_text96_count_locate"]["index"] = e_info
         except Exception as ex:      # noqa: BLE001
             extra["cfg3_text96_count_locate"] = {"error": repr(ex)}
 
@@ -685,17 +743,7 @@ def main():
     # exactly once (pattern lengths / starts / symbols in, ranges and row counts out).  frac <= 1 by construction.
     roof = None
     if cnt_n > 0:
-        cl, ll, trows = ix.trace_lines(npats, batch.d_plen.data_ptr(), batch.d_flat.data_ptr(), batch.d_starts.data_ptr(), args.max_occs)
-        n_sym = int(plen.astype(np.int64).sum())
-        stream_count = npats * (4 + 8) + 2 * n_sym + npats * (8 + 8 + 4) + 8 * ((npats + 255) // 256)
-        stream_locate = trows * (8 + 8)                    # the row in, its text offset out
-        comp_count = 128 * sum(cl.values()) + stream_count
-        comp_locate = 128 * sum(ll.values()) + stream_locate
-        dominant_is_count = cnt_ms >= loc_ms
-        k_ms = cnt_ms if dominant_is_count else loc_ms
-        comp = comp_count if dominant_is_count else comp_locate
-        kname = kernel_names(ix, direct)[0 if dominant_is_count else 1]
-        achieved = comp / (k_ms * 1e-3) / 1e9
+        roof, kname, k_ms, comp, step_bytes = roofline_block(ix, direct, batch, npats, plen, args.max_occs, cnt_ms, loc_ms, cnt_n)
         traffic, traffic_src = None, None
         if args.pmc != "off" and world == 1:
             try:
@@ -704,24 +752,13 @@ def main():
                 log("pmc pass failed:", repr(ex))
         if traffic is None:
             traffic, traffic_src = committed_traffic(args, kname, npats)
-        step_bytes = comp_count + comp_locate
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "traffic_GBs": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
-                "traffic_over_compulsory": (traffic / comp) if traffic else None,
-                "kernel": kname, "kernel_ms": k_ms, "launches_timed": cnt_n,
-                "count_kernel_ms": cnt_ms, "locate_kernel_ms": loc_ms,
-                "compulsory_bytes_per_launch": comp,
-                "compulsory": {"count": {"distinct_lines": cl, "streamed_bytes": stream_count, "bytes": comp_count},
-                               "locate": {"distinct_lines": ll, "streamed_bytes": stream_locate, "bytes": comp_locate, "rows": trows}},
-                "per_pattern_bytes": comp / npats,
-                "whole_step_GBs": step_bytes / (1e-3 * 1e3 * elapsed / args.steps) / 1e9,   # cross-check: compulsory bytes of the step / ms_per_step < peak
-                "bytes_model": "compulsory bytes: 128 B x distinct lines loaded from each derived array (GPU line trace of the same "
-                               "batch, femto_amd_trace_lines) + arrays streamed once (count: 12 B/pattern + 2 B/symbol in, 20 B/pattern "
-                               "out; locate: 16 B/row); kernel time from HIP events on the launch stream",
-                "note": "reference-format equivalent (SURVEY 8d: 335 B per Occ on femto's own wavelet tree) is not what this kernel "
-                        "reads: it walks the derived packed lines after a level table of the first steps"}
+        add_traffic(roof, traffic, traffic_src, k_ms, comp)
+        roof["whole_step_GBs"] = step_bytes / (1e-3 * 1e3 * elapsed / args.steps) / 1e9   # cross-check: compulsory bytes of the step / ms_per_step < peak
+        roof["note"] = ("reference-format equivalent (SURVEY 8d: 335 B per Occ on femto's own wavelet tree) is not what this kernel "
+                        "reads: it walks the derived packed lines after a level table of the first steps")
 
+    if cpu:
+        cpu["gpu_vs_cpu"] = value / cpu["value"]     # a baseline, not a quality measure: the roofline fraction is
     wl = {"acgt": f"T_acgt(2^{args.text_log2}) femto index (default params), {npats} P_rand 20-mers per GPU, count()+locate(max_occs={args.max_occs})",
           "acgt_hit": f"T_acgt(2^{args.text_log2}) femto index (default params), {npats} P_hit 20-mers per GPU, count()+locate(max_occs={args.max_occs})",
           "eng": f"T_eng(2^{args.text_log2}) femto index (default params), {npats} P_hit lengths 8..64 per GPU, count()+locate(max_occs={args.max_occs})"}[args.workload]
@@ -742,7 +779,6 @@ def main():
                                                                                   "; payload = match counts + located offsets" if args.results == "counts" else "; payload = (first,last) ranges")) if world > 1 else ""),
                    "build_s": build_s, "open_s": open_s},
         "roofline": roof, "cpu_baseline": cpu, "reference_equivalent_work": ref_work,
-        "gpu_vs_cpu": (value / cpu["value"]) if cpu else None,
         "extra": extra,
     }
     print(json.dumps(out), flush=True)

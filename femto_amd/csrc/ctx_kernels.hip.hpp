@@ -14,9 +14,10 @@
 //   slot  = 16 bytes {key, value}, key 0 = empty (every field of a key is >= 1);
 //           slots = power of two >= 2 x distinct H-grams; linear probing.
 //
-// A second, WIDE table of the same kind (two-word keys, 32-byte slots {key lo, key hi, value, 0}, H2 <= min(16, 128 / bits))
-// answers patterns of at least H2 symbols: 12 symbols for t ~ 96, after which most sampled patterns of an English-like
-// 1 GiB text are down to a row or two.  A pattern tries the wide table, then the narrow one, then the level table.
+// A second, WIDE table of the same kind (two-word keys, 32-byte slots {key lo, key hi, value, 0}, H2 <= min(16, 128 / bits),
+// 1.4 x the distinct H2-grams slots) answers patterns of at least H2 symbols: 16 symbols for t ~ 96, after which most
+// sampled patterns of an English-like 1 GiB text are down to a row or two (measured: H2 = 11 / 13 / 16 -> 3.29 / 2.99 /
+// 2.78 ms per 10 M-pattern step before the dense pattern window, 2.27 ms with it).  A pattern tries the wide table, then the narrow one, then the level table.
 //
 // The table is COMPLETE for windows without stop characters, so a miss means the range is empty -- exactly what
 // do_string_query (src/main/server.c:832-936) finds after those H steps.  H is the largest of 12, 11, ... whose table fits
@@ -156,8 +157,11 @@ __device__ __forceinline__ void ctx_key2_or(CtxKey2& k, uint64_t field, int sh) 
   }
 }
 
-__device__ __forceinline__ uint64_t ctx_hash2(const CtxKey2& k, int log2_slots) {
-  return ((k.lo * 0x9E3779B97F4A7C15ull) ^ (k.hi * 0xC2B2AE3D27D4EB4Full)) * 0xD6E8FEB86659FD93ull >> (64 - log2_slots);
+// slot of a key in a table of `nslots` slots (any number, not a power of two: the table is 1.4x the distinct keys, not up
+// to 4x): the high half of hash x nslots
+__device__ __forceinline__ uint64_t ctx_hash2(const CtxKey2& k, uint64_t nslots) {
+  const uint64_t h = ((k.lo * 0x9E3779B97F4A7C15ull) ^ (k.hi * 0xC2B2AE3D27D4EB4Full)) * 0xD6E8FEB86659FD93ull;
+  return __umul64hi(h, nslots);
 }
 
 // H-gram (H <= 16) starting at text position p as a wide key ({0,0}: not a key); field i (text order) at bits * (H-1-i)
@@ -204,12 +208,11 @@ __device__ __forceinline__ CtxKey2 ctx_shfl2(const CtxKey2& g, int delta, bool u
 // pass 0: count the group starts; pass 1: every group start claims a slot; pass 2: every group end completes its value
 inline __global__ __launch_bounds__(256) void ctx2_build_kernel(const DevIndex ix, const int64_t row0, const int64_t n, const int H, const uint32_t nstop,
                                                          const int pass, unsigned long long* __restrict__ count,
-                                                         unsigned long long* __restrict__ slots, const int log2_slots) {
+                                                         unsigned long long* __restrict__ slots, const uint64_t nslots) {
   const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const bool in = row < row0 + n;
   const CtxKey2 zero{0, 0};
   const CtxKey2 g = in ? ctx_gram2_of_row(ix, row, H, nstop) : zero;
-  const uint64_t mask = (uint64_t(1) << log2_slots) - 1;
   if (pass < 2) {
     CtxKey2 prev = ctx_shfl2(g, 1, true);
     if ((threadIdx.x & 63u) == 0) prev = in ? ctx_gram2_of_row(ix, row - 1, H, nstop) : zero;
@@ -220,8 +223,8 @@ inline __global__ __launch_bounds__(256) void ctx2_build_kernel(const DevIndex i
       return;
     }
     if (!start) return;
-    uint64_t s = ctx_hash2(g, log2_slots);
-    for (uint64_t probes = 0; probes <= mask; probes++, s = (s + 1) & mask) {
+    uint64_t s = ctx_hash2(g, nslots);
+    for (uint64_t probes = 0; probes < nslots; probes++, s = s + 1 == nslots ? 0 : s + 1) {
       // every distinct key is inserted exactly once (equal keys are contiguous), so a taken slot is simply passed over
       if (atomicCAS(slots + 4 * s, 0ull, static_cast<unsigned long long>(g.lo)) == 0ull) {
         slots[4 * s + 1] = g.hi;
@@ -234,8 +237,8 @@ inline __global__ __launch_bounds__(256) void ctx2_build_kernel(const DevIndex i
   CtxKey2 next = ctx_shfl2(g, 1, false);
   if ((threadIdx.x & 63u) == 63u || row + 1 >= row0 + n) next = in ? ctx_gram2_of_row(ix, row + 1, H, nstop) : zero;
   if (!in || g == zero || g == next) return;
-  uint64_t s = ctx_hash2(g, log2_slots);
-  for (uint64_t probes = 0; probes <= mask; probes++, s = (s + 1) & mask) {
+  uint64_t s = ctx_hash2(g, nslots);
+  for (uint64_t probes = 0; probes < nslots; probes++, s = s + 1 == nslots ? 0 : s + 1) {
     const uint64_t klo = slots[4 * s];
     if (klo == 0) return;
     if (klo == g.lo && slots[4 * s + 1] == g.hi) {
@@ -249,10 +252,9 @@ inline __global__ __launch_bounds__(256) void ctx2_build_kernel(const DevIndex i
 
 // 1: found (first, last set); 0: the H-gram does not occur; -1: too many rows for the value field
 __device__ __forceinline__ int ctx2_lookup(const DevIndex& ix, const CtxKey2& key, int64_t& first, int64_t& last) {
-  const int lg = ix.ctx2_log2;
-  const uint64_t mask = (uint64_t(1) << lg) - 1;
-  uint64_t s = ctx_hash2(key, lg);
-  for (uint64_t probes = 0; probes <= mask; probes++, s = (s + 1) & mask) {
+  const uint64_t nslots = ix.ctx2_slots;
+  uint64_t s = ctx_hash2(key, nslots);
+  for (uint64_t probes = 0; probes < nslots; probes++, s = s + 1 == nslots ? 0 : s + 1) {
     const ulonglong2 e = reinterpret_cast<const ulonglong2*>(ix.ctx2)[2 * s];
     trace_touch(ix, kTraceCtx, uint64_t(ix.ctx2_trace_off) + (s >> 2));
     if (e.x == 0) return 0;

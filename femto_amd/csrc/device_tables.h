@@ -162,9 +162,10 @@ struct DevIndex {           // passed by value to kernels
   int32_t ctx_nstop;        // dense codes below this are characters <= SEOF
   int32_t ctx_bits;         // bits per key field
   const uint64_t* ctx2;     // wide context table: {key lo, key hi, value, 0} slots, or NULL
-  int32_t ctx2_log2;
+  int32_t ctx2_pad;
   int32_t ctx2_syms;        // H2 > ctx_syms
   int64_t ctx2_trace_off;   // its lines follow the narrow table's in the trace region
+  uint64_t ctx2_slots;      // slots of the wide table (any number: slot = high half of hash x slots)
   const int64_t* sa_full;   // SA[row] of EVERY row when HBM allows (8 B/row), else NULL: locate is then one read, no walk
   int32_t isa_shift;        // 0: full inverse suffix array (8 B/row), 3: every 8th position
   int32_t dense_pad;

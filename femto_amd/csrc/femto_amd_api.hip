@@ -804,14 +804,14 @@ int build_ctx(femto_amd_index* ix, int nstop) {
   return 0;
 }
 
-// The wide context table (two-word keys): H2 = the largest of min(16, 128 / bits, 12) .. H1 + 2 whose table (32-byte
-// slots, twice the distinct H2-grams) fits a quarter of the free HBM.  FEMTO_AMD_CTX2=0 disables, FEMTO_AMD_CTX2_SYMS=h forces.
+// The wide context table (two-word keys): H2 = the largest of min(16, 128 / bits) .. H1 + 2 whose table (32-byte
+// slots, 1.4 x the distinct H2-grams) fits a quarter of the free HBM.  FEMTO_AMD_CTX2=0 disables, FEMTO_AMD_CTX2_SYMS=h forces.
 int build_ctx2(femto_amd_index* ix, int nstop) {
   if (ix->dev.ctx2 || !ix->dev.ctx) return 0;
   if (const char* e = getenv("FEMTO_AMD_CTX2")) if (atoi(e) == 0) return 0;
   const int64_t n = ix->host.total_length;
   const int bits = ix->dev.ctx_bits;
-  int hmax = std::min(12, std::min(16, 128 / bits)), hmin = ix->dev.ctx_syms + 2;
+  int hmax = std::min(16, 128 / bits), hmin = ix->dev.ctx_syms + 2;
   if (const char* e = getenv("FEMTO_AMD_CTX2_SYMS")) hmax = hmin = std::max(ix->dev.ctx_syms + 1, std::min(std::min(16, 128 / bits), atoi(e)));
   if (hmin > hmax) return 0;
   size_t free_b = 0, total_b = 0;
@@ -828,39 +828,38 @@ int build_ctx2(femto_amd_index* ix, int nstop) {
   HIP_TRY(hipEventCreate(&e1));
   EventPair ep{e0, e1};
   HIP_TRY(hipEventRecord(e0, nullptr));
-  auto pass = [&](int H, int which, unsigned long long* slots, int lg) {
+  auto pass = [&](int H, int which, unsigned long long* slots, uint64_t nslots) {
     for (int64_t r0 = 0; r0 < n; r0 += chunk) {
       const int64_t cn = std::min(chunk, n - r0);
       hipLaunchKernelGGL(ctx2_build_kernel, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, d, r0, cn, H, uint32_t(nstop), which,
-                         static_cast<unsigned long long*>(cnt.p), slots, lg);
+                         static_cast<unsigned long long*>(cnt.p), slots, nslots);
     }
   };
   for (int H = hmax; H >= hmin; H--) {
     HIP_TRY(hipMemsetAsync(cnt.p, 0, 8, nullptr));
-    pass(H, 0, nullptr, 4);
+    pass(H, 0, nullptr, 64);
     HIP_TRY(hipGetLastError());
     unsigned long long distinct = 0;
     HIP_TRY(hipMemcpy(&distinct, cnt.p, 8, hipMemcpyDeviceToHost));
     if (distinct == 0) continue;
-    int lg = 4;
-    while ((uint64_t(1) << lg) < 2 * distinct) lg++;
-    const int64_t bytes = (int64_t(1) << lg) * 32;
-    if (bytes > budget || lg > 40) continue;
+    const uint64_t nslots = std::max<uint64_t>(64, uint64_t(double(distinct) * 1.4) + 16);     // load factor ~0.7, linear probing
+    const int64_t bytes = int64_t(nslots) * 32;
+    if (bytes > budget) continue;
     if (big_malloc(ix, reinterpret_cast<void**>(&ix->d_ctx2), size_t(bytes)) != hipSuccess) {
       (void)hipGetLastError();
       ix->d_ctx2 = nullptr;
       continue;
     }
     HIP_TRY(big_memset(ix, ix->d_ctx2, 0, size_t(bytes)));
-    pass(H, 1, reinterpret_cast<unsigned long long*>(ix->d_ctx2), lg);
-    pass(H, 2, reinterpret_cast<unsigned long long*>(ix->d_ctx2), lg);
+    pass(H, 1, reinterpret_cast<unsigned long long*>(ix->d_ctx2), nslots);
+    pass(H, 2, reinterpret_cast<unsigned long long*>(ix->d_ctx2), nslots);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
     ix->dev.ctx2 = ix->d_ctx2;
-    ix->dev.ctx2_log2 = lg;
+    ix->dev.ctx2_slots = nslots;
     ix->dev.ctx2_syms = H;
     ix->dev.ctx2_trace_off = ix->ctx_bytes / 128;
     ix->ctx2_bytes = bytes;

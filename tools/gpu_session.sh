@@ -1,7 +1,17 @@
 set -u
-mkdir -p gpurun_out/s6
-bash tools/quick_bench.sh headline -- --pmc off --steps 20 --warmup 5 2>&1 | tee gpurun_out/s6/bench.txt
-bash tools/quick_bench.sh hit -- --pmc off --workload acgt_hit --steps 10 --warmup 3 2>&1 | tee -a gpurun_out/s6/bench.txt
-bash tools/quick_bench.sh reads100 -- --pmc off --workload acgt_hit --plen 100 --npats 4000000 --steps 10 --warmup 3 2>&1 | tee -a gpurun_out/s6/bench.txt
-bash tools/quick_bench.sh eng_ctx2_16 FEMTO_AMD_CTX2_SYMS=16 FEMTO_AMD_CTX2_MB=90000 -- --pmc off --workload eng --steps 6 --warmup 2 2>&1 | tee -a gpurun_out/s6/bench.txt
-python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "not full_size" 2>&1 | tail -15 | tee gpurun_out/s6/parity.txt
+mkdir -p gpurun_out/s7
+SECONDS=0
+python bench.py > gpurun_out/s7/bench_default.json 2> gpurun_out/s7/bench_default.err
+echo "default bench wall: $SECONDS s"
+tail -3 gpurun_out/s7/bench_default.err
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/s7/bench_default.json'))
+r=d['roofline']
+print('headline', round(d['value']/1e9,2), 'G/s', round(d['ms_per_step'],3), 'ms frac', round(r['frac'],3), 'useful', round(r['useful']['frac'],3), 'traffic/comp', r['traffic_over_compulsory'])
+print('cpu', {k:v for k,v in d['cpu_baseline'].items() if k in ('value','cores','kind','gpu_vs_cpu')})
+for k,v in d['extra'].items():
+    print(k, {a:(round(b,3) if isinstance(b,float) else b) for a,b in v.items() if a in ('value','ms_per_step','ms','count_kernel_ms','locate_kernel_ms','error','equal_to_symbol_path')})
+e=d['extra']['cfg3_text96_count_locate'].get('roofline')
+if e: print('cfg3 roofline frac', round(e['frac'],3), 'useful', round(e['useful']['frac'],3), 'traffic/comp', e['traffic_over_compulsory'], 'ctx2', d['extra']['cfg3_text96_count_locate']['index'].get('context2_syms'))
+PY
