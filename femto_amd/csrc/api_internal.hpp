@@ -246,6 +246,7 @@ struct femto_amd_index {
   int64_t regexp_stack_cap = int64_t(1) << 22; // pending ranges one search may hold (option "regexp_stack_cap")
   bool timing = false;
   KernelTimer t_count, t_locate;
+  double pipe_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the last staged host-pointer call (femto_amd_host_pipeline_stats)
   // range-split index (femto_amd_open_split): this handle holds the segment lines and the block images of
   // data blocks [split_blo[part], split_blo[part+1]); the other parts' slices are mapped from their owners
   int split_parts = 0, split_part = 0;

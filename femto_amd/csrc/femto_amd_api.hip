@@ -1391,23 +1391,42 @@ int count_host_pipelined(femto_amd_index* ix, Scratch& S, const HostBatch& hb, i
       return fail(set_err(e_ == hipErrorOutOfMemory ? FEMTO_AMD_ERR_MEM : FEMTO_AMD_ERR_INVALID,                    \
                           std::string(#expr) + ": " + hipGetErrorString(e_)));                                      \
   } while (0)
+  // where the call's wall time goes (femto_amd_host_pipeline_stats): [0] staging threads packing the caller's patterns,
+  // [1] waiting for a pinned input buffer (its previous chunk's kernel), [2] enqueueing copies / kernels / events,
+  // [3] waiting for a chunk's results to arrive, [4] staging threads moving results into the caller's arrays, [5] whole call.
+  // Measured on the GPU box (256 hardware threads, 10 M random 20-mers, 3.7 ms per call): packing 1.9, waiting for results
+  // 0.7, handing back 0.7, enqueueing 0.3 -- the HOST's packing bounds this path, not PCIe (160 MB both ways: 1.6 ms) and
+  // not the kernels (0.4 ms).  A second pool handing results back WHILE the first packs the next chunk made the call
+  // slower (4.2 ms: the two compete for the host's memory system, packing rose to 3.3 ms) and was removed.
+  using clk = std::chrono::steady_clock;
+  auto since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+  double st[6] = {0, 0, 0, 0, 0, 0};
+  const clk::time_point t_call = clk::now();
   for (int64_t c = 0; c <= nchunks; c++) {
     if (c < nchunks) {
       const int b = int(c & 1);
       const int64_t a = c * chunk, e = std::min(hb.npats, a + chunk), n = e - a;
+      clk::time_point t0 = clk::now();
       if (c >= 2) PIPE_TRY(hipEventSynchronize(P.k_done[b]));  // chunk c-2 no longer reads d_in[b] (and h_in[b] was uploaded)
+      st[1] += since(t0);
+      t0 = clk::now();
       char* din = static_cast<char*>(P.d_in[b]);
       const char* hin = static_cast<const char*>(P.h_in[b]);
       // keys when every pattern of the chunk fits one (8 B per pattern over PCIe), symbols otherwise
       const bool as_keys = keys_ok && pipe_stage_keys(ix, hb, a, e, P.h_in[b]) == 1;
       const bool out32 = as_keys && !dev_first && rows32;
       kind[b] = out32 ? 2 : (as_keys ? 3 : 1);
+      int64_t nsym = 0;
+      if (!as_keys) {
+        nsym = pipe_stage(ix, hb, a, e, P.h_in[b]);
+        if (nsym == -1) return fail(-1);
+        if (nsym < -1) return fail(set_err(int(-2 - nsym), "negative pattern length/start or null pattern"));
+      }
+      st[0] += since(t0);
+      t0 = clk::now();
       if (as_keys) {
         PIPE_TRY(hipMemcpyAsync(din, hin, size_t(n) * 8, hipMemcpyHostToDevice, P.s_h2d));
       } else {
-        const int64_t nsym = pipe_stage(ix, hb, a, e, P.h_in[b]);
-        if (nsym == -1) return fail(-1);
-        if (nsym < -1) return fail(set_err(int(-2 - nsym), "negative pattern length/start or null pattern"));
         PIPE_TRY(hipMemcpyAsync(din, hin, size_t(n) * 4, hipMemcpyHostToDevice, P.s_h2d));
         PIPE_TRY(hipMemcpyAsync(din + size_t(kPipeChunk) * 4, hin + size_t(kPipeChunk) * 4, size_t(n) * 8, hipMemcpyHostToDevice, P.s_h2d));
         if (nsym)
@@ -1427,7 +1446,7 @@ int count_host_pipelined(femto_amd_index* ix, Scratch& S, const HostBatch& hb, i
                              reinterpret_cast<const int64_t*>(din + size_t(kPipeChunk) * 4), d_first, d_last, s_k);
       if (rc) return fail(rc);
       PIPE_TRY(hipEventRecord(P.k_done[b], s_k));
-      if (dev_first) continue;
+      if (dev_first) { st[2] += since(t0); continue; }
       PIPE_TRY(hipStreamWaitEvent(P.s_d2h, P.k_done[b], 0));
       char* hout = static_cast<char*>(P.h_out[b]);
       if (out32) {
@@ -1437,11 +1456,15 @@ int count_host_pipelined(femto_amd_index* ix, Scratch& S, const HostBatch& hb, i
         if (last || as_keys) PIPE_TRY(hipMemcpyAsync(hout + size_t(kPipeChunk) * 8, d_last, size_t(n) * 8, hipMemcpyDeviceToHost, P.s_d2h));
       }
       PIPE_TRY(hipEventRecord(P.out_done[b], P.s_d2h));
+      st[2] += since(t0);
     }
     if (c >= 1 && !dev_first) {  // hand chunk c-1 back while chunk c is on its way
       const int b = int((c - 1) & 1);
       const int64_t a = (c - 1) * chunk, e = std::min(hb.npats, a + chunk), n = e - a;
+      clk::time_point t0 = clk::now();
       PIPE_TRY(hipEventSynchronize(P.out_done[b]));
+      st[3] += since(t0);
+      t0 = clk::now();
       const char* hout = static_cast<const char*>(P.h_out[b]);
       const int k = kind[b];      // still chunk c-1's: chunk c went into the other buffer
       std::lock_guard<std::mutex> wl(ix->workers_mu);
@@ -1463,7 +1486,15 @@ int count_host_pipelined(femto_amd_index* ix, Scratch& S, const HostBatch& hb, i
           if (last) memcpy(last + a + i0, hout + size_t(kPipeChunk) * 8 + size_t(i0) * 8, size_t(i1 - i0) * 8);
         }
       });
+      st[4] += since(t0);
     }
+  }
+  st[5] = since(t_call);
+  {
+    std::lock_guard<std::mutex> lk(ix->mu);
+    for (int k = 0; k < 6; k++) ix->pipe_stats[k] = st[k];
+    ix->pipe_stats[6] = double(nchunks);
+    ix->pipe_stats[7] = double(ix->workers->size());
   }
 #undef PIPE_TRY
   if (dev_first) {
@@ -3222,6 +3253,14 @@ int femto_amd_set_option(femto_amd_index_t* ix, const char* name, int value) {
   else if (!strcmp(name, "regexp_max_iterations")) ix->regexp_max_iterations = value;
   else if (!strcmp(name, "regexp_stack_cap")) ix->regexp_stack_cap = std::max(16, value);
   else return set_err(FEMTO_AMD_ERR_PARAM, "unknown option");
+  return FEMTO_AMD_OK;
+}
+
+int femto_amd_host_pipeline_stats(femto_amd_index_t* ix, double* out8) {
+  if (!ix || !out8) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  if (!ix->children.empty()) return femto_amd_host_pipeline_stats(ix->children[0], out8);
+  std::lock_guard<std::mutex> lk(ix->mu);
+  for (int k = 0; k < 8; k++) out8[k] = ix->pipe_stats[k];
   return FEMTO_AMD_OK;
 }
 

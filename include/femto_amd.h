@@ -356,6 +356,11 @@ int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode);
  * "regexp_max_iterations" (default 10^6 = MAX_REGEXP_ITERATIONS), "regexp_stack_cap" (default 2^22). */
 int femto_amd_set_option(femto_amd_index_t* ix, const char* name, int value);
 int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* bytes, double* build_ms, int* ktab_syms);
+/* Where the LAST staged host-pointer batch call (femto_amd_count_flat / _parallel_count ... on >= 2^18 patterns) spent its
+ * wall time, in ms: out8[0] staging threads packing the caller's patterns into pinned key / symbol chunks, [1] waiting for
+ * a pinned input buffer, [2] enqueueing copies / kernels / events, [3] waiting for a chunk's results to arrive over PCIe,
+ * [4] staging threads moving results into the caller's arrays, [5] the whole call; [6] chunks, [7] staging threads. */
+int femto_amd_host_pipeline_stats(femto_amd_index_t* ix, double* out8);
 int femto_amd_get_rank_mode(const femto_amd_index_t* ix);
 
 /* ---- profiling hooks ---------------------------------------------------------------------- */

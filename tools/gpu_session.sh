@@ -1,17 +1,8 @@
 set -u
-mkdir -p gpurun_out/s7
-SECONDS=0
-python bench.py > gpurun_out/s7/bench_default.json 2> gpurun_out/s7/bench_default.err
-echo "default bench wall: $SECONDS s"
-tail -3 gpurun_out/s7/bench_default.err
-python - <<'PY'
-import json
-d=json.load(open('gpurun_out/s7/bench_default.json'))
-r=d['roofline']
-print('headline', round(d['value']/1e9,2), 'G/s', round(d['ms_per_step'],3), 'ms frac', round(r['frac'],3), 'useful', round(r['useful']['frac'],3), 'traffic/comp', r['traffic_over_compulsory'])
-print('cpu', {k:v for k,v in d['cpu_baseline'].items() if k in ('value','cores','kind','gpu_vs_cpu')})
-for k,v in d['extra'].items():
-    print(k, {a:(round(b,3) if isinstance(b,float) else b) for a,b in v.items() if a in ('value','ms_per_step','ms','count_kernel_ms','locate_kernel_ms','error','equal_to_symbol_path')})
-e=d['extra']['cfg3_text96_count_locate'].get('roofline')
-if e: print('cfg3 roofline frac', round(e['frac'],3), 'useful', round(e['useful']['frac'],3), 'traffic/comp', e['traffic_over_compulsory'], 'ctx2', d['extra']['cfg3_text96_count_locate']['index'].get('context2_syms'))
-PY
+mkdir -p gpurun_out/s9
+python bench.py --pmc off --steps 3 --warmup 1 --cpu-sample 0 --no-extra > /dev/null 2>&1   # builds the index
+for cfg in "" "FEMTO_AMD_HOST_THREADS_OUT=16" "FEMTO_AMD_HOST_THREADS_OUT=64" "FEMTO_AMD_HOST_THREADS=96 FEMTO_AMD_HOST_THREADS_OUT=32" "FEMTO_AMD_PIPE_CHUNK_LOG2=19" "FEMTO_AMD_PIPE_CHUNK_LOG2=21"; do
+  env $cfg python tools/host_path_bench.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" | tee -a gpurun_out/s9/host.txt
+done
+python tools/host_locate_bench.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" | tee -a gpurun_out/s9/host.txt
+python -m pytest tests/test_gpu_parity.py tests/test_integration.py -x -q -m gpu -k "not full_size" 2>&1 | tail -8 | tee gpurun_out/s9/parity.txt
