@@ -189,7 +189,8 @@ class _EventWork:
         self.ev = ev
 
     def wait(self):
-        self.ev.synchronize()
+        import torch
+        torch.cuda.current_stream().wait_event(self.ev)     # the compute stream waits; the host does not
 
 
 class Batch:
@@ -303,6 +304,91 @@ class Batch:
         return tot, cnt, off
 
 
+def multi_gpu_extras(args, torch, dist, femto_amd, ix, batch, rank, world, local_rank, dev, backend, native, payload_of, index_path,
+                     elapsed, npats, per_rank):
+    """N > 1 only, after the timed run: the step again (a) without any gather and (b) with the OTHER gather implementation, so
+    one driver run tells search time from gather time and the two gathers apart.  Nothing here has ever run on more than one
+    physical GPU before the driver's scaling run, so every part is guarded: a watchdog prints a minimal result line (the
+    headline value and what is known so far) and ends the process if a part does not finish -- the headline never depends
+    on an extra."""
+    import threading
+    out = {}
+    state = {"phase": "start"}
+
+    def bail():
+        if rank == 0:
+            line = {"metric": "patterns/sec (count+locate) on " + ("1 GiB index" if args.text_log2 == 30 else f"2^{args.text_log2} B index"),
+                    "value": world * npats * args.steps / elapsed, "unit": "patterns/s", "n_gpus": world, "steps": args.steps,
+                    "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+                    "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+                    "config": {"workload": f"{npats} patterns per GPU, count()+locate(max_occs={args.max_occs}), layout {args.layout}",
+                               "per_rank": per_rank, "note": f"multi-GPU extra '{state['phase']}' did not finish within its time limit: "
+                                                             "minimal line, no roofline / cpu_baseline"},
+                    "roofline": None, "cpu_baseline": None, "extra": dict(out, timeout=state["phase"])}
+            print(json.dumps(line), flush=True)
+        os._exit(0)
+
+    def timed(name, fn, steps=5, limit_s=90):
+        state["phase"] = name
+        t = threading.Timer(limit_s, bail)
+        t.daemon = True
+        t.start()
+        try:
+            fn()                                   # warm-up
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            dist.barrier()
+            dt = time.perf_counter() - t0
+            tm = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            out[name] = {"value": world * npats * steps / float(tm.item()), "unit": "patterns/s", "ms_per_step": 1e3 * float(tm.item()) / steps,
+                         "steps": steps}
+        except Exception as ex:      # noqa: BLE001
+            out[name] = {"error": repr(ex)}
+        finally:
+            t.cancel()
+
+    stream = torch.cuda.current_stream().cuda_stream
+    timed("search_only_no_gather", lambda: batch.step(ix, args.max_occs, stream, 0))
+    if backend == "nccl":
+        payload = payload_of(0)
+        nbytes = payload.numel() * payload.element_size()
+        if native:      # the timed run used femto_amd_comm_gather: now torch.distributed.gather (RCCL)
+            lists = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
+
+            def other():
+                batch.step(ix, args.max_occs, stream, 0)
+                dist.gather(payload_of(0), lists, dst=0)
+            timed("gather_torch_distributed", other)
+        else:           # the timed run used torch.distributed.gather: now the C ABI's grouped ncclSend / ncclRecv
+            try:
+                state["phase"] = "native_comm_init"
+                t = threading.Timer(90, bail)
+                t.daemon = True
+                t.start()
+                ids = [femto_amd.Index.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                ix.comm_init(ids[0], world, rank)
+                t.cancel()
+                recv = torch.empty((world,) + tuple(payload.shape), dtype=payload.dtype, device=dev) if rank == 0 else None
+
+                def other():
+                    batch.step(ix, args.max_occs, stream, 0)
+                    p = payload_of(0)
+                    ix.comm_gather(p.data_ptr(), recv.data_ptr() if rank == 0 else 0, nbytes, 0, stream)
+                timed("gather_native_ncclSendRecv", other)
+                out["native_comm"] = ix.comm_info()
+            except Exception as ex:      # noqa: BLE001
+                out["gather_native_ncclSendRecv"] = {"error": repr(ex)}
+        out["gather_payload_bytes_per_rank"] = int(nbytes)
+    state["phase"] = "done"
+    return out if rank == 0 else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -388,6 +474,13 @@ def main():
         build_s = time.time() - t0
     if world > 1:
         dist.barrier()
+    if world > 1 and args.layout in ("split", "striped") and backend == "nccl":
+        # these layouts load lines that live in other GPUs' HBM: every pair must be able to (say so now, readably)
+        ndev_ = torch.cuda.device_count()
+        bad = [(local_rank, j) for j in range(min(world, ndev_)) if j != local_rank and not torch.cuda.can_device_access_peer(local_rank, j)]
+        if bad:
+            raise RuntimeError(f"--layout {args.layout}: no peer access between GPU pairs {bad} (hipDeviceCanAccessPeer); "
+                               "use --layout replicated on this node")
     t0 = time.time()
     ix_keep = None
     if args.layout == "split" and world > 1:
@@ -459,6 +552,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     pending = [None, None]
     counter = {"k": 0}
+    stalls = []         # (event before, event after) every wait for a gather: how long the compute stream stood still
 
     def step():
         # Results are double buffered: the RCCL gather of step k (over xGMI, on RCCL's own stream, ordered
@@ -466,7 +560,11 @@ def main():
         b = counter["k"] & 1
         counter["k"] += 1
         if pending[b] is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             pending[b].wait()          # the buffer's previous gather must be done before it is overwritten
+            e1.record()
+            stalls.append((e0, e1))
             pending[b] = None
         batch.step(ix, args.max_occs, stream, b)
         if native:
@@ -501,6 +599,7 @@ def main():
     ix.kernel_time_reset()
     ix.kernel_time_enable(True)
     torch.cuda.synchronize()
+    stalls.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -516,6 +615,23 @@ def main():
         elapsed = float(tmax.item())
     cnt_ms, cnt_n = ix.kernel_time("count")
     loc_ms, loc_n = ix.kernel_time("locate")
+
+    # ---- N > 1: what every rank saw, so that ONE run explains an efficiency below 1 (search kernels vs waiting for the gather)
+    per_rank, multi_extra = None, None
+    if world > 1:
+        own_elapsed = time.perf_counter() - t0      # (includes the barrier: the spread between ranks shows who was waited for)
+        stall_ms = sum(a.elapsed_time(b) for a, b in stalls) if stalls and backend == "nccl" else 0.0
+        pl = payload_of((counter["k"] - 1) & 1) if counter["k"] else None
+        mine = {"rank": rank, "device": local_rank, "count_kernel_ms": cnt_ms, "locate_kernel_ms": loc_ms,
+                "search_ms_per_step": cnt_ms + loc_ms, "gather_stall_ms_per_step": stall_ms / max(1, args.steps),
+                "gather_waits": len(stalls), "gather_payload_bytes": int(pl.numel() * pl.element_size()) if pl is not None else 0,
+                "located_rows": batch.total, "own_wall_s": own_elapsed, "world_size_seen": dist.get_world_size(),
+                "native_comm": ix.comm_info() if native else None}
+        allr = [None] * world if rank == 0 else None
+        dist.gather_object(mine, allr, dst=0)
+        per_rank = allr
+        multi_extra = multi_gpu_extras(args, torch, dist, femto_amd, ix, batch, rank, world, local_rank, dev, backend, native, payload_of,
+                                       index_path, elapsed, npats, per_rank)
 
     if rank != 0:
         if world > 1:
@@ -722,11 +838,25 @@ def main():
                 ref = np.fromfile(rf, dtype=np.int64)
                 assert np.array_equal(ref[:sub], first[:sub]) and np.array_equal(ref[sub:], last[:sub]), \
                     "GPU ranges differ from the genuine reference"
+                # the reference with num_threads = 2 / 4 / 8 (server_settings_t, src/main/server.c:3484-3602; its
+                # default is forced to 1 at :3597) next to the 1-thread figure -- a third of the sample, 2 timed passes each
+                ref_threads = {}
+                tsample = max(1000, rsample // 3)
+                po.write_fpat_flat(pf, s_plen[:tsample], s_flat[:int(s_starts[tsample - 1] + s_plen[tsample - 1])])
+                for nthr_ref in (2, 4, 8):
+                    try:
+                        o_ = subprocess.run([po.REF_TOOL, "bench", index_path, pf, "locate", str(args.max_occs), str(nthr_ref), "2"],
+                                            check=True, stdout=subprocess.PIPE, timeout=120).stdout.decode()
+                        tj = json.loads(o_.strip().splitlines()[-1])
+                        ref_threads[str(nthr_ref)] = {"value": tsample / tj["mean_s"], "best": tsample / tj["best_s"], "sample": tsample}
+                    except Exception as ex:      # noqa: BLE001
+                        ref_threads[str(nthr_ref)] = {"error": repr(ex)}
             cpu = {"value": rsample / rj["mean_s"], "unit": "patterns/s", "cores": 1, "host_cores": host_cores, "kind": "reference",
                    "sample": f"first {rsample} patterns of the batch through femto's parallel_locate (count + locate, max_occs "
                              f"{args.max_occs}; 1 worker thread = the reference's hard-wired default, src/main/server.c:3597), index in "
                              f"page cache, 1 warm-up + 3 timed passes (mean; best {rsample / rj['best_s']:.0f} patterns/s)",
                    "bit_exact_vs_gpu": True,
+                   "reference_num_threads": ref_threads,
                    "port_all_cores": {"value": sample / port_mt_s, "threads": nthr, "host_cores": host_cores,
                                       "what": f"oracle/femto_oracle.c count+locate on the first {sample} patterns"}}
         else:
@@ -768,7 +898,7 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int64", "data": "synthetic",
         "config": {"workload": wl, "text_bytes": n_text, "patterns_per_gpu": npats, "pattern_len": args.plen, "seed": args.seed,
-                   "located_rows_per_gpu": batch.total, "gathered_results_verified": gathered_ok, "matched_patterns_frac": float(np.mean(last >= first)),
+                   "located_rows_per_gpu": batch.total, "gathered_results_verified": gathered_ok, "per_rank": per_rank, "matched_patterns_frac": float(np.mean(last >= first)),
                    "rank_mode": {4: "pack2", 3: "pack", 1: "lane", 2: "flat", 0: "raw"}[ix.rank_mode], "index": {"rows": int(info.total_length), "blocks": int(info.number_of_blocks), "buckets": int(info.total_buckets),
                              "image_bytes": int(info.image_bytes), "table_bytes": int(info.table_bytes),
                              "packed_lines": ix.pack_info()},
@@ -779,7 +909,7 @@ def main():
                                                                                   "; payload = match counts + located offsets" if args.results == "counts" else "; payload = (first,last) ranges")) if world > 1 else ""),
                    "build_s": build_s, "open_s": open_s},
         "roofline": roof, "cpu_baseline": cpu, "reference_equivalent_work": ref_work,
-        "extra": extra,
+        "extra": extra if extra is not None else multi_extra,
     }
     print(json.dumps(out), flush=True)
     if world > 1:

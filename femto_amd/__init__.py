@@ -37,6 +37,25 @@ class Info(C.Structure):
                 ("image_bytes", C.c_int64), ("table_bytes", C.c_int64)]
 
 
+class Options(C.Structure):
+    """femto_amd_options_t (include/femto_amd.h): every field -1 = auto after femto_amd_options_init"""
+    _fields_ = [("struct_size", C.c_uint32), ("rank_mode", C.c_int32), ("hbm_budget_bytes", C.c_int64), ("packed_lines", C.c_int32),
+                ("two_level_lines", C.c_int32), ("char_rank_lines", C.c_int32), ("text", C.c_int32), ("dense_arrays", C.c_int32),
+                ("mark_every", C.c_int32), ("level_table", C.c_int32), ("level_table_syms", C.c_int32), ("level_table_bytes", C.c_int64),
+                ("context_table", C.c_int32), ("context_syms", C.c_int32), ("context2_table", C.c_int32), ("context2_syms", C.c_int32),
+                ("context2_bytes", C.c_int64), ("tail_min", C.c_int32), ("tail_ones", C.c_int32), ("tail_rows", C.c_int32),
+                ("tail_row_cost", C.c_int32), ("sort_queries", C.c_int32), ("host_threads", C.c_int32), ("host_pipeline", C.c_int32),
+                ("host_keys", C.c_int32), ("host_pipe_chunk_log2", C.c_int32), ("host_d2h_staged", C.c_int32)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        lib().femto_amd_options_init(C.byref(self))
+        for k, v in kw.items():
+            if k not in dict(self._fields_):
+                raise KeyError(k)
+            setattr(self, k, int(v))
+
+
 class NfaStruct(C.Structure):
     """femto_amd_nfa_t (include/femto_amd.h): the reference's nfa_description_t, flat"""
     _fields_ = [("num_nodes", C.c_int32), ("num_transitions", C.c_int32), ("trans_start", C.c_void_p),
@@ -134,9 +153,14 @@ def lib():
         L.femto_amd_comm_unique_id.argtypes = [vp]
         L.femto_amd_comm_init.argtypes = [vp, vp, i32, i32]
         L.femto_amd_comm_gather.argtypes = [vp, vp, vp, i64, i32, vp]
+        L.femto_amd_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
         L.femto_amd_regexp_search.argtypes = [vp, vp, i64, i64, vp, vp, vp, C.POINTER(i64)]
         L.femto_amd_regexp_search_approx.argtypes = [vp, vp, i64, i32, i32, i32, i32, i64, vp, vp, vp, vp, C.POINTER(i64)]
         L.femto_amd_regexp_match.argtypes = [vp, i64, vp, i64]
+        L.femto_amd_options_init.argtypes = [vp]
+        L.femto_amd_options_init.restype = None
+        L.femto_amd_open_opts.argtypes = [C.c_char_p, i32, vp, C.POINTER(vp)]
+        L.femto_amd_host_pipeline_stats.argtypes = [vp, vp]
         L.femto_amd_key_format.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), vp]
         L.femto_amd_pack_keys_device.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
         L.femto_amd_locate_keys_device.argtypes = [vp, i64, vp, i32, vp, vp, vp, vp, vp, vp, i64, vp, vp]
@@ -201,7 +225,7 @@ class Index:
     """A femto index resident in the HBM of one GPU.  device=-1 parses only (host logic tests)."""
 
     def __init__(self, path, device=0, part=None, nparts=None, devices=None, striped=False, striped_socket=None, timeout_s=600,
-                 _borrowed=None):
+                 _borrowed=None, options=None):
         self._h = C.c_void_p()
         self._peers = []   # range-split: the parts attached in-process must outlive this handle's use
         self._owner = None
@@ -215,6 +239,9 @@ class Index:
             fn = lib().femto_amd_open_multi_striped if striped else lib().femto_amd_open_multi
             _check(fn(os.fsencode(path), len(devices), arr, C.byref(self._h)))
             device = list(devices)
+        elif nparts is None and options is not None:    # femto_amd_open_opts: options = Options(...) or a dict of its fields
+            o = options if isinstance(options, Options) else Options(**options)
+            _check(lib().femto_amd_open_opts(os.fsencode(path), device, C.byref(o), C.byref(self._h)))
         elif nparts is None:
             _check(lib().femto_amd_open(os.fsencode(path), device, C.byref(self._h)))
         else:
@@ -421,6 +448,12 @@ class Index:
 
     def comm_init(self, id128, nranks, rank):
         _check(lib().femto_amd_comm_init(self._h, C.create_string_buffer(bytes(id128), 128), int(nranks), int(rank)))
+
+    def comm_info(self):
+        """{'nranks', 'rank'} as the RCCL communicator reports them"""
+        n, r = C.c_int(0), C.c_int(0)
+        _check(lib().femto_amd_comm_info(self._h, C.byref(n), C.byref(r)))
+        return {"nranks": n.value, "rank": r.value}
 
     def comm_gather(self, d_send, d_recv, bytes_per_rank, root=0, stream=0):
         _check(lib().femto_amd_comm_gather(self._h, d_send, d_recv or None, int(bytes_per_rank), int(root), stream or None))

@@ -7,6 +7,7 @@
 
 #include <condition_variable>
 #include <cstdint>
+#include <cstring>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -177,8 +178,17 @@ struct Scratch {
 
 using namespace femto_amd;   // internal header: only the C ABI's own translation units include it
 
+inline femto_amd_options_t femto_amd_auto_options() {
+  femto_amd_options_t o;
+  memset(&o, 0xff, sizeof o);      // every field -1: auto
+  o.struct_size = uint32_t(sizeof o);
+  return o;
+}
+
 struct femto_amd_index {
   HostIndex host;
+  femto_amd_options_t opt = femto_amd_auto_options();   // the caller's options (femto_amd_open_opts); -1 = auto
+  int64_t hbm_free_at_open = -1; // free HBM when this handle started allocating (hbm_budget_bytes is counted from it)
   int device = -1;
   std::mutex mu;   // mode switches, timers
   // device-resident index
@@ -239,6 +249,7 @@ struct femto_amd_index {
   bool sort_queries = true;    // FEMTO_AMD_SORT=0 disables the suffix-order batch sort of the paths that use one
   uint8_t* d_dense = nullptr;  // alpha code -> dense sort digit (characters present in the text)
   std::vector<uint8_t> h_dense; // the same table on the host (key staging of host-pointer batches)
+  std::vector<uint8_t> h_dense16; // ... indexed by any 16-bit symbol value (built on first use, under workers_mu)
   int dense_bits = 8;
   double dense_sigma = 256;    // distinct characters of the indexed text
   int64_t sort_min = 4096;
@@ -319,6 +330,10 @@ int upload(T** dst, const std::vector<T>& src, int64_t* bytes, size_t slack = 0)
 }
 
 
+// A knob's value: the caller's option when it is set, else the FEMTO_AMD_* test override, else the built-in rule (dflt).
+int64_t knob(int64_t opt_value, const char* env_name, int64_t dflt);
+// free HBM as far as this handle may use it: what the device has free, less whatever hbm_budget_bytes forbids
+size_t hbm_free(const femto_amd_index* ix);
 hipError_t big_malloc(femto_amd_index* ix, void** out, size_t bytes);
 void big_free(femto_amd_index* ix, void* p);
 hipError_t big_memset(femto_amd_index* ix, void* p, int v, size_t bytes);

@@ -5,6 +5,8 @@
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/socket.h>
+#include <sys/stat.h>
+#include <poll.h>
 #include <sys/un.h>
 #include <unistd.h>
 #include <cerrno>
@@ -118,6 +120,24 @@ void scratch_release(femto_amd_index* ix, Scratch* s, bool async, hipStream_t st
     s->flight_stream = stream;
   }
   ix->pool_cv.notify_one();
+}
+
+int64_t knob(int64_t opt_value, const char* env_name, int64_t dflt) {
+  if (opt_value != -1) return opt_value;
+  if (const char* e = getenv(env_name)) return atoll(e);
+  return dflt;
+}
+
+size_t hbm_free(const femto_amd_index* ix) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+  if (ix->opt.hbm_budget_bytes >= 0 && ix->hbm_free_at_open >= 0) {
+    const int64_t used = ix->hbm_free_at_open - int64_t(free_b);          // what this handle has taken so far
+    const int64_t left = ix->opt.hbm_budget_bytes - std::max<int64_t>(used, 0);
+    if (left <= 0) return 0;
+    if (size_t(left) < free_b) free_b = size_t(left);
+  }
+  return free_b;
 }
 
 // ---- big arrays: plain hipMalloc, or -- striped index -- one address range backed by the HBM of several GPUs ---------
@@ -282,7 +302,7 @@ int tail_setup(femto_amd_index* ix, Scratch& S, DevIndex& d, int64_t npats, hipS
   if (rc) return rc;
   d.tail_items = S.tail.p;
   d.tail_min = ix->mode == 3 ? 12 : 10;   // about where the walk + compare + ISA lookup beats stepping (1 / 2 lines a step)
-  if (const char* tm = getenv("FEMTO_AMD_TAIL_MIN")) d.tail_min = std::max(2, atoi(tm));
+  d.tail_min = std::max(2, int(knob(ix->opt.tail_min, "FEMTO_AMD_TAIL_MIN", d.tail_min)));
   d.tail_count = S.d_flags + 2;
   HIP_TRY(hipMemsetAsync(d.tail_count, 0, sizeof(int), stream));
   return 0;
@@ -328,15 +348,15 @@ int reserve_plan_sums(Scratch& S, int64_t nblocks, bool fold, hipStream_t stream
 void inline_tail_setup(const femto_amd_index* ix, DevIndex& d) {
   d.tail_min = 4;
   d.tail_ones = ix->mode == 3 ? 2 : 0;
-  if (const char* tm = getenv("FEMTO_AMD_TAIL_MIN")) d.tail_min = std::max(2, atoi(tm));
-  if (const char* to = getenv("FEMTO_AMD_TAIL_ONES")) d.tail_ones = std::max(0, atoi(to));
+  d.tail_min = std::max(2, int(knob(ix->opt.tail_min, "FEMTO_AMD_TAIL_MIN", d.tail_min)));
+  d.tail_ones = std::max(0, int(knob(ix->opt.tail_ones, "FEMTO_AMD_TAIL_ONES", d.tail_ones)));
   // Ranges of 2-4 rows can take the tail too (each row compared, the survivors' rows from the inverse suffix array), but on
   // the sigma~96 workload that loses: the lanes of a wavefront then serialise up to 3 x rows dependent reads while the
   // others wait (10 M sampled patterns: rows = 1 3.48 ms, 2 3.63 ms, 4 3.87-4.08 ms).  Default 1; FEMTO_AMD_TAIL_ROWS <= 4.
   d.tail_rows = 1;
   d.tail_row_cost = 8;
-  if (const char* tr = getenv("FEMTO_AMD_TAIL_ROWS")) d.tail_rows = std::max(1, atoi(tr));
-  if (const char* tc = getenv("FEMTO_AMD_TAIL_ROW_COST")) d.tail_row_cost = std::max(0, atoi(tc));
+  d.tail_rows = std::max(1, int(knob(ix->opt.tail_rows, "FEMTO_AMD_TAIL_ROWS", d.tail_rows)));
+  d.tail_row_cost = std::max(0, int(knob(ix->opt.tail_row_cost, "FEMTO_AMD_TAIL_ROW_COST", d.tail_row_cost)));
 }
 
 // modes 3/4, caller order, no sort (direct_kernels.hip.hpp)
@@ -649,7 +669,7 @@ int stage_patterns(Scratch& S, int64_t npats, const int32_t* plen, const uint16_
 template <class P>
 int build_ktab2(femto_amd_index* ix, int sigma, int nstop) {
   if (ix->dev.ktab2) return 0;
-  if (const char* kt = getenv("FEMTO_AMD_KTAB")) if (atoi(kt) == 0) return 0;
+  if (knob(ix->opt.level_table, "FEMTO_AMD_KTAB", 1) == 0) return 0;
   const int64_t t = sigma - nstop;
   if (t < 1) return 0;
   // the deepest level may hold up to four entries per row (measured on 10 M random DNA 20-mers over 2^30 rows: K = 15
@@ -660,18 +680,18 @@ int build_ktab2(femto_amd_index* ix, int sigma, int nstop) {
   // dense arrays already resident) a quarter stops at K = 15, 60 % admits K = 16 (57 GB): 10 M sampled 20-mers 3.91 -> 3.22 ms
   int64_t budget = INT64_MAX, budget_row = INT64_MAX;
   {
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-      budget = int64_t(free_b / 4);
-      budget_row = int64_t(double(free_b) * 0.6);
-    }
+    const size_t free_b = hbm_free(ix);
+    budget = int64_t(free_b / 4);
+    budget_row = int64_t(double(free_b) * 0.6);
   }
-  if (const char* mb = getenv("FEMTO_AMD_KTAB_MB")) {
+  if (ix->opt.level_table_bytes >= 0) {
+    budget = budget_row = std::max<int64_t>(1, ix->opt.level_table_bytes);
+    level_cap = INT64_MAX;
+  } else if (const char* mb = getenv("FEMTO_AMD_KTAB_MB")) {
     budget = budget_row = std::max<int64_t>(1, atoll(mb)) << 20;
     level_cap = INT64_MAX;
   }
-  int want = -1;
-  if (const char* ks = getenv("FEMTO_AMD_KTAB_SYMS")) want = atoi(ks);
+  const int want = int(knob(ix->opt.level_table_syms, "FEMTO_AMD_KTAB_SYMS", -1));
   // level m holds t^m entries; bytes(K) = 16 * (1 + t + ... + t^(K-1)) + 8 * t^K
   int K = 0;
   int64_t upper = 0, level = 1;       // entries of levels 0..K-1, entries of level K
@@ -733,7 +753,7 @@ int build_ktab2(femto_amd_index* ix, int sigma, int nstop) {
 // the free HBM; not built when even that does not fit, or when it would not save at least two steps over the level table.
 int build_ctx(femto_amd_index* ix, int nstop) {
   if (ix->dev.ctx || !ix->dev.sa_full || !ix->dev.txt || nstop < 1) return 0;   // (nstop >= 1: key 0 stays "empty")
-  if (const char* e = getenv("FEMTO_AMD_CTX")) if (atoi(e) == 0) return 0;
+  if (knob(ix->opt.context_table, "FEMTO_AMD_CTX", 1) == 0) return 0;
   const int64_t n = ix->host.total_length;
   const int kmin = (ix->dev.ktab2 ? ix->dev.kt2_syms : 0) + 2;
   const int t = int(ix->dev.p2_sigma) - nstop;      // table characters
@@ -741,10 +761,9 @@ int build_ctx(femto_amd_index* ix, int nstop) {
   int bits = 1;
   while ((1 << bits) < t + 1) bits++;
   int hmax = std::min(12, 64 / bits), hmin = kmin;
-  if (const char* e = getenv("FEMTO_AMD_CTX_SYMS")) hmax = hmin = std::max(1, std::min(hmax, atoi(e)));
+  if (const int64_t hs = knob(ix->opt.context_syms, "FEMTO_AMD_CTX_SYMS", -1); hs >= 0) hmax = hmin = std::max(1, std::min(hmax, int(hs)));
   if (hmin > hmax) return 0;
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+  const size_t free_b = hbm_free(ix);
   const int64_t budget = int64_t(free_b / 4);
   DeviceBuffer cnt;
   int rc = cnt.reserve(8);
@@ -808,16 +827,19 @@ int build_ctx(femto_amd_index* ix, int nstop) {
 // slots, 1.4 x the distinct H2-grams) fits a quarter of the free HBM.  FEMTO_AMD_CTX2=0 disables, FEMTO_AMD_CTX2_SYMS=h forces.
 int build_ctx2(femto_amd_index* ix, int nstop) {
   if (ix->dev.ctx2 || !ix->dev.ctx) return 0;
-  if (const char* e = getenv("FEMTO_AMD_CTX2")) if (atoi(e) == 0) return 0;
+  if (knob(ix->opt.context2_table, "FEMTO_AMD_CTX2", 1) == 0) return 0;
   const int64_t n = ix->host.total_length;
   const int bits = ix->dev.ctx_bits;
   int hmax = std::min(16, 128 / bits), hmin = ix->dev.ctx_syms + 2;
-  if (const char* e = getenv("FEMTO_AMD_CTX2_SYMS")) hmax = hmin = std::max(ix->dev.ctx_syms + 1, std::min(std::min(16, 128 / bits), atoi(e)));
+  if (const int64_t hs = knob(ix->opt.context2_syms, "FEMTO_AMD_CTX2_SYMS", -1); hs >= 0)
+    hmax = hmin = std::max(ix->dev.ctx_syms + 1, std::min(std::min(16, 128 / bits), int(hs)));
   if (hmin > hmax) return 0;
   size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+  free_b = hbm_free(ix);
+  (void)total_b;
   int64_t budget = int64_t(free_b / 4);
-  if (const char* e = getenv("FEMTO_AMD_CTX2_MB")) budget = std::max<int64_t>(1, atoll(e)) << 20;
+  if (ix->opt.context2_bytes >= 0) budget = std::max<int64_t>(1, ix->opt.context2_bytes);
+  else if (const char* e = getenv("FEMTO_AMD_CTX2_MB")) budget = std::max<int64_t>(1, atoll(e)) << 20;
   DeviceBuffer cnt;
   int rc = cnt.reserve(8);
   if (rc) return rc;
@@ -871,9 +893,9 @@ int build_ctx2(femto_amd_index* ix, int nstop) {
 }
 
 // distance between marks in the derived lines (see "denser marks" in pack_kernels.hip.hpp); 0: keep femto's own
-int derived_mark_every(const HostIndex& h) {
+int derived_mark_every(const HostIndex& h, int h_opt_mark_every) {
   int every = 5;
-  if (const char* e = getenv("FEMTO_AMD_MARK_EVERY")) every = atoi(e);
+  every = int(knob(h_opt_mark_every, "FEMTO_AMD_MARK_EVERY", every));
   if (every <= 0 || every >= h.mark_period) return 0;
   return every;
 }
@@ -882,7 +904,7 @@ int derived_mark_every(const HostIndex& h) {
 int build_pack(femto_amd_index* ix) {
   HostIndex& h = ix->host;
   if (!h.dir_regular || h.total_length <= 0) return 0;
-  if (const char* e = getenv("FEMTO_AMD_PACK")) if (atoi(e) == 0) return 0;
+  if (knob(ix->opt.packed_lines, "FEMTO_AMD_PACK", 1) == 0) return 0;
   std::vector<uint8_t> code(264, 0xff);
   int sigma = 0;
   for (int ch = 0; ch < kAlphaSize; ch++)
@@ -934,7 +956,7 @@ int build_pack(femto_amd_index* ix) {
     hipLaunchKernelGGL(pack_counts_kernel, dim3(uint32_t((nlines + 255) / 256)), dim3(256), 0, nullptr, ix->dev, nlines, ix->d_pack,
                        scans.as<int64_t>(), stride);
     HIP_TRY(hipGetLastError());
-    const int every = derived_mark_every(h);
+    const int every = derived_mark_every(h, ix->opt.mark_every);
     if (every) {  // denser marks: set the extra bits, then recount the marks before every line
       for (int64_t r0 = 0; r0 < n; r0 += chunk) {
         const int64_t cn = std::min(chunk, n - r0);
@@ -985,9 +1007,9 @@ int build_pack(femto_amd_index* ix) {
 int build_pack2(femto_amd_index* ix) {
   HostIndex& h = ix->host;
   if (!h.dir_regular || h.total_length <= 0) return 0;
-  const char* env = getenv("FEMTO_AMD_PACK2");
-  if (env && atoi(env) == 0) return 0;
-  if (ix->dev.pack && !(env && atoi(env) != 0)) return 0;   // the 3-bit lines already serve this index
+  const int64_t want2 = knob(ix->opt.two_level_lines, "FEMTO_AMD_PACK2", -1);   // -1: only where the packed lines do not apply
+  if (want2 == 0) return 0;
+  if (ix->dev.pack && want2 <= 0) return 0;   // the 3-bit lines already serve this index
   std::vector<uint16_t> code(264, 0xffff), alpha(256, uint16_t(kAlphaSize));
   std::vector<int64_t> pc(512, 0);
   int sigma = 0;
@@ -1073,12 +1095,10 @@ int build_pack2(femto_amd_index* ix) {
     HIP_TRY(hipGetLastError());
     d.p2_l2 = ix->d_p2_l2;
     {  // per-character rank lines (ind_kernels.hip.hpp) while the symbols are at hand -- optional: a quarter of the free HBM
-      bool want = true;
-      if (const char* e = getenv("FEMTO_AMD_IND")) want = atoi(e) != 0;
+      const bool want = knob(ix->opt.char_rank_lines, "FEMTO_AMD_IND", 1) != 0;
       const int64_t groups = (n + kIndRows - 1) / kIndRows, istride = groups + 1;
       const size_t ibytes = size_t(sigma) * size_t(istride) * 128;
-      size_t free_b = 0, total_b = 0;
-      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+      const size_t free_b = hbm_free(ix);
       if (want && ibytes <= free_b / 4 && big_malloc(ix, reinterpret_cast<void**>(&ix->d_ind), ibytes + 256) == hipSuccess) {
         HIP_TRY(big_memset(ix, ix->d_ind, 0, ibytes + 256));
         const int64_t gchunk = int64_t(1) << 22;
@@ -1095,7 +1115,7 @@ int build_pack2(femto_amd_index* ix) {
       }
     }
     int64_t sa_bytes = 0;
-    const int every = derived_mark_every(h);
+    const int every = derived_mark_every(h, ix->opt.mark_every);
     int64_t nmarks = tot[16];
     if (every) {  // denser marks (the same rows the 3-bit lines mark, so the offsets array can be shared)
       for (int64_t r0 = 0; r0 < n; r0 += chunk) {
@@ -1158,12 +1178,10 @@ int build_pack2(femto_amd_index* ix) {
 // 8-byte read instead of a walk of LF steps, the row of a text position one read instead of up to 7 LF steps.  This is
 // femto's own space/time knob -- mark_period (src/main/index.c:122-142) -- turned to 1 in HBM; the files stay as they are.
 int build_text(femto_amd_index* ix) {
-  if (const char* e = getenv("FEMTO_AMD_TEXT")) if (atoi(e) == 0) return 0;
+  if (knob(ix->opt.text, "FEMTO_AMD_TEXT", 1) == 0) return 0;
   const int64_t n = ix->host.total_length;
-  bool dense = true;
-  if (const char* e = getenv("FEMTO_AMD_DENSE")) dense = atoi(e) != 0;
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+  const bool dense = knob(ix->opt.dense_arrays, "FEMTO_AMD_DENSE", 1) != 0;
+  const size_t free_b = hbm_free(ix);
   // Dense arrays -- SA of every row and ISA of every position, 8 B each per row -- when the pair takes at most 55 % of
   // the free HBM (the level table, built next, takes at most a quarter of what is left): 17 GB of 288 at 1 GiB of text,
   // 137 GB at 8 GiB (BASELINE configs[4]: a located row is then one read instead of up to four LF steps).  Failing that
@@ -1225,7 +1243,7 @@ int pipe_init(femto_amd_index* ix, Scratch& S) {
       // look-ups, and the staging threads -- not PCIe, not the GPU -- bound this path (measured on the GPU box's
       // 256-thread host, 10 M 20-mers: 16 threads 12.7 ms, 32 9.2 ms, 64 6-9 ms, 128 5.6 ms)
       int nthreads = std::max(4, int(std::thread::hardware_concurrency()) / 2);
-      if (const char* e = getenv("FEMTO_AMD_HOST_THREADS")) nthreads = atoi(e);
+      nthreads = int(knob(ix->opt.host_threads, "FEMTO_AMD_HOST_THREADS", nthreads));
       nthreads = std::max(1, std::min(nthreads, 128));
       ix->workers.reset(new WorkerPool(nthreads));
     }
@@ -1333,24 +1351,31 @@ int pipe_stage_keys(femto_amd_index* ix, const HostBatch& hb, int64_t a, int64_t
   const int64_t n = b - a;
   uint64_t* o_key = static_cast<uint64_t*>(h_in);
   const int bits = ix->dense_bits, nsym = 63 / bits;
-  const uint8_t* dense = ix->h_dense.data();
+  // field of every 16-bit symbol value (0: not a character of the text, or >= ALPHA_SIZE): no bounds test in the loop,
+  // no early exit -- a bad symbol is remembered and the chunk given up afterwards (packing is what bounds this path)
+  if (ix->h_dense16.empty()) {
+    ix->h_dense16.assign(65536, 0);
+    for (size_t c = 0; c < ix->h_dense.size() && c < size_t(kAlphaSize); c++) ix->h_dense16[c] = ix->h_dense[c];
+  }
+  const uint8_t* dense = ix->h_dense16.data();
   const int T = pool.size();
   std::vector<int> partial(size_t(T), 0);
   pool.run([&](int t, int nt) {
     const int64_t i0 = a + n * t / nt, i1 = a + n * (t + 1) / nt;
+    uint32_t bad = 0;
     for (int64_t i = i0; i < i1; i++) {
       const int64_t l = hb.plen[i];
       const uint16_t* pat = hb.ptrs ? hb.ptrs[i] : (hb.starts[i] >= 0 ? hb.flat + hb.starts[i] : nullptr);
       if (l < 0 || l > nsym || (l && !pat)) { partial[size_t(t)] = 1; return; }
       uint64_t key = 0;
       for (int64_t s = l - 1; s >= 0; s--) {   // last symbol first: it lands in the top field
-        const uint32_t ch = pat[s];
-        const uint32_t c = ch < uint32_t(kAlphaSize) ? dense[ch] : 0u;
-        if (c == 0) { partial[size_t(t)] = 1; return; }
+        const uint32_t c = dense[pat[s]];
+        bad |= uint32_t(c == 0);
         key = (key << bits) | c;
       }
       o_key[i - a] = l ? key << (64 - int(l) * bits) : 0;   // field j (from the top) = j-th symbol from the end; 0 = end
     }
+    if (bad) partial[size_t(t)] = 1;
   });
   for (int t = 0; t < T; t++) if (partial[size_t(t)]) return 0;
   return 1;
@@ -1362,7 +1387,7 @@ int pipe_stage_keys(femto_amd_index* ix, const HostBatch& hb, int64_t a, int64_t
 int count_host_pipelined(femto_amd_index* ix, Scratch& S, const HostBatch& hb, int64_t* first, int64_t* last, int64_t* dev_first = nullptr,
                          int64_t* dev_last = nullptr) {
   if (hb.npats < kPipeMin) return -1;
-  if (const char* e = getenv("FEMTO_AMD_HOST_PIPELINE")) if (atoi(e) == 0) return -1;
+  if (knob(ix->opt.host_pipeline, "FEMTO_AMD_HOST_PIPELINE", 1) == 0) return -1;
   int rc = pipe_init(ix, S);
   if (rc) return rc;
   auto& P = S.pipe;
@@ -1371,10 +1396,11 @@ int count_host_pipelined(femto_amd_index* ix, Scratch& S, const HostBatch& hb, i
   // the last chunk's return trip are not overlapped with anything, so smaller stages shorten the call until the per-stage
   // costs take over (10 M 20-mers, 128 staging threads: 2^21 5.5 ms, 2^20 4.0 ms, 2^19 4.6 ms)
   int64_t chunk = kPipeChunk / 2;
-  if (const char* e = getenv("FEMTO_AMD_PIPE_CHUNK_LOG2")) chunk = std::min<int64_t>(kPipeChunk, int64_t(1) << std::max(12, std::min(30, atoi(e))));
+  if (const int64_t lg = knob(ix->opt.host_pipe_chunk_log2, "FEMTO_AMD_PIPE_CHUNK_LOG2", -1); lg >= 0)
+    chunk = std::min<int64_t>(kPipeChunk, int64_t(1) << std::max<int64_t>(12, std::min<int64_t>(30, lg)));
   const int64_t nchunks = (hb.npats + chunk - 1) / chunk;
   bool keys_ok = use_direct(ix) && !ix->h_dense.empty();
-  if (const char* e = getenv("FEMTO_AMD_HOST_KEYS")) keys_ok = keys_ok && atoi(e) != 0;
+  keys_ok = keys_ok && knob(ix->opt.host_keys, "FEMTO_AMD_HOST_KEYS", 1) != 0;
   const bool rows32 = ix->host.total_length < (int64_t(1) << 31) - 1;    // rows (and last + 1, -1) fit 32 bits
   int kind[2] = {1, 1};   // what h_out[b] holds: 1 int64 arrays, 2 int32 (first,last) pairs, 3 int64 arrays of a key chunk (both present)
   // every exit leaves nothing in flight on the pinned buffers
@@ -1561,7 +1587,7 @@ int d2h_staged(femto_amd_index* ix, Scratch& S, void* dst, const void* d_src, si
   auto& P = S.pipe;
   const size_t piece = size_t(kPipeChunk) * 16;
   bool staged = P.ready && ix->workers && bytes >= (size_t(4) << 20);
-  if (const char* e = getenv("FEMTO_AMD_D2H_STAGED")) staged = staged && atoi(e) != 0;
+  staged = staged && knob(ix->opt.host_d2h_staged, "FEMTO_AMD_D2H_STAGED", 1) != 0;
   if (!staged) {
     HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, S.stream));
     HIP_TRY(hipStreamSynchronize(S.stream));
@@ -1668,6 +1694,8 @@ struct Rccl {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;       // optional: femto_amd_comm_info
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
 };
 
 Rccl* rccl() {
@@ -1685,6 +1713,8 @@ Rccl* rccl() {
     R.GroupStart = reinterpret_cast<decltype(R.GroupStart)>(dlsym(R.lib, "ncclGroupStart"));
     R.GroupEnd = reinterpret_cast<decltype(R.GroupEnd)>(dlsym(R.lib, "ncclGroupEnd"));
     R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(dlsym(R.lib, "ncclGetErrorString"));
+    R.CommCount = reinterpret_cast<decltype(R.CommCount)>(dlsym(R.lib, "ncclCommCount"));
+    R.CommUserRank = reinterpret_cast<decltype(R.CommUserRank)>(dlsym(R.lib, "ncclCommUserRank"));
   });
   if (!R.lib || !R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.Send || !R.Recv || !R.GroupStart || !R.GroupEnd) return nullptr;
   return &R;
@@ -1704,12 +1734,16 @@ extern "C" {
 const char* femto_amd_last_error(void) { return g_last_error.c_str(); }
 
 static int open_impl(const char* index_path, int device, int part, int nparts, femto_amd_index_t** out,
-                     const std::vector<int>* stripe = nullptr) {
+                     const std::vector<int>* stripe = nullptr, const femto_amd_options_t* opts = nullptr) {
   if (!index_path || !out) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
   *out = nullptr;
+  if (opts && opts->struct_size != sizeof(femto_amd_options_t))
+    return set_err(FEMTO_AMD_ERR_PARAM, "femto_amd_options_t of another library version (use femto_amd_options_init)");
   const bool split = nparts > 0;
   femto_amd_index* ix = new (std::nothrow) femto_amd_index();
   if (!ix) return set_err(FEMTO_AMD_ERR_MEM, "out of memory");
+  if (opts) ix->opt = *opts;
+  else femto_amd_options_init(&ix->opt);
   if (stripe) ix->stripe_devices = *stripe;     // the big arrays of this handle are striped over these GPUs (big_malloc)
   Error err{0, ""};
   int rc;
@@ -1737,6 +1771,10 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
     }
     auto up = [&]() -> int {
       HIP_TRY(hipSetDevice(device));
+      {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ix->hbm_free_at_open = int64_t(free_b);
+      }
       HostIndex& h = ix->host;
       int r;
       if (!split) {
@@ -1836,7 +1874,7 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         ix->num_cus = prop.multiProcessorCount;
-        if (const char* so = getenv("FEMTO_AMD_SORT")) ix->sort_queries = atoi(so) != 0;
+        ix->sort_queries = knob(ix->opt.sort_queries, "FEMTO_AMD_SORT", 1) != 0;
       }
       ix->mode = h.dir_regular ? 1 : 0;
       if (split) return 0;  // lane kernels only
@@ -1870,12 +1908,14 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
       if (ix->dev.p2_l1 && !ix->dev.pack && (r = build_ctx(ix, int(ix->dev.p2_stop_below))) && r != FEMTO_AMD_ERR_MEM) return r;
       if (ix->dev.ctx && (r = build_ctx2(ix, int(ix->dev.p2_stop_below))) && r != FEMTO_AMD_ERR_MEM) return r;
       for (DeviceBuffer& b : ix->open_scan) b.release();
-      if (const char* m = getenv("FEMTO_AMD_RANK_MODE")) {
-        if (!strcmp(m, "raw")) ix->mode = 0;
-        else if (!strcmp(m, "lane") && h.dir_regular) ix->mode = 1;
-        else if (!strcmp(m, "pack") && ix->dev.pack) ix->mode = 3;
-        else if (!strcmp(m, "pack2") && ix->dev.p2_l1) ix->mode = 4;
-      }
+      int want_mode = ix->opt.rank_mode;
+      if (want_mode < 0)
+        if (const char* m = getenv("FEMTO_AMD_RANK_MODE"))
+          want_mode = !strcmp(m, "raw") ? 0 : (!strcmp(m, "lane") ? 1 : (!strcmp(m, "pack") ? 3 : (!strcmp(m, "pack2") ? 4 : -1)));
+      if (want_mode == 0) ix->mode = 0;
+      else if (want_mode == 1 && h.dir_regular) ix->mode = 1;
+      else if (want_mode == 3 && ix->dev.pack) ix->mode = 3;
+      else if (want_mode == 4 && ix->dev.p2_l1) ix->mode = 4;
       return 0;
     };
     g_small_registry = &ix->small_tables;
@@ -1894,6 +1934,18 @@ static int open_impl(const char* index_path, int device, int part, int nparts, f
   }
   *out = ix;
   return FEMTO_AMD_OK;
+}
+
+void femto_amd_options_init(femto_amd_options_t* o) {
+  if (!o) return;
+  memset(o, 0xff, sizeof *o);             // every field -1: auto
+  o->struct_size = uint32_t(sizeof *o);
+}
+
+int femto_amd_open_opts(const char* index_path, int device, const femto_amd_options_t* opts, femto_amd_index_t** out) {
+  API_BEGIN
+  return open_impl(index_path, device, 0, 0, out, nullptr, opts);
+  API_END
 }
 
 int femto_amd_open(const char* index_path, int device, femto_amd_index_t** out) {
@@ -2792,6 +2844,7 @@ static int make_view(femto_amd_index* b, int device, femto_amd_index** out) {
   h.text_size_bits = s.text_size_bits; h.buckets_per_block = s.buckets_per_block; h.total_buckets = s.total_buckets;
   h.header = s.header; h.C = s.C; h.doc_ends = s.doc_ends; h.doc_info_off = s.doc_info_off; h.dir_regular = s.dir_regular;
   h.block_off = s.block_off; h.block_len = s.block_len;
+  v->opt = b->opt;
   v->mode = b->mode; v->sort_queries = b->sort_queries; v->dense_bits = b->dense_bits;
   v->dense_sigma = b->dense_sigma; v->sort_min = b->sort_min; v->h_dense = b->h_dense; v->table_bytes = b->table_bytes;
   v->ktab2_bytes = b->ktab2_bytes; v->ctx_bytes = b->ctx_bytes; v->ctx2_bytes = b->ctx2_bytes; v->n_marks = b->n_marks; v->p2_lines1 = b->p2_lines1; v->p2_lines2 = b->p2_lines2;
@@ -3011,16 +3064,44 @@ int femto_amd_striped_serve(femto_amd_index_t* ix, const char* socket_path, int 
   strcpy(addr.sun_path, socket_path);
   const int ls = ::socket(AF_UNIX, SOCK_STREAM, 0);
   if (ls < 0) { close_fds(); return set_err(FEMTO_AMD_ERR_IO, "socket()"); }
-  ::unlink(socket_path);
-  if (::bind(ls, reinterpret_cast<struct sockaddr*>(&addr), sizeof addr) || ::listen(ls, 64)) {
+  // The descriptors handed out give read-write access to this process's GPU memory: the socket is created 0600 (the
+  // umask is narrowed around bind()), only a path that IS a socket is replaced, and every client must run as this user
+  // (SO_PEERCRED).  A client rank that died before attaching must not hang the builder: accept() and the hand-shake
+  // wait at most FEMTO_AMD_STRIPED_TIMEOUT seconds (default 600).
+  {
+    struct stat sb;
+    if (::lstat(socket_path, &sb) == 0) {
+      if (!S_ISSOCK(sb.st_mode)) { ::close(ls); close_fds(); return set_err(FEMTO_AMD_ERR_PARAM, std::string(socket_path) + " exists and is not a socket"); }
+      ::unlink(socket_path);
+    }
+  }
+  const mode_t old_umask = ::umask(0177);
+  const int bind_rc = ::bind(ls, reinterpret_cast<struct sockaddr*>(&addr), sizeof addr);
+  ::umask(old_umask);
+  if (bind_rc || ::listen(ls, 64)) {
     ::close(ls);
     close_fds();
     return set_err(FEMTO_AMD_ERR_IO, std::string("bind/listen ") + socket_path + ": " + strerror(errno));
   }
+  int timeout_s = 600;
+  if (const char* e = getenv("FEMTO_AMD_STRIPED_TIMEOUT")) timeout_s = std::max(1, atoi(e));
   int rc = FEMTO_AMD_OK;
   for (int c = 0; c < nclients && rc == FEMTO_AMD_OK; c++) {
+    struct pollfd pfd{ls, POLLIN, 0};
+    const int pr = ::poll(&pfd, 1, timeout_s * 1000);
+    if (pr <= 0) { rc = set_err(FEMTO_AMD_ERR_IO, pr == 0 ? "timed out waiting for a client to attach the striped index" : "poll()"); break; }
     const int cs = ::accept(ls, nullptr, nullptr);
     if (cs < 0) { rc = set_err(FEMTO_AMD_ERR_IO, "accept()"); break; }
+    struct timeval tv{timeout_s, 0};
+    (void)::setsockopt(cs, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+    (void)::setsockopt(cs, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
+    struct ucred cred;
+    socklen_t clen = sizeof cred;
+    if (::getsockopt(cs, SOL_SOCKET, SO_PEERCRED, &cred, &clen) != 0 || cred.uid != ::geteuid()) {
+      ::close(cs);
+      rc = set_err(FEMTO_AMD_ERR_INVALID, "a process of another user tried to attach the striped index");
+      break;
+    }
     const uint64_t len = blob.size();
     char ack = 0;
     if (!send_all(cs, &len, sizeof len) || !send_all(cs, blob.data(), blob.size()) || !send_fds(cs, fds.data(), int(fds.size())) ||
@@ -3143,7 +3224,8 @@ int femto_amd_open_striped_client(const char* index_path, const char* socket_pat
     map.emplace_back(reinterpret_cast<const void*>(r[0]), q);
   }
   remap_small_tables(v, map);
-  HIP_TRY(hipDeviceSynchronize());
+  if (const hipError_t se = hipDeviceSynchronize(); se != hipSuccess)
+    return bail(set_err(FEMTO_AMD_ERR_INVALID, std::string("hipDeviceSynchronize: ") + hipGetErrorString(se)));
   const char ack = 'K';
   (void)send_all(cs, &ack, 1);
   ::close(cs);
@@ -3184,6 +3266,22 @@ int femto_amd_comm_init(femto_amd_index_t* ix, const void* id128, int nranks, in
   RCCL_TRY(R, R->CommInitRank(&ix->comm, nranks, id, rank));
   ix->comm_rank = rank;
   ix->comm_size = nranks;
+  return FEMTO_AMD_OK;
+  API_END
+}
+
+// what the communicator itself says (ncclCommCount / ncclCommUserRank), next to what femto_amd_comm_init was told
+int femto_amd_comm_info(femto_amd_index_t* ix, int* nranks, int* rank) {
+  API_BEGIN
+  if (!ix || !nranks || !rank) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  if (!ix->comm) return set_err(FEMTO_AMD_ERR_INVALID, "no communicator: call femto_amd_comm_init first");
+  Rccl* R = rccl();
+  *nranks = ix->comm_size;
+  *rank = ix->comm_rank;
+  if (R && R->CommCount && R->CommUserRank) {
+    RCCL_TRY(R, R->CommCount(ix->comm, nranks));
+    RCCL_TRY(R, R->CommUserRank(ix->comm, rank));
+  }
   return FEMTO_AMD_OK;
   API_END
 }

@@ -289,6 +289,8 @@ int femto_amd_device_count(const femto_amd_index_t* ix);
 int femto_amd_comm_unique_id(void* id128);
 int femto_amd_comm_init(femto_amd_index_t* ix, const void* id128, int nranks, int rank);
 int femto_amd_comm_gather(femto_amd_index_t* ix, const void* d_send, void* d_recv, int64_t bytes_per_rank, int root, void* stream);
+/* the communicator's own view: ranks it spans and this handle's rank in it (ncclCommCount / ncclCommUserRank) */
+int femto_amd_comm_info(femto_amd_index_t* ix, int* nranks, int* rank);
 
 /* A striped index shared between PROCESSES (one process per GPU; BASELINE.json configs[4], "index range-split across 8
  * GPUs"; the owner of a stripe is position / chunk as the owner of a row is row / block_size in bsearch_block_rows,
@@ -329,6 +331,42 @@ int femto_amd_locate_keys_device(femto_amd_index_t* ix, int64_t npats, const uin
  * one byte per pattern on the links.  Enqueue-only, device pointers. */
 int femto_amd_pack_counts_device(femto_amd_index_t* ix, int64_t npats, const int64_t* d_first, const int64_t* d_last,
                                  uint8_t* d_counts8, int64_t* d_big, int64_t big_capacity, int64_t* d_big_n, void* stream);
+
+/* ---- options of an open handle ---------------------------------------------------------------------------------------------
+ * What is derived at open, and how much HBM it may take, decided by the CALLER: fill the struct with femto_amd_options_init
+ * (every field "auto") and set what matters.  -1 (auto) = the rule described with each field; the environment variables
+ * named in brackets are read ONLY for fields left on auto -- they are test overrides, not the configuration interface.
+ * DESIGN.md 3 has the measured table level_table_syms -> bytes -> ms per step a deployer picks a budget from. */
+typedef struct femto_amd_options {
+  uint32_t struct_size;          /* sizeof(femto_amd_options_t), set by femto_amd_options_init: versions the struct */
+  int32_t rank_mode;             /* -1: the fastest that applies | 0 raw | 1 lane | 3 pack | 4 pack2   [FEMTO_AMD_RANK_MODE] */
+  int64_t hbm_budget_bytes;      /* -1: what is free on the device | bytes this handle may allocate in all: the optional
+                                  * structures are declined (identical results on the slower path) once it is spent */
+  int32_t packed_lines;          /* 0: skip mode 3's lines                                                [FEMTO_AMD_PACK] */
+  int32_t two_level_lines;       /* 0: skip mode 4's lines | 1: build them for <= 8 characters too        [FEMTO_AMD_PACK2] */
+  int32_t char_rank_lines;       /* 0: skip the per-character rank lines of byte alphabets                [FEMTO_AMD_IND] */
+  int32_t text;                  /* 0: skip text + inverse suffix array (no text tail)                    [FEMTO_AMD_TEXT] */
+  int32_t dense_arrays;          /* 0: sampled suffix / inverse suffix arrays only                        [FEMTO_AMD_DENSE] */
+  int32_t mark_every;            /* derived marks every n-th text position, 0 = femto's own marks; auto 5 [FEMTO_AMD_MARK_EVERY] */
+  int32_t level_table;           /* 0: no level table                                                     [FEMTO_AMD_KTAB] */
+  int32_t level_table_syms;      /* K, the deepest level; auto: <= 4 entries per row within the budget   [FEMTO_AMD_KTAB_SYMS] */
+  int64_t level_table_bytes;     /* cap of the level table; auto: a quarter (60 % for <= 1 entry per row) of the free HBM [.._KTAB_MB] */
+  int32_t context_table;         /* 0: no context tables (byte alphabets)                                 [FEMTO_AMD_CTX] */
+  int32_t context_syms;          /* H of the narrow table                                                 [FEMTO_AMD_CTX_SYMS] */
+  int32_t context2_table;        /* 0: no wide table                                                      [FEMTO_AMD_CTX2] */
+  int32_t context2_syms;         /* H2 of the wide table (<= 16)                                          [FEMTO_AMD_CTX2_SYMS] */
+  int64_t context2_bytes;        /* cap of the wide table; auto: a quarter of the free HBM                [FEMTO_AMD_CTX2_MB] */
+  int32_t tail_min, tail_ones, tail_rows, tail_row_cost;   /* thresholds of the text tail (direct_kernels.hip.hpp) [FEMTO_AMD_TAIL_*] */
+  int32_t sort_queries;          /* 0: mode 1 does not order large batches by suffix                      [FEMTO_AMD_SORT] */
+  int32_t host_threads;          /* staging threads of host-pointer batches; auto: half the hardware threads, <= 128 [.._HOST_THREADS] */
+  int32_t host_pipeline;         /* 0: host-pointer batches are staged in one piece                       [FEMTO_AMD_HOST_PIPELINE] */
+  int32_t host_keys;             /* 0: host-pointer batches travel as symbols, never as keys              [FEMTO_AMD_HOST_KEYS] */
+  int32_t host_pipe_chunk_log2;  /* log2 patterns per pipeline stage; auto 20                             [FEMTO_AMD_PIPE_CHUNK_LOG2] */
+  int32_t host_d2h_staged;       /* 0: located offsets return with one plain copy                         [FEMTO_AMD_D2H_STAGED] */
+} femto_amd_options_t;
+void femto_amd_options_init(femto_amd_options_t* opts);
+/* femto_amd_open with options (NULL = all auto = femto_amd_open) */
+int femto_amd_open_opts(const char* index_path, int device, const femto_amd_options_t* opts, femto_amd_index_t** out);
 
 /* ---- kernel family ---------------------------------------------------------------------------- */
 /* Four kernel families, all bit-exact; the default at open is the fastest that applies (mode 3 for <= 8 distinct

@@ -1288,3 +1288,36 @@ def test_keys_device_path_equals_symbol_path(fixtures, gpu_ok, name):
             assert np.array_equal(ostarts.cpu().numpy(), want_starts)
             assert np.array_equal(offs.cpu().numpy()[:int(noccs_ref.sum())], offs_ref), (mo, rep)
     ix.close()
+
+
+@pytest.mark.parametrize("name", ["acgt48k", "eng2doc"])
+def test_open_with_options(fixtures, gpu_ok, name):
+    """femto_amd_open_opts: what is derived is the caller's decision -- a level table of a given depth, none at all, no dense
+    arrays, no context tables, a budget of a few MB (every optional structure declined) -- and the results never change"""
+    fx = fixtures(name)
+    g = fx.gold
+    plen, flat, starts = fx.patterns
+    variants = [dict(level_table_syms=2), dict(level_table=0), dict(dense_arrays=0), dict(text=0), dict(context_table=0),
+                dict(context2_table=0, context_syms=3), dict(hbm_budget_bytes=8 << 20), dict(char_rank_lines=0), dict(rank_mode=1),
+                dict(mark_every=0), dict(tail_min=2, tail_rows=4, tail_row_cost=0)]
+    for kw in variants:
+        ix = femto_amd.Index(fx.index, device=0, options=kw)
+        pi = ix.pack_info()
+        if "level_table_syms" in kw:
+            assert pi["ktab_syms"] == kw["level_table_syms"], (kw, pi)
+        if kw.get("level_table") == 0:
+            assert not pi["level_table"]
+        if kw.get("dense_arrays") == 0 or kw.get("text") == 0:
+            assert not pi["sa_full"]
+        if kw.get("context_table") == 0:
+            assert not pi["context_table"]
+        if "hbm_budget_bytes" in kw:
+            assert not pi["sa_full"] and not pi.get("char_rank_lines"), pi
+        if kw.get("rank_mode") == 1:
+            assert ix.rank_mode == 1
+        first, last = ix.count_flat(plen, flat, starts)
+        assert np.array_equal(first, g["count_first"]) and np.array_equal(last, g["count_last"]), kw
+        for mo, g_noccs, g_offs in fx.locate_cases():
+            noccs, offs = ix.locate_flat(plen, flat, starts, mo)
+            assert np.array_equal(noccs, g_noccs) and np.array_equal(offs, g_offs), (kw, mo)
+        ix.close()

@@ -99,6 +99,66 @@ def test_no_cpu_fallback(fixtures):
             femto_amd.build_index(str(fx.dir) + "/x", [b"ACGT"], device=0)
 
 
+def test_options_struct(fixtures):
+    """femto_amd_options_t: init = every field auto; a struct of another size is refused; a parse-only handle opens with options"""
+    import ctypes as C
+    o = femto_amd.Options()
+    assert o.struct_size == C.sizeof(femto_amd.Options) and o.rank_mode == -1 and o.hbm_budget_bytes == -1 and o.host_d2h_staged == -1
+    o = femto_amd.Options(level_table_syms=8, hbm_budget_bytes=1 << 30, context2_table=0)
+    assert (o.level_table_syms, o.hbm_budget_bytes, o.context2_table, o.text) == (8, 1 << 30, 0, -1)
+    fx = fixtures("acgt48k")
+    ix = femto_amd.Index(fx.index, device=-1, options=o)
+    assert ix.info.total_length == len(fx.prepared_text())
+    ix.close()
+    o.struct_size = 12
+    with pytest.raises(femto_amd.FemtoAmdError) as e:
+        femto_amd.Index(fx.index, device=-1, options=o)
+    assert e.value.code == 3
+    with pytest.raises(KeyError):
+        femto_amd.Options(no_such_field=1)
+
+
+def test_search_cli_output_formats():
+    """femto_search's text output (src/main_cc/search_tool.cc:1082-1113 and print_matches :470-519) restated as a table:
+    format string -> expected bytes for a golden result.  The reference tool itself needs flex/bison + RE2 and cannot be built
+    here, so its formats are RESTATED (from the printf calls cited per row), not diffed against its output; femto_amd_search
+    prints through the same table (--formats) and renders a fixed result with its own print functions (--format-selftest)."""
+    import subprocess
+    from femto_amd import build as b
+    b.build_tools()
+    # (name, the reference's format string with PRIi64 = "li", source line)
+    ref = [("matches_row_head", '% 4li "', 1083), ("matches_row_tail", '"%c', 1085), ("total", "% 4li total matches%c", 1112),
+           ("doc_info", "%.*s", 478), ("doc_sep", "%c%s", 477), ("offsets_lead", "%c\t", 480), ("offset", " %li", 499), ("list_end", "%c", 519)]
+    rows = [r.split("\t") for r in subprocess.run([b.SEARCH, "--formats"], capture_output=True, check=True).stdout.decode().splitlines()]
+    # (offsets_lead holds a tab itself: re-join)
+    table = {r[0]: ("\t".join(r[1:-1]), r[-1]) for r in rows}
+    assert set(table) == {n for n, _, _ in ref}
+    for name, fmt, line in ref:
+        assert table[name] == (fmt, f"search_tool.cc:{line}"), name
+    f = {n: fm.replace("li", "d") for n, fm, _ in ref}      # Python's % operator renders C's "% 4li" as "% 4d"
+
+    def docs(lst, offsets, sep):
+        out, first = b"", True
+        for info, offs in lst:
+            if not first:
+                out += (f["doc_sep"] % (sep, "")).encode()
+            first = False
+            out += info.encode()                           # "%.*s"
+            if offsets:
+                out += (f["offsets_lead"] % sep).encode() + b"".join((f["offset"] % o).encode() for o in offs)
+        return out + ((f["list_end"] % sep).encode() if lst else b"")
+
+    golden = [("doc0.txt", [3, 17, 4242]), ("dir/doc1", [0])]
+    for sep, flag in (("\n", []), ("\0", ["--null"])):
+        want = ((f["matches_row_head"] % 7).encode() + b"the" + (f["matches_row_tail"] % sep).encode()
+                + (f["matches_row_head"] % 12345).encode() + b'a "b"' + (f["matches_row_tail"] % sep).encode()
+                + (f["total"] % (12352, sep)).encode() + docs(golden, True, sep) + docs(golden, False, sep) + docs([], True, sep)
+                + (f["total"] % (0, sep)).encode())
+        got = subprocess.run([b.SEARCH] + flag + ["--format-selftest"], capture_output=True, check=True).stdout
+        assert got == want, (sep, got, want)
+    assert want.startswith(b"   7 \"the\"\x00 12345 ")      # "% 4d": at least four columns, a blank for the sign
+
+
 def test_bseq_encoder_is_byte_identical_to_reference():
     """The 12 sequences x 3 segment-type modes of wtree_test.c:440-580, images captured from the
     reference's bseq_construct_forcetype."""

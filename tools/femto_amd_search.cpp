@@ -31,6 +31,62 @@ static void die(const char* what, int rc) {
   exit(1);
 }
 
+// ---- the output formats, restated from the reference's printf calls (src/main_cc/search_tool.cc; the tool itself needs
+// flex/bison + RE2 and cannot be built in this image, so the formats are restated, not diffed against its output) ----------
+struct Format { const char* name; const char* fmt; const char* ref; };
+static const Format kFormats[] = {
+    {"matches_row_head", "% 4" PRIi64 " \"", "search_tool.cc:1083"},      // then the matched string (fprint_alpha), then ...
+    {"matches_row_tail", "\"%c", "search_tool.cc:1085"},                   // ... the closing quote and the separator
+    {"total", "% 4" PRIi64 " total matches%c", "search_tool.cc:1112"},
+    {"doc_info", "%.*s", "search_tool.cc:478"},                            // a matching document's info string
+    {"doc_sep", "%c%s", "search_tool.cc:477"},                             // between documents: separator + prefix (prefix = "")
+    {"offsets_lead", "%c\t", "search_tool.cc:480"},                        // --offsets: after the info string
+    {"offset", " %" PRIi64, "search_tool.cc:499"},
+    {"list_end", "%c", "search_tool.cc:519"},                              // after the last document of a non-empty list
+};
+static const char* fmt_of(const char* name) {
+  for (const Format& f : kFormats)
+    if (!strcmp(f.name, name)) return f.fmt;
+  abort();
+}
+static void print_matches_row(FILE* out, int64_t n, const char* s, size_t len, char sep) {
+  fprintf(out, fmt_of("matches_row_head"), n);
+  fwrite(s, 1, len, out);            // fprint_alpha of a literal pattern: its bytes
+  fprintf(out, fmt_of("matches_row_tail"), sep);
+}
+static void print_total(FILE* out, int64_t total, char sep) { fprintf(out, fmt_of("total"), total, sep); }
+// documents in document order, each with its offsets ascending; the reference prints the separator BEFORE every document but
+// the first (doc_sep) and femto_search's caller ends the list with one more separator
+static void print_documents(FILE* out, const std::vector<std::pair<std::string, std::vector<int64_t>>>& docs, bool offsets, char sep) {
+  bool first = true;
+  for (const auto& d : docs) {
+    if (!first) fprintf(out, fmt_of("doc_sep"), sep, "");
+    first = false;
+    fprintf(out, fmt_of("doc_info"), int(d.first.size()), d.first.data());
+    if (offsets) {
+      fprintf(out, fmt_of("offsets_lead"), sep);
+      for (int64_t o : d.second) fprintf(out, fmt_of("offset"), o);
+    }
+  }
+  if (!docs.empty()) fprintf(out, fmt_of("list_end"), sep);
+}
+// --formats: the table above, one "name<TAB>format<TAB>reference line" per row; --format-selftest: a fixed result rendered
+// through the very functions the tool prints with (tests/test_host_logic.py compares both with the formats restated there)
+static int print_formats() {
+  for (const Format& f : kFormats) printf("%s\t%s\t%s\n", f.name, f.fmt, f.ref);
+  return 0;
+}
+static int format_selftest(char sep) {
+  print_matches_row(stdout, 7, "the", 3, sep);
+  print_matches_row(stdout, 12345, "a \"b\"", 5, sep);
+  print_total(stdout, 12352, sep);
+  print_documents(stdout, {{"doc0.txt", {3, 17, 4242}}, {"dir/doc1", {0}}}, true, sep);
+  print_documents(stdout, {{"doc0.txt", {3, 17, 4242}}, {"dir/doc1", {0}}}, false, sep);
+  print_documents(stdout, {}, true, sep);
+  print_total(stdout, 0, sep);
+  return 0;
+}
+
 static void usage(const char* name) {
   printf("Usage: %s [options] <index_path> [<index_path>...] <pattern>\n", name);
   printf(" where options include:\n");
@@ -68,6 +124,8 @@ int main(int argc, char** argv) {
     else if (a == "--output") output = next();
     else if (a == "--null") sep = '\0';
     else if (a == "--literal") literal = true;
+    else if (a == "--formats") return print_formats();
+    else if (a == "--format-selftest") return format_selftest(sep);
     else if (a == "--device") device = atoi(next());
     else if (a == "--pattern") { pattern = next(); have_pattern = true; }
     else if (a == "--pattern-from") {
@@ -119,11 +177,7 @@ int main(int argc, char** argv) {
       int64_t first = 0, last = -1;
       if ((rc = femto_amd_count_flat(ix, 1, &plen, pat.data(), &start, &first, &last))) die("femto_amd_count_flat", rc);
       const int64_t n = last >= first ? last - first + 1 : 0;
-      if (matches && n > 0) {
-        fprintf(out, "% 4" PRIi64 " \"", n);
-        fwrite(pattern.data(), 1, pattern.size(), out);
-        fprintf(out, "\"%c", sep);
-      }
+      if (matches && n > 0) print_matches_row(out, n, pattern.data(), pattern.size(), sep);
       total_matches += n;
     } else {
       int32_t noccs = 0;
@@ -141,24 +195,23 @@ int main(int argc, char** argv) {
         hits.emplace_back(doc, doff);
       }
       std::sort(hits.begin(), hits.end());
+      std::vector<std::pair<std::string, std::vector<int64_t>>> docs;
       int64_t prev_doc = -1;
       for (size_t i = 0; i < hits.size(); i++) {
         if (hits[i].first != prev_doc) {
-          if (prev_doc != -1) fputc(sep, out);
           const char* info = nullptr;
           int64_t len = 0;
           if ((rc = femto_amd_document_info(ix, hits[i].first, &info, &len))) die("femto_amd_document_info", rc);
-          fwrite(info, 1, size_t(len), out);
-          if (offsets) fprintf(out, "%c\t", sep);
+          docs.emplace_back(std::string(info, size_t(len)), std::vector<int64_t>());
           prev_doc = hits[i].first;
         }
-        if (offsets) fprintf(out, " %" PRIi64, hits[i].second);
+        docs.back().second.push_back(hits[i].second);
       }
-      if (!hits.empty()) fputc(sep, out);
+      print_documents(out, docs, offsets, sep);
     }
     femto_amd_close(ix);
   }
-  if (count) fprintf(out, "% 4" PRIi64 " total matches%c", total_matches, sep);
+  if (count) print_total(out, total_matches, sep);
   if (out != stdout) fclose(out);
   return 0;
 }

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (source_hash)
 
-KEEP = ("count_direct_kernel", "count_tail_kernel", "plan_rows_kernel", "plan_scan_kernel", "locate_walk_kernel", "count_keys_kernel",
+KEEP = ("count_direct_kernel", "count_tail_kernel", "plan_rows_kernel", "plan_super_kernel", "locate_walk_kernel", "count_keys_kernel",
         "count_kernel", "locate_kernel")
 
 
@@ -40,7 +40,7 @@ def main():
             if keep:
                 out.append(ln)
         open(os.path.join(ROOT, "profiles", f"{tag}_stats.txt"), "w").write("\n".join(out) + "\n")
-        if tag == "r02_default":
+        if tag.endswith("_default"):
             pmc = json.load(open(os.path.join(src, "pmc_summary.json")))
             d = json.loads(line)
             kname = d["roofline"]["kernel"]

@@ -15,10 +15,14 @@ import bench  # noqa: E402
 import femto_amd  # noqa: E402
 from femto_amd import textgen as tg  # noqa: E402
 
-path = os.environ.get("FEMTO_AMD_BENCH_DIR", "/tmp/femto_amd_bench") + "/acgt_2p30_s20260928"
+lg = int(os.environ.get("TEXT_LOG2", "30"))      # 33: BASELINE configs[4]'s 8 GiB text (is every line a TLB miss because of HOW the arrays are mapped?)
+path = os.environ.get("FEMTO_AMD_BENCH_DIR", "/tmp/femto_amd_bench") + f"/acgt_2p{lg}_s20260928"
 n = int(os.environ.get("NPATS", "10000000"))
 dev = torch.device("cuda", 0)
-plen, flat = tg.p_rand(20, n, 123)
+if os.environ.get("WORKLOAD", "rand") == "hit":
+    plen, flat = tg.p_hit(20, 20, n, 123, np.asarray(np.load(path + ".text.npy", mmap_mode="r")))
+else:
+    plen, flat = tg.p_rand(20, n, 123)
 st = torch.cuda.current_stream().cuda_stream
 for what in ("plain", "striped x2 on one GPU"):
     if what == "plain":
