@@ -134,7 +134,7 @@ struct DevIndex {           // passed by value to kernels
   int32_t kt2_syms;         // deepest level K
   int32_t kt2_base;         // t = number of table characters (characters of the text that are not <= SEOF)
   int32_t kt2_nstop;        // dense codes below this are <= SEOF: digit = dense code - kt2_nstop
-  int32_t kt2_pad;
+  int32_t kt2_deep_big;     // deepest-level entries with at least this many rows store "recompute" (0xffffff by default)
   const uint64_t* kt2_deep; // the deepest level, compact: first (40 bits) | rows in the range (24 bits; 0xffffff: see ktab2_lookup)
   int64_t kt2_deep_off;     // heap position of the deepest level's first entry
   uint32_t* trace;          // NULL, or the line bitmaps of femto_amd_trace_lines: bit trace_off[region] + line index

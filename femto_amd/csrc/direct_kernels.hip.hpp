@@ -55,7 +55,8 @@ inline __global__ void ktab2_root_kernel(const DevIndex ix, longlong2* __restric
 // The deepest level holds three quarters of the entries and its ranges are short, so it is stored compactly: 8 bytes =
 // first (40 bits: the format's 2^39 rows) | number of rows (24 bits).  A dead range has last == first - 1 by construction
 // (first = C+Occ(c,first-1), last = C+Occ(c,last)-1 with equal Occs), i.e. 0 rows; a range of 2^24 - 1 rows or more
-// (highly repetitive text) stores 0xffffff and is recomputed from its parent with one ordinary step.
+// (highly repetitive text) stores 0xffffff and is recomputed from its parent with one ordinary step.  (DevIndex::kt2_deep_big is
+// that bound; a test lowers it -- FEMTO_AMD_KTAB_DEEP_BIG -- so that the recomputation runs on every fixture.)
 constexpr uint64_t kDeepBig = 0xffffffu;
 constexpr uint64_t kDeepFirstMask = (uint64_t(1) << 40) - 1;
 
@@ -72,7 +73,7 @@ inline __global__ __launch_bounds__(256) void ktab2_deep_kernel(const DevIndex i
   int64_t first = e.x, last = int64_t(uint64_t(e.y) & kKtabLastMask) - 1;
   if (first <= last) P::search_step(ix, level - 1, digit + uint32_t(ix.kt2_nstop), first, last);
   const uint64_t rows = first <= last ? uint64_t(last - first + 1) : 0;
-  deep[i] = (uint64_t(first) & kDeepFirstMask) | ((rows < kDeepBig ? rows : kDeepBig) << 40);
+  deep[i] = (uint64_t(first) & kDeepFirstMask) | ((rows < uint64_t(ix.kt2_deep_big) ? rows : kDeepBig) << 40);
 }
 
 // the table entry of heap position `pos` at level m: the (first,last) after searching those m symbols

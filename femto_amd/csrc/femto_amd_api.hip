@@ -721,6 +721,8 @@ int build_ktab2(femto_amd_index* ix, int sigma, int nstop) {
   d.kt2_syms = K;
   d.kt2_base = int32_t(t);
   d.kt2_nstop = nstop;
+  d.kt2_deep_big = 0xffffff;
+  if (const char* e = getenv("FEMTO_AMD_KTAB_DEEP_BIG")) d.kt2_deep_big = std::max(1, std::min(0xffffff, atoi(e)));    // test hook
   longlong2* tab = reinterpret_cast<longlong2*>(ix->d_ktab2);
   hipLaunchKernelGGL(ktab2_root_kernel, dim3(1), dim3(64), 0, nullptr, d, tab);
   int64_t cnt = 1;
@@ -743,6 +745,7 @@ int build_ktab2(femto_amd_index* ix, int sigma, int nstop) {
   ix->dev.kt2_syms = K;
   ix->dev.kt2_base = int32_t(t);
   ix->dev.kt2_nstop = nstop;
+  ix->dev.kt2_deep_big = d.kt2_deep_big;
   ix->ktab2_bytes = upper * 16 + level * 8;
   ix->table_bytes += ix->ktab2_bytes;
   return 0;
@@ -864,7 +867,7 @@ int build_ctx2(femto_amd_index* ix, int nstop) {
     unsigned long long distinct = 0;
     HIP_TRY(hipMemcpy(&distinct, cnt.p, 8, hipMemcpyDeviceToHost));
     if (distinct == 0) continue;
-    const uint64_t nslots = std::max<uint64_t>(64, uint64_t(double(distinct) * 1.4) + 16);     // load factor ~0.7, linear probing
+    const uint64_t nslots = (std::max<uint64_t>(64, uint64_t(double(distinct) * 1.4) + 16) + 3) & ~uint64_t(3);   // load ~0.7, buckets of four slots
     const int64_t bytes = int64_t(nslots) * 32;
     if (bytes > budget) continue;
     if (big_malloc(ix, reinterpret_cast<void**>(&ix->d_ctx2), size_t(bytes)) != hipSuccess) {

@@ -1321,3 +1321,25 @@ def test_open_with_options(fixtures, gpu_ok, name):
             noccs, offs = ix.locate_flat(plen, flat, starts, mo)
             assert np.array_equal(noccs, g_noccs) and np.array_equal(offs, g_offs), (kw, mo)
         ix.close()
+
+
+@pytest.mark.parametrize("name", ["acgt48k", "runs3doc", "eng2doc"])
+def test_level_table_deep_entries_recomputed(fixtures, gpu_ok, monkeypatch, name):
+    """The deepest level of the level table stores (first, rows) in 8 bytes; an entry with 2^24 - 1 rows or more stores
+    "recompute" and its range is derived from its parent with one ordinary step (ktab2_lookup).  No fixture has 16.7 M rows
+    under one K-gram, so the bound is lowered (FEMTO_AMD_KTAB_DEEP_BIG = 1 / 2 / 5): every deepest-level entry with that many
+    rows then takes the recomputation, and every result must still be the reference's."""
+    fx = fixtures(name)
+    g = fx.gold
+    plen, flat, starts = fx.patterns
+    for big in (1, 2, 5):
+        monkeypatch.setenv("FEMTO_AMD_KTAB_DEEP_BIG", str(big))
+        for k in (1, 2, 3):
+            ix = femto_amd.Index(fx.index, device=0, options=dict(level_table_syms=k))
+            assert ix.pack_info()["ktab_syms"] == k
+            first, last = ix.count_flat(plen, flat, starts)
+            assert np.array_equal(first, g["count_first"]) and np.array_equal(last, g["count_last"]), (big, k)
+            for mo, g_noccs, g_offs in fx.locate_cases():
+                noccs, offs = ix.locate_flat(plen, flat, starts, mo)
+                assert np.array_equal(noccs, g_noccs) and np.array_equal(offs, g_offs), (big, k, mo)
+            ix.close()
