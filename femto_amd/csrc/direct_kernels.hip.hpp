@@ -200,7 +200,7 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
       if (jmax < base) return;
       const uintptr_t a_hi = reinterpret_cast<uintptr_t>(pat + (len - 1 - base));   // symbol j = base (the highest address)
       const uintptr_t a_lo = reinterpret_cast<uintptr_t>(pat + (len - 1 - jmax));
-      // aligned 32-byte pieces, both halves loaded together (a 20-mer is two of them)
+      // (a REfill: patterns of more than 64 symbols) aligned 32-byte pieces, both halves loaded together
       for (uintptr_t piece = a_hi & ~uintptr_t(31); piece + 31 >= a_lo; piece -= 32) {
         const uint4 va = reinterpret_cast<const uint4*>(piece)[0], vb = reinterpret_cast<const uint4*>(piece)[1];
 #pragma unroll
@@ -220,6 +220,40 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
         }
       }
     };
+    // The FIRST window (symbols 0 .. 63: all of a pattern of up to 64 symbols) is filled here, once, from aligned 64-byte
+    // chunks whose four 16-byte loads are issued together -- a line of the caller's symbols is fetched while it is hot.
+    // (32 wavefronts per CU each hold 64 x 200 bytes of 100-mers in flight: far more than the L1, more than the CU's share of
+    // the L2.  With one 32-byte piece per loop iteration every line was visited four times, iterations apart, and re-fetched:
+    // 3.4x the compulsory traffic on 100-mers, measured; the refills further down keep the small pieces -- they are rare and
+    // sit inside the search loops, where a chunk in registers spills.)
+    if (len > 0 && len <= 24) {
+      fill(0);          // short patterns (a 20-mer is two 32-byte pieces): the small fill is cheaper -- the chunks below cost the
+                        // headline batch 0.07 ms per launch, measured
+    } else if (len > 0) {
+      w0 = 0;
+      const int jmax = (len < 64 ? len : 64) - 1;
+      const uintptr_t a_hi = reinterpret_cast<uintptr_t>(pat + (len - 1));
+      const uintptr_t a_lo = reinterpret_cast<uintptr_t>(pat + (len - 1 - jmax));
+      for (uintptr_t chunk = a_hi & ~uintptr_t(63); chunk + 63 >= a_lo; chunk -= 64) {
+        const uint4* g = reinterpret_cast<const uint4*>(chunk);
+        const uint4 v0 = g[0], v1 = g[1], v2 = g[2], v3 = g[3];
+#pragma unroll
+        for (int sl = 31; sl >= 0; sl--) {
+          const uintptr_t a = chunk + 2u * uint32_t(sl);
+          if (a > a_hi || a < a_lo) continue;
+          const uint4& v = sl < 8 ? v0 : (sl < 16 ? v1 : (sl < 24 ? v2 : v3));
+          const int s8 = sl & 7;
+          const uint32_t w = s8 < 2 ? v.x : (s8 < 4 ? v.y : (s8 < 6 ? v.z : v.w));
+          const uint32_t ch = (sl & 1) ? w >> 16 : w & 0xffffu;
+          uint32_t b = 0xFFu;
+          if (ch < uint32_t(kAlphaSize)) {
+            const uint32_t c = s_code[ch];
+            if (c < 255u && !P::is_stop(ix, c)) b = c;
+          }
+          win[waddr(uint32_t((a_hi - a) >> 1))] = uint8_t(b);
+        }
+      }
+    }
     auto wcode = [&](int j) -> uint32_t {    // dense code of the j-th symbol from the end, or 0xFF
       if (j < w0 || j >= w0 + 64) fill(j & ~3);
       return win[waddr(uint32_t(j - w0))];

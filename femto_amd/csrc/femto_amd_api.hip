@@ -867,9 +867,16 @@ int build_ctx2(femto_amd_index* ix, int nstop) {
     unsigned long long distinct = 0;
     HIP_TRY(hipMemcpy(&distinct, cnt.p, 8, hipMemcpyDeviceToHost));
     if (distinct == 0) continue;
-    const uint64_t nslots = (std::max<uint64_t>(64, uint64_t(double(distinct) * 1.4) + 16) + 3) & ~uint64_t(3);   // load ~0.7, buckets of four slots
+    // slots: twice the distinct keys when that fits the budget (load 0.5: nearly every look-up ends in its first line),
+    // else 1.7x, else 1.4x (load 0.7: a quarter of the look-ups run on into a second line -- the sigma~96 count kernel ran
+    // 2.2 instead of 1.85 ms); only then a shorter key
+    uint64_t nslots = 0;
+    for (const double f : {2.0, 1.7, 1.4}) {
+      const uint64_t cand = (std::max<uint64_t>(64, uint64_t(double(distinct) * f) + 16) + 3) & ~uint64_t(3);
+      if (int64_t(cand) * 32 <= budget) { nslots = cand; break; }
+    }
+    if (!nslots) continue;
     const int64_t bytes = int64_t(nslots) * 32;
-    if (bytes > budget) continue;
     if (big_malloc(ix, reinterpret_cast<void**>(&ix->d_ctx2), size_t(bytes)) != hipSuccess) {
       (void)hipGetLastError();
       ix->d_ctx2 = nullptr;

@@ -1293,12 +1293,12 @@ def test_keys_device_path_equals_symbol_path(fixtures, gpu_ok, name):
 @pytest.mark.parametrize("name", ["acgt48k", "eng2doc"])
 def test_open_with_options(fixtures, gpu_ok, name):
     """femto_amd_open_opts: what is derived is the caller's decision -- a level table of a given depth, none at all, no dense
-    arrays, no context tables, a budget of a few MB (every optional structure declined) -- and the results never change"""
+    arrays, no context tables, a budget of 64 KB (the fixtures are tiny: every optional structure declined) -- and the results never change"""
     fx = fixtures(name)
     g = fx.gold
     plen, flat, starts = fx.patterns
     variants = [dict(level_table_syms=2), dict(level_table=0), dict(dense_arrays=0), dict(text=0), dict(context_table=0),
-                dict(context2_table=0, context_syms=3), dict(hbm_budget_bytes=8 << 20), dict(char_rank_lines=0), dict(rank_mode=1),
+                dict(context2_table=0, context_syms=3), dict(hbm_budget_bytes=1 << 16), dict(char_rank_lines=0), dict(rank_mode=1),
                 dict(mark_every=0), dict(tail_min=2, tail_rows=4, tail_row_cost=0)]
     for kw in variants:
         ix = femto_amd.Index(fx.index, device=0, options=kw)
