@@ -339,6 +339,10 @@ void big_free(femto_amd_index* ix, void* p);
 hipError_t big_memset(femto_amd_index* ix, void* p, int v, size_t bytes);
 hipError_t big_h2d(femto_amd_index* ix, void* p, const void* src, size_t bytes);
 int ensure_device(femto_amd_index* ix);
+void comm_destroy(femto_amd_index* ix);     // api_multi.hip: the RCCL communicator of femto_amd_comm_init, if any
+// femto_amd_open and its variants: part / nparts: a range-split part; stripe: the big arrays over these GPUs' HBM
+int open_impl(const char* index_path, int device, int part, int nparts, femto_amd_index_t** out, const std::vector<int>* stripe = nullptr,
+              const femto_amd_options_t* opts = nullptr);
 int check_err_flag(Scratch& S, hipStream_t stream);
 bool timer_begin(femto_amd_index* ix, KernelTimer& t, hipStream_t stream, hipEvent_t* e0, hipEvent_t* e1);
 void timer_end(femto_amd_index* ix, KernelTimer& t, hipStream_t stream, hipEvent_t e0, hipEvent_t e1);
