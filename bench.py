@@ -873,7 +873,12 @@ def main():
     # exactly once (pattern lengths / starts / symbols in, ranges and row counts out).  frac <= 1 by construction.
     roof = None
     if cnt_n > 0:
-        roof, kname, k_ms, comp, step_bytes = roofline_block(ix, direct, batch, npats, plen, args.max_occs, cnt_ms, loc_ms, cnt_n)
+        try:
+            roof, kname, k_ms, comp, step_bytes = roofline_block(ix, direct, batch, npats, plen, args.max_occs, cnt_ms, loc_ms, cnt_n)
+        except femto_amd.FemtoAmdError as ex:      # the line trace follows the packed modes' pipeline: modes 0 / 1 report times only
+            roof = None
+            log("no roofline block:", ex)
+    if roof is not None:
         traffic, traffic_src = None, None
         if args.pmc != "off" and world == 1:
             try:

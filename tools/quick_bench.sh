@@ -8,7 +8,7 @@ env "${envs[@]}" python bench.py --cpu-sample 20000 --no-extra "$@" 2>/tmp/qb.er
 import sys,json
 t=sys.stdin.read()
 try:
-    d=json.loads(t); r=d['roofline']
-    print('$label', '|', round(d['value']/1e6,1), 'Mpat/s', round(d['ms_per_step'],2), 'ms/step frac', round(r['frac'],3), r['kernel'], 'count_ms', round(r['count_kernel_ms'],2), 'locate_ms', round(r['locate_kernel_ms'],2), 'rows', d['config']['located_rows_per_gpu'])
+    d=json.loads(t); r=d.get('roofline') or {}
+    print('$label', '|', round(d['value']/1e6,1), 'Mpat/s', round(d['ms_per_step'],2), 'ms/step frac', round(r.get('frac') or 0,3), r.get('kernel'), 'count_ms', round(r.get('count_kernel_ms') or 0,2), 'locate_ms', round(r.get('locate_kernel_ms') or 0,2), 'rows', d['config']['located_rows_per_gpu'])
 except Exception as e:
     print('$label FAILED', e, t[:300]); print(open('/tmp/qb.err').read()[-1500:])"
