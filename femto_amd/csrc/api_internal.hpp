@@ -254,7 +254,9 @@ struct femto_amd_index {
   double dense_sigma = 256;    // distinct characters of the indexed text
   int64_t sort_min = 4096;
   int64_t regexp_max_iterations = 1000000;   // MAX_REGEXP_ITERATIONS (src/main/server.c:40); option "regexp_max_iterations"
-  int64_t regexp_stack_cap = int64_t(1) << 22; // pending ranges one search may hold (option "regexp_stack_cap")
+  int64_t regexp_stack_cap = int64_t(1) << 18; // pending ranges one search may hold (option "regexp_stack_cap", <= 2^22): a
+                                               // child looks for a pending entry with its range by scanning them, so the bound also
+                                               // bounds the time a pattern such as `a.*b` (96 children per step) can take: seconds
   bool timing = false;
   KernelTimer t_count, t_locate;
   double pipe_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the last staged host-pointer call (femto_amd_host_pipeline_stats)

@@ -2779,7 +2779,7 @@ int femto_amd_set_option(femto_amd_index_t* ix, const char* name, int value) {
   std::lock_guard<std::mutex> lk(ix->mu);
   if (!strcmp(name, "sort")) ix->sort_queries = value != 0;
   else if (!strcmp(name, "regexp_max_iterations")) ix->regexp_max_iterations = value;
-  else if (!strcmp(name, "regexp_stack_cap")) ix->regexp_stack_cap = std::max(16, value);
+  else if (!strcmp(name, "regexp_stack_cap")) ix->regexp_stack_cap = std::min(1 << 22, std::max(16, value));
   else return set_err(FEMTO_AMD_ERR_PARAM, "unknown option");
   return FEMTO_AMD_OK;
 }

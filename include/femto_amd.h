@@ -214,7 +214,7 @@ int femto_amd_split_info(const femto_amd_index_t* ix, int* part, int* nparts, in
  * included (a range with a final state alive is a result and is NOT extended; a pending range reached again is merged).
  * status_out[q] (may be NULL): 0, FEMTO_AMD_ERR_OVERWORKED (more than MAX_REGEXP_ITERATIONS = 10^6 steps, server.c:40,1821:
  * the reference returns ERR_OVERWORKED and no results) or FEMTO_AMD_ERR_FULL (more pending ranges than option
- * "regexp_stack_cap", default 2^22; the reference has no such bound).  The out arrays hold max_results entries for ALL
+ * "regexp_stack_cap", default 2^18, at most 2^22; the reference has no such bound -- it would run on to ERR_OVERWORKED).  The out arrays hold max_results entries for ALL
  * automata together; *n_out = results in total; max_results == 0 only counts; more results than max_results is
  * FEMTO_AMD_ERR_FULL with *n_out = the number needed (before de-duplication).  Limits: 2048 nodes, 2^22 transitions per
  * automaton, costs and cost_bound 1..255 (errors are counted in one byte, nfa.h:74-76). */
@@ -391,7 +391,7 @@ int femto_amd_open_opts(const char* index_path, int device, const femto_amd_opti
  * slower than what replaced them and were removed.) */
 int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode);
 /* Runtime switches of an open handle: "sort" (default 1: mode 1 orders large batches by pattern suffix),
- * "regexp_max_iterations" (default 10^6 = MAX_REGEXP_ITERATIONS), "regexp_stack_cap" (default 2^22). */
+ * "regexp_max_iterations" (default 10^6 = MAX_REGEXP_ITERATIONS), "regexp_stack_cap" (default 2^18). */
 int femto_amd_set_option(femto_amd_index_t* ix, const char* name, int value);
 int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* bytes, double* build_ms, int* ktab_syms);
 /* Where the LAST staged host-pointer batch call (femto_amd_count_flat / _parallel_count ... on >= 2^18 patterns) spent its

@@ -252,7 +252,7 @@ def test_iteration_limit_and_stack_bound(fixtures):
     assert status[3] == 0 and start[4] - start[3] == 1
     with pytest.raises(femto_amd.FemtoAmdError):
         ix.regexp_search(pats[0])
-    ix.set_option("regexp_stack_cap", 1 << 22)
+    ix.set_option("regexp_stack_cap", 1 << 18)
     # the search that outgrew the first arena is run again in a larger one: same results as unbounded
     first1, last1, mlen1 = ix.regexp_search(pats[0])
     want = o.nfa_search(nfas[0])
