@@ -1,10 +1,9 @@
 #!/usr/bin/env python3
 """tools/regexp_bench.py: batched automaton search (femto_amd_nfa_search_batch = do_regexp_query for many automata, one
 workgroup each) on the bench index: N random DNA motifs with classes, alternations and optional symbols, exact and APPROX 1;
-the genuine reference (oracle/_ref/ref_tool regexp_nfa, one CPU thread) on a sample of the same automata, results compared."""
+GPU timing only -- bench.py's `extra.regexp_batch` line times the genuine reference beside a batch and compares the result lists."""
 import os
 import sys
-import tempfile
 import time
 
 import numpy as np
@@ -12,7 +11,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import femto_amd  # noqa: E402
-from oracle import pyoracle as po  # noqa: E402
 
 path = os.environ.get("FEMTO_AMD_BENCH_DIR", "/tmp/femto_amd_bench") + "/acgt_2p30_s20260928"
 N = int(os.environ.get("NREGEX", "20000"))
@@ -47,14 +45,5 @@ for what, approx, k in (("exact motifs of 14-18 terms", None, (14, 19)), ("APPRO
     nodes = np.mean([a.num_nodes for a in nfas])
     line = "%-34s %6d automata (%.0f nodes avg): %.1f ms per batch = %.0f automata/s, %d result ranges, %d not ok" % (
         what, N, nodes, 1e3 * best, N / best, len(first), int((status != 0).sum()))
-    if po.have_ref():
-        m = 200
-        with tempfile.TemporaryDirectory() as td:
-            t0 = time.perf_counter()
-            ref = po.ref_regexp_nfa(path, nfas[:m], td)
-            dt = time.perf_counter() - t0
-        same = all(r[0] == int(status[i]) and np.array_equal(r[1], first[start[i]:start[i + 1]]) and np.array_equal(r[2], last[start[i]:start[i + 1]])
-                   and np.array_equal(r[3], mlen[start[i]:start[i + 1]]) and np.array_equal(r[4], cost[start[i]:start[i + 1]]) for i, r in enumerate(ref))
-        line += "; reference (1 thread, %d of them incl. process start): %.0f automata/s, identical results: %s" % (m, m / dt, same)
     print(line, flush=True)
 ix.close()
