@@ -376,9 +376,11 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
     return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
   if (!ix->children.empty())
     return femto_amd_nfa_search_batch(ix->children[0], nq, nfas, max_results, result_start, first_out, last_out, len_out, cost_out, status_out, n_out);
-  int rc = ensure_device(ix);
-  if (rc) return rc;
   *n_out = 0;
+  int rc;
+  for (int64_t qi = 0; qi < nq; qi++)       // malformed automata are refused before anything touches the device
+    if ((rc = validate_nfa(nfas[qi], qi))) return rc;
+  if ((rc = ensure_device(ix))) return rc;
   if (nq == 0) return FEMTO_AMD_OK;
   const int mode = ix->mode;
   if (mode != 3 && mode != 4 && !ix->host.dir_regular)
@@ -392,7 +394,6 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   int max_nodes = 1;
   for (int64_t qi = 0; qi < nq; qi++) {
     const femto_amd_nfa_t& a = nfas[qi];
-    if ((rc = validate_nfa(a, qi))) return rc;
     NfaQueryDev& Q = hq[size_t(qi)];
     Q.node_off = int64_t(h_flags.size());
     Q.ent_off = int64_t(h_sd.size());

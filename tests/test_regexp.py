@@ -127,6 +127,32 @@ def test_hostile_patterns_are_refused_not_crashed():
     assert femto_amd.Nfa.from_regex(b"abc", (1, 2, 1, 2)).settings == (2, 2, 1, 2)
 
 
+def test_malformed_automata_are_refused(fixtures):
+    """femto_amd_nfa_search_batch validates every automaton before anything reaches the device: destinations and characters in
+    range, monotone transition starts, costs and cost_bound 1..255 (errors are counted in one byte), at most 2048 nodes"""
+    fx = fixtures("acgt48k")
+    ix = femto_amd.Index(fx.index, device=-1)            # parse-only handle: validation comes first, then "no device"
+    good = femto_amd.Nfa([0, 1, 1], [70], [1], [1, 0], [0, 1])
+    with pytest.raises(femto_amd.FemtoAmdError) as e:
+        ix.nfa_search_batch([good])
+    assert e.value.code == femto_amd.ERR_INVALID           # well-formed: only the missing device stops it
+    bad = [femto_amd.Nfa([0, 1, 1], [70], [2], [1, 0], [0, 1]),            # destination out of range
+           femto_amd.Nfa([0, 1, 1], [261], [1], [1, 0], [0, 1]),           # character >= ALPHA_SIZE
+           femto_amd.Nfa([0, 1, 1], [-1], [1], [1, 0], [0, 1]),
+           femto_amd.Nfa([0, 2, 1], [70], [1], [1, 0], [0, 1]),            # starts not monotone / not spanning
+           femto_amd.Nfa([1, 1, 1], [70], [1], [1, 0], [0, 1]),
+           femto_amd.Nfa([0, 1, 1], [70], [1], [1, 0], [0, 1], (0, 1, 1, 1)),      # cost_bound < 1
+           femto_amd.Nfa([0, 1, 1], [70], [1], [1, 0], [0, 1], (256, 1, 1, 1)),
+           femto_amd.Nfa([0, 1, 1], [70], [1], [1, 0], [0, 1], (2, 0, 1, 1)),      # a cost < 1
+           femto_amd.Nfa([0, 1, 1], [70], [1], [1, 0], [0, 1], (2, 1, 1, 300)),
+           femto_amd.Nfa([0] * 2050, [], [], [1] * 2049, [0] * 2049)]              # too many nodes
+    for a in bad:
+        with pytest.raises(femto_amd.FemtoAmdError) as e:
+            ix.nfa_search_batch([good, a])
+        assert e.value.code == femto_amd.ERR_PARAM, (a.trans_start[:3], a.settings)
+    ix.close()
+
+
 @pytest.mark.parametrize("name", REGEXP_FIXTURES)
 def test_compiled_automata_equal_the_golden_ones(name):
     """the construction (parser -> Thompson -> position automaton of the reversed pattern) is deterministic and pinned:
