@@ -29,6 +29,7 @@
 // DNA index) and the table at most a quarter of the free HBM; the deepest level is stored in 8 bytes per entry (see
 // ktab2_deep_kernel): 22.9 + 34.4 GB there.  FEMTO_AMD_KTAB_SYMS / FEMTO_AMD_KTAB_MB override.
 #pragma once
+#include <type_traits>
 
 namespace femto_amd {
 
@@ -171,91 +172,78 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
     const DevIndex ix, const int64_t npats, const int32_t* __restrict__ plen, const uint16_t* __restrict__ pats,
     const int64_t* __restrict__ starts, int64_t* __restrict__ first_out, int64_t* __restrict__ last_out, int* __restrict__ err_flag,
     const int max_occs, int32_t* __restrict__ noccs, const PlanSums ps, int* __restrict__ big_flag) {
+  constexpr int kWinDw = 18, kWin = 4 * kWinDw;   // the window: 72 symbols per lane
   __shared__ uint16_t s_code[264];
+  __shared__ uint8_t s_byte[264];
   __shared__ int64_t s_w[4];
-  __shared__ uint32_t s_win[16 * 256];       // 64 dense pattern codes per lane (see fill() below)
-  for (int i = threadIdx.x; i < kAlphaSize; i += blockDim.x) s_code[i] = uint16_t(P::code_of(ix, uint32_t(i)));
+  __shared__ uint32_t s_win[kWinDw * 256];
+  for (int i = threadIdx.x; i < 264; i += blockDim.x) {
+    const uint32_t c = i < kAlphaSize ? uint32_t(P::code_of(ix, uint32_t(i))) : 0xffffu;
+    s_code[i] = uint16_t(c);
+    s_byte[i] = uint8_t((c < 255u && !P::is_stop(ix, c)) ? c : 0xFFu);     // the window's byte for this symbol
+  }
   __syncthreads();
   const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   int64_t nocc = 0;
   if (q < npats) {
     const int len = plen[q];
     const uint16_t* pat = pats + starts[q];
-    // The lane's window on its pattern: the DENSE codes of symbols j = w0 .. w0 + 63 (j counts from the pattern's END, the
+    // The lane's window on its pattern: the DENSE codes of symbols j = w0 .. w0 + 71 (j counts from the pattern's END, the
     // order a backward search reads them in), one byte each, in LDS (byte k of lane t in dword (k >> 2) * 256 + t: bank =
-    // t mod 32, the minimum for 64 lanes).  Filled from aligned 64-byte chunks of the caller's symbols, each symbol translated ONCE
-    // (alpha code -> dense code through s_code); 0xFF = "look at the alpha symbol": a code >= ALPHA_SIZE, a character the
-    // text lacks, a character <= SEOF, or dense code 255 -- the fast paths stop there and the ordinary step below reads the
-    // symbol itself.  Every later use -- table digits, context keys, search steps, the comparison with the text, four symbols
-    // per iteration -- reads bytes of the window.  (Round 2 kept the raw 64-byte chunk and translated every symbol at every
-    // use: 5 800 VALU wave-instructions per wavefront on the sigma~96 workload, half of them in the byte-by-byte text
-    // comparison -- the kernel was issue-bound, not memory-bound.)  The aligned 64-byte chunks reach at most 62 bytes before /
-    // behind the pattern and never cross a page (include/femto_amd.h says so).
+    // t mod 32, the minimum for 64 lanes).  Each symbol is translated ONCE (alpha code -> window byte through s_byte);
+    // 0xFF = "look at the alpha symbol": a code >= ALPHA_SIZE, a character the text lacks, a character <= SEOF, or dense
+    // code 255 -- the fast paths stop there and the ordinary step below reads the symbol itself.  Every later use --
+    // table digits, context keys, search steps, the comparison with the text, eight symbols per iteration -- reads bytes
+    // of the window.  (Round 2 kept the raw 64-byte chunk and translated every symbol at every use: 5 800 VALU
+    // wave-instructions per wavefront on the sigma~96 workload.)
+    //
+    // w0 is chosen so that every PAIR of window dwords is one ALIGNED 16-byte piece of the caller's symbols: symbol j lives
+    // at pat + (len - 1 - j), so with w0 = (pat / 2 + len) mod 8 (mod 8) the eight symbols of dwords 2e, 2e+1 are the piece
+    // at pat + (len - 8 - w0) - 8 e, highest address = lowest j = byte 0.  One 16-byte load, eight table reads, two LDS
+    // writes per eight symbols, no per-symbol range test, and as few load INSTRUCTIONS as the pattern allows (a 20-mer: three
+    // or four) -- a load whose 64 lanes hit different lines keeps the CU's address unit busy for ~64 cycles whatever its
+    // width, and that unit is what bounds this kernel (ind_kernels.hip.hpp has the numbers).  The first version tested and
+    // stored byte by byte: 18 VALU instructions per symbol.  A piece at either end of the pattern may hold symbols of the
+    // neighbours (at most 7 = 14 bytes before / behind the pattern, never across a 16-byte boundary, so never across a
+    // page); their window bytes are never read.
+    auto phase = [&]() -> int { return int(((reinterpret_cast<uintptr_t>(pat) >> 1) + uintptr_t(uint32_t(len))) & 7u); };   // (recomputed: one register less across the search loops)
     int w0 = -(1 << 30);         // no window yet
     uint8_t* const win = reinterpret_cast<uint8_t*>(s_win);
     auto waddr = [&](uint32_t k) -> uint32_t { return (((k >> 2) * 256u + threadIdx.x) << 2) + (k & 3u); };
-    auto fill = [&](int base) {  // base: a multiple of 4
-      w0 = base;
-      const int jmax = (len < base + 64 ? len : base + 64) - 1;
-      if (jmax < base) return;
-      const uintptr_t a_hi = reinterpret_cast<uintptr_t>(pat + (len - 1 - base));   // symbol j = base (the highest address)
-      const uintptr_t a_lo = reinterpret_cast<uintptr_t>(pat + (len - 1 - jmax));
-      // (a REfill: patterns of more than 64 symbols) aligned 32-byte pieces, both halves loaded together
-      for (uintptr_t piece = a_hi & ~uintptr_t(31); piece + 31 >= a_lo; piece -= 32) {
-        const uint4 va = reinterpret_cast<const uint4*>(piece)[0], vb = reinterpret_cast<const uint4*>(piece)[1];
+    auto tr4 = [&](const uint32_t a, const uint32_t b) -> uint32_t {     // symbols (a lo, a hi, b lo, b hi) at rising addresses = falling j
+      auto T = [&](uint32_t sym) -> uint32_t { return s_byte[sym < 263u ? sym : 263u]; };
+      return T(b >> 16) | (T(b & 0xffffu) << 8) | (T(a >> 16) << 16) | (T(a & 0xffffu) << 24);
+    };
+    // window at w0 = nw0 (== phase mod 8): kB pieces are loaded together, then translated
+    auto fill_at = [&](const int nw0, auto batch) {
+      constexpr int kB = decltype(batch)::value;
+      w0 = nw0;
+      int emax = (len - 1 - nw0) >> 3;
+      emax = emax < kWinDw / 2 - 1 ? emax : kWinDw / 2 - 1;
+      const uint16_t* const gp0 = pat + (len - 8 - nw0);
+#pragma unroll 1
+      for (int e0 = 0; e0 <= emax; e0 += kB) {
+        uint4 v[kB];
 #pragma unroll
-        for (int sl = 15; sl >= 0; sl--) {
-          const uintptr_t a = piece + 2u * uint32_t(sl);
-          if (a > a_hi || a < a_lo) continue;
-          const uint4& v = sl < 8 ? va : vb;
-          const int s8 = sl & 7;
-          const uint32_t w = s8 < 2 ? v.x : (s8 < 4 ? v.y : (s8 < 6 ? v.z : v.w));
-          const uint32_t ch = (sl & 1) ? w >> 16 : w & 0xffffu;
-          uint32_t b = 0xFFu;
-          if (ch < uint32_t(kAlphaSize)) {
-            const uint32_t c = s_code[ch];
-            if (c < 255u && !P::is_stop(ix, c)) b = c;
+        for (int i = 0; i < kB; i++)
+          if (e0 + i <= emax) v[i] = *reinterpret_cast<const uint4*>(gp0 - 8 * (e0 + i));
+#pragma unroll
+        for (int i = 0; i < kB; i++)
+          if (e0 + i <= emax) {
+            s_win[uint32_t(2 * (e0 + i)) * 256u + threadIdx.x] = tr4(v[i].z, v[i].w);
+            s_win[uint32_t(2 * (e0 + i) + 1) * 256u + threadIdx.x] = tr4(v[i].x, v[i].y);
           }
-          win[waddr(uint32_t((a_hi - a) >> 1))] = uint8_t(b);
-        }
       }
     };
-    // The FIRST window (symbols 0 .. 63: all of a pattern of up to 64 symbols) is filled here, once, from aligned 64-byte
-    // chunks whose four 16-byte loads are issued together -- a line of the caller's symbols is fetched while it is hot.
-    // (32 wavefronts per CU each hold 64 x 200 bytes of 100-mers in flight: far more than the L1, more than the CU's share of
-    // the L2.  With one 32-byte piece per loop iteration every line was visited four times, iterations apart, and re-fetched:
-    // 3.4x the compulsory traffic on 100-mers, measured; the refills further down keep the small pieces -- they are rare and
-    // sit inside the search loops, where a chunk in registers spills.)
-    if (len > 0 && len <= 24) {
-      fill(0);          // short patterns (a 20-mer is two 32-byte pieces): the small fill is cheaper -- the chunks below cost the
-                        // headline batch 0.07 ms per launch, measured
-    } else if (len > 0) {
-      w0 = 0;
-      const int jmax = (len < 64 ? len : 64) - 1;
-      const uintptr_t a_hi = reinterpret_cast<uintptr_t>(pat + (len - 1));
-      const uintptr_t a_lo = reinterpret_cast<uintptr_t>(pat + (len - 1 - jmax));
-      for (uintptr_t chunk = a_hi & ~uintptr_t(63); chunk + 63 >= a_lo; chunk -= 64) {
-        const uint4* g = reinterpret_cast<const uint4*>(chunk);
-        const uint4 v0 = g[0], v1 = g[1], v2 = g[2], v3 = g[3];
-#pragma unroll
-        for (int sl = 31; sl >= 0; sl--) {
-          const uintptr_t a = chunk + 2u * uint32_t(sl);
-          if (a > a_hi || a < a_lo) continue;
-          const uint4& v = sl < 8 ? v0 : (sl < 16 ? v1 : (sl < 24 ? v2 : v3));
-          const int s8 = sl & 7;
-          const uint32_t w = s8 < 2 ? v.x : (s8 < 4 ? v.y : (s8 < 6 ? v.z : v.w));
-          const uint32_t ch = (sl & 1) ? w >> 16 : w & 0xffffu;
-          uint32_t b = 0xFFu;
-          if (ch < uint32_t(kAlphaSize)) {
-            const uint32_t c = s_code[ch];
-            if (c < 255u && !P::is_stop(ix, c)) b = c;
-          }
-          win[waddr(uint32_t((a_hi - a) >> 1))] = uint8_t(b);
-        }
-      }
-    }
+    // The FIRST window holds all of a pattern of up to 64 symbols; its loads are issued four pieces = 64 bytes at a time,
+    // so a line of the caller's symbols is fetched while it is hot.  (32 wavefronts per CU each hold 64 x 200 bytes of
+    // 100-mers in flight: far more than the L1, more than the CU's share of the L2.  Visiting every line four times,
+    // iterations apart, re-fetched it: 3.4x the compulsory traffic on 100-mers, measured.)  Refills (patterns of more than
+    // 64 symbols) sit inside the search loops, where four pieces in registers spill: two at a time there.
+    if (len > 0) fill_at(-((8 - phase()) & 7), std::integral_constant<int, 4>{});
+    auto refill = [&](int j) { fill_at(j - ((j - phase()) & 7), std::integral_constant<int, 2>{}); };
     auto wcode = [&](int j) -> uint32_t {    // dense code of the j-th symbol from the end, or 0xFF
-      if (j < w0 || j >= w0 + 64) fill(j & ~3);
+      if (j < w0 || j >= w0 + kWin) refill(j);
       return win[waddr(uint32_t(j - w0))];
     };
     auto alpha = [&](int j) -> uint32_t { return pat[len - 1 - j]; };     // the symbol itself (0xFF cases only)
@@ -363,9 +351,28 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
         int m = 0;                       // symbols matched
         bool stopped = false;
         if (fast_cmp) {
-          while (m + 4 <= lim) {
+          while (m + 8 <= lim) {          // eight symbols per load (the loads are what this loop costs)
             const int jj = j + m;
-            if (jj < w0 || jj + 4 > w0 + 64) fill(jj & ~3);
+            if (jj < w0 || jj + 8 > w0 + kWin) refill(jj);
+            const uint32_t k = uint32_t(jj - w0), d = k >> 2, sh = k & 3u;
+            const uint32_t wa = s_win[d * 256u + threadIdx.x], wb = s_win[(d + 1u) * 256u + threadIdx.x];
+            const uint32_t wc = sh ? s_win[(d + 2u) * 256u + threadIdx.x] : 0u;
+            const uint64_t pw = uint64_t(__builtin_amdgcn_alignbyte(wb, wa, sh)) | (uint64_t(__builtin_amdgcn_alignbyte(wc, wb, sh)) << 32);
+            uint64_t tw;
+            __builtin_memcpy(&tw, tp - m - 7, 8);                                  // txt[p-8-m .. p-1-m]
+            trace_touch(ix, kTraceTxt, uint64_t(tp - m - 7 - ix.txt) >> 7);
+            trace_touch(ix, kTraceTxt, uint64_t(tp - m - ix.txt) >> 7);
+            const uint64_t x = pw ^ __builtin_bswap64(tw);                          // byte 0: symbol j+m against txt[p-1-m]
+            if (x) {
+              m += (__ffsll(static_cast<long long>(x)) - 1) >> 3;
+              stopped = true;
+              break;
+            }
+            m += 8;
+          }
+          while (!stopped && m + 4 <= lim) {
+            const int jj = j + m;
+            if (jj < w0 || jj + 4 > w0 + kWin) refill(jj);
             const uint32_t k = uint32_t(jj - w0), d = k >> 2, sh = k & 3u;
             const uint32_t lo = s_win[d * 256u + threadIdx.x];
             const uint32_t hi = sh ? s_win[(d + 1u) * 256u + threadIdx.x] : 0u;

@@ -4,14 +4,21 @@
 // the count of the low digit): two memory round trips per search step, the structural cost of cfg 3 in round 1.  A
 // backward-search step, however, knows its character: it only needs rank_c(row) of ONE character's indicator bit vector.
 // When HBM allows, open therefore also derives, for every character c of the text, the plain bit vector
-// B_c[row] = (L[row] == c) cut into 128-byte lines of 960 rows:
+// B_c[row] = (L[row] == c) cut into 128-byte lines of 896 rows = a 16-byte header + seven 16-byte blocks of 128 rows:
 //
-//   qword 0       bits 0..39: C[c] + Occ(c, rows before this line); bits 40..49 / 50..59: set bits in qwords 1..5 /
-//                 1..10 of this line (two sub-block counts: a rank popcounts at most five words)
-//   qword 1..15   bit i of qword 1+k = B_c[960*line + 64k + i]
+//   qword 0       bits 0..39: C[c] + Occ(c, rows before this line)
+//   qword 1       six 10-bit fields: set bits in blocks 0..k-1 of this line, k = 1..6
+//   qword 2 + 2k  block k: bit i of its 128 bits = B_c[896*line + 128k + i]
 //
-// sigma * rows / 7.5 bytes (13.7 GB for a 2^30-row text with 96 characters -- "size everything for 288 GB").  A search
-// step is then two INDEPENDENT line reads (one when both range ends fall into the same 960 rows): half the lines and half
+// A rank is TWO 16-byte loads from ONE line -- the header and the block of the row -- and two masked popcounts.
+// (Round 3's first layout had 960 rows per line, an 8-byte head and three sub-blocks of five words: six 8-byte loads per
+// rank, twelve per search step.  The count kernel on the sigma~96 workload turned out to be bound by the CU's vector-memory
+// ADDRESS rate -- a 64-lane load whose lanes hit 64 different lines occupies the texture addresser for ~64 cycles whatever
+// its width: 134 load instructions per wavefront x 64 lanes x 156 k wavefronts / 256 CUs = 5.2 M cycles = the kernel's
+// 2 ms -- so the number of load instructions per step matters, not the bytes.)
+//
+// sigma * rows / 7 bytes (14.7 GB for a 2^30-row text with 96 characters -- "size everything for 288 GB").  A search
+// step is then two INDEPENDENT line reads (one when both range ends fall into the same 896 rows): half the lines and half
 // the latency of the two-level layout.  LF steps (locate walks, the text build) do not know their character in advance
 // and keep using the two-level lines; with the full suffix array resident there are none left on the query path.
 // Same results as every other layout (tests compare them all against the reference's goldens).
@@ -19,35 +26,27 @@
 
 namespace femto_amd {
 
-constexpr int kIndRows = 960;
+constexpr int kIndRows = 896;
 
-// C[c] + Occ(c, row) for row = 960*line + b.  Only what the rank needs is loaded: the head word and the five words of
-// b's sub-block (the 128-byte line is one memory request either way, but 48 instead of 128 bytes reach the registers and a
-// rank costs ~45 VALU instructions instead of ~150 -- the round-2 profile showed the whole-line version VALU-bound).
+// C[c] + Occ(c, row) for row = 896*line + b
 __device__ __forceinline__ int64_t ind_rank(const uint32_t* __restrict__ ind, uint64_t line, uint32_t b) {
-  const uint64_t* lp = reinterpret_cast<const uint64_t*>(ind + line * 32);
-  const uint64_t head = lp[0];
-  const uint32_t w = b >> 6;                 // data word 0..14
-  const uint32_t sblk = w / 5u;              // sub-block 0..2
-  const uint64_t* dp = lp + 1 + 5u * sblk;
-  uint64_t d[5];
-#pragma unroll
-  for (int k = 0; k < 5; k++) d[k] = dp[k];
-  const int nb = int(b - 320u * sblk) + 1;   // bits of the sub-block to count: 1..320
-  uint32_t cnt = 0;
-#pragma unroll
-  for (int k = 0; k < 5; k++) {
-    const int bits = nb - 64 * k;
-    const uint64_t m = bits >= 64 ? ~0ull : (bits <= 0 ? 0ull : ((1ull << bits) - 1ull));
-    cnt += uint32_t(__popcll(d[k] & m));
-  }
-  const uint32_t sub = sblk == 0 ? 0u : (sblk == 1 ? uint32_t(head >> 40) & 0x3ffu : uint32_t(head >> 50) & 0x3ffu);
-  return int64_t(head & ((1ull << 40) - 1ull)) + int64_t(sub + cnt);
+  const uint4* lp = reinterpret_cast<const uint4*>(ind + line * 32);
+  const uint32_t blk = b >> 7;               // block 0..6
+  const uint4 h = lp[0], v = lp[1 + blk];
+  const int nb = int(b & 127u) + 1;          // bits of the block to count: 1..128
+  const uint64_t lo = uint64_t(v.x) | (uint64_t(v.y) << 32), hi = uint64_t(v.z) | (uint64_t(v.w) << 32);
+  const uint64_t mlo = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
+  const uint64_t mhi = nb <= 64 ? 0ull : (nb >= 128 ? ~0ull : ((1ull << (nb - 64)) - 1ull));
+  const uint32_t cnt = uint32_t(__popcll(lo & mlo)) + uint32_t(__popcll(hi & mhi));
+  const uint32_t fields = blk <= 3u ? h.z : ((h.z >> 30) | (h.w << 2));      // the 10-bit fields of blocks 1..3 / from block 4 on
+  const uint32_t sub = blk == 0u ? 0u : (fields >> (10u * (blk <= 3u ? blk - 1u : blk - 4u))) & 0x3ffu;
+  const uint64_t base = (uint64_t(h.x) | (uint64_t(h.y) << 32)) & ((1ull << 40) - 1ull);
+  return int64_t(base) + int64_t(sub + cnt);
 }
 
 __device__ __forceinline__ void ind_split(int64_t row, uint64_t* line, uint32_t* b) {
-  const uint32_t q = uint32_t(uint64_t(row) >> 6);   // rows < 2^38
-  const uint32_t l = q / 15u;
+  const uint32_t q = uint32_t(uint64_t(row) >> 7);   // rows < 2^38
+  const uint32_t l = q / 7u;
   *line = l;
   *b = uint32_t(uint64_t(row) - uint64_t(l) * kIndRows);
 }
@@ -73,7 +72,7 @@ __device__ __forceinline__ void ind_search_step(const DevIndex& ix, int j, uint3
   last = nl - 1;
 }
 
-// construction: one block per 960 rows; thread c builds character c's line from the block's symbols (LDS) and takes
+// construction: one workgroup per 896 rows; thread c builds character c's line from the rows' symbols (LDS) and takes
 // the count before the line from the two-level lines
 inline __global__ __launch_bounds__(256) void ind_build_kernel(const DevIndex ix, const int64_t nrows, const uint16_t* __restrict__ sym,
                                                         uint32_t* __restrict__ ind, const int64_t stride, const int64_t group0) {
@@ -86,18 +85,19 @@ inline __global__ __launch_bounds__(256) void ind_build_kernel(const DevIndex ix
   if (int(c) >= ix.p2_sigma) return;
   const int64_t before = row0 == 0 ? ix.p2_c[c] : p2_c_plus_occ(ix, c, row0 - 1);
   uint64_t* dst = reinterpret_cast<uint64_t*>(ind + (uint64_t(c) * uint64_t(stride) + uint64_t(g)) * 32);
-  uint32_t sub1 = 0, sub2 = 0, run = 0;
+  uint64_t fields = 0;
+  uint32_t run = 0;
 #pragma unroll 1
-  for (int k = 0; k < 15; k++) {
+  for (int k = 0; k < 14; k++) {
     uint64_t v = 0;
 #pragma unroll
     for (int i = 0; i < 64; i++) v |= uint64_t(uint32_t(s_sym[64 * k + i]) == c ? 1u : 0u) << i;
-    dst[1 + k] = v;
+    dst[2 + k] = v;
     run += uint32_t(__popcll(v));
-    if (k == 4) sub1 = run;
-    if (k == 9) sub2 = run;
+    if ((k & 1) && k < 13) fields |= uint64_t(run) << (10 * (k >> 1));      // set bits in blocks 0 .. k/2
   }
-  dst[0] = (uint64_t(before) & ((1ull << 40) - 1ull)) | (uint64_t(sub1) << 40) | (uint64_t(sub2) << 50);
+  dst[0] = uint64_t(before) & ((1ull << 40) - 1ull);
+  dst[1] = fields;
 }
 
 }  // namespace femto_amd
