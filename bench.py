@@ -141,7 +141,7 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-ENTRY_BYTES = {"level_table": 8, "context_table": 16, "suffix_array": 8, "isa": 8}     # bytes a lookup USES of the 128-byte line it loads
+ENTRY_BYTES = {"level_table": 8, "context_table": 16, "suffix_array": 8, "isa": 8, "char_rank_lines": 32}     # bytes a lookup USES of the 128-byte line it loads
 
 
 def roofline_block(ix, direct, b, npats, plen, max_occs, cnt_ms, loc_ms, cnt_n):
@@ -163,8 +163,8 @@ def roofline_block(ix, direct, b, npats, plen, max_occs, cnt_ms, loc_ms, cnt_n):
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None, "traffic_source": None, "traffic_GBs": None, "traffic_over_compulsory": None,
             "useful": {"bytes": useful, "GBs": useful / (k_ms * 1e-3) / 1e9, "frac": useful / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                       "model": "compulsory bytes with every level-table / context-table / suffix-array / inverse-suffix-array line counted as the "
-                                "entry it is loaded for (8 / 16 / 8 / 8 bytes) instead of 128: line-granular fetches are what the memory moves, "
+                       "model": "compulsory bytes with every level-table / context-table / suffix-array / inverse-suffix-array / per-character rank line counted as the "
+                                "entry it is loaded for (8 / 16 / 8 / 8 / 32 bytes) instead of 128: line-granular fetches are what the memory moves, "
                                 "entry bytes are what the search needs"},
             "kernel": kname, "kernel_ms": k_ms, "launches_timed": cnt_n, "count_kernel_ms": cnt_ms, "locate_kernel_ms": loc_ms,
             "compulsory_bytes_per_launch": comp,

@@ -352,7 +352,9 @@ void inline_tail_setup(const femto_amd_index* ix, DevIndex& d) {
   d.tail_ones = std::max(0, int(knob(ix->opt.tail_ones, "FEMTO_AMD_TAIL_ONES", d.tail_ones)));
   // Ranges of 2-4 rows can take the tail too (each row compared, the survivors' rows from the inverse suffix array), but on
   // the sigma~96 workload that loses: the lanes of a wavefront then serialise up to 3 x rows dependent reads while the
-  // others wait (10 M sampled patterns: rows = 1 3.48 ms, 2 3.63 ms, 4 3.87-4.08 ms).  Default 1; FEMTO_AMD_TAIL_ROWS <= 4.
+  // others wait (10 M sampled patterns, round 2: rows = 1 3.48 ms, 2 3.63 ms, 4 3.87-4.08 ms; round 3, with eight symbols
+  // compared per load: 2.08 / 2.14 / 2.20 ms -- a wavefront lives as long as its slowest lane's chain of dependent reads, and
+  // rows x (SA, text, ISA) is no shorter a chain than the steps it replaces).  Default 1; FEMTO_AMD_TAIL_ROWS <= 4.
   d.tail_rows = 1;
   d.tail_row_cost = 8;
   d.tail_rows = std::max(1, int(knob(ix->opt.tail_rows, "FEMTO_AMD_TAIL_ROWS", d.tail_rows)));

@@ -28,11 +28,9 @@ namespace femto_amd {
 
 constexpr int kIndRows = 896;
 
-// C[c] + Occ(c, row) for row = 896*line + b
-__device__ __forceinline__ int64_t ind_rank(const uint32_t* __restrict__ ind, uint64_t line, uint32_t b) {
-  const uint4* lp = reinterpret_cast<const uint4*>(ind + line * 32);
+// C[c] + Occ(c, row) for row = 896*line + b, from the line's header h and the row's block v
+__device__ __forceinline__ int64_t ind_rank_of(const uint4 h, const uint4 v, uint32_t b) {
   const uint32_t blk = b >> 7;               // block 0..6
-  const uint4 h = lp[0], v = lp[1 + blk];
   const int nb = int(b & 127u) + 1;          // bits of the block to count: 1..128
   const uint64_t lo = uint64_t(v.x) | (uint64_t(v.y) << 32), hi = uint64_t(v.z) | (uint64_t(v.w) << 32);
   const uint64_t mlo = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
@@ -42,6 +40,10 @@ __device__ __forceinline__ int64_t ind_rank(const uint32_t* __restrict__ ind, ui
   const uint32_t sub = blk == 0u ? 0u : (fields >> (10u * (blk <= 3u ? blk - 1u : blk - 4u))) & 0x3ffu;
   const uint64_t base = (uint64_t(h.x) | (uint64_t(h.y) << 32)) & ((1ull << 40) - 1ull);
   return int64_t(base) + int64_t(sub + cnt);
+}
+__device__ __forceinline__ int64_t ind_rank(const uint32_t* __restrict__ ind, uint64_t line, uint32_t b) {
+  const uint4* lp = reinterpret_cast<const uint4*>(ind + line * 32);
+  return ind_rank_of(lp[0], lp[1 + (b >> 7)], b);
 }
 
 __device__ __forceinline__ void ind_split(int64_t row, uint64_t* line, uint32_t* b) {
@@ -66,8 +68,18 @@ __device__ __forceinline__ void ind_search_step(const DevIndex& ix, int j, uint3
   if (haveF) ind_split(first - 1, &lineF, &bF);
   trace_touch(ix, kTraceInd, base + lineL);
   if (haveF && lineF != lineL) trace_touch(ix, kTraceInd, base + lineF);
-  const int64_t nl = ind_rank(ix.ind, base + lineL, bL);      // the two ranks are independent: their loads overlap
-  const int64_t rf = ind_rank(ix.ind, base + lineF, bF);      // (first == 0: line 0 of the character, result unused)
+  // four independent 16-byte loads at most -- and only the ones that differ: the two ends of a narrow range share the
+  // line (its header) and often the block, and a load that a lane does not issue costs the address unit nothing
+  const uint4* const lpL = reinterpret_cast<const uint4*>(ix.ind + (base + lineL) * 32);
+  const uint4 hL = lpL[0], vL = lpL[1 + (bL >> 7)];
+  const bool other_line = haveF && lineF != lineL;
+  const bool other_blk = haveF && (other_line || (bF >> 7) != (bL >> 7));
+  const uint4* const lpF = reinterpret_cast<const uint4*>(ix.ind + (base + (other_line ? lineF : lineL)) * 32);
+  uint4 hF = hL, vF = vL;
+  if (other_line) hF = lpF[0];
+  if (other_blk) vF = lpF[1 + (bF >> 7)];
+  const int64_t nl = ind_rank_of(hL, vL, bL);
+  const int64_t rf = ind_rank_of(hF, vF, bF);      // (first == 0: result unused)
   first = haveF ? rf : ix.p2_c[code];
   last = nl - 1;
 }
