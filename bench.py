@@ -75,7 +75,7 @@ def pmc_traffic(args, kname, pack_info):
         return None, None
     base = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "2", "--warmup", "1", "--text-log2", str(args.text_log2),
             "--npats", str(args.npats), "--plen", str(args.plen), "--seed", str(args.seed), "--max-occs", str(args.max_occs),
-            "--workload", args.workload, "--workdir", args.workdir]
+            "--workload", args.workload, "--workdir", args.workdir] + (["--len-range", args.len_range] if args.len_range else [])
     means = {}
     child_info = None
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
@@ -398,6 +398,7 @@ def main():
     ap.add_argument("--npats", type=int, default=10_000_000, help="patterns per GPU per step")
     ap.add_argument("--plen", type=int, default=20)
     ap.add_argument("--seed", type=int, default=20260928)
+    ap.add_argument("--len-range", default="", help="experiments: 'min,max' pattern lengths of a sampled workload instead of its own")
     ap.add_argument("--max-occs", type=int, default=100)
     ap.add_argument("--cpu-sample", type=int, default=300_000, help="patterns timed on the host CPU (0 = skip)")
     ap.add_argument("--workload", default="acgt", choices=["acgt", "acgt_hit", "eng"],
@@ -501,6 +502,8 @@ def main():
     if hit:
         text = np.load(text_path, mmap_mode="r")
         kmin, kmax = (8, 64) if eng else (args.plen, args.plen)
+        if args.len_range:      # experiments only: the named workloads use the lengths above
+            kmin, kmax = (int(x) for x in args.len_range.split(","))
         plen, flat = tg.p_hit(kmin, kmax, npats, args.seed + 1000 + rank, np.asarray(text))
         del text
     else:

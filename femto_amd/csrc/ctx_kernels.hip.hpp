@@ -254,21 +254,33 @@ inline __global__ __launch_bounds__(256) void ctx2_build_kernel(const DevIndex i
 }
 
 // 1: found (first, last set); 0: the H-gram does not occur; -1: too many rows for the value field
+// The keys of a whole bucket (four slots = one 128-byte line; the probe sequence starts at a bucket and runs on bucket by
+// bucket) are loaded TOGETHER: at a load of 0.5 a key sits 2.1 slots into its sequence on average, but the slowest of a
+// wavefront's 64 lanes 6.8 -- probing slot by slot, every wavefront waited for seven dependent reads; bucket by bucket it
+// waits for two.
+constexpr int kCtx2Gang = 4;
 __device__ __forceinline__ int ctx2_lookup(const DevIndex& ix, const CtxKey2& key, int64_t& first, int64_t& last) {
   const uint64_t nslots = ix.ctx2_slots;
   uint64_t s = ctx_hash2(key, nslots);
-  for (uint64_t probes = 0; probes < nslots; probes++, s = s + 1 == nslots ? 0 : s + 1) {
-    const ulonglong2 e = reinterpret_cast<const ulonglong2*>(ix.ctx2)[2 * s];
+  for (uint64_t probes = 0; probes < nslots; probes += kCtx2Gang) {
+    ulonglong2 e[kCtx2Gang];
+#pragma unroll
+    for (int i = 0; i < kCtx2Gang; i++) e[i] = reinterpret_cast<const ulonglong2*>(ix.ctx2)[2 * (s + uint64_t(i))];
     trace_touch(ix, kTraceCtx, uint64_t(ix.ctx2_trace_off) + (s >> 2));
-    if (e.x == 0) return 0;
-    if (e.x == key.lo && e.y == key.hi) {
-      const uint64_t v = ix.ctx2[4 * s + 2];
-      const uint64_t rows = v >> 40;
-      if (rows == kCtxBig) return -1;
-      first = int64_t(v & kCtxFirstMask);
-      last = first + int64_t(rows) - 1;
-      return 1;
+#pragma unroll
+    for (int i = 0; i < kCtx2Gang; i++) {
+      if (e[i].x == 0) return 0;
+      if (e[i].x == key.lo && e[i].y == key.hi) {
+        const uint64_t v = ix.ctx2[4 * (s + uint64_t(i)) + 2];
+        const uint64_t rows = v >> 40;
+        if (rows == kCtxBig) return -1;
+        first = int64_t(v & kCtxFirstMask);
+        last = first + int64_t(rows) - 1;
+        return 1;
+      }
     }
+    s += kCtx2Gang;
+    if (s >= nslots) s = 0;
   }
   return 0;
 }

@@ -128,10 +128,10 @@ int femto_amd_document_info(const femto_amd_index_t* ix, int64_t doc, const char
  * void* (NULL = default stream).  Calls only enqueue work and return; the caller synchronises.
  * Nothing is reported to the host afterwards: a pattern holding a symbol >= 261 (which the host-pointer
  * calls reject with FEMTO_AMD_ERR_PARAM) has the empty range first = 0, last = -1.
- * READS AROUND THE SYMBOLS: the kernels fetch the patterns in aligned 64-byte chunks, so up to 62 bytes before the first and
- * behind the last symbol of d_pats[] are LOADED (never used, never written).  An aligned chunk cannot cross a page, so this
+ * READS AROUND THE SYMBOLS: the kernels fetch the patterns in aligned 16-byte pieces, so up to 14 bytes before the first and
+ * behind the last symbol of d_pats[] are LOADED (never used, never written).  An aligned piece cannot cross a page, so this
  * cannot fault -- but a memory checker, or a sub-allocator with poisoned guard bytes next to d_pats, will see the reads:
- * give d_pats 64 bytes of slack on either side, or align its ends to 64 bytes, if that matters.  (femto_amd_locate_device
+ * give d_pats 16 bytes of slack on either side, or align its ends to 16 bytes, if that matters.  (femto_amd_locate_device
  * falls back to a host-synchronising path -- it reads the row total back on `stream` -- for rank modes 0 and 1; the
  * packed modes 3 / 4 are enqueue-only as stated.) */
 int femto_amd_count_device(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen,
