@@ -124,10 +124,9 @@ inline __global__ __launch_bounds__(256) void ctx_ends_kernel(const DevIndex ix,
 __device__ __forceinline__ int ctx_lookup(const DevIndex& ix, uint64_t key, int64_t& first, int64_t& last) {
   const int lg = ix.ctx_log2;
   const uint64_t mask = (uint64_t(1) << lg) - 1;
+  const ulonglong2* const tab = reinterpret_cast<const ulonglong2*>(ix.ctx);
   uint64_t s = ctx_hash(key, lg);
-  for (uint64_t probes = 0; probes <= mask; probes++, s = (s + 1) & mask) {
-    const ulonglong2 e = reinterpret_cast<const ulonglong2*>(ix.ctx)[s];
-    trace_touch(ix, kTraceCtx, s >> 3);
+  auto check = [&](const ulonglong2& e) -> int {      // 2: probe on
     if (e.x == key) {
       const uint64_t rows = e.y >> 40;
       if (rows == kCtxBig) return -1;
@@ -135,7 +134,19 @@ __device__ __forceinline__ int ctx_lookup(const DevIndex& ix, uint64_t key, int6
       last = first + int64_t(rows) - 1;
       return 1;
     }
-    if (e.x == 0) return 0;
+    return e.x == 0 ? 0 : 2;
+  };
+  // four slots are loaded together: the wavefront waits for its slowest lane's probes (see ctx2_lookup)
+  for (uint64_t probes = 0; probes <= mask; probes += 4, s = (s + 4) & mask) {
+    const uint64_t s3 = (s + 3) & mask;
+    const ulonglong2 e0 = tab[s], e1 = tab[(s + 1) & mask], e2 = tab[(s + 2) & mask], e3 = tab[s3];
+    trace_touch(ix, kTraceCtx, s >> 3);
+    if ((s3 >> 3) != (s >> 3)) trace_touch(ix, kTraceCtx, s3 >> 3);
+    int r;
+    if ((r = check(e0)) != 2) return r;
+    if ((r = check(e1)) != 2) return r;
+    if ((r = check(e2)) != 2) return r;
+    if ((r = check(e3)) != 2) return r;
   }
   return 0;
 }

@@ -354,7 +354,30 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
         int m = 0;                       // symbols matched
         bool stopped = false;
         if (fast_cmp) {
-          while (m + 8 <= lim) {          // eight symbols per load (the loads are what this loop costs)
+          while (m + 16 <= lim) {         // sixteen symbols per round, both loads in flight together: a round is one dependent
+                                           // read of the lane's chain, and the wavefront waits for its longest chain
+            const int jj = j + m;
+            if (jj < w0 || jj + 16 > w0 + kWin) refill(jj);
+            const uint32_t k = uint32_t(jj - w0), d = k >> 2, sh = k & 3u;
+            const uint32_t wa = s_win[d * 256u + threadIdx.x], wb = s_win[(d + 1u) * 256u + threadIdx.x];
+            const uint32_t wc = s_win[(d + 2u) * 256u + threadIdx.x], wd = s_win[(d + 3u) * 256u + threadIdx.x];
+            const uint32_t we = sh ? s_win[(d + 4u) * 256u + threadIdx.x] : 0u;
+            const uint64_t pa = uint64_t(__builtin_amdgcn_alignbyte(wb, wa, sh)) | (uint64_t(__builtin_amdgcn_alignbyte(wc, wb, sh)) << 32);
+            const uint64_t pb = uint64_t(__builtin_amdgcn_alignbyte(wd, wc, sh)) | (uint64_t(__builtin_amdgcn_alignbyte(we, wd, sh)) << 32);
+            uint64_t ta, tb;
+            __builtin_memcpy(&ta, tp - m - 7, 8);                                  // txt[p-8-m .. p-1-m]
+            __builtin_memcpy(&tb, tp - m - 15, 8);                                 // txt[p-16-m .. p-9-m]
+            trace_touch(ix, kTraceTxt, uint64_t(tp - m - 15 - ix.txt) >> 7);
+            trace_touch(ix, kTraceTxt, uint64_t(tp - m - ix.txt) >> 7);
+            const uint64_t xa = pa ^ __builtin_bswap64(ta), xb = pb ^ __builtin_bswap64(tb);
+            if (xa | xb) {
+              m += xa ? (__ffsll(static_cast<long long>(xa)) - 1) >> 3 : 8 + ((__ffsll(static_cast<long long>(xb)) - 1) >> 3);
+              stopped = true;
+              break;
+            }
+            m += 16;
+          }
+          while (!stopped && m + 8 <= lim) {          // eight symbols per load
             const int jj = j + m;
             if (jj < w0 || jj + 8 > w0 + kWin) refill(jj);
             const uint32_t k = uint32_t(jj - w0), d = k >> 2, sh = k & 3u;
