@@ -1343,3 +1343,59 @@ def test_level_table_deep_entries_recomputed(fixtures, gpu_ok, monkeypatch, name
                 noccs, offs = ix.locate_flat(plen, flat, starts, mo)
                 assert np.array_equal(noccs, g_noccs) and np.array_equal(offs, g_offs), (big, k, mo)
             ix.close()
+
+
+@pytest.mark.parametrize("name,mode", [("acgt48k", 3), ("eng2doc", 4), ("runs3doc", 4)])
+def test_pattern_window_every_alignment_and_length(fixtures, gpu_ok, name, mode):
+    """The count kernel reads a lane's symbols through aligned 16-byte pieces whose phase depends on the pattern's address
+    and length (direct_kernels.hip.hpp): every start address mod 16 bytes x every length 0 .. 150 (one window, its last
+    dword, refills), patterns that occur (substrings of the prepared text, some running over SEOF) and patterns spoilt in
+    one symbol, laid out in the symbol buffer with caller-chosen gaps -- device entry points against the oracle."""
+    import torch
+    fx = fixtures(name)
+    ix = _open(fx.index, mode)
+    o = po.Oracle(fx.index)
+    prepared = fx.prepared_text()
+    rng = np.random.Generator(np.random.PCG64(4242))
+    plen, starts, chunks, pos = [], [], [], 0
+    for ln in range(0, 151):
+        for phase in range(8):
+            gap = (phase - pos) % 8                      # symbol index mod 8 = 16-byte phase of the start address
+            chunks.append(rng.integers(5, 261, gap).astype(np.uint16))     # (neighbouring symbols a piece may also hold)
+            pos += gap
+            s0 = int(rng.integers(0, len(prepared) - ln)) if ln else 0
+            p_ = prepared[s0:s0 + ln].copy()
+            if ln and rng.random() < 0.3:
+                p_[int(rng.integers(0, ln))] = int(rng.choice([3, 5 + 0x41, 5 + 0x7a, 260]))
+            plen.append(ln)
+            starts.append(pos)
+            chunks.append(p_.astype(np.uint16))
+            pos += ln
+    plen, starts = np.array(plen, dtype=np.int32), np.array(starts, dtype=np.int64)
+    flat = np.concatenate(chunks + [np.zeros(8, dtype=np.uint16)])
+    n = len(plen)
+    of, ol = o.count_flat(plen, flat, starts, threads=8)
+    on, oo = o.locate_flat(plen, flat, starts, 5, threads=8)
+    assert (ol >= of).sum() > n // 3 and (ol < of).sum() > n // 10
+    dev = "cuda:0"
+    base = torch.zeros(len(flat) + 8, dtype=torch.int16, device=dev)
+    for shift in (0, 3):                                  # the buffer itself at two different alignments
+        d_flat = base[shift:shift + len(flat)]
+        d_flat.copy_(torch.from_numpy(flat.view(np.int16)))
+        d_plen, d_starts = torch.from_numpy(plen).to(dev), torch.from_numpy(starts).to(dev)
+        f, l = torch.zeros(n, dtype=torch.int64, device=dev), torch.zeros(n, dtype=torch.int64, device=dev)
+        ix.count_device(n, d_plen.data_ptr(), d_flat.data_ptr(), d_starts.data_ptr(), f.data_ptr(), l.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(f.cpu().numpy(), of) and np.array_equal(l.cpu().numpy(), ol), shift
+        cap = int(on.sum()) + 8
+        noccs = torch.zeros(n, dtype=torch.int32, device=dev)
+        ostarts = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        offs = torch.full((cap,), -7, dtype=torch.int64, device=dev)
+        total = torch.zeros(2, dtype=torch.int64, device=dev)
+        ix.locate_device(n, d_plen.data_ptr(), d_flat.data_ptr(), d_starts.data_ptr(), 5, f.data_ptr(), l.data_ptr(), noccs.data_ptr(),
+                         ostarts.data_ptr(), offs.data_ptr(), cap, total.data_ptr())
+        torch.cuda.synchronize()
+        assert total.cpu().tolist() == [int(on.sum()), 0]
+        assert np.array_equal(noccs.cpu().numpy(), on)
+        assert np.array_equal(offs.cpu().numpy()[:int(on.sum())], oo), shift
+    ix.close()
