@@ -345,6 +345,9 @@ void comm_destroy(femto_amd_index* ix);     // api_multi.hip: the RCCL communica
 // femto_amd_open and its variants: part / nparts: a range-split part; stripe: the big arrays over these GPUs' HBM
 int open_impl(const char* index_path, int device, int part, int nparts, femto_amd_index_t** out, const std::vector<int>* stripe = nullptr,
               const femto_amd_options_t* opts = nullptr);
+// exclusive prefix sum of n 64-bit counts on the device (out has n + 1 entries); femto_amd_api.hip
+int device_scan(DeviceBuffer* scan, int64_t n, const int64_t* in, int64_t* out, int level, hipStream_t stream);
+void block_image_range(const HostIndex& h, int64_t b0, int64_t b1, uint64_t* lo, uint64_t* hi);   // image bytes of data blocks [b0, b1)
 int check_err_flag(Scratch& S, hipStream_t stream);
 bool timer_begin(femto_amd_index* ix, KernelTimer& t, hipStream_t stream, hipEvent_t* e0, hipEvent_t* e1);
 void timer_end(femto_amd_index* ix, KernelTimer& t, hipStream_t stream, hipEvent_t e0, hipEvent_t e1);

@@ -476,6 +476,10 @@ int launch_count(femto_amd_index* ix, Scratch& S, int64_t npats, const int32_t* 
   return 0;
 }
 
+}  // namespace
+
+// (shared with api_open.hip, whose derivations prefix-sum their per-line counts)
+namespace femto_amd {
 int device_scan(DeviceBuffer* scan, int64_t n, const int64_t* in, int64_t* out /* n+1 */, int level, hipStream_t stream) {
   if (n <= 0) {
     HIP_TRY(hipMemsetAsync(out, 0, sizeof(int64_t), stream));
@@ -497,6 +501,9 @@ int device_scan(DeviceBuffer* scan, int64_t n, const int64_t* in, int64_t* out /
   HIP_TRY(hipGetLastError());
   return 0;
 }
+}  // namespace femto_amd
+
+namespace {
 
 // key batches (count_keys_kernel): host-pointer key chunks, and -- with a plan -- femto_amd_locate_keys_device
 int launch_count_keys(femto_amd_index* ix, int64_t n, const uint64_t* d_keys, int2* out32, int64_t* d_first, int64_t* d_last, hipStream_t stream,
@@ -659,584 +666,6 @@ int stage_patterns(Scratch& S, int64_t npats, const int32_t* plen, const uint16_
     HIP_TRY(hipMemcpyAsync(S.starts.p, starts, size_t(npats) * 8, hipMemcpyHostToDevice, S.stream));
   }
   if (total) HIP_TRY(hipMemcpyAsync(S.pats.p, pats, size_t(total) * 2, hipMemcpyHostToDevice, S.stream));
-  return 0;
-}
-
-// Level table of the direct pipeline (direct_kernels.hip.hpp): all strings of at most K table characters, heap-numbered.
-// K: the deepest level has at most one entry per row (t^K <= rows, never fewer than 2^16 entries) -- deeper levels would
-// mostly hold empty ranges -- and the whole table takes at most a quarter of the free HBM.  Levels 0..K-1 are 16-byte
-// entries, the deepest level 8-byte ones.  For a 2^30-row DNA index: K = 15, 5.7 + 8.6 GB (the "ftab" of DNA aligners,
-// but of femto's own ranges).  FEMTO_AMD_KTAB_MB bounds the bytes instead, FEMTO_AMD_KTAB_SYMS pins K, FEMTO_AMD_KTAB=0
-// disables the table.
-template <class P>
-int build_ktab2(femto_amd_index* ix, int sigma, int nstop) {
-  if (ix->dev.ktab2) return 0;
-  if (knob(ix->opt.level_table, "FEMTO_AMD_KTAB", 1) == 0) return 0;
-  const int64_t t = sigma - nstop;
-  if (t < 1) return 0;
-  // the deepest level may hold up to four entries per row (measured on 10 M random DNA 20-mers over 2^30 rows: K = 15
-  // 0.645 ms, K = 16 0.489 ms per count launch -- 78 % of random patterns then end at their table entry; 57 instead of
-  // 14 GB), the whole table at most a quarter of the free HBM ...
-  int64_t level_cap = std::max<int64_t>(int64_t(1) << 16, ix->host.total_length * 4);
-  // ... except that the depths with at most ONE entry per row may take 60 % of it: on an 8 GiB DNA text (2^33 rows, 137 GB of
-  // dense arrays already resident) a quarter stops at K = 15, 60 % admits K = 16 (57 GB): 10 M sampled 20-mers 3.91 -> 3.22 ms
-  int64_t budget = INT64_MAX, budget_row = INT64_MAX;
-  {
-    const size_t free_b = hbm_free(ix);
-    budget = int64_t(free_b / 4);
-    budget_row = int64_t(double(free_b) * 0.6);
-  }
-  if (ix->opt.level_table_bytes >= 0) {
-    budget = budget_row = std::max<int64_t>(1, ix->opt.level_table_bytes);
-    level_cap = INT64_MAX;
-  } else if (const char* mb = getenv("FEMTO_AMD_KTAB_MB")) {
-    budget = budget_row = std::max<int64_t>(1, atoll(mb)) << 20;
-    level_cap = INT64_MAX;
-  }
-  const int want = int(knob(ix->opt.level_table_syms, "FEMTO_AMD_KTAB_SYMS", -1));
-  // level m holds t^m entries; bytes(K) = 16 * (1 + t + ... + t^(K-1)) + 8 * t^K
-  int K = 0;
-  int64_t upper = 0, level = 1;       // entries of levels 0..K-1, entries of level K
-  std::vector<int64_t> lo{0};
-  for (;;) {
-    if (K >= 24 || level > (int64_t(1) << 40) / t) break;
-    const int64_t next_level = level * t;
-    const int64_t allowed = next_level <= ix->host.total_length ? budget_row : budget;
-    if (want >= 0 ? K >= want : (next_level > level_cap || ((upper + level) * 16 + next_level * 8) > allowed)) break;
-    upper += level;
-    lo.push_back(upper);
-    level = next_level;
-    K++;
-  }
-  if (K < 1) return 0;
-  // upper = entries of levels 0..K-1 (16 bytes each), level = entries of level K (8 bytes each)
-  if (big_malloc(ix, reinterpret_cast<void**>(&ix->d_ktab2), size_t(upper) * 16) != hipSuccess ||
-      big_malloc(ix, reinterpret_cast<void**>(&ix->d_ktab2_deep), size_t(level) * 8 + 64) != hipSuccess) {
-    (void)hipGetLastError();
-    big_free(ix, ix->d_ktab2);
-    ix->d_ktab2 = nullptr;
-    big_free(ix, ix->d_ktab2_deep);
-    ix->d_ktab2_deep = nullptr;
-    return FEMTO_AMD_ERR_MEM;
-  }
-  DevIndex d = ix->dev;
-  d.kt2_syms = K;
-  d.kt2_base = int32_t(t);
-  d.kt2_nstop = nstop;
-  d.kt2_deep_big = 0xffffff;
-  if (const char* e = getenv("FEMTO_AMD_KTAB_DEEP_BIG")) d.kt2_deep_big = std::max(1, std::min(0xffffff, atoi(e)));    // test hook
-  longlong2* tab = reinterpret_cast<longlong2*>(ix->d_ktab2);
-  hipLaunchKernelGGL(ktab2_root_kernel, dim3(1), dim3(64), 0, nullptr, d, tab);
-  int64_t cnt = 1;
-  const int64_t chunk = int64_t(1) << 30;
-  for (int m = 1; m <= K; m++) {
-    cnt *= t;
-    for (int64_t o = 0; o < cnt; o += chunk) {
-      const int64_t cn = std::min(chunk, cnt - o);
-      if (m < K)
-        hipLaunchKernelGGL(ktab2_level_kernel<P>, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, d, m, lo[size_t(m)] + o, cn, tab);
-      else
-        hipLaunchKernelGGL(ktab2_deep_kernel<P>, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, d, m, lo[size_t(m)] + o, cn,
-                           static_cast<const longlong2*>(tab), reinterpret_cast<uint64_t*>(ix->d_ktab2_deep) + o);
-    }
-  }
-  if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return set_err(FEMTO_AMD_ERR_INVALID, "level table build failed");
-  ix->dev.ktab2 = ix->d_ktab2;
-  ix->dev.kt2_deep = reinterpret_cast<const uint64_t*>(ix->d_ktab2_deep);
-  ix->dev.kt2_deep_off = lo[size_t(K)];
-  ix->dev.kt2_syms = K;
-  ix->dev.kt2_base = int32_t(t);
-  ix->dev.kt2_nstop = nstop;
-  ix->dev.kt2_deep_big = d.kt2_deep_big;
-  ix->ktab2_bytes = upper * 16 + level * 8;
-  ix->table_bytes += ix->ktab2_bytes;
-  return 0;
-}
-
-// Context table of a byte alphabet (ctx_kernels.hip.hpp): needs the dense arrays (suffix array of every row + text).
-// H = the largest of min(12, 64 / bits) .. K+2 whose table (16-byte slots, twice the distinct H-grams, a power of two) fits a quarter of
-// the free HBM; not built when even that does not fit, or when it would not save at least two steps over the level table.
-int build_ctx(femto_amd_index* ix, int nstop) {
-  if (ix->dev.ctx || !ix->dev.sa_full || !ix->dev.txt || nstop < 1) return 0;   // (nstop >= 1: key 0 stays "empty")
-  if (knob(ix->opt.context_table, "FEMTO_AMD_CTX", 1) == 0) return 0;
-  const int64_t n = ix->host.total_length;
-  const int kmin = (ix->dev.ktab2 ? ix->dev.kt2_syms : 0) + 2;
-  const int t = int(ix->dev.p2_sigma) - nstop;      // table characters
-  if (t < 1) return 0;
-  int bits = 1;
-  while ((1 << bits) < t + 1) bits++;
-  int hmax = std::min(12, 64 / bits), hmin = kmin;
-  if (const int64_t hs = knob(ix->opt.context_syms, "FEMTO_AMD_CTX_SYMS", -1); hs >= 0) hmax = hmin = std::max(1, std::min(hmax, int(hs)));
-  if (hmin > hmax) return 0;
-  const size_t free_b = hbm_free(ix);
-  const int64_t budget = int64_t(free_b / 4);
-  DeviceBuffer cnt;
-  int rc = cnt.reserve(8);
-  if (rc) return rc;
-  const int64_t chunk = int64_t(1) << 30;
-  DevIndex d = ix->dev;
-  d.ctx_bits = bits;
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
-  EventPair ep{e0, e1};
-  HIP_TRY(hipEventRecord(e0, nullptr));
-  for (int H = hmax; H >= hmin; H--) {
-    HIP_TRY(hipMemsetAsync(cnt.p, 0, 8, nullptr));
-    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
-      const int64_t cn = std::min(chunk, n - r0);
-      hipLaunchKernelGGL(ctx_count_kernel, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, d, r0, cn, H, uint32_t(nstop),
-                         static_cast<unsigned long long*>(cnt.p));
-    }
-    HIP_TRY(hipGetLastError());
-    unsigned long long distinct = 0;
-    HIP_TRY(hipMemcpy(&distinct, cnt.p, 8, hipMemcpyDeviceToHost));
-    if (distinct == 0) continue;
-    int lg = 4;
-    while ((uint64_t(1) << lg) < 2 * distinct) lg++;
-    const int64_t bytes = (int64_t(1) << lg) * 16;
-    if (bytes > budget || lg > 40) continue;
-    if (big_malloc(ix, reinterpret_cast<void**>(&ix->d_ctx), size_t(bytes)) != hipSuccess) {
-      (void)hipGetLastError();
-      ix->d_ctx = nullptr;
-      continue;
-    }
-    HIP_TRY(big_memset(ix, ix->d_ctx, 0, size_t(bytes)));
-    for (int pass = 0; pass < 2; pass++)
-      for (int64_t r0 = 0; r0 < n; r0 += chunk) {
-        const int64_t cn = std::min(chunk, n - r0);
-        const dim3 grid{uint32_t((cn + 255) / 256)}, block{256};
-        if (pass == 0) hipLaunchKernelGGL(ctx_insert_kernel, grid, block, 0, nullptr, d, r0, cn, H, uint32_t(nstop), reinterpret_cast<unsigned long long*>(ix->d_ctx), lg);
-        else hipLaunchKernelGGL(ctx_ends_kernel, grid, block, 0, nullptr, d, r0, cn, H, uint32_t(nstop), reinterpret_cast<unsigned long long*>(ix->d_ctx), lg);
-      }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(e1, nullptr));
-    HIP_TRY(hipEventSynchronize(e1));
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    ix->dev.ctx = ix->d_ctx;
-    ix->dev.ctx_log2 = lg;
-    ix->dev.ctx_syms = H;
-    ix->dev.ctx_nstop = nstop;
-    ix->dev.ctx_bits = bits;
-    ix->ctx_bytes = bytes;
-    ix->ctx_entries = int64_t(distinct);
-    ix->ctx_build_ms = ms;
-    ix->table_bytes += bytes;
-    return 0;
-  }
-  return 0;
-}
-
-// The wide context table (two-word keys): H2 = the largest of min(16, 128 / bits) .. H1 + 2 whose table (32-byte
-// slots, 1.4 x the distinct H2-grams) fits a quarter of the free HBM.  FEMTO_AMD_CTX2=0 disables, FEMTO_AMD_CTX2_SYMS=h forces.
-int build_ctx2(femto_amd_index* ix, int nstop) {
-  if (ix->dev.ctx2 || !ix->dev.ctx) return 0;
-  if (knob(ix->opt.context2_table, "FEMTO_AMD_CTX2", 1) == 0) return 0;
-  const int64_t n = ix->host.total_length;
-  const int bits = ix->dev.ctx_bits;
-  int hmax = std::min(16, 128 / bits), hmin = ix->dev.ctx_syms + 2;
-  if (const int64_t hs = knob(ix->opt.context2_syms, "FEMTO_AMD_CTX2_SYMS", -1); hs >= 0)
-    hmax = hmin = std::max(ix->dev.ctx_syms + 1, std::min(std::min(16, 128 / bits), int(hs)));
-  if (hmin > hmax) return 0;
-  size_t free_b = 0, total_b = 0;
-  free_b = hbm_free(ix);
-  (void)total_b;
-  int64_t budget = int64_t(free_b / 4);
-  if (ix->opt.context2_bytes >= 0) budget = std::max<int64_t>(1, ix->opt.context2_bytes);
-  else if (const char* e = getenv("FEMTO_AMD_CTX2_MB")) budget = std::max<int64_t>(1, atoll(e)) << 20;
-  DeviceBuffer cnt;
-  int rc = cnt.reserve(8);
-  if (rc) return rc;
-  const int64_t chunk = int64_t(1) << 30;
-  const DevIndex d = ix->dev;
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
-  EventPair ep{e0, e1};
-  HIP_TRY(hipEventRecord(e0, nullptr));
-  auto pass = [&](int H, int which, unsigned long long* slots, uint64_t nslots) {
-    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
-      const int64_t cn = std::min(chunk, n - r0);
-      hipLaunchKernelGGL(ctx2_build_kernel, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, d, r0, cn, H, uint32_t(nstop), which,
-                         static_cast<unsigned long long*>(cnt.p), slots, nslots);
-    }
-  };
-  for (int H = hmax; H >= hmin; H--) {
-    HIP_TRY(hipMemsetAsync(cnt.p, 0, 8, nullptr));
-    pass(H, 0, nullptr, 64);
-    HIP_TRY(hipGetLastError());
-    unsigned long long distinct = 0;
-    HIP_TRY(hipMemcpy(&distinct, cnt.p, 8, hipMemcpyDeviceToHost));
-    if (distinct == 0) continue;
-    // slots: twice the distinct keys when that fits the budget (load 0.5: nearly every look-up ends in its first line),
-    // else 1.7x, else 1.4x (load 0.7: a quarter of the look-ups run on into a second line -- the sigma~96 count kernel ran
-    // 2.2 instead of 1.85 ms); only then a shorter key
-    uint64_t nslots = 0;
-    for (const double f : {2.0, 1.7, 1.4}) {
-      const uint64_t cand = (std::max<uint64_t>(64, uint64_t(double(distinct) * f) + 16) + 3) & ~uint64_t(3);
-      if (int64_t(cand) * 32 <= budget) { nslots = cand; break; }
-    }
-    if (!nslots) continue;
-    const int64_t bytes = int64_t(nslots) * 32;
-    if (big_malloc(ix, reinterpret_cast<void**>(&ix->d_ctx2), size_t(bytes)) != hipSuccess) {
-      (void)hipGetLastError();
-      ix->d_ctx2 = nullptr;
-      continue;
-    }
-    HIP_TRY(big_memset(ix, ix->d_ctx2, 0, size_t(bytes)));
-    pass(H, 1, reinterpret_cast<unsigned long long*>(ix->d_ctx2), nslots);
-    pass(H, 2, reinterpret_cast<unsigned long long*>(ix->d_ctx2), nslots);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(e1, nullptr));
-    HIP_TRY(hipEventSynchronize(e1));
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    ix->dev.ctx2 = ix->d_ctx2;
-    ix->dev.ctx2_slots = nslots;
-    ix->dev.ctx2_syms = H;
-    ix->dev.ctx2_trace_off = ix->ctx_bytes / 128;
-    ix->ctx2_bytes = bytes;
-    ix->ctx_build_ms += ms;
-    ix->table_bytes += bytes;
-    return 0;
-  }
-  return 0;
-}
-
-// distance between marks in the derived lines (see "denser marks" in pack_kernels.hip.hpp); 0: keep femto's own
-int derived_mark_every(const HostIndex& h, int h_opt_mark_every) {
-  int every = 5;
-  every = int(knob(h_opt_mark_every, "FEMTO_AMD_MARK_EVERY", every));
-  if (every <= 0 || every >= h.mark_period) return 0;
-  return every;
-}
-
-// Derives the packed lines of pack_kernels.hip.hpp on the GPU from the uploaded index (needs the lane tables).
-int build_pack(femto_amd_index* ix) {
-  HostIndex& h = ix->host;
-  if (!h.dir_regular || h.total_length <= 0) return 0;
-  if (knob(ix->opt.packed_lines, "FEMTO_AMD_PACK", 1) == 0) return 0;
-  std::vector<uint8_t> code(264, 0xff);
-  int sigma = 0;
-  for (int ch = 0; ch < kAlphaSize; ch++)
-    if (h.C[size_t(ch) + 1] > h.C[size_t(ch)]) {
-      if (sigma == 8) return 0;  // more than 8 distinct characters: the wavelet path stays
-      ix->dev.pack_alpha[sigma] = uint16_t(ch);
-      if (ch <= kSEOF) ix->dev.pack_stop |= 1u << sigma;
-      code[size_t(ch)] = uint8_t(sigma++);
-    }
-  for (int c = sigma; c < 8; c++) ix->dev.pack_alpha[c] = uint16_t(kAlphaSize);
-  std::vector<int64_t> pc(16, 0);
-  for (int c = 0; c < sigma; c++) {
-    pc[size_t(c)] = h.C[ix->dev.pack_alpha[c]];
-    pc[8 + size_t(c)] = h.C[size_t(ix->dev.pack_alpha[c]) + 1] - 1;
-  }
-  ix->dev.pack_sigma = sigma;
-  EventPair ev;
-  hipEvent_t &e0 = ev.e0, &e1 = ev.e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
-  HIP_TRY(hipEventRecord(e0, nullptr));
-  int r;
-  if ((r = upload(&ix->d_pack_code, code, &ix->table_bytes))) return r;
-  ix->dev.pack_code = ix->d_pack_code;
-  if ((r = upload(&ix->d_pack_c, pc, &ix->table_bytes))) return r;
-  ix->dev.pack_c = ix->d_pack_c;
-  const int64_t n = h.total_length;
-  const int64_t nlines = (n + kPackRows - 1) / kPackRows;
-  const int64_t stride = nlines + 1;
-  DeviceBuffer sym, counts, scans;
-  auto cleanup = [&]() { sym.release(); counts.release(); scans.release(); };
-  auto body = [&]() -> int {
-    int rc;
-    if ((rc = sym.reserve(size_t(nlines) * kPackRows))) return rc;
-    if ((rc = counts.reserve(size_t(9 * stride) * 8))) return rc;
-    if ((rc = scans.reserve(size_t(9 * stride) * 8))) return rc;
-    HIP_TRY(hipMemset(sym.p, 0, size_t(nlines) * kPackRows));
-    HIP_TRY(big_malloc(ix, reinterpret_cast<void**>(&ix->d_pack), size_t(nlines) * kPackLineWords * 4));
-    const int64_t chunk = int64_t(1) << 30;
-    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
-      const int64_t cn = std::min(chunk, n - r0);
-      hipLaunchKernelGGL(pack_extract_kernel, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, r0, cn, sym.as<uint8_t>());
-    }
-    hipLaunchKernelGGL(pack_planes_kernel, dim3(uint32_t((nlines + 255) / 256)), dim3(256), 0, nullptr, nlines, sym.as<uint8_t>(),
-                       ix->d_pack, counts.as<int64_t>(), stride);
-    HIP_TRY(hipGetLastError());
-    for (int c = 0; c < 9; c++)
-      if ((rc = device_scan(ix->open_scan, nlines, counts.as<int64_t>() + c * stride, scans.as<int64_t>() + c * stride, 0, nullptr))) return rc;
-    hipLaunchKernelGGL(pack_counts_kernel, dim3(uint32_t((nlines + 255) / 256)), dim3(256), 0, nullptr, ix->dev, nlines, ix->d_pack,
-                       scans.as<int64_t>(), stride);
-    HIP_TRY(hipGetLastError());
-    const int every = derived_mark_every(h, ix->opt.mark_every);
-    if (every) {  // denser marks: set the extra bits, then recount the marks before every line
-      for (int64_t r0 = 0; r0 < n; r0 += chunk) {
-        const int64_t cn = std::min(chunk, n - r0);
-        hipLaunchKernelGGL(pack_densify_kernel<false>, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, ix->d_pack, r0, cn,
-                           sym.as<uint8_t>(), every, int(h.mark_period), static_cast<int64_t*>(nullptr));
-      }
-      hipLaunchKernelGGL(pack_recount_marks_kernel, dim3(uint32_t((nlines + 255) / 256)), dim3(256), 0, nullptr, nlines, ix->d_pack,
-                         counts.as<int64_t>() + 8 * stride);
-      HIP_TRY(hipGetLastError());
-      if ((rc = device_scan(ix->open_scan, nlines, counts.as<int64_t>() + 8 * stride, scans.as<int64_t>() + 8 * stride, 0, nullptr))) return rc;
-      hipLaunchKernelGGL(pack_markcount_kernel, dim3(uint32_t((nlines + 255) / 256)), dim3(256), 0, nullptr, nlines, ix->d_pack,
-                         scans.as<int64_t>() + 8 * stride);
-      HIP_TRY(hipGetLastError());
-    }
-    int64_t nmarks = 0;
-    HIP_TRY(hipMemcpy(&nmarks, scans.as<int64_t>() + 8 * stride + nlines, 8, hipMemcpyDeviceToHost));
-    HIP_TRY(big_malloc(ix, reinterpret_cast<void**>(&ix->d_pack_sa), size_t(nmarks > 0 ? nmarks : 1) * 8));
-    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
-      const int64_t cn = std::min(chunk, n - r0);
-      if (every)
-        hipLaunchKernelGGL(pack_densify_kernel<true>, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, ix->d_pack, r0, cn,
-                           sym.as<uint8_t>(), every, int(h.mark_period), ix->d_pack_sa);
-      else
-        hipLaunchKernelGGL(pack_sa_kernel, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, r0, cn, sym.as<uint8_t>(),
-                           ix->d_pack, ix->d_pack_sa);
-    }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(e1, nullptr));
-    HIP_TRY(hipDeviceSynchronize());
-    ix->n_marks = nmarks;
-    ix->pack_bytes = nlines * kPackLineWords * 4 + nmarks * 8;
-    ix->table_bytes += ix->pack_bytes;
-    return 0;
-  };
-  r = body();
-  cleanup();
-  if (r == 0) {
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    ix->pack_build_ms = ms;
-    ix->dev.pack = ix->d_pack;
-    ix->dev.pack_sa = ix->d_pack_sa;
-  }
-  return r;
-}
-
-// Derives the two-level lines of pack2_kernels.hip.hpp on the GPU (needs the lane tables).
-int build_pack2(femto_amd_index* ix) {
-  HostIndex& h = ix->host;
-  if (!h.dir_regular || h.total_length <= 0) return 0;
-  const int64_t want2 = knob(ix->opt.two_level_lines, "FEMTO_AMD_PACK2", -1);   // -1: only where the packed lines do not apply
-  if (want2 == 0) return 0;
-  if (ix->dev.pack && want2 <= 0) return 0;   // the 3-bit lines already serve this index
-  std::vector<uint16_t> code(264, 0xffff), alpha(256, uint16_t(kAlphaSize));
-  std::vector<int64_t> pc(512, 0);
-  int sigma = 0;
-  uint32_t stop_below = 0;
-  for (int ch = 0; ch < kAlphaSize; ch++)
-    if (h.C[size_t(ch) + 1] > h.C[size_t(ch)]) {
-      if (sigma == 256) return 0;  // more than 256 distinct characters: the wavelet path stays
-      alpha[size_t(sigma)] = uint16_t(ch);
-      pc[size_t(sigma)] = h.C[size_t(ch)];
-      pc[256 + size_t(sigma)] = h.C[size_t(ch) + 1] - 1;
-      if (ch <= kSEOF) stop_below = uint32_t(sigma) + 1;
-      code[size_t(ch)] = uint16_t(sigma++);
-    }
-  EventPair ev;
-  hipEvent_t &e0 = ev.e0, &e1 = ev.e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
-  HIP_TRY(hipEventRecord(e0, nullptr));
-  int r;
-  int64_t bytes0 = ix->table_bytes;
-  if ((r = upload(&ix->d_p2_code, code, &ix->table_bytes))) return r;
-  if ((r = upload(&ix->d_p2_alpha, alpha, &ix->table_bytes))) return r;
-  if ((r = upload(&ix->d_p2_c, pc, &ix->table_bytes))) return r;
-  DevIndex& d = ix->dev;
-  d.p2_code = ix->d_p2_code;
-  d.p2_alpha = ix->d_p2_alpha;
-  d.p2_c = ix->d_p2_c;
-  d.p2_sigma = sigma;
-  d.p2_stop_below = stop_below;
-  const int64_t n = h.total_length;
-  const int64_t nl1 = (n + kP2Rows1 - 1) / kP2Rows1, stride1 = nl1 + 1;
-  DeviceBuffer sym, counts, scans, lo2;
-  auto body = [&]() -> int {
-    int rc;
-    if ((rc = sym.reserve(size_t(n) * 2))) return rc;
-    if ((rc = counts.reserve(size_t(17 * stride1) * 8))) return rc;
-    if ((rc = scans.reserve(size_t(17 * stride1) * 8))) return rc;
-    HIP_TRY(big_malloc(ix, reinterpret_cast<void**>(&ix->d_p2_l1), size_t(nl1) * 128));
-    const int64_t chunk = int64_t(1) << 30;
-    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
-      const int64_t cn = std::min(chunk, n - r0);
-      hipLaunchKernelGGL(p2_extract_kernel, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, r0, cn, sym.as<uint16_t>());
-    }
-    hipLaunchKernelGGL(p2_l1_planes_kernel, dim3(uint32_t((nl1 + 255) / 256)), dim3(256), 0, nullptr, nl1, n, sym.as<uint16_t>(), ix->d_p2_l1,
-                       counts.as<int64_t>(), stride1);
-    HIP_TRY(hipGetLastError());
-    for (int c = 0; c < 17; c++)
-      if ((rc = device_scan(ix->open_scan, nl1, counts.as<int64_t>() + c * stride1, scans.as<int64_t>() + c * stride1, 0, nullptr))) return rc;
-    hipLaunchKernelGGL(p2_l1_counts_kernel, dim3(uint32_t((nl1 + 255) / 256)), dim3(256), 0, nullptr, nl1, ix->d_p2_l1, scans.as<int64_t>(), stride1);
-    HIP_TRY(hipGetLastError());
-    d.p2_l1 = ix->d_p2_l1;
-    // level 2: every h starts on a line boundary
-    std::vector<int64_t> tot(17), base(16);
-    for (int c = 0; c < 17; c++) HIP_TRY(hipMemcpy(&tot[size_t(c)], scans.as<int64_t>() + c * stride1 + nl1, 8, hipMemcpyDeviceToHost));
-    int64_t nl2 = 0;
-    for (int k = 0; k < 16; k++) {
-      base[size_t(k)] = nl2;
-      nl2 += (tot[size_t(k)] + kP2Rows2 - 1) / kP2Rows2;
-    }
-    if (nl2 == 0) nl2 = 1;
-    if ((rc = upload(&ix->d_p2_base, base, &ix->table_bytes))) return rc;
-    d.p2_base = ix->d_p2_base;
-    const int64_t stride2 = nl2 + 1;
-    if ((rc = lo2.reserve(size_t(nl2) * kP2Rows2))) return rc;
-    HIP_TRY(hipMemset(lo2.p, 0, size_t(nl2) * kP2Rows2));
-    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
-      const int64_t cn = std::min(chunk, n - r0);
-      hipLaunchKernelGGL(p2_scatter_kernel, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, r0, cn, sym.as<uint16_t>(),
-                         lo2.as<uint8_t>());
-    }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(big_malloc(ix, reinterpret_cast<void**>(&ix->d_p2_l2), size_t(nl2) * 128));
-    // the level-1 scratch is free again: reuse it for the level-2 counts when it is large enough
-    if ((rc = counts.reserve(size_t(16 * stride2) * 8))) return rc;
-    if ((rc = scans.reserve(size_t(16 * stride2) * 8))) return rc;
-    hipLaunchKernelGGL(p2_l2_planes_kernel, dim3(uint32_t((nl2 + 255) / 256)), dim3(256), 0, nullptr, nl2, lo2.as<uint8_t>(), ix->d_p2_l2,
-                       counts.as<int64_t>(), stride2);
-    HIP_TRY(hipGetLastError());
-    for (int c = 0; c < 16; c++)
-      if ((rc = device_scan(ix->open_scan, nl2, counts.as<int64_t>() + c * stride2, scans.as<int64_t>() + c * stride2, 0, nullptr))) return rc;
-    hipLaunchKernelGGL(p2_l2_counts_kernel, dim3(uint32_t((nl2 + 255) / 256)), dim3(256), 0, nullptr, ix->dev, nl2, ix->d_p2_l2,
-                       scans.as<int64_t>(), stride2);
-    HIP_TRY(hipGetLastError());
-    d.p2_l2 = ix->d_p2_l2;
-    {  // per-character rank lines (ind_kernels.hip.hpp) while the symbols are at hand -- optional: a quarter of the free HBM
-      const bool want = knob(ix->opt.char_rank_lines, "FEMTO_AMD_IND", 1) != 0;
-      const int64_t groups = (n + kIndRows - 1) / kIndRows, istride = groups + 1;
-      const size_t ibytes = size_t(sigma) * size_t(istride) * 128;
-      const size_t free_b = hbm_free(ix);
-      if (want && ibytes <= free_b / 4 && big_malloc(ix, reinterpret_cast<void**>(&ix->d_ind), ibytes + 256) == hipSuccess) {
-        HIP_TRY(big_memset(ix, ix->d_ind, 0, ibytes + 256));
-        const int64_t gchunk = int64_t(1) << 22;
-        for (int64_t g0 = 0; g0 < groups; g0 += gchunk)
-          hipLaunchKernelGGL(ind_build_kernel, dim3(uint32_t(std::min(gchunk, groups - g0))), dim3(256), 0, nullptr, ix->dev, n, sym.as<uint16_t>(),
-                             ix->d_ind, istride, g0);
-        HIP_TRY(hipGetLastError());
-        d.ind = ix->d_ind;
-        d.ind_stride = istride;
-        ix->ind_bytes = int64_t(ibytes);
-        ix->table_bytes += ix->ind_bytes;
-      } else {
-        (void)hipGetLastError();
-      }
-    }
-    int64_t sa_bytes = 0;
-    const int every = derived_mark_every(h, ix->opt.mark_every);
-    int64_t nmarks = tot[16];
-    if (every) {  // denser marks (the same rows the 3-bit lines mark, so the offsets array can be shared)
-      for (int64_t r0 = 0; r0 < n; r0 += chunk) {
-        const int64_t cn = std::min(chunk, n - r0);
-        hipLaunchKernelGGL(p2_densify_kernel<false>, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, ix->d_p2_l1, r0, cn,
-                           sym.as<uint16_t>(), every, int(h.mark_period), static_cast<int64_t*>(nullptr));
-      }
-      if ((rc = counts.reserve(size_t(2 * stride1) * 8))) return rc;
-      hipLaunchKernelGGL(p2_recount_marks_kernel, dim3(uint32_t((nl1 + 255) / 256)), dim3(256), 0, nullptr, nl1, ix->d_p2_l1, counts.as<int64_t>());
-      HIP_TRY(hipGetLastError());
-      if ((rc = device_scan(ix->open_scan, nl1, counts.as<int64_t>(), counts.as<int64_t>() + stride1, 0, nullptr))) return rc;
-      hipLaunchKernelGGL(p2_markcount_kernel, dim3(uint32_t((nl1 + 255) / 256)), dim3(256), 0, nullptr, nl1, ix->d_p2_l1,
-                         counts.as<int64_t>() + stride1);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipMemcpy(&nmarks, counts.as<int64_t>() + stride1 + nl1, 8, hipMemcpyDeviceToHost));
-    }
-    if (!ix->d_pack_sa) {  // offsets of the marked rows (shared with the 3-bit lines when both exist)
-      HIP_TRY(big_malloc(ix, reinterpret_cast<void**>(&ix->d_pack_sa), size_t(nmarks > 0 ? nmarks : 1) * 8));
-      for (int64_t r0 = 0; r0 < n; r0 += chunk) {
-        const int64_t cn = std::min(chunk, n - r0);
-        if (every)
-          hipLaunchKernelGGL(p2_densify_kernel<true>, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, ix->d_p2_l1, r0, cn,
-                             sym.as<uint16_t>(), every, int(h.mark_period), ix->d_pack_sa);
-        else
-          hipLaunchKernelGGL(p2_sa_kernel, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, r0, cn, sym.as<uint16_t>(),
-                             ix->d_pack_sa);
-      }
-      HIP_TRY(hipGetLastError());
-      d.pack_sa = ix->d_pack_sa;
-      sa_bytes = nmarks * 8;
-    }
-    HIP_TRY(hipEventRecord(e1, nullptr));
-    HIP_TRY(hipDeviceSynchronize());
-    ix->p2_lines1 = nl1;
-    ix->p2_lines2 = nl2;
-    if (sa_bytes) ix->n_marks = nmarks;
-    ix->table_bytes += (nl1 + nl2) * 128 + sa_bytes;
-    return 0;
-  };
-  r = body();
-  sym.release();
-  counts.release();
-  scans.release();
-  lo2.release();
-  if (r == 0) {
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    ix->pack2_build_ms = ms;
-    ix->pack2_bytes = ix->table_bytes - bytes0;
-  } else {
-    d.p2_l1 = nullptr;
-    d.p2_l2 = nullptr;
-  }
-  return r;
-}
-
-// text + inverse suffix array for the long-pattern tail (text_kernels.hip.hpp); optional (FEMTO_AMD_TEXT=0).
-// When HBM allows (each at most a fifth of what is free; FEMTO_AMD_DENSE=0 declines) the inverse suffix array is kept for
-// EVERY text position instead of every 8th, and the suffix array itself for every row: locating a row is then one
-// 8-byte read instead of a walk of LF steps, the row of a text position one read instead of up to 7 LF steps.  This is
-// femto's own space/time knob -- mark_period (src/main/index.c:122-142) -- turned to 1 in HBM; the files stay as they are.
-int build_text(femto_amd_index* ix) {
-  if (knob(ix->opt.text, "FEMTO_AMD_TEXT", 1) == 0) return 0;
-  const int64_t n = ix->host.total_length;
-  const bool dense = knob(ix->opt.dense_arrays, "FEMTO_AMD_DENSE", 1) != 0;
-  const size_t free_b = hbm_free(ix);
-  // Dense arrays -- SA of every row and ISA of every position, 8 B each per row -- when the pair takes at most 55 % of
-  // the free HBM (the level table, built next, takes at most a quarter of what is left): 17 GB of 288 at 1 GiB of text,
-  // 137 GB at 8 GiB (BASELINE configs[4]: a located row is then one read instead of up to four LF steps).  Failing that
-  // the suffix array alone when it fits 30 %; the ISA is then sampled.
-  int isa_shift = kIsaShift;
-  bool want_sa = false;
-  if (dense && double(n + 2) * 16.0 <= 0.55 * double(free_b)) {
-    isa_shift = 0;
-    want_sa = true;
-  } else if (dense && double(n) * 8.0 <= 0.30 * double(free_b)) {
-    want_sa = true;
-  }
-  const size_t tb = size_t(n) + 64, ib = (size_t(n >> isa_shift) + 2) * 8, sb = want_sa ? size_t(n) * 8 + 64 : 0;
-  if (big_malloc(ix, reinterpret_cast<void**>(&ix->d_txt), tb) != hipSuccess || big_malloc(ix, reinterpret_cast<void**>(&ix->d_isa8), ib) != hipSuccess ||
-      (sb && big_malloc(ix, reinterpret_cast<void**>(&ix->d_sa_full), sb) != hipSuccess)) {
-    (void)hipGetLastError();
-    big_free(ix, ix->d_txt); ix->d_txt = nullptr;
-    big_free(ix, ix->d_isa8); ix->d_isa8 = nullptr;
-    big_free(ix, ix->d_sa_full); ix->d_sa_full = nullptr;
-    return FEMTO_AMD_ERR_MEM;
-  }
-  HIP_TRY(big_memset(ix, ix->d_txt, 0xff, tb));
-  HIP_TRY(big_memset(ix, ix->d_isa8, 0, ib));
-  const int64_t chunk = int64_t(1) << 30;
-  for (int64_t r0 = 0; r0 < n; r0 += chunk) {
-    const int64_t cn = std::min(chunk, n - r0);
-    const dim3 grid{uint32_t((cn + 255) / 256)}, block{256};
-    if (ix->dev.pack) {
-      if (sb) hipLaunchKernelGGL((text_isa_build_kernel<PackPolicy, true>), grid, block, 0, nullptr, ix->dev, r0, cn, ix->d_txt, ix->d_isa8, isa_shift, ix->d_sa_full);
-      else hipLaunchKernelGGL((text_isa_build_kernel<PackPolicy, false>), grid, block, 0, nullptr, ix->dev, r0, cn, ix->d_txt, ix->d_isa8, isa_shift, ix->d_sa_full);
-    } else {
-      if (sb) hipLaunchKernelGGL((text_isa_build_kernel<Pack2Policy, true>), grid, block, 0, nullptr, ix->dev, r0, cn, ix->d_txt, ix->d_isa8, isa_shift, ix->d_sa_full);
-      else hipLaunchKernelGGL((text_isa_build_kernel<Pack2Policy, false>), grid, block, 0, nullptr, ix->dev, r0, cn, ix->d_txt, ix->d_isa8, isa_shift, ix->d_sa_full);
-    }
-  }
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
-  ix->dev.txt = ix->d_txt;
-  ix->dev.isa8 = ix->d_isa8;
-  ix->dev.isa_shift = isa_shift;
-  ix->dev.sa_full = ix->d_sa_full;
-  ix->text_bytes = int64_t(tb + ib + sb);
-  ix->table_bytes += ix->text_bytes;
   return 0;
 }
 
@@ -1700,209 +1129,6 @@ int multi_run(femto_amd_index* ix, int64_t npats, Fn fn) {
 
 
 const char* femto_amd_last_error(void) { return g_last_error.c_str(); }
-
-int femto_amd::open_impl(const char* index_path, int device, int part, int nparts, femto_amd_index_t** out,
-                         const std::vector<int>* stripe, const femto_amd_options_t* opts) {
-  if (!index_path || !out) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
-  *out = nullptr;
-  if (opts && opts->struct_size != sizeof(femto_amd_options_t))
-    return set_err(FEMTO_AMD_ERR_PARAM, "femto_amd_options_t of another library version (use femto_amd_options_init)");
-  const bool split = nparts > 0;
-  femto_amd_index* ix = new (std::nothrow) femto_amd_index();
-  if (!ix) return set_err(FEMTO_AMD_ERR_MEM, "out of memory");
-  if (opts) ix->opt = *opts;
-  else femto_amd_options_init(&ix->opt);
-  if (stripe) ix->stripe_devices = *stripe;     // the big arrays of this handle are striped over these GPUs (big_malloc)
-  Error err{0, ""};
-  int rc;
-  try {
-    rc = ix->host.load(index_path, &err);
-  } catch (const std::bad_alloc&) {
-    rc = FEMTO_AMD_ERR_MEM;
-    err.msg = "out of memory while reading the index";
-  } catch (const std::exception& ex) {   // a size taken from a damaged header
-    rc = FEMTO_AMD_ERR_FORMAT;
-    err.msg = std::string("damaged index: ") + ex.what();
-  }
-  if (rc) {
-    delete ix;
-    return set_err(rc, err.msg);
-  }
-  ix->device = device;
-  if (device >= 0) {
-    int ndev = 0;
-    hipError_t he = hipGetDeviceCount(&ndev);
-    if (he != hipSuccess || device >= ndev) {
-      delete ix;
-      return set_err(FEMTO_AMD_ERR_INVALID, "no usable HIP device " + std::to_string(device) +
-                                                " (this library has no CPU fallback)");
-    }
-    auto up = [&]() -> int {
-      HIP_TRY(hipSetDevice(device));
-      {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ix->hbm_free_at_open = int64_t(free_b);
-      }
-      HostIndex& h = ix->host;
-      int r;
-      if (!split) {
-        const size_t image_slack = size_t(h.b_size) * size_t(h.text_size_bits) / 8 + 64;   // a mark array read one bucket too far
-        HIP_TRY(big_malloc(ix, reinterpret_cast<void**>(&ix->d_image), h.image.size() + image_slack));
-        HIP_TRY(big_h2d(ix, ix->d_image, h.image.data(), h.image.size()));
-        HIP_TRY(big_memset(ix, ix->d_image + h.image.size(), 0, image_slack));
-        if ((r = upload(&ix->d_nodes, h.nodes, &ix->table_bytes))) return r;
-        if ((r = upload(&ix->d_seqs, h.seqs, &ix->table_bytes))) return r;
-        if ((r = upload(&ix->d_leaf_code, h.leaf_code, &ix->table_bytes))) return r;
-        {  // the segment lines: a big array (striped when the index is)
-          const size_t sb = h.segs.size() * 8, slack = (size_t(h.b_size) / 511 + 4) * 128;
-          HIP_TRY(big_malloc(ix, reinterpret_cast<void**>(&ix->d_segs), sb + slack));
-          if (sb) HIP_TRY(big_h2d(ix, ix->d_segs, h.segs.data(), sb));
-          HIP_TRY(big_memset(ix, reinterpret_cast<char*>(ix->d_segs) + sb, 0, slack));
-          ix->table_bytes += int64_t(sb);
-        }
-        if ((r = upload(&ix->d_cum, h.cum, &ix->table_bytes))) return r;
-        if ((r = upload(&ix->d_hint, h.hint, &ix->table_bytes))) return r;
-        if ((r = upload(&ix->d_lnodes, h.lnodes, &ix->table_bytes))) return r;
-        if ((r = upload(&ix->d_lseqs, h.lseqs, &ix->table_bytes))) return r;
-      } else {
-        // Only this part's blocks: their segment lines and their images (mark arrays).  The lane tables that
-        // point into them (lnodes/lseqs) are uploaded by femto_amd_split_commit once every owner is mapped.
-        if (!h.dir_regular) return set_err(FEMTO_AMD_ERR_INVALID, "range-split needs the lane tables (index has a short non-final segment)");
-        const int64_t nb = h.number_of_blocks;
-        ix->split_parts = nparts;
-        ix->split_part = part;
-        ix->split_blo.resize(size_t(nparts) + 1);
-        for (int p = 0; p <= nparts; p++) ix->split_blo[size_t(p)] = nb * p / nparts;
-        const int64_t b0 = ix->split_blo[size_t(part)], b1 = ix->split_blo[size_t(part) + 1];
-        const uint64_t s0 = h.block_slot_start[size_t(b0)], s1 = h.block_slot_start[size_t(b1)];
-        uint64_t i0, i1;
-        block_image_range(h, b0, b1, &i0, &i1);
-        ix->split_seg_bytes = int64_t((s1 - s0) * kSegmentWords * 8);
-        ix->split_image_bytes = int64_t(i1 - i0);
-        // the same zero slack as the full upload: a damaged index may make a kernel read up to a bucket's worth past a table
-        const size_t seg_slack = (size_t(h.b_size) / 511 + 4) * 128, img_slack = size_t(h.b_size) * size_t(h.text_size_bits) / 8 + 256;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_segs), size_t(ix->split_seg_bytes) + seg_slack));
-        HIP_TRY(hipMemset(ix->d_segs, 0, size_t(ix->split_seg_bytes) + seg_slack));
-        if (s1 > s0) HIP_TRY(hipMemcpy(ix->d_segs, h.segs.data() + s0 * kSegmentWords, size_t(ix->split_seg_bytes), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_image), size_t(ix->split_image_bytes) + img_slack));
-        HIP_TRY(hipMemset(ix->d_image, 0, size_t(ix->split_image_bytes) + img_slack));
-        if (i1 > i0) HIP_TRY(hipMemcpy(ix->d_image, h.image.data() + i0, size_t(ix->split_image_bytes), hipMemcpyHostToDevice));
-        ix->table_bytes += ix->split_seg_bytes;
-        ix->peer_segs.assign(size_t(nparts), nullptr);
-        ix->peer_image.assign(size_t(nparts), nullptr);
-        ix->peer_ipc.assign(size_t(nparts), 0);
-        ix->peer_segs[size_t(part)] = ix->d_segs;
-        ix->peer_image[size_t(part)] = ix->d_image;
-      }
-      if ((r = upload(&ix->d_buckets, h.buckets, &ix->table_bytes, 4 * sizeof(DevBucket)))) return r;
-      if ((r = upload(&ix->d_occ_base, h.occ_base, &ix->table_bytes, 4 * kAlphaSize * 8))) return r;
-      if ((r = upload(&ix->d_C, h.C, &ix->table_bytes))) return r;
-      if ((r = upload(&ix->d_bdir, h.bdir, &ix->table_bytes, (size_t(h.b_size) / 512 + 4) * sizeof(BlockDir)))) return r;
-      if ((r = upload(&ix->d_occ, h.occ, &ix->table_bytes, 4 * kAlphaSize * sizeof(OccEntry)))) return r;
-      {  // dense sort digits: characters with C[ch+1] > C[ch] occur in the text
-        std::vector<uint8_t> dense(512, 0);
-        int sigma = 0;
-        for (int ch = 0; ch < kAlphaSize; ch++)
-          if (h.C[size_t(ch) + 1] > h.C[size_t(ch)]) {
-            // digit = 1 + rank of the character; an 8-bit digit holds ranks 0..254 -- the 256th (and 257th) character of a
-            // full byte alphabet gets digit 0 ("not in the key"): kernels that search from the keys then read that
-            // symbol from the pattern itself, and the sort merely loses locality for such patterns
-            ++sigma;
-            dense[size_t(ch)] = uint8_t(sigma <= 255 ? sigma : 0);
-          }
-        int bits = 1;
-        while ((1 << bits) <= (sigma > 255 ? 255 : sigma)) bits++;
-        ix->dense_bits = bits;
-        ix->dense_sigma = sigma < 2 ? 2 : sigma;
-        if ((r = upload(&ix->d_dense, dense, &ix->table_bytes))) return r;
-        if (sigma <= 255) ix->h_dense = dense;    // keys need every character of the text to have a digit
-      }
-      DevIndex& d = ix->dev;
-      d.image = ix->d_image;
-      d.nodes = ix->d_nodes;
-      d.buckets = ix->d_buckets;
-      d.seqs = ix->d_seqs;
-      d.occ_base = ix->d_occ_base;
-      d.leaf_code = ix->d_leaf_code;
-      d.C = ix->d_C;
-      d.segs = ix->d_segs;
-      d.cum = ix->d_cum;
-      d.hint = ix->d_hint;
-      d.bdir = ix->d_bdir;
-      d.lnodes = ix->d_lnodes;
-      d.lseqs = ix->d_lseqs;
-      d.occ = ix->d_occ;
-      d.total_length = h.total_length;
-      d.total_buckets = h.total_buckets;
-      d.b_size = h.b_size;
-      d.b_shift = (h.b_size & (h.b_size - 1)) == 0 ? __builtin_ctz(unsigned(h.b_size)) : -1;
-      d.text_size_bits = h.text_size_bits;
-      d.walk_limit = 2 * (h.mark_period > 0 ? h.mark_period : 1) + 8;
-      {
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, device));
-        ix->num_cus = prop.multiProcessorCount;
-        ix->sort_queries = knob(ix->opt.sort_queries, "FEMTO_AMD_SORT", 1) != 0;
-      }
-      ix->mode = h.dir_regular ? 1 : 0;
-      if (split) return 0;  // lane kernels only
-      // The derived fast-path layouts are optional: when HBM is too small for them the index still opens and
-      // runs the wavelet-path kernels (on the GPU -- there is no CPU path to fall back to).
-      r = build_pack(ix);
-      if (r == FEMTO_AMD_ERR_MEM) {
-        (void)hipGetLastError();
-        big_free(ix, ix->d_pack); ix->d_pack = nullptr;
-        if (!ix->dev.pack_sa) { big_free(ix, ix->d_pack_sa); ix->d_pack_sa = nullptr; }
-        ix->dev.pack = nullptr;
-        r = 0;
-      }
-      if (r) return r;
-      r = build_pack2(ix);
-      if (r == FEMTO_AMD_ERR_MEM) {
-        (void)hipGetLastError();
-        big_free(ix, ix->d_p2_l1); ix->d_p2_l1 = nullptr;
-        big_free(ix, ix->d_p2_l2); ix->d_p2_l2 = nullptr;
-        ix->dev.p2_l1 = nullptr;
-        ix->dev.p2_l2 = nullptr;
-        r = 0;
-      }
-      if (r) return r;
-      if ((ix->dev.pack || ix->dev.p2_l1) && (r = build_text(ix)) && r != FEMTO_AMD_ERR_MEM) return r;
-      if (ix->dev.pack) ix->mode = 3;
-      else if (ix->dev.p2_l1) ix->mode = 4;
-      if (ix->dev.pack) r = build_ktab2<PackPolicy>(ix, ix->dev.pack_sigma, __builtin_popcount(ix->dev.pack_stop));
-      else if (ix->dev.p2_l1) r = build_ktab2<Pack2Policy>(ix, ix->dev.p2_sigma, int(ix->dev.p2_stop_below));
-      if (r && r != FEMTO_AMD_ERR_MEM) return r;
-      if (ix->dev.p2_l1 && !ix->dev.pack && (r = build_ctx(ix, int(ix->dev.p2_stop_below))) && r != FEMTO_AMD_ERR_MEM) return r;
-      if (ix->dev.ctx && (r = build_ctx2(ix, int(ix->dev.p2_stop_below))) && r != FEMTO_AMD_ERR_MEM) return r;
-      for (DeviceBuffer& b : ix->open_scan) b.release();
-      int want_mode = ix->opt.rank_mode;
-      if (want_mode < 0)
-        if (const char* m = getenv("FEMTO_AMD_RANK_MODE"))
-          want_mode = !strcmp(m, "raw") ? 0 : (!strcmp(m, "lane") ? 1 : (!strcmp(m, "pack") ? 3 : (!strcmp(m, "pack2") ? 4 : -1)));
-      if (want_mode == 0) ix->mode = 0;
-      else if (want_mode == 1 && h.dir_regular) ix->mode = 1;
-      else if (want_mode == 3 && ix->dev.pack) ix->mode = 3;
-      else if (want_mode == 4 && ix->dev.p2_l1) ix->mode = 4;
-      return 0;
-    };
-    g_small_registry = &ix->small_tables;
-    try {
-      rc = up();
-    } catch (const std::bad_alloc&) {
-      rc = set_err(FEMTO_AMD_ERR_MEM, "out of memory");
-    } catch (const std::exception& ex) {
-      rc = set_err(FEMTO_AMD_ERR_FORMAT, std::string("damaged index: ") + ex.what());
-    }
-    g_small_registry = nullptr;
-    if (rc) {
-      femto_amd_close(ix);
-      return rc;
-    }
-  }
-  *out = ix;
-  return FEMTO_AMD_OK;
-}
 
 extern "C" {
 

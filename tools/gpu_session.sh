@@ -1,4 +1,7 @@
 set -u
 SECONDS=0
-timeout 760 python bench.py --steps 10 --warmup 3 --workload acgt_hit --text-log2 33 --no-extra --cpu-sample 20000 --ref-sample 10000 > gpurun_out/r03_cfg5_rerun.json 2> gpurun_out/r03_cfg5_rerun.err; grep -v amdgpu.ids gpurun_out/r03_cfg5_rerun.err | tail -2 | cut -c1-300
+timeout 520 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|Error|error|assert" | tail -6 | cut -c1-220
+echo "tests: $SECONDS s"
+timeout 100 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -2
+timeout 200 bash tools/quick_bench.sh headline -- --steps 20 --warmup 5
 echo "all: $SECONDS s"
