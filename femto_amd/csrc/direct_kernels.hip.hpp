@@ -168,7 +168,7 @@ __host__ __device__ inline PlanSums plan_sums_at(void* base, int64_t nblocks, bo
 // last matching position = ISA[..] (one read) -- instead of being handed to count_tail_kernel (whose LF walks only
 // exist because the sampled arrays need them).  Same result as stepping on: see text_kernels.hip.hpp.
 template <class P, bool kPlan, bool kDense>
-inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, P::kWaves))) void count_direct_kernel(
+inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kDirectWaves, P::kDirectWaves))) void count_direct_kernel(
     const DevIndex ix, const int64_t npats, const int32_t* __restrict__ plen, const uint16_t* __restrict__ pats,
     const int64_t* __restrict__ starts, int64_t* __restrict__ first_out, int64_t* __restrict__ last_out, int* __restrict__ err_flag,
     const int max_occs, int32_t* __restrict__ noccs, const PlanSums ps, int* __restrict__ big_flag) {

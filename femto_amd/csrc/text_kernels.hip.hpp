@@ -25,6 +25,7 @@ struct TailItem {
 
 struct PackPolicy {
   static constexpr int kWaves = 8;     // waves per SIMD the count kernel is built for (64 VGPRs)
+  static constexpr int kDirectWaves = 7;   // ... count_direct_kernel: 72 VGPRs (at 64 it spills 20 bytes per lane)
   static constexpr int kTailRows = 1;  // ranges of up to this many rows take the text tail (direct_kernels.hip.hpp)
   static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
     pack_search_step(ix, ix.pack, j, code, f, l);
@@ -55,6 +56,7 @@ struct PackPolicy {
 
 struct Pack2Policy {
   static constexpr int kWaves = 8;
+  static constexpr int kDirectWaves = 8;
   static constexpr int kTailRows = 4;  // repeated phrases of a byte text: a few rows with tens of symbols to go
   static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
     p2_search_step(ix, j, code, f, l);
