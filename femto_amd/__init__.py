@@ -45,7 +45,8 @@ class Options(C.Structure):
                 ("context_table", C.c_int32), ("context_syms", C.c_int32), ("context2_table", C.c_int32), ("context2_syms", C.c_int32),
                 ("context2_bytes", C.c_int64), ("tail_min", C.c_int32), ("tail_ones", C.c_int32), ("tail_rows", C.c_int32),
                 ("tail_row_cost", C.c_int32), ("sort_queries", C.c_int32), ("host_threads", C.c_int32), ("host_pipeline", C.c_int32),
-                ("host_keys", C.c_int32), ("host_pipe_chunk_log2", C.c_int32), ("host_d2h_staged", C.c_int32)]
+                ("host_keys", C.c_int32), ("host_pipe_chunk_log2", C.c_int32), ("host_d2h_staged", C.c_int32),
+                ("rank_units", C.c_int32), ("marks_32bit", C.c_int32)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -183,6 +184,7 @@ def lib():
         L.femto_amd_set_rank_mode.argtypes = [vp, i32]
         L.femto_amd_get_rank_mode.argtypes = [vp]
         L.femto_amd_pack_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(i32)]
+        L.femto_amd_structures.argtypes = [vp, vp, i32]
         L.femto_amd_flatten_index.argtypes = [C.c_char_p, C.c_char_p]
         L.femto_amd_bseq_encode.argtypes = [vp, i64, i32, vp, i64, C.POINTER(i64)]
         L.femto_amd_open_split.argtypes = [C.c_char_p, i32, i32, i32, C.POINTER(vp)]
@@ -369,8 +371,16 @@ class Index:
         _check(lib().femto_amd_pack_info(self._h, C.byref(a), C.byref(b), C.byref(ms), C.byref(k)))
         return {"available": bool(a.value & 1), "available2": bool(a.value & 2), "level_table": bool(a.value & 4),
                 "sa_full": bool(a.value & 8), "isa_full": bool(a.value & 16), "char_rank_lines": bool(a.value & 32), "context_table": bool(a.value & 64),
-                "context_syms": (a.value >> 8) & 15, "context2_syms": (a.value >> 12) & 31,
+                "context_syms": (a.value >> 8) & 15, "context2_syms": (a.value >> 12) & 31, "rank_units": bool(a.value & (1 << 20)),
                 "bytes": b.value, "build_ms": ms.value, "ktab_syms": k.value}
+
+    def structures(self):
+        """femto_amd_structures: bytes of every structure the handle holds in HBM"""
+        out = (C.c_int64 * 16)()
+        _check(lib().femto_amd_structures(self._h, out, 16))
+        names = ["image", "packed_lines", "marks", "rank_units", "level_table", "context_tables", "char_rank_lines", "text_sa_isa",
+                 "two_level_lines", "derived_total", "mark_every", "level_table_syms", "mark_offset_bytes", "hbm_allocated"]
+        return {k: int(out[i]) for i, k in enumerate(names)}
 
     def document_info(self, doc):
         p, n = C.c_char_p(), C.c_int64(0)
@@ -428,7 +438,7 @@ class Index:
         _check(lib().femto_amd_locate_device(self._h, npats, d_plen, d_pats, d_starts, max_occs, d_first, d_last, d_noccs,
                                              d_out_starts, d_offsets, capacity, d_total, stream or None))
 
-    TRACE_REGIONS = ("pack_lines", "level_table", "suffix_array", "level1_lines", "level2_lines", "text", "isa", "ktab_r1", "char_rank_lines",
+    TRACE_REGIONS = ("pack_lines", "level_table", "suffix_array", "level1_lines", "level2_lines", "text", "isa", "rank_units", "char_rank_lines",
                      "context_table")
 
     def trace_lines(self, npats, d_plen, d_pats, d_starts, max_occs):
@@ -438,6 +448,13 @@ class Index:
         rows = C.c_int64(0)
         _check(lib().femto_amd_trace_lines(self._h, npats, d_plen, d_pats, d_starts, max_occs, _ptr(cl), _ptr(ll), C.byref(rows)))
         return dict(zip(self.TRACE_REGIONS, cl.tolist())), dict(zip(self.TRACE_REGIONS, ll.tolist())), rows.value
+
+    def trace_reads(self):
+        """line READS (not only distinct lines) per derived array of the count / the locate phase of the last trace_lines call"""
+        cr = np.zeros(10, dtype=np.int64)
+        lr = np.zeros(10, dtype=np.int64)
+        _check(lib().femto_amd_trace_reads(self._h, _ptr(cr), _ptr(lr)))
+        return dict(zip(self.TRACE_REGIONS, cr.tolist())), dict(zip(self.TRACE_REGIONS, lr.tolist()))
 
     # ---- multi-process gather of device-resident results (RCCL send/recv, femto_amd_comm_*)
     @staticmethod
@@ -484,13 +501,17 @@ class Index:
         arr = (NfaStruct * max(1, n))(*[a.struct() for a in nfas])
         start = np.zeros(n + 1, dtype=np.int64)
         status = np.zeros(max(1, n), dtype=np.int32)
-        m = max(1, int(max_results))
-        first, last = np.zeros(m, dtype=np.int64), np.zeros(m, dtype=np.int64)
-        mlen, cost = np.zeros(m, dtype=np.int32), np.zeros(m, dtype=np.int32)
+        m = max(0, int(max_results))      # 0: count only (result_start and the total; the result arrays come back empty)
+        first, last = np.zeros(max(1, m), dtype=np.int64), np.zeros(max(1, m), dtype=np.int64)
+        mlen, cost = np.zeros(max(1, m), dtype=np.int32), np.zeros(max(1, m), dtype=np.int32)
         tot = C.c_int64(0)
-        _check(lib().femto_amd_nfa_search_batch(self._h, n, C.cast(arr, C.c_void_p), m, _ptr(start), _ptr(first), _ptr(last), _ptr(mlen),
-                                                _ptr(cost), _ptr(status), C.byref(tot)))
-        k = tot.value
+        self.last_total = 0
+        try:
+            _check(lib().femto_amd_nfa_search_batch(self._h, n, C.cast(arr, C.c_void_p), m, _ptr(start), _ptr(first), _ptr(last), _ptr(mlen),
+                                                    _ptr(cost), _ptr(status), C.byref(tot)))
+        finally:
+            self.last_total = tot.value      # after ERR_FULL: the max_results to call again with
+        k = tot.value if m else 0
         return start, first[:k], last[:k], mlen[:k], cost[:k], status[:n]
 
     def regexp_search_batch(self, regexes, max_results=1 << 20, approx=None):

@@ -188,7 +188,10 @@ inline femto_amd_options_t femto_amd_auto_options() {
 struct femto_amd_index {
   HostIndex host;
   femto_amd_options_t opt = femto_amd_auto_options();   // the caller's options (femto_amd_open_opts); -1 = auto
-  int64_t hbm_free_at_open = -1; // free HBM when this handle started allocating (hbm_budget_bytes is counted from it)
+  int64_t hbm_free_at_open = -1; // free HBM when this handle started allocating
+  int64_t hbm_held = 0;          // bytes of the handle's PERSISTENT device allocations (big arrays + uploaded tables): what
+                                 // hbm_budget_bytes is counted against -- the scratch of the derivations at open comes and goes
+  std::vector<std::pair<void*, size_t>> big_allocs;   // big_malloc()ed arrays and their sizes
   int device = -1;
   std::mutex mu;   // mode switches, timers
   // device-resident index
@@ -235,6 +238,11 @@ struct femto_amd_index {
   double pack2_build_ms = 0;
   int64_t pack_bytes = 0;
   double pack_build_ms = 0;
+  uint64_t* d_ru = nullptr;         // rank units of small alphabets (ru_kernels.hip.hpp)
+  int64_t ru_bytes = 0;
+  int64_t last_trace_reads[2][16] = {};   // femto_amd_trace_lines: line READS of the count / the locate phase, per region
+  int64_t marks_bytes = 0;       // pack_sa
+  int mark_every_used = 0;       // distance between derived marks (0: femto's own marks)
   int num_cus = 256;
   DevIndex dev{};
   int64_t table_bytes = 0;

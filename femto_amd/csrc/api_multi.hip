@@ -360,20 +360,25 @@ int femto_amd_striped_serve(femto_amd_index_t* ix, const char* socket_path, int 
   strcpy(addr.sun_path, socket_path);
   const int ls = ::socket(AF_UNIX, SOCK_STREAM, 0);
   if (ls < 0) { close_fds(); return set_err(FEMTO_AMD_ERR_IO, "socket()"); }
-  // The descriptors handed out give read-write access to this process's GPU memory: the socket is created 0600 (the
-  // umask is narrowed around bind()), only a path that IS a socket is replaced, and every client must run as this user
-  // (SO_PEERCRED).  A client rank that died before attaching must not hang the builder: accept() and the hand-shake
-  // wait at most FEMTO_AMD_STRIPED_TIMEOUT seconds (default 600).
-  {
+  // The descriptors handed out give read-write access to this process's GPU memory: the socket file is created 0600 --
+  // fchmod() on the unbound socket sets the mode bind() creates the file with (Linux: the socket inode's mode, less the
+  // umask), so the process-wide umask is never touched (other threads of a Python / PyTorch host create files meanwhile) --
+  // and every client must run as this user (SO_PEERCRED).  A stale socket file of an earlier run is replaced only when
+  // bind() says the address is in use, and only if the path still IS a socket then.  A client rank that died before
+  // attaching must not hang the builder: accept() and the hand-shake wait at most FEMTO_AMD_STRIPED_TIMEOUT seconds (600).
+  (void)::fchmod(ls, 0600);
+  int bind_rc = ::bind(ls, reinterpret_cast<struct sockaddr*>(&addr), sizeof addr);
+  if (bind_rc && errno == EADDRINUSE) {
     struct stat sb;
-    if (::lstat(socket_path, &sb) == 0) {
-      if (!S_ISSOCK(sb.st_mode)) { ::close(ls); close_fds(); return set_err(FEMTO_AMD_ERR_PARAM, std::string(socket_path) + " exists and is not a socket"); }
-      ::unlink(socket_path);
+    if (::lstat(socket_path, &sb) != 0 || !S_ISSOCK(sb.st_mode)) {
+      ::close(ls);
+      close_fds();
+      return set_err(FEMTO_AMD_ERR_PARAM, std::string(socket_path) + " exists and is not a socket");
     }
+    ::unlink(socket_path);
+    bind_rc = ::bind(ls, reinterpret_cast<struct sockaddr*>(&addr), sizeof addr);
   }
-  const mode_t old_umask = ::umask(0177);
-  const int bind_rc = ::bind(ls, reinterpret_cast<struct sockaddr*>(&addr), sizeof addr);
-  ::umask(old_umask);
+  if (bind_rc == 0) (void)::chmod(socket_path, 0600);      // (belt and braces on kernels that ignore the fchmod)
   if (bind_rc || ::listen(ls, 64)) {
     ::close(ls);
     close_fds();

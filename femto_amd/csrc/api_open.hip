@@ -24,6 +24,7 @@
 #include "index_builder.hpp"
 #include "kernels.hip.hpp"
 #include "pack_kernels.hip.hpp"
+#include "ru_kernels.hip.hpp"
 #include "pack2_kernels.hip.hpp"
 #include "ind_kernels.hip.hpp"
 #include "text_kernels.hip.hpp"
@@ -58,6 +59,12 @@ int build_ktab2(femto_amd_index* ix, int sigma, int nstop) {
     budget = int64_t(free_b / 4);
     budget_row = int64_t(double(free_b) * 0.6);
   }
+  if (ix->opt.hbm_budget_bytes >= 0) {
+    // a handle with an HBM budget spends what is left of it here (the level table is built last and is what saves most
+    // lines per pattern), less a reserve for the handle's small allocations
+    const size_t free_b = hbm_free(ix);
+    budget = budget_row = int64_t(free_b) - std::min<int64_t>(int64_t(32) << 20, ix->opt.hbm_budget_bytes / 64);
+  }
   if (ix->opt.level_table_bytes >= 0) {
     budget = budget_row = std::max<int64_t>(1, ix->opt.level_table_bytes);
     level_cap = INT64_MAX;
@@ -66,24 +73,32 @@ int build_ktab2(femto_amd_index* ix, int sigma, int nstop) {
     level_cap = INT64_MAX;
   }
   const int want = int(knob(ix->opt.level_table_syms, "FEMTO_AMD_KTAB_SYMS", -1));
-  // level m holds t^m entries; bytes(K) = 16 * (1 + t + ... + t^(K-1)) + 8 * t^K
+  // level m holds t^m entries; the last two levels are compact (8 bytes), the levels above 16 bytes:
+  // bytes(K) = 16 * (1 + t + ... + t^(K-2)) + 8 * (t^(K-1) + t^K)
   int K = 0;
-  int64_t upper = 0, level = 1;       // entries of levels 0..K-1, entries of level K
-  std::vector<int64_t> lo{0};
+  int64_t level = 1;       // entries of level K
+  std::vector<int64_t> lo{0, 1};     // lo[m] = heap position of level m's first entry; lo[K + 1] = entries in all
+  auto table_bytes = [&](int k) -> int64_t {        // of a table whose deepest level is k (lo[] filled up to k + 1)
+    const int cfrom = k >= 2 ? k - 1 : k;
+    return lo[size_t(cfrom)] * 16 + (lo[size_t(k) + 1] - lo[size_t(cfrom)]) * 8;
+  };
   for (;;) {
     if (K >= 24 || level > (int64_t(1) << 40) / t) break;
     const int64_t next_level = level * t;
     const int64_t allowed = next_level <= ix->host.total_length ? budget_row : budget;
-    if (want >= 0 ? K >= want : (next_level > level_cap || ((upper + level) * 16 + next_level * 8) > allowed)) break;
-    upper += level;
-    lo.push_back(upper);
+    lo.push_back(lo.back() + next_level);            // tentatively level K + 1
+    if (want >= 0 ? K >= want : (next_level > level_cap || table_bytes(K + 1) > allowed)) {
+      lo.pop_back();
+      break;
+    }
     level = next_level;
     K++;
   }
   if (K < 1) return 0;
-  // upper = entries of levels 0..K-1 (16 bytes each), level = entries of level K (8 bytes each)
+  const int cfrom = K >= 2 ? K - 1 : K;
+  const int64_t upper = lo[size_t(cfrom)], compact = lo[size_t(K) + 1] - upper;
   if (big_malloc(ix, reinterpret_cast<void**>(&ix->d_ktab2), size_t(upper) * 16) != hipSuccess ||
-      big_malloc(ix, reinterpret_cast<void**>(&ix->d_ktab2_deep), size_t(level) * 8 + 64) != hipSuccess) {
+      big_malloc(ix, reinterpret_cast<void**>(&ix->d_ktab2_deep), size_t(compact) * 8 + 64) != hipSuccess) {
     (void)hipGetLastError();
     big_free(ix, ix->d_ktab2);
     ix->d_ktab2 = nullptr;
@@ -97,6 +112,10 @@ int build_ktab2(femto_amd_index* ix, int sigma, int nstop) {
   d.kt2_nstop = nstop;
   d.kt2_deep_big = 0xffffff;
   if (const char* e = getenv("FEMTO_AMD_KTAB_DEEP_BIG")) d.kt2_deep_big = std::max(1, std::min(0xffffff, atoi(e)));    // test hook
+  d.ktab2 = ix->d_ktab2;
+  d.kt2_deep = reinterpret_cast<const uint64_t*>(ix->d_ktab2_deep);
+  d.kt2_deep_off = upper;
+  d.kt2_cfrom = cfrom;
   longlong2* tab = reinterpret_cast<longlong2*>(ix->d_ktab2);
   hipLaunchKernelGGL(ktab2_root_kernel, dim3(1), dim3(64), 0, nullptr, d, tab);
   int64_t cnt = 1;
@@ -105,22 +124,23 @@ int build_ktab2(femto_amd_index* ix, int sigma, int nstop) {
     cnt *= t;
     for (int64_t o = 0; o < cnt; o += chunk) {
       const int64_t cn = std::min(chunk, cnt - o);
-      if (m < K)
+      if (m < cfrom)
         hipLaunchKernelGGL(ktab2_level_kernel<P>, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, d, m, lo[size_t(m)] + o, cn, tab);
       else
         hipLaunchKernelGGL(ktab2_deep_kernel<P>, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, d, m, lo[size_t(m)] + o, cn,
-                           static_cast<const longlong2*>(tab), reinterpret_cast<uint64_t*>(ix->d_ktab2_deep) + o);
+                           reinterpret_cast<uint64_t*>(ix->d_ktab2_deep));
     }
   }
   if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return set_err(FEMTO_AMD_ERR_INVALID, "level table build failed");
   ix->dev.ktab2 = ix->d_ktab2;
   ix->dev.kt2_deep = reinterpret_cast<const uint64_t*>(ix->d_ktab2_deep);
-  ix->dev.kt2_deep_off = lo[size_t(K)];
+  ix->dev.kt2_deep_off = upper;
+  ix->dev.kt2_cfrom = cfrom;
   ix->dev.kt2_syms = K;
   ix->dev.kt2_base = int32_t(t);
   ix->dev.kt2_nstop = nstop;
   ix->dev.kt2_deep_big = d.kt2_deep_big;
-  ix->ktab2_bytes = upper * 16 + level * 8;
+  ix->ktab2_bytes = upper * 16 + compact * 8;
   ix->table_bytes += ix->ktab2_bytes;
   return 0;
 }
@@ -276,10 +296,24 @@ int build_ctx2(femto_amd_index* ix, int nstop) {
   return 0;
 }
 
-// distance between marks in the derived lines (see "denser marks" in pack_kernels.hip.hpp); 0: keep femto's own
-int derived_mark_every(const HostIndex& h, int h_opt_mark_every) {
+// distance between marks in the derived lines (see "denser marks" in pack_kernels.hip.hpp); 0: keep femto's own.
+// Auto: every 5th position -- unless the handle has an HBM budget (femto_amd_options_t::hbm_budget_bytes): then the densest
+// of 5 / 10 / femto's own whose offsets array takes at most an eighth of the budget (a quarter of what the level table,
+// the structure that saves most lines per pattern, is left with).
+int64_t mark_entry_bytes(const femto_amd_index* ix) {
+  const bool can32 = ix->host.total_length < (int64_t(1) << 32);
+  return (can32 && knob(ix->opt.marks_32bit, "FEMTO_AMD_SA32", 1) != 0) ? 4 : 8;
+}
+int derived_mark_every(const femto_amd_index* ix) {
+  const HostIndex& h = ix->host;
   int every = 5;
-  every = int(knob(h_opt_mark_every, "FEMTO_AMD_MARK_EVERY", every));
+  if (ix->opt.mark_every == -1 && !getenv("FEMTO_AMD_MARK_EVERY") && ix->opt.hbm_budget_bytes >= 0) {
+    const int64_t eb = mark_entry_bytes(ix), cap = ix->opt.hbm_budget_bytes / 8;
+    every = 0;
+    for (const int e : {5, 10})
+      if (e < h.mark_period && (h.total_length / e + 1) * eb <= cap) { every = e; break; }
+  }
+  every = int(knob(ix->opt.mark_every, "FEMTO_AMD_MARK_EVERY", every));
   if (every <= 0 || every >= h.mark_period) return 0;
   return every;
 }
@@ -340,7 +374,32 @@ int build_pack(femto_amd_index* ix) {
     hipLaunchKernelGGL(pack_counts_kernel, dim3(uint32_t((nlines + 255) / 256)), dim3(256), 0, nullptr, ix->dev, nlines, ix->d_pack,
                        scans.as<int64_t>(), stride);
     HIP_TRY(hipGetLastError());
-    const int every = derived_mark_every(h, ix->opt.mark_every);
+    {  // rank units of the table characters (ru_kernels.hip.hpp) while the rows' codes are at hand -- optional: a third of
+       // the free HBM at most, and only below 2^35 rows (ru_split)
+      const int nstop = __builtin_popcount(ix->dev.pack_stop), ntab = sigma - nstop;
+      const int64_t ustride = (n + kRuRows - 1) / kRuRows + 1;
+      const size_t rbytes = size_t(std::max(ntab, 0)) * size_t(ustride) * 16;
+      const bool want = knob(ix->opt.rank_units, "FEMTO_AMD_RU", 1) != 0;
+      // (a handle with an HBM budget: at most half of what the budget has left -- the level table takes the rest)
+      if (want && ntab >= 1 && n < (int64_t(1) << 35) && rbytes <= hbm_free(ix) / (ix->opt.hbm_budget_bytes >= 0 ? 2 : 3) &&
+          big_malloc(ix, reinterpret_cast<void**>(&ix->d_ru), rbytes + 256) == hipSuccess) {
+        DevIndex d = ix->dev;
+        d.pack = ix->d_pack;
+        hipLaunchKernelGGL(ru_build_kernel, dim3(uint32_t((ustride + 255) / 256)), dim3(256), 0, nullptr, d, n, sym.as<uint8_t>(), reinterpret_cast<uint4*>(ix->d_ru), ustride,
+                           nstop, ntab);
+        HIP_TRY(hipGetLastError());
+        ix->dev.ru = ix->d_ru;
+        ix->dev.ru_stride = ustride;
+        ix->dev.ru_nstop = nstop;
+        ix->ru_bytes = int64_t(rbytes);
+        ix->table_bytes += ix->ru_bytes;
+      } else {
+        (void)hipGetLastError();
+      }
+    }
+    const int every = derived_mark_every(ix);
+    ix->mark_every_used = every;
+    ix->dev.pack_sa32 = mark_entry_bytes(ix) == 4 ? 1 : 0;
     if (every) {  // denser marks: set the extra bits, then recount the marks before every line
       for (int64_t r0 = 0; r0 < n; r0 += chunk) {
         const int64_t cn = std::min(chunk, n - r0);
@@ -357,7 +416,8 @@ int build_pack(femto_amd_index* ix) {
     }
     int64_t nmarks = 0;
     HIP_TRY(hipMemcpy(&nmarks, scans.as<int64_t>() + 8 * stride + nlines, 8, hipMemcpyDeviceToHost));
-    HIP_TRY(big_malloc(ix, reinterpret_cast<void**>(&ix->d_pack_sa), size_t(nmarks > 0 ? nmarks : 1) * 8));
+    const size_t mbytes = size_t(nmarks > 0 ? nmarks : 1) * size_t(ix->dev.pack_sa32 ? 4 : 8);
+    HIP_TRY(big_malloc(ix, reinterpret_cast<void**>(&ix->d_pack_sa), mbytes + 8));
     for (int64_t r0 = 0; r0 < n; r0 += chunk) {
       const int64_t cn = std::min(chunk, n - r0);
       if (every)
@@ -371,7 +431,8 @@ int build_pack(femto_amd_index* ix) {
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     ix->n_marks = nmarks;
-    ix->pack_bytes = nlines * kPackLineWords * 4 + nmarks * 8;
+    ix->marks_bytes = int64_t(mbytes);
+    ix->pack_bytes = nlines * kPackLineWords * 4 + int64_t(mbytes);
     ix->table_bytes += ix->pack_bytes;
     return 0;
   };
@@ -499,7 +560,7 @@ int build_pack2(femto_amd_index* ix) {
       }
     }
     int64_t sa_bytes = 0;
-    const int every = derived_mark_every(h, ix->opt.mark_every);
+    const int every = derived_mark_every(ix);
     int64_t nmarks = tot[16];
     if (every) {  // denser marks (the same rows the 3-bit lines mark, so the offsets array can be shared)
       for (int64_t r0 = 0; r0 < n; r0 += chunk) {
@@ -517,7 +578,11 @@ int build_pack2(femto_amd_index* ix) {
       HIP_TRY(hipMemcpy(&nmarks, counts.as<int64_t>() + stride1 + nl1, 8, hipMemcpyDeviceToHost));
     }
     if (!ix->d_pack_sa) {  // offsets of the marked rows (shared with the 3-bit lines when both exist)
-      HIP_TRY(big_malloc(ix, reinterpret_cast<void**>(&ix->d_pack_sa), size_t(nmarks > 0 ? nmarks : 1) * 8));
+      ix->dev.pack_sa32 = mark_entry_bytes(ix) == 4 ? 1 : 0;
+      ix->mark_every_used = every;
+      const size_t mbytes = size_t(nmarks > 0 ? nmarks : 1) * size_t(ix->dev.pack_sa32 ? 4 : 8);
+      ix->marks_bytes = int64_t(mbytes);
+      HIP_TRY(big_malloc(ix, reinterpret_cast<void**>(&ix->d_pack_sa), mbytes + 8));
       for (int64_t r0 = 0; r0 < n; r0 += chunk) {
         const int64_t cn = std::min(chunk, n - r0);
         if (every)
@@ -529,7 +594,7 @@ int build_pack2(femto_amd_index* ix) {
       }
       HIP_TRY(hipGetLastError());
       d.pack_sa = ix->d_pack_sa;
-      sa_bytes = nmarks * 8;
+      sa_bytes = int64_t(mbytes);
     }
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipDeviceSynchronize());
@@ -579,6 +644,9 @@ int build_text(femto_amd_index* ix) {
     want_sa = true;
   }
   const size_t tb = size_t(n) + 64, ib = (size_t(n >> isa_shift) + 2) * 8, sb = want_sa ? size_t(n) * 8 + 64 : 0;
+  // a handle with an HBM budget: the text + sampled inverse suffix array (the tail of LONG patterns) only from what the
+  // structures every pattern uses -- lines, rank units, level table -- would leave: at most a fifth of what is free
+  if (ix->opt.hbm_budget_bytes >= 0 && tb + ib + sb > free_b / 5) return 0;
   if (big_malloc(ix, reinterpret_cast<void**>(&ix->d_txt), tb) != hipSuccess || big_malloc(ix, reinterpret_cast<void**>(&ix->d_isa8), ib) != hipSuccess ||
       (sb && big_malloc(ix, reinterpret_cast<void**>(&ix->d_sa_full), sb) != hipSuccess)) {
     (void)hipGetLastError();

@@ -107,7 +107,7 @@ struct DevBucket {          // 16 bytes
 
 // regions of the compulsory-traffic trace (femto_amd_trace_lines): every 128-byte line a query kernel loads from one
 // of these arrays sets one bit; the number of set bits x 128 B is what the launch MUST move from HBM at least once
-enum { kTracePack = 0, kTraceKtab = 1, kTraceSa = 2, kTraceL1 = 3, kTraceL2 = 4, kTraceTxt = 5, kTraceIsa = 6, kTraceKtab1 = 7, kTraceInd = 8,
+enum { kTracePack = 0, kTraceKtab = 1, kTraceSa = 2, kTraceL1 = 3, kTraceL2 = 4, kTraceTxt = 5, kTraceIsa = 6, kTraceRu = 7, kTraceInd = 8,
        kTraceCtx = 9, kTraceRegions = 10 };
 
 struct DevIndex {           // passed by value to kernels
@@ -130,14 +130,21 @@ struct DevIndex {           // passed by value to kernels
   const int64_t* pack_sa;   // offsets of the marked rows, row order
   const uint8_t* pack_code; // [261] alpha code -> dense code 0..7, 0xff: not in the text
   const int64_t* pack_c;    // [16]: C[ch(code)] for code 0..7, then C[ch(code)+1]-1
+  const uint64_t* ru;       // rank units of the table characters (ru_kernels.hip.hpp), two words each: [code - ru_nstop][unit], or NULL
+  int64_t ru_stride;        // units per character
+  int32_t ru_nstop;         // dense codes below this are <= SEOF: no unit vector
+  int32_t pack_sa32;        // 1: pack_sa holds 32-bit offsets (indexes of fewer than 2^32 rows, half the bytes)
   const int64_t* ktab2;     // level table of the first steps, heap-numbered over the table characters (direct_kernels.hip.hpp)
   int32_t kt2_syms;         // deepest level K
   int32_t kt2_base;         // t = number of table characters (characters of the text that are not <= SEOF)
   int32_t kt2_nstop;        // dense codes below this are <= SEOF: digit = dense code - kt2_nstop
   int32_t kt2_deep_big;     // deepest-level entries with at least this many rows store "recompute" (0xffffff by default)
-  const uint64_t* kt2_deep; // the deepest level, compact: first (40 bits) | rows in the range (24 bits; 0xffffff: see ktab2_lookup)
-  int64_t kt2_deep_off;     // heap position of the deepest level's first entry
+  const uint64_t* kt2_deep; // the levels from kt2_cfrom on, compact: first (40 bits) | rows in the range (24 bits; 0xffffff: see ktab2_lookup)
+  int64_t kt2_deep_off;     // heap position of level kt2_cfrom's first entry (= number of 16-byte entries of the levels above)
+  int32_t kt2_cfrom;        // first compact level (K - 1, or K when K == 1)
+  int32_t kt2_pad;
   uint32_t* trace;          // NULL, or the line bitmaps of femto_amd_trace_lines: bit trace_off[region] + line index
+  unsigned long long* trace_reads;   // NULL, or [kTraceRegions] counters: every traced line READ (not only the distinct ones)
   int64_t trace_off[kTraceRegions];   // first bit of every traced region (kTrace* above)
   uint16_t pack_alpha[8];   // dense code -> alpha code
   int32_t pack_sigma;

@@ -53,54 +53,65 @@ inline __global__ void ktab2_root_kernel(const DevIndex ix, longlong2* __restric
   if (threadIdx.x == 0 && blockIdx.x == 0) tab[0] = make_longlong2(0, ix.total_length);   // empty pattern: [0, n-1] (server.c:782-808)
 }
 
-// The deepest level holds three quarters of the entries and its ranges are short, so it is stored compactly: 8 bytes =
-// first (40 bits: the format's 2^39 rows) | number of rows (24 bits).  A dead range has last == first - 1 by construction
-// (first = C+Occ(c,first-1), last = C+Occ(c,last)-1 with equal Occs), i.e. 0 rows; a range of 2^24 - 1 rows or more
-// (highly repetitive text) stores 0xffffff and is recomputed from its parent with one ordinary step.  (DevIndex::kt2_deep_big is
-// that bound; a test lowers it -- FEMTO_AMD_KTAB_DEEP_BIG -- so that the recomputation runs on every fixture.)
+// The deepest levels hold nearly all the entries and their ranges are short, so the last TWO levels (from kt2_cfrom on) are
+// stored compactly: 8 bytes = first (40 bits: the format's 2^39 rows) | number of rows (24 bits).  A dead range has
+// last == first - 1 by construction (first = C+Occ(c,first-1), last = C+Occ(c,last)-1 with equal Occs), i.e. 0 rows; a range
+// of 2^24 - 1 rows or more (highly repetitive text) stores 0xffffff and is recomputed from its parent with one ordinary
+// step.  (DevIndex::kt2_deep_big is that bound; a test lowers it -- FEMTO_AMD_KTAB_DEEP_BIG -- so that the recomputation
+// runs on every fixture.)  Heap positions of consecutive levels are adjacent, so the compact array is indexed by
+// pos - kt2_deep_off across both levels.  (Round 3 kept only the deepest level compact: 16 instead of 8 bytes for a quarter
+// as many entries again -- 0.13 GB of a K = 13 table, 8.6 GB of the K = 16 one.)
 constexpr uint64_t kDeepBig = 0xffffffu;
 constexpr uint64_t kDeepFirstMask = (uint64_t(1) << 40) - 1;
 
+// the table entry of heap position `pos` at level m: the (first,last) after searching those m symbols
+template <class P>
+__device__ __forceinline__ void ktab2_lookup(const DevIndex& ix, int64_t pos, int m, int64_t& first, int64_t& last) {
+  const int64_t t = ix.kt2_base;
+  uint32_t digit[2];
+  int up = 0;               // compact entries that said "recompute": their digits, to be stepped again from the ancestor
+  while (ix.kt2_deep && m >= ix.kt2_cfrom) {
+    const int64_t i = pos - ix.kt2_deep_off;
+    const uint64_t e = ix.kt2_deep[i];
+    trace_touch(ix, kTraceKtab, uint64_t(ix.kt2_deep_off >> 3) + 1 + (uint64_t(i) >> 4));
+    const uint64_t rows = e >> 40;
+    if (rows != kDeepBig) {
+      first = int64_t(e & kDeepFirstMask);
+      last = first + int64_t(rows) - 1;
+      break;
+    }
+    const int64_t parent = (pos - 1) / t;
+    digit[up++] = uint32_t((pos - 1) - parent * t);
+    pos = parent;
+    m--;
+  }
+  if (!(ix.kt2_deep && m >= ix.kt2_cfrom)) {
+    const longlong2 e = reinterpret_cast<const longlong2*>(ix.ktab2)[pos];
+    trace_touch(ix, kTraceKtab, uint64_t(pos) >> 3);
+    first = e.x;
+    last = int64_t(uint64_t(e.y) & kKtabLastMask) - 1;
+  }
+  while (up > 0) {          // (a big range is never empty: the steps below always run on rows)
+    up--;
+    P::search_step(ix, m, digit[up] + uint32_t(ix.kt2_nstop), first, last);
+    m++;
+  }
+}
+
 template <class P>
 inline __global__ __launch_bounds__(256) void ktab2_deep_kernel(const DevIndex ix, const int level, const int64_t lo, const int64_t n,
-                                                         const longlong2* __restrict__ tab, uint64_t* __restrict__ deep) {
+                                                         uint64_t* __restrict__ deep) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int64_t pos = lo + i;
   const int64_t t = ix.kt2_base;
   const int64_t parent = (pos - 1) / t;
   const uint32_t digit = uint32_t((pos - 1) - parent * t);
-  const longlong2 e = tab[parent];
-  int64_t first = e.x, last = int64_t(uint64_t(e.y) & kKtabLastMask) - 1;
+  int64_t first, last;
+  ktab2_lookup<P>(ix, parent, level - 1, first, last);      // (the parent's level is complete: one launch per level)
   if (first <= last) P::search_step(ix, level - 1, digit + uint32_t(ix.kt2_nstop), first, last);
   const uint64_t rows = first <= last ? uint64_t(last - first + 1) : 0;
-  deep[i] = (uint64_t(first) & kDeepFirstMask) | ((rows < uint64_t(ix.kt2_deep_big) ? rows : kDeepBig) << 40);
-}
-
-// the table entry of heap position `pos` at level m: the (first,last) after searching those m symbols
-template <class P>
-__device__ __forceinline__ void ktab2_lookup(const DevIndex& ix, int64_t pos, int m, int64_t& first, int64_t& last) {
-  if (ix.kt2_deep && m == ix.kt2_syms) {
-    const int64_t i = pos - ix.kt2_deep_off;
-    const uint64_t e = ix.kt2_deep[i];
-    trace_touch(ix, kTraceKtab, uint64_t(ix.kt2_deep_off >> 3) + 1 + (uint64_t(i) >> 4));
-    const uint64_t rows = e >> 40;
-    first = int64_t(e & kDeepFirstMask);
-    last = first + int64_t(rows) - 1;
-    if (rows != kDeepBig) return;
-    const int64_t t = ix.kt2_base;
-    const int64_t parent = (pos - 1) / t;
-    const longlong2 pe = reinterpret_cast<const longlong2*>(ix.ktab2)[parent];
-    trace_touch(ix, kTraceKtab, uint64_t(parent) >> 3);
-    first = pe.x;
-    last = int64_t(uint64_t(pe.y) & kKtabLastMask) - 1;
-    P::search_step(ix, m - 1, uint32_t((pos - 1) - parent * t) + uint32_t(ix.kt2_nstop), first, last);
-    return;
-  }
-  const longlong2 e = reinterpret_cast<const longlong2*>(ix.ktab2)[pos];
-  trace_touch(ix, kTraceKtab, uint64_t(pos) >> 3);
-  first = e.x;
-  last = int64_t(uint64_t(e.y) & kKtabLastMask) - 1;
+  deep[pos - ix.kt2_deep_off] = (uint64_t(first) & kDeepFirstMask) | ((rows < uint64_t(ix.kt2_deep_big) ? rows : kDeepBig) << 40);
 }
 
 // sum of `v` over the 256-thread block (all threads must call); valid in thread 0
@@ -773,8 +784,7 @@ inline __global__ __launch_bounds__(256) void locate_walk_kernel(const DevIndex 
       int64_t sa_index, next;
       P::lf(ix, row, code, marked, sa_index, next);
       if (marked) {
-        result = ix.pack_sa[sa_index] + steps;
-        trace_touch(ix, kTraceSa, uint64_t(sa_index) >> 4);
+        result = mark_offset_at(ix, sa_index) + steps;
         break;
       }
       if (P::is_stop(ix, code)) break;              // cannot walk past a document start (server.c:2336-2342)

@@ -32,6 +32,7 @@
 #include "index_builder.hpp"
 #include "kernels.hip.hpp"
 #include "pack_kernels.hip.hpp"
+#include "ru_kernels.hip.hpp"
 #include "pack2_kernels.hip.hpp"
 #include "ind_kernels.hip.hpp"
 #include "text_kernels.hip.hpp"
@@ -131,9 +132,10 @@ int64_t knob(int64_t opt_value, const char* env_name, int64_t dflt) {
 size_t hbm_free(const femto_amd_index* ix) {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
-  if (ix->opt.hbm_budget_bytes >= 0 && ix->hbm_free_at_open >= 0) {
-    const int64_t used = ix->hbm_free_at_open - int64_t(free_b);          // what this handle has taken so far
-    const int64_t left = ix->opt.hbm_budget_bytes - std::max<int64_t>(used, 0);
+  if (ix->opt.hbm_budget_bytes >= 0) {
+    int64_t held = ix->hbm_held;
+    for (const auto& t : ix->small_tables) held += int64_t(t.second);
+    const int64_t left = ix->opt.hbm_budget_bytes - held;
     if (left <= 0) return 0;
     if (size_t(left) < free_b) free_b = size_t(left);
   }
@@ -141,7 +143,16 @@ size_t hbm_free(const femto_amd_index* ix) {
 }
 
 // ---- big arrays: plain hipMalloc, or -- striped index -- one address range backed by the HBM of several GPUs ---------
+static hipError_t big_malloc_raw(femto_amd_index* ix, void** out, size_t bytes);
 hipError_t big_malloc(femto_amd_index* ix, void** out, size_t bytes) {
+  const hipError_t e = big_malloc_raw(ix, out, bytes);
+  if (e == hipSuccess) {
+    ix->hbm_held += int64_t(bytes);
+    ix->big_allocs.emplace_back(*out, bytes);
+  }
+  return e;
+}
+static hipError_t big_malloc_raw(femto_amd_index* ix, void** out, size_t bytes) {
   if (ix->stripe_devices.empty()) return hipMalloc(out, bytes);
   const int N = int(ix->stripe_devices.size());
   hipMemAllocationProp prop{};
@@ -194,6 +205,12 @@ hipError_t big_malloc(femto_amd_index* ix, void** out, size_t bytes) {
 
 void big_free(femto_amd_index* ix, void* p) {
   if (!p) return;
+  for (size_t k = 0; k < ix->big_allocs.size(); k++)
+    if (ix->big_allocs[k].first == p) {
+      ix->hbm_held -= int64_t(ix->big_allocs[k].second);
+      ix->big_allocs.erase(ix->big_allocs.begin() + long(k));
+      break;
+    }
   for (size_t k = 0; k < ix->striped.size(); k++)
     if (ix->striped[k].va == p) {
       auto& st = ix->striped[k];
@@ -314,7 +331,10 @@ void launch_tail(femto_amd_index* ix, const DevIndex& d, dim3 grid, hipStream_t 
                  const TailOut& out, int* err_flag) {
   const dim3 block{uint32_t(kBlockThreads)};
   const int* n_items = d.tail_count;
-  if (ix->mode == 3) {
+  if (ix->mode == 3 && d.ru) {
+    if (d.sa_full) hipLaunchKernelGGL((count_tail_kernel<RuPolicy, true>), grid, block, 0, stream, d, items, n_items, d_plen, d_pats, d_starts, perm, keys, bits, nsym, out, err_flag);
+    else hipLaunchKernelGGL((count_tail_kernel<RuPolicy, false>), grid, block, 0, stream, d, items, n_items, d_plen, d_pats, d_starts, perm, keys, bits, nsym, out, err_flag);
+  } else if (ix->mode == 3) {
     if (d.sa_full) hipLaunchKernelGGL((count_tail_kernel<PackPolicy, true>), grid, block, 0, stream, d, items, n_items, d_plen, d_pats, d_starts, perm, keys, bits, nsym, out, err_flag);
     else hipLaunchKernelGGL((count_tail_kernel<PackPolicy, false>), grid, block, 0, stream, d, items, n_items, d_plen, d_pats, d_starts, perm, keys, bits, nsym, out, err_flag);
   } else {
@@ -394,7 +414,8 @@ int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const in
     else if (dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, false, true>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, ps, big_flag);     \
     else hipLaunchKernelGGL((count_direct_kernel<POLICY, false, false>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, ps, big_flag);              \
   } while (0)
-  if (ix->mode == 3) LAUNCH_COUNT_DIRECT(PackPolicy);
+  if (ix->mode == 3 && d.ru) LAUNCH_COUNT_DIRECT(RuPolicy);     // rank units: one 16-byte load per range end and step
+  else if (ix->mode == 3) LAUNCH_COUNT_DIRECT(PackPolicy);
   else if (d.ind) LAUNCH_COUNT_DIRECT(IndPolicy);     // per-character rank lines: one line per range end and step
   else LAUNCH_COUNT_DIRECT(Pack2Policy);
 #undef LAUNCH_COUNT_DIRECT
@@ -529,7 +550,8 @@ int launch_count_keys(femto_amd_index* ix, int64_t n, const uint64_t* d_keys, in
     if (plan) hipLaunchKernelGGL((count_keys_kernel<POLICY, true>), grid, block, 0, stream, ix->dev, n, d_keys, bits, nsym, out32, d_first, d_last, mo, noccs, ps, big_flag); \
     else hipLaunchKernelGGL((count_keys_kernel<POLICY, false>), grid, block, 0, stream, ix->dev, n, d_keys, bits, nsym, out32, d_first, d_last, mo, noccs, ps, big_flag);     \
   } while (0)
-  if (ix->mode == 3) LAUNCH_KEYS(PackPolicy);
+  if (ix->mode == 3 && ix->dev.ru) LAUNCH_KEYS(RuPolicy);
+  else if (ix->mode == 3) LAUNCH_KEYS(PackPolicy);
   else if (ix->dev.ind) LAUNCH_KEYS(IndPolicy);
   else LAUNCH_KEYS(Pack2Policy);
 #undef LAUNCH_KEYS
@@ -1294,7 +1316,7 @@ void femto_amd_close(femto_amd_index_t* ix) {
       for (void* q : {static_cast<void*>(ix->d_image), static_cast<void*>(ix->d_segs), static_cast<void*>(ix->d_pack), static_cast<void*>(ix->d_pack_sa),
                       static_cast<void*>(ix->d_txt), static_cast<void*>(ix->d_isa8), static_cast<void*>(ix->d_p2_l1), static_cast<void*>(ix->d_p2_l2),
                       static_cast<void*>(ix->d_ktab2), static_cast<void*>(ix->d_ktab2_deep), static_cast<void*>(ix->d_sa_full), static_cast<void*>(ix->d_ind),
-                      static_cast<void*>(ix->d_ctx), static_cast<void*>(ix->d_ctx2)})
+                      static_cast<void*>(ix->d_ctx), static_cast<void*>(ix->d_ctx2), static_cast<void*>(ix->d_ru)})
         big_free(ix, q);
       for (void* q : {static_cast<void*>(ix->d_nodes), static_cast<void*>(ix->d_buckets), static_cast<void*>(ix->d_seqs), static_cast<void*>(ix->d_occ_base),
                       static_cast<void*>(ix->d_leaf_code), static_cast<void*>(ix->d_C), static_cast<void*>(ix->d_cum), static_cast<void*>(ix->d_hint),
@@ -1349,6 +1371,7 @@ int femto_amd_count_device(femto_amd_index_t* ix, int64_t npats, const int32_t* 
                            const int64_t* d_starts, int64_t* d_first, int64_t* d_last, void* stream) {
   API_BEGIN
   if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
+  if (reinterpret_cast<uintptr_t>(d_pats) & 1u) return set_err(FEMTO_AMD_ERR_PARAM, "d_pats must be 2-byte aligned (uint16 symbols; the kernels read them in aligned 16-byte pieces)");
   int rc = ensure_device(ix);
   if (rc) return rc;
   Lease L(ix, static_cast<hipStream_t>(stream));
@@ -1451,6 +1474,7 @@ int femto_amd_locate_plan_device(femto_amd_index_t* ix, int64_t npats, const int
                                  int32_t* d_noccs, int64_t* d_out_starts, void* stream_) {
   API_BEGIN
   if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
+  if (reinterpret_cast<uintptr_t>(d_pats) & 1u) return set_err(FEMTO_AMD_ERR_PARAM, "d_pats must be 2-byte aligned (uint16 symbols; the kernels read them in aligned 16-byte pieces)");
   if (max_occs_each < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative max_occs_each");
   int rc = ensure_device(ix);
   if (rc) return rc;
@@ -1481,6 +1505,7 @@ int femto_amd_locate_device(femto_amd_index_t* ix, int64_t npats, const int32_t*
                             int64_t* d_total, void* stream_) {
   API_BEGIN
   if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
+  if (reinterpret_cast<uintptr_t>(d_pats) & 1u) return set_err(FEMTO_AMD_ERR_PARAM, "d_pats must be 2-byte aligned (uint16 symbols; the kernels read them in aligned 16-byte pieces)");
   if (max_occs_each < 0 || offsets_capacity < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative max_occs_each / capacity");
   if (npats && (!d_first || !d_last || !d_noccs || !d_out_starts || !d_total)) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
   int rc = ensure_device(ix);
@@ -1897,7 +1922,7 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
   region_lines[kTraceTxt] = ix->dev.txt ? (n + 64) / 128 + 1 : 0;
   region_lines[kTraceIsa] = ix->dev.isa8 ? ((n >> ix->dev.isa_shift) + 2) / 16 + 1 : 0;
   region_lines[kTraceCtx] = ix->ctx_bytes / 128 + ix->ctx2_bytes / 128;
-  region_lines[kTraceKtab1] = 0;
+  region_lines[kTraceRu] = ix->ru_bytes / 128 + 1;
   int64_t off[kTraceRegions + 1];
   off[0] = 0;
   for (int r = 0; r < kTraceRegions; r++) off[r + 1] = (off[r] + region_lines[r] + 63) & ~int64_t(63);
@@ -1908,7 +1933,7 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
     const size_t bm_bytes = size_t(off[kTraceRegions]) / 8 + 64;
     const int64_t nblocks = (npats + kBlockThreads - 1) / kBlockThreads;
     if ((r2 = bitmap.reserve(bm_bytes))) return r2;
-    if ((r2 = counts.reserve(16 * 8))) return r2;
+    if ((r2 = counts.reserve(32 * 8))) return r2;
     if ((r2 = S.first.reserve(size_t(npats + 1) * 8))) return r2;
     if ((r2 = S.last.reserve(size_t(npats + 1) * 8))) return r2;
     if ((r2 = S.noccs.reserve(size_t(npats + 1) * 4))) return r2;
@@ -1942,10 +1967,12 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
     a.flags = S.d_flags;
     a.total = S.d_total;
     a.bitmap = static_cast<uint32_t*>(bitmap.p);
+    a.reads = reinterpret_cast<unsigned long long*>(counts.p) + 16;
     a.trace_off = off;
     a.stream = st;
-    auto collect = [&](int64_t* out) -> int {
-      HIP_TRY(hipMemsetAsync(counts.p, 0, 16 * 8, st));
+    auto collect = [&](int64_t* out, int phase) -> int {
+      HIP_TRY(hipMemcpyAsync(ix->last_trace_reads[phase], a.reads, kTraceRegions * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemsetAsync(counts.p, 0, 32 * 8, st));
       for (int r = 0; r < kTraceRegions; r++)
         if (region_lines[r])
           HIP_TRY(ta::traced_popcount(static_cast<const uint32_t*>(bitmap.p), off[r] / 32, (off[r] + region_lines[r] + 31) / 32,
@@ -1955,8 +1982,9 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
       return 0;
     };
     HIP_TRY(hipMemsetAsync(bitmap.p, 0, bm_bytes, st));
+    HIP_TRY(hipMemsetAsync(counts.p, 0, 32 * 8, st));
     HIP_TRY(ta::traced_count_plan(a));
-    if ((r2 = collect(count_lines))) return r2;
+    if ((r2 = collect(count_lines, 0))) return r2;
     int64_t total = 0;
     HIP_TRY(hipMemcpyAsync(&total, S.d_total, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1965,7 +1993,7 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
       if ((r2 = S.offsets.reserve(size_t(total) * 8))) return r2;
       HIP_TRY(ta::traced_walk(a, S.offsets.as<int64_t>(), total));
     }
-    if ((r2 = collect(locate_lines))) return r2;
+    if ((r2 = collect(locate_lines, 1))) return r2;
     if (rows_out) *rows_out = total;
     HIP_TRY(hipMemsetAsync(S.d_flags, 0, 4 * sizeof(int), st));
     return 0;
@@ -1976,6 +2004,15 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
   counts.release();
   return rc;
   API_END
+}
+
+int femto_amd_trace_reads(const femto_amd_index_t* ix, int64_t* count_reads, int64_t* locate_reads) {
+  if (!ix || !count_reads || !locate_reads) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  for (int r = 0; r < 10; r++) {
+    count_reads[r] = ix->last_trace_reads[0][r];
+    locate_reads[r] = ix->last_trace_reads[1][r];
+  }
+  return FEMTO_AMD_OK;
 }
 
 int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode) {
@@ -2030,10 +2067,34 @@ int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* by
   if (available && ix->dev.ind) *available |= 32;     // bit 5: per-character rank lines (byte alphabets)
   if (available && ix->dev.ctx) *available |= 64 | (ix->dev.ctx_syms << 8);   // bit 6: context table; bits 8-11: its H
   if (available && ix->dev.ctx2) *available |= ix->dev.ctx2_syms << 12;        // bits 12-16: H2 of the wide context table
+  if (available && ix->dev.ru) *available |= 1 << 20;   // bit 20: rank units (small alphabets)
   if (available && ix->dev.sa_full) *available |= 8;  // bit 3: the full suffix array is resident
   if (available && ix->dev.isa8 && ix->dev.isa_shift == 0) *available |= 16;   // bit 4: the full inverse suffix array
   if (bytes) *bytes = ix->pack_bytes + ix->pack2_bytes;
   if (build_ms) *build_ms = ix->pack_build_ms + ix->pack2_build_ms;
+  return FEMTO_AMD_OK;
+}
+
+int femto_amd_structures(const femto_amd_index_t* ix, int64_t* out, int n) {
+  if (!ix || !out || n < 0 || n > 16) return set_err(FEMTO_AMD_ERR_PARAM, "bad argument");
+  if (!ix->children.empty()) return femto_amd_structures(ix->children[0], out, n);
+  int64_t v[16] = {0};
+  v[0] = int64_t(ix->host.image.size());
+  v[1] = ix->pack_bytes - ix->marks_bytes;
+  v[2] = ix->marks_bytes;
+  v[3] = ix->ru_bytes;
+  v[4] = ix->ktab2_bytes;
+  v[5] = ix->ctx_bytes + ix->ctx2_bytes;
+  v[6] = ix->ind_bytes;
+  v[7] = ix->text_bytes;
+  v[8] = (ix->p2_lines1 + ix->p2_lines2) * 128;
+  v[9] = ix->table_bytes;
+  v[10] = ix->mark_every_used;
+  v[11] = ix->dev.ktab2 ? ix->dev.kt2_syms : 0;
+  v[12] = ix->dev.pack_sa ? (ix->dev.pack_sa32 ? 4 : 8) : 0;
+  v[13] = ix->hbm_held;
+  for (const auto& t : ix->small_tables) v[13] += int64_t(t.second);
+  for (int i = 0; i < n; i++) out[i] = v[i];
   return FEMTO_AMD_OK;
 }
 

@@ -245,8 +245,7 @@ inline __global__ __launch_bounds__(256) void locate_kernel_pack2(const DevIndex
   while (row >= 0 && steps <= int64_t(ix.walk_limit)) {
     const P2Step s = p2_step(ix, row);
     if (s.marked) {
-      result = ix.pack_sa[s.sa_index] + steps;
-      trace_touch(ix, kTraceSa, uint64_t(s.sa_index) >> 4);
+      result = mark_offset_at(ix, s.sa_index) + steps;
       break;
     }
     if (s.code < ix.p2_stop_below) break;                  // cannot walk past a document start (server.c:2336-2342)
@@ -450,7 +449,7 @@ inline __global__ __launch_bounds__(256) void p2_sa_kernel(const DevIndex ix, co
   const uint32_t r = uint32_t(row) & 63u;
   const uint64_t pm = (uint64_t(lp[9]) << 32) | lp[8];
   const uint64_t below = r ? ((1ull << r) - 1ull) : 0ull;
-  sa[int64_t((uint64_t(lp[31] & 0xffu) << 32) | lp[30]) + int64_t(__popcll(pm & below))] = off;
+  mark_offset_store(ix, sa, int64_t((uint64_t(lp[31] & 0xffu) << 32) | lp[30]) + int64_t(__popcll(pm & below)), off);
 }
 
 // ---- denser marks (derived), see pack_kernels.hip.hpp ---------------------------------------------------------------
@@ -472,7 +471,7 @@ inline __global__ __launch_bounds__(256) void p2_densify_kernel(const DevIndex i
   int64_t off = 0;
   if (kStore) {
     off = lane_mark_offset(ix, row);
-    sa[p2_mark_rank(l1, row)] = off;
+    mark_offset_store(ix, sa, p2_mark_rank(l1, row), off);
   }
   int64_t r = row;
   for (int j = 1; j < period; j++) {
@@ -480,7 +479,7 @@ inline __global__ __launch_bounds__(256) void p2_densify_kernel(const DevIndex i
     if (s.code < ix.p2_stop_below) break;
     r = s.c_plus_occ - 1;
     if (j % every == 0) {
-      if (kStore) sa[p2_mark_rank(l1, r)] = off - j;
+      if (kStore) mark_offset_store(ix, sa, p2_mark_rank(l1, r), off - j);
       else atomicOr(l1 + (uint64_t(r) >> 6) * 32 + 8 + ((uint32_t(r) & 63u) >> 5), 1u << (uint32_t(r) & 31u));
     }
   }

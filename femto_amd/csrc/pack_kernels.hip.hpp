@@ -33,9 +33,20 @@ __device__ __forceinline__ void trace_touch(const DevIndex& ix, int region, uint
 #ifdef FEMTO_AMD_TRACE
   const uint64_t b = uint64_t(ix.trace_off[region]) + line;
   atomicOr(ix.trace + (b >> 5), 1u << (b & 31u));
+  if (ix.trace_reads) atomicAdd(ix.trace_reads + region, 1ull);
 #else
   (void)ix; (void)region; (void)line;
 #endif
+}
+
+// offset of the i-th marked row (pack_sa: 8-byte entries, or 4-byte ones when the index has fewer than 2^32 rows)
+__device__ __forceinline__ int64_t mark_offset_at(const DevIndex& ix, int64_t i) {
+  trace_touch(ix, kTraceSa, uint64_t(i) >> (ix.pack_sa32 ? 5 : 4));
+  return ix.pack_sa32 ? int64_t(reinterpret_cast<const uint32_t*>(ix.pack_sa)[i]) : ix.pack_sa[i];
+}
+__device__ __forceinline__ void mark_offset_store(const DevIndex& ix, int64_t* sa, int64_t i, int64_t off) {
+  if (ix.pack_sa32) reinterpret_cast<uint32_t*>(sa)[i] = uint32_t(uint64_t(off));
+  else sa[i] = off;
 }
 
 __device__ __forceinline__ void pack_split(int64_t row, uint64_t* line, uint32_t* r) {
@@ -235,8 +246,7 @@ inline __global__ __launch_bounds__(256) void locate_kernel_pack(const DevIndex 
     trace_touch(ix, kTracePack, line);
     const PackStep s = pack_step(L, r);
     if (s.marked) {
-      result = ix.pack_sa[s.sa_index] + steps;
-      trace_touch(ix, kTraceSa, uint64_t(s.sa_index) >> 4);
+      result = mark_offset_at(ix, s.sa_index) + steps;
       break;
     }
     if ((ix.pack_stop >> s.code) & 1u) break;              // cannot walk past a document start (server.c:2336-2342)
@@ -406,7 +416,7 @@ inline __global__ __launch_bounds__(256) void pack_sa_kernel(const DevIndex ix, 
     const uint32_t msk = bits >= 32 ? ~0u : (bits <= 0 ? 0u : ((1u << bits) - 1u));
     mb += uint32_t(__popc(lp[15 + j] & msk));
   }
-  sa[int64_t((uint64_t(lp[31] & 0xffu) << 32) | lp[28]) + int64_t(mb)] = off;
+  mark_offset_store(ix, sa, int64_t((uint64_t(lp[31] & 0xffu) << 32) | lp[28]) + int64_t(mb), off);
 }
 
 // ---- denser marks (derived) ---------------------------------------------------------------------------------------
@@ -449,7 +459,7 @@ inline __global__ __launch_bounds__(256) void pack_densify_kernel(const DevIndex
     const LaneSeq sq = ix.lseqs[bk.seq_base + seq_in_bucket(bk, seq)];
     const RankResult m = bseq_rank_lane(ix, sq.mark_table, cnt);
     off = int64_t(read_bits_ptr(wrap_ptr(ix.image, sq.mark_array), mark_rec(ix, m.o1) * uint64_t(ix.text_size_bits), ix.text_size_bits));
-    sa[pack_mark_rank(pack, row)] = off;
+    mark_offset_store(ix, sa, pack_mark_rank(pack, row), off);
   }
   int64_t r = row;
   for (int j = 1; j < period; j++) {
@@ -463,7 +473,7 @@ inline __global__ __launch_bounds__(256) void pack_densify_kernel(const DevIndex
     r = s.c_plus_occ - 1;
     if (j % every == 0) {
       if (kStore) {
-        sa[pack_mark_rank(pack, r)] = off - j;
+        mark_offset_store(ix, sa, pack_mark_rank(pack, r), off - j);
       } else {
         pack_split(r, &line, &rr);
         atomicOr(pack + line * kPackLineWords + 15 + (rr >> 5), 1u << (rr & 31u));

@@ -29,6 +29,7 @@
 #include "api_internal.hpp"
 #include "kernels.hip.hpp"
 #include "pack_kernels.hip.hpp"
+#include "ru_kernels.hip.hpp"
 #include "pack2_kernels.hip.hpp"
 #include "ind_kernels.hip.hpp"
 #include "text_kernels.hip.hpp"
@@ -430,10 +431,13 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
     std::vector<DeviceBuffer*> b;
     ~Free() { for (DeviceBuffer* x : b) x->release(); }
   } guard{{&d_q, &d_flags, &d_sd, &d_ch, &d_bychar, &d_arena, &d_results, &d_misc, &d_order}};
-  const int64_t result_cap = std::max<int64_t>(max_results, 1);
+  // Raw results (before the per-automaton sort drops ranges inside other results, and including the attempts of searches
+  // that are run again in a larger arena) land in a buffer of the library's own, which grows and the batch runs again
+  // when it is too small: max_results bounds what the CALLER's arrays receive, nothing else (max_results == 0: count only).
+  int64_t result_cap = std::max<int64_t>(2 * max_results, 1 << 12);
   if ((rc = d_q.reserve(hq.size() * sizeof(NfaQueryDev))) || (rc = d_flags.reserve(h_flags.size() + 16)) ||
       (rc = d_sd.reserve(h_sd.size() * 4 + 16)) || (rc = d_ch.reserve(h_ch.size() * 2 + 16)) || (rc = d_bychar.reserve(h_bychar.size() * 4)) ||
-      (rc = d_results.reserve(size_t(result_cap) * sizeof(NfaResultDev))) || (rc = d_misc.reserve(64 + size_t(nq) * 4)) ||
+      (rc = d_misc.reserve(64 + size_t(nq) * 4)) ||
       (rc = d_order.reserve(size_t(nq) * 4)))
     return rc;
   HIP_TRY(hipMemcpyAsync(d_q.p, hq.data(), hq.size() * sizeof(NfaQueryDev), hipMemcpyHostToDevice, st));
@@ -443,7 +447,6 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
     HIP_TRY(hipMemcpyAsync(d_ch.p, h_ch.data(), h_ch.size() * 2, hipMemcpyHostToDevice, st));
   }
   HIP_TRY(hipMemcpyAsync(d_bychar.p, h_bychar.data(), h_bychar.size() * 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemsetAsync(d_misc.p, 0, 64 + size_t(nq) * 4, st));
   // d_misc: [0] work counter (i32), [8] result count (u64), [64...] status per query
   int32_t* d_next = d_misc.as<int32_t>();
   unsigned long long* d_count = reinterpret_cast<unsigned long long*>(static_cast<char*>(d_misc.p) + 8);
@@ -455,8 +458,6 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   B.ent_ch = d_ch.as<uint16_t>();
   B.bychar = d_bychar.as<int32_t>();
   B.next = d_next;
-  B.results = d_results.as<NfaResultDev>();
-  B.result_cap = result_cap;
   B.result_count = d_count;
   B.status = d_status;
   B.max_iterations = ix->regexp_max_iterations;
@@ -467,7 +468,14 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
   const size_t budget = std::min<size_t>(free_b / 2, size_t(16) << 30);
-  std::vector<int32_t> todo(static_cast<size_t>(nq)), status(static_cast<size_t>(nq), 0), last_pass(static_cast<size_t>(nq), 0);
+  std::vector<int32_t> todo, status(static_cast<size_t>(nq), 0), last_pass(static_cast<size_t>(nq), 0);
+  unsigned long long count = 0;
+  for (int attempt = 0;; attempt++) {
+  if ((rc = d_results.reserve(size_t(result_cap) * sizeof(NfaResultDev)))) return rc;
+  B.results = d_results.as<NfaResultDev>();
+  B.result_cap = result_cap;
+  HIP_TRY(hipMemsetAsync(d_misc.p, 0, 64 + size_t(nq) * 4, st));
+  todo.resize(static_cast<size_t>(nq));
   for (int64_t i = 0; i < nq; i++) todo[size_t(i)] = int32_t(i);
   int64_t cap = std::min<int64_t>(1024, ix->regexp_stack_cap);
   for (int pass = 0;; pass++) {
@@ -484,7 +492,8 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
     for (int32_t q : todo) last_pass[size_t(q)] = pass;
     HIP_TRY(hipMemcpyAsync(d_order.p, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(d_next, 0, 4, st));
-    if (mode == 3) launch_nfa<PackPolicy>(ix->dev, B, blocks, st);
+    if (mode == 3 && ix->dev.ru) launch_nfa<RuPolicy>(ix->dev, B, blocks, st);
+    else if (mode == 3) launch_nfa<PackPolicy>(ix->dev, B, blocks, st);
     else if (mode == 4 && ix->dev.ind) launch_nfa<IndPolicy>(ix->dev, B, blocks, st);
     else if (mode == 4) launch_nfa<Pack2Policy>(ix->dev, B, blocks, st);
     else launch_nfa<WavePolicy>(ix->dev, B, blocks, st);
@@ -498,11 +507,15 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
     cap = std::min<int64_t>(cap * 64, ix->regexp_stack_cap);
     todo.swap(again);
   }
-  unsigned long long count = 0;
   HIP_TRY(hipMemcpy(&count, d_count, 8, hipMemcpyDeviceToHost));
-  if (int64_t(count) > result_cap) {
+  if (int64_t(count) <= result_cap) break;
+  // the raw buffer was too small: once more from the start with room for what this attempt produced (a search's raw
+  // count does not depend on the buffer, only on the arena sizes its passes ran with, which repeat)
+  result_cap = int64_t(count) + int64_t(count) / 8 + 1024;
+  if (attempt >= 3 || size_t(result_cap) * sizeof(NfaResultDev) > budget) {
     *n_out = int64_t(count);
-    return set_err(FEMTO_AMD_ERR_FULL, "more results than max_results (before sorting: " + std::to_string(count) + ")");
+    return set_err(FEMTO_AMD_ERR_FULL, "more raw result ranges than the device buffer may hold (" + std::to_string(count) + ")");
+  }
   }
   std::vector<NfaResultDev> raw(static_cast<size_t>(count));
   if (count) HIP_TRY(hipMemcpy(raw.data(), d_results.p, size_t(count) * sizeof(NfaResultDev), hipMemcpyDeviceToHost));
@@ -522,8 +535,8 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   result_start[nq] = n;
   *n_out = n;
   if (status_out) std::memcpy(status_out, status.data(), size_t(nq) * 4);
-  if (max_results == 0) return FEMTO_AMD_OK;        // count only
-  if (n > max_results) return set_err(FEMTO_AMD_ERR_FULL, "more results than max_results");
+  if (max_results == 0) return FEMTO_AMD_OK;        // count only: *n_out and result_start[] are what a second call needs
+  if (n > max_results) return set_err(FEMTO_AMD_ERR_FULL, "more results than max_results: *n_out holds the number to call again with");
   for (int64_t qi = 0; qi < nq; qi++) {
     const std::vector<NfaHostResult>& r = per[size_t(qi)];
     int64_t at = result_start[qi];

@@ -1,0 +1,115 @@
+// ru_kernels.hip.hpp -- rank units: ONE 16-byte load per Occ of a backward-search step on a small alphabet.
+//
+// A backward-search step (do_string_query, src/main/server.c:909-936) knows its character c: it needs rank_c at the two
+// ends of the range and nothing else.  The packed lines of pack_kernels.hip.hpp answer that from one 128-byte line, but
+// with SIX load instructions per range end (four plane pieces + a count word + its high byte), and a scattered load
+// costs the CU's address unit ~64 cycles per instruction whatever its width, and one address translation per lane.
+// For every TABLE character c (a character of the text that is not <= SEOF) open therefore also derives the plain bit
+// vector B_c[row] = (L[row] == c), cut into self-contained 16-byte units of 88 rows:
+//
+//   bits   0.. 39   C[c] + Occ(c, rows before this unit)          (40 bits: the format's 2^39-row limit)
+//   bits  40..127   bit 40 + i = B_c[88 * unit + i]
+//
+// so that  C[c] + Occ(c, row) = count + popcount(bits 40 .. 40 + row % 88)  is ONE load and two masked popcounts, and
+// the two ends of a narrow range are usually the SAME unit (one load per step).  Eight units share a 128-byte line
+// (704 rows).  (table characters) x rows / 5.5 bytes: 0.78 GB for a 2^30-row DNA index -- less than the packed lines,
+// which stay: an LF step (locate walk, text build) does not know its character and needs L[row] and the mark plane.
+// Patterns' stop characters (<= SEOF inside a pattern) keep stepping on the packed lines.  Same results as every other
+// layout (the tests compare them all with the reference's goldens); measured in profiles/r04_*.
+#pragma once
+
+namespace femto_amd {
+
+constexpr int kRuRows = 88;
+
+__device__ __forceinline__ void ru_split(int64_t row, uint64_t* unit, uint32_t* r) {
+  const uint32_t q = uint32_t(uint64_t(row) >> 3);   // rows < 2^35 (checked at open)
+  const uint32_t u = q / 11u;
+  *unit = u;
+  *r = uint32_t(uint64_t(row) - uint64_t(u) * kRuRows);
+}
+
+// C[c] + Occ(c, row) for row = 88 * unit + r
+__device__ __forceinline__ int64_t ru_rank_of(const uint4 v, uint32_t r) {
+  const uint64_t lo = uint64_t(v.x) | (uint64_t(v.y) << 32), hi = uint64_t(v.z) | (uint64_t(v.w) << 32);
+  const int nb = int(r) + 1;                       // bits to count: 1..88; the first 24 live in lo's top bits
+  const uint64_t mlo = nb >= 24 ? 0xffffffull : ((1ull << nb) - 1ull);
+  const uint64_t mhi = nb <= 24 ? 0ull : (nb >= 88 ? ~0ull : ((1ull << (nb - 24)) - 1ull));
+  const uint32_t cnt = uint32_t(__popcll((lo >> 40) & mlo)) + uint32_t(__popcll(hi & mhi));
+  return int64_t(lo & ((1ull << 40) - 1ull)) + int64_t(cnt);
+}
+
+// one step of the backward search with dense code `code` (server.c:909-936): [first,last] -> rows preceded by code
+__device__ __forceinline__ void ru_search_step(const DevIndex& ix, int j, uint32_t code, int64_t& first, int64_t& last) {
+  if (j == 0) {
+    first = ix.pack_c[code];
+    last = ix.pack_c[8 + code];
+    return;
+  }
+  if (code < uint32_t(ix.ru_nstop)) {    // a stop character inside a pattern: no unit vector, the packed lines answer
+    pack_search_step(ix, ix.pack, j, code, first, last);
+    return;
+  }
+  const uint4* const ub = reinterpret_cast<const uint4*>(ix.ru);
+  const uint4* const up = ub + uint64_t(code - uint32_t(ix.ru_nstop)) * uint64_t(ix.ru_stride);
+  uint64_t uL, uF = 0;
+  uint32_t rL, rF = 0;
+  ru_split(last, &uL, &rL);
+  const bool haveF = first != 0;
+  if (haveF) ru_split(first - 1, &uF, &rF);
+  const uint4 vL = up[uL];
+  trace_touch(ix, kTraceRu, uint64_t(up + uL - ub) >> 3);
+  uint4 vF = vL;
+  if (haveF && uF != uL) {       // both ends of a narrow range usually share the unit
+    vF = up[uF];
+    trace_touch(ix, kTraceRu, uint64_t(up + uF - ub) >> 3);
+  }
+  const int64_t nl = ru_rank_of(vL, rL);
+  const int64_t nf = ru_rank_of(vF, rF);    // (first == 0: unused)
+  first = haveF ? nf : ix.pack_c[code];
+  last = nl - 1;
+}
+
+// construction: one thread per unit and table character, from the rows' dense codes (sym, as pack_extract_kernel left
+// them) and the packed lines (the count before the unit)
+inline __global__ __launch_bounds__(256) void ru_build_kernel(const DevIndex ix, const int64_t nrows, const uint8_t* __restrict__ sym,
+                                                       uint4* __restrict__ ru, const int64_t stride, const int nstop, const int ntab) {
+  const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (u >= stride) return;
+  const int64_t row0 = u * kRuRows;
+  // the unit's 88 codes: 5.5 aligned 16-byte pieces of sym
+  uint64_t blo[8], bhi[8];
+#pragma unroll
+  for (int t = 0; t < 8; t++) blo[t] = bhi[t] = 0;
+  for (int i = 0; i < kRuRows; i++) {
+    const int64_t row = row0 + i;
+    if (row >= nrows) break;
+    const int t = int(sym[row] & 0x7fu) - nstop;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (t == k) {
+        if (i < 24) blo[k] |= 1ull << (40 + i);
+        else bhi[k] |= 1ull << (i - 24);
+      }
+  }
+  uint64_t line = 0;
+  uint32_t r = 0;
+  PackPlanes P;
+  if (row0 > 0 && row0 <= nrows) {
+    pack_split(row0 - 1, &line, &r);
+    pack_load_planes(ix.pack, line, P);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (k >= ntab) break;
+    const uint32_t code = uint32_t(k + nstop);
+    int64_t before;
+    if (row0 == 0) before = ix.pack_c[code];
+    else if (row0 > nrows) before = ix.pack_c[8 + code] + 1;     // past the end: C[c] + all occurrences of c (never read)
+    else before = pack_base(ix.pack, line, code) + int64_t(pack_match(P, code, r + 1));
+    const uint64_t lo = (uint64_t(before) & ((1ull << 40) - 1ull)) | blo[k];
+    ru[uint64_t(k) * uint64_t(stride) + uint64_t(u)] = make_uint4(uint32_t(lo), uint32_t(lo >> 32), uint32_t(bhi[k]), uint32_t(bhi[k] >> 32));
+  }
+}
+
+}  // namespace femto_amd

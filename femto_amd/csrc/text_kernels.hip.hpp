@@ -54,6 +54,14 @@ struct PackPolicy {
   }
 };
 
+// small alphabets with the rank units resident (ru_kernels.hip.hpp): a search step is ONE 16-byte load per range end;
+// LF steps (locate walks) do not know their character and stay on the packed lines
+struct RuPolicy : PackPolicy {
+  static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
+    ru_search_step(ix, j, code, f, l);
+  }
+};
+
 struct Pack2Policy {
   static constexpr int kWaves = 8;
   static constexpr int kDirectWaves = 8;
@@ -104,8 +112,7 @@ __device__ __forceinline__ bool tail_locate(const DevIndex& ix, int64_t row, int
     P::lf(ix, row, code, marked, sa_index, next);
     if (steps == 0 && first_code) *first_code = code;
     if (marked) {
-      *pos = ix.pack_sa[sa_index] + steps;
-      trace_touch(ix, kTraceSa, uint64_t(sa_index) >> 4);
+      *pos = mark_offset_at(ix, sa_index) + steps;
       return true;
     }
     if (P::is_stop(ix, code) || steps > int64_t(ix.walk_limit)) return false;

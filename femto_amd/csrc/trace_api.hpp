@@ -22,6 +22,7 @@ struct TraceArgs {
   int* flags;               // [0] error, [1] long ranges, [2] tail item count
   int64_t* total;
   uint32_t* bitmap;
+  unsigned long long* reads; // [kTraceRegions] read counters (zeroed by the caller)
   const int64_t* trace_off; // [kTraceRegions]
   hipStream_t stream;
 };

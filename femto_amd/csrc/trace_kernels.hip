@@ -14,6 +14,7 @@
 
 #include "kernels.hip.hpp"
 #include "pack_kernels.hip.hpp"
+#include "ru_kernels.hip.hpp"
 #include "pack2_kernels.hip.hpp"
 #include "ind_kernels.hip.hpp"
 #include "text_kernels.hip.hpp"
@@ -33,6 +34,7 @@ static DevIndex make_dev(const TraceArgs& a) {
   DevIndex d;
   memcpy(&d, a.dev, sizeof d);
   d.trace = a.bitmap;
+  d.trace_reads = a.reads;
   for (int r = 0; r < kTraceRegions; r++) d.trace_off[r] = a.trace_off[r];
   d.tail_items = a.tail_items;
   d.tail_count = a.flags + 2;
@@ -57,7 +59,8 @@ hipError_t traced_count_plan(const TraceArgs& a) {
     if (dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, true, true>), grid, block, 0, a.stream, d, a.npats, a.plen, a.pats, a.starts, a.first, a.last, a.flags, a.max_occs, a.noccs, ps, big_flag); \
     else hipLaunchKernelGGL((count_direct_kernel<POLICY, true, false>), grid, block, 0, a.stream, d, a.npats, a.plen, a.pats, a.starts, a.first, a.last, a.flags, a.max_occs, a.noccs, ps, big_flag);     \
   } while (0)
-  if (a.mode == 3) LAUNCH_COUNT_DIRECT(PackPolicy);
+  if (a.mode == 3 && d.ru) LAUNCH_COUNT_DIRECT(RuPolicy);
+  else if (a.mode == 3) LAUNCH_COUNT_DIRECT(PackPolicy);
   else if (d.ind) LAUNCH_COUNT_DIRECT(IndPolicy);
   else LAUNCH_COUNT_DIRECT(Pack2Policy);
 #undef LAUNCH_COUNT_DIRECT
@@ -68,7 +71,10 @@ hipError_t traced_count_plan(const TraceArgs& a) {
     const int* n_items = d.tail_count;
     const uint32_t* perm = nullptr;
     const uint64_t* keys = nullptr;
-    if (a.mode == 3) {
+    if (a.mode == 3 && d.ru) {
+      if (d.sa_full) hipLaunchKernelGGL((count_tail_kernel<RuPolicy, true>), tgrid, block, 0, a.stream, d, items, n_items, a.plen, a.pats, a.starts, perm, keys, 1, 0, out, a.flags);
+      else hipLaunchKernelGGL((count_tail_kernel<RuPolicy, false>), tgrid, block, 0, a.stream, d, items, n_items, a.plen, a.pats, a.starts, perm, keys, 1, 0, out, a.flags);
+    } else if (a.mode == 3) {
       if (d.sa_full) hipLaunchKernelGGL((count_tail_kernel<PackPolicy, true>), tgrid, block, 0, a.stream, d, items, n_items, a.plen, a.pats, a.starts, perm, keys, 1, 0, out, a.flags);
       else hipLaunchKernelGGL((count_tail_kernel<PackPolicy, false>), tgrid, block, 0, a.stream, d, items, n_items, a.plen, a.pats, a.starts, perm, keys, 1, 0, out, a.flags);
     } else {

@@ -131,7 +131,8 @@ int femto_amd_document_info(const femto_amd_index_t* ix, int64_t doc, const char
  * READS AROUND THE SYMBOLS: the kernels fetch the patterns in aligned 16-byte pieces, so up to 14 bytes before the first and
  * behind the last symbol of d_pats[] are LOADED (never used, never written).  An aligned piece cannot cross a page, so this
  * cannot fault -- but a memory checker, or a sub-allocator with poisoned guard bytes next to d_pats, will see the reads:
- * give d_pats 16 bytes of slack on either side, or align its ends to 16 bytes, if that matters.  (femto_amd_locate_device
+ * give d_pats 16 bytes of slack on either side, or align its ends to 16 bytes, if that matters.  d_pats itself must be
+ * 2-byte aligned (FEMTO_AMD_ERR_PARAM otherwise).  (femto_amd_locate_device
  * falls back to a host-synchronising path -- it reads the row total back on `stream` -- for rank modes 0 and 1; the
  * packed modes 3 / 4 are enqueue-only as stated.) */
 int femto_amd_count_device(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen,
@@ -215,8 +216,9 @@ int femto_amd_split_info(const femto_amd_index_t* ix, int* part, int* nparts, in
  * status_out[q] (may be NULL): 0, FEMTO_AMD_ERR_OVERWORKED (more than MAX_REGEXP_ITERATIONS = 10^6 steps, server.c:40,1821:
  * the reference returns ERR_OVERWORKED and no results) or FEMTO_AMD_ERR_FULL (more pending ranges than option
  * "regexp_stack_cap", default 2^18, at most 2^22; the reference has no such bound -- it would run on to ERR_OVERWORKED).  The out arrays hold max_results entries for ALL
- * automata together; *n_out = results in total; max_results == 0 only counts; more results than max_results is
- * FEMTO_AMD_ERR_FULL with *n_out = the number needed (before de-duplication).  Limits: 2048 nodes, 2^22 transitions per
+ * automata together; *n_out = results in total; max_results == 0 only counts (result_start[] and *n_out are filled, the
+ * other out arrays may be NULL); more results than max_results is FEMTO_AMD_ERR_FULL with *n_out = the exact number
+ * to call again with (raw result ranges are buffered by the library itself, however many there are).  Limits: 2048 nodes, 2^22 transitions per
  * automaton, costs and cost_bound 1..255 (errors are counted in one byte, nfa.h:74-76). */
 typedef struct femto_amd_nfa {
   int32_t num_nodes;
@@ -340,8 +342,9 @@ int femto_amd_pack_counts_device(femto_amd_index_t* ix, int64_t npats, const int
 typedef struct femto_amd_options {
   uint32_t struct_size;          /* sizeof(femto_amd_options_t), set by femto_amd_options_init: versions the struct */
   int32_t rank_mode;             /* -1: the fastest that applies | 0 raw | 1 lane | 3 pack | 4 pack2   [FEMTO_AMD_RANK_MODE] */
-  int64_t hbm_budget_bytes;      /* -1: what is free on the device | bytes this handle may allocate in all: the optional
-                                  * structures are declined (identical results on the slower path) once it is spent */
+  int64_t hbm_budget_bytes;      /* -1: what is free on the device | bytes this handle may HOLD in all (femto_amd_structures
+                                  * [13]): the optional structures are declined (identical results on the slower path) once it
+                                  * is spent; with a budget the level table takes what the lines, marks and rank units leave */
   int32_t packed_lines;          /* 0: skip mode 3's lines                                                [FEMTO_AMD_PACK] */
   int32_t two_level_lines;       /* 0: skip mode 4's lines | 1: build them for <= 8 characters too        [FEMTO_AMD_PACK2] */
   int32_t char_rank_lines;       /* 0: skip the per-character rank lines of byte alphabets                [FEMTO_AMD_IND] */
@@ -363,6 +366,8 @@ typedef struct femto_amd_options {
   int32_t host_keys;             /* 0: host-pointer batches travel as symbols, never as keys              [FEMTO_AMD_HOST_KEYS] */
   int32_t host_pipe_chunk_log2;  /* log2 patterns per pipeline stage; auto 20                             [FEMTO_AMD_PIPE_CHUNK_LOG2] */
   int32_t host_d2h_staged;       /* 0: located offsets return with one plain copy                         [FEMTO_AMD_D2H_STAGED] */
+  int32_t rank_units;            /* 0: skip the 16-byte rank units of small alphabets (ru_kernels.hip.hpp) [FEMTO_AMD_RU] */
+  int32_t marks_32bit;           /* 0: derived mark offsets stay 8 bytes; auto: 4 bytes when the index has < 2^32 rows [FEMTO_AMD_SA32] */
 } femto_amd_options_t;
 void femto_amd_options_init(femto_amd_options_t* opts);
 /* femto_amd_open with options (NULL = all auto = femto_amd_open) */
@@ -394,6 +399,14 @@ int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode);
  * "regexp_max_iterations" (default 10^6 = MAX_REGEXP_ITERATIONS), "regexp_stack_cap" (default 2^18). */
 int femto_amd_set_option(femto_amd_index_t* ix, const char* name, int value);
 int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* bytes, double* build_ms, int* ktab_syms);
+/* What the handle holds in HBM, in bytes -- the server's "what may a handle spend" made visible (the counterpart of
+ * server_settings_t's cache sizes, src/main/server.c:3484-3602): out[0] the femto block files as uploaded, [1] packed lines,
+ * [2] offsets of the derived marks, [3] rank units, [4] level table, [5] context tables, [6] per-character rank lines,
+ * [7] text + suffix / inverse suffix arrays, [8] two-level lines, [9] everything derived (lane tables included),
+ * [10] distance between derived marks (0: femto's own), [11] level-table depth K, [12] bytes per mark offset,
+ * [13] HBM the handle holds in all (every persistent allocation: what hbm_budget_bytes is counted against; the scratch
+ * of a running batch call -- patterns, results -- is the caller's in the device-pointer API and not part of it).  n <= 16. */
+int femto_amd_structures(const femto_amd_index_t* ix, int64_t* out, int n);
 /* Where the LAST staged host-pointer batch call (femto_amd_count_flat / _parallel_count ... on >= 2^18 patterns) spent its
  * wall time, in ms: out8[0] staging threads packing the caller's patterns into pinned key / symbol chunks, [1] waiting for
  * a pinned input buffer, [2] enqueueing copies / kernels / events, [3] waiting for a chunk's results to arrive over PCIe,
@@ -411,12 +424,15 @@ void femto_amd_kernel_time_enable(femto_amd_index_t* ix, int on);
 /* Compulsory HBM traffic of a batch (bench.py's roofline): runs the batch once with a line trace and reports how many
  * DISTINCT 128-byte lines of each derived array the count phase (count_lines[10]) and the row expansion + locate walk
  * (locate_lines[10]) loaded; *rows_out = rows located.  Regions: 0 packed lines (mode 3), 1 level table, 2 suffix
- * array / offsets of the marked rows, 3 / 4 level-1 / level-2 lines (mode 4), 5 text, 6 inverse suffix array, 7 round-1
- * table, 8 per-character rank lines, 9 context table.
+ * array / offsets of the marked rows, 3 / 4 level-1 / level-2 lines (mode 4), 5 text, 6 inverse suffix array, 7 rank
+ * units, 8 per-character rank lines, 9 context table.
  * Device pointers as in femto_amd_count_device; blocking; not to be called while other calls use the handle. */
 int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
                           const int64_t* d_starts, int max_occs_each, int64_t* count_lines, int64_t* locate_lines,
                           int64_t* rows_out);
+/* ... and how many lines of each region the two phases of that LAST trace READ in all (the same line read for two patterns
+ * counts twice): what an unsorted batch fetches when the structure is far larger than the caches. */
+int femto_amd_trace_reads(const femto_amd_index_t* ix, int64_t* count_reads /* [10] */, int64_t* locate_reads /* [10] */);
 
 /* ---- index construction (femto block-file writer) ------------------------- */
 /* Builds a femto index directory (byte-identical to index_documents(map=NULL),

@@ -1,7 +1,7 @@
-/* femto_amd_shim.c -- routes femto's batch count/locate (src/main/femto.c:275,331,481) to the MI355X engine.
+/* femto_amd_shim.c -- routes femto's batch count/locate (src/main/femto.c:275,331,402,481) to the MI355X engine.
  *
  * This is the file a femto maintainer adds to src/main/.  The reference's callers (index_test.c:356-410,
- * query_tool.c:133-206, ...) keep calling parallel_count / parallel_locate / parallel_locate_range with the signatures
+ * query_tool.c:133-206, ...) keep calling parallel_count / parallel_locate / serial_locate / parallel_locate_range with the signatures
  * of src/main/femto_internal.h:63-75; the bodies below forward to the C ABI of include/femto_amd.h.  The reference's own
  * CPU implementations stay linked under the names femto_cpu_* (femto.c compiled with
  * -Dparallel_count=femto_cpu_parallel_count ... -- see oracle/Makefile; in the reference tree that is an
@@ -161,6 +161,38 @@ error_t parallel_locate(femto_server_t* srv, index_locator_t loc,
   error_t err = amd_get(srv, loc, &ix);
   if( err ) return err;
   return amd_err(femto_amd_parallel_locate(ix, npats, plen, (const uint16_t* const*) pats, max_occs_each, noccs, offsets));
+}
+
+/* src/main/femto.c:402 -- parallel_locate's test twin (query_tool.c:157): one pattern at a time, and its OWN clamp,
+ * "1+last-first >= max_occs_each" (femto.c:427-428; parallel_locate's is "last-first > max_occs", server.c:4411), so the
+ * two differ when a pattern has exactly max_occs_each + 1 rows.  Reproduced as written: the range from the GPU's count,
+ * the offsets of its first noccs rows from the GPU's range locate. */
+error_t serial_locate(femto_server_t* srv, index_locator_t loc,
+                      int npats, int* plen, alpha_t** pats,
+                      int max_occs_each,
+                      int* noccs, int64_t** offsets)
+{
+  femto_amd_index_t* ix = NULL;
+  error_t err;
+  int i;
+  if( ! srv ) return ERR_PARAM;
+  err = amd_get(srv, loc, &ix);
+  if( err ) return err;
+  for( i = 0; i < npats; i++ ) {
+    int64_t first = -1, last = -1;
+    int rc = femto_amd_parallel_count(ix, 1, &plen[i], (const uint16_t* const*) &pats[i], &first, &last);
+    if( rc ) return amd_err(rc);
+    if( 1+last-first >= max_occs_each ) noccs[i] = max_occs_each;
+    else noccs[i] = (int) (1+last-first);
+    offsets[i] = NULL;
+    if( noccs[i] > 0 ) {
+      offsets[i] = malloc(sizeof(int64_t) * noccs[i]);
+      if( ! offsets[i] ) return ERR_MEM;
+      rc = femto_amd_parallel_locate_range(ix, first, first + noccs[i] - 1, offsets[i]);
+      if( rc ) return amd_err(rc);
+    }
+  }
+  return ERR_NOERR;
 }
 
 /* src/main/femto.c:481 */

@@ -372,6 +372,32 @@ static int cmd_locate(int argc, char** argv)
   return 0;
 }
 
+/* serial <index> <patfile> <max_occs> <out.bin>: serial_locate one pattern at a time, as query_tool.c:157 calls it;
+   same output layout as locate */
+static int cmd_serial(int argc, char** argv)
+{
+  if (argc < 4) return 2;
+  femto_server_t srv = start_srv(0);
+  index_locator_t loc;
+  error_t err = femto_loc_for_path_err(&srv, argv[0], &loc);
+  if (err) die("femto_loc_for_path_err", err);
+  patset_t ps = read_patterns(argv[1]);
+  int max_occs = atoi(argv[2]);
+  int* noccs = calloc(ps.npats + 1, sizeof(int));
+  int64_t** offsets = calloc(ps.npats + 1, sizeof(int64_t*));
+  for (int i = 0; i < ps.npats; i++) {
+    err = serial_locate(&srv, loc, 1, &ps.plen[i], &ps.pats[i], max_occs, &noccs[i], &offsets[i]);
+    if (err) die("serial_locate", err);
+  }
+  FILE* out = fopen(argv[3], "wb");
+  fwrite(noccs, 4, ps.npats, out);
+  for (int i = 0; i < ps.npats; i++)
+    if (noccs[i] > 0) fwrite(offsets[i], 8, noccs[i], out);
+  fclose(out);
+  femto_stop_server(&srv);
+  return 0;
+}
+
 /* bench <index> <patfile> <count|locate> <max_occs> <threads> <reps> [out.bin]
    (out.bin, count mode: i64 first[n], i64 last[n] of the last repetition -- lets the caller check
    the very results that were timed) */
@@ -535,6 +561,7 @@ int main(int argc, char** argv)
   if (!strcmp(c, "occs")) return cmd_occs(argc - 2, argv + 2);
   if (!strcmp(c, "count")) return cmd_count(argc - 2, argv + 2);
   if (!strcmp(c, "locate")) return cmd_locate(argc - 2, argv + 2);
+  if (!strcmp(c, "serial")) return cmd_serial(argc - 2, argv + 2);
   if (!strcmp(c, "bench")) return cmd_bench(argc - 2, argv + 2);
   if (!strcmp(c, "forward")) return cmd_forward(argc - 2, argv + 2);
   if (!strcmp(c, "bseq")) return cmd_bseq(argc - 2, argv + 2);

@@ -286,6 +286,15 @@ def test_iteration_limit_and_stack_bound(fixtures):
     # more results than the caller's arrays hold
     with pytest.raises(femto_amd.FemtoAmdError):
         ix.nfa_search_batch(nfas, max_results=2)
+    # ... ERR_FULL leaves the exact number to call again with; max_results = 0 only counts (the raw ranges -- before the sort drops
+    # ranges inside other results -- are buffered by the library, so neither depends on the caller's capacity)
+    need = ix.last_total
+    full = ix.nfa_search_batch(nfas, max_results=1 << 20)
+    assert need == len(full[1]) > 2
+    exact = ix.nfa_search_batch(nfas, max_results=need)
+    assert all(np.array_equal(a, b) for a, b in zip(full, exact))
+    cstart, cf, cl, cm, cc, cst = ix.nfa_search_batch(nfas, max_results=0)
+    assert ix.last_total == need and len(cf) == 0 and np.array_equal(cstart, full[0]) and np.array_equal(cst, full[5])
     o.close()
     ix.close()
 
