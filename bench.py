@@ -47,8 +47,8 @@ def kernel_names(ix, direct):
         cn = "femto_amd::count_direct_kernel<femto_amd::RuPolicy, true"
     if direct and ix.rank_mode == 4 and pi.get("char_rank_lines"):
         cn = "femto_amd::count_direct_kernel<femto_amd::IndPolicy, true"
-    if direct and pi.get("sa_full"):
-        ln = "femto_amd::plan_rows_kernel<true>"      # the full suffix array is resident: locate is fused into the row expansion
+    if direct:      # locate is fused into the row expansion: offsets from the resident suffix array (1) or by a walk per row (2)
+        ln = "femto_amd::plan_rows_kernel<1," if pi.get("sa_full") else "femto_amd::plan_rows_kernel<2,"
     return cn, ln
 
 

@@ -110,13 +110,14 @@ struct KernelTimer {
 // batches) the stream and pinned staging a call writes -- from a small pool owned by the handle, so concurrent calls
 // on one handle never share mutable device state and overlap on the GPU.  An enqueue-only (device-pointer) call
 // returns its lease with an event recorded on the caller's stream; the scratch is reused once that event is done.
+constexpr int kPipeDepth = 3;            // chunks in flight: one being packed, one on the wire / in the kernel, one coming back
 struct HostPipe {
-  void* h_in[2] = {nullptr, nullptr};    // [plen i32 x chunk | starts i64 x chunk | symbols u16 x sym_cap]
-  void* h_out[2] = {nullptr, nullptr};   // [first i64 x chunk | last i64 x chunk]
-  void* d_in[2] = {nullptr, nullptr};
-  void* d_out[2] = {nullptr, nullptr};
+  void* h_in[kPipeDepth] = {};           // [plen i32 x chunk | starts i64 x chunk | symbols u16 x sym_cap]
+  void* h_out[kPipeDepth] = {};          // [first i64 x chunk | last i64 x chunk]
+  void* d_in[kPipeDepth] = {};
+  void* d_out[kPipeDepth] = {};
   hipStream_t s_h2d = nullptr, s_d2h = nullptr;
-  hipEvent_t in_done[2] = {nullptr, nullptr}, k_done[2] = {nullptr, nullptr}, out_done[2] = {nullptr, nullptr};
+  hipEvent_t in_done[kPipeDepth] = {}, k_done[kPipeDepth] = {}, out_done[kPipeDepth] = {};
   bool ready = false;
 };
 
@@ -156,7 +157,7 @@ struct Scratch {
     for (DeviceBuffer* b : {&plen, &pats, &starts, &first, &last, &noccs, &noccs64, &out_starts, &offsets, &scan[0], &scan[1], &scan[2],
                             &rows, &ch, &occ, &off, &keys, &keys2, &idx, &idx2, &sorttmp, &pairs, &tail, &bsums})
       b->release();
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < kPipeDepth; b++) {
       if (pipe.h_in[b]) (void)hipHostFree(pipe.h_in[b]);
       if (pipe.h_out[b]) (void)hipHostFree(pipe.h_out[b]);
       if (pipe.d_in[b]) (void)hipFree(pipe.d_in[b]);
@@ -238,6 +239,7 @@ struct femto_amd_index {
   double pack2_build_ms = 0;
   int64_t pack_bytes = 0;
   double pack_build_ms = 0;
+  int64_t* d_ru_stop = nullptr;  // rows of the stop characters (ru_stop_step)
   uint64_t* d_ru = nullptr;         // rank units of small alphabets (ru_kernels.hip.hpp)
   int64_t ru_bytes = 0;
   int64_t last_trace_reads[2][16] = {};   // femto_amd_trace_lines: line READS of the count / the locate phase, per region
@@ -262,9 +264,8 @@ struct femto_amd_index {
   double dense_sigma = 256;    // distinct characters of the indexed text
   int64_t sort_min = 4096;
   int64_t regexp_max_iterations = 1000000;   // MAX_REGEXP_ITERATIONS (src/main/server.c:40); option "regexp_max_iterations"
-  int64_t regexp_stack_cap = int64_t(1) << 18; // pending ranges one search may hold (option "regexp_stack_cap", <= 2^22): a
-                                               // child looks for a pending entry with its range by scanning them, so the bound also
-                                               // bounds the time a pattern such as `a.*b` (96 children per step) can take: seconds
+  int64_t regexp_stack_cap = int64_t(1) << 18; // pending ranges one search may hold (option "regexp_stack_cap", <= 2^22); the reference
+                                               // has no bound: it runs on to ERR_OVERWORKED
   bool timing = false;
   KernelTimer t_count, t_locate;
   double pipe_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the last staged host-pointer call (femto_amd_host_pipeline_stats)

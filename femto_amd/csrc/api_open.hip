@@ -381,20 +381,37 @@ int build_pack(femto_amd_index* ix) {
       const size_t rbytes = size_t(std::max(ntab, 0)) * size_t(ustride) * 16;
       const bool want = knob(ix->opt.rank_units, "FEMTO_AMD_RU", 1) != 0;
       // (a handle with an HBM budget: at most half of what the budget has left -- the level table takes the rest)
-      if (want && ntab >= 1 && n < (int64_t(1) << 35) && rbytes <= hbm_free(ix) / (ix->opt.hbm_budget_bytes >= 0 ? 2 : 3) &&
-          big_malloc(ix, reinterpret_cast<void**>(&ix->d_ru), rbytes + 256) == hipSuccess) {
+      // the rows of the stop characters (one per document and character <= SEOF): 8 bytes each, listed for ru_stop_step
+      int64_t nstoprows = 0;
+      int32_t soff[4] = {0, 0, 0, 0};
+      for (int c = 0; c < 3; c++) {
+        if (c < nstop) nstoprows += pc[8 + size_t(c)] + 1 - pc[size_t(c)];
+        soff[c + 1] = int32_t(std::min<int64_t>(nstoprows, INT32_MAX));
+      }
+      if (want && ntab >= 1 && nstop <= 3 && nstoprows < INT32_MAX && n < (int64_t(1) << 35) &&
+          rbytes + size_t(nstoprows) * 8 <= hbm_free(ix) / (ix->opt.hbm_budget_bytes >= 0 ? 2 : 3) &&
+          big_malloc(ix, reinterpret_cast<void**>(&ix->d_ru), rbytes + 256) == hipSuccess &&
+          big_malloc(ix, reinterpret_cast<void**>(&ix->d_ru_stop), size_t(nstoprows) * 8 + 64) == hipSuccess) {
         DevIndex d = ix->dev;
         d.pack = ix->d_pack;
+        for (int c = 0; c < 4; c++) d.ru_stop_off[c] = ix->dev.ru_stop_off[c] = soff[c];
+        hipLaunchKernelGGL(ru_stop_rows_kernel, dim3(uint32_t((nlines + 255) / 256)), dim3(256), 0, nullptr, d, nlines, n, sym.as<uint8_t>(),
+                           scans.as<int64_t>(), stride, nstop, ix->d_ru_stop);
+        ix->dev.ru_stop_rows = ix->d_ru_stop;
         hipLaunchKernelGGL(ru_build_kernel, dim3(uint32_t((ustride + 255) / 256)), dim3(256), 0, nullptr, d, n, sym.as<uint8_t>(), reinterpret_cast<uint4*>(ix->d_ru), ustride,
                            nstop, ntab);
         HIP_TRY(hipGetLastError());
         ix->dev.ru = ix->d_ru;
         ix->dev.ru_stride = ustride;
         ix->dev.ru_nstop = nstop;
-        ix->ru_bytes = int64_t(rbytes);
+        ix->ru_bytes = int64_t(rbytes) + nstoprows * 8;
         ix->table_bytes += ix->ru_bytes;
       } else {
         (void)hipGetLastError();
+        big_free(ix, ix->d_ru);
+        ix->d_ru = nullptr;
+        big_free(ix, ix->d_ru_stop);
+        ix->d_ru_stop = nullptr;
       }
     }
     const int every = derived_mark_every(ix);

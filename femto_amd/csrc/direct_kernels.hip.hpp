@@ -629,12 +629,33 @@ inline __global__ void copy_total_kernel(const int64_t* __restrict__ src, int64_
   }
 }
 
+// the text offset of `row` by the locate walk (do_back_query / do_context_query, src/main/server.c:2228-2359, :2627-2795):
+// LF steps until a marked row; -1 when a document start or the walk limit comes first
+template <class P>
+__device__ __forceinline__ int64_t walk_row(const DevIndex& ix, int64_t row) {
+  int64_t steps = 0;
+  while (row >= 0 && steps <= int64_t(ix.walk_limit)) {
+    uint32_t code;
+    bool marked;
+    int64_t sa_index, next;
+    P::lf(ix, row, code, marked, sa_index, next);
+    if (marked) return mark_offset_at(ix, sa_index) + steps;
+    if (P::is_stop(ix, code)) break;              // cannot walk past a document start (server.c:2336-2342)
+    row = next;                                    // LF (server.c:2279-2282)
+    steps++;
+  }
+  return -1;
+}
+
 // out_starts[q] = rows located for the patterns before q; pattern q's rows first[q] .. first[q]+noccs-1 are written at
 // offsets[out_starts[q] ..] (the walk replaces each row by its text offset).  Ranges longer than kExpandSerialMax rows
 // (the empty pattern with a huge max_occs) are left to expand_big_rows_kernel.
-// kSa: the full suffix array is resident -- the offsets themselves are written (offsets[..] = SA[first + k], consecutive
-// reads) and no walk follows.
-template <bool kSa>
+// kMode 1: the full suffix array is resident -- the offsets themselves are written (offsets[..] = SA[first + k], consecutive
+// reads) and no walk follows.  kMode 2: sampled marks -- the offsets themselves again, each by its walk (walk_row<P>), right
+// here: the rows are never written and read back and no walk kernel is launched behind this one (a step of the
+// footprint-bounded handle: 1.116 -> ... ms, profiles/r04_*).  kMode 0: the rows (two-call API; femto_amd_locate_walk_device walks them).
+constexpr int kRowsOnly = 0, kRowsSa = 1, kRowsWalk = 2;
+template <int kMode, class P>
 inline __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npats, const int32_t* __restrict__ noccs, const int64_t* __restrict__ first,
                                                         const int2* __restrict__ first32 /* or NULL: (first,last) pairs instead of first[] */,
                                                         const PlanSums ps, int64_t* __restrict__ out_starts,
@@ -682,7 +703,7 @@ inline __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npa
   const int64_t base = q < npats ? s_boff + woff + int64_t(incl) - n : 0;
   if (q < npats) out_starts[q] = base;
   if (!offsets) return;
-  if (kSa) {
+  if (kMode != kRowsOnly) {
     // The wavefront writes its patterns' offsets TOGETHER: output slot s of the wavefront's span belongs to the lane whose
     // inclusive in-wave count first exceeds it, so consecutive lanes write consecutive slots (coalesced) and read
     // consecutive suffix-array entries of a pattern's range.  Long ranges go to plan_big_rows_kernel as before.
@@ -715,8 +736,12 @@ inline __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npa
         const int64_t slot = s_lbase[wave][lo] + k;
         if (slot < capacity) {
           const int64_t row = s_first[wave][lo] + k;
-          offsets[slot] = ix.sa_full[row];
-          trace_touch(ix, kTraceSa, uint64_t(row) >> 4);
+          if (kMode == kRowsSa) {
+            offsets[slot] = ix.sa_full[row];
+            trace_touch(ix, kTraceSa, uint64_t(row) >> 4);
+          } else {
+            offsets[slot] = walk_row<P>(ix, row);
+          }
         }
       }
     }
@@ -733,7 +758,7 @@ inline __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npa
 }
 
 // the long ranges left over by plan_rows_kernel: grid-stride, one thread per output slot (idle unless the flag is set)
-template <bool kSa>
+template <int kMode, class P>
 inline __global__ __launch_bounds__(256) void plan_big_rows_kernel(const int64_t npats, const int64_t* __restrict__ first, const int2* __restrict__ first32,
                                                             const int64_t* __restrict__ out_starts, const int64_t* __restrict__ total_ptr,
                                                             const int64_t capacity, int64_t* __restrict__ offsets, const int* __restrict__ big_flag,
@@ -749,9 +774,11 @@ inline __global__ __launch_bounds__(256) void plan_big_rows_kernel(const int64_t
     const int64_t end = lo + 1 < npats ? out_starts[lo + 1] : *total_ptr;
     if (end - out_starts[lo] > kExpandSerialMax) {
       const int64_t row = (first32 ? int64_t(first32[lo].x) : first[lo]) + (item - out_starts[lo]);
-      if (kSa) {
+      if (kMode == kRowsSa) {
         offsets[item] = ix.sa_full[row];
         trace_touch(ix, kTraceSa, uint64_t(row) >> 4);
+      } else if (kMode == kRowsWalk) {
+        offsets[item] = walk_row<P>(ix, row);
       } else {
         offsets[item] = row;
       }
@@ -776,22 +803,7 @@ inline __global__ __launch_bounds__(256) void locate_walk_kernel(const DevIndex 
                                                           int64_t* __restrict__ offsets) {
   const int64_t total = *total_ptr < capacity ? *total_ptr : capacity;
   for (int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; item < total; item += int64_t(gridDim.x) * blockDim.x) {
-    int64_t row = offsets[item];
-    int64_t steps = 0, result = -1;
-    while (row >= 0 && steps <= int64_t(ix.walk_limit)) {
-      uint32_t code;
-      bool marked;
-      int64_t sa_index, next;
-      P::lf(ix, row, code, marked, sa_index, next);
-      if (marked) {
-        result = mark_offset_at(ix, sa_index) + steps;
-        break;
-      }
-      if (P::is_stop(ix, code)) break;              // cannot walk past a document start (server.c:2336-2342)
-      row = next;                                    // LF (server.c:2279-2282)
-      steps++;
-    }
-    offsets[item] = result;
+    offsets[item] = walk_row<P>(ix, offsets[item]);
   }
 }
 

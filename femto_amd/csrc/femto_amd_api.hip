@@ -589,26 +589,38 @@ int launch_count_plan(femto_amd_index* ix, Scratch& S, int64_t npats, const int3
 
 // direct pipeline, after launch_count_plan: out_starts[] and -- when d_offsets is given -- the rows to locate
 int launch_plan_rows(femto_amd_index* ix, Scratch& S, int64_t npats, const int32_t* d_noccs, const int64_t* d_first,
-                     int64_t* d_out_starts, int64_t* d_offsets, int64_t capacity, hipStream_t stream, const int2* d_first32 = nullptr) {
+                     int64_t* d_out_starts, int64_t* d_offsets, int64_t capacity, hipStream_t stream, const int2* d_first32 = nullptr,
+                     bool fuse_walk = false) {
   if (npats <= 0) return 0;
   int* big_flag = S.d_flags + 1;      // cleared by the count kernel
   const int64_t nblocks = (npats + kBlockThreads - 1) / kBlockThreads;
   const dim3 grid{uint32_t(nblocks)}, bgrid{uint32_t(std::min<int64_t>(nblocks, int64_t(ix->num_cus) * 8))}, block{uint32_t(kBlockThreads)};
   const PlanSums ps = plan_sums_at(S.bsums.p, nblocks, false, S.bsums_parity);
   S.bsums_clean = true;
-  const bool sa = d_offsets && ix->dev.sa_full;    // the offsets themselves, no walk afterwards
+  // what lands in d_offsets: the offsets themselves from the resident suffix array (no walk afterwards); the offsets
+  // themselves by a walk per row inside the expansion (fuse_walk: sampled marks, one-call chains); or the rows
+  const int mode = (d_offsets && ix->dev.sa_full) ? kRowsSa : ((d_offsets && fuse_walk) ? kRowsWalk : kRowsOnly);
+  const bool timed = mode != kRowsOnly;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (sa) timer_begin(ix, ix->t_locate, stream, &e0, &e1);
-  if (sa) hipLaunchKernelGGL(plan_rows_kernel<true>, grid, block, 0, stream, npats, d_noccs, d_first, d_first32, ps, d_out_starts, d_offsets, capacity, big_flag, ix->dev, S.d_total, S.total_user);
-  else hipLaunchKernelGGL(plan_rows_kernel<false>, grid, block, 0, stream, npats, d_noccs, d_first, d_first32, ps, d_out_starts, d_offsets, capacity, big_flag, ix->dev, S.d_total, S.total_user);
-  if (d_offsets) {
-    if (sa) hipLaunchKernelGGL(plan_big_rows_kernel<true>, bgrid, block, 0, stream, npats, d_first, d_first32, static_cast<const int64_t*>(d_out_starts),
-                               static_cast<const int64_t*>(S.d_total), capacity, d_offsets, static_cast<const int*>(big_flag), ix->dev);
-    else hipLaunchKernelGGL(plan_big_rows_kernel<false>, bgrid, block, 0, stream, npats, d_first, d_first32, static_cast<const int64_t*>(d_out_starts),
-                            static_cast<const int64_t*>(S.d_total), capacity, d_offsets, static_cast<const int*>(big_flag), ix->dev);
-  }
+  if (timed) timer_begin(ix, ix->t_locate, stream, &e0, &e1);
+  const int64_t* starts_c = d_out_starts;
+  const int64_t* total_c = S.d_total;
+  const int* big_c = big_flag;
+#define LAUNCH_PLAN(MODE, POLICY)                                                                                                         \
+  do {                                                                                                                                    \
+    hipLaunchKernelGGL((plan_rows_kernel<MODE, POLICY>), grid, block, 0, stream, npats, d_noccs, d_first, d_first32, ps, d_out_starts,  \
+                       d_offsets, capacity, big_flag, ix->dev, S.d_total, S.total_user);                                                  \
+    if (d_offsets)                                                                                                                        \
+      hipLaunchKernelGGL((plan_big_rows_kernel<MODE, POLICY>), bgrid, block, 0, stream, npats, d_first, d_first32, starts_c, total_c,    \
+                         capacity, d_offsets, big_c, ix->dev);                                                                            \
+  } while (0)
+  if (mode == kRowsSa) LAUNCH_PLAN(kRowsSa, PackPolicy);            // (the policy only matters to the walk)
+  else if (mode == kRowsOnly) LAUNCH_PLAN(kRowsOnly, PackPolicy);
+  else if (ix->mode == 3) LAUNCH_PLAN(kRowsWalk, PackPolicy);
+  else LAUNCH_PLAN(kRowsWalk, Pack2Policy);
+#undef LAUNCH_PLAN
   HIP_TRY(hipGetLastError());
-  if (sa) timer_end(ix, ix->t_locate, stream, e0, e1);
+  if (timed) timer_end(ix, ix->t_locate, stream, e0, e1);
   return 0;
 }
 
@@ -713,7 +725,7 @@ int pipe_init(femto_amd_index* ix, Scratch& S) {
   }
   auto& P = S.pipe;
   if (P.ready) return 0;
-  for (int b = 0; b < 2; b++) {
+  for (int b = 0; b < kPipeDepth; b++) {
     HIP_TRY(hipHostMalloc(&P.h_in[b], pipe_in_bytes(), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(&P.h_out[b], size_t(kPipeChunk) * 16, hipHostMallocDefault));
     HIP_TRY(hipMalloc(&P.d_in[b], pipe_in_bytes()));
@@ -865,7 +877,13 @@ int count_host_pipelined(femto_amd_index* ix, Scratch& S, const HostBatch& hb, i
   bool keys_ok = use_direct(ix) && !ix->h_dense.empty();
   keys_ok = keys_ok && knob(ix->opt.host_keys, "FEMTO_AMD_HOST_KEYS", 1) != 0;
   const bool rows32 = ix->host.total_length < (int64_t(1) << 31) - 1;    // rows (and last + 1, -1) fit 32 bits
-  int kind[2] = {1, 1};   // what h_out[b] holds: 1 int64 arrays, 2 int32 (first,last) pairs, 3 int64 arrays of a key chunk (both present)
+  int kind[kPipeDepth] = {1, 1, 1};   // what h_out[b] holds: 1 int64 arrays, 2 int32 (first,last) pairs, 3 int64 arrays of a key chunk (both present)
+  // chunk c - kLag is handed back while chunk c is packed: with kLag = 2 its results have had a whole packing stage more to
+  // arrive (kLag = 1, two buffers in use: 0.7-0.9 ms of a 3.7 ms call waited for them).  FEMTO_AMD_PIPE_LAG=1 for A/B runs.
+  int kLag = kPipeDepth - 1;
+  if (const char* e = getenv("FEMTO_AMD_PIPE_LAG")) kLag = std::max(1, std::min(kPipeDepth - 1, atoi(e)));
+  const int depth = kLag + 1;
+  static const bool nt_stores = [] { const char* e = getenv("FEMTO_AMD_NT_STORES"); return !e || atoi(e) != 0; }();
   // every exit leaves nothing in flight on the pinned buffers
   auto fail = [&](int code) {
     (void)hipStreamSynchronize(P.s_h2d);
@@ -891,12 +909,12 @@ int count_host_pipelined(femto_amd_index* ix, Scratch& S, const HostBatch& hb, i
   auto since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
   double st[6] = {0, 0, 0, 0, 0, 0};
   const clk::time_point t_call = clk::now();
-  for (int64_t c = 0; c <= nchunks; c++) {
+  for (int64_t c = 0; c < nchunks + kLag; c++) {
     if (c < nchunks) {
-      const int b = int(c & 1);
+      const int b = int(c % depth);
       const int64_t a = c * chunk, e = std::min(hb.npats, a + chunk), n = e - a;
       clk::time_point t0 = clk::now();
-      if (c >= 2) PIPE_TRY(hipEventSynchronize(P.k_done[b]));  // chunk c-2 no longer reads d_in[b] (and h_in[b] was uploaded)
+      if (c >= depth) PIPE_TRY(hipEventSynchronize(P.k_done[b]));  // chunk c-3 no longer reads d_in[b] (and h_in[b] was uploaded)
       st[1] += since(t0);
       t0 = clk::now();
       char* din = static_cast<char*>(P.d_in[b]);
@@ -923,7 +941,7 @@ int count_host_pipelined(femto_amd_index* ix, Scratch& S, const HostBatch& hb, i
       }
       PIPE_TRY(hipEventRecord(P.in_done[b], P.s_h2d));
       PIPE_TRY(hipStreamWaitEvent(s_k, P.in_done[b], 0));
-      if (c >= 2) PIPE_TRY(hipStreamWaitEvent(s_k, P.out_done[b], 0));  // results of chunk c-2 have left d_out[b]
+      if (c >= depth) PIPE_TRY(hipStreamWaitEvent(s_k, P.out_done[b], 0));  // results of chunk c-3 have left d_out[b]
       int64_t* d_first = static_cast<int64_t*>(P.d_out[b]);
       int64_t* d_last = (last || as_keys) ? d_first + kPipeChunk : nullptr;
       if (dev_first) {
@@ -947,24 +965,33 @@ int count_host_pipelined(femto_amd_index* ix, Scratch& S, const HostBatch& hb, i
       PIPE_TRY(hipEventRecord(P.out_done[b], P.s_d2h));
       st[2] += since(t0);
     }
-    if (c >= 1 && !dev_first) {  // hand chunk c-1 back while chunk c is on its way
-      const int b = int((c - 1) & 1);
-      const int64_t a = (c - 1) * chunk, e = std::min(hb.npats, a + chunk), n = e - a;
+    if (c >= kLag && !dev_first) {  // hand chunk c-2 back while chunks c-1 and c are on their way
+      const int b = int((c - kLag) % depth);
+      const int64_t a = (c - kLag) * chunk, e = std::min(hb.npats, a + chunk), n = e - a;
       clk::time_point t0 = clk::now();
       PIPE_TRY(hipEventSynchronize(P.out_done[b]));
       st[3] += since(t0);
       t0 = clk::now();
       const char* hout = static_cast<const char*>(P.h_out[b]);
-      const int k = kind[b];      // still chunk c-1's: chunk c went into the other buffer
+      const int k = kind[b];      // still chunk c-2's: chunks c-1 and c went into the other buffers
       std::lock_guard<std::mutex> wl(ix->workers_mu);
       ix->workers->run([&](int t, int nt) {
         const int64_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
         if (k == 2) {          // 32-bit (first,last) pairs: widened into the caller's arrays (or the counts, femto.c:313-318)
           const int32_t* pr = reinterpret_cast<const int32_t*>(hout);
-          for (int64_t i = i0; i < i1; i++) {
-            const int64_t f = pr[2 * i], l = pr[2 * i + 1];
-            if (last) { first[a + i] = f; last[a + i] = l; }
-            else first[a + i] = l - f + 1;
+          // (streaming stores: the caller's arrays are written once and not read here -- no read-for-ownership of 160 MB)
+          if (nt_stores) {
+            for (int64_t i = i0; i < i1; i++) {
+              const int64_t f = pr[2 * i], l = pr[2 * i + 1];
+              if (last) { __builtin_nontemporal_store(f, first + a + i); __builtin_nontemporal_store(l, last + a + i); }
+              else __builtin_nontemporal_store(l - f + 1, first + a + i);
+            }
+          } else {
+            for (int64_t i = i0; i < i1; i++) {
+              const int64_t f = pr[2 * i], l = pr[2 * i + 1];
+              if (last) { first[a + i] = f; last[a + i] = l; }
+              else first[a + i] = l - f + 1;
+            }
           }
         } else if (!last && k == 3) {   // key chunk with 64-bit rows and no `last` array: counts from both
           const int64_t* pf = reinterpret_cast<const int64_t*>(hout);
@@ -1316,7 +1343,7 @@ void femto_amd_close(femto_amd_index_t* ix) {
       for (void* q : {static_cast<void*>(ix->d_image), static_cast<void*>(ix->d_segs), static_cast<void*>(ix->d_pack), static_cast<void*>(ix->d_pack_sa),
                       static_cast<void*>(ix->d_txt), static_cast<void*>(ix->d_isa8), static_cast<void*>(ix->d_p2_l1), static_cast<void*>(ix->d_p2_l2),
                       static_cast<void*>(ix->d_ktab2), static_cast<void*>(ix->d_ktab2_deep), static_cast<void*>(ix->d_sa_full), static_cast<void*>(ix->d_ind),
-                      static_cast<void*>(ix->d_ctx), static_cast<void*>(ix->d_ctx2), static_cast<void*>(ix->d_ru)})
+                      static_cast<void*>(ix->d_ctx), static_cast<void*>(ix->d_ctx2), static_cast<void*>(ix->d_ru), static_cast<void*>(ix->d_ru_stop)})
         big_free(ix, q);
       for (void* q : {static_cast<void*>(ix->d_nodes), static_cast<void*>(ix->d_buckets), static_cast<void*>(ix->d_seqs), static_cast<void*>(ix->d_occ_base),
                       static_cast<void*>(ix->d_leaf_code), static_cast<void*>(ix->d_C), static_cast<void*>(ix->d_cum), static_cast<void*>(ix->d_hint),
@@ -1517,8 +1544,7 @@ int femto_amd_locate_device(femto_amd_index_t* ix, int64_t npats, const int32_t*
   Plan plan{max_occs_each, d_noccs, d_out_starts, offsets_capacity, false, d_total};
   if ((rc = launch_count_plan(ix, S, npats, d_plen, d_pats, d_starts, d_first, d_last, &plan, stream))) return rc;
   if (plan.done) {   // direct pipeline: one stream-ordered chain, nothing returns to the host (d_total: plan_rows_kernel's last block)
-    if ((rc = launch_plan_rows(ix, S, npats, d_noccs, d_first, d_out_starts, d_offsets, offsets_capacity, stream))) return rc;
-    if (offsets_capacity > 0 && d_offsets && !ix->dev.sa_full && (rc = launch_walk_device_total(ix, S, d_offsets, offsets_capacity, stream))) return rc;
+    if ((rc = launch_plan_rows(ix, S, npats, d_noccs, d_first, d_out_starts, d_offsets, offsets_capacity, stream, nullptr, /*fuse_walk=*/true))) return rc;
   } else {           // other kernel families size the walk on the host
     int64_t tot[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(tot, S.d_total, sizeof tot, hipMemcpyDeviceToHost, stream));
@@ -1588,8 +1614,7 @@ int femto_amd_locate_keys_device(femto_amd_index_t* ix, int64_t npats, const uin
   }
   Plan plan{max_occs_each, d_noccs, d_out_starts, offsets_capacity, false, d_total};
   if ((rc = launch_count_keys(ix, npats, d_keys, r32, d_first, d_last, stream, &S, &plan))) return rc;
-  if ((rc = launch_plan_rows(ix, S, npats, d_noccs, d_first, d_out_starts, d_offsets, offsets_capacity, stream, r32))) return rc;
-  if (offsets_capacity > 0 && d_offsets && !ix->dev.sa_full && (rc = launch_walk_device_total(ix, S, d_offsets, offsets_capacity, stream))) return rc;
+  if ((rc = launch_plan_rows(ix, S, npats, d_noccs, d_first, d_out_starts, d_offsets, offsets_capacity, stream, r32, /*fuse_walk=*/true))) return rc;
   return FEMTO_AMD_OK;
   API_END
 }

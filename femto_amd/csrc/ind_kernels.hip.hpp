@@ -69,17 +69,28 @@ __device__ __forceinline__ void ind_search_step(const DevIndex& ix, int j, uint3
   trace_touch(ix, kTraceInd, base + lineL);
   if (haveF && lineF != lineL) trace_touch(ix, kTraceInd, base + lineF);
   // four independent 16-byte loads at most -- and only the ones that differ: the two ends of a narrow range share the
-  // line (its header) and often the block, and a load that a lane does not issue costs the address unit nothing
+  // line (its header) and often the block, and a load that a lane does not issue costs the address unit nothing.  ALL of
+  // them are issued before any is waited for: the first end's header / block registers are defined by their own loads only
+  // and the three possible ranks (same block, other block of the line, other line) are selected as numbers.  (Written as
+  // `hF = hL; if (other_line) hF = load;` the compiler waited for hL in order to copy it -- up to three dependent round trips
+  // per step instead of one; found in round 4 on the rank units, whose first version did the same.)
   const uint4* const lpL = reinterpret_cast<const uint4*>(ix.ind + (base + lineL) * 32);
-  const uint4 hL = lpL[0], vL = lpL[1 + (bL >> 7)];
   const bool other_line = haveF && lineF != lineL;
   const bool other_blk = haveF && (other_line || (bF >> 7) != (bL >> 7));
   const uint4* const lpF = reinterpret_cast<const uint4*>(ix.ind + (base + (other_line ? lineF : lineL)) * 32);
-  uint4 hF = hL, vF = vL;
-  if (other_line) hF = lpF[0];
-  if (other_blk) vF = lpF[1 + (bF >> 7)];
+  // (the compiler closes every conditional block that loads with a wait for everything in flight: so the unconditional loads
+  // go first and ONE conditional block issues whatever else the lane needs -- its header is loaded again when only the block
+  // differs: the same address as hL, an L1 hit, cheaper than a second round trip)
+  const uint4 hL = lpL[0], vL = lpL[1 + (bL >> 7)];
+  uint4 hF, vF;
+  if (other_blk) {
+    vF = lpF[1 + (bF >> 7)];
+    hF = lpF[0];
+  }
   const int64_t nl = ind_rank_of(hL, vL, bL);
-  const int64_t rf = ind_rank_of(hF, vF, bF);      // (first == 0: result unused)
+  int64_t rf = 0;                                   // (first == 0: unused)
+  if (other_blk) rf = ind_rank_of(hF, vF, bF);
+  else if (haveF) rf = ind_rank_of(hL, vL, bF);
   first = haveF ? rf : ix.p2_c[code];
   last = nl - 1;
 }

@@ -67,6 +67,7 @@ struct NfaBatchDev {
   uint8_t* arena;            // per workgroup: first[cap] i64 | last[cap] i64 | len[cap] i32 | cost[cap][cost_stride] u8
   int64_t arena_bytes;
   int32_t cap, cost_stride;
+  int32_t hash_size;          // heads of the pending-range hash: a power of two >= 2 * cap
   int32_t* next;             // work counter
   NfaResultDev* results;
   int64_t result_cap;
@@ -120,7 +121,20 @@ __global__ __launch_bounds__(64) void nfa_search_kernel(const DevIndex ix, const
   int64_t* const e_first = reinterpret_cast<int64_t*>(arena);
   int64_t* const e_last = e_first + cap;
   int32_t* const e_len = reinterpret_cast<int32_t*>(e_last + cap);
-  uint8_t* const e_cost = reinterpret_cast<uint8_t*>(e_len + cap);
+  // add_mapping's "is this range already pending?" (server.c:1558-1620; the reference keeps a hash on (first,last),
+  // queue_map.c): chained hashing over the stack -- heads[h] = the newest pending entry of bucket h, e_next[] the one before
+  // it.  The stack is LIFO, so the entry being popped is always the head of its chain: removal is one store, no tombstones.
+  // (Until round 4 every pop scanned the whole stack for every child: sp x children / 64 steps, minutes for a pattern like
+  // `.*` with approximate matching.)
+  int32_t* const e_next = e_len + cap;
+  int32_t* const heads = e_next + cap;
+  const uint32_t hmask = uint32_t(B.hash_size) - 1u;
+  uint8_t* const e_cost = reinterpret_cast<uint8_t*>(heads + B.hash_size);
+  auto hash_of = [&](int64_t f, int64_t l) -> uint32_t {
+    uint64_t x = uint64_t(f) * 0x9e3779b97f4a7c15ull ^ (uint64_t(l) + 0x7f4a7c15ull) * 0xff51afd7ed558ccdull;
+    x ^= x >> 29;
+    return uint32_t(x) & hmask;
+  };
   for (;;) {
     if (t == 0) s_q = atomicAdd(B.next, 1);
     __syncthreads();
@@ -137,10 +151,14 @@ __global__ __launch_bounds__(64) void nfa_search_kernel(const DevIndex ix, const
     for (int i = t; i < 262; i += 64) s_bychar[i] = B.bychar[Q.bychar_off + i];
     // the initial mapping: the whole index -> the start states (server.c:1786-1812)
     for (int i = t; i < N; i += 64) e_cost[i] = (flags[i] & 1u) ? 0 : kNfaDead;
+    for (int i = t; i < B.hash_size; i += 64) heads[i] = -1;
+    __syncthreads();
     if (t == 0) {
       e_first[0] = 0;
       e_last[0] = ix.total_length - 1;
       e_len[0] = 0;
+      e_next[0] = -1;
+      heads[hash_of(0, ix.total_length - 1)] = 0;
     }
     int sp = 1, status = 0;
     int64_t iters = 0;
@@ -151,6 +169,7 @@ __global__ __launch_bounds__(64) void nfa_search_kernel(const DevIndex ix, const
       sp--;
       const int64_t first = e_first[sp], last = e_last[sp];
       const int len = e_len[sp];
+      if (t == 0) heads[hash_of(first, last)] = e_next[sp];      // the top of the stack is the head of its chain
       // ---- a final state alive: a result, not extended (approx_is_final_state: the first such node's cost)
       int fin = INT_MAX;
       for (int i = t; i < N; i += 64) {
@@ -242,10 +261,11 @@ __global__ __launch_bounds__(64) void nfa_search_kernel(const DevIndex ix, const
       }
       __syncthreads();
       // ---- add_mapping's lookup: a pending entry with a child's range?  (children of one pop have disjoint ranges)
-      for (int s = t; s < sp; s += 64) {
-        const int64_t ef = e_first[s], el = e_last[s];
-        for (int k = 0; k < nchild; k++)
-          if (s_child_f[k] == ef && s_child_l[k] == el) s_child_found[k] = s;
+      for (int k = t; k < nchild; k += 64) {
+        const int64_t cf = s_child_f[k], cl = s_child_l[k];
+        if (cl < cf) continue;
+        for (int s = heads[hash_of(cf, cl)]; s >= 0; s = e_next[s])
+          if (e_first[s] == cf && e_last[s] == cl) { s_child_found[k] = s; break; }
       }
       // ---- substitutions: states after reading any character at subst_cost (server.c:2107-2110)
       if (approx) {
@@ -295,6 +315,9 @@ __global__ __launch_bounds__(64) void nfa_search_kernel(const DevIndex ix, const
             e_first[slot] = cf;
             e_last[slot] = cl;
             e_len[slot] = len + 1;
+            const uint32_t h = hash_of(cf, cl);
+            e_next[slot] = heads[h];
+            heads[h] = slot;
           } else if (len + 1 > e_len[slot]) {
             e_len[slot] = len + 1;                                              // the longer match is kept (server.c:1611-1619)
           }
@@ -464,7 +487,7 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   B.cost_stride = (max_nodes + 3) & ~3;
   // Stack capacity: most searches keep a few dozen pending entries; the ones that run out (status FULL) are run again
   // with a larger arena and fewer workgroups, up to regexp_stack_cap entries.
-  const size_t entry_bytes = 20 + size_t(B.cost_stride);
+  const size_t entry_bytes = 24 + size_t(B.cost_stride);      // first, last, match length, hash link, costs
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
   const size_t budget = std::min<size_t>(free_b / 2, size_t(16) << 30);
@@ -480,7 +503,10 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   int64_t cap = std::min<int64_t>(1024, ix->regexp_stack_cap);
   for (int pass = 0;; pass++) {
     int blocks = int(std::min<int64_t>(int64_t(todo.size()), int64_t(ix->num_cus) * 8));
-    const size_t per_block = (size_t(cap) * entry_bytes + 255) & ~size_t(255);
+    int64_t hsize = 64;
+    while (hsize < 2 * cap) hsize <<= 1;
+    const size_t per_block = (size_t(cap) * entry_bytes + size_t(hsize) * 4 + 255) & ~size_t(255);
+    B.hash_size = int32_t(hsize);
     if (size_t(blocks) * per_block > budget) blocks = int(std::max<size_t>(1, budget / per_block));
     if ((rc = d_arena.reserve(size_t(blocks) * per_block))) return rc;
     B.arena = d_arena.as<uint8_t>();

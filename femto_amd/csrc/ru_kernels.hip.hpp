@@ -14,7 +14,7 @@
 // the two ends of a narrow range are usually the SAME unit (one load per step).  Eight units share a 128-byte line
 // (704 rows).  (table characters) x rows / 5.5 bytes: 0.78 GB for a 2^30-row DNA index -- less than the packed lines,
 // which stay: an LF step (locate walk, text build) does not know its character and needs L[row] and the mark plane.
-// Patterns' stop characters (<= SEOF inside a pattern) keep stepping on the packed lines.  Same results as every other
+// Patterns' stop characters (<= SEOF inside a pattern) are answered from a sorted list of their rows.  Same results as every other
 // layout (the tests compare them all with the reference's goldens); measured in profiles/r04_*.
 #pragma once
 
@@ -39,6 +39,27 @@ __device__ __forceinline__ int64_t ru_rank_of(const uint4 v, uint32_t r) {
   return int64_t(lo & ((1ull << 40) - 1ull)) + int64_t(cnt);
 }
 
+// A STOP character inside a pattern (a character <= SEOF: one row per document holds it) has no unit vector; the rows
+// whose L is that character are listed in row order (ru_stop_rows), and C[c] + Occ(c,row) is C[c] + the number of listed
+// rows <= row: a binary search.  (Falling back to the packed lines here put their sixteen plane registers into the
+// count kernel: 70 instead of 43 VGPRs, seven instead of eight waves per SIMD for a case that hardly ever runs.)
+__device__ __forceinline__ void ru_stop_step(const DevIndex& ix, uint32_t code, int64_t& first, int64_t& last) {
+  const int64_t* const rows = ix.ru_stop_rows + ix.ru_stop_off[code];
+  const int64_t n = int64_t(ix.ru_stop_off[code + 1]) - int64_t(ix.ru_stop_off[code]);
+  auto count_le = [&](int64_t row) -> int64_t {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (rows[mid] <= row) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  const int64_t c = ix.pack_c[code];
+  const int64_t nl = c + count_le(last);
+  first = first == 0 ? c : c + count_le(first - 1);
+  last = nl - 1;
+}
+
 // one step of the backward search with dense code `code` (server.c:909-936): [first,last] -> rows preceded by code
 __device__ __forceinline__ void ru_search_step(const DevIndex& ix, int j, uint32_t code, int64_t& first, int64_t& last) {
   if (j == 0) {
@@ -47,7 +68,7 @@ __device__ __forceinline__ void ru_search_step(const DevIndex& ix, int j, uint32
     return;
   }
   if (code < uint32_t(ix.ru_nstop)) {    // a stop character inside a pattern: no unit vector, the packed lines answer
-    pack_search_step(ix, ix.pack, j, code, first, last);
+    ru_stop_step(ix, code, first, last);
     return;
   }
   const uint4* const ub = reinterpret_cast<const uint4*>(ix.ru);
@@ -57,16 +78,20 @@ __device__ __forceinline__ void ru_search_step(const DevIndex& ix, int j, uint32
   ru_split(last, &uL, &rL);
   const bool haveF = first != 0;
   if (haveF) ru_split(first - 1, &uF, &rF);
+  // Both ends of a narrow range usually share the unit: the second load is issued only by the lanes that need it -- and
+  // BEFORE the first one is waited for (the compiler closes a conditional block that loads with a wait for everything in
+  // flight: the unconditional load goes first).  (Written as `vF = vL; if (other) vF = up[uF];` the compiler waited for vL to copy
+  // it, so every wavefront with one such lane -- half of them at 64 lanes x 1/88 -- paid two dependent round trips per step,
+  // and split the second load in two: 124 M instead of 87 M memory requests per launch on 10 M sampled 20-mers.)
+  const bool other = haveF && uF != uL;
   const uint4 vL = up[uL];
+  uint4 vF;
+  if (other) vF = up[uF];
   trace_touch(ix, kTraceRu, uint64_t(up + uL - ub) >> 3);
-  uint4 vF = vL;
-  if (haveF && uF != uL) {       // both ends of a narrow range usually share the unit
-    vF = up[uF];
-    trace_touch(ix, kTraceRu, uint64_t(up + uF - ub) >> 3);
-  }
+  if (other) trace_touch(ix, kTraceRu, uint64_t(up + uF - ub) >> 3);
   const int64_t nl = ru_rank_of(vL, rL);
-  const int64_t nf = ru_rank_of(vF, rF);    // (first == 0: unused)
-  first = haveF ? nf : ix.pack_c[code];
+  const int64_t nfL = ru_rank_of(vL, rF), nfF = other ? ru_rank_of(vF, rF) : 0;
+  first = haveF ? (other ? nfF : nfL) : ix.pack_c[code];
   last = nl - 1;
 }
 
@@ -109,6 +134,26 @@ inline __global__ __launch_bounds__(256) void ru_build_kernel(const DevIndex ix,
     else before = pack_base(ix.pack, line, code) + int64_t(pack_match(P, code, r + 1));
     const uint64_t lo = (uint64_t(before) & ((1ull << 40) - 1ull)) | blo[k];
     ru[uint64_t(k) * uint64_t(stride) + uint64_t(u)] = make_uint4(uint32_t(lo), uint32_t(lo >> 32), uint32_t(bhi[k]), uint32_t(bhi[k] >> 32));
+  }
+}
+
+// the rows whose L is a stop character, per character in row order: one thread per packed line; scans[c * stride + line] =
+// rows with code c before the line (the exclusive scans build_pack made for the line counts)
+inline __global__ __launch_bounds__(256) void ru_stop_rows_kernel(const DevIndex ix, const int64_t nlines, const int64_t nrows,
+                                                            const uint8_t* __restrict__ sym, const int64_t* __restrict__ scans,
+                                                            const int64_t stride, const int nstop, int64_t* __restrict__ out) {
+  const int64_t line = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (line >= nlines) return;
+  int64_t at[3];
+  for (int c = 0; c < 3; c++) at[c] = c < nstop ? int64_t(ix.ru_stop_off[c]) + scans[int64_t(c) * stride + line] : 0;
+  for (int i = 0; i < kPackRows; i++) {
+    const int64_t row = line * kPackRows + i;
+    if (row >= nrows) break;
+    const int c = int(sym[row] & 0x7fu);
+    if (c < nstop) {
+      const int64_t slot = c == 0 ? at[0]++ : (c == 1 ? at[1]++ : at[2]++);
+      out[slot] = row;
+    }
   }
 }
 

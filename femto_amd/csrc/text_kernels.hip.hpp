@@ -56,7 +56,11 @@ struct PackPolicy {
 
 // small alphabets with the rank units resident (ru_kernels.hip.hpp): a search step is ONE 16-byte load per range end;
 // LF steps (locate walks) do not know their character and stay on the packed lines
+#ifndef FEMTO_AMD_EXP_RU_WAVES
+#define FEMTO_AMD_EXP_RU_WAVES 8       // (experiments: tools/ab_bench.sh builds a second library with another value)
+#endif
 struct RuPolicy : PackPolicy {
+  static constexpr int kDirectWaves = FEMTO_AMD_EXP_RU_WAVES;   // 43-64 VGPRs: eight waves per SIMD without spilling
   static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
     ru_search_step(ix, j, code, f, l);
   }

@@ -1260,6 +1260,26 @@ def test_bench_two_ranks_control_flow(tmp_path, gpu_ok, layout):
     assert line["config"]["parallelism"].startswith("striped index" if layout == "striped" else "replicated index")
 
 
+def test_bench_eight_ranks_dry_run(tmp_path, gpu_ok):
+    """The argument path of the driver's 8-GPU scaling run (`bench.py --gpus 8` under torch.distributed.run), dry: eight
+    ranks sharing this box's GPU, the gather through gloo, a 16 MiB text.  It must finish under the watchdogs and print ONE
+    headline line with eight `config.per_rank` entries (search / gather-stall times, payload bytes, world size seen) -- what
+    makes the first hardware run self-explaining.  Never a measurement."""
+    import json
+    root = os.path.join(os.path.dirname(__file__), "..")
+    env = dict(os.environ, FEMTO_AMD_BENCH_BACKEND="gloo", FEMTO_AMD_BENCH_DIR=str(tmp_path), MASTER_ADDR="127.0.0.1")
+    out = _torchrun(8, [os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--text-log2", "24",
+                        "--npats", "100000", "--cpu-sample", "2000"], env, cwd=root)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [json.loads(ln) for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    line = lines[-1]
+    assert "metric" in line and line["n_gpus"] == 8 and line["scaling"] == "weak" and line["value"] > 0
+    pr = line["config"]["per_rank"]
+    assert len(pr) == 8 and sorted(r["rank"] for r in pr) == list(range(8)) and all(r["world_size_seen"] == 8 for r in pr)
+    assert line["config"]["gathered_results_verified"] is True and line["cpu_baseline"]["bit_exact_vs_gpu"] is True
+    assert all("extra" in ln for ln in lines[:-1])          # whatever precedes the headline is an `extra` line
+
+
 @pytest.mark.parametrize("name", ["acgt48k", "eng2doc", "runs3doc"])
 def test_keys_device_path_equals_symbol_path(fixtures, gpu_ok, name):
     """femto_amd_pack_keys_device + femto_amd_locate_keys_device: patterns as 64-bit keys, ranges as int32 pairs -- the same

@@ -21,6 +21,35 @@ __device__ __forceinline__ uint64_t mix(uint64_t x) {
   return x;
 }
 
+// load flavours: 0 plain global_load_dwordx4, 1 nontemporal (nt), 2 sc0 sc1 (system-scope), 3 sc1, 4 sc0 sc1 nt
+template <int kFlavour>
+__device__ __forceinline__ uint4 load16(const uint4* p) {
+  if (kFlavour == 0) return *p;
+  uint4 v;
+  if (kFlavour == 1) asm volatile("global_load_dwordx4 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  else if (kFlavour == 2) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  else if (kFlavour == 3) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  else asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+template <int kFlavour>
+__global__ __launch_bounds__(256) void probe_flavour(const uint8_t* __restrict__ base, const uint64_t ngran, const int gran_shift, const int chain,
+                                                     const int64_t n, uint64_t* __restrict__ out) {
+  const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  uint64_t s = mix(uint64_t(q) * 0x9e3779b97f4a7c15ULL + 12345);
+  uint64_t acc = 0;
+  for (int c = 0; c < chain; c++) {
+    const uint64_t g = s % ngran;
+    const uint4 w = load16<kFlavour>(reinterpret_cast<const uint4*>(base + (g << gran_shift)));
+    const uint64_t v = w.x + w.y + w.z + w.w;
+    acc += v;
+    s = mix(s + v);
+  }
+  if (acc == 0x1234567) out[0] = acc;
+}
+
 template <int kPieces>
 __global__ __launch_bounds__(256) void probe(const uint8_t* __restrict__ base, const uint64_t ngran, const int gran_shift, const int chain,
                                              const int64_t n, uint64_t* __restrict__ out, const int spread) {
@@ -62,6 +91,36 @@ int main(int argc, char** argv) {
   printf("# W_GiB gran pieces chain spread ms Ggran/s TB/s_as_128B_lines\n");
   struct Cfg { int gran_shift, pieces, chain, spread; };
   const Cfg cfgs[] = {{7, 1, 4, 0}, {7, 8, 4, 0}, {7, 2, 4, 0}, {6, 1, 4, 0}, {6, 4, 4, 0}, {5, 1, 4, 0}, {5, 2, 4, 0}, {7, 1, 1, 0}, {7, 1, 8, 0}, {7, 1, 4, 4}, {8, 8, 4, 0}};
+  if (argc > 2) {   // load flavours at 1 GiB: does any cache policy make the memory-side request smaller than 128 bytes?
+    printf("# flavour gran chain ms Ggran/s   (0 plain, 1 nt, 2 sc0 sc1, 3 sc1, 4 sc0 sc1 nt)\n");
+    const size_t W = size_t(1) << 30;
+    for (int fl = 0; fl < 5; fl++)
+      for (int gs : {5, 6, 7}) {
+        const uint64_t ngran = W >> gs;
+        const int blocks = int((n + 255) / 256), chain = 4;
+        auto launch = [&]() {
+          switch (fl) {
+            case 0: hipLaunchKernelGGL(probe_flavour<0>, dim3(blocks), dim3(256), 0, 0, buf, ngran, gs, chain, n, d_out); break;
+            case 1: hipLaunchKernelGGL(probe_flavour<1>, dim3(blocks), dim3(256), 0, 0, buf, ngran, gs, chain, n, d_out); break;
+            case 2: hipLaunchKernelGGL(probe_flavour<2>, dim3(blocks), dim3(256), 0, 0, buf, ngran, gs, chain, n, d_out); break;
+            case 3: hipLaunchKernelGGL(probe_flavour<3>, dim3(blocks), dim3(256), 0, 0, buf, ngran, gs, chain, n, d_out); break;
+            default: hipLaunchKernelGGL(probe_flavour<4>, dim3(blocks), dim3(256), 0, 0, buf, ngran, gs, chain, n, d_out); break;
+          }
+        };
+        launch();
+        launch();
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < 5; r++) launch();
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= 5;
+        printf("%d %4d %d %8.3f %8.2f\n", fl, 1 << gs, chain, ms, double(n) * chain / (ms * 1e-3) / 1e9);
+        fflush(stdout);
+      }
+    return 0;
+  }
   for (double w : ws_gb) {
     const size_t W = size_t(w * (1ull << 30));
     if (W > max_bytes) continue;
