@@ -354,6 +354,33 @@ void comm_destroy(femto_amd_index* ix);     // api_multi.hip: the RCCL communica
 // femto_amd_open and its variants: part / nparts: a range-split part; stripe: the big arrays over these GPUs' HBM
 int open_impl(const char* index_path, int device, int part, int nparts, femto_amd_index_t** out, const std::vector<int>* stripe = nullptr,
               const femto_amd_options_t* opts = nullptr);
+// ---- the launch layer (femto_amd_api.hip, the translation unit that holds the query kernels) as the host-pointer paths of
+// api_host.hip see it
+// The locate plan that can ride along with a count: do_locate_query's clamp (src/main/server.c:4405-4415) and the
+// exclusive prefix sum of the row counts.  `done` is set when the count path produced noccs[], the block offsets in
+// S.bsums and S.d_total (the direct pipeline); otherwise the caller runs clamp_kernel + device_scan.
+struct Plan {
+  int max_occs;
+  int32_t* noccs;        // device, npats
+  int64_t* out_starts;   // device, npats + 1
+  int64_t capacity;      // rows the caller's offsets buffer holds (INT64_MAX when it is sized afterwards)
+  bool done;
+  int64_t* total_user = nullptr;   // device, 2 words: the caller's copy of S.d_total, written by plan_rows_kernel itself
+};
+// modes 3 / 4: the caller-order pipeline of direct_kernels.hip.hpp (with or without a level table)
+inline bool use_direct(const femto_amd_index* ix) { return ix->mode == 3 || ix->mode == 4; }
+int launch_count(femto_amd_index* ix, Scratch& S, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats, const int64_t* d_starts,
+                 int64_t* d_first, int64_t* d_last, hipStream_t stream, Plan* plan = nullptr);
+int launch_count_keys(femto_amd_index* ix, int64_t n, const uint64_t* d_keys, int2* out32, int64_t* d_first, int64_t* d_last, hipStream_t stream,
+                      Scratch* S = nullptr, Plan* plan = nullptr);
+int launch_count_plan(femto_amd_index* ix, Scratch& S, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats, const int64_t* d_starts,
+                      int64_t* d_first, int64_t* d_last, Plan* plan, hipStream_t stream);
+int launch_plan_rows(femto_amd_index* ix, Scratch& S, int64_t npats, const int32_t* d_noccs, const int64_t* d_first, int64_t* d_out_starts,
+                     int64_t* d_offsets, int64_t capacity, hipStream_t stream, const int2* d_first32 = nullptr, bool fuse_walk = false);
+int launch_walk_device_total(femto_amd_index* ix, Scratch& S, int64_t* d_offsets, int64_t capacity, hipStream_t stream);
+int launch_locate(femto_amd_index* ix, Scratch& S, int64_t npats, const int64_t* d_first, const int64_t* d_out_starts, int64_t total,
+                  int64_t* d_offsets, hipStream_t stream);
+int launch_clamp(int64_t npats, const int64_t* d_first, const int64_t* d_last, int max_occs, int32_t* d_noccs, int64_t* d_noccs64, hipStream_t stream);
 // exclusive prefix sum of n 64-bit counts on the device (out has n + 1 entries); femto_amd_api.hip
 int device_scan(DeviceBuffer* scan, int64_t n, const int64_t* in, int64_t* out, int level, hipStream_t stream);
 void block_image_range(const HostIndex& h, int64_t b0, int64_t b1, uint64_t* lo, uint64_t* hi);   // image bytes of data blocks [b0, b1)

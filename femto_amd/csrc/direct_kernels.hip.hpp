@@ -378,8 +378,7 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
             uint64_t ta, tb;
             __builtin_memcpy(&ta, tp - m - 7, 8);                                  // txt[p-8-m .. p-1-m]
             __builtin_memcpy(&tb, tp - m - 15, 8);                                 // txt[p-16-m .. p-9-m]
-            trace_touch(ix, kTraceTxt, uint64_t(tp - m - 15 - ix.txt) >> 7);
-            trace_touch(ix, kTraceTxt, uint64_t(tp - m - ix.txt) >> 7);
+            trace_touch_span(ix, kTraceTxt, uint64_t(tp - m - 15 - ix.txt), uint64_t(tp - m - ix.txt));
             const uint64_t xa = pa ^ __builtin_bswap64(ta), xb = pb ^ __builtin_bswap64(tb);
             if (xa | xb) {
               m += xa ? (__ffsll(static_cast<long long>(xa)) - 1) >> 3 : 8 + ((__ffsll(static_cast<long long>(xb)) - 1) >> 3);
@@ -397,8 +396,7 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
             const uint64_t pw = uint64_t(__builtin_amdgcn_alignbyte(wb, wa, sh)) | (uint64_t(__builtin_amdgcn_alignbyte(wc, wb, sh)) << 32);
             uint64_t tw;
             __builtin_memcpy(&tw, tp - m - 7, 8);                                  // txt[p-8-m .. p-1-m]
-            trace_touch(ix, kTraceTxt, uint64_t(tp - m - 7 - ix.txt) >> 7);
-            trace_touch(ix, kTraceTxt, uint64_t(tp - m - ix.txt) >> 7);
+            trace_touch_span(ix, kTraceTxt, uint64_t(tp - m - 7 - ix.txt), uint64_t(tp - m - ix.txt));
             const uint64_t x = pw ^ __builtin_bswap64(tw);                          // byte 0: symbol j+m against txt[p-1-m]
             if (x) {
               m += (__ffsll(static_cast<long long>(x)) - 1) >> 3;
@@ -416,8 +414,7 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
             const uint32_t pw = __builtin_amdgcn_alignbyte(hi, lo, sh);           // window bytes k .. k+3, k in the low byte
             uint32_t tw;
             __builtin_memcpy(&tw, tp - m - 3, 4);                                  // txt[p-4-m .. p-1-m]
-            trace_touch(ix, kTraceTxt, uint64_t(tp - m - 3 - ix.txt) >> 7);
-            trace_touch(ix, kTraceTxt, uint64_t(tp - m - ix.txt) >> 7);
+            trace_touch_span(ix, kTraceTxt, uint64_t(tp - m - 3 - ix.txt), uint64_t(tp - m - ix.txt));
             const uint32_t x = pw ^ __builtin_bswap32(tw);                          // byte 0: symbol j+m against txt[p-1-m]
             if (x) {
               m += (__ffs(int(x)) - 1) >> 3;

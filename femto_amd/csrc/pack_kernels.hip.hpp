@@ -49,6 +49,12 @@ __device__ __forceinline__ void mark_offset_store(const DevIndex& ix, int64_t* s
   else sa[i] = off;
 }
 
+// a load of bytes [b0, b1] of a traced array: one line, or two when it straddles a boundary
+__device__ __forceinline__ void trace_touch_span(const DevIndex& ix, int region, uint64_t b0, uint64_t b1) {
+  trace_touch(ix, region, b0 >> 7);
+  if ((b1 >> 7) != (b0 >> 7)) trace_touch(ix, region, b1 >> 7);
+}
+
 __device__ __forceinline__ void pack_split(int64_t row, uint64_t* line, uint32_t* r) {
   const uint32_t q = uint32_t(uint64_t(row) >> 5);  // rows < 2^37
   const uint32_t l = q / 5u;

@@ -1260,6 +1260,46 @@ def test_bench_two_ranks_control_flow(tmp_path, gpu_ok, layout):
     assert line["config"]["parallelism"].startswith("striped index" if layout == "striped" else "replicated index")
 
 
+@pytest.mark.parametrize("name", ["acgt48k", "eng2doc", "runs3doc", "chunks2doc"])
+def test_device_chain_walks_inside_the_row_expansion(fixtures, gpu_ok, name):
+    """femto_amd_locate_device / _locate_keys_device WITHOUT the resident suffix array: plan_rows_kernel<2> walks every located
+    row to its next derived mark inside the row expansion (no rows written, no walk kernel).  Same noccs / out_starts /
+    offsets as the reference's goldens for every mark density (femto's own, every 3rd, every 5th), 4- and 8-byte mark offsets,
+    a capacity that cuts the output short, and ranges longer than the per-lane limit (the empty pattern with a huge max_occs:
+    plan_big_rows_kernel walks those)."""
+    import torch
+    fx = fixtures(name)
+    plen, flat, starts = fx.patterns
+    n = len(plen)
+    dev = "cuda:0"
+    d_plen, d_flat, d_starts = torch.from_numpy(plen).to(dev), torch.from_numpy(flat.view(np.int16)).to(dev), torch.from_numpy(starts).to(dev)
+    for kw in (dict(dense_arrays=0), dict(dense_arrays=0, mark_every=0), dict(dense_arrays=0, mark_every=3, marks_32bit=0),
+               dict(dense_arrays=0, text=0, rank_units=0), dict(hbm_budget_bytes=600_000), dict(hbm_budget_bytes=150_000)):
+        ix = femto_amd.Index(fx.index, device=0, options=kw)
+        assert "hbm_budget_bytes" in kw or not ix.pack_info()["sa_full"]
+        if ix.rank_mode not in (3, 4) or ix.pack_info()["sa_full"]:      # (a budget that still pays for the dense arrays of a tiny fixture)
+            ix.close()
+            continue
+        for mo, g_noccs, g_offs in list(fx.locate_cases()) + [(1 << 20, None, None)]:
+            if g_noccs is None:      # a limit nothing reaches: every row of every pattern, the empty pattern's whole index
+                g_noccs, g_offs = ix.locate_flat(plen, flat, starts, mo)
+            tot = int(g_noccs.astype(np.int64).sum())
+            for cap in (tot + 8, max(1, tot // 2)):
+                f, l = torch.zeros(n, dtype=torch.int64, device=dev), torch.zeros(n, dtype=torch.int64, device=dev)
+                noccs = torch.zeros(n, dtype=torch.int32, device=dev)
+                ostarts = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+                offs = torch.full((cap,), -7, dtype=torch.int64, device=dev)
+                total = torch.zeros(2, dtype=torch.int64, device=dev)
+                for rep in range(2):
+                    ix.locate_device(n, d_plen.data_ptr(), d_flat.data_ptr(), d_starts.data_ptr(), mo, f.data_ptr(), l.data_ptr(), noccs.data_ptr(),
+                                     ostarts.data_ptr(), offs.data_ptr(), cap, total.data_ptr())
+                    torch.cuda.synchronize()
+                    assert total.cpu().tolist() == [tot, 1 if tot > cap else 0], (kw, mo, cap)
+                    assert np.array_equal(noccs.cpu().numpy(), g_noccs) and np.array_equal(f.cpu().numpy(), fx.gold["count_first"])
+                    assert np.array_equal(offs.cpu().numpy()[:min(cap, tot)], g_offs[:min(cap, tot)]), (kw, mo, cap, rep)
+        ix.close()
+
+
 def test_bench_eight_ranks_dry_run(tmp_path, gpu_ok):
     """The argument path of the driver's 8-GPU scaling run (`bench.py --gpus 8` under torch.distributed.run), dry: eight
     ranks sharing this box's GPU, the gather through gloo, a 16 MiB text.  It must finish under the watchdogs and print ONE

@@ -16,9 +16,11 @@ KEEP = ("count_direct_kernel", "count_tail_kernel", "plan_rows_kernel", "plan_su
 def main():
     for tag in sys.argv[1:]:
         src = os.path.join(ROOT, "gpurun_out", tag)
-        line = open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1]
-        json.loads(line)
-        open(os.path.join(ROOT, "profiles", f"{tag}_bench.json"), "w").write(line + "\n")
+        lines = [ln for ln in open(os.path.join(src, "bench.json")).read().strip().splitlines() if ln.startswith("{")]
+        line = lines[-1]      # the headline; the `extra` lines before it are kept too (one JSON object per line)
+        for ln in lines:
+            json.loads(ln)
+        open(os.path.join(ROOT, "profiles", f"{tag}_bench.json"), "w").write("\n".join(lines) + "\n")
         rec = json.loads(line)
         sh = ((rec.get("roofline") or {}).get("traffic_source") or {}).get("source_hash") or bench.source_hash()
         out = [f"# {tag}: tools/profile_round.sh (rocprofv3 --kernel-trace --stats of `python bench.py ...`, then separate --pmc passes)",
