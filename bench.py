@@ -946,15 +946,18 @@ def main():
         hl_ = np.zeros(npats, dtype=np.int64) + 1
         hstarts = np.ascontiguousarray(batch.starts, dtype=np.int64)
         L = femto_amd.lib()
-        hs = None
-        for _ in range(2):                             # first call allocates the pinned staging buffers
+        hts = []
+        for _ in range(6):                             # first call allocates the pinned staging buffers
             t0 = time.perf_counter()
             rc = L.femto_amd_count_flat(ix.handle, npats, plen.ctypes.data, flat.ctypes.data, hstarts.ctypes.data,
                                         hf_.ctypes.data, hl_.ctypes.data)
-            hs = time.perf_counter() - t0
+            hts.append(time.perf_counter() - t0)
             assert rc == 0
-        extra["host_pointer_count"] = {"what": "femto_amd_count_flat on the same 10M-pattern batch, pageable host arrays in and out (staging threads + PCIe + kernels, pipelined in 1M-pattern stages)",
-                                       "value": npats / hs, "unit": "patterns/s", "ms": 1e3 * hs,
+        hs = min(hts[1:])
+        extra["host_pointer_count"] = {"what": "femto_amd_count_flat on the same 10M-pattern batch, pageable host arrays in and out (staging threads + PCIe + kernels, pipelined in "
+                                               "1M-pattern stages, three in flight); value = fastest of 5 calls after a warm-up (single calls run 2-3x longer when the 128 spinning "
+                                               "staging threads meet the container's CPU quota: mean_ms)",
+                                       "value": npats / hs, "unit": "patterns/s", "ms": 1e3 * hs, "mean_ms": 1e3 * sum(hts[1:]) / len(hts[1:]),
                                        "equal_to_device_path": bool(np.array_equal(hf_, first) and np.array_equal(hl_, last))}
         del hf_, hl_
         extra.update(shim_extras(args, index_path, plen, flat, first, last, located_rows))
