@@ -197,15 +197,7 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
   // (Lanes take the workgroup's patterns in the caller's order.  Taking them in order of LENGTH -- a counting sort in LDS, so
   // that a wavefront's lanes run chains of similar length -- was tried on the mixed-length sigma~96 batch: 1.70 instead of
   // 1.64 ms; neighbouring lanes then no longer read neighbouring patterns.)
-  // PERSISTENT workgroups: the grid is what the GPU holds at once (launch_count_direct: CUs x 8) and every workgroup takes
-  // the 256-pattern tiles tile, tile + gridDim.x, ... -- the alphabet map above is built once per workgroup instead of once
-  // per tile, and a tile costs no dispatch (39 063 tiles per 10 M patterns; a grid of one workgroup per tile works too: the
-  // traced twins launch it that way).
-  const int64_t ntiles = (npats + int64_t(blockDim.x) - 1) / int64_t(blockDim.x);
-  for (int64_t tile = int64_t(blockIdx.x); tile < ntiles; tile += int64_t(gridDim.x)) {
-  uint32_t tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));      // (opaque per tile: nothing that depends on the lane is hoisted out of the loop into registers)
-  const int64_t q = tile * blockDim.x + tid;
+  const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   int64_t nocc = 0;
   if (q < npats) {
     const int len = plen[q];
@@ -231,7 +223,7 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
     auto phase = [&]() -> int { return int(((reinterpret_cast<uintptr_t>(pat) >> 1) + uintptr_t(uint32_t(len))) & 7u); };   // (recomputed: one register less across the search loops)
     int w0 = -(1 << 30);         // no window yet
     uint8_t* const win = reinterpret_cast<uint8_t*>(s_win);
-    auto waddr = [&](uint32_t k) -> uint32_t { return (((k >> 2) * 256u + tid) << 2) + (k & 3u); };
+    auto waddr = [&](uint32_t k) -> uint32_t { return (((k >> 2) * 256u + threadIdx.x) << 2) + (k & 3u); };
     auto tr4 = [&](const uint32_t a, const uint32_t b) -> uint32_t {     // symbols (a lo, a hi, b lo, b hi) at rising addresses = falling j
       auto T = [&](uint32_t sym) -> uint32_t { return s_byte[sym < 263u ? sym : 263u]; };
       return T(b >> 16) | (T(b & 0xffffu) << 8) | (T(a >> 16) << 16) | (T(a & 0xffffu) << 24);
@@ -252,8 +244,8 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
 #pragma unroll
         for (int i = 0; i < kB; i++)
           if (e0 + i <= emax) {
-            s_win[uint32_t(2 * (e0 + i)) * 256u + tid] = tr4(v[i].z, v[i].w);
-            s_win[uint32_t(2 * (e0 + i) + 1) * 256u + tid] = tr4(v[i].x, v[i].y);
+            s_win[uint32_t(2 * (e0 + i)) * 256u + threadIdx.x] = tr4(v[i].z, v[i].w);
+            s_win[uint32_t(2 * (e0 + i) + 1) * 256u + threadIdx.x] = tr4(v[i].x, v[i].y);
           }
       }
     };
@@ -378,9 +370,9 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
             const int jj = j + m;
             if (jj < w0 || jj + 16 > w0 + kWin) refill(jj);
             const uint32_t k = uint32_t(jj - w0), d = k >> 2, sh = k & 3u;
-            const uint32_t wa = s_win[d * 256u + tid], wb = s_win[(d + 1u) * 256u + tid];
-            const uint32_t wc = s_win[(d + 2u) * 256u + tid], wd = s_win[(d + 3u) * 256u + tid];
-            const uint32_t we = sh ? s_win[(d + 4u) * 256u + tid] : 0u;
+            const uint32_t wa = s_win[d * 256u + threadIdx.x], wb = s_win[(d + 1u) * 256u + threadIdx.x];
+            const uint32_t wc = s_win[(d + 2u) * 256u + threadIdx.x], wd = s_win[(d + 3u) * 256u + threadIdx.x];
+            const uint32_t we = sh ? s_win[(d + 4u) * 256u + threadIdx.x] : 0u;
             const uint64_t pa = uint64_t(__builtin_amdgcn_alignbyte(wb, wa, sh)) | (uint64_t(__builtin_amdgcn_alignbyte(wc, wb, sh)) << 32);
             const uint64_t pb = uint64_t(__builtin_amdgcn_alignbyte(wd, wc, sh)) | (uint64_t(__builtin_amdgcn_alignbyte(we, wd, sh)) << 32);
             uint64_t ta, tb;
@@ -399,8 +391,8 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
             const int jj = j + m;
             if (jj < w0 || jj + 8 > w0 + kWin) refill(jj);
             const uint32_t k = uint32_t(jj - w0), d = k >> 2, sh = k & 3u;
-            const uint32_t wa = s_win[d * 256u + tid], wb = s_win[(d + 1u) * 256u + tid];
-            const uint32_t wc = sh ? s_win[(d + 2u) * 256u + tid] : 0u;
+            const uint32_t wa = s_win[d * 256u + threadIdx.x], wb = s_win[(d + 1u) * 256u + threadIdx.x];
+            const uint32_t wc = sh ? s_win[(d + 2u) * 256u + threadIdx.x] : 0u;
             const uint64_t pw = uint64_t(__builtin_amdgcn_alignbyte(wb, wa, sh)) | (uint64_t(__builtin_amdgcn_alignbyte(wc, wb, sh)) << 32);
             uint64_t tw;
             __builtin_memcpy(&tw, tp - m - 7, 8);                                  // txt[p-8-m .. p-1-m]
@@ -417,8 +409,8 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
             const int jj = j + m;
             if (jj < w0 || jj + 4 > w0 + kWin) refill(jj);
             const uint32_t k = uint32_t(jj - w0), d = k >> 2, sh = k & 3u;
-            const uint32_t lo = s_win[d * 256u + tid];
-            const uint32_t hi = sh ? s_win[(d + 1u) * 256u + tid] : 0u;
+            const uint32_t lo = s_win[d * 256u + threadIdx.x];
+            const uint32_t hi = sh ? s_win[(d + 1u) * 256u + threadIdx.x] : 0u;
             const uint32_t pw = __builtin_amdgcn_alignbyte(hi, lo, sh);           // window bytes k .. k+3, k in the low byte
             uint32_t tw;
             __builtin_memcpy(&tw, tp - m - 3, 4);                                  // txt[p-4-m .. p-1-m]
@@ -477,16 +469,14 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
   }
   if (kPlan) {
     const int64_t s = block_sum_256(nocc, s_w);
-    if (tid == 0) {
-      ps.sums[tile] = s;
+    if (threadIdx.x == 0) {
+      ps.sums[blockIdx.x] = s;
       if (ps.acc && s) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(&ps.super[tile >> 6]), static_cast<unsigned long long>(s));
-        atomicAdd(reinterpret_cast<unsigned long long*>(&ps.super2[tile >> 12]), static_cast<unsigned long long>(s));
+        atomicAdd(reinterpret_cast<unsigned long long*>(&ps.super[blockIdx.x >> 6]), static_cast<unsigned long long>(s));
+        atomicAdd(reinterpret_cast<unsigned long long*>(&ps.super2[blockIdx.x >> 12]), static_cast<unsigned long long>(s));
       }
-      if (tile == 0 && big_flag) *big_flag = 0;      // plan_rows_kernel's "long ranges" flag
+      if (blockIdx.x == 0 && big_flag) *big_flag = 0;      // plan_rows_kernel's "long ranges" flag
     }
-    __syncthreads();      // (s_w is read by everybody above and written again by the next tile's sum)
-  }
   }
 }
 

@@ -390,10 +390,7 @@ int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const in
   int64_t* bsums = ps.sums;
   hipEvent_t e0, e1;
   timer_begin(ix, ix->t_count, stream, &e0, &e1);
-  // persistent workgroups (count_direct_kernel): as many as the GPU holds at once -- 8 waves per SIMD = 8 workgroups of 4 waves per CU.
-  // FEMTO_AMD_PERSISTENT=0: one workgroup per 256-pattern tile, as until round 4 (A/B runs)
-  static const bool persistent = [] { const char* e = getenv("FEMTO_AMD_PERSISTENT"); return !e || atoi(e) != 0; }();
-  const dim3 grid{uint32_t(persistent ? std::min<int64_t>(nblocks, int64_t(ix->num_cus) * 8) : nblocks)}, block{uint32_t(kBlockThreads)};
+  const dim3 grid{uint32_t(nblocks)}, block{uint32_t(kBlockThreads)};
   const int mo = plan ? plan->max_occs : 0;
   int32_t* noccs = plan ? plan->noccs : nullptr;
   const bool dense = inline_tail;
