@@ -174,22 +174,19 @@ def roofline_block(ix, direct, b, npats, plen, max_occs, cnt_ms, loc_ms, cnt_n):
     read_bytes = 128 * sum(reads.values()) + (stream_count if dominant_is_count else stream_locate)
     line_reads = {"bytes": read_bytes, "GBs": read_bytes / (k_ms * 1e-3) / 1e9, "frac": read_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                   "lines_read": reads, "lines_read_per_pattern": sum(reads.values()) / npats,
-                  "model": "128 B x every line READ by the traced kernels (no credit for lines shared between patterns) + streamed arrays"}
+                  "model": "128 B x every line READ (no credit for lines two patterns share) + streamed arrays"}
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "line_reads": line_reads,
             "traffic": None, "traffic_source": None, "traffic_GBs": None, "traffic_over_compulsory": None,
             "useful": {"bytes": useful, "GBs": useful / (k_ms * 1e-3) / 1e9, "frac": useful / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                       "model": "compulsory bytes with every level-table / context-table / suffix-array / inverse-suffix-array / per-character rank line counted as the "
-                                "entry it is loaded for (8 / 16 / 8 / 8 / 32 bytes) instead of 128: line-granular fetches are what the memory moves, "
-                                "entry bytes are what the search needs"},
+                       "model": "as frac, with table / array / rank lines counted as the entry used of them (8-32 B) instead of 128 B"},
             "kernel": kname, "kernel_ms": k_ms, "launches_timed": cnt_n, "count_kernel_ms": cnt_ms, "locate_kernel_ms": loc_ms,
             "compulsory_bytes_per_launch": comp,
             "compulsory": {"count": {"distinct_lines": cl, "streamed_bytes": stream_count, "bytes": comp_count},
                            "locate": {"distinct_lines": ll, "streamed_bytes": stream_locate, "bytes": comp_locate, "rows": trows}},
             "per_pattern_bytes": comp / npats,
-            "bytes_model": "compulsory bytes: 128 B x distinct lines loaded from each derived array (GPU line trace of the same "
-                           "batch, femto_amd_trace_lines) + arrays streamed once (count: 12 B/pattern + 2 B/symbol in, 20 B/pattern "
-                           "out; locate: 16 B/row); kernel time from HIP events on the launch stream"}, kname, k_ms, comp, comp_count + comp_locate
+            "bytes_model": "128 B x DISTINCT lines loaded (GPU line trace of the same batch) + arrays streamed once; kernel time from HIP events "
+                           "on the launch stream; DESIGN.md section 4"}, kname, k_ms, comp, comp_count + comp_locate
 
 
 def add_traffic(roof, traffic, traffic_src, k_ms, comp):
@@ -428,8 +425,7 @@ def reference_format_block(cd, csub, npats, k_ms):
     b = (cd["n_rank"] * (12 + 64) + cd["s_bytes"] + cd["n_occ"] * 20 + cd["n_mark"] * 8) / csub
     gbs = b * npats / (k_ms * 1e-3) / 1e9 if k_ms else None
     return {"bytes_per_pattern": b, "GBs": gbs, "x_peak": (gbs / HBM_PEAK_GBS) if gbs else None,
-            "formula": "N_rank*(12+64) + S_bytes + N_occ*20 + N_mark*8 (SURVEY 8d), counters of oracle/femto_oracle.c on "
-                       f"{csub} patterns of the batch; bytes x patterns / kernel ms"}
+            "formula": f"SURVEY 8(d): N_rank*(12+64) + S_bytes + N_occ*20 + N_mark*8, oracle counters on {csub} patterns"}
 
 
 def budget_extra(args, torch, femto_amd, tg, dev, local_rank, index_path, text_path, batch, plen, ref_results, stream, n_text):
@@ -991,9 +987,7 @@ def main():
         ref_work = {"sample": csub, "occ_per_pattern": cd["n_occ"] / csub, "bseq_rank_per_pattern": cd["n_rank"] / csub,
                     "lf_steps_per_pattern": cd["n_lf"] / csub, "mark_reads_per_pattern": cd["n_mark"] / csub,
                     "occ_per_s": value * cd["n_occ"] / csub,
-                    "what": "Occ / bseq_rank / LF-step / mark-read counts of femto's own algorithm (parallel_locate: search + locate walk) for this batch, from "
-                            "oracle/femto_oracle.c's counters; occ_per_s = value x occ_per_pattern -- the reference-equivalent Occ rate, "
-                            "not the number of lines this engine reads (see roofline)"}
+                    "what": "operation counts of femto's own algorithm for this batch (oracle counters); occ_per_s = value x occ_per_pattern"}
         if po.have_ref():
             rsample = min(sample, args.ref_sample)       # ~5 s per pass at the reference's ~19 k patterns/s
             with tempfile.TemporaryDirectory() as td:
@@ -1062,8 +1056,7 @@ def main():
         roof["whole_step_GBs"] = step_bytes / (1e-3 * 1e3 * elapsed / args.steps) / 1e9   # cross-check: compulsory bytes of the step / ms_per_step < peak
         if cd_count:
             roof["reference_format"] = reference_format_block(cd_count, csub, npats, cnt_ms)
-            roof["reference_format"]["note"] = ("what femto's own algorithm would move on femto's own format for this batch's count phase; x_peak > 1 says the "
-                                                "timed kernel does not do that work: it reads the lines / units / table entries counted in `compulsory` and `line_reads`")
+            roof["reference_format"]["note"] = "femto's own algorithm on femto's own format; x_peak > 1: the timed kernel does not do that work (see compulsory / line_reads)"
     if want_extra:
         res_ref = (first, last, g_noccs, g_ost, g_offs)
         extra["budget4x"] = budget_extra(args, torch, femto_amd, tg, dev, local_rank, index_path, text_path, batch, plen, res_ref, stream, n_text)

@@ -1316,7 +1316,7 @@ int femto_amd_structures(const femto_amd_index_t* ix, int64_t* out, int n) {
   if (!ix->children.empty()) return femto_amd_structures(ix->children[0], out, n);
   int64_t v[16] = {0};
   v[0] = int64_t(ix->host.image.size());
-  v[1] = ix->pack_bytes - ix->marks_bytes;
+  v[1] = ix->dev.pack ? ix->pack_bytes - ix->marks_bytes : 0;      // (byte alphabets: the marks belong to the two-level lines)
   v[2] = ix->marks_bytes;
   v[3] = ix->ru_bytes;
   v[4] = ix->ktab2_bytes;

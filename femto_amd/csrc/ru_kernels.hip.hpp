@@ -152,7 +152,7 @@ inline __global__ __launch_bounds__(256) void ru_stop_rows_kernel(const DevIndex
     const int c = int(sym[row] & 0x7fu);
     if (c < nstop) {
       const int64_t slot = c == 0 ? at[0]++ : (c == 1 ? at[1]++ : at[2]++);
-      out[slot] = row;
+      if (slot >= int64_t(ix.ru_stop_off[c]) && slot < int64_t(ix.ru_stop_off[c + 1])) out[slot] = row;   // (a damaged index: L disagrees with C)
     }
   }
 }
