@@ -243,6 +243,7 @@ inline __global__ __launch_bounds__(256) void ctx2_build_kernel(const DevIndex i
       if (atomicCAS(slots + 4 * s, 0ull, static_cast<unsigned long long>(g.lo)) == 0ull) {
         slots[4 * s + 1] = g.hi;
         slots[4 * s + 2] = uint64_t(row) & kCtxFirstMask;
+        slots[4 * s + 3] = uint64_t(ix.sa_full[row]);      // the text position of the range's FIRST row (ctx2_lookup's sa_first)
         return;
       }
     }
@@ -270,7 +271,9 @@ inline __global__ __launch_bounds__(256) void ctx2_build_kernel(const DevIndex i
 // wavefront's 64 lanes 6.8 -- probing slot by slot, every wavefront waited for seven dependent reads; bucket by bucket it
 // waits for two.
 constexpr int kCtx2Gang = 4;
-__device__ __forceinline__ int ctx2_lookup(const DevIndex& ix, const CtxKey2& key, int64_t& first, int64_t& last) {
+// *sa_first = SA[first], stored in the slot's fourth word: a pattern whose sixteen last symbols occur ONCE -- most of a sampled
+// batch on a large text -- goes from this line straight to the text, without the suffix-array read in between.
+__device__ __forceinline__ int ctx2_lookup(const DevIndex& ix, const CtxKey2& key, int64_t& first, int64_t& last, int64_t* sa_first = nullptr) {
   const uint64_t nslots = ix.ctx2_slots;
   uint64_t s = ctx_hash2(key, nslots);
   for (uint64_t probes = 0; probes < nslots; probes += kCtx2Gang) {
@@ -282,7 +285,9 @@ __device__ __forceinline__ int ctx2_lookup(const DevIndex& ix, const CtxKey2& ke
     for (int i = 0; i < kCtx2Gang; i++) {
       if (e[i].x == 0) return 0;
       if (e[i].x == key.lo && e[i].y == key.hi) {
-        const uint64_t v = ix.ctx2[4 * (s + uint64_t(i)) + 2];
+        const ulonglong2 vv = reinterpret_cast<const ulonglong2*>(ix.ctx2)[2 * (s + uint64_t(i)) + 1];
+        const uint64_t v = vv.x;
+        if (sa_first) *sa_first = int64_t(vv.y);
         const uint64_t rows = v >> 40;
         if (rows == kCtxBig) return -1;
         first = int64_t(v & kCtxFirstMask);

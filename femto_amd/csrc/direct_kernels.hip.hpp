@@ -262,6 +262,7 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
     };
     auto alpha = [&](int j) -> uint32_t { return pat[len - 1 - j]; };     // the symbol itself (0xFF cases only)
     int64_t first = 0, last = ix.total_length - 1;
+    int64_t sa_hint = -1;       // SA[first] as the wide context table delivered it; forgotten with the first search step
     int j = 0;
     if (ix.ctx && len >= ix.ctx_syms) {     // byte alphabets: the last H symbols as one hashed read (ctx_kernels.hip.hpp)
       const int H1 = ix.ctx_syms, H2 = (ix.ctx2 && len >= ix.ctx2_syms) ? ix.ctx2_syms : 0;
@@ -280,8 +281,9 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
       }
       // A miss means the range dies within these symbols; the shorter table / the level table / the steps below then find
       // where, because the reference's (first, last) of an empty range are those of the step that emptied it.
-      if (H2 && okn == H2 && ctx2_lookup(ix, key2, first, last) == 1) j = H2;
+      if (H2 && okn == H2 && ctx2_lookup(ix, key2, first, last, &sa_hint) == 1) j = H2;
       else if (okn >= H1 && ctx_lookup(ix, key1, first, last) == 1) j = H1;
+      if (j != H2 || H2 == 0) sa_hint = -1;
     }
     if (j == 0 && ix.ktab2) {
       const int kmax = len < ix.kt2_syms ? len : ix.kt2_syms;
@@ -346,6 +348,7 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
           }
         }
         P::search_step(ix, j, code, first, last);
+        sa_hint = -1;
         if (first > last) { finished = true; break; }
         tried = false;
         ones = first == last ? ones + 1 : 0;
@@ -357,8 +360,11 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
       int best = 0;                      // most symbols any row of the range matches; [qmin, qmax] = the rows of those that do
       int64_t qmin = 0, qmax = -1;
       for (int64_t row = first; row <= last; row++) {
-        const int64_t p = ix.sa_full[row];
-        trace_touch(ix, kTraceSa, uint64_t(row) >> 4);
+        int64_t p = sa_hint;
+        if (!(kDense && row == first && sa_hint >= 0)) {
+          p = ix.sa_full[row];
+          trace_touch(ix, kTraceSa, uint64_t(row) >> 4);
+        }
         if (p <= 0 || p >= ix.total_length) continue;   // (p = -1: the row could not be located, see text_isa_build_kernel)
         const int lim = p < int64_t(remaining) ? int(p) : remaining;
         const uint8_t* const tp = ix.txt + (p - 1);       // txt[p - 1 - m] = tp[-m]
@@ -443,6 +449,7 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
           }
         }
       }
+      sa_hint = -1;        // (it described the range this tail started from)
       if (best > 0) {      // the rows whose text goes on with `best` more pattern symbols: one contiguous range again
         first = qmin;
         last = qmax;
