@@ -142,6 +142,23 @@ def committed_traffic(args, kname, npats):
     return None, None
 
 
+def cpu_quota():
+    """CPUs the container may use on average (cgroup v2 cpu.max / v1 cfs quota), or None: the GPU box shows 256 hardware threads
+    but runs this process under a quota of 16 -- host-side stages that use 128 threads are bursts, and back-to-back bursts are
+    throttled (the 40-75 ms outliers of the host-pointer path)"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:      # noqa: BLE001
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:      # noqa: BLE001
+        return None
+
+
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
@@ -952,8 +969,9 @@ def main():
         hs = min(hts[1:])
         extra["host_pointer_count"] = {"what": "femto_amd_count_flat on the same 10M-pattern batch, pageable host arrays in and out (staging threads + PCIe + kernels, pipelined in "
                                                "1M-pattern stages, three in flight); value = fastest of 5 calls after a warm-up (single calls run 2-3x longer when the 128 spinning "
-                                               "staging threads meet the container's CPU quota: mean_ms)",
+                                               "staging threads exhaust the container's CPU quota -- cgroup_cpu_quota CPUs on average: mean_ms)",
                                        "value": npats / hs, "unit": "patterns/s", "ms": 1e3 * hs, "mean_ms": 1e3 * sum(hts[1:]) / len(hts[1:]),
+                                       "host_hardware_threads": os.cpu_count(), "cgroup_cpu_quota": cpu_quota(),
                                        "equal_to_device_path": bool(np.array_equal(hf_, first) and np.array_equal(hl_, last))}
         del hf_, hl_
         extra.update(shim_extras(args, index_path, plen, flat, first, last, located_rows))
@@ -1133,6 +1151,7 @@ def main():
             extra["cfg3_text96_count_locate"] = {"error": repr(ex)}
 
     if cpu:
+        cpu["cgroup_cpu_quota"] = cpu_quota()       # CPUs this container may use on average (None: no quota); `cores` above is what was used
         cpu["gpu_vs_cpu"] = value / cpu["value"]     # a baseline, not a quality measure: the roofline fraction is
     wl = {"acgt": f"T_acgt(2^{args.text_log2}) femto index (default params), {npats} P_rand 20-mers per GPU, count()+locate(max_occs={args.max_occs})",
           "acgt_hit": f"T_acgt(2^{args.text_log2}) femto index (default params), {npats} P_hit 20-mers per GPU, count()+locate(max_occs={args.max_occs})",

@@ -58,6 +58,25 @@ constexpr int64_t kPipeChunk = int64_t(1) << 21;      // patterns per chunk
 constexpr int64_t kPipeSymCap = int64_t(1) << 26;     // symbols per chunk (128 MB)
 constexpr int64_t kPipeMin = int64_t(1) << 18;        // smaller batches take the plain path
 
+// CPUs the process may use on average: cgroup v2 cpu.max ("<quota> <period>" or "max ..."), v1 cpu.cfs_quota_us / _period_us; 0: none
+double cgroup_cpu_quota() {
+  double q = 0, per = 0;
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char buf[64] = {0};
+    const int n = fscanf(f, "%63s %lf", buf, &per);
+    fclose(f);
+    if (n == 2 && strcmp(buf, "max") != 0 && per > 0) return atof(buf) / per;
+    return 0;
+  }
+  FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r");
+  FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+  if (fq && fp && fscanf(fq, "%lf", &q) == 1 && fscanf(fp, "%lf", &per) == 1 && q > 0 && per > 0) q = q / per;
+  else q = 0;
+  if (fq) fclose(fq);
+  if (fp) fclose(fp);
+  return q;
+}
+
 size_t pipe_in_bytes() { return size_t(kPipeChunk) * 12 + size_t(kPipeSymCap) * 2 + 64; }
 
 int pipe_init(femto_amd_index* ix, Scratch& S) {
@@ -68,6 +87,11 @@ int pipe_init(femto_amd_index* ix, Scratch& S) {
       // look-ups, and the staging threads -- not PCIe, not the GPU -- bound this path (measured on the GPU box's
       // 256-thread host, 10 M 20-mers: 16 threads 12.7 ms, 32 9.2 ms, 64 6-9 ms, 128 5.6 ms)
       int nthreads = std::max(4, int(std::thread::hardware_concurrency()) / 2);
+      // ... unless the process runs under a CPU quota (cgroup cpu.max): threads beyond about twice the quota only burn it, and a
+      // process that has spent its quota stands still until the period ends.  Measured on the GPU box (256 hardware threads,
+      // quota 16 CPUs, 20 calls of 10 M 20-mers back to back): 128 threads 4.1 ms best / 38 ms mean (calls of 50-100 ms),
+      // 64 threads 4.7 / 16.4, 32 threads 4.0 / 6.6, 16 threads 6.9 / 7.4 -- packing is memory-bound, 32 threads pack as fast as 128.
+      if (const double quota = cgroup_cpu_quota(); quota > 0) nthreads = std::min(nthreads, std::max(8, int(2.0 * quota + 0.5)));
       nthreads = int(knob(ix->opt.host_threads, "FEMTO_AMD_HOST_THREADS", nthreads));
       nthreads = std::max(1, std::min(nthreads, 128));
       ix->workers.reset(new WorkerPool(nthreads));

@@ -361,7 +361,7 @@ typedef struct femto_amd_options {
   int64_t context2_bytes;        /* cap of the wide table; auto: a quarter of the free HBM                [FEMTO_AMD_CTX2_MB] */
   int32_t tail_min, tail_ones, tail_rows, tail_row_cost;   /* thresholds of the text tail (direct_kernels.hip.hpp) [FEMTO_AMD_TAIL_*] */
   int32_t sort_queries;          /* 0: mode 1 does not order large batches by suffix                      [FEMTO_AMD_SORT] */
-  int32_t host_threads;          /* staging threads of host-pointer batches; auto: half the hardware threads, <= 128 [.._HOST_THREADS] */
+  int32_t host_threads;          /* staging threads of host-pointer batches; auto: half the hardware threads, <= 128, <= twice a cgroup CPU quota [.._HOST_THREADS] */
   int32_t host_pipeline;         /* 0: host-pointer batches are staged in one piece                       [FEMTO_AMD_HOST_PIPELINE] */
   int32_t host_keys;             /* 0: host-pointer batches travel as symbols, never as keys              [FEMTO_AMD_HOST_KEYS] */
   int32_t host_pipe_chunk_log2;  /* log2 patterns per pipeline stage; auto 20                             [FEMTO_AMD_PIPE_CHUNK_LOG2] */
