@@ -188,6 +188,12 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
   __shared__ uint8_t s_byte[264];
   __shared__ int64_t s_w[4];
   __shared__ uint32_t s_win[kWinDw * 256];
+  // (the lane's length and start are requested BEFORE the alphabet map is built: the map's loads and the barrier behind them
+  // then overlap the first memory round trip of the pattern instead of preceding it -- a workgroup lives for three or four
+  // round trips on a batch of random patterns, and this was one of them)
+  const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int len_q = q < npats ? plen[q] : 0;
+  const int64_t start_q = q < npats ? starts[q] : 0;
   for (int i = threadIdx.x; i < 264; i += blockDim.x) {
     const uint32_t c = i < kAlphaSize ? uint32_t(P::code_of(ix, uint32_t(i))) : 0xffffu;
     s_code[i] = uint16_t(c);
@@ -197,11 +203,10 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
   // (Lanes take the workgroup's patterns in the caller's order.  Taking them in order of LENGTH -- a counting sort in LDS, so
   // that a wavefront's lanes run chains of similar length -- was tried on the mixed-length sigma~96 batch: 1.70 instead of
   // 1.64 ms; neighbouring lanes then no longer read neighbouring patterns.)
-  const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   int64_t nocc = 0;
   if (q < npats) {
-    const int len = plen[q];
-    const uint16_t* pat = pats + starts[q];
+    const int len = len_q;
+    const uint16_t* pat = pats + start_q;
     // The lane's window on its pattern: the DENSE codes of symbols j = w0 .. w0 + 71 (j counts from the pattern's END, the
     // order a backward search reads them in), one byte each, in LDS (byte k of lane t in dword (k >> 2) * 256 + t: bank =
     // t mod 32, the minimum for 64 lanes).  Each symbol is translated ONCE (alpha code -> window byte through s_byte);
