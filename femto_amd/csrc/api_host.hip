@@ -426,7 +426,7 @@ int plan_host(femto_amd_index* ix, Scratch& S, const HostBatch& hb, int max_occs
   }
   if (plan.done) {
     *direct_plan = true;
-    if ((rc = launch_plan_rows(ix, S, npats, S.noccs.as<int32_t>(), S.first.as<int64_t>(), S.out_starts.as<int64_t>(), nullptr, INT64_MAX, st))) return rc;
+    if ((rc = launch_plan_rows(ix, S, npats, S.noccs.as<int32_t>(), S.first.as<int64_t>(), S.out_starts.as<int64_t>(), nullptr, INT64_MAX, st))) return rc;   // (rows only: no offsets buffer yet)
   }
   if ((rc = check_err_flag(S, st))) return rc;
   if (max_occs_each == 0 && npats) {

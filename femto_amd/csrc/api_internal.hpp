@@ -366,6 +366,7 @@ struct Plan {
   int64_t capacity;      // rows the caller's offsets buffer holds (INT64_MAX when it is sized afterwards)
   bool done;
   int64_t* total_user = nullptr;   // device, 2 words: the caller's copy of S.d_total, written by plan_rows_kernel itself
+  const int64_t* sa_known = nullptr;   // set by the count: text positions of one-row patterns it already knows (count_direct_kernel's sa_out)
 };
 // modes 3 / 4: the caller-order pipeline of direct_kernels.hip.hpp (with or without a level table)
 inline bool use_direct(const femto_amd_index* ix) { return ix->mode == 3 || ix->mode == 4; }
@@ -376,7 +377,8 @@ int launch_count_keys(femto_amd_index* ix, int64_t n, const uint64_t* d_keys, in
 int launch_count_plan(femto_amd_index* ix, Scratch& S, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats, const int64_t* d_starts,
                       int64_t* d_first, int64_t* d_last, Plan* plan, hipStream_t stream);
 int launch_plan_rows(femto_amd_index* ix, Scratch& S, int64_t npats, const int32_t* d_noccs, const int64_t* d_first, int64_t* d_out_starts,
-                     int64_t* d_offsets, int64_t capacity, hipStream_t stream, const int2* d_first32 = nullptr, bool fuse_walk = false);
+                     int64_t* d_offsets, int64_t capacity, hipStream_t stream, const int2* d_first32 = nullptr, bool fuse_walk = false,
+                     const int64_t* d_sa_known = nullptr);
 int launch_walk_device_total(femto_amd_index* ix, Scratch& S, int64_t* d_offsets, int64_t capacity, hipStream_t stream);
 int launch_locate(femto_amd_index* ix, Scratch& S, int64_t npats, const int64_t* d_first, const int64_t* d_out_starts, int64_t total,
                   int64_t* d_offsets, hipStream_t stream);

@@ -182,7 +182,7 @@ template <class P, bool kPlan, bool kDense>
 inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kDirectWaves, P::kDirectWaves))) void count_direct_kernel(
     const DevIndex ix, const int64_t npats, const int32_t* __restrict__ plen, const uint16_t* __restrict__ pats,
     const int64_t* __restrict__ starts, int64_t* __restrict__ first_out, int64_t* __restrict__ last_out, int* __restrict__ err_flag,
-    const int max_occs, int32_t* __restrict__ noccs, const PlanSums ps, int* __restrict__ big_flag) {
+    const int max_occs, int32_t* __restrict__ noccs, const PlanSums ps, int* __restrict__ big_flag, int64_t* __restrict__ sa_out) {
   constexpr int kWinDw = 18, kWin = 4 * kWinDw;   // the window: 72 symbols per lane
   __shared__ uint16_t s_code[264];
   __shared__ uint8_t s_byte[264];
@@ -267,7 +267,8 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
     };
     auto alpha = [&](int j) -> uint32_t { return pat[len - 1 - j]; };     // the symbol itself (0xFF cases only)
     int64_t first = 0, last = ix.total_length - 1;
-    int64_t sa_hint = -1;       // SA[first] as the wide context table delivered it; forgotten with the first search step
+    int64_t sa_hint = -1;       // SA[first] where it is known: as the wide context table delivered it, or behind a text tail that left one row;
+                                // forgotten with the next search step
     int j = 0;
     if (ix.ctx && len >= ix.ctx_syms) {     // byte alphabets: the last H symbols as one hashed read (ctx_kernels.hip.hpp)
       const int H1 = ix.ctx_syms, H2 = (ix.ctx2 && len >= ix.ctx2_syms) ? ix.ctx2_syms : 0;
@@ -364,6 +365,7 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
       const int remaining = len - j;
       int best = 0;                      // most symbols any row of the range matches; [qmin, qmax] = the rows of those that do
       int64_t qmin = 0, qmax = -1;
+      int64_t pbest = -1;                // text position behind qmin (the match of `best` symbols starts there: SA[qmin])
       for (int64_t row = first; row <= last; row++) {
         int64_t p = sa_hint;
         if (!(kDense && row == first && sa_hint >= 0)) {
@@ -448,6 +450,7 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
           if (m > best) {
             best = m;
             qmin = qmax = q2;
+            pbest = p - m;
           } else {
             qmin = q2 < qmin ? q2 : qmin;
             qmax = q2 > qmax ? q2 : qmax;
@@ -459,6 +462,7 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
         first = qmin;
         last = qmax;
         j += best;
+        if (qmin == qmax) sa_hint = pbest;     // (rows are distinct positions: one row left means pbest is ITS position)
       }
       if (j >= len) break;
     }
@@ -474,6 +478,13 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
         else if (last - first > int64_t(max_occs)) nocc = max_occs;
         else nocc = last - first + 1;
         noccs[q] = int32_t(nocc);
+        // kDense: a search that ended in the text tail (or in the wide context table) on ONE row knows that row's text
+        // position already -- it is where the compared text starts.  Handing it to plan_rows_kernel saves that pattern's
+        // suffix-array read there: one scattered request less per located pattern.  Written by the wavefronts that hold
+        // a one-row pattern only (plan_rows_kernel reads sa_out[q] only where noccs[q] == 1); -1 = not known.
+        if (kDense && sa_out) {
+          if (__ballot(nocc == 1)) sa_out[q] = first == last ? sa_hint : -1;
+        }
       }
     } else if (kPlan) {
       noccs[q] = 0;    // count_tail_kernel stores the real value and adds it to the block's sum
@@ -669,7 +680,8 @@ inline __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npa
                                                         const int2* __restrict__ first32 /* or NULL: (first,last) pairs instead of first[] */,
                                                         const PlanSums ps, int64_t* __restrict__ out_starts,
                                                         int64_t* __restrict__ offsets, const int64_t capacity, int* __restrict__ big_flag,
-                                                        const DevIndex ix, int64_t* __restrict__ total_out, int64_t* __restrict__ total_user) {
+                                                        const DevIndex ix, int64_t* __restrict__ total_out, int64_t* __restrict__ total_user,
+                                                        const int64_t* __restrict__ sa_known /* or NULL: count_direct_kernel's sa_out */) {
   __shared__ int64_t s_w[4];
   __shared__ int64_t s_boff;
   const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -728,7 +740,12 @@ inline __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npa
       if (lane >= d) inc += y;
     }
     s_incl[wave][lane] = inc;
-    s_first[wave][lane] = mine ? (first32 ? int64_t(first32[q].x) : first[q]) : 0;      // (only ranges with rows: most lines of first[] are never touched on a random batch)
+    int64_t f0 = mine ? (first32 ? int64_t(first32[q].x) : first[q]) : 0;      // (only ranges with rows: most lines of first[] are never touched on a random batch)
+    if (kMode == kRowsSa && sa_known && mine == 1u) {      // the count kernel may know this row's position: ~position < 0 in place of the row
+      const int64_t known = sa_known[q];
+      if (known >= 0) f0 = ~known;
+    }
+    s_first[wave][lane] = f0;
     s_lbase[wave][lane] = base;      // slots are addressed per lane: a long range keeps its slots but is not written here
     const uint32_t total = uint32_t(__shfl(int(inc), 63, 64));
     __syncthreads();
@@ -744,10 +761,14 @@ inline __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npa
         const int64_t k = int64_t(sidx - before);
         const int64_t slot = s_lbase[wave][lo] + k;
         if (slot < capacity) {
-          const int64_t row = s_first[wave][lo] + k;
+          const int64_t f = s_first[wave][lo], row = f + k;
           if (kMode == kRowsSa) {
-            offsets[slot] = ix.sa_full[row];
-            trace_touch(ix, kTraceSa, uint64_t(row) >> 4);
+            if (f < 0) {
+              offsets[slot] = ~f;
+            } else {
+              offsets[slot] = ix.sa_full[row];
+              trace_touch(ix, kTraceSa, uint64_t(row) >> 4);
+            }
           } else {
             offsets[slot] = walk_row<P>(ix, row);
           }

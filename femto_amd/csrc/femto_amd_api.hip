@@ -394,12 +394,20 @@ int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const in
   const int mo = plan ? plan->max_occs : 0;
   int32_t* noccs = plan ? plan->noccs : nullptr;
   const bool dense = inline_tail;
+  // one-row patterns whose text position the search already knows (the text tail's, the wide context table's): handed to
+  // plan_rows_kernel, which then skips their suffix-array read (S.noccs64 is free on this path: the block sums replace the scan)
+  int64_t* sa_out = nullptr;
+  if (plan && dense) {
+    if ((rc = S.noccs64.reserve(size_t(npats + 1) * 8))) return rc;
+    sa_out = S.noccs64.as<int64_t>();
+    plan->sa_known = sa_out;
+  }
 #define LAUNCH_COUNT_DIRECT(POLICY)                                                                                                        \
   do {                                                                                                                                     \
-    if (plan && dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, true, true>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, ps, big_flag); \
-    else if (plan) hipLaunchKernelGGL((count_direct_kernel<POLICY, true, false>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, ps, big_flag);       \
-    else if (dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, false, true>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, ps, big_flag);     \
-    else hipLaunchKernelGGL((count_direct_kernel<POLICY, false, false>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, ps, big_flag);              \
+    if (plan && dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, true, true>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, ps, big_flag, sa_out); \
+    else if (plan) hipLaunchKernelGGL((count_direct_kernel<POLICY, true, false>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, ps, big_flag, sa_out);       \
+    else if (dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, false, true>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, ps, big_flag, sa_out);     \
+    else hipLaunchKernelGGL((count_direct_kernel<POLICY, false, false>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, ps, big_flag, sa_out);              \
   } while (0)
   if (ix->mode == 3 && d.ru) LAUNCH_COUNT_DIRECT(RuPolicy);     // rank units: one 16-byte load per range end and step
   else if (ix->mode == 3) LAUNCH_COUNT_DIRECT(PackPolicy);
@@ -570,7 +578,7 @@ int launch_count_plan(femto_amd_index* ix, Scratch& S, int64_t npats, const int3
 // direct pipeline, after launch_count_plan: out_starts[] and -- when d_offsets is given -- the rows to locate
 int launch_plan_rows(femto_amd_index* ix, Scratch& S, int64_t npats, const int32_t* d_noccs, const int64_t* d_first,
                      int64_t* d_out_starts, int64_t* d_offsets, int64_t capacity, hipStream_t stream, const int2* d_first32,
-                     bool fuse_walk) {
+                     bool fuse_walk, const int64_t* d_sa_known) {
   if (npats <= 0) return 0;
   int* big_flag = S.d_flags + 1;      // cleared by the count kernel
   const int64_t nblocks = (npats + kBlockThreads - 1) / kBlockThreads;
@@ -589,7 +597,7 @@ int launch_plan_rows(femto_amd_index* ix, Scratch& S, int64_t npats, const int32
 #define LAUNCH_PLAN(MODE, POLICY)                                                                                                         \
   do {                                                                                                                                    \
     hipLaunchKernelGGL((plan_rows_kernel<MODE, POLICY>), grid, block, 0, stream, npats, d_noccs, d_first, d_first32, ps, d_out_starts,  \
-                       d_offsets, capacity, big_flag, ix->dev, S.d_total, S.total_user);                                                  \
+                       d_offsets, capacity, big_flag, ix->dev, S.d_total, S.total_user, d_sa_known);                                      \
     if (d_offsets)                                                                                                                        \
       hipLaunchKernelGGL((plan_big_rows_kernel<MODE, POLICY>), bgrid, block, 0, stream, npats, d_first, d_first32, starts_c, total_c,    \
                          capacity, d_offsets, big_c, ix->dev);                                                                            \
@@ -945,7 +953,7 @@ int femto_amd_locate_device(femto_amd_index_t* ix, int64_t npats, const int32_t*
   Plan plan{max_occs_each, d_noccs, d_out_starts, offsets_capacity, false, d_total};
   if ((rc = launch_count_plan(ix, S, npats, d_plen, d_pats, d_starts, d_first, d_last, &plan, stream))) return rc;
   if (plan.done) {   // direct pipeline: one stream-ordered chain, nothing returns to the host (d_total: plan_rows_kernel's last block)
-    if ((rc = launch_plan_rows(ix, S, npats, d_noccs, d_first, d_out_starts, d_offsets, offsets_capacity, stream, nullptr, /*fuse_walk=*/true))) return rc;
+    if ((rc = launch_plan_rows(ix, S, npats, d_noccs, d_first, d_out_starts, d_offsets, offsets_capacity, stream, nullptr, /*fuse_walk=*/true, plan.sa_known))) return rc;
   } else {           // other kernel families size the walk on the host
     int64_t tot[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(tot, S.d_total, sizeof tot, hipMemcpyDeviceToHost, stream));
@@ -1196,6 +1204,8 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
     a.first = S.first.as<int64_t>();
     a.last = S.last.as<int64_t>();
     a.noccs = S.noccs.as<int32_t>();
+    if ((r2 = S.noccs64.reserve(size_t(npats + 1) * 8))) return r2;
+    a.sa_known = S.noccs64.as<int64_t>();      // (used where launch_count_direct would: dense handles)
     a.out_starts = S.out_starts.as<int64_t>();
     a.bsums = S.bsums.as<int64_t>();
     a.parity = S.bsums_parity;

@@ -15,6 +15,7 @@ struct TraceArgs {
   int max_occs;
   int64_t *first, *last;
   int32_t* noccs;
+  int64_t* sa_known;        // npats: count_direct_kernel's sa_out on a dense handle (text positions the search already knows)
   int64_t *out_starts, *bsums;
   int parity;               // which set of group sums of bsums this launch uses (PlanSums)
   void* tail_items;         // NULL: no text tail

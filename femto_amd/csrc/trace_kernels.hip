@@ -56,8 +56,8 @@ hipError_t traced_count_plan(const TraceArgs& a) {
   int* big_flag = a.flags + 1;
 #define LAUNCH_COUNT_DIRECT(POLICY)                                                                                                     \
   do {                                                                                                                                  \
-    if (dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, true, true>), grid, block, 0, a.stream, d, a.npats, a.plen, a.pats, a.starts, a.first, a.last, a.flags, a.max_occs, a.noccs, ps, big_flag); \
-    else hipLaunchKernelGGL((count_direct_kernel<POLICY, true, false>), grid, block, 0, a.stream, d, a.npats, a.plen, a.pats, a.starts, a.first, a.last, a.flags, a.max_occs, a.noccs, ps, big_flag);     \
+    if (dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, true, true>), grid, block, 0, a.stream, d, a.npats, a.plen, a.pats, a.starts, a.first, a.last, a.flags, a.max_occs, a.noccs, ps, big_flag, a.sa_known); \
+    else hipLaunchKernelGGL((count_direct_kernel<POLICY, true, false>), grid, block, 0, a.stream, d, a.npats, a.plen, a.pats, a.starts, a.first, a.last, a.flags, a.max_occs, a.noccs, ps, big_flag, static_cast<int64_t*>(nullptr));     \
   } while (0)
   if (a.mode == 3 && d.ru) LAUNCH_COUNT_DIRECT(RuPolicy);
   else if (a.mode == 3) LAUNCH_COUNT_DIRECT(PackPolicy);
@@ -84,7 +84,7 @@ hipError_t traced_count_plan(const TraceArgs& a) {
   }
   if (tail) hipLaunchKernelGGL(plan_super_kernel, dim3(uint32_t(((nblocks + 63) / 64 + 3) / 4)), block, 0, a.stream, ps);
   hipLaunchKernelGGL((plan_rows_kernel<kRowsOnly, PackPolicy>), grid, block, 0, a.stream, a.npats, static_cast<const int32_t*>(a.noccs), static_cast<const int64_t*>(a.first), static_cast<const int2*>(nullptr),
-                     ps, a.out_starts, static_cast<int64_t*>(nullptr), INT64_MAX, a.flags + 1, d, a.total, static_cast<int64_t*>(nullptr));
+                     ps, a.out_starts, static_cast<int64_t*>(nullptr), INT64_MAX, a.flags + 1, d, a.total, static_cast<int64_t*>(nullptr), static_cast<const int64_t*>(nullptr));
   return hipGetLastError();
 }
 
@@ -101,16 +101,16 @@ hipError_t traced_walk(const TraceArgs& a, int64_t* offsets, int64_t capacity) {
   const PlanSums boffs = plan_sums_at(a.bsums, nblocks, false, a.parity);
   const int* big = a.flags + 1;
   if (d.sa_full) {   // the offsets themselves, no walk
-    hipLaunchKernelGGL((plan_rows_kernel<kRowsSa, PackPolicy>), grid, block, 0, a.stream, a.npats, noccs, first, static_cast<const int2*>(nullptr), boffs, a.out_starts, offsets, capacity, a.flags + 1, d, a.total, static_cast<int64_t*>(nullptr));
+    hipLaunchKernelGGL((plan_rows_kernel<kRowsSa, PackPolicy>), grid, block, 0, a.stream, a.npats, noccs, first, static_cast<const int2*>(nullptr), boffs, a.out_starts, offsets, capacity, a.flags + 1, d, a.total, static_cast<int64_t*>(nullptr), static_cast<const int64_t*>(a.sa_known));
     hipLaunchKernelGGL((plan_big_rows_kernel<kRowsSa, PackPolicy>), wgrid, block, 0, a.stream, a.npats, first, static_cast<const int2*>(nullptr), ostarts, total, capacity, offsets, big, d);
     return hipGetLastError();
   }
   // sampled marks: the walk runs inside the row expansion, as femto_amd_locate_device launches it
   if (a.mode == 3) {
-    hipLaunchKernelGGL((plan_rows_kernel<kRowsWalk, PackPolicy>), grid, block, 0, a.stream, a.npats, noccs, first, static_cast<const int2*>(nullptr), boffs, a.out_starts, offsets, capacity, a.flags + 1, d, a.total, static_cast<int64_t*>(nullptr));
+    hipLaunchKernelGGL((plan_rows_kernel<kRowsWalk, PackPolicy>), grid, block, 0, a.stream, a.npats, noccs, first, static_cast<const int2*>(nullptr), boffs, a.out_starts, offsets, capacity, a.flags + 1, d, a.total, static_cast<int64_t*>(nullptr), static_cast<const int64_t*>(nullptr));
     hipLaunchKernelGGL((plan_big_rows_kernel<kRowsWalk, PackPolicy>), wgrid, block, 0, a.stream, a.npats, first, static_cast<const int2*>(nullptr), ostarts, total, capacity, offsets, big, d);
   } else {
-    hipLaunchKernelGGL((plan_rows_kernel<kRowsWalk, Pack2Policy>), grid, block, 0, a.stream, a.npats, noccs, first, static_cast<const int2*>(nullptr), boffs, a.out_starts, offsets, capacity, a.flags + 1, d, a.total, static_cast<int64_t*>(nullptr));
+    hipLaunchKernelGGL((plan_rows_kernel<kRowsWalk, Pack2Policy>), grid, block, 0, a.stream, a.npats, noccs, first, static_cast<const int2*>(nullptr), boffs, a.out_starts, offsets, capacity, a.flags + 1, d, a.total, static_cast<int64_t*>(nullptr), static_cast<const int64_t*>(nullptr));
     hipLaunchKernelGGL((plan_big_rows_kernel<kRowsWalk, Pack2Policy>), wgrid, block, 0, a.stream, a.npats, first, static_cast<const int2*>(nullptr), ostarts, total, capacity, offsets, big, d);
   }
   return hipGetLastError();
