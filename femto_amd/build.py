@@ -11,7 +11,10 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.environ.get("FEMTO_AMD_LIB") or os.path.join(HERE, "libfemto_amd.so")
 SOURCES = ["femto_amd_api.hip", "api_host.hip", "api_open.hip", "api_multi.hip", "regexp_search.hip", "trace_kernels.hip", "host_index.cpp", "index_builder.cpp", "suffix_sort.hip",
-           "query_sort.hip"]
+           "query_sort.hip", "host_pack.cpp"]
+# host-only translation units compiled as plain C++ (x86 intrinsics; no device pass)
+PLAIN_CXX = {"host_pack.cpp"}
+CXX_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-pthread"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-Wno-unused-result", "-Wno-cuda-compat"]
 # experiments only (tools/ab_bench.sh): extra compiler flags and a separate object directory for a second build of the library
 FLAGS += os.environ.get("FEMTO_AMD_EXTRA_FLAGS", "").split()
@@ -59,7 +62,10 @@ def build(force=False, verbose=False):
     todo = [s for s in SOURCES if force or _stale(s, hdr_time)]
 
     def compile_one(src):
-        cmd = ["hipcc"] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", _obj(src)]
+        if src in PLAIN_CXX:
+            cmd = ["hipcc"] + CXX_FLAGS + ["-x", "c++", "-c", os.path.join(CSRC, src), "-o", _obj(src)]
+        else:
+            cmd = ["hipcc"] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", _obj(src)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

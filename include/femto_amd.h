@@ -412,6 +412,15 @@ int femto_amd_structures(const femto_amd_index_t* ix, int64_t* out, int n);
  * a pinned input buffer, [2] enqueueing copies / kernels / events, [3] waiting for a chunk's results to arrive over PCIe,
  * [4] staging threads moving results into the caller's arrays, [5] the whole call; [6] chunks, [7] staging threads. */
 int femto_amd_host_pipeline_stats(femto_amd_index_t* ix, double* out8);
+/* The staging threads' packing loop on its own (no handle, no device; diagnostic): keys_out[i] = the 64-bit key of pattern i
+ * (symbols flat[starts[i] .. starts[i] + plen[i]), dense[sym] = the symbol's field for sym < ndense, `bits` bits per field,
+ * last symbol in the top field: what femto_amd_pack_keys_device computes on the GPU).  Returns 1 when every pattern is described
+ * by its key, 0 when some pattern is not (longer than 63 / bits symbols, a symbol without a field: such a chunk travels as
+ * symbols), -1 on bad arguments.  force_scalar != 0: the plain loop instead of the AVX-512 VBMI / BMI2 one the host-pointer
+ * paths use where the CPU has them (*simd_used says which ran).  Replaces the per-pattern copy of do_parallel_query's setup
+ * (src/main/server.c:691-695). */
+int femto_amd_host_pack_keys(const uint8_t* dense, int ndense, int bits, int64_t npats, const int32_t* plen, const uint16_t* flat,
+                             const int64_t* starts, int force_scalar, uint64_t* keys_out, int* simd_used);
 int femto_amd_get_rank_mode(const femto_amd_index_t* ix);
 
 /* ---- profiling hooks ---------------------------------------------------------------------- */

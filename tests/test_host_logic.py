@@ -337,3 +337,73 @@ int main() {
     subprocess.run(["g++", "-std=c++17", "-O2", "-pthread", "-I", os.path.join(ROOT, "femto_amd", "csrc"), "-o", str(exe), str(src)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "ok" in out.stdout
+
+
+def _pack_keys_reference(dense, bits, plen, flat, starts):
+    """the key format of count_keys_kernel, by definition: field j from the top = dense code of the j-th symbol from the end"""
+    nsym = 63 // bits
+    keys = np.zeros(len(plen), dtype=np.uint64)
+    ok = True
+    for i, (l, s) in enumerate(zip(plen.tolist(), starts.tolist())):
+        if l > nsym:
+            return None, False
+        key = 0
+        for j in range(l):
+            sym = int(flat[s + l - 1 - j])
+            c = int(dense[sym]) if sym < len(dense) else 0
+            ok = ok and c != 0
+            key |= c << (64 - bits * (j + 1))
+        keys[i] = key
+    return keys, ok
+
+
+@pytest.mark.parametrize("bits,alphabet", [(3, b"ACGT"), (3, b"\x00ACGNT"), (7, bytes(range(32, 127))), (8, bytes(range(3, 256))), (1, b"A"), (2, b"AB")])
+def test_host_key_packing_simd_equals_scalar_equals_definition(bits, alphabet):
+    """host_pack.cpp: the AVX-512 VBMI / BMI2 packing loop of the host-pointer batches against the plain loop and against the
+    key format written out in Python -- every length 0 .. 63 / bits, patterns starting at odd addresses and at the very end of
+    the symbol array (the masked load must not read past it), bytes 251..255 (symbols 256..260: the scalar way inside the
+    SIMD loop), a symbol without a code (the chunk is given up: return 0, same in both)."""
+    lib = femto_amd.lib()
+    fn = lib.femto_amd_host_pack_keys
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(bits * 1000 + len(alphabet))
+    dense = np.zeros(261, dtype=np.uint8)
+    chars = sorted(set(alphabet))[: (1 << bits) - 1]
+    for rank, ch in enumerate(chars):
+        dense[ch + 5] = rank + 1           # alpha_t = byte + 5 (index_types.h:64-69)
+    nsym = 63 // bits
+    lens = np.concatenate([np.arange(0, nsym + 1), rng.integers(0, nsym + 1, size=3000)]).astype(np.int32)
+    starts = np.zeros(len(lens), dtype=np.int64)
+    starts[1:] = np.cumsum(lens[:-1])
+    total = int(lens.sum())
+    flat = (np.array(chars, dtype=np.uint16)[rng.integers(0, len(chars), size=total)] + 5).astype(np.uint16)
+
+    def run(force_scalar, flat_arr):
+        keys = np.full(len(lens), 0xDEADBEEF, dtype=np.uint64)
+        used = C.c_int(-1)
+        rc = fn(dense.ctypes.data, 261, bits, len(lens), lens.ctypes.data, flat_arr.ctypes.data, starts.ctypes.data, force_scalar,
+                keys.ctypes.data, C.byref(used))
+        return rc, keys, used.value
+
+    want, ok = _pack_keys_reference(dense, bits, lens, flat, starts)
+    assert ok
+    rc_s, k_s, used_s = run(1, flat)
+    rc_v, k_v, used_v = run(0, flat)
+    assert rc_s == 1 and rc_v == 1 and used_s == 0
+    assert np.array_equal(k_s, want)
+    assert np.array_equal(k_v, want)
+    # a symbol without a code somewhere: both give the chunk up
+    if total:
+        bad = flat.copy()
+        bad[total // 2] = 2 if dense[2] == 0 else 300
+        assert run(1, bad)[0] == 0 and run(0, bad)[0] == 0
+    # a pattern longer than a key holds
+    long_lens = lens.copy()
+    if nsym < 63:
+        long_lens[5] = nsym + 1
+        keys = np.zeros(len(lens), dtype=np.uint64)
+        big = np.concatenate([flat, flat[: nsym + 2]])
+        for force in (0, 1):
+            assert fn(dense.ctypes.data, 261, bits, len(lens), long_lens.ctypes.data, big.ctypes.data, starts.ctypes.data, force,
+                      keys.ctypes.data, None) == 0
