@@ -222,7 +222,8 @@ struct femto_amd_index {
   int64_t ktab2_bytes = 0;
   uint64_t* d_ctx = nullptr;     // context tables of byte alphabets (ctx_kernels.hip.hpp)
   uint64_t* d_ctx2 = nullptr;
-  int64_t ctx_bytes = 0, ctx_entries = 0, ctx2_bytes = 0;
+  uint64_t* d_ctxm = nullptr;
+  int64_t ctx_bytes = 0, ctx_entries = 0, ctx2_bytes = 0, ctxm_bytes = 0;
   double ctx_build_ms = 0;
   uint8_t* d_txt = nullptr;
   int64_t* d_isa8 = nullptr;

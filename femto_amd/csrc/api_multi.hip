@@ -143,7 +143,7 @@ static int make_view(femto_amd_index* b, int device, femto_amd_index** out) {
   v->opt = b->opt;
   v->mode = b->mode; v->sort_queries = b->sort_queries; v->dense_bits = b->dense_bits;
   v->dense_sigma = b->dense_sigma; v->sort_min = b->sort_min; v->h_dense = b->h_dense; v->table_bytes = b->table_bytes;
-  v->ktab2_bytes = b->ktab2_bytes; v->ctx_bytes = b->ctx_bytes; v->ctx2_bytes = b->ctx2_bytes; v->n_marks = b->n_marks; v->p2_lines1 = b->p2_lines1; v->p2_lines2 = b->p2_lines2;
+  v->ktab2_bytes = b->ktab2_bytes; v->ctx_bytes = b->ctx_bytes; v->ctx2_bytes = b->ctx2_bytes; v->ctxm_bytes = b->ctxm_bytes; v->n_marks = b->n_marks; v->p2_lines1 = b->p2_lines1; v->p2_lines2 = b->p2_lines2;
   v->ind_bytes = b->ind_bytes; v->text_bytes = b->text_bytes; v->pack_bytes = b->pack_bytes; v->pack2_bytes = b->pack2_bytes;
   if (hipSetDevice(device) != hipSuccess) return fail(set_err(FEMTO_AMD_ERR_INVALID, "no usable HIP device " + std::to_string(device)));
   hipDeviceProp_t prop;
@@ -212,7 +212,7 @@ namespace {
 struct SharedFacts {       // what make_view copies from the builder, as plain data
   int32_t mode, sort_queries, dense_bits;
   double dense_sigma;
-  int64_t sort_min, table_bytes, ktab2_bytes, ctx_bytes, ctx2_bytes, n_marks, p2_lines1, p2_lines2, ind_bytes, text_bytes, pack_bytes, pack2_bytes;
+  int64_t sort_min, table_bytes, ktab2_bytes, ctx_bytes, ctx2_bytes, ctxm_bytes, n_marks, p2_lines1, p2_lines2, ind_bytes, text_bytes, pack_bytes, pack2_bytes;
   uint64_t d_dense;
   uint64_t dev_bytes, n_dense, n_ranges, n_small, n_fds;
 };
@@ -321,7 +321,7 @@ int femto_amd_striped_serve(femto_amd_index_t* ix, const char* socket_path, int 
   SharedFacts f{};
   f.mode = b->mode; f.sort_queries = b->sort_queries; f.dense_bits = b->dense_bits;
   f.dense_sigma = b->dense_sigma; f.sort_min = b->sort_min;
-  f.table_bytes = b->table_bytes; f.ktab2_bytes = b->ktab2_bytes; f.ctx_bytes = b->ctx_bytes; f.ctx2_bytes = b->ctx2_bytes;
+  f.table_bytes = b->table_bytes; f.ktab2_bytes = b->ktab2_bytes; f.ctx_bytes = b->ctx_bytes; f.ctx2_bytes = b->ctx2_bytes; f.ctxm_bytes = b->ctxm_bytes;
   f.n_marks = b->n_marks; f.p2_lines1 = b->p2_lines1; f.p2_lines2 = b->p2_lines2; f.ind_bytes = b->ind_bytes;
   f.text_bytes = b->text_bytes; f.pack_bytes = b->pack_bytes; f.pack2_bytes = b->pack2_bytes;
   f.d_dense = reinterpret_cast<uint64_t>(b->d_dense);
@@ -473,7 +473,7 @@ int femto_amd_open_striped_client(const char* index_path, const char* socket_pat
   if (f.n_dense && !R.get(v->h_dense.data(), size_t(f.n_dense))) return bail(set_err(FEMTO_AMD_ERR_FORMAT, "short description"));
   v->mode = f.mode; v->sort_queries = f.sort_queries != 0; v->dense_bits = f.dense_bits;
   v->dense_sigma = f.dense_sigma; v->sort_min = f.sort_min;
-  v->table_bytes = f.table_bytes; v->ktab2_bytes = f.ktab2_bytes; v->ctx_bytes = f.ctx_bytes; v->ctx2_bytes = f.ctx2_bytes;
+  v->table_bytes = f.table_bytes; v->ktab2_bytes = f.ktab2_bytes; v->ctx_bytes = f.ctx_bytes; v->ctx2_bytes = f.ctx2_bytes; v->ctxm_bytes = f.ctxm_bytes;
   v->n_marks = f.n_marks; v->p2_lines1 = f.p2_lines1; v->p2_lines2 = f.p2_lines2; v->ind_bytes = f.ind_bytes;
   v->text_bytes = f.text_bytes; v->pack_bytes = f.pack_bytes; v->pack2_bytes = f.pack2_bytes;
   v->d_dense = reinterpret_cast<uint8_t*>(f.d_dense);

@@ -220,23 +220,36 @@ int build_ctx(femto_amd_index* ix, int nstop) {
   return 0;
 }
 
-// The wide context table (two-word keys): H2 = the largest of min(16, 128 / bits) .. H1 + 2 whose table (32-byte
-// slots, 1.4 x the distinct H2-grams) fits a quarter of the free HBM.  FEMTO_AMD_CTX2=0 disables, FEMTO_AMD_CTX2_SYMS=h forces.
-int build_ctx2(femto_amd_index* ix, int nstop) {
-  if (ix->dev.ctx2 || !ix->dev.ctx) return 0;
-  if (knob(ix->opt.context2_table, "FEMTO_AMD_CTX2", 1) == 0) return 0;
+// The wide context tables (two-word keys).  mid == false: H2 = the largest of min(16, 128 / bits) .. H1 + 2 whose table (32-byte
+// slots, 1.4 - 2 x the distinct H2-grams) fits a quarter of the free HBM.  FEMTO_AMD_CTX2=0 disables, FEMTO_AMD_CTX2_SYMS=h forces.
+// mid == true (after the other two): one more table of the length half way between them, HM = (H1 + H2) / 2, when they are
+// at least four symbols apart -- a pattern of H1 < len < H2 symbols otherwise steps len - H1 times after the narrow table,
+// two lines per step and range end, and a wavefront waits for the lane with the most steps.  OFF unless asked for
+// (femto_amd_options_t::context_mid_table = 1 / FEMTO_AMD_CTXM=1): on the sigma~96 workload (lengths 8..64) the 12-gram table
+// cost 36 GB and took the count kernel from 1.42 to 1.39 ms -- the per-character rank lines read per launch went from 11.9 M
+// to 10.0 M only, most of that batch's steps belong to LONG patterns whose last sixteen symbols occur more than once.
+int build_ctx_wide(femto_amd_index* ix, int nstop, bool mid) {
+  if (!ix->dev.ctx) return 0;
+  if (!mid && ix->dev.ctx2) return 0;
+  if (mid && (ix->dev.ctxm || !ix->dev.ctx2)) return 0;
+  if (!mid && knob(ix->opt.context2_table, "FEMTO_AMD_CTX2", 1) == 0) return 0;
+  if (mid && knob(ix->opt.context_mid_table, "FEMTO_AMD_CTXM", 0) == 0) return 0;
   const int64_t n = ix->host.total_length;
   const int bits = ix->dev.ctx_bits;
   int hmax = std::min(16, 128 / bits), hmin = ix->dev.ctx_syms + 2;
-  if (const int64_t hs = knob(ix->opt.context2_syms, "FEMTO_AMD_CTX2_SYMS", -1); hs >= 0)
+  if (mid) {
+    if (ix->dev.ctx2_syms - ix->dev.ctx_syms < 4) return 0;
+    hmax = hmin = (ix->dev.ctx_syms + ix->dev.ctx2_syms) / 2;
+  } else if (const int64_t hs = knob(ix->opt.context2_syms, "FEMTO_AMD_CTX2_SYMS", -1); hs >= 0) {
     hmax = hmin = std::max(ix->dev.ctx_syms + 1, std::min(std::min(16, 128 / bits), int(hs)));
+  }
   if (hmin > hmax) return 0;
-  size_t free_b = 0, total_b = 0;
-  free_b = hbm_free(ix);
-  (void)total_b;
+  const size_t free_b = hbm_free(ix);
   int64_t budget = int64_t(free_b / 4);
-  if (ix->opt.context2_bytes >= 0) budget = std::max<int64_t>(1, ix->opt.context2_bytes);
-  else if (const char* e = getenv("FEMTO_AMD_CTX2_MB")) budget = std::max<int64_t>(1, atoll(e)) << 20;
+  if (!mid) {
+    if (ix->opt.context2_bytes >= 0) budget = std::max<int64_t>(1, ix->opt.context2_bytes);
+    else if (const char* e = getenv("FEMTO_AMD_CTX2_MB")) budget = std::max<int64_t>(1, atoll(e)) << 20;
+  }
   DeviceBuffer cnt;
   int rc = cnt.reserve(8);
   if (rc) return rc;
@@ -271,24 +284,33 @@ int build_ctx2(femto_amd_index* ix, int nstop) {
     }
     if (!nslots) continue;
     const int64_t bytes = int64_t(nslots) * 32;
-    if (big_malloc(ix, reinterpret_cast<void**>(&ix->d_ctx2), size_t(bytes)) != hipSuccess) {
+    uint64_t* table = nullptr;
+    if (big_malloc(ix, reinterpret_cast<void**>(&table), size_t(bytes)) != hipSuccess) {
       (void)hipGetLastError();
-      ix->d_ctx2 = nullptr;
       continue;
     }
-    HIP_TRY(big_memset(ix, ix->d_ctx2, 0, size_t(bytes)));
-    pass(H, 1, reinterpret_cast<unsigned long long*>(ix->d_ctx2), nslots);
-    pass(H, 2, reinterpret_cast<unsigned long long*>(ix->d_ctx2), nslots);
+    (mid ? ix->d_ctxm : ix->d_ctx2) = table;
+    HIP_TRY(big_memset(ix, table, 0, size_t(bytes)));
+    pass(H, 1, reinterpret_cast<unsigned long long*>(table), nslots);
+    pass(H, 2, reinterpret_cast<unsigned long long*>(table), nslots);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
-    ix->dev.ctx2 = ix->d_ctx2;
-    ix->dev.ctx2_slots = nslots;
-    ix->dev.ctx2_syms = H;
-    ix->dev.ctx2_trace_off = ix->ctx_bytes / 128;
-    ix->ctx2_bytes = bytes;
+    if (mid) {
+      ix->dev.ctxm = table;
+      ix->dev.ctxm_slots = nslots;
+      ix->dev.ctxm_syms = H;
+      ix->dev.ctxm_trace_off = (ix->ctx_bytes + ix->ctx2_bytes) / 128;
+      ix->ctxm_bytes = bytes;
+    } else {
+      ix->dev.ctx2 = table;
+      ix->dev.ctx2_slots = nslots;
+      ix->dev.ctx2_syms = H;
+      ix->dev.ctx2_trace_off = ix->ctx_bytes / 128;
+      ix->ctx2_bytes = bytes;
+    }
     ix->ctx_build_ms += ms;
     ix->table_bytes += bytes;
     return 0;
@@ -872,7 +894,8 @@ int femto_amd::open_impl(const char* index_path, int device, int part, int npart
       else if (ix->dev.p2_l1) r = build_ktab2<Pack2Policy>(ix, ix->dev.p2_sigma, int(ix->dev.p2_stop_below));
       if (r && r != FEMTO_AMD_ERR_MEM) return r;
       if (ix->dev.p2_l1 && !ix->dev.pack && (r = build_ctx(ix, int(ix->dev.p2_stop_below))) && r != FEMTO_AMD_ERR_MEM) return r;
-      if (ix->dev.ctx && (r = build_ctx2(ix, int(ix->dev.p2_stop_below))) && r != FEMTO_AMD_ERR_MEM) return r;
+      if (ix->dev.ctx && (r = build_ctx_wide(ix, int(ix->dev.p2_stop_below), false)) && r != FEMTO_AMD_ERR_MEM) return r;
+      if (ix->dev.ctx2 && (r = build_ctx_wide(ix, int(ix->dev.p2_stop_below), true)) && r != FEMTO_AMD_ERR_MEM) return r;
       for (DeviceBuffer& b : ix->open_scan) b.release();
       int want_mode = ix->opt.rank_mode;
       if (want_mode < 0)

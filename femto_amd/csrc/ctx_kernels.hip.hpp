@@ -273,19 +273,19 @@ inline __global__ __launch_bounds__(256) void ctx2_build_kernel(const DevIndex i
 constexpr int kCtx2Gang = 4;
 // *sa_first = SA[first], stored in the slot's fourth word: a pattern whose sixteen last symbols occur ONCE -- most of a sampled
 // batch on a large text -- goes from this line straight to the text, without the suffix-array read in between.
-__device__ __forceinline__ int ctx2_lookup(const DevIndex& ix, const CtxKey2& key, int64_t& first, int64_t& last, int64_t* sa_first = nullptr) {
-  const uint64_t nslots = ix.ctx2_slots;
+__device__ __forceinline__ int ctx2_lookup_in(const DevIndex& ix, const uint64_t* __restrict__ table, const uint64_t nslots, const int64_t trace_off,
+                                              const CtxKey2& key, int64_t& first, int64_t& last, int64_t* sa_first) {
   uint64_t s = ctx_hash2(key, nslots);
   for (uint64_t probes = 0; probes < nslots; probes += kCtx2Gang) {
     ulonglong2 e[kCtx2Gang];
 #pragma unroll
-    for (int i = 0; i < kCtx2Gang; i++) e[i] = reinterpret_cast<const ulonglong2*>(ix.ctx2)[2 * (s + uint64_t(i))];
-    trace_touch(ix, kTraceCtx, uint64_t(ix.ctx2_trace_off) + (s >> 2));
+    for (int i = 0; i < kCtx2Gang; i++) e[i] = reinterpret_cast<const ulonglong2*>(table)[2 * (s + uint64_t(i))];
+    trace_touch(ix, kTraceCtx, uint64_t(trace_off) + (s >> 2));
 #pragma unroll
     for (int i = 0; i < kCtx2Gang; i++) {
       if (e[i].x == 0) return 0;
       if (e[i].x == key.lo && e[i].y == key.hi) {
-        const ulonglong2 vv = reinterpret_cast<const ulonglong2*>(ix.ctx2)[2 * (s + uint64_t(i)) + 1];
+        const ulonglong2 vv = reinterpret_cast<const ulonglong2*>(table)[2 * (s + uint64_t(i)) + 1];
         const uint64_t v = vv.x;
         if (sa_first) *sa_first = int64_t(vv.y);
         const uint64_t rows = v >> 40;
@@ -299,6 +299,18 @@ __device__ __forceinline__ int ctx2_lookup(const DevIndex& ix, const CtxKey2& ke
     if (s >= nslots) s = 0;
   }
   return 0;
+}
+__device__ __forceinline__ int ctx2_lookup(const DevIndex& ix, const CtxKey2& key, int64_t& first, int64_t& last, int64_t* sa_first = nullptr) {
+  return ctx2_lookup_in(ix, ix.ctx2, ix.ctx2_slots, ix.ctx2_trace_off, key, first, last, sa_first);
+}
+// the table of the middle length: its key is the wide key cut down to the last ctxm_syms symbols (field j from the end sits at
+// bits * j in both)
+__device__ __forceinline__ int ctxm_lookup(const DevIndex& ix, const CtxKey2& key2, int64_t& first, int64_t& last, int64_t* sa_first = nullptr) {
+  const int nb = ix.ctx_bits * ix.ctxm_syms;
+  CtxKey2 key;
+  key.lo = nb >= 64 ? key2.lo : (key2.lo & ((1ull << nb) - 1ull));
+  key.hi = nb <= 64 ? 0ull : (nb >= 128 ? key2.hi : (key2.hi & ((1ull << (nb - 64)) - 1ull)));
+  return ctx2_lookup_in(ix, ix.ctxm, ix.ctxm_slots, ix.ctxm_trace_off, key, first, last, sa_first);
 }
 
 }  // namespace femto_amd

@@ -176,6 +176,11 @@ struct DevIndex {           // passed by value to kernels
   int32_t ctx2_syms;        // H2 > ctx_syms
   int64_t ctx2_trace_off;   // its lines follow the narrow table's in the trace region
   uint64_t ctx2_slots;      // slots of the wide table (any number: slot = high half of hash x slots)
+  const uint64_t* ctxm;     // a second wide table of a length between the two (ctx_syms < ctxm_syms < ctx2_syms), or NULL
+  uint64_t ctxm_slots;
+  int64_t ctxm_trace_off;
+  int32_t ctxm_syms;
+  int32_t ctxm_pad;
   const int64_t* sa_full;   // SA[row] of EVERY row when HBM allows (8 B/row), else NULL: locate is then one read, no walk
   int32_t isa_shift;        // 0: full inverse suffix array (8 B/row), 3: every 8th position
   int32_t dense_pad;

@@ -272,7 +272,8 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
     int j = 0;
     if (ix.ctx && len >= ix.ctx_syms) {     // byte alphabets: the last H symbols as one hashed read (ctx_kernels.hip.hpp)
       const int H1 = ix.ctx_syms, H2 = (ix.ctx2 && len >= ix.ctx2_syms) ? ix.ctx2_syms : 0;
-      const int HH = H2 ? H2 : H1;
+      const int HM = (ix.ctxm && len >= ix.ctxm_syms) ? ix.ctxm_syms : 0;     // the table in between: patterns of H1 < len < H2 symbols
+      const int HH = H2 ? H2 : (HM ? HM : H1);
       const uint32_t nstop = uint32_t(ix.ctx_nstop);
       const int bits = ix.ctx_bits;
       uint64_t key1 = 0;
@@ -283,13 +284,14 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
         if (code == 0xFFu) break;
         const uint64_t field = uint64_t(code - nstop + 1u);
         if (okn < H1) key1 |= field << (bits * okn);
-        if (H2) ctx_key2_or(key2, field, bits * okn);
+        if (H2 | HM) ctx_key2_or(key2, field, bits * okn);
       }
       // A miss means the range dies within these symbols; the shorter table / the level table / the steps below then find
       // where, because the reference's (first, last) of an empty range are those of the step that emptied it.
       if (H2 && okn == H2 && ctx2_lookup(ix, key2, first, last, &sa_hint) == 1) j = H2;
+      else if (HM && okn >= HM && ctxm_lookup(ix, key2, first, last, &sa_hint) == 1) j = HM;
       else if (okn >= H1 && ctx_lookup(ix, key1, first, last) == 1) j = H1;
-      if (j != H2 || H2 == 0) sa_hint = -1;
+      if (j == 0 || j == H1) sa_hint = -1;        // (a wide-table miss may have left a value behind)
     }
     if (j == 0 && ix.ktab2) {
       const int kmax = len < ix.kt2_syms ? len : ix.kt2_syms;

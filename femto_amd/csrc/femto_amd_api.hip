@@ -841,7 +841,7 @@ void femto_amd_close(femto_amd_index_t* ix) {
       for (void* q : {static_cast<void*>(ix->d_image), static_cast<void*>(ix->d_segs), static_cast<void*>(ix->d_pack), static_cast<void*>(ix->d_pack_sa),
                       static_cast<void*>(ix->d_txt), static_cast<void*>(ix->d_isa8), static_cast<void*>(ix->d_p2_l1), static_cast<void*>(ix->d_p2_l2),
                       static_cast<void*>(ix->d_ktab2), static_cast<void*>(ix->d_ktab2_deep), static_cast<void*>(ix->d_sa_full), static_cast<void*>(ix->d_ind),
-                      static_cast<void*>(ix->d_ctx), static_cast<void*>(ix->d_ctx2), static_cast<void*>(ix->d_ru), static_cast<void*>(ix->d_ru_stop)})
+                      static_cast<void*>(ix->d_ctx), static_cast<void*>(ix->d_ctx2), static_cast<void*>(ix->d_ctxm), static_cast<void*>(ix->d_ru), static_cast<void*>(ix->d_ru_stop)})
         big_free(ix, q);
       for (void* q : {static_cast<void*>(ix->d_nodes), static_cast<void*>(ix->d_buckets), static_cast<void*>(ix->d_seqs), static_cast<void*>(ix->d_occ_base),
                       static_cast<void*>(ix->d_leaf_code), static_cast<void*>(ix->d_C), static_cast<void*>(ix->d_cum), static_cast<void*>(ix->d_hint),
@@ -1173,7 +1173,7 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
   region_lines[kTraceL2] = ix->p2_lines2;
   region_lines[kTraceTxt] = ix->dev.txt ? (n + 64) / 128 + 1 : 0;
   region_lines[kTraceIsa] = ix->dev.isa8 ? ((n >> ix->dev.isa_shift) + 2) / 16 + 1 : 0;
-  region_lines[kTraceCtx] = ix->ctx_bytes / 128 + ix->ctx2_bytes / 128;
+  region_lines[kTraceCtx] = ix->ctx_bytes / 128 + ix->ctx2_bytes / 128 + ix->ctxm_bytes / 128;
   region_lines[kTraceRu] = ix->ru_bytes / 128 + 1;
   int64_t off[kTraceRegions + 1];
   off[0] = 0;
@@ -1313,6 +1313,7 @@ int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* by
   if (available && ix->dev.ind) *available |= 32;     // bit 5: per-character rank lines (byte alphabets)
   if (available && ix->dev.ctx) *available |= 64 | (ix->dev.ctx_syms << 8);   // bit 6: context table; bits 8-11: its H
   if (available && ix->dev.ctx2) *available |= ix->dev.ctx2_syms << 12;        // bits 12-16: H2 of the wide context table
+  if (available && ix->dev.ctxm) *available |= ix->dev.ctxm_syms << 24;        // bits 24-28: HM of the table in between
   if (available && ix->dev.ru) *available |= 1 << 20;   // bit 20: rank units (small alphabets)
   if (available && ix->dev.sa_full) *available |= 8;  // bit 3: the full suffix array is resident
   if (available && ix->dev.isa8 && ix->dev.isa_shift == 0) *available |= 16;   // bit 4: the full inverse suffix array
@@ -1330,7 +1331,7 @@ int femto_amd_structures(const femto_amd_index_t* ix, int64_t* out, int n) {
   v[2] = ix->marks_bytes;
   v[3] = ix->ru_bytes;
   v[4] = ix->ktab2_bytes;
-  v[5] = ix->ctx_bytes + ix->ctx2_bytes;
+  v[5] = ix->ctx_bytes + ix->ctx2_bytes + ix->ctxm_bytes;
   v[6] = ix->ind_bytes;
   v[7] = ix->text_bytes;
   v[8] = (ix->p2_lines1 + ix->p2_lines2) * 128;

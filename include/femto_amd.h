@@ -368,6 +368,8 @@ typedef struct femto_amd_options {
   int32_t host_d2h_staged;       /* 0: located offsets return with one plain copy                         [FEMTO_AMD_D2H_STAGED] */
   int32_t rank_units;            /* 0: skip the 16-byte rank units of small alphabets (ru_kernels.hip.hpp) [FEMTO_AMD_RU] */
   int32_t marks_32bit;           /* 0: derived mark offsets stay 8 bytes; auto: 4 bytes when the index has < 2^32 rows [FEMTO_AMD_SA32] */
+  int32_t context_mid_table;     /* 1: a third context table of the length half way between the other two; auto: none [FEMTO_AMD_CTXM] */
+  int32_t reserved0;             /* (keeps the struct a multiple of 8 bytes) */
 } femto_amd_options_t;
 void femto_amd_options_init(femto_amd_options_t* opts);
 /* femto_amd_open with options (NULL = all auto = femto_amd_open) */

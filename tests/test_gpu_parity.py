@@ -1462,7 +1462,8 @@ def test_open_with_options(fixtures, gpu_ok, name):
     variants = [dict(level_table_syms=2), dict(level_table=0), dict(dense_arrays=0), dict(text=0), dict(context_table=0),
                 dict(context2_table=0, context_syms=3), dict(hbm_budget_bytes=1 << 16), dict(char_rank_lines=0), dict(rank_mode=1),
                 dict(mark_every=0), dict(tail_min=2, tail_rows=4, tail_row_cost=0), dict(rank_units=0), dict(marks_32bit=0, mark_every=3),
-                dict(hbm_budget_bytes=400_000), dict(hbm_budget_bytes=400_000, text=0), dict(level_table_syms=5, rank_units=1, dense_arrays=0)]
+                dict(hbm_budget_bytes=400_000), dict(hbm_budget_bytes=400_000, text=0), dict(level_table_syms=5, rank_units=1, dense_arrays=0),
+                dict(context_mid_table=1), dict(context_syms=4, context2_syms=10, context_mid_table=1)]
     for kw in variants:
         ix = femto_amd.Index(fx.index, device=0, options=kw)
         pi = ix.pack_info()
@@ -1485,6 +1486,10 @@ def test_open_with_options(fixtures, gpu_ok, name):
             assert not pi["sa_full"]
         if kw.get("context_table") == 0:
             assert not pi["context_table"]
+        if "context_mid_table" not in kw:
+            assert pi["context_mid_syms"] == 0
+        if name == "eng2doc" and kw == dict(context_syms=4, context2_syms=10, context_mid_table=1):
+            assert pi["context_syms"] == 4 and pi["context2_syms"] == 10 and pi["context_mid_syms"] == 7, pi   # the table half way between
         if "hbm_budget_bytes" in kw:
             assert not pi["sa_full"] and not pi.get("char_rank_lines"), pi
         if kw.get("rank_mode") == 1:
@@ -1519,7 +1524,7 @@ def test_level_table_deep_entries_recomputed(fixtures, gpu_ok, monkeypatch, name
             ix.close()
 
 
-@pytest.mark.parametrize("name,mode", [("acgt48k", 3), ("eng2doc", 4), ("runs3doc", 4)])
+@pytest.mark.parametrize("name,mode", [("acgt48k", 3), ("eng2doc", 4), ("runs3doc", 4), ("eng2doc", "mid"), ("runs3doc", "mid")])
 def test_pattern_window_every_alignment_and_length(fixtures, gpu_ok, name, mode):
     """The count kernel reads a lane's symbols through aligned 16-byte pieces whose phase depends on the pattern's address
     and length (direct_kernels.hip.hpp): every start address mod 16 bytes x every length 0 .. 150 (one window, its last
@@ -1527,7 +1532,12 @@ def test_pattern_window_every_alignment_and_length(fixtures, gpu_ok, name, mode)
     one symbol, laid out in the symbol buffer with caller-chosen gaps -- device entry points against the oracle."""
     import torch
     fx = fixtures(name)
-    ix = _open(fx.index, mode)
+    if mode == "mid":      # ... and with the third context table (context_mid_table: patterns between the two tables' lengths)
+        ix = femto_amd.Index(fx.index, device=0, options=dict(context_mid_table=1, context_syms=3, context2_syms=9))
+        pi = ix.pack_info()
+        assert (pi["context_syms"], pi["context_mid_syms"], pi["context2_syms"]) == (3, 6, 9), pi
+    else:
+        ix = _open(fx.index, mode)
     o = po.Oracle(fx.index)
     prepared = fx.prepared_text()
     rng = np.random.Generator(np.random.PCG64(4242))
