@@ -968,8 +968,8 @@ def main():
             assert rc == 0
         hs = min(hts[1:])
         extra["host_pointer_count"] = {"what": "femto_amd_count_flat on the same 10M-pattern batch, pageable host arrays in and out (staging threads + PCIe + kernels, pipelined in "
-                                               "1M-pattern stages, three in flight); value = fastest of 5 calls after a warm-up (single calls run 2-3x longer when the 128 spinning "
-                                               "staging threads exhaust the container's CPU quota -- cgroup_cpu_quota CPUs on average: mean_ms)",
+                                               "1M-pattern stages, three in flight); value = fastest of 5 calls after a warm-up (single calls run longer once the spinning "
+                                               "staging threads have spent the container's CPU quota -- cgroup_cpu_quota CPUs on average: mean_ms)",
                                        "value": npats / hs, "unit": "patterns/s", "ms": 1e3 * hs, "mean_ms": 1e3 * sum(hts[1:]) / len(hts[1:]),
                                        "host_hardware_threads": os.cpu_count(), "cgroup_cpu_quota": cpu_quota(),
                                        "equal_to_device_path": bool(np.array_equal(hf_, first) and np.array_equal(hl_, last))}

@@ -1524,7 +1524,7 @@ def test_level_table_deep_entries_recomputed(fixtures, gpu_ok, monkeypatch, name
             ix.close()
 
 
-@pytest.mark.parametrize("name,mode", [("acgt48k", 3), ("eng2doc", 4), ("runs3doc", 4), ("eng2doc", "mid"), ("runs3doc", "mid")])
+@pytest.mark.parametrize("name,mode", [("acgt48k", 3), ("eng2doc", 4), ("runs3doc", 4), ("eng2doc", "mid")])
 def test_pattern_window_every_alignment_and_length(fixtures, gpu_ok, name, mode):
     """The count kernel reads a lane's symbols through aligned 16-byte pieces whose phase depends on the pattern's address
     and length (direct_kernels.hip.hpp): every start address mod 16 bytes x every length 0 .. 150 (one window, its last
@@ -1533,9 +1533,9 @@ def test_pattern_window_every_alignment_and_length(fixtures, gpu_ok, name, mode)
     import torch
     fx = fixtures(name)
     if mode == "mid":      # ... and with the third context table (context_mid_table: patterns between the two tables' lengths)
-        ix = femto_amd.Index(fx.index, device=0, options=dict(context_mid_table=1, context_syms=3, context2_syms=9))
+        ix = femto_amd.Index(fx.index, device=0, options=dict(two_level_lines=1, rank_mode=4, context_mid_table=1, context_syms=3, context2_syms=9))
         pi = ix.pack_info()
-        assert (pi["context_syms"], pi["context_mid_syms"], pi["context2_syms"]) == (3, 6, 9), pi
+        assert ix.rank_mode == 4 and (pi["context_syms"], pi["context_mid_syms"], pi["context2_syms"]) == (3, 6, 9), pi
     else:
         ix = _open(fx.index, mode)
     o = po.Oracle(fx.index)
