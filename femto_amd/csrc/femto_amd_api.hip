@@ -351,9 +351,12 @@ int reserve_plan_sums(Scratch& S, int64_t nblocks, bool fold, hipStream_t stream
 // three dependent lines, so it pays from four symbols to go (measured: cfg 3 5.22 -> 5.08 ms against the hand-over
 // thresholds 12 / 10).  Packed lines (<= 8 characters): only once the row has survived two steps -- a random pattern's
 // last row usually dies on the next step, one line, and 10 M random DNA 20-mers ran 0.86 instead of 0.65 ms when they
-// jumped at once; a pattern that occurs pays two lines more.
+// jumped at once; a pattern that occurs pays two lines more.  With the rank units a step is ONE line, so three symbols to go
+// cost the same three requests either way -- but a tail also hands the row's text position to the row expansion, which then
+// skips its suffix-array read: from three symbols on small alphabets (cfg 5, whose 20-mers leave the K = 16 table with ~2
+// rows and reach one row a step or two later: 1.53 -> 1.47 ms/step, rows 0.28 -> 0.18 ms; two symbols: 1.48; cfg 3: no change).
 void inline_tail_setup(const femto_amd_index* ix, DevIndex& d) {
-  d.tail_min = 4;
+  d.tail_min = ix->mode == 3 ? 3 : 4;
   d.tail_ones = ix->mode == 3 ? 2 : 0;
   d.tail_min = std::max(2, int(knob(ix->opt.tail_min, "FEMTO_AMD_TAIL_MIN", d.tail_min)));
   d.tail_ones = std::max(0, int(knob(ix->opt.tail_ones, "FEMTO_AMD_TAIL_ONES", d.tail_ones)));
