@@ -407,3 +407,39 @@ def test_host_key_packing_simd_equals_scalar_equals_definition(bits, alphabet):
         for force in (0, 1):
             assert fn(dense.ctypes.data, 261, bits, len(lens), long_lens.ctypes.data, big.ctypes.data, starts.ctypes.data, force,
                       keys.ctypes.data, None) == 0
+
+
+def test_host_key_packing_never_reads_past_the_last_symbol():
+    """The AVX-512 loop loads 32 symbols' worth of lanes per pattern with the lanes beyond the pattern masked off: a pattern that
+    ends on the last bytes of a mapped page, with an inaccessible page behind it, must pack without a fault (and equal the scalar keys)."""
+    import mmap
+    lib = femto_amd.lib()
+    fn = lib.femto_amd_host_pack_keys
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    libc = C.CDLL(None, use_errno=True)
+    libc.mprotect.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    page = mmap.PAGESIZE
+    m = mmap.mmap(-1, 2 * page)
+    base = C.addressof(C.c_char.from_buffer(m))
+    assert libc.mprotect(base + page, page, 0) == 0          # PROT_NONE behind the first page
+    try:
+        dense = np.zeros(261, dtype=np.uint8)
+        for rank, ch in enumerate(b"ACGT"):
+            dense[ch + 5] = rank + 1
+        nsym_page = page // 2
+        flat = np.frombuffer(m, dtype=np.uint16, count=nsym_page)      # the accessible page as symbols
+        rng = np.random.default_rng(9)
+        flat[:] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, nsym_page)].astype(np.uint16) + 5
+        lens = np.array([1, 2, 7, 8, 9, 15, 16, 17, 20, 21], dtype=np.int32)
+        starts = (nsym_page - lens).astype(np.int64)                   # every pattern ends with the page
+        want, ok = _pack_keys_reference(dense, 3, lens, flat, starts)
+        assert ok
+        for force in (1, 0):
+            keys = np.zeros(len(lens), dtype=np.uint64)
+            assert fn(dense.ctypes.data, 261, 3, len(lens), lens.ctypes.data, base, starts.ctypes.data, force, keys.ctypes.data, None) == 1
+            assert np.array_equal(keys, want), force
+        del flat
+    finally:
+        libc.mprotect(base + page, page, 3)
+        m.close()
