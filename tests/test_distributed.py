@@ -6,6 +6,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -45,12 +46,13 @@ def _worker(rank, world, port, index_path, npz, q):
     dist.destroy_process_group()
 
 
-def test_sharded_count_and_locate_world2_gloo(fixtures):
+@pytest.mark.parametrize("world", [2, 3])      # 3: shards of unequal size
+def test_sharded_count_and_locate_world2_gloo(fixtures, world):
     fx = fixtures("eng2doc")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, fx.index, os.path.join(GOLDEN, "eng2doc.npz"), q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fx.index, os.path.join(GOLDEN, "eng2doc.npz"), q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
