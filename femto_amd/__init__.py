@@ -99,6 +99,31 @@ class Nfa:
         finally:
             lib().femto_amd_regexp_free(h)
 
+    @classmethod
+    def from_query(cls, query, icase=False, streamline=True):
+        """femto_amd_query_compile: a whole femto_search query prepared as search_tool.cc prepares it (streamline_query,
+        simplify_query, --icase).  Returns (Nfa, literal alpha codes or None, the query echoed as ast_to_string prints it)."""
+        q = np.frombuffer(bytes(query) + b"\0", dtype=np.uint8)
+        h = C.c_void_p()
+        _check(lib().femto_amd_query_compile(_ptr(q), len(query), (1 if icase else 0) | (0 if streamline else 2), C.byref(h)))
+        try:
+            v = lib().femto_amd_regexp_nfa(h).contents
+            n, t = v.num_nodes, v.num_transitions
+
+            def arr(p, count, ct):
+                return np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(count,)).copy() if count else np.zeros(0, dtype=ct)
+
+            a = cls(arr(v.trans_start, n + 1, C.c_int32), arr(v.trans_char, t, C.c_int32), arr(v.trans_dest, t, C.c_int32),
+                    arr(v.is_start, n, C.c_uint8), arr(v.is_final, n, C.c_uint8),
+                    (v.cost_bound, v.subst_cost, v.delete_cost, v.insert_cost))
+            sp, sn = C.c_void_p(), C.c_int64(0)
+            lit = None
+            if lib().femto_amd_regexp_literal(h, C.byref(sp), C.byref(sn)):
+                lit = arr(sp, sn.value, C.c_uint16)
+            return a, lit, lib().femto_amd_regexp_echo(h)
+        finally:
+            lib().femto_amd_regexp_free(h)
+
     def struct(self):
         return NfaStruct(self.num_nodes, len(self.trans_char), self.trans_start.ctypes.data, self.trans_char.ctypes.data,
                          self.trans_dest.ctypes.data, self.is_start.ctypes.data, self.is_final.ctypes.data, *self.settings)
@@ -181,6 +206,11 @@ def lib():
         L.femto_amd_build_index.argtypes = [C.c_char_p, i32, vp, vp, vp, C.c_char_p, i32]
         L.femto_amd_build_index_from_sa.argtypes = [C.c_char_p, i32, vp, vp, vp, C.c_char_p, vp]
         L.femto_amd_forward_steps.argtypes = [vp, i64, vp, vp, vp, vp]
+        L.femto_amd_query_compile.argtypes = [vp, i64, i32, C.POINTER(vp)]
+        L.femto_amd_regexp_literal.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+        L.femto_amd_regexp_echo.argtypes = [vp]
+        L.femto_amd_regexp_echo.restype = C.c_char_p
+        L.femto_amd_query_echo.argtypes = [vp, i64, i32, i32, vp, i64]
         L.femto_amd_set_rank_mode.argtypes = [vp, i32]
         L.femto_amd_get_rank_mode.argtypes = [vp]
         L.femto_amd_pack_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(i32)]
@@ -565,6 +595,15 @@ def regexp_match(regex, s):
     sb = np.frombuffer(bytes(s) + b"\0", dtype=np.uint8)
     r = lib().femto_amd_regexp_match(_ptr(rx), len(regex), _ptr(sb), len(s))
     return None if r < 0 else bool(r)
+
+
+def query_echo(query, streamline=True, usequotes=False):
+    """test hook: the query parsed, streamlined (streamline_query) or not, and printed back as ast_to_string prints it
+    (None: syntax error)"""
+    q = np.frombuffer(bytes(query) + b"\0", dtype=np.uint8)
+    buf = C.create_string_buffer(8 * len(query) + 64)
+    r = lib().femto_amd_query_echo(_ptr(q), len(query), int(streamline), int(usequotes), buf, len(buf))
+    return None if r < 0 else buf.raw[:r]
 
 
 def bseq_encode(raw_bytes, bitlen, force_type=0):

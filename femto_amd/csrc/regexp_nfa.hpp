@@ -3,9 +3,8 @@
 //
 // The reference parses a query with a flex/bison grammar into an AST, reverses it (reverse_regexp), compiles it to a
 // Thompson NFA and removes the epsilon edges (src/main/compile_regexp.c:658-705); do_regexp_query (src/main/server.c:1656)
-// then walks the index backwards simulating that automaton.  Here the pattern language is the byte-regular-expression part
-// of src/main/QUERY_FORMAT.txt (literals, `.`, `[...]` classes, `( )`, `|`, `*`, `+`, `?`, backslash escapes, quotes;
-// unescaped whitespace separates terms and is ignored), without the boolean keywords; the automaton handed to the search is
+// then walks the index backwards simulating that automaton.  The pattern language is femto's (query_parser.hpp restates the
+// scanner and the grammar rule by rule, without the boolean operators); the automaton handed to the search is
 // the Glushkov (position) automaton of the reversed pattern -- epsilon-free by construction, one node per character
 // position plus the start node.  The reference's front end cannot be generated in this image (no flex/bison), so parity is
 // pinned one level below it: the SAME nfa_description_t is fed to the genuine do_regexp_query through
@@ -64,204 +63,6 @@ struct RegexNfa {
 using StateSet = std::vector<uint64_t>;
 inline bool ss_get(const StateSet& s, int i) { return (s[size_t(i) >> 6] >> (i & 63)) & 1u; }
 inline void ss_set(StateSet& s, int i) { s[size_t(i) >> 6] |= uint64_t(1) << (i & 63); }
-
-// ---- parser (recursive descent) -----------------------------------------------------------------------------------
-class RegexParser {
- public:
-  RegexParser(const uint8_t* p, int64_t n, RegexNfa* nfa) : p_(p), n_(n), nfa_(nfa) {}
-  // returns false with *err set on a syntax error
-  bool parse(std::string* err) {
-    if (n_ > kRegexMaxLen) { *err = "pattern text too long"; return false; }
-    Frag f;
-    if (!alt(&f)) { *err = err_; return false; }
-    if (nfa_->too_large) { *err = "regular expression too large"; return false; }
-    skip_ws();
-    if (at_ < n_) { *err = "unexpected '" + std::string(1, char(p_[at_])) + "'"; return false; }
-    nfa_->start = f.in;
-    nfa_->accept = f.out;
-    nfa_->finish();
-    if (nfa_->size() > kRegexMaxStates) { *err = "regular expression too large"; return false; }
-    return true;
-  }
-
- private:
-  struct Frag { int in, out; };
-  const uint8_t* p_;
-  int64_t n_, at_ = 0;
-  RegexNfa* nfa_;
-  int depth_ = 0;
-  std::string err_;
-  bool fail(const std::string& m) { err_ = m; return false; }
-  void skip_ws() { while (at_ < n_ && (p_[at_] == ' ' || p_[at_] == '\t' || p_[at_] == '\n' || p_[at_] == '\r')) at_++; }
-  Frag lit(const CharClass& c) {
-    const int a = nfa_->add(), b = nfa_->add();
-    nfa_->cls[size_t(a)] = c;
-    nfa_->to[size_t(a)] = b;
-    return {a, b};
-  }
-  Frag empty() {
-    const int a = nfa_->add(), b = nfa_->add();
-    nfa_->eps[size_t(a)].push_back(b);
-    return {a, b};
-  }
-  bool escape(int* byte) {   // after the backslash (QUERY_FORMAT.txt "QUOTING")
-    if (at_ >= n_) return fail("dangling backslash");
-    const uint8_t c = p_[at_++];
-    switch (c) {
-      case 'n': *byte = 0x0a; return true;
-      case 't': *byte = 0x09; return true;
-      case 'r': *byte = 0x0d; return true;
-      case 'b': *byte = 0x08; return true;
-      case 'f': *byte = 0x0c; return true;
-      case 'a': *byte = 0x07; return true;
-      case 'e': *byte = 0x1b; return true;
-      case 'v': *byte = 0x0b; return true;
-      case 'x': {
-        int v = 0;
-        for (int k = 0; k < 2; k++) {
-          if (at_ >= n_) return fail("\\x needs two hexadecimal digits");
-          const uint8_t h = p_[at_++];
-          int d;
-          if (h >= '0' && h <= '9') d = h - '0';
-          else if (h >= 'a' && h <= 'f') d = h - 'a' + 10;
-          else if (h >= 'A' && h <= 'F') d = h - 'A' + 10;
-          else return fail("\\x needs two hexadecimal digits");
-          v = v * 16 + d;
-        }
-        *byte = v;
-        return true;
-      }
-      default: *byte = c; return true;
-    }
-  }
-  bool char_class(Frag* out) {   // after '['
-    CharClass cc;
-    bool neg = false;
-    if (at_ < n_ && p_[at_] == '^') { neg = true; at_++; }
-    bool first = true;
-    for (;;) {
-      if (at_ >= n_) return fail("unterminated [");
-      int lo = p_[at_++];
-      if (lo == ']' && !first) break;
-      if (lo == '\\' && !escape(&lo)) return false;
-      int hi = lo;
-      if (at_ + 1 < n_ && p_[at_] == '-' && p_[at_ + 1] != ']') {
-        at_++;
-        hi = p_[at_++];
-        if (hi == '\\' && !escape(&hi)) return false;
-        if (hi < lo) return fail("reversed range in [ ]");
-      }
-      for (int b = lo; b <= hi; b++) cc.set_byte(b);
-      first = false;
-    }
-    if (neg) cc.invert_bytes();
-    *out = lit(cc);
-    return true;
-  }
-  bool quoted(uint8_t q, Frag* out) {   // "..." honours escapes, '...' is literal
-    Frag f = empty();
-    for (;;) {
-      if (at_ >= n_) return fail("unterminated quote");
-      if (nfa_->too_large) return fail("regular expression too large");
-      int c = p_[at_++];
-      if (c == q) break;
-      if (q == '"' && c == '\\' && !escape(&c)) return false;
-      CharClass cc;
-      cc.set_byte(c);
-      const Frag g = lit(cc);
-      nfa_->eps[size_t(f.out)].push_back(g.in);
-      f.out = g.out;
-    }
-    *out = f;
-    return true;
-  }
-  bool atom(Frag* out) {
-    skip_ws();
-    if (at_ >= n_) return fail("pattern ends where a term was expected");
-    const uint8_t c = p_[at_];
-    if (c == '(') {
-      at_++;
-      if (++depth_ > kRegexMaxDepth) return fail("parentheses nested too deeply");   // the descent recurses per '(': bound the stack
-      const bool ok = alt(out);
-      depth_--;
-      if (!ok) return false;
-      skip_ws();
-      if (at_ >= n_ || p_[at_] != ')') return fail("missing )");
-      at_++;
-      return true;
-    }
-    if (c == '[') { at_++; return char_class(out); }
-    if (c == '"' || c == '\'') { at_++; return quoted(c, out); }
-    if (c == '.') {
-      at_++;
-      CharClass cc;
-      for (int b = 0; b < 256; b++) cc.set_byte(b);
-      *out = lit(cc);
-      return true;
-    }
-    if (c == ')' || c == '|' || c == '*' || c == '+' || c == '?' || c == ']' || c == '{' || c == '}')
-      return fail(std::string("unexpected '") + char(c) + "'");
-    at_++;
-    int b = c;
-    if (c == '\\' && !escape(&b)) return false;
-    CharClass cc;
-    cc.set_byte(b);
-    *out = lit(cc);
-    return true;
-  }
-  bool repeat(Frag* out) {
-    Frag f;
-    if (!atom(&f)) return false;
-    for (;;) {
-      skip_ws();
-      if (at_ >= n_) break;
-      const uint8_t c = p_[at_];
-      if (c != '*' && c != '+' && c != '?') break;
-      at_++;
-      const int a = nfa_->add(), b = nfa_->add();
-      nfa_->eps[size_t(a)].push_back(f.in);
-      nfa_->eps[size_t(f.out)].push_back(b);
-      if (c == '*' || c == '?') nfa_->eps[size_t(a)].push_back(b);      // zero times
-      if (c == '*' || c == '+') nfa_->eps[size_t(f.out)].push_back(f.in); // again
-      f = {a, b};
-    }
-    *out = f;
-    return true;
-  }
-  bool concat(Frag* out) {
-    Frag f = empty();
-    for (;;) {
-      skip_ws();
-      if (at_ >= n_ || p_[at_] == '|' || p_[at_] == ')') break;
-      if (nfa_->too_large) return fail("regular expression too large");
-      Frag g;
-      if (!repeat(&g)) return false;
-      nfa_->eps[size_t(f.out)].push_back(g.in);
-      f.out = g.out;
-    }
-    *out = f;
-    return true;
-  }
-  bool alt(Frag* out) {
-    Frag f;
-    if (!concat(&f)) return false;
-    skip_ws();
-    while (at_ < n_ && p_[at_] == '|') {
-      at_++;
-      Frag g;
-      if (!concat(&g)) return false;
-      const int a = nfa_->add(), b = nfa_->add();
-      nfa_->eps[size_t(a)].push_back(f.in);
-      nfa_->eps[size_t(a)].push_back(g.in);
-      nfa_->eps[size_t(f.out)].push_back(b);
-      nfa_->eps[size_t(g.out)].push_back(b);
-      f = {a, b};
-      skip_ws();
-    }
-    *out = f;
-    return true;
-  }
-};
 
 // ---- simulation helpers ---------------------------------------------------------------------------------------------
 // closure under REVERSED epsilon edges (in place)

@@ -34,6 +34,7 @@
 #include "ind_kernels.hip.hpp"
 #include "text_kernels.hip.hpp"
 #include "regexp_nfa.hpp"
+#include "query_parser.hpp"
 
 using namespace femto_amd;
 
@@ -578,10 +579,13 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   API_END
 }
 
-// ---- regular expressions: pattern text -> automaton (regexp_nfa.hpp) --------------------------------------------------------
+// ---- regular expressions: pattern text -> automaton (query_parser.hpp, regexp_nfa.hpp) ----------------------------------------
 struct femto_amd_regexp {
   NfaDesc desc;
   femto_amd_nfa_t view;
+  bool literal = false;                 // simplify_query: the query is one string
+  std::vector<uint16_t> literal_syms;
+  std::string echo;                     // ast_to_string(ast, 0, 1)
 };
 
 static int settings_check(int max_cost, int subst_cost, int delete_cost, int insert_cost) {
@@ -594,24 +598,24 @@ static int settings_check(int max_cost, int subst_cost, int delete_cost, int ins
   return 0;
 }
 
-int femto_amd_regexp_compile(const uint8_t* regex, int64_t regex_len, int max_cost, int subst_cost, int delete_cost, int insert_cost,
-                             femto_amd_regexp_t** out) {
-  API_BEGIN
-  if (!out || (regex_len && !regex) || regex_len < 0) return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
-  *out = nullptr;
-  int rc = settings_check(max_cost, subst_cost, delete_cost, insert_cost);
+// tree -> automaton + the handle's views; the tree's own APPROX settings are already in q
+static int finish_regexp(QRegexp& q, femto_amd_regexp_t** out) {
+  int rc = settings_check(q.cost_bound - 1, q.subst_cost, q.delete_cost, q.insert_cost);
   if (rc) return rc;
+  std::unique_ptr<femto_amd_regexp> r(new femto_amd_regexp());
+  r->literal = q_simple(q, &r->literal_syms);
+  if (!r->literal) r->literal_syms.clear();
+  q_echo(q, r->echo, true);
   RegexNfa nfa;
   std::string perr;
-  RegexParser parser(regex, regex_len, &nfa);
-  if (!parser.parse(&perr)) return set_err(FEMTO_AMD_ERR_PARAM, "regular expression: " + perr);
-  std::unique_ptr<femto_amd_regexp> r(new femto_amd_regexp());
+  QueryCompiler comp(&nfa);
+  if (!comp.compile(q, &perr)) return set_err(FEMTO_AMD_ERR_PARAM, "regular expression: " + perr);
   if (!build_reversed_nfa(nfa, &r->desc)) return set_err(FEMTO_AMD_ERR_PARAM, "regular expression: too many transitions");
   if (r->desc.num_nodes > kNfaMaxNodes) return set_err(FEMTO_AMD_ERR_PARAM, "regular expression too large");
-  r->desc.cost_bound = max_cost + 1;
-  r->desc.subst_cost = std::min(subst_cost, kNfaDead);
-  r->desc.delete_cost = std::min(delete_cost, kNfaDead);
-  r->desc.insert_cost = std::min(insert_cost, kNfaDead);
+  r->desc.cost_bound = q.cost_bound;
+  r->desc.subst_cost = std::min(q.subst_cost, kNfaDead);
+  r->desc.delete_cost = std::min(q.delete_cost, kNfaDead);
+  r->desc.insert_cost = std::min(q.insert_cost, kNfaDead);
   femto_amd_nfa_t& v = r->view;
   v.num_nodes = r->desc.num_nodes;
   v.num_transitions = int32_t(r->desc.trans_char.size());
@@ -626,7 +630,82 @@ int femto_amd_regexp_compile(const uint8_t* regex, int64_t regex_len, int max_co
   v.insert_cost = r->desc.insert_cost;
   *out = r.release();
   return FEMTO_AMD_OK;
+}
+
+int femto_amd_regexp_compile(const uint8_t* regex, int64_t regex_len, int max_cost, int subst_cost, int delete_cost, int insert_cost,
+                             femto_amd_regexp_t** out) {
+  API_BEGIN
+  if (!out || (regex_len && !regex) || regex_len < 0) return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
+  *out = nullptr;
+  int rc = settings_check(max_cost, subst_cost, delete_cost, insert_cost);
+  if (rc) return rc;
+  QRegexp q;
+  std::string perr;
+  if (!parse_query(regex, regex_len, &q, &perr)) return set_err(FEMTO_AMD_ERR_PARAM, "regular expression: " + perr);
+  if (q.cost_bound == 1) {               // no APPROX in the text: the arguments decide
+    q.cost_bound = max_cost + 1;
+    q.subst_cost = subst_cost;
+    q.delete_cost = delete_cost;
+    q.insert_cost = insert_cost;
+  }
+  return finish_regexp(q, out);
   API_END
+}
+
+int femto_amd_query_compile(const uint8_t* query, int64_t query_len, int flags, femto_amd_regexp_t** out) {
+  API_BEGIN
+  if (!out || (query_len && !query) || query_len < 0) return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
+  *out = nullptr;
+  QRegexp q;
+  std::string perr;
+  if (!parse_query(query, query_len, &q, &perr)) return set_err(FEMTO_AMD_ERR_PARAM, "query: " + perr);
+  if (!(flags & FEMTO_AMD_QUERY_NO_STREAMLINE)) q_streamline(q);
+  {
+    // simplify_query (ast.c:1239-1269): a query that is one string is REPLACED by a string node
+    std::vector<uint16_t> lit;
+    if (q_simple(q, &lit)) {
+      QAtom a;
+      a.kind = QAtom::STRING;
+      a.str.swap(lit);
+      QSequence seq;
+      seq.atoms.push_back(std::move(a));
+      q.choices.clear();
+      q.choices.push_back(std::move(seq));
+    }
+  }
+  if (flags & FEMTO_AMD_QUERY_ICASE) {
+    // search_tool.cc:732-751: the string is extracted (simplify_query) BEFORE icase_ast widens it
+    q_icase(q);
+  }
+  return finish_regexp(q, out);
+  API_END
+}
+
+int femto_amd_regexp_literal(const femto_amd_regexp_t* r, const uint16_t** syms, int64_t* n) {
+  if (!r) return 0;
+  if (syms) *syms = r->literal ? r->literal_syms.data() : nullptr;
+  if (n) *n = r->literal ? int64_t(r->literal_syms.size()) : 0;
+  return r->literal ? 1 : 0;
+}
+
+const char* femto_amd_regexp_echo(const femto_amd_regexp_t* r) { return r ? r->echo.c_str() : ""; }
+
+/* test hook (src/main/query_planning_test.c): parse, optionally streamline, and print the tree back as ast_to_string does */
+int femto_amd_query_echo(const uint8_t* query, int64_t query_len, int streamline, int usequotes, char* out, int64_t cap) {
+  try {
+    if ((query_len && !query) || query_len < 0 || !out || cap < 1) return -1;
+    QRegexp q;
+    std::string perr;
+    if (!parse_query(query, query_len, &q, &perr)) { set_err(FEMTO_AMD_ERR_PARAM, "query: " + perr); return -1; }
+    if (streamline) q_streamline(q);
+    std::string o;
+    q_echo(q, o, usequotes != 0);
+    if (int64_t(o.size()) + 1 > cap) return -1;
+    std::memcpy(out, o.c_str(), o.size() + 1);
+    return int(o.size());
+  } catch (...) {
+    return -1;
+  }
 }
 
 const femto_amd_nfa_t* femto_amd_regexp_nfa(const femto_amd_regexp_t* r) { return r ? &r->view : nullptr; }
@@ -677,10 +756,12 @@ int femto_amd_regexp_search(femto_amd_index_t* ix, const uint8_t* regex, int64_t
 int femto_amd_regexp_match(const uint8_t* regex, int64_t regex_len, const uint8_t* s, int64_t len) {
   try {
     if ((regex_len && !regex) || (len && !s) || regex_len < 0 || len < 0) return -1;
-    RegexNfa nfa;
+    QRegexp q;
     std::string perr;
-    RegexParser parser(regex, regex_len, &nfa);
-    if (!parser.parse(&perr)) { set_err(FEMTO_AMD_ERR_PARAM, "regular expression: " + perr); return -1; }
+    if (!parse_query(regex, regex_len, &q, &perr)) { set_err(FEMTO_AMD_ERR_PARAM, "regular expression: " + perr); return -1; }
+    RegexNfa nfa;
+    QueryCompiler comp(&nfa);
+    if (!comp.compile(q, &perr)) { set_err(FEMTO_AMD_ERR_PARAM, "regular expression: " + perr); return -1; }
     return nfa_full_match(nfa, s, len) ? 1 : 0;
   } catch (...) {
     return -1;

@@ -233,19 +233,38 @@ typedef struct femto_amd_nfa {
 int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_amd_nfa_t* nfas, int64_t max_results,
                                int64_t* result_start /* nq + 1 */, int64_t* first_out, int64_t* last_out, int32_t* len_out,
                                int32_t* cost_out, int32_t* status_out, int64_t* n_out);
-/* Pattern text -> automaton.  Pattern language: the byte-regular-expression part of src/main/QUERY_FORMAT.txt -- literal
- * bytes, `.`, `[a-z]` / `[^...]`, `( )`, `|`, `*`, `+`, `?`, backslash escapes (\n \t \xNN ...), "double" and 'single'
- * quotes; unescaped whitespace separates terms and is ignored; no boolean keywords.  The automaton is the position
- * (Glushkov) automaton of the reversed pattern.  (The reference's own front end -- flex/bison grammar, compile_regexp.c --
- * cannot be generated in this image; parity is pinned at the automaton: the same femto_amd_nfa_t goes to the genuine
- * do_regexp_query and to femto_amd_nfa_search_batch.)  APPROX (QUERY_FORMAT.txt "APPROXIMATE SEARCH",
- * max_cost:subst_cost:delete_cost:insert_cost): cost_bound = max_cost + 1, validated as compile_regexp_from_ast does
- * (compile_regexp.c:673-685: three substitutions or insertions are refused).  Limits: 2^20 bytes of pattern text,
- * parentheses nested 256 deep, 4096 Thompson states: beyond them FEMTO_AMD_ERR_PARAM, never a crash. */
+/* Pattern text -> automaton.  Pattern language: femto's own (src/main/QUERY_FORMAT.txt), restated token rule by token rule
+ * and production by production from src/main/posix.flex.l and src/main/posix.bison.y (femto_amd/csrc/query_parser.hpp names
+ * the corners): literal bytes, `.`, `[a-z]` / `[^...]`, `( )`, `|`, one of `*` `+` `?` `{m}` `{m,}` `{m,n}` per term, backslash
+ * escapes (\n \t \xNN, \x-NN for the codes below the bytes), "double" and 'single' quotes, `{x 00 01}` hex strings, `#`
+ * comments, runs of three or more letters as one term; unescaped whitespace separates terms and is ignored; a leading
+ * APPROX [max_cost[:subst[:delete[:insert]]]] sets the costs.  The boolean operators (AND OR NOT THEN WITHIN: document-level
+ * result sets) are recognised and refused.  The automaton is the position (Glushkov) automaton of the reversed pattern.
+ * (The reference's generated front end -- flex/bison, then compile_regexp.c -- cannot be built in this image; search parity
+ * is pinned at the automaton: the same femto_amd_nfa_t goes to the genuine do_regexp_query and to
+ * femto_amd_nfa_search_batch; the grammar is pinned by the known answers of src/main/query_planning_test.c and by the
+ * query set of src/test/test.pl.)  APPROX costs are validated as compile_regexp_from_ast does (compile_regexp.c:673-685:
+ * three substitutions or insertions are refused).  Limits: 2^20 bytes of pattern text, parentheses nested 256 deep,
+ * repeat counts <= 4096, 4096 Thompson states: beyond them FEMTO_AMD_ERR_PARAM, never a crash. */
 typedef struct femto_amd_regexp femto_amd_regexp_t;
 int femto_amd_regexp_compile(const uint8_t* regex, int64_t regex_len, int max_cost, int subst_cost, int delete_cost,
                              int insert_cost, femto_amd_regexp_t** out);
 const femto_amd_nfa_t* femto_amd_regexp_nfa(const femto_amd_regexp_t* r);   /* valid until femto_amd_regexp_free */
+/* A whole femto_search query, prepared as src/main_cc/search_tool.cc:716-751 prepares it: parse_string, then streamline_query
+ * (src/main/query_planning.c:24: optional parts at either end of the pattern are dropped and repeats there trimmed to their
+ * minimum -- "a*(bc|d)+" is searched as "(bc|d)"), simplify_query (ast.c:1239: a query without alternatives is ONE string),
+ * and, with FEMTO_AMD_QUERY_ICASE, icase_ast (ast.c:556; femto_search --icase).  An APPROX prefix in the text sets the costs. */
+#define FEMTO_AMD_QUERY_ICASE 1
+#define FEMTO_AMD_QUERY_NO_STREAMLINE 2
+int femto_amd_query_compile(const uint8_t* query, int64_t query_len, int flags, femto_amd_regexp_t** out);
+/* 1 when the prepared query is one plain string (search it with femto_amd_count_flat / _locate_flat as femto_search runs a
+ * string query, src/main/server.c:713): *syms / *n its alpha codes, owned by r; 0 otherwise */
+int femto_amd_regexp_literal(const femto_amd_regexp_t* r, const uint16_t** syms, int64_t* n);
+/* the prepared query printed back as ast_to_string(ast, 0, 1) prints it (src/main/ast.c:1122; femto_search --json "pattern") */
+const char* femto_amd_regexp_echo(const femto_amd_regexp_t* r);
+/* test hook for the known answers of src/main/query_planning_test.c: parse, streamline (or not), print back with or without
+ * quotes into out[cap]; returns the length, -1 on a syntax error or a buffer too small */
+int femto_amd_query_echo(const uint8_t* query, int64_t query_len, int streamline, int usequotes, char* out, int64_t cap);
 void femto_amd_regexp_free(femto_amd_regexp_t* r);
 /* compile + search, a batch of patterns with the same costs (max_cost = 0, costs 1: exact) */
 int femto_amd_regexp_search_batch(femto_amd_index_t* ix, int64_t nq, const uint8_t* const* regex, const int64_t* regex_len,

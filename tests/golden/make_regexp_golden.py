@@ -96,7 +96,7 @@ def main():
             index = os.path.join(td, "index")
             docs = [np.fromfile(os.path.join(td, f), dtype=np.uint8) for f in sorted(os.listdir(td)) if f.startswith("doc")]
             text_chars = np.unique(np.concatenate(docs)).astype(np.int32) + 5
-            labelled = [(femto_amd.Nfa.from_regex(p), p, (0, 1, 1, 1)) for p in pats]
+            labelled = [(femto_amd.Nfa.from_regex(p or b"''"), p, (0, 1, 1, 1)) for p in pats]      # '' is femto's spelling of the empty pattern
             labelled += [(femto_amd.Nfa.from_regex(p, k), p, k) for p, k in APPROX.get(name, [])]
             rng = np.random.Generator(np.random.PCG64(sum(name.encode()) + 17))
             # characters of the text (twice: most transitions can be followed), SEOF, one character the text lacks

@@ -119,23 +119,26 @@ def test_options_struct(fixtures):
 
 
 def test_search_cli_output_formats():
-    """femto_search's text output (src/main_cc/search_tool.cc:1082-1113 and print_matches :470-519) restated as a table:
-    format string -> expected bytes for a golden result.  The reference tool itself needs flex/bison + RE2 and cannot be built
+    """femto_search's text and JSON output (src/main_cc/search_tool.cc:889-894, :1038-1048, :1075-1087, :1105-1114, print_matches
+    :470-519; alphatos src/main/index_types.h:104-118; encode_ch_json src/main/json.c:35-62) restated as a table: format
+    string -> expected bytes for a golden result.  The reference tool itself needs flex/bison + RE2 and cannot be built
     here, so its formats are RESTATED (from the printf calls cited per row), not diffed against its output; femto_amd_search
     prints through the same table (--formats) and renders a fixed result with its own print functions (--format-selftest)."""
     import subprocess
     from femto_amd import build as b
     b.build_tools()
     # (name, the reference's format string with PRIi64 = "li", source line)
-    ref = [("matches_row_head", '% 4li "', 1083), ("matches_row_tail", '"%c', 1085), ("total", "% 4li total matches%c", 1112),
-           ("doc_info", "%.*s", 478), ("doc_sep", "%c%s", 477), ("offsets_lead", "%c\t", 480), ("offset", " %li", 499), ("list_end", "%c", 519)]
+    ref = [("matches_row_head", '% 4li "', "1084"), ("matches_row_tail", '"%c', "1086"), ("total", "% 4li total matches%c", "1112"),
+           ("doc_info", "%.*s", "478"), ("doc_sep", "%c%s", "477"), ("offsets_lead", "%c\\t", "480"), ("offset", " %li", "499"), ("list_end", "%c", "519"),
+           ("by_index_head", "Results from %s\\n", "1038"), ("by_index_row", '% 4li [%li,%li] "', "1046"),
+           ("json_open", '{\\n "pattern":"', "890-891"), ("json_results", '",\\n "results":[\\n   ', "893"), ("json_row_sep", ",\\n   ", "1077"),
+           ("json_total", ',\\n "total":%li', "1111"), ("json_close", "\\n}\\n", "1114")]
     rows = [r.split("\t") for r in subprocess.run([b.SEARCH, "--formats"], capture_output=True, check=True).stdout.decode().splitlines()]
-    # (offsets_lead holds a tab itself: re-join)
-    table = {r[0]: ("\t".join(r[1:-1]), r[-1]) for r in rows}
+    table = {r[0]: (r[1], r[2]) for r in rows}
     assert set(table) == {n for n, _, _ in ref}
     for name, fmt, line in ref:
         assert table[name] == (fmt, f"search_tool.cc:{line}"), name
-    f = {n: fm.replace("li", "d") for n, fm, _ in ref}      # Python's % operator renders C's "% 4li" as "% 4d"
+    f = {n: fm.replace("li", "d").replace("\\t", "\t").replace("\\n", "\n") for n, fm, _ in ref}      # Python's % renders C's "% 4li" as "% 4d"
 
     def docs(lst, offsets, sep):
         out, first = b"", True
@@ -150,10 +153,17 @@ def test_search_cli_output_formats():
 
     golden = [("doc0.txt", [3, 17, 4242]), ("dir/doc1", [0])]
     for sep, flag in (("\n", []), ("\0", ["--null"])):
+        # the matched strings go through alphatos: backslash and quote escaped, other bytes printable or \xNN, codes below the
+        # bytes \x-NN (alpha 2 = 5 - 3 is the end-of-document marker)
         want = ((f["matches_row_head"] % 7).encode() + b"the" + (f["matches_row_tail"] % sep).encode()
-                + (f["matches_row_head"] % 12345).encode() + b'a "b"' + (f["matches_row_tail"] % sep).encode()
+                + (f["matches_row_head"] % 12345).encode() + b'a \\"b\\"\\\\\\x01\\xff' + (f["matches_row_tail"] % sep).encode()
+                + (f["matches_row_head"] % 1).encode() + b"\\x-03A" + (f["matches_row_tail"] % sep).encode()
                 + (f["total"] % (12352, sep)).encode() + docs(golden, True, sep) + docs(golden, False, sep) + docs([], True, sep)
                 + (f["total"] % (0, sep)).encode())
+        # JSON (print_matches' json branches): a new document closes the one before it with "] ]," -- the offsets list of the
+        # LAST document of an index is closed by " ] ] "; '|' in an info string separates grouped documents
+        want += (b'[ ["a","b"], [3, 17] ],\n   [ ["c\\"d"], [0 ] ] ' + b',\n   [ ["e"], [ ] ] ' + b"\n"
+                 + b'q\\\\\\"\\\\\\\\\\\\x01' + b"\n")
         got = subprocess.run([b.SEARCH] + flag + ["--format-selftest"], capture_output=True, check=True).stdout
         assert got == want, (sep, got, want)
     assert want.startswith(b"   7 \"the\"\x00 12345 ")      # "% 4d": at least four columns, a blank for the sign
