@@ -206,6 +206,8 @@ def lib():
         L.femto_amd_build_index.argtypes = [C.c_char_p, i32, vp, vp, vp, C.c_char_p, i32]
         L.femto_amd_build_index_from_sa.argtypes = [C.c_char_p, i32, vp, vp, vp, C.c_char_p, vp]
         L.femto_amd_forward_steps.argtypes = [vp, i64, vp, vp, vp, vp]
+        L.femto_amd_resolve_batch.argtypes = [vp, i64, vp, vp, vp]
+        L.femto_amd_resolve_device.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp]
         L.femto_amd_query_compile.argtypes = [vp, i64, i32, C.POINTER(vp)]
         L.femto_amd_regexp_literal.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
         L.femto_amd_regexp_echo.argtypes = [vp]
@@ -442,6 +444,18 @@ class Index:
         d, o = C.c_int64(), C.c_int64()
         _check(lib().femto_amd_resolve_location(self._h, offset, C.byref(d), C.byref(o)))
         return d.value, o.value
+
+    def resolve_batch(self, offsets):
+        """femto_amd_resolve_batch: (document int64[], offset in document int64[]) for host offsets, searched on the GPU"""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        doc, off = np.zeros(len(offsets), dtype=np.int64), np.zeros(len(offsets), dtype=np.int64)
+        _check(lib().femto_amd_resolve_batch(self._h, len(offsets), _ptr(offsets), _ptr(doc), _ptr(off)))
+        return doc, off
+
+    def resolve_device(self, d_offsets, n, d_doc=0, d_doc32=0, d_doc_offset=0, d_n=0, stream=0):
+        """femto_amd_resolve_device (raw device pointers; enqueue-only)"""
+        _check(lib().femto_amd_resolve_device(self._h, d_offsets, n, d_n or None, d_doc or None, d_doc32 or None, d_doc_offset or None,
+                                              stream or None))
 
     # ---- device-pointer API (raw pointers, e.g. torch tensors' data_ptr())
     def count_device(self, npats, d_plen, d_pats, d_starts, d_first, d_last, stream=0):

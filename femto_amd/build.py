@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.environ.get("FEMTO_AMD_LIB") or os.path.join(HERE, "libfemto_amd.so")
-SOURCES = ["femto_amd_api.hip", "api_host.hip", "api_open.hip", "api_multi.hip", "regexp_search.hip", "trace_kernels.hip", "host_index.cpp", "index_builder.cpp", "suffix_sort.hip",
+SOURCES = ["femto_amd_api.hip", "api_host.hip", "api_open.hip", "api_multi.hip", "regexp_search.hip", "resolve.hip", "trace_kernels.hip", "host_index.cpp", "index_builder.cpp", "suffix_sort.hip",
            "query_sort.hip", "host_pack.cpp"]
 # host-only translation units compiled as plain C++ (x86 intrinsics; no device pass)
 PLAIN_CXX = {"host_pack.cpp"}

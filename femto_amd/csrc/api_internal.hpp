@@ -268,7 +268,8 @@ struct femto_amd_index {
   int64_t regexp_stack_cap = int64_t(1) << 18; // pending ranges one search may hold (option "regexp_stack_cap", <= 2^22); the reference
                                                // has no bound: it runs on to ERR_OVERWORKED
   bool timing = false;
-  KernelTimer t_count, t_locate;
+  KernelTimer t_count, t_locate, t_resolve, t_regexp;
+  int64_t* d_doc_ends = nullptr;   // the header block's doc_ends[] on the device (resolve.hip; uploaded on first use)
   double pipe_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the last staged host-pointer call (femto_amd_host_pipeline_stats)
   // range-split index (femto_amd_open_split): this handle holds the segment lines and the block images of
   // data blocks [split_blo[part], split_blo[part+1]); the other parts' slices are mapped from their owners

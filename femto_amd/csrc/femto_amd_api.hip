@@ -827,6 +827,9 @@ void femto_amd_close(femto_amd_index_t* ix) {
     (void)hipSetDevice(ix->device);
     ix->t_count.destroy();
     ix->t_locate.destroy();
+    ix->t_resolve.destroy();
+    ix->t_regexp.destroy();
+    if (ix->d_doc_ends) (void)hipFree(ix->d_doc_ends);
     (void)hipDeviceSynchronize();   // enqueue-only calls may still be running on the caller's streams
     for (auto& s : ix->pool) s->release();
     ix->pool.clear();
@@ -1356,9 +1359,11 @@ void femto_amd_kernel_time_reset(femto_amd_index_t* ix) {
   if (!ix) return;
   std::lock_guard<std::mutex> lk(ix->mu);
   ix->t_count.drain();
-  ix->t_locate.drain();
-  ix->t_count.total_ms = ix->t_locate.total_ms = 0;
-  ix->t_count.launches = ix->t_locate.launches = 0;
+  for (KernelTimer* t : {&ix->t_count, &ix->t_locate, &ix->t_resolve, &ix->t_regexp}) {
+    t->drain();
+    t->total_ms = 0;
+    t->launches = 0;
+  }
 }
 
 int femto_amd_kernel_time_ms(femto_amd_index_t* ix, const char* kernel, double* avg_ms, int64_t* n_launches) {
@@ -1367,6 +1372,8 @@ int femto_amd_kernel_time_ms(femto_amd_index_t* ix, const char* kernel, double* 
   KernelTimer* t = nullptr;
   if (!strcmp(kernel, "count")) t = &ix->t_count;
   else if (!strcmp(kernel, "locate")) t = &ix->t_locate;
+  else if (!strcmp(kernel, "resolve")) t = &ix->t_resolve;
+  else if (!strcmp(kernel, "regexp")) t = &ix->t_regexp;
   else return set_err(FEMTO_AMD_ERR_PARAM, "unknown kernel name");
   t->drain();
   if (avg_ms) *avg_ms = t->launches ? t->total_ms / double(t->launches) : 0.0;

@@ -519,11 +519,14 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
     for (int32_t q : todo) last_pass[size_t(q)] = pass;
     HIP_TRY(hipMemcpyAsync(d_order.p, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(d_next, 0, 4, st));
+    hipEvent_t te0 = nullptr, te1 = nullptr;
+    const bool timed = timer_begin(ix, ix->t_regexp, st, &te0, &te1);
     if (mode == 3 && ix->dev.ru) launch_nfa<RuPolicy>(ix->dev, B, blocks, st);
     else if (mode == 3) launch_nfa<PackPolicy>(ix->dev, B, blocks, st);
     else if (mode == 4 && ix->dev.ind) launch_nfa<IndPolicy>(ix->dev, B, blocks, st);
     else if (mode == 4) launch_nfa<Pack2Policy>(ix->dev, B, blocks, st);
     else launch_nfa<WavePolicy>(ix->dev, B, blocks, st);
+    if (timed) timer_end(ix, ix->t_regexp, st, te0, te1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(status.data(), d_status, size_t(nq) * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

@@ -123,6 +123,11 @@ int femto_amd_resolve_location(const femto_amd_index_t* ix, int64_t offset, int6
  * into memory owned by the handle (valid until femto_amd_close; NOT NUL-terminated), *len its length. */
 int femto_amd_document_info(const femto_amd_index_t* ix, int64_t doc, const char** info, int64_t* len);
 
+/* resolve_location for a batch (the reference resolves every located row: one header_loc_query_t each,
+ * do_range_to_results_query src/main/server.c:4800-4823): doc[i] / doc_offset[i] for offsets[i]; either output may be NULL.
+ * Host arrays; the search runs on the GPU (femto_amd_resolve_device below is the form without the copies). */
+int femto_amd_resolve_batch(femto_amd_index_t* ix, int64_t n, const int64_t* offsets, int64_t* doc, int64_t* doc_offset);
+
 /* ---- device-pointer batch API (inputs and outputs already resident in HBM) ---------------- */
 /* All pointers are device pointers on the index's device; `stream` is a hipStream_t passed as
  * void* (NULL = default stream).  Calls only enqueue work and return; the caller synchronises.
@@ -158,6 +163,16 @@ int femto_amd_locate_device(femto_amd_index_t* ix, int64_t npats, const int32_t*
                             const uint16_t* d_pats, const int64_t* d_starts, int max_occs_each,
                             int64_t* d_first, int64_t* d_last, int32_t* d_noccs, int64_t* d_out_starts,
                             int64_t* d_offsets, int64_t offsets_capacity, int64_t* d_total, void* stream);
+
+/* resolve_location (src/main/index.c:1587) on the device, one lane per offset: d_doc[i] (int64) and / or d_doc32[i] (int32:
+ * indexes of fewer than 2^31 documents) = the document holding text offset d_offsets[i], d_doc_offset[i] = the offset inside
+ * it; any of the three outputs may be NULL, and d_doc_offset may be d_offsets itself (in place).  d_n != NULL: only
+ * min(n, *d_n) offsets are live -- pass the d_total of femto_amd_locate_device and its offsets_capacity as n to resolve the
+ * located rows of an enqueue-only chain without a host round trip.  Enqueue-only.  The located offsets of a match are
+ * inside a document; an offset at or beyond the last document's end resolves, as in the reference, to document
+ * number_of_documents. */
+int femto_amd_resolve_device(femto_amd_index_t* ix, const int64_t* d_offsets, int64_t n, const int64_t* d_n, int64_t* d_doc,
+                             int32_t* d_doc32, int64_t* d_doc_offset, void* stream);
 
 /* ---- leaf requests (the reference's block_request interface, src/main/index.h:300-394) ---- */
 /* For rows[i] (global row numbers, host memory): ch_out = L[row] (BLOCK_REQUEST_CHAR),
@@ -445,7 +460,7 @@ int femto_amd_host_pack_keys(const uint8_t* dense, int ndense, int bits, int64_t
 int femto_amd_get_rank_mode(const femto_amd_index_t* ix);
 
 /* ---- profiling hooks ---------------------------------------------------------------------- */
-/* Average duration (ms) of the launches of the named kernel ("count", "locate") since the last
+/* Average duration (ms) of the launches of the named kernel ("count", "locate", "resolve", "regexp") since the last
  * reset, measured with HIP events on the stream the kernel was launched on; n_launches out. */
 int femto_amd_kernel_time_ms(femto_amd_index_t* ix, const char* kernel, double* avg_ms, int64_t* n_launches);
 void femto_amd_kernel_time_reset(femto_amd_index_t* ix);

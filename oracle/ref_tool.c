@@ -15,6 +15,7 @@
  *   forward : the leaf requests of do_forward_query (src/main/server.c:2424) for every row
  *   bseq    : bseq_construct_forcetype (src/main/wtree.c:365) -> encoded image
  *   flatten : flatten_index (src/main/index.c:2260)
+ *   resolve : header_loc_request(HDR_LOC_RESOLVE_LOCATION) = resolve_location (src/main/index.c:1587) for every offset
  *   regexp_nfa : setup_regexp_query_take_nfa (src/main/server.h:838, server.c:1342) + femto_run_query: do_regexp_query
  *             (server.c:1656) on hand-fed nfa_description_t automata (filled as nfa_test.c:57-80 fills them); the
  *             reference's regex FRONT END (flex/bison) is not needed for this, and is not built
@@ -549,6 +550,48 @@ static int cmd_regexp_nfa(int argc, char** argv)
   return 0;
 }
 
+/* resolve <index> <out.bin>: header_loc_request(HDR_LOC_RESOLVE_LOCATION | HDR_LOC_REQUEST_DOC_LEN) = resolve_location
+ * (src/main/index.c:1587) for EVERY logical offset 0 .. total_length - 1 (the end-of-document markers' offsets included):
+ * i64 n, i64 ndocs, then (i64 doc, i64 offset in doc) x n, then i64 document_length x ndocs */
+static int cmd_resolve(int argc, char** argv)
+{
+  if (argc < 2) return 2;
+  error_t err;
+  path_translator_t pt;
+  index_locator_t loc;
+  header_block_t hb;
+  memset(&pt, 0, sizeof pt);
+  err = path_translator_init(&pt);
+  if (err) die("path_translator_init", err);
+  err = path_translator_id_for_path(&pt, argv[0], &loc);
+  if (err) die("id_for_path", err);
+  err = open_header_block(&hb, &pt, loc);
+  if (err) die("open_header_block", err);
+  int64_t n = hb.hdr.total_length, ndocs = hb.hdr.number_of_documents;
+  FILE* out = fopen(argv[1], "wb");
+  if (!out) die("fopen", 0);
+  fwrite(&n, 8, 1, out);
+  fwrite(&ndocs, 8, 1, out);
+  for (int64_t off = 0; off < n; off++) {
+    header_loc_request_t r; memset(&r, 0, sizeof r);
+    r.offset = off;
+    err = header_loc_request(&hb, HDR_LOC_RESOLVE_LOCATION, &r);
+    if (err) die("HDR_LOC_RESOLVE_LOCATION", err);
+    fwrite(&r.loc.doc, 8, 1, out);
+    fwrite(&r.loc.offset, 8, 1, out);
+  }
+  for (int64_t d = 0; d < ndocs; d++) {
+    header_loc_request_t r; memset(&r, 0, sizeof r);
+    r.loc.doc = d;
+    err = header_loc_request(&hb, HDR_LOC_REQUEST_DOC_LEN, &r);
+    if (err) die("HDR_LOC_REQUEST_DOC_LEN", err);
+    fwrite(&r.doc_len, 8, 1, out);
+  }
+  fclose(out);
+  close_header_block(&hb);
+  return 0;
+}
+
 int main(int argc, char** argv)
 {
   if (argc < 2) {
@@ -567,6 +610,7 @@ int main(int argc, char** argv)
   if (!strcmp(c, "bseq")) return cmd_bseq(argc - 2, argv + 2);
   if (!strcmp(c, "flatten")) return cmd_flatten(argc - 2, argv + 2);
   if (!strcmp(c, "regexp_nfa")) return cmd_regexp_nfa(argc - 2, argv + 2);
+  if (!strcmp(c, "resolve")) return cmd_resolve(argc - 2, argv + 2);
   fprintf(stderr, "unknown command %s\n", c);
   return 2;
 }

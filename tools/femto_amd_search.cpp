@@ -390,13 +390,11 @@ int main(int argc, char** argv) {
           i = end + 1;
         }
       }
-      std::vector<std::pair<int64_t, int64_t>> hits;  // (document, offset in document)
+      std::vector<std::pair<int64_t, int64_t>> hits;  // (document, offset in document): resolve_location for every located row
+      std::vector<int64_t> rdoc(offs.size()), roff(offs.size());
+      if ((rc = femto_amd_resolve_batch(ix, int64_t(offs.size()), offs.data(), rdoc.data(), roff.data()))) die("femto_amd_resolve_batch", rc);
       hits.reserve(offs.size());
-      for (int64_t o : offs) {
-        int64_t doc = 0, doff = 0;
-        if ((rc = femto_amd_resolve_location(ix, o, &doc, &doff))) die("femto_amd_resolve_location", rc);
-        hits.emplace_back(doc, doff);
-      }
+      for (size_t k = 0; k < offs.size(); k++) hits.emplace_back(rdoc[k], roff[k]);
       std::sort(hits.begin(), hits.end());             // results_create_sort_locations + unionResults: a sorted SET
       hits.erase(std::unique(hits.begin(), hits.end()), hits.end());
       DocList docs;
