@@ -100,17 +100,39 @@ int pipe_init(femto_amd_index* ix, Scratch& S) {
   }
   auto& P = S.pipe;
   if (P.ready) return 0;
-  for (int b = 0; b < kPipeDepth; b++) {
-    HIP_TRY(hipHostMalloc(&P.h_in[b], pipe_in_bytes(), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc(&P.h_out[b], size_t(kPipeChunk) * 16, hipHostMallocDefault));
-    HIP_TRY(hipMalloc(&P.d_in[b], pipe_in_bytes()));
-    HIP_TRY(hipMalloc(&P.d_out[b], size_t(kPipeChunk) * 16));
-    HIP_TRY(hipEventCreateWithFlags(&P.in_done[b], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&P.k_done[b], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&P.out_done[b], hipEventDisableTiming));
+  // The staging buffers (kPipeDepth x ~140 MB pinned host + as much device memory per leased scratch) live until the handle is
+  // closed; they belong to a CALL's scratch, like the pattern and result buffers of the plain path, and are not part of what
+  // hbm_budget_bytes / femto_amd_structures[13] count (the index's own structures).  When any of them cannot be had, what
+  // was allocated is released again and the caller takes the unpipelined path (-1), which needs none of it.
+  bool ok = true;
+  for (int b = 0; b < kPipeDepth && ok; b++) {
+    ok = hipHostMalloc(&P.h_in[b], pipe_in_bytes(), hipHostMallocDefault) == hipSuccess &&
+         hipHostMalloc(&P.h_out[b], size_t(kPipeChunk) * 16, hipHostMallocDefault) == hipSuccess &&
+         hipMalloc(&P.d_in[b], pipe_in_bytes()) == hipSuccess && hipMalloc(&P.d_out[b], size_t(kPipeChunk) * 16) == hipSuccess &&
+         hipEventCreateWithFlags(&P.in_done[b], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&P.k_done[b], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&P.out_done[b], hipEventDisableTiming) == hipSuccess;
   }
-  HIP_TRY(hipStreamCreateWithFlags(&P.s_h2d, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&P.s_d2h, hipStreamNonBlocking));
+  ok = ok && hipStreamCreateWithFlags(&P.s_h2d, hipStreamNonBlocking) == hipSuccess &&
+       hipStreamCreateWithFlags(&P.s_d2h, hipStreamNonBlocking) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    for (int b = 0; b < kPipeDepth; b++) {
+      if (P.h_in[b]) (void)hipHostFree(P.h_in[b]);
+      if (P.h_out[b]) (void)hipHostFree(P.h_out[b]);
+      if (P.d_in[b]) (void)hipFree(P.d_in[b]);
+      if (P.d_out[b]) (void)hipFree(P.d_out[b]);
+      if (P.in_done[b]) (void)hipEventDestroy(P.in_done[b]);
+      if (P.k_done[b]) (void)hipEventDestroy(P.k_done[b]);
+      if (P.out_done[b]) (void)hipEventDestroy(P.out_done[b]);
+      P.h_in[b] = P.h_out[b] = P.d_in[b] = P.d_out[b] = nullptr;
+      P.in_done[b] = P.k_done[b] = P.out_done[b] = nullptr;
+    }
+    if (P.s_h2d) (void)hipStreamDestroy(P.s_h2d);
+    if (P.s_d2h) (void)hipStreamDestroy(P.s_d2h);
+    P.s_h2d = P.s_d2h = nullptr;
+    return -1;
+  }
   P.ready = true;
   return 0;
 }
@@ -227,6 +249,13 @@ int count_host_pipelined(femto_amd_index* ix, Scratch& S, const HostBatch& hb, i
                          int64_t* dev_last = nullptr) {
   if (hb.npats < kPipeMin) return -1;
   if (knob(ix->opt.host_pipeline, "FEMTO_AMD_HOST_PIPELINE", 1) == 0) return -1;
+  if (!hb.plen) return set_err(FEMTO_AMD_ERR_PARAM, "null pattern lengths");
+  if (!hb.ptrs && (!hb.flat || !hb.starts)) {
+    // the flat form without its arrays: only a batch of empty patterns needs neither (the plain path validates the rest)
+    for (int64_t i = 0; i < hb.npats; i++)
+      if (hb.plen[i] != 0) return set_err(FEMTO_AMD_ERR_PARAM, hb.starts ? "null pattern symbols" : "null pattern starts");
+    return -1;
+  }
   int rc = pipe_init(ix, S);
   if (rc) return rc;
   auto& P = S.pipe;

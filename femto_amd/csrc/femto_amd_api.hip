@@ -1268,6 +1268,8 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
 
 int femto_amd_trace_reads(const femto_amd_index_t* ix, int64_t* count_reads, int64_t* locate_reads) {
   if (!ix || !count_reads || !locate_reads) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  if (!ix->children.empty()) return femto_amd_trace_reads(ix->children[0], count_reads, locate_reads);   // like femto_amd_structures
+  std::lock_guard<std::mutex> lk(const_cast<femto_amd_index_t*>(ix)->mu);
   for (int r = 0; r < 10; r++) {
     count_reads[r] = ix->last_trace_reads[0][r];
     locate_reads[r] = ix->last_trace_reads[1][r];

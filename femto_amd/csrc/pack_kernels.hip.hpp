@@ -42,10 +42,14 @@ __device__ __forceinline__ void trace_touch(const DevIndex& ix, int region, uint
 // offset of the i-th marked row (pack_sa: 8-byte entries, or 4-byte ones when the index has fewer than 2^32 rows)
 __device__ __forceinline__ int64_t mark_offset_at(const DevIndex& ix, int64_t i) {
   trace_touch(ix, kTraceSa, uint64_t(i) >> (ix.pack_sa32 ? 5 : 4));
-  return ix.pack_sa32 ? int64_t(reinterpret_cast<const uint32_t*>(ix.pack_sa)[i]) : ix.pack_sa[i];
+  if (!ix.pack_sa32) return ix.pack_sa[i];
+  const uint32_t v = reinterpret_cast<const uint32_t*>(ix.pack_sa)[i];
+  return v == 0xffffffffu ? int64_t(-1) : int64_t(v);      // (an index of < 2^32 rows has no offset 2^32 - 1)
 }
+// A derived offset can only be negative on a DAMAGED index (a mark offset smaller than the steps walked back from it); the
+// 4-byte form keeps it negative (-1) instead of wrapping it into a large valid-looking offset.
 __device__ __forceinline__ void mark_offset_store(const DevIndex& ix, int64_t* sa, int64_t i, int64_t off) {
-  if (ix.pack_sa32) reinterpret_cast<uint32_t*>(sa)[i] = uint32_t(uint64_t(off));
+  if (ix.pack_sa32) reinterpret_cast<uint32_t*>(sa)[i] = off < 0 ? 0xffffffffu : uint32_t(uint64_t(off));
   else sa[i] = off;
 }
 

@@ -458,7 +458,8 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   // Raw results (before the per-automaton sort drops ranges inside other results, and including the attempts of searches
   // that are run again in a larger arena) land in a buffer of the library's own, which grows and the batch runs again
   // when it is too small: max_results bounds what the CALLER's arrays receive, nothing else (max_results == 0: count only).
-  int64_t result_cap = std::max<int64_t>(2 * max_results, 1 << 12);
+  // (the first size is a guess, not a promise: a generous max_results does not reserve memory up front)
+  int64_t result_cap = std::max<int64_t>(std::min<int64_t>(2 * max_results, int64_t(1) << 22), 1 << 12);
   if ((rc = d_q.reserve(hq.size() * sizeof(NfaQueryDev))) || (rc = d_flags.reserve(h_flags.size() + 16)) ||
       (rc = d_sd.reserve(h_sd.size() * 4 + 16)) || (rc = d_ch.reserve(h_ch.size() * 2 + 16)) || (rc = d_bychar.reserve(h_bychar.size() * 4)) ||
       (rc = d_misc.reserve(64 + size_t(nq) * 4)) ||

@@ -233,7 +233,8 @@ int femto_amd_split_info(const femto_amd_index_t* ix, int* part, int* nparts, in
  * "regexp_stack_cap", default 2^18, at most 2^22; the reference has no such bound -- it would run on to ERR_OVERWORKED).  The out arrays hold max_results entries for ALL
  * automata together; *n_out = results in total; max_results == 0 only counts (result_start[] and *n_out are filled, the
  * other out arrays may be NULL); more results than max_results is FEMTO_AMD_ERR_FULL with *n_out = the exact number
- * to call again with (raw result ranges are buffered by the library itself, however many there are).  Limits: 2048 nodes, 2^22 transitions per
+ * to call again with (raw result ranges are buffered by the library itself; only when even its buffer -- up to half of the
+ * free HBM, 16 GB at most -- cannot hold them is *n_out the RAW count: an upper bound, before equal and nested ranges are dropped).  Limits: 2048 nodes, 2^22 transitions per
  * automaton, costs and cost_bound 1..255 (errors are counted in one byte, nfa.h:74-76). */
 typedef struct femto_amd_nfa {
   int32_t num_nodes;
@@ -440,8 +441,9 @@ int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* by
  * [2] offsets of the derived marks, [3] rank units, [4] level table, [5] context tables, [6] per-character rank lines,
  * [7] text + suffix / inverse suffix arrays, [8] two-level lines, [9] everything derived (lane tables included),
  * [10] distance between derived marks (0: femto's own), [11] level-table depth K, [12] bytes per mark offset,
- * [13] HBM the handle holds in all (every persistent allocation: what hbm_budget_bytes is counted against; the scratch
- * of a running batch call -- patterns, results -- is the caller's in the device-pointer API and not part of it).  n <= 16. */
+ * [13] HBM the handle holds in all (every persistent allocation of the INDEX: what hbm_budget_bytes is counted against; the
+ * scratch of batch calls -- patterns, results; in the host-pointer API also the staging buffers a call's scratch keeps for the
+ * next call, up to ~0.4 GB pinned host + ~0.4 GB device per concurrently calling thread -- is not part of it).  n <= 16. */
 int femto_amd_structures(const femto_amd_index_t* ix, int64_t* out, int n);
 /* Where the LAST staged host-pointer batch call (femto_amd_count_flat / _parallel_count ... on >= 2^18 patterns) spent its
  * wall time, in ms: out8[0] staging threads packing the caller's patterns into pinned key / symbol chunks, [1] waiting for

@@ -967,6 +967,49 @@ def test_full_size_text96_properties(tmp_path, gpu_ok):
     assert np.array_equal(of, first[:m]) and np.array_equal(ol, last[:m])
     on, oo = o.locate_flat(plen[:m], flat, starts[:m], 20, threads=16)
     assert np.array_equal(on, noccs[:m]) and np.array_equal(oo, offs[:int(noccs[:m].sum())])
+    # The MISS paths at full size (round-4 verdict, task 1): patterns that mostly do NOT occur -- 100 k uniform over the text's
+    # alphabet, lengths 8..64 (they leave the hashed context tables on a 9- / 16-gram the text does not hold, and the table has to
+    # hand back so that the emptying step's (first, last) comes out, direct_kernels.hip.hpp), and 100 k sampled patterns with ONE
+    # byte substituted (they miss or hit the tables depending on where the substitution falls, and die in the rank steps or the
+    # text tail).  max_occs 100 as benchmarked.  Mode 4 against mode 1 (femto's own wavelet tree: no tables at all) on all of
+    # them, against the oracle on 60 000, the (first, last) of dead ranges compared explicitly.
+    rng = np.random.Generator(np.random.PCG64(99))
+    alphabet = np.flatnonzero(np.bincount(text[:1 << 26], minlength=256)).astype(np.uint16) + 5
+    assert 90 <= len(alphabet) <= 100
+    nmiss = 100_000
+    rlen = rng.integers(8, 65, nmiss).astype(np.int32)
+    rflat = alphabet[rng.integers(0, len(alphabet), int(rlen.sum()))].astype(np.uint16)
+    mlen, mflat = tg.p_hit(8, 64, nmiss, 13, text)
+    mstarts = tg.starts_of(mlen)
+    at = mstarts + rng.integers(0, 1 << 30, nmiss) % mlen
+    mflat = mflat.copy()
+    mflat[at] = alphabet[rng.integers(0, len(alphabet), nmiss)]
+    qlen = np.concatenate([rlen, mlen, plen[:50_000]])
+    qflat = np.concatenate([rflat, mflat, flat[:int(starts[50_000])]])
+    qstarts = tg.starts_of(qlen)
+    f4, l4 = ix.count_flat(qlen, qflat, qstarts)
+    n4, o4 = ix.locate_flat(qlen, qflat, qstarts, 100)
+    dead = l4 < f4
+    assert 0.5 < dead.mean() < 0.85 and dead[:nmiss].mean() > 0.99 and 0.5 < dead[nmiss:2 * nmiss].mean() < 1.0
+    c4 = l4 - f4 + 1
+    assert np.array_equal(n4, np.where(dead, 0, np.minimum(c4, np.where(c4 - 1 > 100, 100, c4))))
+    ix.set_rank_mode(1)
+    f1, l1 = ix.count_flat(qlen, qflat, qstarts)
+    n1, o1 = ix.locate_flat(qlen, qflat, qstarts, 100)
+    assert np.array_equal(f4[dead], f1[dead]) and np.array_equal(l4[dead], l1[dead])          # the emptying step's values
+    assert np.array_equal(f4, f1) and np.array_equal(l4, l1) and np.array_equal(n4, n1) and np.array_equal(o4, o1)
+    ix.set_rank_mode(4)
+    pick = np.concatenate([np.arange(0, 20_000), np.arange(nmiss, nmiss + 20_000), np.arange(2 * nmiss, 2 * nmiss + 20_000)])
+    sub_len = qlen[pick]
+    sub_flat = np.concatenate([qflat[qstarts[i]:qstarts[i] + qlen[i]] for i in pick])
+    sub_starts = tg.starts_of(sub_len)
+    of, ol = o.count_flat(sub_len, sub_flat, sub_starts, threads=32)
+    assert np.array_equal(of, f4[pick]) and np.array_equal(ol, l4[pick])
+    on, oo = o.locate_flat(sub_len, sub_flat, sub_starts, 100, threads=32)
+    o_starts = np.concatenate([[0], np.cumsum(n4)])
+    want = np.concatenate([o4[o_starts[i]:o_starts[i + 1]] for i in pick])
+    assert np.array_equal(on, n4[pick]) and np.array_equal(oo, want)
+    ix.close()
 
 
 def test_full_size_8gib_properties(tmp_path, gpu_ok):
@@ -975,14 +1018,20 @@ def test_full_size_8gib_properties(tmp_path, gpu_ok):
     in two parts.  Size-independent properties plus an oracle spot check:
       * every sampled 20-mer is found and every located offset really is an occurrence;
       * the packed lines (default) and the wavelet path (mode 1) agree; the two-part range-split handle agrees with both;
-      * 1 000 random + sampled patterns agree bit-for-bit with the oracle (count and locate)."""
+      * 20 000 random + sampled patterns agree bit-for-bit with the oracle (count and locate)."""
     import shutil
-    if shutil.disk_usage(str(tmp_path)).free < 12 * (1 << 30):
-        pytest.skip("needs ~10 GB of scratch disk for the 8 GiB index")
+    free_disk = shutil.disk_usage(str(tmp_path)).free
+    if free_disk < 12 * (1 << 30):
+        why = "BASELINE configs[4] (8 GiB index) NOT TESTED on this box: %.1f GB of scratch disk free, ~10 GB needed" % (free_disk / 1e9)
+        print("\n*** " + why + " ***", flush=True)
+        pytest.skip(why)
     try:
         import psutil
-        if psutil.virtual_memory().available < 200 * (1 << 30):
-            pytest.skip("needs ~200 GB of host memory for the 8 GiB text and its suffix array")
+        avail = psutil.virtual_memory().available
+        if avail < 200 * (1 << 30):
+            why = "BASELINE configs[4] (8 GiB index) NOT TESTED on this box: %.0f GB of host memory available, ~200 GB needed for the text and its suffix array" % (avail / 1e9)
+            print("\n*** " + why + " ***", flush=True)
+            pytest.skip(why)
     except ImportError:
         pass
     n = 1 << 33
@@ -1007,9 +1056,9 @@ def test_full_size_8gib_properties(tmp_path, gpu_ok):
         assert np.array_equal(text[offs + k], pat_bytes[owner, k]), k
     # oracle spot check (random + sampled)
     o = po.Oracle(path)
-    rp, rf = tg.p_rand(20, 500, 5)
-    p2 = np.concatenate([rp, plen[:500]])
-    f2 = np.concatenate([rf, flat[:500 * 20]])
+    rp, rf = tg.p_rand(20, 10_000, 5)                    # (round-4 verdict: >= 20 k patterns against the oracle at this size)
+    p2 = np.concatenate([rp, plen[:10_000]])
+    f2 = np.concatenate([rf, flat[:10_000 * 20]])
     s2 = tg.starts_of(p2)
     gf, gl = ix.count_flat(p2, f2, s2)
     of, ol = o.count_flat(p2, f2, s2, threads=16)
