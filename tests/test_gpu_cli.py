@@ -94,10 +94,12 @@ def test_search_cli_string_queries(fixtures, tmp_path, gpu_ok):
     assert _run(["--count", fx.index, "th e"]).stdout == _run(["--count", fx.index, "the"]).stdout
     # two indexes: the same string found in both is ONE row with the sum
     n1 = int(_run(["--count", fx.index, "the"]).stdout.split()[0])
-    r = _run(["--count", fx.index, fx.flat, "the"])
+    flat = str(tmp_path / "index.flat")                    # the flattened container is the same index
+    femto_amd.flatten_index(fx.index, flat)
+    r = _run(["--count", fx.index, flat, "the"])
     assert r.stdout == b"% 4d \"the\"\n% 4d total matches\n" % (2 * n1, 2 * n1)
-    r = _run(["--count", "--by_index", fx.index, fx.flat, "the"]).stdout.split(b"\n")
-    assert r[0] == b"Results from " + fx.index.encode() and r[2] == b"Results from " + fx.flat.encode() and r[1].startswith(b"% 4d [" % n1)
+    r = _run(["--count", "--by_index", fx.index, flat, "the"]).stdout.split(b"\n")
+    assert r[0] == b"Results from " + fx.index.encode() and r[2] == b"Results from " + flat.encode() and r[1].startswith(b"% 4d [" % n1)
     # --max_results: the first chunk of rows (do_range_to_results_query, server.c:4754): rows first .. first + n - 1
     ix = femto_amd.Index(fx.index, device=0)
     first, last = ix.count([np.frombuffer(b"the", dtype=np.uint8).astype(np.uint16) + 5])
@@ -134,13 +136,14 @@ def test_search_cli_regular_expressions(fixtures, tmp_path, gpu_ok):
     occ = _occurrences(docs, re.compile(rb"[Tt][Hh][Ee]", re.S))
     r = _run(["--count", "--icase", fx.index, "The"])
     assert r.stdout == _rows(occ) + b"% 4d total matches\n" % sum(len(v) for v in occ.values())
-    # APPROX 1: the strings within one edit are the rows (a string whose range lies inside another result's -- "which" inside
-    # "whic" -- is dropped by regexp_result_list_sort, so the total covers the exact matches without naming them)
-    exact = int(_run(["--count", fx.index, "which"]).stdout.split()[0])
-    r = _run(["--count", fx.index, "APPROX 1 which"])
+    # APPROX 1: the strings within one edit are the rows (a string whose range lies inside another result's -- "whichx" inside
+    # "which" -- is dropped by regexp_result_list_sort, so the total covers the exact matches without naming them)
+    word = re.search(rb"[a-z]{6}", docs[0][500:]).group(0).decode()       # six letters that do occur
+    exact = int(_run(["--count", fx.index, word]).stdout.split()[0])
+    r = _run(["--count", fx.index, "APPROX 1 " + word])
     assert r.returncode == 0 and exact > 0 and int(r.stdout.split(b"\n")[-2].split()[0]) >= exact and r.stdout.count(b"\n") >= 2
     o = femto_amd.Index(fx.index, device=0)
-    f, l, m, c = o.regexp_search(b"which", approx=(1, 1, 1, 1))
+    f, l, m, c = o.regexp_search(word.encode(), approx=(1, 1, 1, 1))
     o.close()
     assert int(r.stdout.split(b"\n")[-2].split()[0]) == int((l - f + 1).sum()) and r.stdout.count(b"\n") - 1 <= len(f)
     # --json: one object, the query echoed as ast_to_string prints it, rows as [string, count] / [[info], [offsets]]
