@@ -304,6 +304,9 @@ def write_fnfa(path, nfas):
             f.write(np.ascontiguousarray(a.is_final, dtype=np.uint8).tobytes())
 
 
+last_regexp_query_s = None
+
+
 def ref_regexp_nfa(index_path, nfas, tmpdir, timeout=600):
     """the GENUINE do_regexp_query (setup_regexp_query_take_nfa, src/main/server.h:838) on hand-fed automata:
     one (err_code, first, last, match_len, cost) per automaton, in the order of the reference's sorted result list"""
@@ -311,7 +314,12 @@ def ref_regexp_nfa(index_path, nfas, tmpdir, timeout=600):
     write_fnfa(nf, nfas)
     # (do_regexp_query never returns when a pending range's alive states can read NOTHING: it then schedules zero
     # requests and waits for them, server.c:1954-1990 -- hence the timeout; automata from a pattern have no such state)
-    ref_tool("regexp_nfa", index_path, nf, of, timeout=timeout)
+    global last_regexp_query_s
+    txt = ref_tool("regexp_nfa", index_path, nf, of, timeout=timeout)
+    try:      # wall time inside femto_run_query only (process start, index open, result writing excluded)
+        last_regexp_query_s = json.loads(txt.strip().splitlines()[-1])["query_s"]
+    except Exception:      # noqa: BLE001
+        last_regexp_query_s = None
     raw = open(of, "rb").read()
     out, o = [], 0
     rec = np.dtype([("first", "<i8"), ("last", "<i8"), ("len", "<i4"), ("cost", "<i4")])

@@ -498,6 +498,7 @@ static int cmd_regexp_nfa(int argc, char** argv)
   if (magic != 0x41464e46u) { fprintf(stderr, "bad FNFA magic\n"); return 2; }
   FILE* out = fopen(argv[2], "wb");
   if (!out) { perror(argv[2]); return 2; }
+  double query_s = 0;       /* wall time inside femto_run_query only (setup, index open and result writing excluded) */
   for (uint32_t qi = 0; qi < nq; qi++) {
     int32_t hd[6];
     memcpy(hd, p, 24); p += 24;
@@ -528,7 +529,9 @@ static int cmd_regexp_nfa(int argc, char** argv)
     regexp_query_t* q = malloc(sizeof(regexp_query_t));
     err = setup_regexp_query_take_nfa(q, NULL, loc, nfa, 0);
     if (err) die("setup_regexp_query_take_nfa", err);
+    const double tq = now_s();
     err = femto_run_query(&srv, (query_entry_t*) q);
+    query_s += now_s() - tq;
     if (err) die("femto_run_query", err);
     int32_t code = q->proc.entry.err_code, nres = code ? 0 : q->results.num_results;
     fwrite(&code, 4, 1, out);
@@ -546,6 +549,7 @@ static int cmd_regexp_nfa(int argc, char** argv)
   }
   fclose(out);
   free(fb);
+  printf("{\"automata\": %u, \"query_s\": %.6f}\n", nq, query_s);
   femto_stop_server(&srv);
   return 0;
 }

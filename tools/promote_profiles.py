@@ -7,7 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench  # noqa: E402  (source_hash)
+from benchlib import common as bench  # noqa: E402  (source_hash)
 
 KEEP = ("count_direct_kernel", "count_tail_kernel", "plan_rows_kernel", "plan_super_kernel", "locate_walk_kernel", "count_keys_kernel",
         "count_kernel", "locate_kernel")
