@@ -73,3 +73,10 @@ def fixtures(tmp_path_factory):
         return cache[name]
 
     return get
+
+
+@pytest.fixture(scope="session")
+def gpu_ok():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return True

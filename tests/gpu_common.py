@@ -1,0 +1,56 @@
+"""helpers shared by the `-m gpu` test modules"""
+import os
+
+import pytest
+
+import femto_amd
+
+# 3: packed small-alphabet lines (default when the index has <= 8 characters); 4: two-level 16-ary lines (default for
+# 9..256 characters); 1: lane per query on femto's wavelet tree (default otherwise); 0: wavefront-per-query raw walk
+MODES = [3, 4, 1, 0]
+
+
+def _torchrun(nproc, script_and_args, env, cwd=None, attempts=2):
+    """python -m torch.distributed.run on 127.0.0.1 with a free port; one retry (a port can be taken between probing and use)"""
+    import socket
+    import subprocess
+    import sys
+    out = None
+    for _ in range(attempts):
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+                              "--master-addr", "127.0.0.1", "--master-port", str(port)] + script_and_args,
+                             env=env, capture_output=True, text=True, timeout=600, cwd=cwd)
+        if out.returncode == 0:
+            break
+    return out
+
+
+def _open(path, mode=None):
+    """open on GPU 0; mode 4 is built for small alphabets too (FEMTO_AMD_PACK2=1) so that every fixture exercises it"""
+    old = os.environ.get("FEMTO_AMD_PACK2")
+    os.environ["FEMTO_AMD_PACK2"] = "1"
+    try:
+        ix = femto_amd.Index(path, device=0)
+    finally:
+        if old is None:
+            del os.environ["FEMTO_AMD_PACK2"]
+        else:
+            os.environ["FEMTO_AMD_PACK2"] = old
+    if mode is not None:
+        _set_mode(ix, mode)
+    return ix
+
+
+def _set_mode(ix, mode):
+    if mode == 3 and not ix.pack_info()["available"]:
+        ix.close()
+        pytest.skip("more than 8 distinct characters: no packed lines for this index")
+    if mode == 4 and not ix.pack_info()["available2"]:
+        ix.close()
+        pytest.skip("more than 256 distinct characters: no two-level lines for this index")
+    ix.set_rank_mode(mode)
+    assert ix.rank_mode == mode

@@ -99,7 +99,7 @@ def test_range_split_two_devices(fixtures, name):
 @need2
 def test_range_split_across_processes_on_two_devices(fixtures, tmp_path):
     """tests/split_worker.py with one GPU per rank: hipIpc handles of ANOTHER device's memory"""
-    from test_gpu_parity import _torchrun
+    from gpu_common import _torchrun
     fx = fixtures("acgt48k")
     script = os.path.join(os.path.dirname(__file__), "split_worker.py")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
