@@ -76,6 +76,7 @@ struct NfaBatchDev {
   int32_t* status;           // per query
   int64_t max_iterations;    // MAX_REGEXP_ITERATIONS (src/main/server.c:40)
   int32_t pass;
+  int32_t lds_nodes, lds_children;   // sizes of the workgroup's dynamic LDS arrays (nfa_lds_bytes)
 };
 
 // mode 1: femto's own wavelet tree through the derived segment lines (alphabets of more than 256 characters, range-split
@@ -104,17 +105,29 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
   return v;
 }
 
+// Dynamic LDS of one workgroup (sized per launch from the LARGEST automaton of the batch and the number of characters the
+// text holds, so that typical automata -- a few dozen nodes on a small alphabet -- leave room for a CU's full complement of
+// wavefronts; until round 5 the arrays were static for 2048 nodes and 264 children: 19 KB, 8 workgroups per CU):
+//   s_tmp u32[nn] | s_child_f i64[cc] | s_child_l i64[cc] | s_child_found i32[cc] | s_live i32[cc] | s_child_ch u16[cc] |
+//   s_cur u8[nn] | s_sub u8[nn]            nn = lds_nodes (multiple of 8), cc = lds_children (multiple of 4)
+__host__ __device__ inline size_t nfa_lds_bytes(int nn, int cc) { return size_t(nn) * 4 + size_t(cc) * (8 + 8 + 4 + 4 + 2) + size_t(nn) * 2 + 16; }
+
 template <class P>
 __global__ __launch_bounds__(64) void nfa_search_kernel(const DevIndex ix, const NfaBatchDev B) {
-  __shared__ uint8_t s_cur[kNfaMaxNodes];       // nfa_states: the popped entry's costs, deletions merged in
-  __shared__ uint8_t s_sub[kNfaMaxNodes];       // states after one substitution error (any character)
-  __shared__ uint32_t s_tmp[kNfaMaxNodes];      // tmp_states being accumulated (atomicMin)
+  extern __shared__ __align__(16) uint8_t s_dyn[];
   __shared__ int32_t s_bychar[264];
   __shared__ uint32_t s_rc[9];                  // r_c: reachable characters
-  __shared__ uint16_t s_child_ch[264];
-  __shared__ int64_t s_child_f[264], s_child_l[264];
-  __shared__ int32_t s_child_found[264];
+  __shared__ uint32_t s_text[9];                // characters that occur in the text (a range stepped with any other is empty)
   __shared__ int32_t s_q;
+  const int nn = B.lds_nodes, cc = B.lds_children;
+  uint32_t* const s_tmp = reinterpret_cast<uint32_t*>(s_dyn);                    // tmp_states being accumulated (atomicMin)
+  int64_t* const s_child_f = reinterpret_cast<int64_t*>(s_tmp + nn);
+  int64_t* const s_child_l = s_child_f + cc;
+  int32_t* const s_child_found = reinterpret_cast<int32_t*>(s_child_l + cc);
+  int32_t* const s_live = s_child_found + cc;
+  uint16_t* const s_child_ch = reinterpret_cast<uint16_t*>(s_live + cc);
+  uint8_t* const s_cur = reinterpret_cast<uint8_t*>(s_child_ch + cc);            // nfa_states: the popped entry's costs, deletions merged in
+  uint8_t* const s_sub = s_cur + nn;                                             // states after one substitution error (any character)
   const int t = threadIdx.x;
   uint8_t* const arena = B.arena + size_t(blockIdx.x) * size_t(B.arena_bytes);
   const int cap = B.cap;
@@ -136,6 +149,15 @@ __global__ __launch_bounds__(64) void nfa_search_kernel(const DevIndex ix, const
     x ^= x >> 29;
     return uint32_t(x) & hmask;
   };
+  // The characters of the text, once per workgroup: stepping a range with a character the text lacks gives the empty range
+  // (Occ == 0), which add_mapping ignores (server.c:1565) -- such characters never become children, so an APPROX search on DNA
+  // fans out over 4 characters per pop, not over the alphabet's 256 (five rounds of the fan-out and a 256-iteration child
+  // loop per pop until round 5).  The ORDER of the children that remain is untouched.
+  if (t < 9) s_text[t] = 0;
+  __syncthreads();
+  for (int c = t; c < kAlphaSize; c += 64)
+    if (P::code_of(ix, uint32_t(c)) != 0xffffu) atomicOr(&s_text[c >> 5], 1u << (c & 31));
+  __syncthreads();
   for (;;) {
     if (t == 0) s_q = atomicAdd(B.next, 1);
     __syncthreads();
@@ -221,11 +243,15 @@ __global__ __launch_bounds__(64) void nfa_search_kernel(const DevIndex ix, const
           atomicOr(&s_rc[ch >> 5], 1u << (ch & 31u));
         }
       __syncthreads();
-      if (allchars && t < 9) {      // CHARACTER_OFFSET .. ALPHA_SIZE - 1
-        uint32_t mask = ~0u;
-        if (t == 0) mask = ~0u << kNfaOffset;
-        if (t == 8) mask = (1u << (kAlphaSize - 256)) - 1u;
-        s_rc[t] |= mask;
+      if (t < 9) {
+        uint32_t w = s_rc[t];
+        if (allchars) {               // CHARACTER_OFFSET .. ALPHA_SIZE - 1
+          uint32_t mask = ~0u;
+          if (t == 0) mask = ~0u << kNfaOffset;
+          if (t == 8) mask = (1u << (kAlphaSize - 256)) - 1u;
+          w |= mask;
+        }
+        s_rc[t] = w & s_text[t];      // ... that the text holds
       }
       __syncthreads();
       // ---- the children in push order: characters >= CHARACTER_OFFSET ascending (the substitution loop creates their
@@ -236,7 +262,7 @@ __global__ __launch_bounds__(64) void nfa_search_kernel(const DevIndex ix, const
         n_all = wave_sum_i32(__popc(w));
         n_low = __popc(s_rc[0] & ((1u << kNfaOffset) - 1u));
       }
-      const int nchild = n_all;
+      const int nchild = n_all;       // <= characters of the text <= lds_children
       for (int c = t; c < kAlphaSize; c += 64) {
         if (!((s_rc[c >> 5] >> (c & 31)) & 1u)) continue;
         int rank = __popc(s_rc[c >> 5] & ((1u << (c & 31)) - 1u));
@@ -245,28 +271,29 @@ __global__ __launch_bounds__(64) void nfa_search_kernel(const DevIndex ix, const
         s_child_ch[pos] = uint16_t(c);
       }
       __syncthreads();
-      // ---- the fan-out: lane k steps the range with the k-th character (server.c:1954-2060)
-      for (int k = t; k < nchild; k += 64) {
-        const uint32_t ch = s_child_ch[k];
-        const uint32_t code = P::code_of(ix, ch);
-        int64_t f = first, l = last;
-        if (code == 0xffffu) {         // the character does not occur in the text: Occ == 0, an empty range
-          f = 1;
-          l = 0;
-        } else {
-          P::search_step(ix, 1, code, f, l);
+      // ---- the fan-out: lane k steps the range with the k-th character (server.c:1954-2060); then add_mapping's lookup: a
+      // pending entry with the child's range?  (children of one pop have disjoint ranges); the children with rows are listed
+      // in order (s_live): the merge loop below visits only those
+      int nlive = 0;
+      for (int k0 = 0; k0 < nchild; k0 += 64) {
+        const int k = k0 + t;
+        bool live = false;
+        if (k < nchild) {
+          const uint32_t ch = s_child_ch[k];
+          int64_t f = first, l = last;
+          P::search_step(ix, 1, P::code_of(ix, ch), f, l);
+          s_child_f[k] = f;
+          s_child_l[k] = l;
+          int found = -1;
+          live = l >= f;                               // add_mapping ignores empty ranges (server.c:1565)
+          if (live)
+            for (int s2 = heads[hash_of(f, l)]; s2 >= 0; s2 = e_next[s2])
+              if (e_first[s2] == f && e_last[s2] == l) { found = s2; break; }
+          s_child_found[k] = found;
         }
-        s_child_f[k] = f;
-        s_child_l[k] = l;
-        s_child_found[k] = -1;
-      }
-      __syncthreads();
-      // ---- add_mapping's lookup: a pending entry with a child's range?  (children of one pop have disjoint ranges)
-      for (int k = t; k < nchild; k += 64) {
-        const int64_t cf = s_child_f[k], cl = s_child_l[k];
-        if (cl < cf) continue;
-        for (int s = heads[hash_of(cf, cl)]; s >= 0; s = e_next[s])
-          if (e_first[s] == cf && e_last[s] == cl) { s_child_found[k] = s; break; }
+        const unsigned long long mask = __ballot(live);
+        if (live) s_live[nlive + __popcll(mask & ((1ull << t) - 1ull))] = k;
+        nlive += __popcll(mask);
       }
       // ---- substitutions: states after reading any character at subst_cost (server.c:2107-2110)
       if (approx) {
@@ -281,9 +308,9 @@ __global__ __launch_bounds__(64) void nfa_search_kernel(const DevIndex ix, const
         for (int i = t; i < N; i += 64) s_sub[i] = uint8_t(s_tmp[i]);
       }
       __syncthreads();
-      for (int k = 0; k < nchild; k++) {
+      for (int kk = 0; kk < nlive; kk++) {
+        const int k = s_live[kk];
         const int64_t cf = s_child_f[k], cl = s_child_l[k];
-        if (cl < cf) continue;                      // add_mapping ignores empty ranges (server.c:1565)
         const int ch = s_child_ch[k];
         for (int i = t; i < N; i += 64) s_tmp[i] = kNfaDead;
         __syncthreads();
@@ -360,8 +387,16 @@ int validate_nfa(const femto_amd_nfa_t& a, int64_t qi) {
 }
 
 template <class P>
-void launch_nfa(const DevIndex& d, const NfaBatchDev& B, int blocks, hipStream_t st) {
-  hipLaunchKernelGGL((nfa_search_kernel<P>), dim3(uint32_t(blocks)), dim3(64), 0, st, d, B);
+void launch_nfa(const DevIndex& d, const NfaBatchDev& B, int blocks, size_t lds, hipStream_t st) {
+  hipLaunchKernelGGL((nfa_search_kernel<P>), dim3(uint32_t(blocks)), dim3(64), lds, st, d, B);
+}
+// workgroups of 64 lanes a CU holds at once with `lds` bytes of dynamic LDS each (the grid is sized to fill the chip once:
+// the workgroups take automata from a counter)
+template <class P>
+int nfa_blocks_per_cu(size_t lds) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, nfa_search_kernel<P>, 64, lds) != hipSuccess || n < 1) n = 8;
+  return n;
 }
 
 }  // namespace
@@ -487,6 +522,21 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   B.status = d_status;
   B.max_iterations = ix->regexp_max_iterations;
   B.cost_stride = (max_nodes + 3) & ~3;
+  B.lds_nodes = (max_nodes + 7) & ~7;
+  {
+    int nchars = 0;       // characters the text holds: the most children a pop can have
+    for (int c = 0; c < kAlphaSize && size_t(c) + 1 < ix->host.C.size(); c++)
+      if (ix->host.C[size_t(c) + 1] > ix->host.C[size_t(c)]) nchars++;
+    B.lds_children = (std::max(nchars, 4) + 3) & ~3;
+  }
+  const size_t lds = nfa_lds_bytes(B.lds_nodes, B.lds_children);
+  int per_cu = 8;
+  if (mode == 3 && ix->dev.ru) per_cu = nfa_blocks_per_cu<RuPolicy>(lds);
+  else if (mode == 3) per_cu = nfa_blocks_per_cu<PackPolicy>(lds);
+  else if (mode == 4 && ix->dev.ind) per_cu = nfa_blocks_per_cu<IndPolicy>(lds);
+  else if (mode == 4) per_cu = nfa_blocks_per_cu<Pack2Policy>(lds);
+  else per_cu = nfa_blocks_per_cu<WavePolicy>(lds);
+  per_cu = std::min(per_cu, 32);
   // Stack capacity: most searches keep a few dozen pending entries; the ones that run out (status FULL) are run again
   // with a larger arena and fewer workgroups, up to regexp_stack_cap entries.
   const size_t entry_bytes = 24 + size_t(B.cost_stride);      // first, last, match length, hash link, costs
@@ -504,7 +554,7 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   for (int64_t i = 0; i < nq; i++) todo[size_t(i)] = int32_t(i);
   int64_t cap = std::min<int64_t>(1024, ix->regexp_stack_cap);
   for (int pass = 0;; pass++) {
-    int blocks = int(std::min<int64_t>(int64_t(todo.size()), int64_t(ix->num_cus) * 8));
+    int blocks = int(std::min<int64_t>(int64_t(todo.size()), int64_t(ix->num_cus) * per_cu));
     int64_t hsize = 64;
     while (hsize < 2 * cap) hsize <<= 1;
     const size_t per_block = (size_t(cap) * entry_bytes + size_t(hsize) * 4 + 255) & ~size_t(255);
@@ -522,11 +572,11 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
     HIP_TRY(hipMemsetAsync(d_next, 0, 4, st));
     hipEvent_t te0 = nullptr, te1 = nullptr;
     const bool timed = timer_begin(ix, ix->t_regexp, st, &te0, &te1);
-    if (mode == 3 && ix->dev.ru) launch_nfa<RuPolicy>(ix->dev, B, blocks, st);
-    else if (mode == 3) launch_nfa<PackPolicy>(ix->dev, B, blocks, st);
-    else if (mode == 4 && ix->dev.ind) launch_nfa<IndPolicy>(ix->dev, B, blocks, st);
-    else if (mode == 4) launch_nfa<Pack2Policy>(ix->dev, B, blocks, st);
-    else launch_nfa<WavePolicy>(ix->dev, B, blocks, st);
+    if (mode == 3 && ix->dev.ru) launch_nfa<RuPolicy>(ix->dev, B, blocks, lds, st);
+    else if (mode == 3) launch_nfa<PackPolicy>(ix->dev, B, blocks, lds, st);
+    else if (mode == 4 && ix->dev.ind) launch_nfa<IndPolicy>(ix->dev, B, blocks, lds, st);
+    else if (mode == 4) launch_nfa<Pack2Policy>(ix->dev, B, blocks, lds, st);
+    else launch_nfa<WavePolicy>(ix->dev, B, blocks, lds, st);
     if (timed) timer_end(ix, ix->t_regexp, st, te0, te1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(status.data(), d_status, size_t(nq) * 4, hipMemcpyDeviceToHost, st));

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""tools/regexp_bench.py: batched automaton search (femto_amd_nfa_search_batch = do_regexp_query for many automata, one
-workgroup each) on the bench index: N random DNA motifs with classes, alternations and optional symbols, exact and APPROX 1;
-GPU timing only -- bench.py's `extra.regexp_batch` line times the genuine reference beside a batch and compares the result lists."""
+"""tools/regexp_bench.py [--which exact|approx|both] [--n N] [--text-log2 K]: the two automaton batches of bench.py's `regexp_batch`
+extra (benchlib/extras.py regexp_workloads) on the bench index, alone -- the command rocprofv3 profiles for
+profiles/r05_regexp_stats.txt (`--kernel-trace --stats`, and separate `--pmc` passes).  Prints one JSON line per batch:
+wall ms of the femto_amd_nfa_search_batch call, the nfa_search_kernel's own time (HIP events), automata/s."""
+import argparse
+import json
 import os
 import sys
 import time
@@ -10,40 +13,46 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import femto_amd  # noqa: E402
-
-path = os.environ.get("FEMTO_AMD_BENCH_DIR", "/tmp/femto_amd_bench") + "/acgt_2p30_s20260928"
-N = int(os.environ.get("NREGEX", "20000"))
-rng = np.random.Generator(np.random.PCG64(7))
 
 
-def motif(k):
-    out = b""
-    for _ in range(k):
-        r = rng.random()
-        if r < 0.70:
-            out += bytes([b"ACGT"[rng.integers(0, 4)]])
-        elif r < 0.85:
-            out += b"[" + bytes(sorted(set(b"ACGT"[i] for i in rng.integers(0, 4, 2)))) + b"]"
-        elif r < 0.93:
-            out += b"(" + bytes(b"ACGT"[i] for i in rng.integers(0, 4, 2)) + b"|" + bytes(b"ACGT"[i] for i in rng.integers(0, 4, 2)) + b")"
-        else:
-            out += bytes([b"ACGT"[rng.integers(0, 4)]]) + b"?"
-    return out
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--which", default="both", choices=["exact", "approx", "both"])
+    ap.add_argument("--n", type=int, default=20000)
+    ap.add_argument("--text-log2", type=int, default=30)
+    ap.add_argument("--seed", type=int, default=20260928)
+    ap.add_argument("--workdir", default=os.environ.get("FEMTO_AMD_BENCH_DIR", "/tmp/femto_amd_bench"))
+    ap.add_argument("--reps", type=int, default=2)
+    args = ap.parse_args()
+    import torch  # noqa: F401
+    import femto_amd
+    from femto_amd import textgen as tg
+    from benchlib.extras import regexp_workloads
+    path = os.path.join(args.workdir, f"acgt_2p{args.text_log2}_s{args.seed}")
+    if not os.path.exists(os.path.join(path, "_femto_index")):
+        os.makedirs(args.workdir, exist_ok=True)
+        femto_amd.build_index(path, [tg.t_acgt(1 << args.text_log2, args.seed)], params=None, infos=["bench"], device=0)
+    ix = femto_amd.Index(path, device=0)
+    work = regexp_workloads(femto_amd, args.seed, args.n, args.n)
+    ix.nfa_search_batch(work["exact_motifs_14_18"][:128], max_results=1 << 22)
+    for name, nfas in work.items():
+        if args.which != "both" and not name.startswith(args.which):
+            continue
+        pre = femto_amd.NfaBatch(nfas)
+        for rep in range(args.reps):
+            ix.kernel_time_reset()
+            ix.kernel_time_enable(True)
+            t0 = time.perf_counter()
+            r = ix.nfa_search_batch(pre, max_results=1 << 25)
+            dt = time.perf_counter() - t0
+            ix.kernel_time_enable(False)
+            k_ms, k_n = ix.kernel_time("regexp")
+            print(json.dumps({"batch": name, "rep": rep, "automata": len(nfas), "nodes_avg": float(np.mean([a.num_nodes for a in nfas])),
+                              "wall_ms": 1e3 * dt, "automata_per_s": len(nfas) / dt, "kernel_ms_total": k_ms * k_n, "kernel_launches": k_n,
+                              "kernel_automata_per_s": len(nfas) / (k_ms * k_n * 1e-3) if k_n else None, "result_ranges": int(len(r[1])),
+                              "not_ok": int((r[5] != 0).sum())}), flush=True)
+    ix.close()
 
 
-ix = femto_amd.Index(path, device=0)
-for what, approx, k in (("exact motifs of 14-18 terms", None, (14, 19)), ("APPROX 1 motifs of 16-20 terms", (1, 1, 1, 1), (16, 21))):
-    pats = [motif(int(rng.integers(*k))) for _ in range(N)]
-    nfas = [femto_amd.Nfa.from_regex(p, approx) for p in pats]
-    ix.nfa_search_batch(nfas[:256], max_results=1 << 22)          # warm-up (scratch, arena)
-    best = 1e9
-    for _ in range(3):
-        t0 = time.perf_counter()
-        start, first, last, mlen, cost, status = ix.nfa_search_batch(nfas, max_results=1 << 24)
-        best = min(best, time.perf_counter() - t0)
-    nodes = np.mean([a.num_nodes for a in nfas])
-    line = "%-34s %6d automata (%.0f nodes avg): %.1f ms per batch = %.0f automata/s, %d result ranges, %d not ok" % (
-        what, N, nodes, 1e3 * best, N / best, len(first), int((status != 0).sum()))
-    print(line, flush=True)
-ix.close()
+if __name__ == "__main__":
+    main()
