@@ -77,7 +77,10 @@ def main():
     ap.add_argument("--open-opts", default="", help="experiments: femto_amd_options_t fields of the headline handle, 'name=value,...' "
                                                     "(e.g. hbm_budget_bytes=4294967296,rank_units=0)")
     args = ap.parse_args()
-    open_opts = {k: int(v) for k, v in (kv.split("=") for kv in args.open_opts.split(",") if kv)} or None
+    open_opts = {k: int(v) for k, v in (kv.split("=") for kv in args.open_opts.split(",") if kv)}
+    # the benchmark's handles take whatever HBM is free (dense suffix arrays, deepest tables: rounds 1-4's rule and numbers); the
+    # library's DEFAULT is a bound (include/femto_amd.h hbm_budget_bytes) -- measured by the `default_open` extra
+    open_opts.setdefault("hbm_budget_bytes", -2)
 
     import torch
     import torch.distributed as dist
@@ -410,6 +413,7 @@ def main():
             roof["reference_format"]["note"] = "femto's own algorithm on femto's own format; x_peak > 1: the timed kernel does not do that work (see compulsory / line_reads)"
     if want_extra:
         extra["budget4x"] = bx.budget_extra(ctx, batch, plen, res_ref)
+        extra["default_open"] = bx.budget_extra(ctx, batch, plen, res_ref, budget="default")
         extra["mode1_wavelet_tree"] = bx.mode1_extra(ctx, ix, batch, res_ref, cd_count, csub)
         extra["mode0_wavefront_per_query"] = bx.mode0_extra(ctx, ix, batch, res_ref)
         if roof is not None:      # compact copies inside the block the driver keeps
@@ -420,6 +424,14 @@ def main():
                                 "traffic_GBs": br.get("traffic_GBs"), "hbm_held": (b4.get("structures") or {}).get("hbm_allocated"),
                                 "level_table_syms": (b4.get("structures") or {}).get("level_table_syms"),
                                 "p_hit_value": (b4.get("p_hit") or {}).get("value"), "error": b4.get("error")}
+            d0 = extra["default_open"]
+            dr = d0.get("roofline") or {}
+            roof["default_open"] = {"value": d0.get("value"), "ms_per_step": d0.get("ms_per_step"), "kernel_ms": dr.get("kernel_ms"),
+                                    "frac_distinct_lines": dr.get("frac"), "frac_line_reads": (dr.get("line_reads") or {}).get("frac"),
+                                    "traffic_GBs": dr.get("traffic_GBs"), "hbm_held": (d0.get("structures") or {}).get("hbm_allocated"),
+                                    "hbm_budget": (d0.get("structures") or {}).get("hbm_budget"),
+                                    "level_table_syms": (d0.get("structures") or {}).get("level_table_syms"),
+                                    "p_hit_value": (d0.get("p_hit") or {}).get("value"), "error": d0.get("error")}
             m1 = extra["mode1_wavelet_tree"]
             roof["mode1"] = {"value": m1.get("value"), "count_kernel_ms": m1.get("count_kernel_ms"), "frac_reference_format": (m1.get("roofline") or {}).get("frac"),
                              "traffic_GBs": (m1.get("roofline") or {}).get("traffic_GBs"), "error": m1.get("error")}

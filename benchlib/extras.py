@@ -20,18 +20,28 @@ class Ctx:
         self.__dict__.update(kw)
 
 
-def budget_extra(c, batch, plen, ref_results):
-    """The footprint-bounded open (round-3 verdict, task 1): the SAME index with hbm_budget_bytes = 4 x text bytes -- packed lines,
-    rank units, sampled marks and the level table the rest pays for; no dense suffix arrays, no text -- on the headline batch
-    (random 20-mers) and on 20-mers sampled from the text, with its own roofline block and live PMC traffic."""
+def budget_extra(c, batch, plen, ref_results, budget="4x"):
+    """A footprint-bounded open of the SAME index on the headline batch (random 20-mers) and on 20-mers sampled from the text,
+    with its own roofline block and live PMC traffic.  budget = "4x": hbm_budget_bytes = 4 x text bytes (round-3 verdict,
+    task 1): packed lines, rank units, sampled marks and the level table the rest pays for; no dense suffix arrays, no text.
+    budget = "default": femto_amd_open as a drop-in caller gets it -- the library's default bound, min(free / 4, max(8 x text, 2 GiB))."""
     args, torch, femto_amd, tg, dev, local_rank, stream = c.args, c.torch, c.femto_amd, c.tg, c.dev, c.local_rank, c.stream
     index_path, text_path, n_text = c.index_path, c.text_path, c.n_text
     npats = args.npats
-    budget = 4 * n_text
-    opts = {"hbm_budget_bytes": budget}
-    bix = femto_amd.Index(index_path, device=local_rank, options=opts)
-    out = {"what": f"same index opened with femto_amd_open_opts(hbm_budget_bytes = 4 x text = {budget}): search steps on the rank units / packed lines, "
-                   "no dense suffix arrays, no text tail", "structures": bix.structures(), "index": bix.pack_info()}
+    if budget == "default":
+        bix = femto_amd.Index(index_path, device=local_rank)
+        held = bix.structures()
+        budget_bytes = held["hbm_budget"]
+        out = {"what": f"same index opened with plain femto_amd_open: the library's DEFAULT bound (hbm_budget_bytes auto = {budget_bytes} bytes here)",
+               "structures": held, "index": bix.pack_info()}
+        assert held["hbm_budget_is_default"] == 1 and held["hbm_allocated"] <= budget_bytes
+        pmc_opts = ""
+    else:
+        budget_bytes = 4 * n_text
+        bix = femto_amd.Index(index_path, device=local_rank, options={"hbm_budget_bytes": budget_bytes})
+        out = {"what": f"same index opened with femto_amd_open_opts(hbm_budget_bytes = 4 x text = {budget_bytes}): search steps on the rank units / packed lines, "
+                       "no dense suffix arrays, no text tail", "structures": bix.structures(), "index": bix.pack_info()}
+        pmc_opts = f"hbm_budget_bytes={budget_bytes}"
     try:
         steps = max(5, args.steps)
         el, (c_ms, c_n), (l_ms, _) = timed_steps(torch, bix, batch, args.max_occs, stream, steps)
@@ -60,7 +70,7 @@ def budget_extra(c, batch, plen, ref_results):
         bix = None
         if args.pmc != "off":
             try:
-                tr, trs = pmc_traffic(args, kname, info, open_opts=f"hbm_budget_bytes={budget}")
+                tr, trs = pmc_traffic(args, kname, info, open_opts=pmc_opts or "hbm_budget_bytes=-1")
                 add_traffic(roof, tr, trs, k_ms, comp)
             except Exception as ex:      # noqa: BLE001
                 log("budget pmc pass failed:", repr(ex))
@@ -339,7 +349,7 @@ def cfg3_extra(c, world):
     e_text = tg.t_eng_torch(n_text, args.seed, f"cuda:{local_rank}")
     if not os.path.exists(os.path.join(e_path, "_femto_index")):
         femto_amd.build_index(e_path, [e_text], params=None, infos=["bench"], device=local_rank)
-    eix = femto_amd.Index(e_path, device=local_rank)
+    eix = femto_amd.Index(e_path, device=local_rank, options={"hbm_budget_bytes": femto_amd.BUDGET_ALL})
     try:
         ep, ef = tg.p_hit(8, 64, npats, args.seed + 3000, e_text)
         del e_text

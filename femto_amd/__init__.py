@@ -22,6 +22,7 @@ CHARACTER_OFFSET = 5
 ERR_NAMES = {0: "NOERR", 1: "MEM", 2: "IO", 3: "PARAM", 4: "FORMAT", 5: "BZ_DATA", 6: "INVALID",
              8: "MISSING", 10: "FULL", 11: "OVERWORKED", 12: "UNKNOWN"}
 ERR_PARAM, ERR_INVALID, ERR_FULL, ERR_OVERWORKED = 3, 6, 10, 11
+BUDGET_ALL = -2       # femto_amd_options_t::hbm_budget_bytes: whatever is free on the device (the default is a bound, include/femto_amd.h)
 
 
 class FemtoAmdError(RuntimeError):
@@ -421,7 +422,8 @@ class Index:
         out = (C.c_int64 * 16)()
         _check(lib().femto_amd_structures(self._h, out, 16))
         names = ["image", "packed_lines", "marks", "rank_units", "level_table", "context_tables", "char_rank_lines", "text_sa_isa",
-                 "two_level_lines", "derived_total", "mark_every", "level_table_syms", "mark_offset_bytes", "hbm_allocated"]
+                 "two_level_lines", "derived_total", "mark_every", "level_table_syms", "mark_offset_bytes", "hbm_allocated", "hbm_budget",
+                 "hbm_budget_is_default"]
         return {k: int(out[i]) for i, k in enumerate(names)}
 
     def document_info(self, doc):

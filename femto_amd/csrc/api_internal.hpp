@@ -190,6 +190,7 @@ struct femto_amd_index {
   HostIndex host;
   femto_amd_options_t opt = femto_amd_auto_options();   // the caller's options (femto_amd_open_opts); -1 = auto
   int64_t hbm_free_at_open = -1; // free HBM when this handle started allocating
+  bool budget_is_default = false; // opt.hbm_budget_bytes was left on auto: the default bound is in force
   int64_t hbm_held = 0;          // bytes of the handle's PERSISTENT device allocations (big arrays + uploaded tables): what
                                  // hbm_budget_bytes is counted against -- the scratch of the derivations at open comes and goes
   std::vector<std::pair<void*, size_t>> big_allocs;   // big_malloc()ed arrays and their sizes

@@ -1347,6 +1347,8 @@ int femto_amd_structures(const femto_amd_index_t* ix, int64_t* out, int n) {
   v[10] = ix->mark_every_used;
   v[11] = ix->dev.ktab2 ? ix->dev.kt2_syms : 0;
   v[12] = ix->dev.pack_sa ? (ix->dev.pack_sa32 ? 4 : 8) : 0;
+  v[14] = ix->opt.hbm_budget_bytes;                    // the budget in force (-1: everything that is free)
+  v[15] = ix->budget_is_default ? 1 : 0;
   v[13] = ix->hbm_held;
   for (const auto& t : ix->small_tables) v[13] += int64_t(t.second);
   for (int i = 0; i < n; i++) out[i] = v[i];

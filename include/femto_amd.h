@@ -374,12 +374,17 @@ int femto_amd_pack_counts_device(femto_amd_index_t* ix, int64_t npats, const int
  * (every field "auto") and set what matters.  -1 (auto) = the rule described with each field; the environment variables
  * named in brackets are read ONLY for fields left on auto -- they are test overrides, not the configuration interface.
  * DESIGN.md 3 has the measured table level_table_syms -> bytes -> ms per step a deployer picks a budget from. */
+#define FEMTO_AMD_BUDGET_ALL (-2)
 typedef struct femto_amd_options {
   uint32_t struct_size;          /* sizeof(femto_amd_options_t), set by femto_amd_options_init: versions the struct */
   int32_t rank_mode;             /* -1: the fastest that applies | 0 raw | 1 lane | 3 pack | 4 pack2   [FEMTO_AMD_RANK_MODE] */
-  int64_t hbm_budget_bytes;      /* -1: what is free on the device | bytes this handle may HOLD in all (femto_amd_structures
-                                  * [13]): the optional structures are declined (identical results on the slower path) once it
-                                  * is spent; with a budget the level table takes what the lines, marks and rank units leave */
+  int64_t hbm_budget_bytes;      /* bytes this handle may HOLD in all (femto_amd_structures[13]): the optional structures are
+                                  * declined (identical results on the slower path) once it is spent; the level table takes
+                                  * what the lines, marks and rank units leave.  -1 (auto): the DEFAULT BOUND
+                                  * min(free HBM / 4, max(8 x indexed text bytes, 2 GiB)) -- 8.6 GB for a 1 GiB text, where a
+                                  * random 20-mer costs ~3 memory requests instead of ~1.3.  FEMTO_AMD_BUDGET_ALL (-2): whatever
+                                  * is free on the device (dense suffix arrays, deepest tables: the benchmark's setting; DESIGN.md
+                                  * 3 has bytes -> patterns/s).                                        [FEMTO_AMD_HBM_BUDGET] */
   int32_t packed_lines;          /* 0: skip mode 3's lines                                                [FEMTO_AMD_PACK] */
   int32_t two_level_lines;       /* 0: skip mode 4's lines | 1: build them for <= 8 characters too        [FEMTO_AMD_PACK2] */
   int32_t char_rank_lines;       /* 0: skip the per-character rank lines of byte alphabets                [FEMTO_AMD_IND] */
@@ -441,6 +446,7 @@ int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* by
  * [2] offsets of the derived marks, [3] rank units, [4] level table, [5] context tables, [6] per-character rank lines,
  * [7] text + suffix / inverse suffix arrays, [8] two-level lines, [9] everything derived (lane tables included),
  * [10] distance between derived marks (0: femto's own), [11] level-table depth K, [12] bytes per mark offset,
+ * [14] the HBM budget in force (-1: everything that is free), [15] 1 when it is the default bound (hbm_budget_bytes auto),
  * [13] HBM the handle holds in all (every persistent allocation of the INDEX: what hbm_budget_bytes is counted against; the
  * scratch of batch calls -- patterns, results; in the host-pointer API also the staging buffers a call's scratch keeps for the
  * next call, up to ~0.4 GB pinned host + ~0.4 GB device per concurrently calling thread -- is not part of it).  n <= 16. */

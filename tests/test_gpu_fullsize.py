@@ -27,7 +27,7 @@ def test_full_size_1gib_properties(tmp_path, gpu_ok):
     text = tg.t_acgt(1 << 30, 424242)
     path = str(tmp_path / "acgt1g")
     femto_amd.build_index(path, [text], params=None, infos=["full"], device=0)
-    ix = femto_amd.Index(path, device=0)
+    ix = femto_amd.Index(path, device=0, options=dict(hbm_budget_bytes=femto_amd.BUDGET_ALL))     # the benchmark's setting: all free HBM
     assert ix.info.total_length == (1 << 30) + 1 and ix.info.number_of_blocks == 9 and ix.info.total_buckets == 1025
     npat = 1_000_000
     plen, flat = tg.p_hit(20, 20, npat, 11, text)
@@ -116,7 +116,7 @@ def test_full_size_1gib_properties(tmp_path, gpu_ok):
     assert np.array_equal(bn, noccs) and np.array_equal(bo, offs)
     bx.close()
     # the same index with its big arrays striped over "three GPUs" (all stripes on this one): same kernels, same answers
-    sx = femto_amd.Index(path, devices=[0, 0, 0], striped=True)
+    sx = femto_amd.Index(path, devices=[0, 0, 0], striped=True)      # (the library's default bound: 8 x text over the three stripes)
     fs, ls = sx.count_flat(plen, flat, starts)
     assert np.array_equal(fs, first) and np.array_equal(ls, last)
     ns, os_ = sx.locate_flat(plen, flat, starts, 100)
@@ -131,8 +131,9 @@ def test_full_size_text96_properties(tmp_path, gpu_ok):
     text = tg.t_eng_torch(1 << 30, 515, "cuda:0")
     path = str(tmp_path / "eng1g")
     femto_amd.build_index(path, [text], params=None, infos=["full"], device=0)
-    ix = femto_amd.Index(path, device=0)
+    ix = femto_amd.Index(path, device=0, options=dict(hbm_budget_bytes=femto_amd.BUDGET_ALL))     # the context tables need it (57 GB)
     assert ix.info.total_length == (1 << 30) + 1 and ix.rank_mode == 4
+    assert ix.pack_info()["context_table"] and ix.pack_info()["context2_syms"] == 16 and ix.pack_info()["sa_full"]
     npat = 200_000
     plen, flat = tg.p_hit(8, 64, npat, 12, text)
     starts = tg.starts_of(plen)
@@ -233,7 +234,7 @@ def test_full_size_8gib_properties(tmp_path, gpu_ok):
     text = tg.t_acgt(n, 808)
     path = str(tmp_path / "acgt8g")
     femto_amd.build_index(path, [text], params=None, infos=["full8"], device=0)
-    ix = femto_amd.Index(path, device=0)
+    ix = femto_amd.Index(path, device=0, options=dict(hbm_budget_bytes=femto_amd.BUDGET_ALL))
     assert ix.info.total_length == n + 1 and ix.info.number_of_blocks == 65 and ix.info.total_buckets == 8193
     assert ix.info.text_size_bits == 34 and ix.rank_mode == 3
     npat = 200_000

@@ -32,7 +32,7 @@ def main():
     if not os.path.exists(os.path.join(path, "_femto_index")):
         os.makedirs(args.workdir, exist_ok=True)
         femto_amd.build_index(path, [tg.t_acgt(1 << args.text_log2, args.seed)], params=None, infos=["bench"], device=0)
-    ix = femto_amd.Index(path, device=0)
+    ix = femto_amd.Index(path, device=0, options={"hbm_budget_bytes": femto_amd.BUDGET_ALL})
     work = regexp_workloads(femto_amd, args.seed, args.n, args.n)
     ix.nfa_search_batch(work["exact_motifs_14_18"][:128], max_results=1 << 22)
     for name, nfas in work.items():
