@@ -626,12 +626,13 @@ def regexp_match(regex, s):
     return None if r < 0 else bool(r)
 
 
-def query_echo(query, streamline=True, usequotes=False):
-    """test hook: the query parsed, streamlined (streamline_query) or not, and printed back as ast_to_string prints it
-    (None: syntax error)"""
+def query_echo(query, streamline=True, usequotes=False, simplify=False, icase=False, dump=False):
+    """test hook: the query parsed, then streamline_query / simplify_query / icase_ast as asked (femto_search's order), printed
+    back as ast_to_string prints it (None: syntax error); dump=True: the PARSED tree in the form oracle/ref_tool.c `ast` reads"""
     q = np.frombuffer(bytes(query) + b"\0", dtype=np.uint8)
-    buf = C.create_string_buffer(8 * len(query) + 64)
-    r = lib().femto_amd_query_echo(_ptr(q), len(query), int(streamline), int(usequotes), buf, len(buf))
+    buf = C.create_string_buffer(64 * len(query) + 4096)
+    flags = (1 if streamline else 0) | (2 if simplify else 0) | (4 if icase else 0)
+    r = lib().femto_amd_query_echo(_ptr(q), len(query), flags, 2 if dump else int(usequotes), buf, len(buf))
     return None if r < 0 else buf.raw[:r]
 
 

@@ -491,11 +491,14 @@ inline bool q_simple(const QRegexp& r, std::vector<uint16_t>* out) {
 }
 
 // ---- icase_ast (ast.c:457-589; toloweralpha / toupperalpha index_types.h:74-83: C-locale tolower/toupper of the byte) ----
-inline int q_lower(int alpha) { const int b = alpha - 5; return b >= 'A' && b <= 'Z' ? alpha + 32 : alpha; }
-inline int q_upper(int alpha) { const int b = alpha - 5; return b >= 'a' && b <= 'z' ? alpha - 32 : alpha; }
+// (A code below the bytes -- \x-NN -- goes through tolower() as a NEGATIVE int; glibc's table answers -128..-1 like the byte
+// 256 + c, so the reference's --icase turns alpha 2 into alpha 258 = byte 0xfd.  Kept: tests/golden/query_ast_golden.json.)
+inline int q_lower(int alpha) { const int b = alpha - 5; return b < 0 ? alpha + 256 : (b >= 'A' && b <= 'Z' ? alpha + 32 : alpha); }
+inline int q_upper(int alpha) { const int b = alpha - 5; return b < 0 ? alpha + 256 : (b >= 'a' && b <= 'z' ? alpha - 32 : alpha); }
 inline CharClass q_both_cases(int alpha) {
   CharClass c;
-  if (alpha >= 5) { c.set(q_lower(alpha)); c.set(q_upper(alpha)); } else c.set(alpha);
+  c.set(q_lower(alpha));
+  c.set(q_upper(alpha));
   return c;
 }
 inline void q_icase(QRegexp& r) {
@@ -506,7 +509,7 @@ inline void q_icase(QRegexp& r) {
         case QAtom::CHARACTER: a.kind = QAtom::SET; a.set = q_both_cases(a.ch); atoms.push_back(std::move(a)); break;
         case QAtom::SET: {
           CharClass c = a.set;
-          for (int k = 5; k < kRegexAlpha; k++) if (a.set.get(k)) { c.set(q_lower(k)); c.set(q_upper(k)); }
+          for (int k = 0; k < kRegexAlpha; k++) if (a.set.get(k)) { c.set(q_lower(k)); c.set(q_upper(k)); }
           a.set = c;
           atoms.push_back(std::move(a));
           break;
@@ -617,6 +620,50 @@ inline void q_echo(const QRegexp& r, std::string& o, bool usequotes) {
     if (r.choices.size() > 1 && i + 1 < r.choices.size()) o.push_back('|');
   }
   if (r.choices.size() > 1) o.push_back(')');
+}
+
+// ---- the parsed tree as text, for oracle/ref_tool.c `ast` (tests/golden/make_query_golden.py): the genuine reference rebuilds
+// it with its own constructors (ast.h) and runs its own streamline_query / simplify_query / icase_ast / ast_to_string on it --
+// everything behind the generated parser is then pinned to the reference, not to a restatement.  Format, blank-separated:
+//   R <cost_bound> <subst> <delete> <insert> <nchoices> { S <natoms> { A <rmin> <rmax> <kind ...> } }
+//   kinds: C <alpha> | T <n> <alpha>... (set) | G <n> <alpha>... (string) | P R ... (group)
+inline void q_dump(const QRegexp& r, std::string& o) {
+  o += "R " + std::to_string(r.cost_bound) + " " + std::to_string(r.subst_cost) + " " + std::to_string(r.delete_cost) + " " +
+       std::to_string(r.insert_cost) + " " + std::to_string(r.choices.size()) + " ";
+  for (const QSequence& s : r.choices) {
+    o += "S " + std::to_string(s.atoms.size()) + " ";
+    for (const QAtom& a : s.atoms) {
+      o += "A " + std::to_string(a.rmin) + " " + std::to_string(a.rmax) + " ";
+      switch (a.kind) {
+        case QAtom::CHARACTER: o += "C " + std::to_string(a.ch) + " "; break;
+        case QAtom::SET: {
+          int n = 0;
+          for (int c = 0; c < kRegexAlpha; c++) n += a.set.get(c) ? 1 : 0;
+          o += "T " + std::to_string(n) + " ";
+          for (int c = 0; c < kRegexAlpha; c++) if (a.set.get(c)) o += std::to_string(c) + " ";
+          break;
+        }
+        case QAtom::STRING:
+          o += "G " + std::to_string(a.str.size()) + " ";
+          for (uint16_t c : a.str) o += std::to_string(c) + " ";
+          break;
+        case QAtom::GROUP: o += "P "; q_dump(a.group[0], o); break;
+      }
+    }
+  }
+}
+
+// simplify_query (ast.c:1239-1269): a query that is one string is REPLACED by a string node
+inline void q_simplify(QRegexp& q) {
+  std::vector<uint16_t> lit;
+  if (!q_simple(q, &lit)) return;
+  QAtom a;
+  a.kind = QAtom::STRING;
+  a.str.swap(lit);
+  QSequence seq;
+  seq.atoms.push_back(std::move(a));
+  q.choices.clear();
+  q.choices.push_back(std::move(seq));
 }
 
 // ---- syntax tree -> Thompson automaton (compile_regexp_thompson, compile_regexp.c:150-360: repeats are copies) -------------

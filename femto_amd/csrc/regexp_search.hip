@@ -714,19 +714,7 @@ int femto_amd_query_compile(const uint8_t* query, int64_t query_len, int flags, 
   std::string perr;
   if (!parse_query(query, query_len, &q, &perr)) return set_err(FEMTO_AMD_ERR_PARAM, "query: " + perr);
   if (!(flags & FEMTO_AMD_QUERY_NO_STREAMLINE)) q_streamline(q);
-  {
-    // simplify_query (ast.c:1239-1269): a query that is one string is REPLACED by a string node
-    std::vector<uint16_t> lit;
-    if (q_simple(q, &lit)) {
-      QAtom a;
-      a.kind = QAtom::STRING;
-      a.str.swap(lit);
-      QSequence seq;
-      seq.atoms.push_back(std::move(a));
-      q.choices.clear();
-      q.choices.push_back(std::move(seq));
-    }
-  }
+  q_simplify(q);
   if (flags & FEMTO_AMD_QUERY_ICASE) {
     // search_tool.cc:732-751: the string is extracted (simplify_query) BEFORE icase_ast widens it
     q_icase(q);
@@ -744,16 +732,24 @@ int femto_amd_regexp_literal(const femto_amd_regexp_t* r, const uint16_t** syms,
 
 const char* femto_amd_regexp_echo(const femto_amd_regexp_t* r) { return r ? r->echo.c_str() : ""; }
 
-/* test hook (src/main/query_planning_test.c): parse, optionally streamline, and print the tree back as ast_to_string does */
-int femto_amd_query_echo(const uint8_t* query, int64_t query_len, int streamline, int usequotes, char* out, int64_t cap) {
+/* test hook (src/main/query_planning_test.c; tests/golden/make_query_golden.py): parse, then -- flags bit 0 streamline_query,
+ * bit 1 simplify_query, bit 2 icase_ast, in femto_search's order -- print the tree back as ast_to_string does; usequotes
+ * == 2: the PARSED tree in the text form oracle/ref_tool.c `ast` reads (query_parser.hpp q_dump) */
+int femto_amd_query_echo(const uint8_t* query, int64_t query_len, int flags, int usequotes, char* out, int64_t cap) {
   try {
     if ((query_len && !query) || query_len < 0 || !out || cap < 1) return -1;
     QRegexp q;
     std::string perr;
     if (!parse_query(query, query_len, &q, &perr)) { set_err(FEMTO_AMD_ERR_PARAM, "query: " + perr); return -1; }
-    if (streamline) q_streamline(q);
     std::string o;
-    q_echo(q, o, usequotes != 0);
+    if (usequotes == 2) {
+      q_dump(q, o);
+    } else {
+      if (flags & 1) q_streamline(q);
+      if (flags & 2) q_simplify(q);
+      if (flags & 4) q_icase(q);
+      q_echo(q, o, usequotes != 0);
+    }
     if (int64_t(o.size()) + 1 > cap) return -1;
     std::memcpy(out, o.c_str(), o.size() + 1);
     return int(o.size());

@@ -278,9 +278,11 @@ int femto_amd_query_compile(const uint8_t* query, int64_t query_len, int flags, 
 int femto_amd_regexp_literal(const femto_amd_regexp_t* r, const uint16_t** syms, int64_t* n);
 /* the prepared query printed back as ast_to_string(ast, 0, 1) prints it (src/main/ast.c:1122; femto_search --json "pattern") */
 const char* femto_amd_regexp_echo(const femto_amd_regexp_t* r);
-/* test hook for the known answers of src/main/query_planning_test.c: parse, streamline (or not), print back with or without
- * quotes into out[cap]; returns the length, -1 on a syntax error or a buffer too small */
-int femto_amd_query_echo(const uint8_t* query, int64_t query_len, int streamline, int usequotes, char* out, int64_t cap);
+/* test hook for the known answers of src/main/query_planning_test.c and for tests/golden/query_ast_golden.json (the genuine
+ * streamline_query / simplify_query / icase_ast / ast_to_string run on the tree this parser produced): parse, then flags bit 0
+ * streamline, bit 1 simplify, bit 2 icase; print back with (1) or without (0) quotes into out[cap] -- usequotes 2: the parsed
+ * tree in the text form oracle/ref_tool.c `ast` reads.  Returns the length, -1 on a syntax error or a buffer too small */
+int femto_amd_query_echo(const uint8_t* query, int64_t query_len, int flags, int usequotes, char* out, int64_t cap);
 void femto_amd_regexp_free(femto_amd_regexp_t* r);
 /* compile + search, a batch of patterns with the same costs (max_cost = 0, costs 1: exact) */
 int femto_amd_regexp_search_batch(femto_amd_index_t* ix, int64_t nq, const uint8_t* const* regex, const int64_t* regex_len,

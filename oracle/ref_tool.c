@@ -15,6 +15,8 @@
  *   forward : the leaf requests of do_forward_query (src/main/server.c:2424) for every row
  *   bseq    : bseq_construct_forcetype (src/main/wtree.c:365) -> encoded image
  *   flatten : flatten_index (src/main/index.c:2260)
+ *   ast     : streamline_query / simplify_query / icase_ast / ast_to_string (src/main/query_planning.c, ast.c) on a query tree
+ *             rebuilt with the reference's own constructors from the text form our parser dumps
  *   resolve : header_loc_request(HDR_LOC_RESOLVE_LOCATION) = resolve_location (src/main/index.c:1587) for every offset
  *   regexp_nfa : setup_regexp_query_take_nfa (src/main/server.h:838, server.c:1342) + femto_run_query: do_regexp_query
  *             (server.c:1656) on hand-fed nfa_description_t automata (filled as nfa_test.c:57-80 fills them); the
@@ -43,6 +45,8 @@
 #include "wtree_funcs.h"
 #include "nfa.h"
 #include "bit_array.h"
+#include "ast.h"
+#include "query_planning.h"
 
 #define FPAT_MAGIC 0x54415046u
 
@@ -596,6 +600,110 @@ static int cmd_resolve(int argc, char** argv)
   return 0;
 }
 
+/* ast <trees.txt> <out.txt> [icase]: for every line of trees.txt -- a query as OUR parser (femto_amd/csrc/query_parser.hpp) parsed
+ * it, in q_dump's text form -- rebuild the tree with the reference's own constructors (src/main/ast.h), then do what femto_search
+ * does to a parsed query (src/main_cc/search_tool.cc:726-751): streamline_query (src/main/query_planning.c:24), simplify_query
+ * (src/main/ast.c:1239), optionally icase_ast (ast.c:556); print ast_to_string(ast, 0, 1) and ast_to_string(ast, 0, 0), TAB-separated.
+ * The generated parser (flex/bison) is not involved: this pins everything BEHIND it to the genuine code. */
+static struct regexp_node* ast_read_regexp(char** p);
+static long ast_int(char** p)
+{
+  while (**p == ' ') (*p)++;
+  long v = strtol(*p, p, 10);
+  return v;
+}
+static char ast_tag(char** p)
+{
+  while (**p == ' ') (*p)++;
+  char c = **p;
+  if (c) (*p)++;
+  return c;
+}
+static struct atom_node* ast_read_atom(char** p)
+{
+  if (ast_tag(p) != 'A') die("ast: expected A", 0);
+  range_t rep;
+  rep.min = (int) ast_int(p);
+  rep.max = (int) ast_int(p);
+  struct ast_node* child = NULL;
+  const char kind = ast_tag(p);
+  if (kind == 'C') {
+    child = (struct ast_node*) character_node_new((int) ast_int(p) - CHARACTER_OFFSET);
+  } else if (kind == 'T') {
+    struct set_node* sn = set_node_new();
+    long n = ast_int(p);
+    for (long i = 0; i < n; i++) set_node_set_one(sn, (alpha_t) ast_int(p));
+    child = (struct ast_node*) sn;
+  } else if (kind == 'G') {
+    string_t str;
+    str.len = (int) ast_int(p);
+    str.chars = malloc(sizeof(alpha_t) * (str.len ? str.len : 1));
+    for (int i = 0; i < str.len; i++) str.chars[i] = (alpha_t) ast_int(p);
+    child = (struct ast_node*) string_node_new(str);
+  } else if (kind == 'P') {
+    child = (struct ast_node*) ast_read_regexp(p);
+  } else die("ast: bad atom kind", 0);
+  struct atom_node* a = atom_node_new(child);
+  return atom_node_set_repeats(a, rep);
+}
+static struct regexp_node* ast_read_regexp(char** p)
+{
+  if (ast_tag(p) != 'R') die("ast: expected R", 0);
+  regexp_settings_t st;
+  st.cost_bound = (int) ast_int(p);
+  st.subst_cost = (int) ast_int(p);
+  st.delete_cost = (int) ast_int(p);
+  st.insert_cost = (int) ast_int(p);
+  long nch = ast_int(p);
+  struct regexp_node* r = NULL;
+  for (long c = 0; c < nch; c++) {
+    if (ast_tag(p) != 'S') die("ast: expected S", 0);
+    long na = ast_int(p);
+    struct sequence_node* sq = sequence_node_new_empty();
+    for (long a = 0; a < na; a++) sequence_node_add_atom(sq, ast_read_atom(p));
+    r = r ? regexp_node_add_choice(r, sq) : regexp_node_new(sq);
+  }
+  if (!r) die("ast: regexp without choices", 0);
+  r->s = st;
+  return r;
+}
+static int cmd_ast(int argc, char** argv)
+{
+  if (argc < 2) return 2;
+  const int icase = argc >= 3 && atoi(argv[2]);
+  int64_t flen;
+  unsigned char* fb = slurp(argv[0], &flen);
+  FILE* out = fopen(argv[1], "wb");
+  if (!out) die("fopen", 0);
+  char* line = (char*) fb;
+  char* end = (char*) fb + flen;
+  while (line < end) {
+    char* nl = memchr(line, '\n', (size_t)(end - line));
+    if (!nl) nl = end;
+    char saved = *nl;
+    *nl = 0;
+    if (*line) {
+      char* p = line;
+      struct ast_node* ast = (struct ast_node*) ast_read_regexp(&p);
+      streamline_query(ast);
+      error_t err = simplify_query(&ast);
+      if (err) die("simplify_query", err);
+      if (icase) icase_ast(&ast);
+      char* quoted = ast_to_string(ast, 0, 1);
+      char* plain = ast_to_string(ast, 0, 0);
+      fprintf(out, "%s\t%s\n", quoted ? quoted : "", plain ? plain : "");
+      free(quoted);
+      free(plain);
+      free_ast_node(ast);
+    }
+    *nl = saved;
+    line = nl + 1;
+  }
+  fclose(out);
+  free(fb);
+  return 0;
+}
+
 int main(int argc, char** argv)
 {
   if (argc < 2) {
@@ -615,6 +723,7 @@ int main(int argc, char** argv)
   if (!strcmp(c, "flatten")) return cmd_flatten(argc - 2, argv + 2);
   if (!strcmp(c, "regexp_nfa")) return cmd_regexp_nfa(argc - 2, argv + 2);
   if (!strcmp(c, "resolve")) return cmd_resolve(argc - 2, argv + 2);
+  if (!strcmp(c, "ast")) return cmd_ast(argc - 2, argv + 2);
   fprintf(stderr, "unknown command %s\n", c);
   return 2;
 }

@@ -152,3 +152,20 @@ def test_the_reference_end_to_end_query_set(seed):
             regex += 1
         assert got == want, (fe, py.pattern)
     assert literal > 300 and regex > 80
+
+
+def test_behind_the_parser_equals_the_genuine_reference():
+    """tests/golden/query_ast_golden.json (tests/golden/make_query_golden.py): 924 queries -- the reference's end-to-end test's
+    whole query set, query_planning_test.c's strings, QUERY_FORMAT.txt's constructs, 400 random expressions -- whose trees, as
+    THIS parser built them, were rebuilt with the reference's own constructors and run through the GENUINE streamline_query,
+    simplify_query, icase_ast and ast_to_string (compiled from /root/reference by oracle/Makefile; only the flex/bison parser
+    cannot be).  The product's restatements of those four must print the same, with and without --icase, with and without quotes."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "query_ast_golden.json")))
+    assert len(g) >= 1800
+    for e in g:
+        q = e["query"].encode("latin-1")
+        for usequotes, key in ((True, "quoted"), (False, "plain")):
+            got = femto_amd.query_echo(q, streamline=True, simplify=True, icase=bool(e["icase"]), usequotes=usequotes)
+            assert got is not None and got.decode("latin-1") == e[key], (q, e["icase"], key, got, e[key])
