@@ -298,7 +298,7 @@ def main():
         mine = {"rank": rank, "device": local_rank, "count_kernel_ms": cnt_ms, "locate_kernel_ms": loc_ms,
                 "search_ms_per_step": cnt_ms + loc_ms, "gather_stall_ms_per_step": stall_ms / max(1, args.steps),
                 "gather_waits": len(stalls), "gather_payload_bytes": int(pl.numel() * pl.element_size()) if pl is not None else 0,
-                "located_rows": batch.total, "own_wall_s": own_elapsed, "world_size_seen": dist.get_world_size(),
+                "located_rows": int(batch.d_total[0].item()), "own_wall_s": own_elapsed, "world_size_seen": dist.get_world_size(),
                 "native_comm": ix.comm_info() if native else None}
         allr = [None] * world if rank == 0 else None
         dist.gather_object(mine, allr, dst=0)
@@ -312,6 +312,7 @@ def main():
             dist.destroy_process_group()
         return
 
+    batch.total = int(batch.d_total[0].item())      # the LAST step's row total (the steps rotate through batches of different totals)
     first = batch.d_res[0].cpu().numpy()
     last = batch.d_res[1].cpu().numpy()
     g_noccs = batch.d_noccs.cpu().numpy()
