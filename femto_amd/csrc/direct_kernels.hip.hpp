@@ -355,20 +355,8 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
             break;
           }
         }
-        if (!kDense && kPlan && P::kSpotMarks && sa_out && first == last && j > 0) {
-          // MARK SPOTTING (handles without the dense suffix array and without the text: every located row costs a walk to the next
-          // mark, ~period / 2 lines).  A pattern that occurs spends its last steps on ONE row; such a step is answered by the
-          // row's own packed line -- one line, like the rank unit -- which also says whether that row is marked.  If it is, the
-          // pattern's text position is known right here (the marked row's offset minus the symbols still to go) and the row
-          // expansion skips the walk: with marks every 10th position and ~5 one-row steps per 20-mer, half of the patterns --
-          // the half with the LONGEST walks -- never walk at all.
-          int64_t pos;
-          P::single_row_step(ix, code, first, last, &pos);
-          if (pos >= 0 && sa_hint < 0) sa_hint = pos - int64_t(len - j);     // SA of the row BEFORE this step = position of symbol j's successor
-        } else {
-          P::search_step(ix, j, code, first, last);
-          sa_hint = -1;
-        }
+        P::search_step(ix, j, code, first, last);
+        sa_hint = -1;
         if (first > last) { finished = true; break; }
         tried = false;
         ones = first == last ? ones + 1 : 0;
@@ -496,7 +484,7 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
         // position already -- it is where the compared text starts.  Handing it to plan_rows_kernel saves that pattern's
         // suffix-array read there: one scattered request less per located pattern.  Written by the wavefronts that hold
         // a one-row pattern only (plan_rows_kernel reads sa_out[q] only where noccs[q] == 1); -1 = not known.
-        if ((kDense || P::kSpotMarks) && sa_out) {
+        if (kDense && sa_out) {
           if (__ballot(nocc == 1)) sa_out[q] = first == last ? sa_hint : -1;
         }
       }
@@ -755,7 +743,7 @@ inline __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npa
     }
     s_incl[wave][lane] = inc;
     int64_t f0 = mine ? (first32 ? int64_t(first32[q].x) : first[q]) : 0;      // (only ranges with rows: most lines of first[] are never touched on a random batch)
-    if (kMode != kRowsOnly && sa_known && mine == 1u) {    // the count kernel may know this row's position: ~position < 0 in place of the row
+    if (kMode == kRowsSa && sa_known && mine == 1u) {      // the count kernel may know this row's position: ~position < 0 in place of the row
       const int64_t known = sa_known[q];
       if (known >= 0) f0 = ~known;
     }
@@ -784,7 +772,7 @@ inline __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npa
               trace_touch(ix, kTraceSa, uint64_t(row) >> 4);
             }
           } else {
-            offsets[slot] = f < 0 ? ~f : walk_row<P>(ix, row);      // (f < 0: spotted during the search, no walk)
+            offsets[slot] = walk_row<P>(ix, row);
           }
         }
       }

@@ -399,11 +399,8 @@ int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const in
   const bool dense = inline_tail;
   // one-row patterns whose text position the search already knows (the text tail's, the wide context table's): handed to
   // plan_rows_kernel, which then skips their suffix-array read (S.noccs64 is free on this path: the block sums replace the scan)
-  // ... or, on a small-alphabet handle WITHOUT the dense arrays and the text (a footprint-bounded open): positions spotted on marked
-  // rows during the one-row steps of the search (direct_kernels.hip.hpp "mark spotting"): the row expansion skips those walks
-  const bool spot = plan && !dense && !tail && ix->mode == 3 && d.pack && d.pack_sa && knob(-1, "FEMTO_AMD_SPOT_MARKS", 1) != 0;
   int64_t* sa_out = nullptr;
-  if (plan && (dense || spot)) {
+  if (plan && dense) {
     if ((rc = S.noccs64.reserve(size_t(npats + 1) * 8))) return rc;
     sa_out = S.noccs64.as<int64_t>();
     plan->sa_known = sa_out;

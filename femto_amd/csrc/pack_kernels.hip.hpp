@@ -204,39 +204,6 @@ __device__ __forceinline__ PackStep pack_step(const PackLine& L, uint32_t r) {
   return s;
 }
 
-// A search step on a range of ONE row, answered by the row's own packed line (an LF step that checks its character): the
-// line holds L[row] -- does the pattern's symbol precede this suffix? --, C + Occ for every character (the row of the
-// preceding position, or the values the reference's step dies with: first = C[c] + Occ(c, row - 1), last = first - 1, since
-// L[row] != c), AND the row's mark bit.  One memory line like the rank unit it replaces; the mark is what it is for: a search
-// of a pattern that occurs spends its last steps on one row, and if one of those rows is marked the pattern's text position
-// is known without any locate walk (count_direct_kernel, "mark spotting").  *pos: SA[row] when the row is marked, else -1.
-__device__ __forceinline__ void pack_single_row_step(const DevIndex& ix, uint32_t code, int64_t& first, int64_t& last, int64_t* pos) {
-  uint64_t line;
-  uint32_t r;
-  pack_split(first, &line, &r);
-  PackLine L;
-  pack_load_line(ix.pack, line, L);
-  trace_touch(ix, kTracePack, line);
-  const PackStep s = pack_step(L, r);
-  *pos = s.marked ? mark_offset_at(ix, s.sa_index) : int64_t(-1);
-  if (s.code == code) {
-    first = last = s.c_plus_occ - 1;
-    return;
-  }
-  PackPlanes P;
-#pragma unroll
-  for (int j = 0; j < 15; j++) P.w[j] = L.w[j];
-  uint32_t lo = 0, hw = 0;
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const uint32_t is = code == uint32_t(j) ? ~0u : 0u;
-    lo |= L.w[20 + j] & is;
-    hw |= ((L.w[29 + (j >> 2)] >> (8 * (j & 3))) & 0xffu) & is;
-  }
-  first = int64_t((uint64_t(hw) << 32) | lo) + int64_t(pack_match(P, code, r));     // rows before `row` in the line that hold `code`
-  last = first - 1;
-}
-
 // rows to locate, written where their offsets will go: pattern q's rows first[q] .. first[q]+noccs-1 at
 // offsets[out_starts[q] ..] (setup_locate_range, src/main/server.c:4047).  One thread per pattern; the walk kernel
 // then needs no search for "which pattern owns output slot i".

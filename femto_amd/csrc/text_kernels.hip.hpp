@@ -27,12 +27,8 @@ struct PackPolicy {
   static constexpr int kWaves = 8;     // waves per SIMD the count kernel is built for (64 VGPRs)
   static constexpr int kDirectWaves = 7;   // ... count_direct_kernel: 72 VGPRs (at 64 it spills 20 bytes per lane)
   static constexpr int kTailRows = 1;  // ranges of up to this many rows take the text tail (direct_kernels.hip.hpp)
-  static constexpr bool kSpotMarks = true;   // one-row steps can be answered from the row's own line, mark bit included
   static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
     pack_search_step(ix, ix.pack, j, code, f, l);
-  }
-  static __device__ __forceinline__ void single_row_step(const DevIndex& ix, uint32_t code, int64_t& f, int64_t& l, int64_t* pos) {
-    pack_single_row_step(ix, code, f, l, pos);
   }
   // one LF step from `row`: its character, mark state and the row of the preceding position
   static __device__ __forceinline__ void lf(const DevIndex& ix, int64_t row, uint32_t& code, bool& marked, int64_t& sa_index, int64_t& next) {
@@ -74,8 +70,6 @@ struct Pack2Policy {
   static constexpr int kWaves = 8;
   static constexpr int kDirectWaves = 8;
   static constexpr int kTailRows = 4;  // repeated phrases of a byte text: a few rows with tens of symbols to go
-  static constexpr bool kSpotMarks = false;
-  static __device__ __forceinline__ void single_row_step(const DevIndex&, uint32_t, int64_t&, int64_t&, int64_t*) {}
   static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
     p2_search_step(ix, j, code, f, l);
   }
