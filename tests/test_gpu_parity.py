@@ -295,7 +295,8 @@ def test_device_chain_walks_inside_the_row_expansion(fixtures, gpu_ok, name):
     dev = "cuda:0"
     d_plen, d_flat, d_starts = torch.from_numpy(plen).to(dev), torch.from_numpy(flat.view(np.int16)).to(dev), torch.from_numpy(starts).to(dev)
     for kw in (dict(dense_arrays=0), dict(dense_arrays=0, mark_every=0), dict(dense_arrays=0, mark_every=3, marks_32bit=0),
-               dict(dense_arrays=0, text=0, rank_units=0), dict(hbm_budget_bytes=600_000), dict(hbm_budget_bytes=150_000)):
+               dict(dense_arrays=0, text=0, rank_units=0), dict(dense_arrays=0, text=0), dict(dense_arrays=0, text=0, mark_every=10),
+               dict(hbm_budget_bytes=600_000), dict(hbm_budget_bytes=150_000)):
         ix = femto_amd.Index(fx.index, device=0, options=kw)
         assert "hbm_budget_bytes" in kw or not ix.pack_info()["sa_full"]
         if ix.rank_mode not in (3, 4) or ix.pack_info()["sa_full"]:      # (a budget that still pays for the dense arrays of a tiny fixture)
@@ -317,6 +318,7 @@ def test_device_chain_walks_inside_the_row_expansion(fixtures, gpu_ok, name):
                     torch.cuda.synchronize()
                     assert total.cpu().tolist() == [tot, 1 if tot > cap else 0], (kw, mo, cap)
                     assert np.array_equal(noccs.cpu().numpy(), g_noccs) and np.array_equal(f.cpu().numpy(), fx.gold["count_first"])
+                    assert np.array_equal(l.cpu().numpy(), fx.gold["count_last"])
                     assert np.array_equal(offs.cpu().numpy()[:min(cap, tot)], g_offs[:min(cap, tot)]), (kw, mo, cap, rep)
         ix.close()
 
