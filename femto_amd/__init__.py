@@ -47,7 +47,7 @@ class Options(C.Structure):
                 ("context2_bytes", C.c_int64), ("tail_min", C.c_int32), ("tail_ones", C.c_int32), ("tail_rows", C.c_int32),
                 ("tail_row_cost", C.c_int32), ("sort_queries", C.c_int32), ("host_threads", C.c_int32), ("host_pipeline", C.c_int32),
                 ("host_keys", C.c_int32), ("host_pipe_chunk_log2", C.c_int32), ("host_d2h_staged", C.c_int32),
-                ("rank_units", C.c_int32), ("marks_32bit", C.c_int32), ("context_mid_table", C.c_int32), ("reserved0", C.c_int32)]
+                ("rank_units", C.c_int32), ("marks_32bit", C.c_int32), ("context_mid_table", C.c_int32), ("wavelet_lines", C.c_int32)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -414,7 +414,7 @@ class Index:
         _check(lib().femto_amd_pack_info(self._h, C.byref(a), C.byref(b), C.byref(ms), C.byref(k)))
         return {"available": bool(a.value & 1), "available2": bool(a.value & 2), "level_table": bool(a.value & 4),
                 "sa_full": bool(a.value & 8), "isa_full": bool(a.value & 16), "char_rank_lines": bool(a.value & 32), "context_table": bool(a.value & 64),
-                "context_syms": (a.value >> 8) & 15, "context2_syms": (a.value >> 12) & 31, "context_mid_syms": (a.value >> 24) & 31, "rank_units": bool(a.value & (1 << 20)),
+                "context_syms": (a.value >> 8) & 15, "context2_syms": (a.value >> 12) & 31, "context_mid_syms": (a.value >> 24) & 31, "rank_units": bool(a.value & (1 << 20)), "rank_units_marked": bool(a.value & (1 << 21)),
                 "bytes": b.value, "build_ms": ms.value, "ktab_syms": k.value}
 
     def structures(self):

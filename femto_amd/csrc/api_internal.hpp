@@ -191,6 +191,7 @@ struct femto_amd_index {
   femto_amd_options_t opt = femto_amd_auto_options();   // the caller's options (femto_amd_open_opts); -1 = auto
   int64_t hbm_free_at_open = -1; // free HBM when this handle started allocating
   bool budget_is_default = false; // opt.hbm_budget_bytes was left on auto: the default bound is in force
+  bool segs_released = false;    // d_segs was dropped after the derivations (release_wavelet_lines); the host copy is the source
   int64_t hbm_held = 0;          // bytes of the handle's PERSISTENT device allocations (big arrays + uploaded tables): what
                                  // hbm_budget_bytes is counted against -- the scratch of the derivations at open comes and goes
   std::vector<std::pair<void*, size_t>> big_allocs;   // big_malloc()ed arrays and their sizes
@@ -348,6 +349,8 @@ int upload(T** dst, const std::vector<T>& src, int64_t* bytes, size_t slack = 0)
 int64_t knob(int64_t opt_value, const char* env_name, int64_t dflt);
 // free HBM as far as this handle may use it: what the device has free, less whatever hbm_budget_bytes forbids
 size_t hbm_free(const femto_amd_index* ix);
+int release_wavelet_lines(femto_amd_index* ix);   // a handle with a budget drops femto's segment lines once the derived layouts stand ...
+int ensure_wavelet_lines(femto_amd_index* ix);    // ... and calls that need them (modes 0/1, forward steps) bring them back (caller holds ix->mu or is the only user)
 hipError_t big_malloc(femto_amd_index* ix, void** out, size_t bytes);
 void big_free(femto_amd_index* ix, void* p);
 hipError_t big_memset(femto_amd_index* ix, void* p, int v, size_t bytes);

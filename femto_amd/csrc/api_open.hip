@@ -320,8 +320,7 @@ int build_ctx_wide(femto_amd_index* ix, int nstop, bool mid) {
 
 // distance between marks in the derived lines (see "denser marks" in pack_kernels.hip.hpp); 0: keep femto's own.
 // Auto: every 5th position -- unless the handle has an HBM budget (femto_amd_options_t::hbm_budget_bytes): then the densest
-// of 5 / 10 / femto's own whose offsets array takes at most an eighth of the budget (a quarter of what the level table,
-// the structure that saves most lines per pattern, is left with).
+// of 5 / 10 / femto's own whose offsets array takes at most a fifth of the budget.
 int64_t mark_entry_bytes(const femto_amd_index* ix) {
   const bool can32 = ix->host.total_length < (int64_t(1) << 32);
   return (can32 && knob(ix->opt.marks_32bit, "FEMTO_AMD_SA32", 1) != 0) ? 4 : 8;
@@ -330,7 +329,9 @@ int derived_mark_every(const femto_amd_index* ix) {
   const HostIndex& h = ix->host;
   int every = 5;
   if (ix->opt.mark_every == -1 && !getenv("FEMTO_AMD_MARK_EVERY") && ix->opt.hbm_budget_bytes >= 0) {
-    const int64_t eb = mark_entry_bytes(ix), cap = ix->opt.hbm_budget_bytes / 8;
+    // (a fifth of the budget and a little: with the marked rank units a search that stands on a marked row needs no walk at all,
+    // and five one-row steps always meet a mark placed every 5th position -- until round 5 the cap was an eighth)
+    const int64_t eb = mark_entry_bytes(ix), cap = ix->opt.hbm_budget_bytes / 5 + ix->opt.hbm_budget_bytes / 1024;
     every = 0;
     for (const int e : {5, 10})
       if (e < h.mark_period && (h.total_length / e + 1) * eb <= cap) { every = e; break; }
@@ -338,6 +339,24 @@ int derived_mark_every(const femto_amd_index* ix) {
   every = int(knob(ix->opt.mark_every, "FEMTO_AMD_MARK_EVERY", every));
   if (every <= 0 || every >= h.mark_period) return 0;
   return every;
+}
+
+// Will build_text keep the suffix array of every row, with `free_b` bytes to spend?  (Its rules, evaluated ahead of time:
+// build_pack chooses between the plain rank units and the marked ones with it -- marks only matter to handles that walk.)
+bool sa_will_be_resident(const femto_amd_index* ix, size_t free_b) {
+  if (knob(ix->opt.text, "FEMTO_AMD_TEXT", 1) == 0 || knob(ix->opt.dense_arrays, "FEMTO_AMD_DENSE", 1) == 0) return false;
+  const int64_t n = ix->host.total_length;
+  int isa_shift = kIsaShift;
+  bool want_sa = false;
+  if (double(n + 2) * 16.0 <= 0.55 * double(free_b)) {
+    isa_shift = 0;
+    want_sa = true;
+  } else if (double(n) * 8.0 <= 0.30 * double(free_b)) {
+    want_sa = true;
+  }
+  const size_t tb = size_t(n) + 64, ib = (size_t(n >> isa_shift) + 2) * 8, sb = want_sa ? size_t(n) * 8 + 64 : 0;
+  if (ix->opt.hbm_budget_bytes >= 0 && tb + ib + sb > free_b / 5) return false;
+  return want_sa;
 }
 
 // Derives the packed lines of pack_kernels.hip.hpp on the GPU from the uploaded index (needs the lane tables).
@@ -375,6 +394,7 @@ int build_pack(femto_amd_index* ix) {
   const int64_t nlines = (n + kPackRows - 1) / kPackRows;
   const int64_t stride = nlines + 1;
   DeviceBuffer sym, counts, scans;
+  bool ru_marked = false;
   auto cleanup = [&]() { sym.release(); counts.release(); scans.release(); };
   auto body = [&]() -> int {
     int rc;
@@ -399,9 +419,19 @@ int build_pack(femto_amd_index* ix) {
     {  // rank units of the table characters (ru_kernels.hip.hpp) while the rows' codes are at hand -- optional: a third of
        // the free HBM at most, and only below 2^35 rows (ru_split)
       const int nstop = __builtin_popcount(ix->dev.pack_stop), ntab = sigma - nstop;
-      const int64_t ustride = (n + kRuRows - 1) / kRuRows + 1;
+      // rank_units: 0 none, 1 auto, 2 the plain units of 88 rows, 3 the MARKED units of 64 rows.  Auto: marked when the handle
+      // will not hold the suffix array (every located row then costs a walk, which a marked row met during the search saves)
+      const int64_t ru_knob = knob(ix->opt.rank_units, "FEMTO_AMD_RU", 1);
+      const size_t ru_est = size_t(std::max(ntab, 0)) * size_t(n / kRuRows + 2) * 16;
+      // (what the budget has left counts the wavelet segment lines as gone where open releases them after the derivations)
+      const bool segs_go = ix->d_segs && ix->stripe_devices.empty() &&
+                           knob(ix->opt.wavelet_lines, "FEMTO_AMD_WAVELET_LINES", ix->opt.hbm_budget_bytes >= 0 ? 0 : 1) == 0;
+      const size_t free_now = hbm_free(ix) + (segs_go && ix->opt.hbm_budget_bytes >= 0 ? h.segs.size() * 8 : 0);
+      ru_marked = ru_knob == 3 || (ru_knob == 1 && !sa_will_be_resident(ix, free_now > ru_est ? free_now - ru_est : 0));
+      const int urows = ru_marked ? kRumRows : kRuRows;
+      const int64_t ustride = (n + urows - 1) / urows + 1;
       const size_t rbytes = size_t(std::max(ntab, 0)) * size_t(ustride) * 16;
-      const bool want = knob(ix->opt.rank_units, "FEMTO_AMD_RU", 1) != 0;
+      const bool want = ru_knob != 0;
       // (a handle with an HBM budget: at most half of what the budget has left -- the level table takes the rest)
       // the rows of the stop characters (one per document and character <= SEOF): 8 bytes each, listed for ru_stop_step
       int64_t nstoprows = 0;
@@ -411,7 +441,7 @@ int build_pack(femto_amd_index* ix) {
         soff[c + 1] = int32_t(std::min<int64_t>(nstoprows, INT32_MAX));
       }
       if (want && ntab >= 1 && nstop <= 3 && nstoprows < INT32_MAX && n < (int64_t(1) << 35) &&
-          rbytes + size_t(nstoprows) * 8 <= hbm_free(ix) / (ix->opt.hbm_budget_bytes >= 0 ? 2 : 3) &&
+          rbytes + size_t(nstoprows) * 8 <= free_now / (ix->opt.hbm_budget_bytes >= 0 ? 2 : 3) &&
           big_malloc(ix, reinterpret_cast<void**>(&ix->d_ru), rbytes + 256) == hipSuccess &&
           big_malloc(ix, reinterpret_cast<void**>(&ix->d_ru_stop), size_t(nstoprows) * 8 + 64) == hipSuccess) {
         DevIndex d = ix->dev;
@@ -420,10 +450,12 @@ int build_pack(femto_amd_index* ix) {
         hipLaunchKernelGGL(ru_stop_rows_kernel, dim3(uint32_t((nlines + 255) / 256)), dim3(256), 0, nullptr, d, nlines, n, sym.as<uint8_t>(),
                            scans.as<int64_t>(), stride, nstop, ix->d_ru_stop);
         ix->dev.ru_stop_rows = ix->d_ru_stop;
-        hipLaunchKernelGGL(ru_build_kernel, dim3(uint32_t((ustride + 255) / 256)), dim3(256), 0, nullptr, d, n, sym.as<uint8_t>(), reinterpret_cast<uint4*>(ix->d_ru), ustride,
-                           nstop, ntab);
-        HIP_TRY(hipGetLastError());
-        ix->dev.ru = ix->d_ru;
+        if (!ru_marked) {
+          hipLaunchKernelGGL(ru_build_kernel, dim3(uint32_t((ustride + 255) / 256)), dim3(256), 0, nullptr, d, n, sym.as<uint8_t>(), reinterpret_cast<uint4*>(ix->d_ru), ustride,
+                             nstop, ntab);
+          HIP_TRY(hipGetLastError());
+          ix->dev.ru = ix->d_ru;
+        }      // (the marked units are filled below, once the lines' mark planes are final)
         ix->dev.ru_stride = ustride;
         ix->dev.ru_nstop = nstop;
         ix->ru_bytes = int64_t(rbytes) + nstoprows * 8;
@@ -467,6 +499,16 @@ int build_pack(femto_amd_index* ix) {
                            ix->d_pack, ix->d_pack_sa);
     }
     HIP_TRY(hipGetLastError());
+    if (ru_marked && ix->d_ru) {      // the marked rank units: the mark planes are final now
+      DevIndex d = ix->dev;
+      d.pack = ix->d_pack;
+      const int nstop = __builtin_popcount(ix->dev.pack_stop);
+      hipLaunchKernelGGL(rum_build_kernel, dim3(uint32_t((ix->dev.ru_stride + 255) / 256)), dim3(256), 0, nullptr, d, n, sym.as<uint8_t>(),
+                         reinterpret_cast<uint4*>(ix->d_ru), ix->dev.ru_stride, nstop, sigma - nstop);
+      HIP_TRY(hipGetLastError());
+      ix->dev.ru = ix->d_ru;
+      ix->dev.ru_marks = 1;
+    }
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     ix->n_marks = nmarks;
@@ -670,6 +712,7 @@ int build_text(femto_amd_index* ix) {
   const int64_t n = ix->host.total_length;
   const bool dense = knob(ix->opt.dense_arrays, "FEMTO_AMD_DENSE", 1) != 0;
   const size_t free_b = hbm_free(ix);
+  // (sa_will_be_resident above repeats the rules below for build_pack's choice of rank units)
   // Dense arrays -- SA of every row and ISA of every position, 8 B each per row -- when the pair takes at most 55 % of
   // the free HBM (the level table, built next, takes at most a quarter of what is left): 17 GB of 288 at 1 GiB of text,
   // 137 GB at 8 GiB (BASELINE configs[4]: a located row is then one read instead of up to four LF steps).  Failing that
@@ -902,6 +945,12 @@ int femto_amd::open_impl(const char* index_path, int device, int part, int npart
         r = 0;
       }
       if (r) return r;
+      // a handle with a budget: femto's wavelet tree as segment lines has served every derivation above and is not read by the
+      // derived layouts' kernels -- released (0.76 GB of a 1 GiB DNA index; it comes back, counted, when a call needs it:
+      // ensure_wavelet_lines) so that the budget pays for structures the searches read
+      if ((ix->dev.pack || ix->dev.p2_l1) && knob(ix->opt.wavelet_lines, "FEMTO_AMD_WAVELET_LINES", ix->opt.hbm_budget_bytes >= 0 ? 0 : 1) == 0 &&
+          (r = release_wavelet_lines(ix)))
+        return r;
       if ((ix->dev.pack || ix->dev.p2_l1) && (r = build_text(ix)) && r != FEMTO_AMD_ERR_MEM) return r;
       if (ix->dev.pack) ix->mode = 3;
       else if (ix->dev.p2_l1) ix->mode = 4;
@@ -920,6 +969,7 @@ int femto_amd::open_impl(const char* index_path, int device, int part, int npart
       else if (want_mode == 1 && h.dir_regular) ix->mode = 1;
       else if (want_mode == 3 && ix->dev.pack) ix->mode = 3;
       else if (want_mode == 4 && ix->dev.p2_l1) ix->mode = 4;
+      if (ix->mode <= 1 && (r = ensure_wavelet_lines(ix))) return r;      // (a handle opened INTO femto's own tables needs them after all)
       return 0;
     };
     g_small_registry = &ix->small_tables;

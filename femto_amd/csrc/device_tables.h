@@ -136,7 +136,7 @@ struct DevIndex {           // passed by value to kernels
   const int64_t* ru_stop_rows;   // rows whose L is a stop character, per character in row order (ru_stop_step)
   int32_t ru_stop_off[4];   // stop character c's rows: entries ru_stop_off[c] .. ru_stop_off[c + 1] - 1
   int32_t pack_sa32;        // 1: pack_sa holds 32-bit offsets (indexes of fewer than 2^32 rows, half the bytes)
-  int32_t ru_pad;
+  int32_t ru_marks;         // 1: the units are the MARKED ones of 64 rows (ru_kernels.hip.hpp: mark bits of the rows holding the character)
   const int64_t* ktab2;     // level table of the first steps, heap-numbered over the table characters (direct_kernels.hip.hpp)
   int32_t kt2_syms;         // deepest level K
   int32_t kt2_base;         // t = number of table characters (characters of the text that are not <= SEOF)

@@ -267,6 +267,7 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
     };
     auto alpha = [&](int j) -> uint32_t { return pat[len - 1 - j]; };     // the symbol itself (0xFF cases only)
     int64_t first = 0, last = ix.total_length - 1;
+    int64_t spot = -1;          // P::kSpotMarks: the last marked row a one-row step stood on | symbols it had to go << 40
     int64_t sa_hint = -1;       // SA[first] where it is known: as the wide context table delivered it, or behind a text tail that left one row;
                                 // forgotten with the next search step
     int j = 0;
@@ -355,7 +356,21 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
             break;
           }
         }
-        P::search_step(ix, j, code, first, last);
+        if constexpr (P::kSpotMarks && kPlan && !kDense) {
+          // MARK SPOTTING (handles without the suffix array: every located row costs a walk to the next mark).  A pattern that
+          // occurs spends its last steps on ONE row, and the marked rank unit a step loads anyway says whether that row is
+          // marked.  A marked row met with len - j symbols to go fixes the pattern's text position: SA[final row] =
+          // SA[this row] - (len - j); plan_rows_kernel then reads that row's mark instead of walking from the final row.
+          // The hint travels as row | symbols-to-go << 40 (one register pair); a step with a stop character forgets it (a
+          // walk does not cross a document start, server.c:2336-2342).
+          bool spotted;
+          const int64_t row = last;
+          P::search_step_spot(ix, j, code, first, last, &spotted);
+          if (P::is_stop(ix, code)) spot = -1;
+          else if (spotted && len - j < (1 << 22)) spot = row | (int64_t(len - j) << 40);
+        } else {
+          P::search_step(ix, j, code, first, last);
+        }
         sa_hint = -1;
         if (first > last) { finished = true; break; }
         tried = false;
@@ -487,9 +502,14 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
         if (kDense && sa_out) {
           if (__ballot(nocc == 1)) sa_out[q] = first == last ? sa_hint : -1;
         }
+        // ... or, without the suffix array, a marked row the search stood on: <= -2 encodes the hint (see "MARK SPOTTING")
+        if (!kDense && P::kSpotMarks && sa_out) {
+          if (__ballot(nocc == 1)) sa_out[q] = (first == last && spot >= 0) ? -2 - spot : -1;
+        }
       }
     } else if (kPlan) {
       noccs[q] = 0;    // count_tail_kernel stores the real value and adds it to the block's sum
+      if (!kDense && P::kSpotMarks && sa_out) sa_out[q] = -1;
     }
   }
   if (kPlan) {
@@ -747,6 +767,10 @@ inline __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npa
       const int64_t known = sa_known[q];
       if (known >= 0) f0 = ~known;
     }
+    if (kMode == kRowsWalk && sa_known && mine == 1u) {    // ... or a MARKED row its search stood on (<= -2: marked row | symbols to go << 40)
+      const int64_t known = sa_known[q];
+      if (known <= -2) f0 = known;
+    }
     s_first[wave][lane] = f0;
     s_lbase[wave][lane] = base;      // slots are addressed per lane: a long range keeps its slots but is not written here
     const uint32_t total = uint32_t(__shfl(int(inc), 63, 64));
@@ -771,6 +795,10 @@ inline __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npa
               offsets[slot] = ix.sa_full[row];
               trace_touch(ix, kTraceSa, uint64_t(row) >> 4);
             }
+          } else if (f <= -2) {      // spotted during the search: the marked row's offset minus the symbols searched after it
+            const int64_t h = -2 - f;
+            const int64_t off = P::marked_offset(ix, h & ((int64_t(1) << 40) - 1));
+            offsets[slot] = off < 0 ? -1 : off - (h >> 40);
           } else {
             offsets[slot] = walk_row<P>(ix, row);
           }

@@ -252,6 +252,36 @@ hipError_t big_h2d(femto_amd_index* ix, void* p, const void* src, size_t bytes) 
   return big_pieces(ix, p, bytes, [&](char* dst, size_t off, size_t n) { return hipMemcpy(dst, static_cast<const char*>(src) + off, n, hipMemcpyHostToDevice); });
 }
 
+// femto's wavelet tree as segment lines (HostIndex::segs -> d_segs): the source of every derivation and the data of modes 0/1,
+// not read by the derived layouts' kernels.  A handle with a budget releases them after open (0.76 GB of a 1 GiB DNA index)
+// and uploads them again -- counted in hbm_held -- when a call needs them.
+int release_wavelet_lines(femto_amd_index* ix) {
+  if (!ix->d_segs || ix->split_parts > 0 || !ix->stripe_devices.empty()) return 0;
+  HIP_TRY(hipDeviceSynchronize());
+  big_free(ix, ix->d_segs);
+  ix->d_segs = nullptr;
+  ix->dev.segs = nullptr;
+  ix->table_bytes -= int64_t(ix->host.segs.size() * 8);
+  ix->segs_released = true;
+  return 0;
+}
+int ensure_wavelet_lines(femto_amd_index* ix) {
+  if (!ix->segs_released || ix->d_segs) return 0;
+  HostIndex& h = ix->host;
+  const size_t sb = h.segs.size() * 8, slack = (size_t(h.b_size) / 511 + 4) * 128;
+  if (big_malloc(ix, reinterpret_cast<void**>(&ix->d_segs), sb + slack) != hipSuccess) {
+    (void)hipGetLastError();
+    ix->d_segs = nullptr;
+    return set_err(FEMTO_AMD_ERR_MEM, "no HBM for femto's wavelet segment lines (modes 0/1)");
+  }
+  if (sb) HIP_TRY(big_h2d(ix, ix->d_segs, h.segs.data(), sb));
+  HIP_TRY(big_memset(ix, reinterpret_cast<char*>(ix->d_segs) + sb, 0, slack));
+  ix->dev.segs = ix->d_segs;
+  ix->table_bytes += int64_t(sb);
+  ix->segs_released = false;
+  return 0;
+}
+
 int ensure_device(femto_amd_index* ix) {
   if (ix->device < 0) return set_err(FEMTO_AMD_ERR_INVALID, "index was opened without a device (parse-only handle)");
   if (ix->split_parts > 0 && !ix->split_ready)
@@ -318,7 +348,10 @@ void launch_tail(femto_amd_index* ix, const DevIndex& d, dim3 grid, hipStream_t 
                  const TailOut& out, int* err_flag) {
   const dim3 block{uint32_t(kBlockThreads)};
   const int* n_items = d.tail_count;
-  if (ix->mode == 3 && d.ru) {
+  if (ix->mode == 3 && d.ru && d.ru_marks) {
+    if (d.sa_full) hipLaunchKernelGGL((count_tail_kernel<RumPolicy, true>), grid, block, 0, stream, d, items, n_items, d_plen, d_pats, d_starts, perm, keys, bits, nsym, out, err_flag);
+    else hipLaunchKernelGGL((count_tail_kernel<RumPolicy, false>), grid, block, 0, stream, d, items, n_items, d_plen, d_pats, d_starts, perm, keys, bits, nsym, out, err_flag);
+  } else if (ix->mode == 3 && d.ru) {
     if (d.sa_full) hipLaunchKernelGGL((count_tail_kernel<RuPolicy, true>), grid, block, 0, stream, d, items, n_items, d_plen, d_pats, d_starts, perm, keys, bits, nsym, out, err_flag);
     else hipLaunchKernelGGL((count_tail_kernel<RuPolicy, false>), grid, block, 0, stream, d, items, n_items, d_plen, d_pats, d_starts, perm, keys, bits, nsym, out, err_flag);
   } else if (ix->mode == 3) {
@@ -399,8 +432,11 @@ int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const in
   const bool dense = inline_tail;
   // one-row patterns whose text position the search already knows (the text tail's, the wide context table's): handed to
   // plan_rows_kernel, which then skips their suffix-array read (S.noccs64 is free on this path: the block sums replace the scan)
+  // ... or, on a handle WITHOUT the suffix array whose rank units carry the rows' mark bits (ru_kernels.hip.hpp), a marked
+  // row the search stood on: plan_rows_kernel starts from it instead of walking from the final row ("mark spotting")
+  const bool spot = plan && !dense && ix->mode == 3 && d.ru && d.ru_marks && d.pack && d.pack_sa;
   int64_t* sa_out = nullptr;
-  if (plan && dense) {
+  if (plan && (dense || spot)) {
     if ((rc = S.noccs64.reserve(size_t(npats + 1) * 8))) return rc;
     sa_out = S.noccs64.as<int64_t>();
     plan->sa_known = sa_out;
@@ -412,7 +448,8 @@ int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const in
     else if (dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, false, true>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, ps, big_flag, sa_out);     \
     else hipLaunchKernelGGL((count_direct_kernel<POLICY, false, false>), grid, block, 0, stream, d, npats, d_plen, d_pats, d_starts, d_first, d_last, S.err, mo, noccs, ps, big_flag, sa_out);              \
   } while (0)
-  if (ix->mode == 3 && d.ru) LAUNCH_COUNT_DIRECT(RuPolicy);     // rank units: one 16-byte load per range end and step
+  if (ix->mode == 3 && d.ru && d.ru_marks) LAUNCH_COUNT_DIRECT(RumPolicy);     // ... of 64 rows with their mark bits
+  else if (ix->mode == 3 && d.ru) LAUNCH_COUNT_DIRECT(RuPolicy);     // rank units: one 16-byte load per range end and step
   else if (ix->mode == 3) LAUNCH_COUNT_DIRECT(PackPolicy);
   else if (d.ind) LAUNCH_COUNT_DIRECT(IndPolicy);     // per-character rank lines: one line per range end and step
   else LAUNCH_COUNT_DIRECT(Pack2Policy);
@@ -541,7 +578,8 @@ int launch_count_keys(femto_amd_index* ix, int64_t n, const uint64_t* d_keys, in
     if (plan) hipLaunchKernelGGL((count_keys_kernel<POLICY, true>), grid, block, 0, stream, ix->dev, n, d_keys, bits, nsym, out32, d_first, d_last, mo, noccs, ps, big_flag); \
     else hipLaunchKernelGGL((count_keys_kernel<POLICY, false>), grid, block, 0, stream, ix->dev, n, d_keys, bits, nsym, out32, d_first, d_last, mo, noccs, ps, big_flag);     \
   } while (0)
-  if (ix->mode == 3 && ix->dev.ru) LAUNCH_KEYS(RuPolicy);
+  if (ix->mode == 3 && ix->dev.ru && ix->dev.ru_marks) LAUNCH_KEYS(RumPolicy);
+  else if (ix->mode == 3 && ix->dev.ru) LAUNCH_KEYS(RuPolicy);
   else if (ix->mode == 3) LAUNCH_KEYS(PackPolicy);
   else if (ix->dev.ind) LAUNCH_KEYS(IndPolicy);
   else LAUNCH_KEYS(Pack2Policy);
@@ -1067,6 +1105,10 @@ int femto_amd_block_requests(femto_amd_index_t* ix, int64_t n, const int64_t* ro
     if (ch_in && ch_in[i] >= kAlphaSize) return set_err(FEMTO_AMD_ERR_PARAM, "character out of range");
   }
   if (n == 0) return FEMTO_AMD_OK;
+  {      // LOCATION requests are answered from femto's own mark tables, whatever the mode (lane_mark_offset)
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if ((rc = ensure_wavelet_lines(ix))) return rc;
+  }
   Lease L(ix);
   if (!L.s) return L.rc;
   Scratch& S = *L.s;
@@ -1131,6 +1173,10 @@ int femto_amd_forward_steps(femto_amd_index_t* ix, int64_t n, const int64_t* row
   for (int64_t i = 0; i < n; i++)
     if (rows[i] < 0 || rows[i] >= ix->host.total_length) return set_err(FEMTO_AMD_ERR_PARAM, "row out of range");
   if (n == 0) return FEMTO_AMD_OK;
+  {
+    std::lock_guard<std::mutex> lk(ix->mu);      // femto's own tables answer this: bring the segment lines back if the handle released them
+    if ((rc = ensure_wavelet_lines(ix))) return rc;
+  }
   Lease L(ix);
   if (!L.s) return L.rc;
   Scratch& S = *L.s;
@@ -1291,6 +1337,10 @@ int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode) {
     return set_err(FEMTO_AMD_ERR_INVALID, "this index has a short non-final segment: only the raw walk (mode 0) applies");
   if (ix->split_parts > 0 && mode != 1) return set_err(FEMTO_AMD_ERR_INVALID, "a range-split index runs the lane kernels (mode 1) only");
   std::lock_guard<std::mutex> lk(ix->mu);
+  if (mode <= 1 && ix->device >= 0) {      // femto's own wavelet tree: its segment lines may have been released (a handle with a budget)
+    HIP_TRY(hipSetDevice(ix->device));
+    if (int rc = ensure_wavelet_lines(ix)) return rc;
+  }
   ix->mode = mode;
   return FEMTO_AMD_OK;
 }
@@ -1323,6 +1373,7 @@ int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* by
   if (available && ix->dev.ctx2) *available |= ix->dev.ctx2_syms << 12;        // bits 12-16: H2 of the wide context table
   if (available && ix->dev.ctxm) *available |= ix->dev.ctxm_syms << 24;        // bits 24-28: HM of the table in between
   if (available && ix->dev.ru) *available |= 1 << 20;   // bit 20: rank units (small alphabets)
+  if (available && ix->dev.ru && ix->dev.ru_marks) *available |= 1 << 21;   // bit 21: ... the marked ones (64 rows + mark bits)
   if (available && ix->dev.sa_full) *available |= 8;  // bit 3: the full suffix array is resident
   if (available && ix->dev.isa8 && ix->dev.isa_shift == 0) *available |= 16;   // bit 4: the full inverse suffix array
   if (bytes) *bytes = ix->pack_bytes + ix->pack2_bytes;

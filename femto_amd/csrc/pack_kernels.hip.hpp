@@ -204,6 +204,30 @@ __device__ __forceinline__ PackStep pack_step(const PackLine& L, uint32_t r) {
   return s;
 }
 
+// SA[row] of a row the caller KNOWS to be marked (count_direct_kernel met it during a search: the marked rank units of
+// ru_kernels.hip.hpp): only the line's mark plane and mark count are read -- three of its eight 16-byte pieces -- then the
+// offset.  A row that is not marked after all (a damaged index): -1.
+__device__ __forceinline__ int64_t pack_marked_offset(const DevIndex& ix, int64_t row) {
+  uint64_t line;
+  uint32_t r;
+  pack_split(row, &line, &r);
+  const uint4* lp = reinterpret_cast<const uint4*>(ix.pack + line * kPackLineWords);
+  const uint4 a = lp[3], b = lp[4], c = lp[7];     // dwords 12..15, 16..19, 28..31
+  trace_touch(ix, kTracePack, line);
+  const uint32_t m[kPackPlaneWords] = {a.w, b.x, b.y, b.z, b.w};
+  uint32_t xm = 0, mb = 0;
+#pragma unroll
+  for (int k = 0; k < kPackPlaneWords; k++) {
+    const uint32_t d = r - 32u * uint32_t(k);
+    xm |= m[k] & (d < 32u ? (1u << d) : 0u);
+    const int bits = int(r) - 32 * k;
+    const uint32_t below = bits >= 32 ? ~0u : (bits <= 0 ? 0u : ((1u << bits) - 1u));
+    mb += uint32_t(__popc(m[k] & below));
+  }
+  if (!xm) return -1;
+  return mark_offset_at(ix, int64_t((uint64_t(c.w & 0xffu) << 32) | c.x) + int64_t(mb));
+}
+
 // rows to locate, written where their offsets will go: pattern q's rows first[q] .. first[q]+noccs-1 at
 // offsets[out_starts[q] ..] (setup_locate_range, src/main/server.c:4047).  One thread per pattern; the walk kernel
 // then needs no search for "which pattern owns output slot i".

@@ -531,7 +531,8 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   }
   const size_t lds = nfa_lds_bytes(B.lds_nodes, B.lds_children);
   int per_cu = 8;
-  if (mode == 3 && ix->dev.ru) per_cu = nfa_blocks_per_cu<RuPolicy>(lds);
+  if (mode == 3 && ix->dev.ru && ix->dev.ru_marks) per_cu = nfa_blocks_per_cu<RumPolicy>(lds);
+  else if (mode == 3 && ix->dev.ru) per_cu = nfa_blocks_per_cu<RuPolicy>(lds);
   else if (mode == 3) per_cu = nfa_blocks_per_cu<PackPolicy>(lds);
   else if (mode == 4 && ix->dev.ind) per_cu = nfa_blocks_per_cu<IndPolicy>(lds);
   else if (mode == 4) per_cu = nfa_blocks_per_cu<Pack2Policy>(lds);
@@ -572,7 +573,8 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
     HIP_TRY(hipMemsetAsync(d_next, 0, 4, st));
     hipEvent_t te0 = nullptr, te1 = nullptr;
     const bool timed = timer_begin(ix, ix->t_regexp, st, &te0, &te1);
-    if (mode == 3 && ix->dev.ru) launch_nfa<RuPolicy>(ix->dev, B, blocks, lds, st);
+    if (mode == 3 && ix->dev.ru && ix->dev.ru_marks) launch_nfa<RumPolicy>(ix->dev, B, blocks, lds, st);
+    else if (mode == 3 && ix->dev.ru) launch_nfa<RuPolicy>(ix->dev, B, blocks, lds, st);
     else if (mode == 3) launch_nfa<PackPolicy>(ix->dev, B, blocks, lds, st);
     else if (mode == 4 && ix->dev.ind) launch_nfa<IndPolicy>(ix->dev, B, blocks, lds, st);
     else if (mode == 4) launch_nfa<Pack2Policy>(ix->dev, B, blocks, lds, st);

@@ -24,6 +24,8 @@ struct TailItem {
 };
 
 struct PackPolicy {
+  static constexpr bool kSpotMarks = false;   // search steps do not report marked rows (RumPolicy does)
+  static __device__ __forceinline__ int64_t marked_offset(const DevIndex& ix, int64_t row) { return pack_marked_offset(ix, row); }
   static constexpr int kWaves = 8;     // waves per SIMD the count kernel is built for (64 VGPRs)
   static constexpr int kDirectWaves = 7;   // ... count_direct_kernel: 72 VGPRs (at 64 it spills 20 bytes per lane)
   static constexpr int kTailRows = 1;  // ranges of up to this many rows take the text tail (direct_kernels.hip.hpp)
@@ -66,7 +68,22 @@ struct RuPolicy : PackPolicy {
   }
 };
 
+// ... with the MARKED rank units (handles without the suffix array): a one-row step also says whether its row is marked
+struct RumPolicy : PackPolicy {
+  static constexpr int kDirectWaves = FEMTO_AMD_EXP_RU_WAVES;
+  static constexpr bool kSpotMarks = true;
+  static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
+    bool s;
+    rum_search_step(ix, j, code, f, l, &s);
+  }
+  static __device__ __forceinline__ void search_step_spot(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l, bool* spotted) {
+    rum_search_step(ix, j, code, f, l, spotted);
+  }
+};
+
 struct Pack2Policy {
+  static constexpr bool kSpotMarks = false;
+  static __device__ __forceinline__ int64_t marked_offset(const DevIndex&, int64_t) { return -1; }
   static constexpr int kWaves = 8;
   static constexpr int kDirectWaves = 8;
   static constexpr int kTailRows = 4;  // repeated phrases of a byte text: a few rows with tens of symbols to go

@@ -57,9 +57,11 @@ hipError_t traced_count_plan(const TraceArgs& a) {
 #define LAUNCH_COUNT_DIRECT(POLICY)                                                                                                     \
   do {                                                                                                                                  \
     if (dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, true, true>), grid, block, 0, a.stream, d, a.npats, a.plen, a.pats, a.starts, a.first, a.last, a.flags, a.max_occs, a.noccs, ps, big_flag, a.sa_known); \
-    else hipLaunchKernelGGL((count_direct_kernel<POLICY, true, false>), grid, block, 0, a.stream, d, a.npats, a.plen, a.pats, a.starts, a.first, a.last, a.flags, a.max_occs, a.noccs, ps, big_flag, static_cast<int64_t*>(nullptr));     \
+    else hipLaunchKernelGGL((count_direct_kernel<POLICY, true, false>), grid, block, 0, a.stream, d, a.npats, a.plen, a.pats, a.starts, a.first, a.last, a.flags, a.max_occs, a.noccs, ps, big_flag, spot ? a.sa_known : static_cast<int64_t*>(nullptr));     \
   } while (0)
-  if (a.mode == 3 && d.ru) LAUNCH_COUNT_DIRECT(RuPolicy);
+  const bool spot = a.mode == 3 && d.ru && d.ru_marks && d.pack && d.pack_sa && !dense;    // as launch_count_direct decides
+  if (a.mode == 3 && d.ru && d.ru_marks) LAUNCH_COUNT_DIRECT(RumPolicy);
+  else if (a.mode == 3 && d.ru) LAUNCH_COUNT_DIRECT(RuPolicy);
   else if (a.mode == 3) LAUNCH_COUNT_DIRECT(PackPolicy);
   else if (d.ind) LAUNCH_COUNT_DIRECT(IndPolicy);
   else LAUNCH_COUNT_DIRECT(Pack2Policy);
@@ -71,7 +73,10 @@ hipError_t traced_count_plan(const TraceArgs& a) {
     const int* n_items = d.tail_count;
     const uint32_t* perm = nullptr;
     const uint64_t* keys = nullptr;
-    if (a.mode == 3 && d.ru) {
+    if (a.mode == 3 && d.ru && d.ru_marks) {
+      if (d.sa_full) hipLaunchKernelGGL((count_tail_kernel<RumPolicy, true>), tgrid, block, 0, a.stream, d, items, n_items, a.plen, a.pats, a.starts, perm, keys, 1, 0, out, a.flags);
+      else hipLaunchKernelGGL((count_tail_kernel<RumPolicy, false>), tgrid, block, 0, a.stream, d, items, n_items, a.plen, a.pats, a.starts, perm, keys, 1, 0, out, a.flags);
+    } else if (a.mode == 3 && d.ru) {
       if (d.sa_full) hipLaunchKernelGGL((count_tail_kernel<RuPolicy, true>), tgrid, block, 0, a.stream, d, items, n_items, a.plen, a.pats, a.starts, perm, keys, 1, 0, out, a.flags);
       else hipLaunchKernelGGL((count_tail_kernel<RuPolicy, false>), tgrid, block, 0, a.stream, d, items, n_items, a.plen, a.pats, a.starts, perm, keys, 1, 0, out, a.flags);
     } else if (a.mode == 3) {
@@ -107,7 +112,8 @@ hipError_t traced_walk(const TraceArgs& a, int64_t* offsets, int64_t capacity) {
   }
   // sampled marks: the walk runs inside the row expansion, as femto_amd_locate_device launches it
   if (a.mode == 3) {
-    hipLaunchKernelGGL((plan_rows_kernel<kRowsWalk, PackPolicy>), grid, block, 0, a.stream, a.npats, noccs, first, static_cast<const int2*>(nullptr), boffs, a.out_starts, offsets, capacity, a.flags + 1, d, a.total, static_cast<int64_t*>(nullptr), static_cast<const int64_t*>(nullptr));
+    const bool spot = d.ru && d.ru_marks && d.pack && d.pack_sa;      // the count twin left its hints in a.sa_known
+    hipLaunchKernelGGL((plan_rows_kernel<kRowsWalk, PackPolicy>), grid, block, 0, a.stream, a.npats, noccs, first, static_cast<const int2*>(nullptr), boffs, a.out_starts, offsets, capacity, a.flags + 1, d, a.total, static_cast<int64_t*>(nullptr), spot ? static_cast<const int64_t*>(a.sa_known) : static_cast<const int64_t*>(nullptr));
     hipLaunchKernelGGL((plan_big_rows_kernel<kRowsWalk, PackPolicy>), wgrid, block, 0, a.stream, a.npats, first, static_cast<const int2*>(nullptr), ostarts, total, capacity, offsets, big, d);
   } else {
     hipLaunchKernelGGL((plan_rows_kernel<kRowsWalk, Pack2Policy>), grid, block, 0, a.stream, a.npats, noccs, first, static_cast<const int2*>(nullptr), boffs, a.out_starts, offsets, capacity, a.flags + 1, d, a.total, static_cast<int64_t*>(nullptr), static_cast<const int64_t*>(nullptr));

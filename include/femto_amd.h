@@ -408,10 +408,13 @@ typedef struct femto_amd_options {
   int32_t host_keys;             /* 0: host-pointer batches travel as symbols, never as keys              [FEMTO_AMD_HOST_KEYS] */
   int32_t host_pipe_chunk_log2;  /* log2 patterns per pipeline stage; auto 20                             [FEMTO_AMD_PIPE_CHUNK_LOG2] */
   int32_t host_d2h_staged;       /* 0: located offsets return with one plain copy                         [FEMTO_AMD_D2H_STAGED] */
-  int32_t rank_units;            /* 0: skip the 16-byte rank units of small alphabets (ru_kernels.hip.hpp) [FEMTO_AMD_RU] */
+  int32_t rank_units;            /* the 16-byte rank units of small alphabets (ru_kernels.hip.hpp): 0 none, 1 auto, 2 plain (88 rows), 3 marked (64 rows + mark bits; auto picks them when the handle will not hold the suffix array) [FEMTO_AMD_RU] */
   int32_t marks_32bit;           /* 0: derived mark offsets stay 8 bytes; auto: 4 bytes when the index has < 2^32 rows [FEMTO_AMD_SA32] */
   int32_t context_mid_table;     /* 1: a third context table of the length half way between the other two; auto: none [FEMTO_AMD_CTXM] */
-  int32_t reserved0;             /* (keeps the struct a multiple of 8 bytes) */
+  int32_t wavelet_lines;         /* femto's own wavelet tree as segment lines (modes 0/1; every derivation reads them): 1 keep them in HBM |
+                                  * 0 release them once the derived layouts stand (they come back, counted, when a call needs them:
+                                  * femto_amd_set_rank_mode(0/1), femto_amd_forward_steps) | auto: released on handles with a budget,
+                                  * 0.76 GB of a 1 GiB DNA index that then pays for rank units and marks  [FEMTO_AMD_WAVELET_LINES] */
 } femto_amd_options_t;
 void femto_amd_options_init(femto_amd_options_t* opts);
 /* femto_amd_open with options (NULL = all auto = femto_amd_open) */

@@ -54,3 +54,23 @@ def _set_mode(ix, mode):
         pytest.skip("more than 256 distinct characters: no two-level lines for this index")
     ix.set_rank_mode(mode)
     assert ix.rank_mode == mode
+
+
+def device_locate(ix, plen, flat, starts, max_occs, capacity):
+    """femto_amd_locate_device (the one-call device chain: count -> plan_rows with the walk inside) on host arrays:
+    (first, last, noccs, out_starts, offsets[:min(total, capacity)], total)."""
+    import numpy as np
+    import torch
+    dev = "cuda:0"
+    n = len(plen)
+    d_plen, d_flat, d_starts = torch.from_numpy(plen).to(dev), torch.from_numpy(flat.view(np.int16)).to(dev), torch.from_numpy(starts).to(dev)
+    f, l = torch.zeros(n, dtype=torch.int64, device=dev), torch.zeros(n, dtype=torch.int64, device=dev)
+    noccs = torch.zeros(n, dtype=torch.int32, device=dev)
+    ostarts = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    offs = torch.full((capacity,), -7, dtype=torch.int64, device=dev)
+    total = torch.zeros(2, dtype=torch.int64, device=dev)
+    ix.locate_device(n, d_plen.data_ptr(), d_flat.data_ptr(), d_starts.data_ptr(), max_occs, f.data_ptr(), l.data_ptr(), noccs.data_ptr(),
+                     ostarts.data_ptr(), offs.data_ptr(), capacity, total.data_ptr())
+    torch.cuda.synchronize()
+    tot = int(total[0])
+    return (f.cpu().numpy(), l.cpu().numpy(), noccs.cpu().numpy(), ostarts.cpu().numpy(), offs[:min(tot, capacity)].cpu().numpy(), tot)

@@ -10,7 +10,7 @@ import pytest
 import femto_amd
 from conftest import INDEX_FIXTURES
 from femto_amd import textgen as tg
-from gpu_common import MODES, _open, _set_mode, _torchrun
+from gpu_common import MODES, _open, _set_mode, _torchrun, device_locate
 from oracle import pyoracle as po
 
 pytestmark = pytest.mark.gpu
@@ -114,6 +114,11 @@ def test_full_size_1gib_properties(tmp_path, gpu_ok):
     assert np.array_equal(bf, first) and np.array_equal(bl, last)
     bn, bo = bx.locate_flat(plen, flat, starts, 100)
     assert np.array_equal(bn, noccs) and np.array_equal(bo, offs)
+    # ... and through the one-call device chain, where the marked rank units hand plan_rows_kernel a marked row the search
+    # stood on ("mark spotting"): the offsets of every sampled pattern once more
+    assert bx.pack_info()["rank_units_marked"], bx.pack_info()
+    df, dl, dn, dst, do, dtot = device_locate(bx, plen, flat, starts, 100, len(offs) + 16)
+    assert dtot == len(offs) and np.array_equal(df, first) and np.array_equal(dl, last) and np.array_equal(dn, noccs) and np.array_equal(do, offs)
     bx.close()
     # the same index with its big arrays striped over "three GPUs" (all stripes on this one): same kernels, same answers
     sx = femto_amd.Index(path, devices=[0, 0, 0], striped=True)      # (the library's default bound: 8 x text over the three stripes)

@@ -296,9 +296,15 @@ def test_device_chain_walks_inside_the_row_expansion(fixtures, gpu_ok, name):
     d_plen, d_flat, d_starts = torch.from_numpy(plen).to(dev), torch.from_numpy(flat.view(np.int16)).to(dev), torch.from_numpy(starts).to(dev)
     for kw in (dict(dense_arrays=0), dict(dense_arrays=0, mark_every=0), dict(dense_arrays=0, mark_every=3, marks_32bit=0),
                dict(dense_arrays=0, text=0, rank_units=0), dict(dense_arrays=0, text=0), dict(dense_arrays=0, text=0, mark_every=10),
-               dict(hbm_budget_bytes=600_000), dict(hbm_budget_bytes=150_000)):
+               dict(hbm_budget_bytes=600_000), dict(hbm_budget_bytes=150_000),
+               # the marked rank units ("mark spotting": the search hands plan_rows_kernel a marked row it stood on) against the
+               # plain ones, with few table symbols so that most steps run on units, at three mark densities
+               dict(dense_arrays=0, text=0, rank_units=2), dict(dense_arrays=0, text=0, rank_units=3, level_table_syms=2),
+               dict(text=0, rank_units=3, level_table=0, mark_every=3), dict(dense_arrays=0, rank_units=3, mark_every=0, level_table_syms=1)):
         ix = femto_amd.Index(fx.index, device=0, options=kw)
         assert "hbm_budget_bytes" in kw or not ix.pack_info()["sa_full"]
+        if ix.pack_info()["rank_units"]:      # auto: marked exactly where the handle walks
+            assert ix.pack_info()["rank_units_marked"] == (kw.get("rank_units", 1) != 2), (kw, ix.pack_info())
         if ix.rank_mode not in (3, 4) or ix.pack_info()["sa_full"]:      # (a budget that still pays for the dense arrays of a tiny fixture)
             ix.close()
             continue
