@@ -21,7 +21,7 @@ def kernel_names(ix, direct):
     pi = ix.pack_info()
     cn, ln = KERNEL_NAMES[(ix.rank_mode, direct)], LOCATE_NAMES[(ix.rank_mode, direct)]
     if direct and ix.rank_mode == 3 and pi.get("rank_units"):
-        cn = "femto_amd::count_direct_kernel<femto_amd::RuPolicy, true"
+        cn = "femto_amd::count_direct_kernel<femto_amd::RumPolicy, true" if pi.get("rank_units_marked") else "femto_amd::count_direct_kernel<femto_amd::RuPolicy, true"
     if direct and ix.rank_mode == 4 and pi.get("char_rank_lines"):
         cn = "femto_amd::count_direct_kernel<femto_amd::IndPolicy, true"
     if direct:      # locate is fused into the row expansion: offsets from the resident suffix array (1) or by a walk per row (2)

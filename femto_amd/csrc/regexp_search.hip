@@ -77,11 +77,13 @@ struct NfaBatchDev {
   int64_t max_iterations;    // MAX_REGEXP_ITERATIONS (src/main/server.c:40)
   int32_t pass;
   int32_t lds_nodes, lds_children;   // sizes of the workgroup's dynamic LDS arrays (nfa_lds_bytes)
+  int32_t lds_ents;                  // > 0: every automaton's transitions and node flags are copied to LDS (room for this many entries)
 };
 
 // mode 1: femto's own wavelet tree through the derived segment lines (alphabets of more than 256 characters, range-split
 // indexes); "code" is the alpha code itself
 struct WavePolicy {
+  static constexpr int kNfaWaves = 3;
   static __device__ __forceinline__ void search_step(const DevIndex& ix, int, uint32_t ch, int64_t& f, int64_t& l) {
     const int64_t nf = f == 0 ? ix.C[ch] : c_plus_occ_lane(ix, ch, f - 1);
     const int64_t nl = c_plus_occ_lane(ix, ch, l) - 1;
@@ -99,6 +101,14 @@ __device__ __forceinline__ int wave_min_i32(int v) {
   }
   return v;
 }
+// a value every lane of the wavefront holds (read from one address, or the result of a wavefront reduction), moved to a
+// scalar register: the search loop below is one wavefront working on ONE automaton, and most of what it carries -- the
+// popped range, counts, slots -- is uniform; left in vector registers it cost the kernel its occupancy (105 VGPRs)
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t uni64(int64_t v) {
+  const uint32_t lo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(uint64_t(v))))), hi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(uint64_t(v) >> 32))));
+  return int64_t((uint64_t(hi) << 32) | lo);
+}
 __device__ __forceinline__ int wave_sum_i32(int v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
@@ -110,10 +120,18 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 // wavefronts; until round 5 the arrays were static for 2048 nodes and 264 children: 19 KB, 8 workgroups per CU):
 //   s_tmp u32[nn] | s_child_f i64[cc] | s_child_l i64[cc] | s_child_found i32[cc] | s_live i32[cc] | s_child_ch u16[cc] |
 //   s_cur u8[nn] | s_sub u8[nn]            nn = lds_nodes (multiple of 8), cc = lds_children (multiple of 4)
-__host__ __device__ inline size_t nfa_lds_bytes(int nn, int cc) { return size_t(nn) * 4 + size_t(cc) * (8 + 8 + 4 + 4 + 2) + size_t(nn) * 2 + 16; }
+//   kLds (the batch's largest automaton has at most kNfaLdsEnts transitions): + s_ent_sd u32[ne] | s_ent_ch u16[ne] | s_flags u8[nn] --
+//   the automaton itself.  A pop reads the transition list five or six times (deletions, reachable characters,
+//   substitutions, one slice per live child) and the node flags once; from global memory each of those is a dependent
+//   round trip of a kernel that waits two thirds of its cycles (profiles/r05_regexp_stats.txt: SQ_WAIT_ANY 68 % of the
+//   wave cycles at 4 waves per SIMD); the copy is made once per automaton.
+constexpr int kNfaLdsEnts = 2048;
+__host__ __device__ inline size_t nfa_lds_bytes(int nn, int cc, int ne) {
+  return size_t(nn) * 4 + size_t(cc) * (8 + 8 + 4 + 4 + 2) + size_t(nn) * 2 + 16 + size_t(ne) * 6 + (ne ? size_t(nn) + 16 : 0);
+}
 
-template <class P>
-__global__ __launch_bounds__(64) void nfa_search_kernel(const DevIndex ix, const NfaBatchDev B) {
+template <class P, bool kLds>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves, P::kNfaWaves))) void nfa_search_kernel(const DevIndex ix, const NfaBatchDev B) {
   extern __shared__ __align__(16) uint8_t s_dyn[];
   __shared__ int32_t s_bychar[264];
   __shared__ uint32_t s_rc[9];                  // r_c: reachable characters
@@ -128,6 +146,9 @@ __global__ __launch_bounds__(64) void nfa_search_kernel(const DevIndex ix, const
   uint16_t* const s_child_ch = reinterpret_cast<uint16_t*>(s_live + cc);
   uint8_t* const s_cur = reinterpret_cast<uint8_t*>(s_child_ch + cc);            // nfa_states: the popped entry's costs, deletions merged in
   uint8_t* const s_sub = s_cur + nn;                                             // states after one substitution error (any character)
+  uint32_t* const s_ent_sd = reinterpret_cast<uint32_t*>(s_dyn + ((nfa_lds_bytes(nn, cc, 0) + 3) & ~size_t(3)));   // kLds: the automaton's transitions ...
+  uint16_t* const s_ent_ch = reinterpret_cast<uint16_t*>(s_ent_sd + B.lds_ents);
+  uint8_t* const s_flags = reinterpret_cast<uint8_t*>(s_ent_ch + B.lds_ents);                                       // ... and node flags
   const int t = threadIdx.x;
   uint8_t* const arena = B.arena + size_t(blockIdx.x) * size_t(B.arena_bytes);
   const int cap = B.cap;
@@ -155,25 +176,41 @@ __global__ __launch_bounds__(64) void nfa_search_kernel(const DevIndex ix, const
   // loop per pop until round 5).  The ORDER of the children that remain is untouched.
   if (t < 9) s_text[t] = 0;
   __syncthreads();
+  #pragma unroll 1
   for (int c = t; c < kAlphaSize; c += 64)
     if (P::code_of(ix, uint32_t(c)) != 0xffffu) atomicOr(&s_text[c >> 5], 1u << (c & 31));
   __syncthreads();
   for (;;) {
     if (t == 0) s_q = atomicAdd(B.next, 1);
     __syncthreads();
-    const int qi = s_q;
+    const int qi = uni(s_q);
     __syncthreads();
     if (qi >= B.nq) break;
     const int q = B.order ? B.order[qi] : qi;
     const NfaQueryDev Q = B.queries[q];
     const int N = Q.num_nodes, T = Q.num_ents, bound = Q.cost_bound;
     const bool approx = bound > 1;
-    const uint8_t* const flags = B.node_flags + Q.node_off;
-    const uint32_t* const ent_sd = B.ent_sd + Q.ent_off;
-    const uint16_t* const ent_ch = B.ent_ch + Q.ent_off;
+    const uint8_t* const g_flags = B.node_flags + Q.node_off;
+    const uint32_t* const g_ent_sd = B.ent_sd + Q.ent_off;
+    const uint16_t* const g_ent_ch = B.ent_ch + Q.ent_off;
+    if constexpr (kLds) {
+      #pragma unroll 1
+      for (int e = t; e < T; e += 64) {
+        s_ent_sd[e] = g_ent_sd[e];
+        s_ent_ch[e] = g_ent_ch[e];
+      }
+      #pragma unroll 1
+      for (int i = t; i < N; i += 64) s_flags[i] = g_flags[i];
+    }
+    auto ENT_SD = [&](int e) -> uint32_t { if constexpr (kLds) return s_ent_sd[e]; else return g_ent_sd[e]; };
+    auto ENT_CH = [&](int e) -> uint32_t { if constexpr (kLds) return s_ent_ch[e]; else return g_ent_ch[e]; };
+    auto FLAGS = [&](int i) -> uint32_t { if constexpr (kLds) return s_flags[i]; else return g_flags[i]; };
+    #pragma unroll 1
     for (int i = t; i < 262; i += 64) s_bychar[i] = B.bychar[Q.bychar_off + i];
     // the initial mapping: the whole index -> the start states (server.c:1786-1812)
-    for (int i = t; i < N; i += 64) e_cost[i] = (flags[i] & 1u) ? 0 : kNfaDead;
+    #pragma unroll 1
+    for (int i = t; i < N; i += 64) e_cost[i] = (g_flags[i] & 1u) ? 0 : kNfaDead;
+    #pragma unroll 1
     for (int i = t; i < B.hash_size; i += 64) heads[i] = -1;
     __syncthreads();
     if (t == 0) {
@@ -190,17 +227,18 @@ __global__ __launch_bounds__(64) void nfa_search_kernel(const DevIndex ix, const
       if (iters > B.max_iterations) { status = kNfaStatusOverworked; break; }   // server.c:1821
       if (sp == 0) break;
       sp--;
-      const int64_t first = e_first[sp], last = e_last[sp];
-      const int len = e_len[sp];
+      const int64_t first = uni64(e_first[sp]), last = uni64(e_last[sp]);
+      const int len = uni(e_len[sp]);
       if (t == 0) heads[hash_of(first, last)] = e_next[sp];      // the top of the stack is the head of its chain
       // ---- a final state alive: a result, not extended (approx_is_final_state: the first such node's cost)
       int fin = INT_MAX;
+      #pragma unroll 1
       for (int i = t; i < N; i += 64) {
         const uint8_t c = e_cost[size_t(sp) * stride + i];
         s_cur[i] = c;
-        if (int(c) < bound && (flags[i] & 2u) && i < fin) fin = i;
+        if (int(c) < bound && (FLAGS(i) & 2u) && i < fin) fin = i;
       }
-      fin = wave_min_i32(fin);
+      fin = uni(wave_min_i32(fin));
       __syncthreads();
       if (fin != INT_MAX) {
         if (t == 0) {
@@ -213,14 +251,17 @@ __global__ __launch_bounds__(64) void nfa_search_kernel(const DevIndex ix, const
       const int base5 = s_bychar[kNfaOffset];    // entries of characters >= CHARACTER_OFFSET start here
       // ---- deletions: states after reading ANY character at delete_cost, merged in (server.c:1854-1863)
       if (approx) {
+        #pragma unroll 1
         for (int i = t; i < N; i += 64) s_tmp[i] = kNfaDead;
         __syncthreads();
+        #pragma unroll 1
         for (int e = base5 + t; e < T; e += 64) {
-          const uint32_t sd = ent_sd[e];
+          const uint32_t sd = ENT_SD(e);
           const int c = int(s_cur[sd & 0xffffu]) + Q.del;
           if (c < bound) atomicMin(&s_tmp[sd >> 16], uint32_t(c));
         }
         __syncthreads();
+        #pragma unroll 1
         for (int i = t; i < N; i += 64) {
           const uint32_t v = s_tmp[i];
           if (v < uint32_t(s_cur[i])) s_cur[i] = uint8_t(v);
@@ -229,17 +270,19 @@ __global__ __launch_bounds__(64) void nfa_search_kernel(const DevIndex ix, const
       }
       // ---- may any character be an error from here?  (nfa_errcnt_t arithmetic: one byte, as the reference computes it)
       int m = bound;
+      #pragma unroll 1
       for (int i = t; i < N; i += 64) m = int(s_cur[i]) < m ? int(s_cur[i]) : m;
-      m = wave_min_i32(m);
+      m = uni(wave_min_i32(m));
       const int ms = m + Q.subst, mi = m + Q.ins;
       const int min_err = (ms < mi ? ms : mi) & 0xff;
       const bool allchars = min_err < bound && iters > 0;
       // ---- r_c: the characters an alive state can read
       if (t < 9) s_rc[t] = 0;
       __syncthreads();
+      #pragma unroll 1
       for (int e = t; e < T; e += 64)
-        if (int(s_cur[ent_sd[e] & 0xffffu]) < bound) {
-          const uint32_t ch = ent_ch[e];
+        if (int(s_cur[ENT_SD(e) & 0xffffu]) < bound) {
+          const uint32_t ch = ENT_CH(e);
           atomicOr(&s_rc[ch >> 5], 1u << (ch & 31u));
         }
       __syncthreads();
@@ -259,10 +302,11 @@ __global__ __launch_bounds__(64) void nfa_search_kernel(const DevIndex ix, const
       int n_all = 0, n_low;
       {
         const uint32_t w = t < 9 ? s_rc[t] : 0u;
-        n_all = wave_sum_i32(__popc(w));
-        n_low = __popc(s_rc[0] & ((1u << kNfaOffset) - 1u));
+        n_all = uni(wave_sum_i32(__popc(w)));
+        n_low = uni(__popc(s_rc[0] & ((1u << kNfaOffset) - 1u)));
       }
       const int nchild = n_all;       // <= characters of the text <= lds_children
+      #pragma unroll 1
       for (int c = t; c < kAlphaSize; c += 64) {
         if (!((s_rc[c >> 5] >> (c & 31)) & 1u)) continue;
         int rank = __popc(s_rc[c >> 5] & ((1u << (c & 31)) - 1u));
@@ -297,33 +341,39 @@ __global__ __launch_bounds__(64) void nfa_search_kernel(const DevIndex ix, const
       }
       // ---- substitutions: states after reading any character at subst_cost (server.c:2107-2110)
       if (approx) {
+        #pragma unroll 1
         for (int i = t; i < N; i += 64) s_tmp[i] = kNfaDead;
         __syncthreads();
+        #pragma unroll 1
         for (int e = base5 + t; e < T; e += 64) {
-          const uint32_t sd = ent_sd[e];
+          const uint32_t sd = ENT_SD(e);
           const int c = int(s_cur[sd & 0xffffu]) + Q.subst;
           if (c < bound) atomicMin(&s_tmp[sd >> 16], uint32_t(c));
         }
         __syncthreads();
+        #pragma unroll 1
         for (int i = t; i < N; i += 64) s_sub[i] = uint8_t(s_tmp[i]);
       }
       __syncthreads();
       for (int kk = 0; kk < nlive; kk++) {
-        const int k = s_live[kk];
-        const int64_t cf = s_child_f[k], cl = s_child_l[k];
-        const int ch = s_child_ch[k];
+        const int k = uni(s_live[kk]);
+        const int64_t cf = uni64(s_child_f[k]), cl = uni64(s_child_l[k]);
+        const int ch = uni(s_child_ch[k]);
+        #pragma unroll 1
         for (int i = t; i < N; i += 64) s_tmp[i] = kNfaDead;
         __syncthreads();
+        #pragma unroll 1
         for (int e = s_bychar[ch] + t; e < s_bychar[ch + 1]; e += 64) {    // approx_get_reachable_states(ch)
-          const uint32_t sd = ent_sd[e];
+          const uint32_t sd = ENT_SD(e);
           const uint32_t c = s_cur[sd & 0xffffu];
           if (int(c) < bound) atomicMin(&s_tmp[sd >> 16], c);
         }
         __syncthreads();
-        const int found = s_child_found[k];
+        const int found = uni(s_child_found[k]);
         if (found < 0 && sp >= cap) { status = kNfaStatusFull; break; }
         const int slot = found < 0 ? sp : found;
         uint8_t* const dst = e_cost + size_t(slot) * stride;
+        #pragma unroll 1
         for (int i = t; i < N; i += 64) {
           uint32_t v = s_tmp[i];
           if (approx) {
@@ -388,14 +438,17 @@ int validate_nfa(const femto_amd_nfa_t& a, int64_t qi) {
 
 template <class P>
 void launch_nfa(const DevIndex& d, const NfaBatchDev& B, int blocks, size_t lds, hipStream_t st) {
-  hipLaunchKernelGGL((nfa_search_kernel<P>), dim3(uint32_t(blocks)), dim3(64), lds, st, d, B);
+  if (B.lds_ents) hipLaunchKernelGGL((nfa_search_kernel<P, true>), dim3(uint32_t(blocks)), dim3(64), lds, st, d, B);
+  else hipLaunchKernelGGL((nfa_search_kernel<P, false>), dim3(uint32_t(blocks)), dim3(64), lds, st, d, B);
 }
 // workgroups of 64 lanes a CU holds at once with `lds` bytes of dynamic LDS each (the grid is sized to fill the chip once:
 // the workgroups take automata from a counter)
 template <class P>
-int nfa_blocks_per_cu(size_t lds) {
+int nfa_blocks_per_cu(size_t lds, bool lds_ents) {
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, nfa_search_kernel<P>, 64, lds) != hipSuccess || n < 1) n = 8;
+  const hipError_t e = lds_ents ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, nfa_search_kernel<P, true>, 64, lds)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, nfa_search_kernel<P, false>, 64, lds);
+  if (e != hipSuccess || n < 1) n = 8;
   return n;
 }
 
@@ -529,14 +582,19 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
       if (ix->host.C[size_t(c) + 1] > ix->host.C[size_t(c)]) nchars++;
     B.lds_children = (std::max(nchars, 4) + 3) & ~3;
   }
-  const size_t lds = nfa_lds_bytes(B.lds_nodes, B.lds_children);
+  {
+    size_t max_ents = 0;
+    for (const NfaQueryDev& Q : hq) max_ents = std::max(max_ents, size_t(Q.num_ents));
+    B.lds_ents = max_ents <= size_t(kNfaLdsEnts) ? int32_t((std::max<size_t>(max_ents, 2) + 1) & ~size_t(1)) : 0;
+  }
+  const size_t lds = nfa_lds_bytes(B.lds_nodes, B.lds_children, B.lds_ents);
   int per_cu = 8;
-  if (mode == 3 && ix->dev.ru && ix->dev.ru_marks) per_cu = nfa_blocks_per_cu<RumPolicy>(lds);
-  else if (mode == 3 && ix->dev.ru) per_cu = nfa_blocks_per_cu<RuPolicy>(lds);
-  else if (mode == 3) per_cu = nfa_blocks_per_cu<PackPolicy>(lds);
-  else if (mode == 4 && ix->dev.ind) per_cu = nfa_blocks_per_cu<IndPolicy>(lds);
-  else if (mode == 4) per_cu = nfa_blocks_per_cu<Pack2Policy>(lds);
-  else per_cu = nfa_blocks_per_cu<WavePolicy>(lds);
+  if (mode == 3 && ix->dev.ru && ix->dev.ru_marks) per_cu = nfa_blocks_per_cu<RumPolicy>(lds, B.lds_ents != 0);
+  else if (mode == 3 && ix->dev.ru) per_cu = nfa_blocks_per_cu<RuPolicy>(lds, B.lds_ents != 0);
+  else if (mode == 3) per_cu = nfa_blocks_per_cu<PackPolicy>(lds, B.lds_ents != 0);
+  else if (mode == 4 && ix->dev.ind) per_cu = nfa_blocks_per_cu<IndPolicy>(lds, B.lds_ents != 0);
+  else if (mode == 4) per_cu = nfa_blocks_per_cu<Pack2Policy>(lds, B.lds_ents != 0);
+  else per_cu = nfa_blocks_per_cu<WavePolicy>(lds, B.lds_ents != 0);
   per_cu = std::min(per_cu, 32);
   // Stack capacity: most searches keep a few dozen pending entries; the ones that run out (status FULL) are run again
   // with a larger arena and fewer workgroups, up to regexp_stack_cap entries.

@@ -27,6 +27,7 @@ struct PackPolicy {
   static constexpr bool kSpotMarks = false;   // search steps do not report marked rows (RumPolicy does)
   static __device__ __forceinline__ int64_t marked_offset(const DevIndex& ix, int64_t row) { return pack_marked_offset(ix, row); }
   static constexpr int kWaves = 8;     // waves per SIMD the count kernel is built for (64 VGPRs)
+  static constexpr int kNfaWaves = 4;  // ... nfa_search_kernel (regexp_search.hip): what it reaches without scratch
   static constexpr int kDirectWaves = 7;   // ... count_direct_kernel: 72 VGPRs (at 64 it spills 20 bytes per lane)
   static constexpr int kTailRows = 1;  // ranges of up to this many rows take the text tail (direct_kernels.hip.hpp)
   static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
@@ -62,6 +63,7 @@ struct PackPolicy {
 #define FEMTO_AMD_EXP_RU_WAVES 8       // (experiments: tools/ab_bench.sh builds a second library with another value)
 #endif
 struct RuPolicy : PackPolicy {
+  static constexpr int kNfaWaves = 6;  // (80 VGPRs, 8 bytes of scratch: the kernel waits for memory two thirds of its cycles, occupancy is what it lacks)
   static constexpr int kDirectWaves = FEMTO_AMD_EXP_RU_WAVES;   // 43-64 VGPRs: eight waves per SIMD without spilling
   static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
     ru_search_step(ix, j, code, f, l);
@@ -70,6 +72,7 @@ struct RuPolicy : PackPolicy {
 
 // ... with the MARKED rank units (handles without the suffix array): a one-row step also says whether its row is marked
 struct RumPolicy : PackPolicy {
+  static constexpr int kNfaWaves = 6;
   static constexpr int kDirectWaves = FEMTO_AMD_EXP_RU_WAVES;
   static constexpr bool kSpotMarks = true;
   static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
@@ -82,6 +85,7 @@ struct RumPolicy : PackPolicy {
 };
 
 struct Pack2Policy {
+  static constexpr int kNfaWaves = 4;
   static constexpr bool kSpotMarks = false;
   static __device__ __forceinline__ int64_t marked_offset(const DevIndex&, int64_t) { return -1; }
   static constexpr int kWaves = 8;
@@ -110,6 +114,7 @@ struct Pack2Policy {
 // byte alphabets with the per-character rank lines resident (ind_kernels.hip.hpp): search steps read one line per range
 // end; everything that does not know its character in advance (LF steps) stays on the two-level lines
 struct IndPolicy : Pack2Policy {
+  static constexpr int kNfaWaves = 5;
   static constexpr int kWaves = 8;
   static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
     ind_search_step(ix, j, code, f, l);
