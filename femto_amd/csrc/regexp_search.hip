@@ -74,6 +74,7 @@ struct NfaBatchDev {
   int64_t result_cap;
   unsigned long long* result_count;
   int32_t* status;           // per query
+  int32_t* iters_out;        // NULL, or per query: entries popped (FEMTO_AMD_NFA_STATS=1 prints their distribution)
   int64_t max_iterations;    // MAX_REGEXP_ITERATIONS (src/main/server.c:40)
   int32_t pass;
   int32_t lds_nodes, lds_children;   // sizes of the workgroup's dynamic LDS arrays (nfa_lds_bytes)
@@ -118,16 +119,18 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 // Dynamic LDS of one workgroup (sized per launch from the LARGEST automaton of the batch and the number of characters the
 // text holds, so that typical automata -- a few dozen nodes on a small alphabet -- leave room for a CU's full complement of
 // wavefronts; until round 5 the arrays were static for 2048 nodes and 264 children: 19 KB, 8 workgroups per CU):
-//   s_tmp u32[nn] | s_child_f i64[cc] | s_child_l i64[cc] | s_child_found i32[cc] | s_live i32[cc] | s_child_ch u16[cc] |
-//   s_cur u8[nn] | s_sub u8[nn]            nn = lds_nodes (multiple of 8), cc = lds_children (multiple of 4)
+//   s_tmp u32[nn] | s_child_f i64[cc] | s_child_l i64[cc] | s_child_found i32[cc] | s_live i32[cc] | s_child_h u32[cc] |
+//   s_child_head i32[cc] | s_child_slot i32[cc] | s_child_ch u16[cc] | s_cur u8[nn] | s_sub u8[nn] | s_top u8[nn]
+//                                           nn = lds_nodes (multiple of 8), cc = lds_children (multiple of 4)
 //   kLds (the batch's largest automaton has at most kNfaLdsEnts transitions): + s_ent_sd u32[ne] | s_ent_ch u16[ne] | s_flags u8[nn] --
 //   the automaton itself.  A pop reads the transition list five or six times (deletions, reachable characters,
 //   substitutions, one slice per live child) and the node flags once; from global memory each of those is a dependent
 //   round trip of a kernel that waits two thirds of its cycles (profiles/r05_regexp_stats.txt: SQ_WAIT_ANY 68 % of the
 //   wave cycles at 4 waves per SIMD); the copy is made once per automaton.
 constexpr int kNfaLdsEnts = 2048;
+constexpr int kNfaPend = 1024;            // counters of pending entries by hash bucket, in LDS
 __host__ __device__ inline size_t nfa_lds_bytes(int nn, int cc, int ne) {
-  return size_t(nn) * 4 + size_t(cc) * (8 + 8 + 4 + 4 + 2) + size_t(nn) * 2 + 16 + size_t(ne) * 6 + (ne ? size_t(nn) + 16 : 0);
+  return size_t(nn) * 4 + size_t(cc) * (8 + 8 + 4 + 4 + 4 + 4 + 4 + 2) + size_t(nn) * 3 + 16 + size_t(ne) * 6 + (ne ? size_t(nn) + 16 : 0);
 }
 
 template <class P, bool kLds>
@@ -143,9 +146,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
   int64_t* const s_child_l = s_child_f + cc;
   int32_t* const s_child_found = reinterpret_cast<int32_t*>(s_child_l + cc);
   int32_t* const s_live = s_child_found + cc;
-  uint16_t* const s_child_ch = reinterpret_cast<uint16_t*>(s_live + cc);
+  uint32_t* const s_child_h = reinterpret_cast<uint32_t*>(s_live + cc);          // the child's hash bucket,
+  int32_t* const s_child_head = reinterpret_cast<int32_t*>(s_child_h + cc);      // that bucket's head as the fan-out saw it,
+  int32_t* const s_child_slot = s_child_head + cc;                               // and the slot the child was pushed into (-1: merged / not yet)
+  uint16_t* const s_child_ch = reinterpret_cast<uint16_t*>(s_child_slot + cc);
   uint8_t* const s_cur = reinterpret_cast<uint8_t*>(s_child_ch + cc);            // nfa_states: the popped entry's costs, deletions merged in
   uint8_t* const s_sub = s_cur + nn;                                             // states after one substitution error (any character)
+  uint8_t* const s_top = s_sub + nn;                                             // the costs of the entry on top of the stack (see "top")
+  __shared__ uint8_t s_pend[kNfaPend];                                           // pending entries per hash bucket mod kNfaPend (see "pend")
   uint32_t* const s_ent_sd = reinterpret_cast<uint32_t*>(s_dyn + ((nfa_lds_bytes(nn, cc, 0) + 3) & ~size_t(3)));   // kLds: the automaton's transitions ...
   uint16_t* const s_ent_ch = reinterpret_cast<uint16_t*>(s_ent_sd + B.lds_ents);
   uint8_t* const s_flags = reinterpret_cast<uint8_t*>(s_ent_ch + B.lds_ents);                                       // ... and node flags
@@ -212,29 +220,58 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
     for (int i = t; i < N; i += 64) e_cost[i] = (g_flags[i] & 1u) ? 0 : kNfaDead;
     #pragma unroll 1
     for (int i = t; i < B.hash_size; i += 64) heads[i] = -1;
+    #pragma unroll 1
+    for (int i = t; i < kNfaPend / 4; i += 64) reinterpret_cast<uint32_t*>(s_pend)[i] = 0;
     __syncthreads();
     if (t == 0) {
       e_first[0] = 0;
       e_last[0] = ix.total_length - 1;
       e_len[0] = 0;
       e_next[0] = -1;
-      heads[hash_of(0, ix.total_length - 1)] = 0;
+      const uint32_t h0 = hash_of(0, ix.total_length - 1);
+      heads[h0] = 0;
+      s_pend[h0 & (kNfaPend - 1)] = 1;
     }
     int sp = 1, status = 0;
     int64_t iters = 0;
+    // "top": the entry pushed LAST by a pop is the one the next pop takes.  Its range, match length and costs stay in
+    // registers / LDS (s_top) and it never reaches the arena, the hash or the counters: nothing can look it up or merge into
+    // it before it is popped (lookups happen in the NEXT pop's fan-out, after it is gone).  A pop of it costs no memory round
+    // trip; a search that goes down a path pops such entries most of the time.
+    // "pend": s_pend[b] counts the pending (arena) entries whose hash bucket is b mod kNfaPend (saturating at 255, then never
+    // decremented).  Zero means the bucket's chain is empty: the fan-out then knows "not pending, head = -1" without
+    // touching the arena -- the lookup that was one dependent round trip per pop.
+    int top_slot = -1, top_len = 0;
+    int64_t top_f = 0, top_l = 0;
     __syncthreads();
     for (;;) {
       if (iters > B.max_iterations) { status = kNfaStatusOverworked; break; }   // server.c:1821
       if (sp == 0) break;
       sp--;
-      const int64_t first = uni64(e_first[sp]), last = uni64(e_last[sp]);
-      const int len = uni(e_len[sp]);
-      if (t == 0) heads[hash_of(first, last)] = e_next[sp];      // the top of the stack is the head of its chain
+      const bool from_top = sp == top_slot;
+      top_slot = -1;
+      int64_t first, last;
+      int len;
+      if (from_top) {
+        first = top_f;
+        last = top_l;
+        len = top_len;
+      } else {
+        first = uni64(e_first[sp]);
+        last = uni64(e_last[sp]);
+        len = uni(e_len[sp]);
+        if (t == 0) {      // the top of the stack is the head of its chain
+          const uint32_t h = hash_of(first, last);
+          heads[h] = e_next[sp];
+          const uint8_t pc = s_pend[h & (kNfaPend - 1)];
+          if (pc != 255) s_pend[h & (kNfaPend - 1)] = uint8_t(pc - 1);
+        }
+      }
       // ---- a final state alive: a result, not extended (approx_is_final_state: the first such node's cost)
       int fin = INT_MAX;
       #pragma unroll 1
       for (int i = t; i < N; i += 64) {
-        const uint8_t c = e_cost[size_t(sp) * stride + i];
+        const uint8_t c = from_top ? s_top[i] : e_cost[size_t(sp) * stride + i];
         s_cur[i] = c;
         if (int(c) < bound && (FLAGS(i) & 2u) && i < fin) fin = i;
       }
@@ -328,16 +365,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
           P::search_step(ix, 1, P::code_of(ix, ch), f, l);
           s_child_f[k] = f;
           s_child_l[k] = l;
-          int found = -1;
+          int found = -1, head = -1;
           live = l >= f;                               // add_mapping ignores empty ranges (server.c:1565)
-          if (live)
-            for (int s2 = heads[hash_of(f, l)]; s2 >= 0; s2 = e_next[s2])
-              if (e_first[s2] == f && e_last[s2] == l) { found = s2; break; }
+          if (live) {
+            const uint32_t h = hash_of(f, l);
+            s_child_h[k] = h;
+            if (s_pend[h & (kNfaPend - 1)] != 0) {     // ("pend": an empty bucket needs no look at the arena)
+              head = heads[h];
+              for (int s2 = head; s2 >= 0; s2 = e_next[s2])
+                if (e_first[s2] == f && e_last[s2] == l) { found = s2; break; }
+            }
+            s_child_head[k] = head;
+            s_child_slot[k] = -1;
+          }
           s_child_found[k] = found;
         }
         const unsigned long long mask = __ballot(live);
         if (live) s_live[nlive + __popcll(mask & ((1ull << t) - 1ull))] = k;
         nlive += __popcll(mask);
+      }
+      // the last NEW child in push order becomes the "top" (it is the next entry popped)
+      int last_new = -1;
+      {
+        __syncthreads();
+        for (int j0 = 0; j0 < nlive; j0 += 64) {
+          const int j = j0 + t;
+          const bool isnew = j < nlive && s_child_found[s_live[j]] < 0;
+          const unsigned long long nm = __ballot(isnew);
+          if (nm) last_new = j0 + 63 - __builtin_clzll(nm);
+        }
       }
       // ---- substitutions: states after reading any character at subst_cost (server.c:2107-2110)
       if (approx) {
@@ -372,6 +428,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
         const int found = uni(s_child_found[k]);
         if (found < 0 && sp >= cap) { status = kNfaStatusFull; break; }
         const int slot = found < 0 ? sp : found;
+        const bool to_top = kk == last_new;                                     // ("top": registers and s_top instead of the arena)
         uint8_t* const dst = e_cost + size_t(slot) * stride;
         #pragma unroll 1
         for (int i = t; i < N; i += 64) {
@@ -386,19 +443,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
             const uint32_t old = dst[i];
             v = old < v ? old : v;                                              // nfa_states_union
           }
-          dst[i] = uint8_t(v);
+          if (to_top) s_top[i] = uint8_t(v);
+          else dst[i] = uint8_t(v);
         }
-        if (t == 0) {
-          if (found < 0) {
+        if (to_top) {
+          top_slot = slot;
+          top_f = cf;
+          top_l = cl;
+          top_len = len + 1;
+        } else if (found < 0) {
+          // the bucket's head NOW: an earlier new child of this pop in the same bucket, else what the fan-out saw
+          const uint32_t h = uni(int(s_child_h[k]));
+          int cur_head = uni(s_child_head[k]);
+          for (int j0 = 0; j0 < kk; j0 += 64) {
+            const int j = j0 + t;
+            int sl = -1;
+            if (j < kk) {
+              const int k2 = s_live[j];
+              if (s_child_h[k2] == h) sl = s_child_slot[k2];
+            }
+            const unsigned long long hm = __ballot(sl >= 0);
+            if (hm) cur_head = __shfl(sl, 63 - __builtin_clzll(hm), 64);
+          }
+          if (t == 0) {
             e_first[slot] = cf;
             e_last[slot] = cl;
             e_len[slot] = len + 1;
-            const uint32_t h = hash_of(cf, cl);
-            e_next[slot] = heads[h];
+            e_next[slot] = cur_head;
             heads[h] = slot;
-          } else if (len + 1 > e_len[slot]) {
-            e_len[slot] = len + 1;                                              // the longer match is kept (server.c:1611-1619)
+            s_child_slot[k] = slot;
+            const uint8_t pc = s_pend[h & (kNfaPend - 1)];
+            if (pc != 255) s_pend[h & (kNfaPend - 1)] = uint8_t(pc + 1);
           }
+        } else if (t == 0 && len + 1 > e_len[slot]) {
+          e_len[slot] = len + 1;                                                // the longer match is kept (server.c:1611-1619)
         }
         if (found < 0) sp++;
         __syncthreads();
@@ -406,7 +484,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
       if (status) break;
       iters++;
     }
-    if (t == 0) B.status[q] = status;
+    if (t == 0) {
+      B.status[q] = status;
+      if (B.iters_out) B.iters_out[q] = int32_t(iters < INT_MAX ? iters : INT_MAX);
+    }
     __syncthreads();
   }
 }
@@ -550,7 +631,7 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   int64_t result_cap = std::max<int64_t>(std::min<int64_t>(2 * max_results, int64_t(1) << 22), 1 << 12);
   if ((rc = d_q.reserve(hq.size() * sizeof(NfaQueryDev))) || (rc = d_flags.reserve(h_flags.size() + 16)) ||
       (rc = d_sd.reserve(h_sd.size() * 4 + 16)) || (rc = d_ch.reserve(h_ch.size() * 2 + 16)) || (rc = d_bychar.reserve(h_bychar.size() * 4)) ||
-      (rc = d_misc.reserve(64 + size_t(nq) * 4)) ||
+      (rc = d_misc.reserve(64 + size_t(nq) * 8)) ||
       (rc = d_order.reserve(size_t(nq) * 4)))
     return rc;
   HIP_TRY(hipMemcpyAsync(d_q.p, hq.data(), hq.size() * sizeof(NfaQueryDev), hipMemcpyHostToDevice, st));
@@ -573,6 +654,8 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   B.next = d_next;
   B.result_count = d_count;
   B.status = d_status;
+  const bool want_stats = getenv("FEMTO_AMD_NFA_STATS") != nullptr;
+  B.iters_out = want_stats ? d_status + nq : nullptr;
   B.max_iterations = ix->regexp_max_iterations;
   B.cost_stride = (max_nodes + 3) & ~3;
   B.lds_nodes = (max_nodes + 7) & ~7;
@@ -608,7 +691,7 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   if ((rc = d_results.reserve(size_t(result_cap) * sizeof(NfaResultDev)))) return rc;
   B.results = d_results.as<NfaResultDev>();
   B.result_cap = result_cap;
-  HIP_TRY(hipMemsetAsync(d_misc.p, 0, 64 + size_t(nq) * 4, st));
+  HIP_TRY(hipMemsetAsync(d_misc.p, 0, 64 + size_t(nq) * 8, st));
   todo.resize(static_cast<size_t>(nq));
   for (int64_t i = 0; i < nq; i++) todo[size_t(i)] = int32_t(i);
   int64_t cap = std::min<int64_t>(1024, ix->regexp_stack_cap);
@@ -641,6 +724,19 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(status.data(), d_status, size_t(nq) * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (want_stats) {      // entries popped per automaton: the kernel ends with its longest search (profiles/r05_regexp_*)
+      std::vector<int32_t> it(static_cast<size_t>(nq));
+      HIP_TRY(hipMemcpy(it.data(), d_status + nq, size_t(nq) * 4, hipMemcpyDeviceToHost));
+      std::vector<int32_t> v;
+      for (int32_t q : todo) v.push_back(it[size_t(q)]);
+      std::sort(v.begin(), v.end());
+      double sum = 0;
+      for (int32_t x : v) sum += x;
+      auto pct = [&](double p) { return v.empty() ? 0 : v[std::min(v.size() - 1, size_t(p * double(v.size())))]; };
+      fprintf(stderr, "[femto_amd] nfa pass %d: %zu automata, %d workgroups, pops: mean %.0f  p50 %d  p90 %d  p99 %d  p99.9 %d  max %d  (sum %.3g; max / (sum / workgroups) = %.2f)\n",
+              pass, v.size(), blocks, v.empty() ? 0.0 : sum / double(v.size()), pct(0.5), pct(0.9), pct(0.99), pct(0.999), v.empty() ? 0 : v.back(), sum,
+              sum > 0 ? double(v.empty() ? 0 : v.back()) / (sum / double(blocks)) : 0.0);
+    }
     std::vector<int32_t> again;
     for (int32_t q : todo)
       if (status[size_t(q)] == kNfaStatusFull) again.push_back(q);
