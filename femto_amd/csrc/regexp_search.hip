@@ -74,10 +74,12 @@ struct NfaBatchDev {
   int64_t result_cap;
   unsigned long long* result_count;
   int32_t* status;           // per query
-  int32_t* iters_out;        // NULL, or per query: entries popped (FEMTO_AMD_NFA_STATS=1 prints their distribution)
+  int32_t* iters_out;        // NULL, or per query: entries popped | cycles / 1024 | start / 1024 (FEMTO_AMD_NFA_STATS=1 prints their distribution)
+  int32_t nq_all;
   int64_t max_iterations;    // MAX_REGEXP_ITERATIONS (src/main/server.c:40)
   int32_t pass;
   int32_t lds_nodes, lds_children;   // sizes of the workgroup's dynamic LDS arrays (nfa_lds_bytes)
+  int32_t lds_group;                 // children merged together per round of the child phase (s_tmpg holds their tmp_states)
   int32_t lds_ents;                  // > 0: every automaton's transitions and node flags are copied to LDS (room for this many entries)
 };
 
@@ -92,15 +94,25 @@ struct WavePolicy {
     l = nl;
   }
   static __device__ __forceinline__ uint32_t code_of(const DevIndex& ix, uint32_t ch) { return ix.C[ch + 1] > ix.C[ch] ? ch : 0xffffu; }
+  static __device__ __forceinline__ uint32_t touch(const DevIndex&, uint32_t, int64_t) { return 0; }
 };
 
+// min over the wavefront's 64 lanes by DPP (four steps inside each row of 16 lanes, two row broadcasts; the result lands in
+// lane 63): six VALU instructions.  The xor-shuffle form it replaces was six ds_bpermute round trips through the LDS pipe, each
+// waited for -- and this kernel's time IS such chains (one wavefront per automaton, every phase of a pop waits for the one before).
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ int dpp_min_step(int v) {
+  const int o = __builtin_amdgcn_update_dpp(v, v, kCtrl, kRowMask, 0xf, false);
+  return o < v ? o : v;
+}
 __device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    const int o = __shfl_xor(v, d, 64);
-    v = o < v ? o : v;
-  }
-  return v;
+  v = dpp_min_step<0xb1, 0xf>(v);     // quad_perm [1,0,3,2]
+  v = dpp_min_step<0x4e, 0xf>(v);     // quad_perm [2,3,0,1]
+  v = dpp_min_step<0x114, 0xf>(v);    // row_shr:4
+  v = dpp_min_step<0x118, 0xf>(v);    // row_shr:8   (lane 15 of every row: the row's minimum)
+  v = dpp_min_step<0x142, 0xa>(v);    // row_bcast:15 into rows 1 and 3
+  v = dpp_min_step<0x143, 0xc>(v);    // row_bcast:31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
 }
 // a value every lane of the wavefront holds (read from one address, or the result of a wavefront reduction), moved to a
 // scalar register: the search loop below is one wavefront working on ONE automaton, and most of what it carries -- the
@@ -110,12 +122,6 @@ __device__ __forceinline__ int64_t uni64(int64_t v) {
   const uint32_t lo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(uint64_t(v))))), hi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(uint64_t(v) >> 32))));
   return int64_t((uint64_t(hi) << 32) | lo);
 }
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
-}
-
 // Dynamic LDS of one workgroup (sized per launch from the LARGEST automaton of the batch and the number of characters the
 // text holds, so that typical automata -- a few dozen nodes on a small alphabet -- leave room for a CU's full complement of
 // wavefronts; until round 5 the arrays were static for 2048 nodes and 264 children: 19 KB, 8 workgroups per CU):
@@ -128,17 +134,20 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 //   round trip of a kernel that waits two thirds of its cycles (profiles/r05_regexp_stats.txt: SQ_WAIT_ANY 68 % of the
 //   wave cycles at 4 waves per SIMD); the copy is made once per automaton.
 constexpr int kNfaLdsEnts = 2048;
-constexpr int kNfaPend = 1024;            // counters of pending entries by hash bucket, in LDS
-__host__ __device__ inline size_t nfa_lds_bytes(int nn, int cc, int ne) {
-  return size_t(nn) * 4 + size_t(cc) * (8 + 8 + 4 + 4 + 4 + 4 + 4 + 2) + size_t(nn) * 3 + 16 + size_t(ne) * 6 + (ne ? size_t(nn) + 16 : 0);
+constexpr int kNfaPend = 256;             // counters of pending entries by hash bucket (mod this), in LDS
+__host__ __device__ inline size_t nfa_lds_bytes(int nn, int cc, int ne, int group) {
+  return size_t(nn) * 4 + size_t(cc) * (8 + 8 + 4 + 4 + 4 + 4 + 4 + 2) + size_t(nn) * 3 + 16 + size_t(ne) * 6 + (ne ? size_t(nn) + 16 : 0) +
+         (group ? size_t(group) * size_t(nn) * 4 + 16 : 0);
 }
 
 template <class P, bool kLds>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves, P::kNfaWaves))) void nfa_search_kernel(const DevIndex ix, const NfaBatchDev B) {
   extern __shared__ __align__(16) uint8_t s_dyn[];
   __shared__ int32_t s_bychar[264];
-  __shared__ uint32_t s_rc[9];                  // r_c: reachable characters
   __shared__ uint32_t s_text[9];                // characters that occur in the text (a range stepped with any other is empty)
+  __shared__ uint16_t s_code[264];              // ... and their codes in the index's rank layout (P::code_of, read from memory once)
+  __shared__ uint16_t s_textch[264];            // the text's characters as a list, ascending
+  __shared__ uint8_t s_alive[264];              // per character: an alive state can read it (set and cleared within a pop)
   __shared__ int32_t s_q;
   const int nn = B.lds_nodes, cc = B.lds_children;
   uint32_t* const s_tmp = reinterpret_cast<uint32_t*>(s_dyn);                    // tmp_states being accumulated (atomicMin)
@@ -153,8 +162,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
   uint8_t* const s_cur = reinterpret_cast<uint8_t*>(s_child_ch + cc);            // nfa_states: the popped entry's costs, deletions merged in
   uint8_t* const s_sub = s_cur + nn;                                             // states after one substitution error (any character)
   uint8_t* const s_top = s_sub + nn;                                             // the costs of the entry on top of the stack (see "top")
-  __shared__ uint8_t s_pend[kNfaPend];                                           // pending entries per hash bucket mod kNfaPend (see "pend")
-  uint32_t* const s_ent_sd = reinterpret_cast<uint32_t*>(s_dyn + ((nfa_lds_bytes(nn, cc, 0) + 3) & ~size_t(3)));   // kLds: the automaton's transitions ...
+  __shared__ uint32_t s_pend[kNfaPend];                                          // pending entries per hash bucket mod kNfaPend (see "pend")
+  __shared__ int16_t s_char_child[264];                                          // character -> its child's place in the group being merged, or -1
+  uint32_t* const s_tmpg = reinterpret_cast<uint32_t*>(s_dyn + ((nfa_lds_bytes(nn, cc, B.lds_ents, 0) + 3) & ~size_t(3)));   // [lds_group][N]: tmp_states of a GROUP of children
+  uint32_t* const s_ent_sd = reinterpret_cast<uint32_t*>(s_dyn + ((nfa_lds_bytes(nn, cc, 0, 0) + 3) & ~size_t(3)));   // kLds: the automaton's transitions ...
   uint16_t* const s_ent_ch = reinterpret_cast<uint16_t*>(s_ent_sd + B.lds_ents);
   uint8_t* const s_flags = reinterpret_cast<uint8_t*>(s_ent_ch + B.lds_ents);                                       // ... and node flags
   const int t = threadIdx.x;
@@ -183,10 +194,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
   // fans out over 4 characters per pop, not over the alphabet's 256 (five rounds of the fan-out and a 256-iteration child
   // loop per pop until round 5).  The ORDER of the children that remain is untouched.
   if (t < 9) s_text[t] = 0;
+  #pragma unroll 1
+  for (int c = t; c < 264; c += 64) s_char_child[c] = -1;
   __syncthreads();
   #pragma unroll 1
-  for (int c = t; c < kAlphaSize; c += 64)
-    if (P::code_of(ix, uint32_t(c)) != 0xffffu) atomicOr(&s_text[c >> 5], 1u << (c & 31));
+  for (int c = t; c < kAlphaSize; c += 64) {
+    const uint32_t code = P::code_of(ix, uint32_t(c));
+    s_code[c] = uint16_t(code);
+    if (code != 0xffffu) atomicOr(&s_text[c >> 5], 1u << (c & 31));
+  }
+  __syncthreads();
+  int ntext = 0;
+  {
+    uint32_t tw[9];
+#pragma unroll
+    for (int w = 0; w < 9; w++) tw[w] = s_text[w];
+#pragma unroll
+    for (int w = 0; w < 9; w++) ntext += __popc(tw[w]);
+    ntext = uni(ntext);
+    #pragma unroll 1
+    for (int c = t; c < kAlphaSize; c += 64) {
+      const int cw = c >> 5;
+      uint32_t mine = 0;
+      int rank = 0;
+#pragma unroll
+      for (int w = 0; w < 9; w++) {
+        if (w == cw) mine = tw[w];
+        rank += w < cw ? __popc(tw[w]) : 0;
+      }
+      if (!((mine >> (c & 31)) & 1u)) continue;
+      rank += __popc(mine & ((1u << (c & 31)) - 1u));
+      s_textch[rank] = uint16_t(c);
+    }
+    #pragma unroll 1
+    for (int c = t; c < 264; c += 64) s_alive[c] = 0;
+  }
+  const int ntext_all = ntext;      // <= 261
+  int n_lowtext = 0;                // ... of them below CHARACTER_OFFSET (the first entries of the list)
+  for (int c = 0; c < kNfaOffset; c++) n_lowtext += int((s_text[0] >> c) & 1u);
+  n_lowtext = uni(n_lowtext);
+  if (ntext > 64) ntext = 0;        // ("warm": byte alphabets of more than 64 characters: no guessing ahead)
   __syncthreads();
   for (;;) {
     if (t == 0) s_q = atomicAdd(B.next, 1);
@@ -195,6 +242,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
     __syncthreads();
     if (qi >= B.nq) break;
     const int q = B.order ? B.order[qi] : qi;
+    const long long t_begin = B.iters_out ? clock64() : 0;
     const NfaQueryDev Q = B.queries[q];
     const int N = Q.num_nodes, T = Q.num_ents, bound = Q.cost_bound;
     const bool approx = bound > 1;
@@ -221,7 +269,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
     #pragma unroll 1
     for (int i = t; i < B.hash_size; i += 64) heads[i] = -1;
     #pragma unroll 1
-    for (int i = t; i < kNfaPend / 4; i += 64) reinterpret_cast<uint32_t*>(s_pend)[i] = 0;
+    for (int i = t; i < kNfaPend; i += 64) s_pend[i] = 0;
     __syncthreads();
     if (t == 0) {
       e_first[0] = 0;
@@ -238,9 +286,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
     // registers / LDS (s_top) and it never reaches the arena, the hash or the counters: nothing can look it up or merge into
     // it before it is popped (lookups happen in the NEXT pop's fan-out, after it is gone).  A pop of it costs no memory round
     // trip; a search that goes down a path pops such entries most of the time.
-    // "pend": s_pend[b] counts the pending (arena) entries whose hash bucket is b mod kNfaPend (saturating at 255, then never
-    // decremented).  Zero means the bucket's chain is empty: the fan-out then knows "not pending, head = -1" without
+    // "pend": s_pend[b] counts the pending (arena) entries whose hash bucket is b mod kNfaPend.  Zero means the bucket's chain is empty: the fan-out then knows "not pending, head = -1" without
     // touching the arena -- the lookup that was one dependent round trip per pop.
+    // "warm": the moment a pop knows its top child's range it asks for the lines that child's own fan-out will read -- one rank
+    // line per character of the text and range end -- and lets them arrive while the rest of this pop and the start of the next
+    // run.  A search is ONE chain of dependent pops, each with one rank request in the middle (4.3 us per pop measured, half of
+    // it that request's latency); the batch ends with its longest search (profiles/r05_regexp_stats.txt), so the latency of a
+    // single chain is what the kernel's time is made of.
+    uint32_t warm = 0, warm2 = 0;
+    // built with -DFEMTO_AMD_NFA_PROF (tools/ab_bench.sh): shader-clock cycles per phase of a pop, summed over the automaton (phase k =
+    // from PROF(k) to the next), printed by FEMTO_AMD_NFA_STATS=1.  Not in the product build: the accumulators cost registers.
+#ifdef FEMTO_AMD_NFA_PROF
+    long long prof_t = 0, prof_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int prof_k = 8;
+#define PROF(k)                                             \
+  if (B.iters_out) {                                        \
+    const long long now_ = clock64();                       \
+    prof_acc[prof_k] += now_ - prof_t;                      \
+    prof_t = now_;                                          \
+    prof_k = (k);                                           \
+  }
+    if (B.iters_out) prof_t = clock64();
+#else
+#define PROF(k)
+#endif
     int top_slot = -1, top_len = 0;
     int64_t top_f = 0, top_l = 0;
     __syncthreads();
@@ -263,19 +332,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
         if (t == 0) {      // the top of the stack is the head of its chain
           const uint32_t h = hash_of(first, last);
           heads[h] = e_next[sp];
-          const uint8_t pc = s_pend[h & (kNfaPend - 1)];
-          if (pc != 255) s_pend[h & (kNfaPend - 1)] = uint8_t(pc - 1);
+          s_pend[h & (kNfaPend - 1)] -= 1u;
         }
       }
+      PROF(0);
       // ---- a final state alive: a result, not extended (approx_is_final_state: the first such node's cost)
       int fin = INT_MAX;
       #pragma unroll 1
-      for (int i = t; i < N; i += 64) {
-        const uint8_t c = from_top ? s_top[i] : e_cost[size_t(sp) * stride + i];
-        s_cur[i] = c;
-        if (int(c) < bound && (FLAGS(i) & 2u) && i < fin) fin = i;
+      for (int i0 = 0; i0 < N; i0 += 64) {        // (the first alive final node: the first lane of the first round that has one)
+        const int i = i0 + t;
+        bool is_fin = false;
+        if (i < N) {
+          const uint8_t c = from_top ? s_top[i] : e_cost[size_t(sp) * stride + i];
+          s_cur[i] = c;
+          is_fin = int(c) < bound && (FLAGS(i) & 2u);
+        }
+        const unsigned long long fm = __ballot(is_fin);
+        if (fm && fin == INT_MAX) fin = i0 + __ffsll(static_cast<long long>(fm)) - 1;
       }
-      fin = uni(wave_min_i32(fin));
       __syncthreads();
       if (fin != INT_MAX) {
         if (t == 0) {
@@ -286,6 +360,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
         continue;
       }
       const int base5 = s_bychar[kNfaOffset];    // entries of characters >= CHARACTER_OFFSET start here
+      PROF(1);
       // ---- deletions: states after reading ANY character at delete_cost, merged in (server.c:1854-1863)
       if (approx) {
         #pragma unroll 1
@@ -305,6 +380,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
         }
         __syncthreads();
       }
+      PROF(2);
       // ---- may any character be an error from here?  (nfa_errcnt_t arithmetic: one byte, as the reference computes it)
       int m = bound;
       #pragma unroll 1
@@ -313,48 +389,51 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
       const int ms = m + Q.subst, mi = m + Q.ins;
       const int min_err = (ms < mi ? ms : mi) & 0xff;
       const bool allchars = min_err < bound && iters > 0;
-      // ---- r_c: the characters an alive state can read
-      if (t < 9) s_rc[t] = 0;
-      __syncthreads();
+      // ---- r_c: the characters an alive state can read, as one flag per character (cleared again as they are read below)
       #pragma unroll 1
       for (int e = t; e < T; e += 64)
-        if (int(s_cur[ENT_SD(e) & 0xffffu]) < bound) {
-          const uint32_t ch = ENT_CH(e);
-          atomicOr(&s_rc[ch >> 5], 1u << (ch & 31u));
-        }
-      __syncthreads();
-      if (t < 9) {
-        uint32_t w = s_rc[t];
-        if (allchars) {               // CHARACTER_OFFSET .. ALPHA_SIZE - 1
-          uint32_t mask = ~0u;
-          if (t == 0) mask = ~0u << kNfaOffset;
-          if (t == 8) mask = (1u << (kAlphaSize - 256)) - 1u;
-          w |= mask;
-        }
-        s_rc[t] = w & s_text[t];      // ... that the text holds
-      }
+        if (int(s_cur[ENT_SD(e) & 0xffffu]) < bound) s_alive[ENT_CH(e)] = 1;
       __syncthreads();
       // ---- the children in push order: characters >= CHARACTER_OFFSET ascending (the substitution loop creates their
-      // entries first, server.c:2114-2120), then the characters below it (regular loop, :2123-2130)
-      int n_all = 0, n_low;
-      {
-        const uint32_t w = t < 9 ? s_rc[t] : 0u;
-        n_all = uni(wave_sum_i32(__popc(w)));
-        n_low = uni(__popc(s_rc[0] & ((1u << kNfaOffset) - 1u)));
+      // entries first, server.c:2114-2120), then the characters below it (regular loop, :2123-2130).  Only characters the text
+      // holds can have rows, so the lanes go over the TEXT's characters (ascending: those below CHARACTER_OFFSET come first in
+      // the list), 64 at a time, and a child's place is a count of ballot bits.  (Until round 5 this went over all 261 characters
+      // with nine-word bit arithmetic per lane: 4 300 of a pop's 12 000 cycles, measured with FEMTO_AMD_NFA_STATS.)
+      unsigned long long cm[5] = {0, 0, 0, 0, 0};
+      int nchild = 0;
+#pragma unroll
+      for (int w = 0; w < 5; w++) {
+        if (64 * w >= ntext_all) break;
+        const int j = 64 * w + t;
+        bool isch = false;
+        if (j < ntext_all) {
+          const int c = s_textch[j];
+          isch = s_alive[c] != 0 || (allchars && c >= kNfaOffset);
+          s_alive[c] = 0;
+        }
+        cm[w] = __ballot(isch);
+        nchild += int(__popcll(cm[w]));
       }
-      const int nchild = n_all;       // <= characters of the text <= lds_children
-      #pragma unroll 1
-      for (int c = t; c < kAlphaSize; c += 64) {
-        if (!((s_rc[c >> 5] >> (c & 31)) & 1u)) continue;
-        int rank = __popc(s_rc[c >> 5] & ((1u << (c & 31)) - 1u));
-        for (int w = 0; w < (c >> 5); w++) rank += __popc(s_rc[w]);
-        const int pos = c >= kNfaOffset ? rank - n_low : (n_all - n_low) + rank;
-        s_child_ch[pos] = uint16_t(c);
+      const int n_lo = int(__popcll(cm[0] & ((1ull << n_lowtext) - 1ull)));      // children below CHARACTER_OFFSET: pushed last
+      {
+        int before = 0;
+#pragma unroll
+        for (int w = 0; w < 5; w++) {
+          if (64 * w >= ntext_all) break;
+          const int j = 64 * w + t;
+          if ((cm[w] >> t) & 1ull) {
+            const int rank = before + int(__popcll(cm[w] & ((1ull << t) - 1ull)));      // children before this one in character order
+            s_child_ch[j < n_lowtext ? (nchild - n_lo) + rank : rank - n_lo] = s_textch[j];
+          }
+          before += int(__popcll(cm[w]));
+        }
       }
       __syncthreads();
+      PROF(3);
       // ---- the fan-out: lane k steps the range with the k-th character (server.c:1954-2060); then add_mapping's lookup: a
       // pending entry with the child's range?  (children of one pop have disjoint ranges); the children with rows are listed
       // in order (s_live): the merge loop below visits only those
+      asm volatile("" ::"v"(warm), "v"(warm2));      // ("warm": the lines asked for by the previous pop have arrived by now, or are waited for here)
       int nlive = 0;
       for (int k0 = 0; k0 < nchild; k0 += 64) {
         const int k = k0 + t;
@@ -362,7 +441,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
         if (k < nchild) {
           const uint32_t ch = s_child_ch[k];
           int64_t f = first, l = last;
-          P::search_step(ix, 1, P::code_of(ix, ch), f, l);
+          P::search_step(ix, 1, s_code[ch], f, l);
           s_child_f[k] = f;
           s_child_l[k] = l;
           int found = -1, head = -1;
@@ -384,17 +463,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
         if (live) s_live[nlive + __popcll(mask & ((1ull << t) - 1ull))] = k;
         nlive += __popcll(mask);
       }
-      // the last NEW child in push order becomes the "top" (it is the next entry popped)
-      int last_new = -1;
-      {
-        __syncthreads();
-        for (int j0 = 0; j0 < nlive; j0 += 64) {
-          const int j = j0 + t;
-          const bool isnew = j < nlive && s_child_found[s_live[j]] < 0;
-          const unsigned long long nm = __ballot(isnew);
-          if (nm) last_new = j0 + 63 - __builtin_clzll(nm);
+      PROF(4);
+      // ---- slots, in push order: a child whose range is pending keeps that entry's slot, the new ones take sp, sp + 1, ...;
+      // the LAST new one becomes the "top" (the next entry popped)
+      __syncthreads();
+      int n_new = 0, last_new = -1;
+      for (int j0 = 0; j0 < nlive; j0 += 64) {
+        const int j = j0 + t;
+        int k = 0;
+        bool isnew = false;
+        if (j < nlive) {
+          k = s_live[j];
+          isnew = s_child_found[k] < 0;
         }
+        const unsigned long long nm = __ballot(isnew);
+        if (j < nlive) s_child_slot[k] = isnew ? sp + n_new + int(__popcll(nm & ((1ull << t) - 1ull))) : s_child_found[k];
+        if (nm) last_new = j0 + 63 - __builtin_clzll(nm);
+        n_new += int(__popcll(nm));
       }
+      if (sp + n_new > cap) { status = kNfaStatusFull; break; }     // (some new child would find the stack full)
+      if (last_new >= 0 && ntext > 0) {      // "warm" (uniform condition; every lane loads, unconditionally: a load inside a divergent
+                                             // block is waited for where the block ends)
+        const int k = uni(s_live[last_new]);
+        const int64_t wf = uni64(s_child_f[k]), wl = uni64(s_child_l[k]);
+        const uint32_t code = s_code[s_textch[t < ntext ? t : 0]];
+        warm = P::touch(ix, code, wl);
+        warm2 = P::touch(ix, code, wf > 0 ? wf - 1 : 0);      // (two registers, nothing computed from them here: a use is where the wait goes)
+      }
+      PROF(5);
       // ---- substitutions: states after reading any character at subst_cost (server.c:2107-2110)
       if (approx) {
         #pragma unroll 1
@@ -411,82 +507,117 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
         for (int i = t; i < N; i += 64) s_sub[i] = uint8_t(s_tmp[i]);
       }
       __syncthreads();
-      for (int kk = 0; kk < nlive; kk++) {
-        const int k = uni(s_live[kk]);
-        const int64_t cf = uni64(s_child_f[k]), cl = uni64(s_child_l[k]);
-        const int ch = uni(s_child_ch[k]);
+      PROF(6);
+      // ---- the children's states, a GROUP of children at a time (until round 5 one child at a time, five dependent LDS phases
+      // each): tmp_states of every child of the group are accumulated in ONE pass over the transitions of the group's
+      // characters (approx_get_reachable_states, nfa.c), then every (child, node) pair is finished and stored by its own lane
+      // (approx_add_error_allchars nfa.c:305, the substitution states, nfa_states_union with a pending entry's)
+      const int G = B.lds_group;
+      for (int g0 = 0; g0 < nlive; g0 += G) {
+        const int gn = nlive - g0 < G ? nlive - g0 : G;
         #pragma unroll 1
-        for (int i = t; i < N; i += 64) s_tmp[i] = kNfaDead;
+        for (int x = t; x < gn * N; x += 64) s_tmpg[x] = kNfaDead;
+        int elo = INT_MAX, ehi = 0, my_ch = 0;
+        if (t < gn) {
+          my_ch = s_child_ch[s_live[g0 + t]];
+          s_char_child[my_ch] = int16_t(t);
+          elo = s_bychar[my_ch];
+          ehi = s_bychar[my_ch + 1];
+        }
+        elo = wave_min_i32(elo);
+        ehi = -wave_min_i32(-ehi);
         __syncthreads();
         #pragma unroll 1
-        for (int e = s_bychar[ch] + t; e < s_bychar[ch + 1]; e += 64) {    // approx_get_reachable_states(ch)
+        for (int e = elo + t; e < ehi; e += 64) {
+          const int ci = s_char_child[ENT_CH(e)];
+          if (ci < 0) continue;
           const uint32_t sd = ENT_SD(e);
           const uint32_t c = s_cur[sd & 0xffffu];
-          if (int(c) < bound) atomicMin(&s_tmp[sd >> 16], c);
+          if (int(c) < bound) atomicMin(&s_tmpg[ci * N + int(sd >> 16)], c);
         }
         __syncthreads();
-        const int found = uni(s_child_found[k]);
-        if (found < 0 && sp >= cap) { status = kNfaStatusFull; break; }
-        const int slot = found < 0 ? sp : found;
-        const bool to_top = kk == last_new;                                     // ("top": registers and s_top instead of the arena)
-        uint8_t* const dst = e_cost + size_t(slot) * stride;
         #pragma unroll 1
-        for (int i = t; i < N; i += 64) {
-          uint32_t v = s_tmp[i];
+        for (int x = t; x < gn * N; x += 64) {
+          const int ci = x / N, i = x - ci * N;
+          const int k = s_live[g0 + ci];
+          const int ch = s_child_ch[k], found = s_child_found[k], slot = s_child_slot[k];
+          uint32_t v = s_tmpg[x];
           if (approx) {
             const uint32_t ins = uint32_t(s_cur[i]) + uint32_t(Q.ins);          // approx_add_error_allchars (nfa.c:305)
             v = ins < v ? ins : v;
             if (ch >= kNfaOffset && uint32_t(s_sub[i]) < v) v = s_sub[i];
           }
           if (int(v) >= bound) v = kNfaDead;                                    // beyond the bound is dead, whatever the number
-          if (found >= 0) {
-            const uint32_t old = dst[i];
-            v = old < v ? old : v;                                              // nfa_states_union
-          }
-          if (to_top) s_top[i] = uint8_t(v);
-          else dst[i] = uint8_t(v);
-        }
-        if (to_top) {
-          top_slot = slot;
-          top_f = cf;
-          top_l = cl;
-          top_len = len + 1;
-        } else if (found < 0) {
-          // the bucket's head NOW: an earlier new child of this pop in the same bucket, else what the fan-out saw
-          const uint32_t h = uni(int(s_child_h[k]));
-          int cur_head = uni(s_child_head[k]);
-          for (int j0 = 0; j0 < kk; j0 += 64) {
-            const int j = j0 + t;
-            int sl = -1;
-            if (j < kk) {
-              const int k2 = s_live[j];
-              if (s_child_h[k2] == h) sl = s_child_slot[k2];
+          if (g0 + ci == last_new) {
+            s_top[i] = uint8_t(v);                                              // ("top": not the arena)
+          } else {
+            uint8_t* const dst = e_cost + size_t(slot) * stride + i;
+            if (found >= 0) {
+              const uint32_t old = *dst;
+              v = old < v ? old : v;                                            // nfa_states_union
             }
-            const unsigned long long hm = __ballot(sl >= 0);
-            if (hm) cur_head = __shfl(sl, 63 - __builtin_clzll(hm), 64);
+            *dst = uint8_t(v);
           }
-          if (t == 0) {
-            e_first[slot] = cf;
-            e_last[slot] = cl;
-            e_len[slot] = len + 1;
-            e_next[slot] = cur_head;
-            heads[h] = slot;
-            s_child_slot[k] = slot;
-            const uint8_t pc = s_pend[h & (kNfaPend - 1)];
-            if (pc != 255) s_pend[h & (kNfaPend - 1)] = uint8_t(pc + 1);
-          }
-        } else if (t == 0 && len + 1 > e_len[slot]) {
-          e_len[slot] = len + 1;                                                // the longer match is kept (server.c:1611-1619)
         }
-        if (found < 0) sp++;
+        if (t < gn) s_char_child[my_ch] = -1;
         __syncthreads();
       }
+      PROF(7);
+      // ---- the entries themselves, one lane per child: a pending entry keeps the longer match (server.c:1611-1619); a new one
+      // is linked into its bucket's chain behind the new children of this pop that precede it there (push order), and the last
+      // of a bucket becomes its head
+      for (int j0 = 0; j0 < nlive; j0 += 64) {
+        const int j = j0 + t;
+        if (j >= nlive) continue;
+        const int k = s_live[j];
+        const int found = s_child_found[k], slot = s_child_slot[k];
+        if (found >= 0) {
+          if (len + 1 > e_len[found]) e_len[found] = len + 1;
+        } else if (j != last_new) {
+          const uint32_t h = s_child_h[k];
+          int prev = s_child_head[k];
+          bool later = false;
+          #pragma unroll 1
+          for (int j2 = 0; j2 < nlive; j2++) {
+            if (j2 == j || j2 == last_new) continue;
+            const int k2 = s_live[j2];
+            if (s_child_found[k2] >= 0 || s_child_h[k2] != h) continue;
+            if (j2 < j) prev = s_child_slot[k2];
+            else later = true;
+          }
+          e_first[slot] = s_child_f[k];
+          e_last[slot] = s_child_l[k];
+          e_len[slot] = len + 1;
+          e_next[slot] = prev;
+          if (!later) heads[h] = slot;
+          atomicAdd(&s_pend[h & (kNfaPend - 1)], 1u);
+        }
+      }
+      if (last_new >= 0) {
+        const int k = uni(s_live[last_new]);
+        top_slot = uni(s_child_slot[k]);
+        top_f = uni64(s_child_f[k]);
+        top_l = uni64(s_child_l[k]);
+        top_len = len + 1;
+      }
+      sp += n_new;
+      __syncthreads();
+      PROF(8);
       if (status) break;
       iters++;
     }
     if (t == 0) {
       B.status[q] = status;
-      if (B.iters_out) B.iters_out[q] = int32_t(iters < INT_MAX ? iters : INT_MAX);
+      if (B.iters_out) {      // pops, shader-clock cycles / 1024 spent, and when it started
+        B.iters_out[q] = int32_t(iters < INT_MAX ? iters : INT_MAX);
+        const long long now = clock64();
+        B.iters_out[B.nq_all + q] = int32_t((now - t_begin) >> 10);
+        B.iters_out[2 * B.nq_all + q] = int32_t(uint32_t(uint64_t(t_begin) >> 10));
+#ifdef FEMTO_AMD_NFA_PROF
+        prof_acc[prof_k] += now - prof_t;
+        for (int k = 0; k < 9; k++) atomicAdd(reinterpret_cast<unsigned long long*>(B.iters_out + 3 * B.nq_all) + k, static_cast<unsigned long long>(prof_acc[k]));
+#endif
+      }
     }
     __syncthreads();
   }
@@ -631,7 +762,7 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   int64_t result_cap = std::max<int64_t>(std::min<int64_t>(2 * max_results, int64_t(1) << 22), 1 << 12);
   if ((rc = d_q.reserve(hq.size() * sizeof(NfaQueryDev))) || (rc = d_flags.reserve(h_flags.size() + 16)) ||
       (rc = d_sd.reserve(h_sd.size() * 4 + 16)) || (rc = d_ch.reserve(h_ch.size() * 2 + 16)) || (rc = d_bychar.reserve(h_bychar.size() * 4)) ||
-      (rc = d_misc.reserve(64 + size_t(nq) * 8)) ||
+      (rc = d_misc.reserve(64 + size_t(nq) * 16 + 128)) ||
       (rc = d_order.reserve(size_t(nq) * 4)))
     return rc;
   HIP_TRY(hipMemcpyAsync(d_q.p, hq.data(), hq.size() * sizeof(NfaQueryDev), hipMemcpyHostToDevice, st));
@@ -656,6 +787,7 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   B.status = d_status;
   const bool want_stats = getenv("FEMTO_AMD_NFA_STATS") != nullptr;
   B.iters_out = want_stats ? d_status + nq : nullptr;
+  B.nq_all = int32_t(nq);
   B.max_iterations = ix->regexp_max_iterations;
   B.cost_stride = (max_nodes + 3) & ~3;
   B.lds_nodes = (max_nodes + 7) & ~7;
@@ -670,7 +802,8 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
     for (const NfaQueryDev& Q : hq) max_ents = std::max(max_ents, size_t(Q.num_ents));
     B.lds_ents = max_ents <= size_t(kNfaLdsEnts) ? int32_t((std::max<size_t>(max_ents, 2) + 1) & ~size_t(1)) : 0;
   }
-  const size_t lds = nfa_lds_bytes(B.lds_nodes, B.lds_children, B.lds_ents);
+  B.lds_group = std::max(1, std::min({int(B.lds_children), 64, 16384 / (int(B.lds_nodes) * 4)}));
+  const size_t lds = nfa_lds_bytes(B.lds_nodes, B.lds_children, B.lds_ents, B.lds_group);
   int per_cu = 8;
   if (mode == 3 && ix->dev.ru && ix->dev.ru_marks) per_cu = nfa_blocks_per_cu<RumPolicy>(lds, B.lds_ents != 0);
   else if (mode == 3 && ix->dev.ru) per_cu = nfa_blocks_per_cu<RuPolicy>(lds, B.lds_ents != 0);
@@ -691,7 +824,7 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   if ((rc = d_results.reserve(size_t(result_cap) * sizeof(NfaResultDev)))) return rc;
   B.results = d_results.as<NfaResultDev>();
   B.result_cap = result_cap;
-  HIP_TRY(hipMemsetAsync(d_misc.p, 0, 64 + size_t(nq) * 8, st));
+  HIP_TRY(hipMemsetAsync(d_misc.p, 0, 64 + size_t(nq) * 16 + 128, st));
   todo.resize(static_cast<size_t>(nq));
   for (int64_t i = 0; i < nq; i++) todo[size_t(i)] = int32_t(i);
   int64_t cap = std::min<int64_t>(1024, ix->regexp_stack_cap);
@@ -725,8 +858,8 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
     HIP_TRY(hipMemcpyAsync(status.data(), d_status, size_t(nq) * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (want_stats) {      // entries popped per automaton: the kernel ends with its longest search (profiles/r05_regexp_*)
-      std::vector<int32_t> it(static_cast<size_t>(nq));
-      HIP_TRY(hipMemcpy(it.data(), d_status + nq, size_t(nq) * 4, hipMemcpyDeviceToHost));
+      std::vector<int32_t> it(static_cast<size_t>(nq) * 3);
+      HIP_TRY(hipMemcpy(it.data(), d_status + nq, size_t(nq) * 12, hipMemcpyDeviceToHost));
       std::vector<int32_t> v;
       for (int32_t q : todo) v.push_back(it[size_t(q)]);
       std::sort(v.begin(), v.end());
@@ -736,6 +869,39 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
       fprintf(stderr, "[femto_amd] nfa pass %d: %zu automata, %d workgroups, pops: mean %.0f  p50 %d  p90 %d  p99 %d  p99.9 %d  max %d  (sum %.3g; max / (sum / workgroups) = %.2f)\n",
               pass, v.size(), blocks, v.empty() ? 0.0 : sum / double(v.size()), pct(0.5), pct(0.9), pct(0.99), pct(0.999), v.empty() ? 0 : v.back(), sum,
               sum > 0 ? double(v.empty() ? 0 : v.back()) / (sum / double(blocks)) : 0.0);
+      {      // the clock: which search ended last, when it started, what a pop of it cost; how busy the workgroups were
+        uint32_t t0 = UINT32_MAX;
+        for (int32_t q : todo) t0 = std::min(t0, uint32_t(it[size_t(2 * nq + q)]));
+        int32_t qlast = todo.empty() ? 0 : todo[0], qmax = qlast;
+        double busy = 0;
+        uint32_t tend = 0;
+        for (int32_t q : todo) {
+          const uint32_t st_ = uint32_t(it[size_t(2 * nq + q)]) - t0, en = st_ + uint32_t(it[size_t(nq + q)]);
+          busy += double(uint32_t(it[size_t(nq + q)]));
+          if (en > tend) { tend = en; qlast = q; }
+          if (it[size_t(q)] > it[size_t(qmax)]) qmax = q;
+        }
+        auto line = [&](const char* what, int32_t q) {
+          fprintf(stderr, "[femto_amd]   %s: automaton %d, %d pops, started at %.3g Mcycles, ran %.3g Mcycles = %.0f cycles per pop\n", what, q, it[size_t(q)],
+                  double(uint32_t(it[size_t(2 * nq + q)]) - t0) * 1024e-6, double(uint32_t(it[size_t(nq + q)])) * 1024e-6,
+                  it[size_t(q)] ? double(uint32_t(it[size_t(nq + q)])) * 1024.0 / double(it[size_t(q)]) : 0.0);
+        };
+        line("ended last", qlast);
+        line("most pops ", qmax);
+        {
+          unsigned long long ph[9];
+          HIP_TRY(hipMemcpy(ph, d_status + 4 * nq, sizeof ph, hipMemcpyDeviceToHost));
+          static const char* const names[9] = {"pop + final test", "deletions", "min cost + reachable characters + child list", "fan-out: rank step + pending lookup", "slots + warm",
+                                               "substitutions", "children's states (groups)", "entries: link / top", "between pops (results, loop)"};
+          double tot = 0;
+          for (int k = 0; k < 9; k++) tot += double(ph[k]);
+          for (int k = 0; k < 9 && tot > 0; k++)
+            fprintf(stderr, "[femto_amd]     phase %d  %-46s %6.0f cycles per pop  %5.1f %%\n", k, names[k], sum > 0 ? double(ph[k]) / sum : 0.0, tot > 0 ? 100.0 * double(ph[k]) / tot : 0.0);
+          HIP_TRY(hipMemset(d_status + 4 * nq, 0, sizeof ph));
+        }
+        fprintf(stderr, "[femto_amd]   all searches: %.3g Mcycles on the shader clock; busy workgroup-cycles %.3g M = %.2f of workgroups x span; mean cycles per pop %.0f\n",
+                double(tend) * 1024e-6, busy * 1024e-6, tend ? busy / (double(tend) * double(blocks)) : 0.0, sum > 0 ? busy * 1024.0 / sum : 0.0);
+      }
     }
     std::vector<int32_t> again;
     for (int32_t q : todo)

@@ -26,6 +26,14 @@ struct TailItem {
 struct PackPolicy {
   static constexpr bool kSpotMarks = false;   // search steps do not report marked rows (RumPolicy does)
   static __device__ __forceinline__ int64_t marked_offset(const DevIndex& ix, int64_t row) { return pack_marked_offset(ix, row); }
+  // one word of the memory line search_step(code, .. row) will read: issued early by a caller that knows the row ahead of time
+  // (nfa_search_kernel: the entry it pops next), so that the line is on its way while other work runs
+  static __device__ __forceinline__ uint32_t touch(const DevIndex& ix, uint32_t, int64_t row) {
+    uint64_t line;
+    uint32_t r;
+    pack_split(row, &line, &r);
+    return ix.pack[line * kPackLineWords];
+  }
   static constexpr int kWaves = 8;     // waves per SIMD the count kernel is built for (64 VGPRs)
   static constexpr int kNfaWaves = 4;  // ... nfa_search_kernel (regexp_search.hip): what it reaches without scratch
   static constexpr int kDirectWaves = 7;   // ... count_direct_kernel: 72 VGPRs (at 64 it spills 20 bytes per lane)
@@ -63,16 +71,23 @@ struct PackPolicy {
 #define FEMTO_AMD_EXP_RU_WAVES 8       // (experiments: tools/ab_bench.sh builds a second library with another value)
 #endif
 struct RuPolicy : PackPolicy {
-  static constexpr int kNfaWaves = 6;  // (80 VGPRs, 8 bytes of scratch: the kernel waits for memory two thirds of its cycles, occupancy is what it lacks)
+  static constexpr int kNfaWaves = 5;  // (96 VGPRs, no scratch: a spill reload would sit in the chain of dependent steps that IS this kernel's time)
   static constexpr int kDirectWaves = FEMTO_AMD_EXP_RU_WAVES;   // 43-64 VGPRs: eight waves per SIMD without spilling
   static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
     ru_search_step(ix, j, code, f, l);
+  }
+  static __device__ __forceinline__ uint32_t touch(const DevIndex& ix, uint32_t code, int64_t row) {
+    const uint32_t tc = code < uint32_t(ix.ru_nstop) ? 0u : code - uint32_t(ix.ru_nstop);      // (a stop character has no units: any valid address, unconditionally)
+    uint64_t u;
+    uint32_t r;
+    ru_split(row, &u, &r);
+    return reinterpret_cast<const uint32_t*>(ix.ru)[(uint64_t(tc) * uint64_t(ix.ru_stride) + u) * 4];
   }
 };
 
 // ... with the MARKED rank units (handles without the suffix array): a one-row step also says whether its row is marked
 struct RumPolicy : PackPolicy {
-  static constexpr int kNfaWaves = 6;
+  static constexpr int kNfaWaves = 5;
   static constexpr int kDirectWaves = FEMTO_AMD_EXP_RU_WAVES;
   static constexpr bool kSpotMarks = true;
   static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
@@ -82,9 +97,14 @@ struct RumPolicy : PackPolicy {
   static __device__ __forceinline__ void search_step_spot(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l, bool* spotted) {
     rum_search_step(ix, j, code, f, l, spotted);
   }
+  static __device__ __forceinline__ uint32_t touch(const DevIndex& ix, uint32_t code, int64_t row) {
+    const uint32_t tc = code < uint32_t(ix.ru_nstop) ? 0u : code - uint32_t(ix.ru_nstop);
+    return reinterpret_cast<const uint32_t*>(ix.ru)[(uint64_t(tc) * uint64_t(ix.ru_stride) + (uint64_t(row) >> 6)) * 4];
+  }
 };
 
 struct Pack2Policy {
+  static __device__ __forceinline__ uint32_t touch(const DevIndex&, uint32_t, int64_t) { return 0; }     // (two dependent lines: not worth a guess)
   static constexpr int kNfaWaves = 4;
   static constexpr bool kSpotMarks = false;
   static __device__ __forceinline__ int64_t marked_offset(const DevIndex&, int64_t) { return -1; }
@@ -115,6 +135,12 @@ struct Pack2Policy {
 // end; everything that does not know its character in advance (LF steps) stays on the two-level lines
 struct IndPolicy : Pack2Policy {
   static constexpr int kNfaWaves = 5;
+  static __device__ __forceinline__ uint32_t touch(const DevIndex& ix, uint32_t code, int64_t row) {
+    uint64_t line;
+    uint32_t b;
+    ind_split(row, &line, &b);
+    return ix.ind[(uint64_t(code) * uint64_t(ix.ind_stride) + line) * 32];
+  }
   static constexpr int kWaves = 8;
   static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
     ind_search_step(ix, j, code, f, l);
