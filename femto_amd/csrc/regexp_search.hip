@@ -80,6 +80,7 @@ struct NfaBatchDev {
   int32_t pass;
   int32_t lds_nodes, lds_children;   // sizes of the workgroup's dynamic LDS arrays (nfa_lds_bytes)
   int32_t lds_group;                 // children merged together per round of the child phase (s_tmpg holds their tmp_states)
+  int32_t lds_tc;                    // > 0: tmp_states of EVERY character of the text fit s_tmpg (this many characters): the by-character pass
   int32_t lds_ents;                  // > 0: every automaton's transitions and node flags are copied to LDS (room for this many entries)
 };
 
@@ -125,7 +126,7 @@ __device__ __forceinline__ int64_t uni64(int64_t v) {
 // Dynamic LDS of one workgroup (sized per launch from the LARGEST automaton of the batch and the number of characters the
 // text holds, so that typical automata -- a few dozen nodes on a small alphabet -- leave room for a CU's full complement of
 // wavefronts; until round 5 the arrays were static for 2048 nodes and 264 children: 19 KB, 8 workgroups per CU):
-//   s_tmp u32[nn] | s_child_f i64[cc] | s_child_l i64[cc] | s_child_found i32[cc] | s_live i32[cc] | s_child_h u32[cc] |
+//   s_tmp u32[nn] | s_child_f i64[cc] | s_child_l i64[cc] | s_child_found i32[cc] | s_lv_ch u16[cc] (+ room) | s_child_h u32[cc] |
 //   s_child_head i32[cc] | s_child_slot i32[cc] | s_child_ch u16[cc] | s_cur u8[nn] | s_sub u8[nn] | s_top u8[nn]
 //                                           nn = lds_nodes (multiple of 8), cc = lds_children (multiple of 4)
 //   kLds (the batch's largest automaton has at most kNfaLdsEnts transitions): + s_ent_sd u32[ne] | s_ent_ch u16[ne] | s_flags u8[nn] --
@@ -148,14 +149,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
   __shared__ uint16_t s_code[264];              // ... and their codes in the index's rank layout (P::code_of, read from memory once)
   __shared__ uint16_t s_textch[264];            // the text's characters as a list, ascending
   __shared__ uint8_t s_alive[264];              // per character: an alive state can read it (set and cleared within a pop)
+  __shared__ uint8_t s_textpos[264];            // per character: its place in s_textch, or 255 (the by-character pass: B.lds_tc)
   __shared__ int32_t s_q;
   const int nn = B.lds_nodes, cc = B.lds_children;
   uint32_t* const s_tmp = reinterpret_cast<uint32_t*>(s_dyn);                    // tmp_states being accumulated (atomicMin)
   int64_t* const s_child_f = reinterpret_cast<int64_t*>(s_tmp + nn);
   int64_t* const s_child_l = s_child_f + cc;
   int32_t* const s_child_found = reinterpret_cast<int32_t*>(s_child_l + cc);
-  int32_t* const s_live = s_child_found + cc;
-  uint32_t* const s_child_h = reinterpret_cast<uint32_t*>(s_live + cc);          // the child's hash bucket,
+  uint16_t* const s_lv_ch = reinterpret_cast<uint16_t*>(s_child_found + cc);     // (i32[cc] of room: the live children's characters, push order)
+  uint32_t* const s_child_h = reinterpret_cast<uint32_t*>(s_child_found + 2 * cc);  // the child's hash bucket,
   int32_t* const s_child_head = reinterpret_cast<int32_t*>(s_child_h + cc);      // that bucket's head as the fan-out saw it,
   int32_t* const s_child_slot = s_child_head + cc;                               // and the slot the child was pushed into (-1: merged / not yet)
   uint16_t* const s_child_ch = reinterpret_cast<uint16_t*>(s_child_slot + cc);
@@ -204,6 +206,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
     if (code != 0xffffu) atomicOr(&s_text[c >> 5], 1u << (c & 31));
   }
   __syncthreads();
+  #pragma unroll 1
+  for (int c = t; c < 264; c += 64) s_textpos[c] = 255;
+  __syncthreads();
   int ntext = 0;
   {
     uint32_t tw[9];
@@ -225,10 +230,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
       if (!((mine >> (c & 31)) & 1u)) continue;
       rank += __popc(mine & ((1u << (c & 31)) - 1u));
       s_textch[rank] = uint16_t(c);
+      if (rank < 255) s_textpos[c] = uint8_t(rank);
     }
     #pragma unroll 1
     for (int c = t; c < 264; c += 64) s_alive[c] = 0;
   }
+  const bool tcmode = B.lds_tc > 0 && ntext <= B.lds_tc;      // (the host counted the same characters: ntext == B.lds_tc <= 64)
   const int ntext_all = ntext;      // <= 261
   int n_lowtext = 0;                // ... of them below CHARACTER_OFFSET (the first entries of the list)
   for (int c = 0; c < kNfaOffset; c++) n_lowtext += int((s_text[0] >> c) & 1u);
@@ -279,6 +286,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
       const uint32_t h0 = hash_of(0, ix.total_length - 1);
       heads[h0] = 0;
       s_pend[h0 & (kNfaPend - 1)] = 1;
+    }
+    if (tcmode) {      // tmp_states of every character of the text, and the substitution states: "dead" whenever a pop begins
+      #pragma unroll 1
+      for (int x = t; x < B.lds_tc * N; x += 64) s_tmpg[x] = kNfaDead;
+      #pragma unroll 1
+      for (int i = t; i < N; i += 64) s_tmp[i] = kNfaDead;
     }
     int sp = 1, status = 0;
     int64_t iters = 0;
@@ -363,9 +376,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
       PROF(1);
       // ---- deletions: states after reading ANY character at delete_cost, merged in (server.c:1854-1863)
       if (approx) {
-        #pragma unroll 1
-        for (int i = t; i < N; i += 64) s_tmp[i] = kNfaDead;
-        __syncthreads();
+        if (!tcmode) {
+          #pragma unroll 1
+          for (int i = t; i < N; i += 64) s_tmp[i] = kNfaDead;
+          __syncthreads();
+        }
         #pragma unroll 1
         for (int e = base5 + t; e < T; e += 64) {
           const uint32_t sd = ENT_SD(e);
@@ -377,6 +392,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
         for (int i = t; i < N; i += 64) {
           const uint32_t v = s_tmp[i];
           if (v < uint32_t(s_cur[i])) s_cur[i] = uint8_t(v);
+          if (tcmode) s_tmp[i] = kNfaDead;      // (dead again for the substitution states of the pass below)
         }
         __syncthreads();
       }
@@ -390,9 +406,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
       const int min_err = (ms < mi ? ms : mi) & 0xff;
       const bool allchars = min_err < bound && iters > 0;
       // ---- r_c: the characters an alive state can read, as one flag per character (cleared again as they are read below)
+      // By-character pass (B.lds_tc: small alphabets and automata): the SAME pass over the transitions also accumulates, for
+      // every character of the text, the states reached by reading it (approx_get_reachable_states -- the children's tmp_states,
+      // whichever of them turn out to have rows) and the states after a substitution error (server.c:2107-2110): one pass and
+      // one barrier instead of three passes of three dependent LDS phases each.
       #pragma unroll 1
-      for (int e = t; e < T; e += 64)
-        if (int(s_cur[ENT_SD(e) & 0xffffu]) < bound) s_alive[ENT_CH(e)] = 1;
+      for (int e = t; e < T; e += 64) {
+        const uint32_t sd = ENT_SD(e);
+        const uint32_t c = s_cur[sd & 0xffffu];
+        if (int(c) >= bound) continue;
+        const uint32_t ch = ENT_CH(e);
+        s_alive[ch] = 1;
+        if (tcmode) {
+          const uint32_t tp = s_textpos[ch];
+          if (tp != 255u) atomicMin(&s_tmpg[tp * uint32_t(N) + (sd >> 16)], c);
+          if (approx && e >= base5 && int(c) + Q.subst < bound) atomicMin(&s_tmp[sd >> 16], c + uint32_t(Q.subst));
+        }
+      }
       __syncthreads();
       // ---- the children in push order: characters >= CHARACTER_OFFSET ascending (the substitution loop creates their
       // entries first, server.c:2114-2120), then the characters below it (regular loop, :2123-2130).  Only characters the text
@@ -431,68 +461,68 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
       __syncthreads();
       PROF(3);
       // ---- the fan-out: lane k steps the range with the k-th character (server.c:1954-2060); then add_mapping's lookup: a
-      // pending entry with the child's range?  (children of one pop have disjoint ranges); the children with rows are listed
-      // in order (s_live): the merge loop below visits only those
+      // pending entry with the child's range?  (children of one pop have disjoint ranges.)  The children WITH rows are written
+      // out in push order (index j: s_lv_ch / s_child_*), each with its slot -- a child whose range is pending keeps that entry's
+      // slot, the new ones take sp, sp + 1, ... -- all from ballots over the lanes' own registers; the LAST new one becomes the
+      // "top" (the next entry popped) and its range goes straight into scalar registers.
       asm volatile("" ::"v"(warm), "v"(warm2));      // ("warm": the lines asked for by the previous pop have arrived by now, or are waited for here)
-      int nlive = 0;
+      int nlive = 0, n_new = 0, last_new = -1;
       for (int k0 = 0; k0 < nchild; k0 += 64) {
         const int k = k0 + t;
         bool live = false;
+        uint32_t ch = 0, h = 0;
+        int64_t f = first, l = last;
+        int found = -1, head = -1;
         if (k < nchild) {
-          const uint32_t ch = s_child_ch[k];
-          int64_t f = first, l = last;
+          ch = s_child_ch[k];
           P::search_step(ix, 1, s_code[ch], f, l);
-          s_child_f[k] = f;
-          s_child_l[k] = l;
-          int found = -1, head = -1;
           live = l >= f;                               // add_mapping ignores empty ranges (server.c:1565)
           if (live) {
-            const uint32_t h = hash_of(f, l);
-            s_child_h[k] = h;
+            h = hash_of(f, l);
             if (s_pend[h & (kNfaPend - 1)] != 0) {     // ("pend": an empty bucket needs no look at the arena)
               head = heads[h];
               for (int s2 = head; s2 >= 0; s2 = e_next[s2])
                 if (e_first[s2] == f && e_last[s2] == l) { found = s2; break; }
             }
-            s_child_head[k] = head;
-            s_child_slot[k] = -1;
           }
-          s_child_found[k] = found;
         }
-        const unsigned long long mask = __ballot(live);
-        if (live) s_live[nlive + __popcll(mask & ((1ull << t) - 1ull))] = k;
-        nlive += __popcll(mask);
-      }
-      PROF(4);
-      // ---- slots, in push order: a child whose range is pending keeps that entry's slot, the new ones take sp, sp + 1, ...;
-      // the LAST new one becomes the "top" (the next entry popped)
-      __syncthreads();
-      int n_new = 0, last_new = -1;
-      for (int j0 = 0; j0 < nlive; j0 += 64) {
-        const int j = j0 + t;
-        int k = 0;
-        bool isnew = false;
-        if (j < nlive) {
-          k = s_live[j];
-          isnew = s_child_found[k] < 0;
+        const bool isnew = live && found < 0;
+        const unsigned long long lm = __ballot(live), nm = __ballot(isnew);
+        const unsigned long long below = (1ull << t) - 1ull;
+        if (live) {
+          const int j = nlive + int(__popcll(lm & below));
+          s_lv_ch[j] = uint16_t(ch);
+          s_child_f[j] = f;
+          s_child_l[j] = l;
+          s_child_found[j] = found;
+          s_child_slot[j] = isnew ? sp + n_new + int(__popcll(nm & below)) : found;
+          s_child_h[j] = h;
+          s_child_head[j] = head;
         }
-        const unsigned long long nm = __ballot(isnew);
-        if (j < nlive) s_child_slot[k] = isnew ? sp + n_new + int(__popcll(nm & ((1ull << t) - 1ull))) : s_child_found[k];
-        if (nm) last_new = j0 + 63 - __builtin_clzll(nm);
+        if (nm) {
+          const int lane = 63 - __builtin_clzll(nm);
+          last_new = nlive + int(__popcll(lm & ((1ull << lane) - 1ull)));
+          top_f = int64_t((uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(uint64_t(f) >> 32)), lane))) << 32) |
+                          uint32_t(__builtin_amdgcn_readlane(int(uint32_t(uint64_t(f))), lane)));
+          top_l = int64_t((uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(uint64_t(l) >> 32)), lane))) << 32) |
+                          uint32_t(__builtin_amdgcn_readlane(int(uint32_t(uint64_t(l))), lane)));
+          top_slot = sp + n_new + int(__popcll(nm)) - 1;
+          top_len = len + 1;
+        }
+        nlive += int(__popcll(lm));
         n_new += int(__popcll(nm));
       }
+      PROF(4);
       if (sp + n_new > cap) { status = kNfaStatusFull; break; }     // (some new child would find the stack full)
       if (last_new >= 0 && ntext > 0) {      // "warm" (uniform condition; every lane loads, unconditionally: a load inside a divergent
                                              // block is waited for where the block ends)
-        const int k = uni(s_live[last_new]);
-        const int64_t wf = uni64(s_child_f[k]), wl = uni64(s_child_l[k]);
         const uint32_t code = s_code[s_textch[t < ntext ? t : 0]];
-        warm = P::touch(ix, code, wl);
-        warm2 = P::touch(ix, code, wf > 0 ? wf - 1 : 0);      // (two registers, nothing computed from them here: a use is where the wait goes)
+        warm = P::touch(ix, code, top_l);
+        warm2 = P::touch(ix, code, top_f > 0 ? top_f - 1 : 0);      // (two registers, nothing computed from them here: a use is where the wait goes)
       }
       PROF(5);
       // ---- substitutions: states after reading any character at subst_cost (server.c:2107-2110)
-      if (approx) {
+      if (approx && !tcmode) {
         #pragma unroll 1
         for (int i = t; i < N; i += 64) s_tmp[i] = kNfaDead;
         __syncthreads();
@@ -512,14 +542,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
       // each): tmp_states of every child of the group are accumulated in ONE pass over the transitions of the group's
       // characters (approx_get_reachable_states, nfa.c), then every (child, node) pair is finished and stored by its own lane
       // (approx_add_error_allchars nfa.c:305, the substitution states, nfa_states_union with a pending entry's)
+      if (tcmode) {      // every (live child, node) pair by its own lane, from the rows the by-character pass filled
+        #pragma unroll 1
+        for (int x = t; x < nlive * N; x += 64) {
+          const int k = x / N, i = x - k * N;
+          const int ch = s_lv_ch[k], found = s_child_found[k], slot = s_child_slot[k];
+          uint32_t v = s_tmpg[uint32_t(s_textpos[ch]) * uint32_t(N) + uint32_t(i)];
+          if (approx) {
+            const uint32_t ins = uint32_t(s_cur[i]) + uint32_t(Q.ins);          // approx_add_error_allchars (nfa.c:305)
+            v = ins < v ? ins : v;
+            const uint32_t sub = s_tmp[i];
+            if (ch >= kNfaOffset && sub < v) v = sub;
+          }
+          if (int(v) >= bound) v = kNfaDead;                                    // beyond the bound is dead, whatever the number
+          if (k == last_new) {
+            s_top[i] = uint8_t(v);                                              // ("top": not the arena)
+          } else {
+            uint8_t* const dst = e_cost + size_t(slot) * stride + i;
+            if (found >= 0) {
+              const uint32_t old = *dst;
+              v = old < v ? old : v;                                            // nfa_states_union
+            }
+            *dst = uint8_t(v);
+          }
+        }
+        __syncthreads();
+        #pragma unroll 1
+        for (int x = t; x < B.lds_tc * N; x += 64) s_tmpg[x] = kNfaDead;     // "dead" again for the next pop
+        if (approx) {
+          #pragma unroll 1
+          for (int i = t; i < N; i += 64) s_tmp[i] = kNfaDead;
+        }
+      }
       const int G = B.lds_group;
-      for (int g0 = 0; g0 < nlive; g0 += G) {
+      for (int g0 = 0; g0 < nlive && !tcmode; g0 += G) {
         const int gn = nlive - g0 < G ? nlive - g0 : G;
         #pragma unroll 1
         for (int x = t; x < gn * N; x += 64) s_tmpg[x] = kNfaDead;
         int elo = INT_MAX, ehi = 0, my_ch = 0;
         if (t < gn) {
-          my_ch = s_child_ch[s_live[g0 + t]];
+          my_ch = s_lv_ch[g0 + t];
           s_char_child[my_ch] = int16_t(t);
           elo = s_bychar[my_ch];
           ehi = s_bychar[my_ch + 1];
@@ -539,8 +601,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
         #pragma unroll 1
         for (int x = t; x < gn * N; x += 64) {
           const int ci = x / N, i = x - ci * N;
-          const int k = s_live[g0 + ci];
-          const int ch = s_child_ch[k], found = s_child_found[k], slot = s_child_slot[k];
+          const int k = g0 + ci;
+          const int ch = s_lv_ch[k], found = s_child_found[k], slot = s_child_slot[k];
           uint32_t v = s_tmpg[x];
           if (approx) {
             const uint32_t ins = uint32_t(s_cur[i]) + uint32_t(Q.ins);          // approx_add_error_allchars (nfa.c:305)
@@ -569,7 +631,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
       for (int j0 = 0; j0 < nlive; j0 += 64) {
         const int j = j0 + t;
         if (j >= nlive) continue;
-        const int k = s_live[j];
+        const int k = j;
         const int found = s_child_found[k], slot = s_child_slot[k];
         if (found >= 0) {
           if (len + 1 > e_len[found]) e_len[found] = len + 1;
@@ -580,7 +642,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
           #pragma unroll 1
           for (int j2 = 0; j2 < nlive; j2++) {
             if (j2 == j || j2 == last_new) continue;
-            const int k2 = s_live[j2];
+            const int k2 = j2;
             if (s_child_found[k2] >= 0 || s_child_h[k2] != h) continue;
             if (j2 < j) prev = s_child_slot[k2];
             else later = true;
@@ -592,13 +654,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
           if (!later) heads[h] = slot;
           atomicAdd(&s_pend[h & (kNfaPend - 1)], 1u);
         }
-      }
-      if (last_new >= 0) {
-        const int k = uni(s_live[last_new]);
-        top_slot = uni(s_child_slot[k]);
-        top_f = uni64(s_child_f[k]);
-        top_l = uni64(s_child_l[k]);
-        top_len = len + 1;
       }
       sp += n_new;
       __syncthreads();
@@ -791,11 +846,13 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   B.max_iterations = ix->regexp_max_iterations;
   B.cost_stride = (max_nodes + 3) & ~3;
   B.lds_nodes = (max_nodes + 7) & ~7;
+  int text_chars = 0;
   {
     int nchars = 0;       // characters the text holds: the most children a pop can have
     for (int c = 0; c < kAlphaSize && size_t(c) + 1 < ix->host.C.size(); c++)
       if (ix->host.C[size_t(c) + 1] > ix->host.C[size_t(c)]) nchars++;
     B.lds_children = (std::max(nchars, 4) + 3) & ~3;
+    text_chars = nchars;
   }
   {
     size_t max_ents = 0;
@@ -803,6 +860,8 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
     B.lds_ents = max_ents <= size_t(kNfaLdsEnts) ? int32_t((std::max<size_t>(max_ents, 2) + 1) & ~size_t(1)) : 0;
   }
   B.lds_group = std::max(1, std::min({int(B.lds_children), 64, 16384 / (int(B.lds_nodes) * 4)}));
+  // small alphabets and automata (DNA motifs: 5 characters x ~24 nodes): one row of tmp_states per character of the TEXT
+  B.lds_tc = (text_chars <= 64 && text_chars <= B.lds_group && size_t(text_chars) * size_t(B.lds_nodes) * 4 <= 4096) ? text_chars : 0;
   const size_t lds = nfa_lds_bytes(B.lds_nodes, B.lds_children, B.lds_ents, B.lds_group);
   int per_cu = 8;
   if (mode == 3 && ix->dev.ru && ix->dev.ru_marks) per_cu = nfa_blocks_per_cu<RumPolicy>(lds, B.lds_ents != 0);
