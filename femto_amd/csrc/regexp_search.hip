@@ -76,6 +76,7 @@ struct NfaBatchDev {
   int32_t* status;           // per query
   int32_t* iters_out;        // NULL, or per query: entries popped | cycles / 1024 | start / 1024 (FEMTO_AMD_NFA_STATS=1 prints their distribution)
   int32_t nq_all;
+  int32_t warm;              // 0: do not request the next pop's rank lines ahead (FEMTO_AMD_NFA_WARM=0: experiments)
   int64_t max_iterations;    // MAX_REGEXP_ITERATIONS (src/main/server.c:40)
   int32_t pass;
   int32_t lds_nodes, lds_children;   // sizes of the workgroup's dynamic LDS arrays (nfa_lds_bytes)
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
       }
       PROF(4);
       if (sp + n_new > cap) { status = kNfaStatusFull; break; }     // (some new child would find the stack full)
-      if (last_new >= 0 && ntext > 0) {      // "warm" (uniform condition; every lane loads, unconditionally: a load inside a divergent
+      if (last_new >= 0 && ntext > 0 && B.warm) {      // "warm" (uniform condition; every lane loads, unconditionally: a load inside a divergent
                                              // block is waited for where the block ends)
         const uint32_t code = s_code[s_textch[t < ntext ? t : 0]];
         warm = P::touch(ix, code, top_l);
@@ -843,6 +844,7 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   const bool want_stats = getenv("FEMTO_AMD_NFA_STATS") != nullptr;
   B.iters_out = want_stats ? d_status + nq : nullptr;
   B.nq_all = int32_t(nq);
+  B.warm = knob(-1, "FEMTO_AMD_NFA_WARM", 1) != 0;
   B.max_iterations = ix->regexp_max_iterations;
   B.cost_stride = (max_nodes + 3) & ~3;
   B.lds_nodes = (max_nodes + 7) & ~7;
