@@ -445,6 +445,10 @@ int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode);
 /* Runtime switches of an open handle: "sort" (default 1: mode 1 orders large batches by pattern suffix),
  * "regexp_max_iterations" (default 10^6 = MAX_REGEXP_ITERATIONS), "regexp_stack_cap" (default 2^18). */
 int femto_amd_set_option(femto_amd_index_t* ix, const char* name, int value);
+/* What was derived (diagnostics; femto_amd/__init__.py pack_info() names every bit): *available bit 0 packed lines, 1 two-level lines,
+ * 2 level table, 3 suffix array of every row, 4 inverse suffix array of every position, 5 per-character rank lines, 6 context table,
+ * bits 8..11 / 12..16 / 24..28 the context tables' symbol counts, bit 20 rank units, bit 21 the MARKED rank units (64 rows + mark
+ * bits: handles that walk to marks). */
 int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* bytes, double* build_ms, int* ktab_syms);
 /* What the handle holds in HBM, in bytes -- the server's "what may a handle spend" made visible (the counterpart of
  * server_settings_t's cache sizes, src/main/server.c:3484-3602): out[0] the femto block files as uploaded, [1] packed lines,

@@ -445,6 +445,40 @@ def test_open_with_options(fixtures, gpu_ok, name):
         ix.close()
 
 
+@pytest.mark.parametrize("name", ["acgt48k", "eng2doc"])
+def test_released_wavelet_lines_come_back(fixtures, gpu_ok, name):
+    """A handle with a budget (the default open included) releases femto's wavelet tree as segment lines once the derived
+    layouts stand (femto_amd_options_t::wavelet_lines auto) and uploads them again, counted, when a call needs them: leaf
+    requests, forward steps, femto_amd_set_rank_mode(1 / 0).  Same goldens before and after; wavelet_lines = 1 keeps them."""
+    fx = fixtures(name)
+    g = fx.gold
+    plen, flat, starts = fx.patterns
+    kept = femto_amd.Index(fx.index, device=0, options=dict(wavelet_lines=1))
+    ix = femto_amd.Index(fx.index, device=0)                    # the default bound: a handle with a budget
+    assert ix.structures()["hbm_budget_is_default"] == 1 and ix.rank_mode in (3, 4)
+    held0, held_kept = ix.structures()["hbm_allocated"], kept.structures()["hbm_allocated"]
+    assert held0 < held_kept, (held0, held_kept)                # the segment lines are gone
+    first, last = ix.count_flat(plen, flat, starts)             # the derived layouts do not read them
+    assert np.array_equal(first, g["count_first"]) and np.array_equal(last, g["count_last"])
+    assert ix.structures()["hbm_allocated"] == held0
+    rows = np.arange(ix.info.total_length, dtype=np.int64)
+    ch, occ, off = ix.block_requests(rows)                      # LOCATION leaves read femto's own mark tables: the lines come back
+    assert np.array_equal(ch, g["L"]) and np.array_equal(occ, g["occ"]) and np.array_equal(off, g["off"])
+    assert held0 < ix.structures()["hbm_allocated"] <= held_kept + 4096
+    for mode in (1, 0, ix.rank_mode):
+        ix.set_rank_mode(mode)
+        f2, l2 = ix.count_flat(plen, flat, starts)
+        assert np.array_equal(f2, g["count_first"]) and np.array_equal(l2, g["count_last"]), mode
+        for mo, g_noccs, g_offs in fx.locate_cases():
+            noccs, offs = ix.locate_flat(plen, flat, starts, mo)
+            assert np.array_equal(noccs, g_noccs) and np.array_equal(offs, g_offs), (mode, mo)
+    ix.close()
+    ix = femto_amd.Index(fx.index, device=0, options=dict(hbm_budget_bytes=femto_amd.BUDGET_ALL))
+    assert ix.structures()["image"] == kept.structures()["image"]          # no budget: nothing released
+    ix.close()
+    kept.close()
+
+
 @pytest.mark.parametrize("name", ["acgt48k", "runs3doc", "eng2doc"])
 def test_level_table_deep_entries_recomputed(fixtures, gpu_ok, monkeypatch, name):
     """The deepest level of the level table stores (first, rows) in 8 bytes; an entry with 2^24 - 1 rows or more stores
