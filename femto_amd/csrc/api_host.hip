@@ -80,7 +80,9 @@ double cgroup_cpu_quota() {
 
 size_t pipe_in_bytes() { return size_t(kPipeChunk) * 12 + size_t(kPipeSymCap) * 2 + 64; }
 
-int pipe_init(femto_amd_index* ix, Scratch& S) {
+}  // namespace
+// the handle's host worker pool (staging threads of host-pointer batches; the automaton batch's result sort), created on first use
+void femto_amd::ensure_workers(femto_amd_index* ix) {
   {
     std::lock_guard<std::mutex> lk(ix->workers_mu);
     if (!ix->workers) {
@@ -98,6 +100,11 @@ int pipe_init(femto_amd_index* ix, Scratch& S) {
       ix->workers.reset(new WorkerPool(nthreads));
     }
   }
+}
+namespace {
+
+int pipe_init(femto_amd_index* ix, Scratch& S) {
+  ensure_workers(ix);
   auto& P = S.pipe;
   if (P.ready) return 0;
   // The staging buffers (kPipeDepth x ~140 MB pinned host + as much device memory per leased scratch) live until the handle is

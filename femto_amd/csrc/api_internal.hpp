@@ -349,6 +349,7 @@ int upload(T** dst, const std::vector<T>& src, int64_t* bytes, size_t slack = 0)
 int64_t knob(int64_t opt_value, const char* env_name, int64_t dflt);
 // free HBM as far as this handle may use it: what the device has free, less whatever hbm_budget_bytes forbids
 size_t hbm_free(const femto_amd_index* ix);
+void ensure_workers(femto_amd_index* ix);         // creates ix->workers (api_host.hip) if it does not exist yet
 int release_wavelet_lines(femto_amd_index* ix);   // a handle with a budget drops femto's segment lines once the derived layouts stand ...
 int ensure_wavelet_lines(femto_amd_index* ix);    // ... and calls that need them (modes 0/1, forward steps) bring them back (caller holds ix->mu or is the only user)
 hipError_t big_malloc(femto_amd_index* ix, void** out, size_t bytes);

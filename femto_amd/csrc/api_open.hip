@@ -428,11 +428,7 @@ int build_pack(femto_amd_index* ix) {
                            knob(ix->opt.wavelet_lines, "FEMTO_AMD_WAVELET_LINES", ix->opt.hbm_budget_bytes >= 0 ? 0 : 1) == 0;
       const size_t free_now = hbm_free(ix) + (segs_go && ix->opt.hbm_budget_bytes >= 0 ? h.segs.size() * 8 : 0);
       ru_marked = ru_knob == 3 || (ru_knob == 1 && !sa_will_be_resident(ix, free_now > ru_est ? free_now - ru_est : 0));
-      const int urows = ru_marked ? kRumRows : kRuRows;
-      const int64_t ustride = (n + urows - 1) / urows + 1;
-      const size_t rbytes = size_t(std::max(ntab, 0)) * size_t(ustride) * 16;
       const bool want = ru_knob != 0;
-      // (a handle with an HBM budget: at most half of what the budget has left -- the level table takes the rest)
       // the rows of the stop characters (one per document and character <= SEOF): 8 bytes each, listed for ru_stop_step
       int64_t nstoprows = 0;
       int32_t soff[4] = {0, 0, 0, 0};
@@ -440,8 +436,17 @@ int build_pack(femto_amd_index* ix) {
         if (c < nstop) nstoprows += pc[8 + size_t(c)] + 1 - pc[size_t(c)];
         soff[c + 1] = int32_t(std::min<int64_t>(nstoprows, INT32_MAX));
       }
+      const size_t ru_share = free_now / (ix->opt.hbm_budget_bytes >= 0 ? 2 : 3);
+      auto units_bytes = [&](bool marked) { return size_t(std::max(ntab, 0)) * size_t((n + (marked ? kRumRows : kRuRows) - 1) / (marked ? kRumRows : kRuRows) + 1) * 16; };
+      // (auto: where the marked units do not fit their share of the budget but the plain ones do, the plain ones are built --
+      // 3 x text, `profiles/r05_budget_sweep.txt`)
+      if (ru_marked && ru_knob == 1 && units_bytes(true) + size_t(nstoprows) * 8 > ru_share) ru_marked = false;
+      const int urows = ru_marked ? kRumRows : kRuRows;
+      const int64_t ustride = (n + urows - 1) / urows + 1;
+      const size_t rbytes = units_bytes(ru_marked);
+      // (a handle with an HBM budget: at most half of what the budget has left -- the level table takes the rest)
       if (want && ntab >= 1 && nstop <= 3 && nstoprows < INT32_MAX && n < (int64_t(1) << 35) &&
-          rbytes + size_t(nstoprows) * 8 <= free_now / (ix->opt.hbm_budget_bytes >= 0 ? 2 : 3) &&
+          rbytes + size_t(nstoprows) * 8 <= ru_share &&
           big_malloc(ix, reinterpret_cast<void**>(&ix->d_ru), rbytes + 256) == hipSuccess &&
           big_malloc(ix, reinterpret_cast<void**>(&ix->d_ru_stop), size_t(nstoprows) * 8 + 64) == hipSuccess) {
         DevIndex d = ix->dev;

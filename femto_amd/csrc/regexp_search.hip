@@ -23,6 +23,7 @@
 // reports), so the result lists are IDENTICAL to do_regexp_query's for the same nfa_description_t: pinned by
 // tests/golden/*_regexp.npz (generated through setup_regexp_query_take_nfa, oracle/ref_tool.c) and tests/test_regexp.py.
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cstring>
 
@@ -724,28 +725,28 @@ int nfa_blocks_per_cu(size_t lds, bool lds_ents) {
 
 // regexp_result_list_sort (src/main/server.c:1528-1573): sort by first ascending, last descending; drop equal ranges (the one
 // appended first stays: glibc's qsort is a stable merge sort) and ranges inside the last kept one
-static void sort_results(std::vector<NfaHostResult>& r) {
-  std::stable_sort(r.begin(), r.end(), [](const NfaHostResult& a, const NfaHostResult& b) {
+// regexp_result_list_sort (server.c:1528-1573) of one automaton's raw results, in place; returns how many are kept
+static size_t sort_results(NfaHostResult* r, size_t count) {
+  std::stable_sort(r, r + count, [](const NfaHostResult& a, const NfaHostResult& b) {
     if (a.first != b.first) return a.first < b.first;
     if (a.last != b.last) return a.last > b.last;
     return a.seq < b.seq;
   });
   size_t n = 0;
-  for (size_t k = 0; k < r.size(); k++) {
+  for (size_t k = 0; k < count; k++) {
     if (n && r[k].first == r[n - 1].first && r[k].last == r[n - 1].last) continue;
     r[n++] = r[k];
   }
-  r.resize(n);
-  if (r.empty()) return;
+  if (n == 0) return 0;
   int64_t first = r[0].first, last = r[0].last;
   size_t i = 1;
-  for (size_t k = 1; k < r.size(); k++) {
+  for (size_t k = 1; k < n; k++) {
     if (r[k].first >= first && r[k].last <= last) continue;
     first = r[k].first;
     last = r[k].last;
     r[i++] = r[k];
   }
-  r.resize(i);
+  return i;
 }
 
 int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_amd_nfa_t* nfas, int64_t max_results,
@@ -766,6 +767,9 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   const int mode = ix->mode;
   if (mode != 3 && mode != 4 && !ix->host.dir_regular)
     return set_err(FEMTO_AMD_ERR_INVALID, "regular-expression search needs the derived segment lines");
+  const auto t_call = std::chrono::steady_clock::now();      // FEMTO_AMD_NFA_STATS: where the call's time goes on the host
+  auto ms_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+  double t_flat = 0, t_search = 0, t_copy = 0, t_sort = 0;
   // ---- the automata, flat: transitions sorted by character (reading ch touches only its own entries)
   std::vector<NfaQueryDev> hq(static_cast<size_t>(nq));
   std::vector<uint8_t> h_flags;
@@ -803,6 +807,7 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
         h_ch[at] = uint16_t(c);
       }
   }
+  t_flat = ms_since(t_call);
   Lease L(ix);
   if (!L.s) return L.rc;
   hipStream_t st = L.s->stream;
@@ -981,35 +986,58 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
     return set_err(FEMTO_AMD_ERR_FULL, "more raw result ranges than the device buffer may hold (" + std::to_string(count) + ")");
   }
   }
+  t_search = ms_since(t_call) - t_flat;
   std::vector<NfaResultDev> raw(static_cast<size_t>(count));
   if (count) HIP_TRY(hipMemcpy(raw.data(), d_results.p, size_t(count) * sizeof(NfaResultDev), hipMemcpyDeviceToHost));
-  // a search that was run again appended its earlier attempts' results too: only the last attempt's count
-  std::vector<std::vector<NfaHostResult>> per(static_cast<size_t>(nq));
+  t_copy = ms_since(t_call) - t_flat - t_search;
+  // a search that was run again appended its earlier attempts' results too: only the last attempt's count.  The raw results are
+  // grouped by automaton in one flat array (count, prefix, scatter) and every automaton's list is sorted by the handle's host
+  // threads (regexp_result_list_sort, server.c:1528-1573: 2.98 M raw ranges of 20 000 APPROX 1 motifs took one thread 167 ms --
+  // a quarter of the call, next to 490 ms of search)
+  std::vector<int64_t> seg(static_cast<size_t>(nq) + 1, 0);
   for (size_t k = 0; k < raw.size(); k++)
-    if (raw[k].pass == last_pass[size_t(raw[k].query)])
-      per[size_t(raw[k].query)].push_back({raw[k].first, raw[k].last, raw[k].len, raw[k].cost, int64_t(k)});
+    if (raw[k].pass == last_pass[size_t(raw[k].query)] && status[size_t(raw[k].query)] == 0) seg[size_t(raw[k].query) + 1]++;   // (an error: the reference returns no results, RETURN_ERROR)
+  for (int64_t qi = 0; qi < nq; qi++) seg[size_t(qi) + 1] += seg[size_t(qi)];
+  std::vector<NfaHostResult> flat(static_cast<size_t>(seg[size_t(nq)]));
+  {
+    std::vector<int64_t> at(seg.begin(), seg.end() - 1);
+    for (size_t k = 0; k < raw.size(); k++)
+      if (raw[k].pass == last_pass[size_t(raw[k].query)] && status[size_t(raw[k].query)] == 0)
+        flat[size_t(at[size_t(raw[k].query)]++)] = {raw[k].first, raw[k].last, raw[k].len, raw[k].cost, int64_t(k)};
+  }
+  std::vector<int64_t> kept(static_cast<size_t>(nq), 0);
+  auto sort_some = [&](int t, int nt) {
+    for (int64_t qi = t; qi < nq; qi += nt) kept[size_t(qi)] = int64_t(sort_results(flat.data() + seg[size_t(qi)], size_t(seg[size_t(qi) + 1] - seg[size_t(qi)])));
+  };
+  if (flat.size() >= (size_t(1) << 16)) {
+    ensure_workers(ix);
+    std::lock_guard<std::mutex> wl(ix->workers_mu);
+    ix->workers->run(sort_some);
+  } else {
+    sort_some(0, 1);
+  }
   int64_t n = 0;
   for (int64_t qi = 0; qi < nq; qi++) {
-    std::vector<NfaHostResult>& r = per[size_t(qi)];
-    if (status[size_t(qi)] != 0) r.clear();        // the reference returns an error and no results (RETURN_ERROR)
-    sort_results(r);
     result_start[qi] = n;
-    n += int64_t(r.size());
+    n += kept[size_t(qi)];
   }
   result_start[nq] = n;
   *n_out = n;
+  t_sort = ms_since(t_call) - t_flat - t_search - t_copy;
+  if (want_stats)
+    fprintf(stderr, "[femto_amd] nfa call, host side: flatten the automata %.1f ms, upload + search passes %.1f, results to the host %.1f (%llu raw), per-automaton sort %.1f\n",
+            t_flat, t_search, t_copy, count, t_sort);
   if (status_out) std::memcpy(status_out, status.data(), size_t(nq) * 4);
   if (max_results == 0) return FEMTO_AMD_OK;        // count only: *n_out and result_start[] are what a second call needs
   if (n > max_results) return set_err(FEMTO_AMD_ERR_FULL, "more results than max_results: *n_out holds the number to call again with");
   for (int64_t qi = 0; qi < nq; qi++) {
-    const std::vector<NfaHostResult>& r = per[size_t(qi)];
+    const NfaHostResult* r = flat.data() + seg[size_t(qi)];
     int64_t at = result_start[qi];
-    for (const NfaHostResult& x : r) {
-      first_out[at] = x.first;
-      last_out[at] = x.last;
-      if (len_out) len_out[at] = x.len;
-      if (cost_out) cost_out[at] = x.cost;
-      at++;
+    for (int64_t k = 0; k < kept[size_t(qi)]; k++, at++) {
+      first_out[at] = r[k].first;
+      last_out[at] = r[k].last;
+      if (len_out) len_out[at] = r[k].len;
+      if (cost_out) cost_out[at] = r[k].cost;
     }
   }
   return FEMTO_AMD_OK;
