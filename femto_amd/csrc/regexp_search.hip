@@ -88,7 +88,7 @@ struct NfaBatchDev {
 
 // mode 1: femto's own wavelet tree through the derived segment lines (alphabets of more than 256 characters, range-split
 // indexes); "code" is the alpha code itself
-struct WavePolicy {
+struct WavePolicy : NoSpec {
   static constexpr int kNfaWaves = 3;
   static __device__ __forceinline__ void search_step(const DevIndex& ix, int, uint32_t ch, int64_t& f, int64_t& l) {
     const int64_t nf = f == 0 ? ix.C[ch] : c_plus_occ_lane(ix, ch, f - 1);
@@ -238,6 +238,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
     for (int c = t; c < 264; c += 64) s_alive[c] = 0;
   }
   const bool tcmode = B.lds_tc > 0 && ntext <= B.lds_tc;      // (the host counted the same characters: ntext == B.lds_tc <= 64)
+  // tcmode: lane j IS the text's j-th character for the whole kernel (its character and code in registers)
+  __syncthreads();
+  const uint32_t my_ch = (tcmode && t < ntext) ? uint32_t(s_textch[t]) : 0u;
+  const uint32_t my_code = (tcmode && t < ntext) ? uint32_t(s_code[my_ch]) : 0u;
   const int ntext_all = ntext;      // <= 261
   int n_lowtext = 0;                // ... of them below CHARACTER_OFFSET (the first entries of the list)
   for (int c = 0; c < kNfaOffset; c++) n_lowtext += int((s_text[0] >> c) & 1u);
@@ -309,6 +313,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
     // it that request's latency); the batch ends with its longest search (profiles/r05_regexp_stats.txt), so the latency of a
     // single chain is what the kernel's time is made of.
     uint32_t warm = 0, warm2 = 0;
+    // "spec" (tcmode on a policy whose step is one load per range end): not just a word of the top child's lines but the UNITS
+    // its fan-out will need are loaded when its range is known -- lane j for the text's j-th character -- and stay in registers:
+    // the next pop's fan-out is arithmetic, the rank request's latency is off the chain altogether.
+    typename P::Spec spec;
+    bool spec_ok = false;
     // built with -DFEMTO_AMD_NFA_PROF (tools/ab_bench.sh): shader-clock cycles per phase of a pop, summed over the automaton (phase k =
     // from PROF(k) to the next), printed by FEMTO_AMD_NFA_STATS=1.  Not in the product build: the accumulators cost registers.
 #ifdef FEMTO_AMD_NFA_PROF
@@ -334,6 +343,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
       sp--;
       const bool from_top = sp == top_slot;
       top_slot = -1;
+      const bool use_spec = from_top && spec_ok;
+      spec_ok = false;
       int64_t first, last;
       int len;
       if (from_top) {
@@ -426,58 +437,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
         }
       }
       __syncthreads();
-      // ---- the children in push order: characters >= CHARACTER_OFFSET ascending (the substitution loop creates their
-      // entries first, server.c:2114-2120), then the characters below it (regular loop, :2123-2130).  Only characters the text
-      // holds can have rows, so the lanes go over the TEXT's characters (ascending: those below CHARACTER_OFFSET come first in
-      // the list), 64 at a time, and a child's place is a count of ballot bits.  (Until round 5 this went over all 261 characters
-      // with nine-word bit arithmetic per lane: 4 300 of a pop's 12 000 cycles, measured with FEMTO_AMD_NFA_STATS.)
-      unsigned long long cm[5] = {0, 0, 0, 0, 0};
-      int nchild = 0;
-#pragma unroll
-      for (int w = 0; w < 5; w++) {
-        if (64 * w >= ntext_all) break;
-        const int j = 64 * w + t;
-        bool isch = false;
-        if (j < ntext_all) {
-          const int c = s_textch[j];
-          isch = s_alive[c] != 0 || (allchars && c >= kNfaOffset);
-          s_alive[c] = 0;
-        }
-        cm[w] = __ballot(isch);
-        nchild += int(__popcll(cm[w]));
-      }
-      const int n_lo = int(__popcll(cm[0] & ((1ull << n_lowtext) - 1ull)));      // children below CHARACTER_OFFSET: pushed last
-      {
-        int before = 0;
-#pragma unroll
-        for (int w = 0; w < 5; w++) {
-          if (64 * w >= ntext_all) break;
-          const int j = 64 * w + t;
-          if ((cm[w] >> t) & 1ull) {
-            const int rank = before + int(__popcll(cm[w] & ((1ull << t) - 1ull)));      // children before this one in character order
-            s_child_ch[j < n_lowtext ? (nchild - n_lo) + rank : rank - n_lo] = s_textch[j];
-          }
-          before += int(__popcll(cm[w]));
-        }
-      }
-      __syncthreads();
-      PROF(3);
-      // ---- the fan-out: lane k steps the range with the k-th character (server.c:1954-2060); then add_mapping's lookup: a
-      // pending entry with the child's range?  (children of one pop have disjoint ranges.)  The children WITH rows are written
-      // out in push order (index j: s_lv_ch / s_child_*), each with its slot -- a child whose range is pending keeps that entry's
-      // slot, the new ones take sp, sp + 1, ... -- all from ballots over the lanes' own registers; the LAST new one becomes the
-      // "top" (the next entry popped) and its range goes straight into scalar registers.
-      asm volatile("" ::"v"(warm), "v"(warm2));      // ("warm": the lines asked for by the previous pop have arrived by now, or are waited for here)
       int nlive = 0, n_new = 0, last_new = -1;
-      for (int k0 = 0; k0 < nchild; k0 += 64) {
-        const int k = k0 + t;
+      if (tcmode) {
+        // ---- children and fan-out, one lane per character of the text (small alphabets): lane j's character is a child when an
+        // alive state reads it (or any character may be an error); the lane steps the range with it -- from the units loaded
+        // ahead when the popped entry was the top ("spec") -- looks the child's range up among the pending entries, and the
+        // places in push order (characters >= CHARACTER_OFFSET ascending, then those below it: server.c:2114-2130) are counts
+        // of ballot bits.  No list of children in LDS, no second round trip for the character and its code.
+        bool isch = false;
+        if (t < ntext) {
+          isch = s_alive[my_ch] != 0 || (allchars && my_ch >= uint32_t(kNfaOffset));
+          s_alive[my_ch] = 0;
+        }
+        PROF(3);
+        asm volatile("" ::"v"(warm), "v"(warm2));
         bool live = false;
-        uint32_t ch = 0, h = 0;
+        uint32_t h = 0;
         int64_t f = first, l = last;
         int found = -1, head = -1;
-        if (k < nchild) {
-          ch = s_child_ch[k];
-          P::search_step(ix, 1, s_code[ch], f, l);
+        if (isch) {
+          if constexpr (P::kNfaSpec) {
+            if (use_spec) P::spec_step(ix, my_code, f, l, spec);
+            else P::search_step(ix, 1, my_code, f, l);
+          } else {
+            P::search_step(ix, 1, my_code, f, l);
+          }
           live = l >= f;                               // add_mapping ignores empty ranges (server.c:1565)
           if (live) {
             h = hash_of(f, l);
@@ -490,33 +474,129 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
         }
         const bool isnew = live && found < 0;
         const unsigned long long lm = __ballot(live), nm = __ballot(isnew);
-        const unsigned long long below = (1ull << t) - 1ull;
+        const unsigned long long lowm = (1ull << n_lowtext) - 1ull, below = (1ull << t) - 1ull;
+        const bool lo = t < n_lowtext;      // a character below CHARACTER_OFFSET: pushed after all the others
         if (live) {
-          const int j = nlive + int(__popcll(lm & below));
-          s_lv_ch[j] = uint16_t(ch);
+          const int j = lo ? int(__popcll(lm & ~lowm)) + int(__popcll(lm & lowm & below)) : int(__popcll(lm & ~lowm & below));
+          const int nb = lo ? int(__popcll(nm & ~lowm)) + int(__popcll(nm & lowm & below)) : int(__popcll(nm & ~lowm & below));
+          s_lv_ch[j] = uint16_t(my_ch);
           s_child_f[j] = f;
           s_child_l[j] = l;
           s_child_found[j] = found;
-          s_child_slot[j] = isnew ? sp + n_new + int(__popcll(nm & below)) : found;
+          s_child_slot[j] = isnew ? sp + nb : found;
           s_child_h[j] = h;
           s_child_head[j] = head;
         }
+        nlive = int(__popcll(lm));
+        n_new = int(__popcll(nm));
         if (nm) {
-          const int lane = 63 - __builtin_clzll(nm);
-          last_new = nlive + int(__popcll(lm & ((1ull << lane) - 1ull)));
+          const unsigned long long pick = (nm & lowm) ? (nm & lowm) : nm;      // the new child pushed last
+          const int lane = 63 - __builtin_clzll(pick);
+          last_new = (nm & lowm) ? int(__popcll(lm & ~lowm)) + int(__popcll(lm & lowm & ((1ull << lane) - 1ull))) : int(__popcll(lm & ~lowm & ((1ull << lane) - 1ull)));
           top_f = int64_t((uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(uint64_t(f) >> 32)), lane))) << 32) |
                           uint32_t(__builtin_amdgcn_readlane(int(uint32_t(uint64_t(f))), lane)));
           top_l = int64_t((uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(uint64_t(l) >> 32)), lane))) << 32) |
                           uint32_t(__builtin_amdgcn_readlane(int(uint32_t(uint64_t(l))), lane)));
-          top_slot = sp + n_new + int(__popcll(nm)) - 1;
+          top_slot = sp + n_new - 1;
           top_len = len + 1;
         }
-        nlive += int(__popcll(lm));
-        n_new += int(__popcll(nm));
+      } else {
+        // ---- the children in push order: characters >= CHARACTER_OFFSET ascending (the substitution loop creates their
+        // entries first, server.c:2114-2120), then the characters below it (regular loop, :2123-2130).  Only characters the text
+        // holds can have rows, so the lanes go over the TEXT's characters (ascending: those below CHARACTER_OFFSET come first in
+        // the list), 64 at a time, and a child's place is a count of ballot bits.  (Until round 5 this went over all 261 characters
+        // with nine-word bit arithmetic per lane: 4 300 of a pop's 12 000 cycles, measured with FEMTO_AMD_NFA_STATS.)
+        unsigned long long cm[5] = {0, 0, 0, 0, 0};
+        int nchild = 0;
+#pragma unroll
+        for (int w = 0; w < 5; w++) {
+          if (64 * w >= ntext_all) break;
+          const int j = 64 * w + t;
+          bool isch = false;
+          if (j < ntext_all) {
+            const int c = s_textch[j];
+            isch = s_alive[c] != 0 || (allchars && c >= kNfaOffset);
+            s_alive[c] = 0;
+          }
+          cm[w] = __ballot(isch);
+          nchild += int(__popcll(cm[w]));
+        }
+        const int n_lo = int(__popcll(cm[0] & ((1ull << n_lowtext) - 1ull)));      // children below CHARACTER_OFFSET: pushed last
+        {
+          int before = 0;
+#pragma unroll
+          for (int w = 0; w < 5; w++) {
+            if (64 * w >= ntext_all) break;
+            const int j = 64 * w + t;
+            if ((cm[w] >> t) & 1ull) {
+              const int rank = before + int(__popcll(cm[w] & ((1ull << t) - 1ull)));      // children before this one in character order
+              s_child_ch[j < n_lowtext ? (nchild - n_lo) + rank : rank - n_lo] = s_textch[j];
+            }
+            before += int(__popcll(cm[w]));
+          }
+        }
+        __syncthreads();
+        PROF(3);
+        asm volatile("" ::"v"(warm), "v"(warm2));      // ("warm": the lines asked for by the previous pop have arrived by now, or are waited for here)
+        // ---- the fan-out: lane k steps the range with the k-th character (server.c:1954-2060); then add_mapping's lookup: a
+        // pending entry with the child's range?  (children of one pop have disjoint ranges.)  The children WITH rows are written
+        // out in push order (index j: s_lv_ch / s_child_*), each with its slot -- a child whose range is pending keeps that entry's
+        // slot, the new ones take sp, sp + 1, ... -- all from ballots over the lanes' own registers; the LAST new one becomes the
+        // "top" (the next entry popped) and its range goes straight into scalar registers.
+        for (int k0 = 0; k0 < nchild; k0 += 64) {
+          const int k = k0 + t;
+          bool live = false;
+          uint32_t ch = 0, h = 0;
+          int64_t f = first, l = last;
+          int found = -1, head = -1;
+          if (k < nchild) {
+            ch = s_child_ch[k];
+            P::search_step(ix, 1, s_code[ch], f, l);
+            live = l >= f;                               // add_mapping ignores empty ranges (server.c:1565)
+            if (live) {
+              h = hash_of(f, l);
+              if (s_pend[h & (kNfaPend - 1)] != 0) {     // ("pend": an empty bucket needs no look at the arena)
+                head = heads[h];
+                for (int s2 = head; s2 >= 0; s2 = e_next[s2])
+                  if (e_first[s2] == f && e_last[s2] == l) { found = s2; break; }
+              }
+            }
+          }
+          const bool isnew = live && found < 0;
+          const unsigned long long lm = __ballot(live), nm = __ballot(isnew);
+          const unsigned long long below = (1ull << t) - 1ull;
+          if (live) {
+            const int j = nlive + int(__popcll(lm & below));
+            s_lv_ch[j] = uint16_t(ch);
+            s_child_f[j] = f;
+            s_child_l[j] = l;
+            s_child_found[j] = found;
+            s_child_slot[j] = isnew ? sp + n_new + int(__popcll(nm & below)) : found;
+            s_child_h[j] = h;
+            s_child_head[j] = head;
+          }
+          if (nm) {
+            const int lane = 63 - __builtin_clzll(nm);
+            last_new = nlive + int(__popcll(lm & ((1ull << lane) - 1ull)));
+            top_f = int64_t((uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(uint64_t(f) >> 32)), lane))) << 32) |
+                            uint32_t(__builtin_amdgcn_readlane(int(uint32_t(uint64_t(f))), lane)));
+            top_l = int64_t((uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(uint64_t(l) >> 32)), lane))) << 32) |
+                            uint32_t(__builtin_amdgcn_readlane(int(uint32_t(uint64_t(l))), lane)));
+            top_slot = sp + n_new + int(__popcll(nm)) - 1;
+            top_len = len + 1;
+          }
+          nlive += int(__popcll(lm));
+          n_new += int(__popcll(nm));
+        }
       }
       PROF(4);
       if (sp + n_new > cap) { status = kNfaStatusFull; break; }     // (some new child would find the stack full)
-      if (last_new >= 0 && ntext > 0 && B.warm) {      // "warm" (uniform condition; every lane loads, unconditionally: a load inside a divergent
+      if (P::kNfaSpec && tcmode && B.warm) {
+        if (last_new >= 0) {      // "spec" (uniform condition; every lane loads, unconditionally)
+          P::spec_load(ix, my_code, top_f, top_l, spec);
+          spec_ok = true;
+        }
+      } else if (last_new >= 0 && ntext > 0 && B.warm) {      // "warm" (uniform condition; every lane loads, unconditionally: a load inside a divergent
                                              // block is waited for where the block ends)
         const uint32_t code = s_code[s_textch[t < ntext ? t : 0]];
         warm = P::touch(ix, code, top_l);

@@ -23,7 +23,14 @@ struct TailItem {
   int64_t row;        // first == last
 };
 
-struct PackPolicy {
+// nfa_search_kernel's "spec" (regexp_search.hip): a policy whose search step is ONE load per range end may split it into the
+// loads (issued as soon as the next entry's range is known) and the arithmetic (done when that entry is popped)
+struct NoSpec {
+  static constexpr bool kNfaSpec = false;
+  struct Spec {};
+  static __device__ __forceinline__ void spec_load(const DevIndex&, uint32_t, int64_t, int64_t, Spec&) {}
+};
+struct PackPolicy : NoSpec {
   static constexpr bool kSpotMarks = false;   // search steps do not report marked rows (RumPolicy does)
   static __device__ __forceinline__ int64_t marked_offset(const DevIndex& ix, int64_t row) { return pack_marked_offset(ix, row); }
   // one word of the memory line search_step(code, .. row) will read: issued early by a caller that knows the row ahead of time
@@ -71,7 +78,7 @@ struct PackPolicy {
 #define FEMTO_AMD_EXP_RU_WAVES 8       // (experiments: tools/ab_bench.sh builds a second library with another value)
 #endif
 struct RuPolicy : PackPolicy {
-  static constexpr int kNfaWaves = 5;  // (96 VGPRs, no scratch: a spill reload would sit in the chain of dependent steps that IS this kernel's time)
+  static constexpr int kNfaWaves = 4;  // (no scratch: a spill reload would sit in the chain of dependent steps that IS this kernel's time, and the batch ends with its longest search: occupancy buys little)
   static constexpr int kDirectWaves = FEMTO_AMD_EXP_RU_WAVES;   // 43-64 VGPRs: eight waves per SIMD without spilling
   static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
     ru_search_step(ix, j, code, f, l);
@@ -83,11 +90,38 @@ struct RuPolicy : PackPolicy {
     ru_split(row, &u, &r);
     return reinterpret_cast<const uint32_t*>(ix.ru)[(uint64_t(tc) * uint64_t(ix.ru_stride) + u) * 4];
   }
+  static constexpr bool kNfaSpec = true;
+  struct Spec { uint4 vL, vF; };
+  // the two units search_step(code, [f, l]) reads, loaded unconditionally (a stop character: any valid units, never used)
+  static __device__ __forceinline__ void spec_load(const DevIndex& ix, uint32_t code, int64_t f, int64_t l, Spec& sp) {
+    const uint32_t tc = code < uint32_t(ix.ru_nstop) ? 0u : code - uint32_t(ix.ru_nstop);
+    const uint4* const up = reinterpret_cast<const uint4*>(ix.ru) + uint64_t(tc) * uint64_t(ix.ru_stride);
+    uint64_t uL, uF;
+    uint32_t r;
+    ru_split(l, &uL, &r);
+    ru_split(f > 0 ? f - 1 : 0, &uF, &r);
+    sp.vL = up[uL];
+    sp.vF = up[uF];
+  }
+  // ... and the step itself from them (j > 0)
+  static __device__ __forceinline__ void spec_step(const DevIndex& ix, uint32_t code, int64_t& f, int64_t& l, const Spec& sp) {
+    if (code < uint32_t(ix.ru_nstop)) {
+      ru_stop_step(ix, code, f, l);
+      return;
+    }
+    uint64_t u;
+    uint32_t rL, rF = 0;
+    ru_split(l, &u, &rL);
+    if (f > 0) ru_split(f - 1, &u, &rF);
+    const int64_t nl = ru_rank_of(sp.vL, rL);
+    f = f > 0 ? ru_rank_of(sp.vF, rF) : ix.pack_c[code];
+    l = nl - 1;
+  }
 };
 
 // ... with the MARKED rank units (handles without the suffix array): a one-row step also says whether its row is marked
 struct RumPolicy : PackPolicy {
-  static constexpr int kNfaWaves = 5;
+  static constexpr int kNfaWaves = 4;
   static constexpr int kDirectWaves = FEMTO_AMD_EXP_RU_WAVES;
   static constexpr bool kSpotMarks = true;
   static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
@@ -101,11 +135,28 @@ struct RumPolicy : PackPolicy {
     const uint32_t tc = code < uint32_t(ix.ru_nstop) ? 0u : code - uint32_t(ix.ru_nstop);
     return reinterpret_cast<const uint32_t*>(ix.ru)[(uint64_t(tc) * uint64_t(ix.ru_stride) + (uint64_t(row) >> 6)) * 4];
   }
+  static constexpr bool kNfaSpec = true;
+  struct Spec { uint4 vL, vF; };
+  static __device__ __forceinline__ void spec_load(const DevIndex& ix, uint32_t code, int64_t f, int64_t l, Spec& sp) {
+    const uint32_t tc = code < uint32_t(ix.ru_nstop) ? 0u : code - uint32_t(ix.ru_nstop);
+    const uint4* const up = reinterpret_cast<const uint4*>(ix.ru) + uint64_t(tc) * uint64_t(ix.ru_stride);
+    sp.vL = up[uint64_t(l) >> 6];
+    sp.vF = up[uint64_t(f > 0 ? f - 1 : 0) >> 6];
+  }
+  static __device__ __forceinline__ void spec_step(const DevIndex& ix, uint32_t code, int64_t& f, int64_t& l, const Spec& sp) {
+    if (code < uint32_t(ix.ru_nstop)) {
+      ru_stop_step(ix, code, f, l);
+      return;
+    }
+    const int64_t nl = rum_rank_of(sp.vL, uint32_t(l) & 63u);
+    f = f > 0 ? rum_rank_of(sp.vF, uint32_t(f - 1) & 63u) : ix.pack_c[code];
+    l = nl - 1;
+  }
 };
 
-struct Pack2Policy {
+struct Pack2Policy : NoSpec {
   static __device__ __forceinline__ uint32_t touch(const DevIndex&, uint32_t, int64_t) { return 0; }     // (two dependent lines: not worth a guess)
-  static constexpr int kNfaWaves = 4;
+  static constexpr int kNfaWaves = 3;
   static constexpr bool kSpotMarks = false;
   static __device__ __forceinline__ int64_t marked_offset(const DevIndex&, int64_t) { return -1; }
   static constexpr int kWaves = 8;
@@ -134,7 +185,7 @@ struct Pack2Policy {
 // byte alphabets with the per-character rank lines resident (ind_kernels.hip.hpp): search steps read one line per range
 // end; everything that does not know its character in advance (LF steps) stays on the two-level lines
 struct IndPolicy : Pack2Policy {
-  static constexpr int kNfaWaves = 5;
+  static constexpr int kNfaWaves = 4;
   static __device__ __forceinline__ uint32_t touch(const DevIndex& ix, uint32_t code, int64_t row) {
     uint64_t line;
     uint32_t b;

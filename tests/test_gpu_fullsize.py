@@ -276,6 +276,17 @@ def test_full_size_8gib_properties(tmp_path, gpu_ok):
     assert np.array_equal(n1, noccs[:m]) and np.array_equal(o1, offs[:int(noccs[:m].sum())])
     ix.close()
     del text
+    # the library's DEFAULT open at this size (a budget of 8 x text: no suffix array, 8-byte mark offsets, the marked rank units,
+    # femto's segment lines released): the device chain with mark spotting returns the same rows and offsets beyond 2^32
+    bx = femto_amd.Index(path, device=0)
+    st, pi = bx.structures(), bx.pack_info()
+    assert st["hbm_budget_is_default"] == 1 and st["hbm_allocated"] <= st["hbm_budget"] and not pi["sa_full"] and pi["rank_units_marked"], (st, pi)
+    assert st["mark_offset_bytes"] == 8, st
+    df, dl, dn, dst, do, dtot = device_locate(bx, plen, flat, starts, 100, len(offs) + 16)
+    assert dtot == len(offs) and np.array_equal(df, first) and np.array_equal(dl, last) and np.array_equal(dn, noccs) and np.array_equal(do, offs)
+    bn, bo = bx.locate_flat(plen[:m], flat, starts[:m], 100)
+    assert np.array_equal(bn, noccs[:m]) and np.array_equal(bo, offs[:int(noccs[:m].sum())])
+    bx.close()
     # range-split in two parts (both on this GPU): part p keeps blocks [65p/2, 65(p+1)/2) and reads the rest from its peer
     parts = [femto_amd.Index(path, device=0, part=p, nparts=2) for p in range(2)]
     for a in parts:
