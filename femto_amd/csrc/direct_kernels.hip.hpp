@@ -536,12 +536,13 @@ template <class P, bool kPlan>
 inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kWaves, P::kWaves))) void count_keys_kernel(
     const DevIndex ix, const int64_t npats, const uint64_t* __restrict__ keys, const int bits, const int nsym,
     int2* __restrict__ out32, int64_t* __restrict__ first_out, int64_t* __restrict__ last_out, const int max_occs,
-    int32_t* __restrict__ noccs, const PlanSums ps, int* __restrict__ big_flag) {
+    int32_t* __restrict__ noccs, const PlanSums ps, int* __restrict__ big_flag, int64_t* __restrict__ sa_out /* or NULL: "MARK SPOTTING" as in count_direct_kernel */) {
   __shared__ int64_t s_w[4];
   const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   int64_t nocc = 0;
   if (q < npats) {
     const uint64_t key = keys[q];
+    int64_t spot = -1;
     const uint32_t fmask = (1u << bits) - 1u;
     auto field = [&](int j) -> uint32_t { return uint32_t(key >> (64 - bits * (j + 1))) & fmask; };
     int64_t first = 0, last = ix.total_length - 1;
@@ -561,13 +562,23 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
       ktab2_lookup<P>(ix, pos, j, first, last);
       if (first > last) ended = true;
     }
+    int len = j;      // (symbols of the key: counted on as the steps run)
     if (!ended)
       for (; j < nsym; j++) {
         const uint32_t f = field(j);
         if (f == 0) break;
-        P::search_step(ix, j, f - 1, first, last);
+        if constexpr (P::kSpotMarks && kPlan) {
+          bool spotted;
+          const int64_t row = last;
+          P::search_step_spot(ix, j, f - 1, first, last, &spotted);
+          if (P::is_stop(ix, f - 1)) spot = -1;
+          else if (spotted) spot = row | (int64_t(j) << 40);      // (symbols DONE before this step; turned into symbols to go below)
+        } else {
+          P::search_step(ix, j, f - 1, first, last);
+        }
         if (first > last) break;
       }
+    len = j;
     if (out32) {
       out32[q] = make_int2(int(first), int(last));
     } else {
@@ -579,6 +590,11 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
       else if (last - first > int64_t(max_occs)) nocc = max_occs;      // server.c:4411 (">": see Appendix C of SURVEY.md)
       else nocc = last - first + 1;
       noccs[q] = int32_t(nocc);
+      if (P::kSpotMarks && sa_out) {      // a marked row the search stood on with (len - done) symbols to go: plan_rows_kernel starts there
+        int64_t hint = -1;
+        if (first == last && spot >= 0) hint = -2 - ((spot & ((int64_t(1) << 40) - 1)) | (int64_t(len - int(spot >> 40)) << 40));
+        if (__ballot(nocc == 1)) sa_out[q] = hint;
+      }
     }
   }
   if (kPlan) {

@@ -571,12 +571,20 @@ int launch_count_keys(femto_amd_index* ix, int64_t n, const uint64_t* d_keys, in
   }
   const int mo = plan ? plan->max_occs : 0;
   int32_t* noccs = plan ? plan->noccs : nullptr;
+  // a handle that walks to marks and whose rank units carry the mark bits: the search hands plan_rows_kernel a marked row it
+  // stood on (launch_count_direct's "spot")
+  int64_t* sa_out = nullptr;
+  if (plan && S && ix->mode == 3 && ix->dev.ru && ix->dev.ru_marks && ix->dev.pack && ix->dev.pack_sa && !ix->dev.sa_full) {
+    if ((rc = S->noccs64.reserve(size_t(n + 1) * 8))) return rc;
+    sa_out = S->noccs64.as<int64_t>();
+    plan->sa_known = sa_out;
+  }
   hipEvent_t e0, e1;
   timer_begin(ix, ix->t_count, stream, &e0, &e1);
 #define LAUNCH_KEYS(POLICY)                                                                                                                                  \
   do {                                                                                                                                                       \
-    if (plan) hipLaunchKernelGGL((count_keys_kernel<POLICY, true>), grid, block, 0, stream, ix->dev, n, d_keys, bits, nsym, out32, d_first, d_last, mo, noccs, ps, big_flag); \
-    else hipLaunchKernelGGL((count_keys_kernel<POLICY, false>), grid, block, 0, stream, ix->dev, n, d_keys, bits, nsym, out32, d_first, d_last, mo, noccs, ps, big_flag);     \
+    if (plan) hipLaunchKernelGGL((count_keys_kernel<POLICY, true>), grid, block, 0, stream, ix->dev, n, d_keys, bits, nsym, out32, d_first, d_last, mo, noccs, ps, big_flag, sa_out); \
+    else hipLaunchKernelGGL((count_keys_kernel<POLICY, false>), grid, block, 0, stream, ix->dev, n, d_keys, bits, nsym, out32, d_first, d_last, mo, noccs, ps, big_flag, sa_out);     \
   } while (0)
   if (ix->mode == 3 && ix->dev.ru && ix->dev.ru_marks) LAUNCH_KEYS(RumPolicy);
   else if (ix->mode == 3 && ix->dev.ru) LAUNCH_KEYS(RuPolicy);
@@ -1067,7 +1075,7 @@ int femto_amd_locate_keys_device(femto_amd_index_t* ix, int64_t npats, const uin
   }
   Plan plan{max_occs_each, d_noccs, d_out_starts, offsets_capacity, false, d_total};
   if ((rc = launch_count_keys(ix, npats, d_keys, r32, d_first, d_last, stream, &S, &plan))) return rc;
-  if ((rc = launch_plan_rows(ix, S, npats, d_noccs, d_first, d_out_starts, d_offsets, offsets_capacity, stream, r32, /*fuse_walk=*/true))) return rc;
+  if ((rc = launch_plan_rows(ix, S, npats, d_noccs, d_first, d_out_starts, d_offsets, offsets_capacity, stream, r32, /*fuse_walk=*/true, plan.sa_known))) return rc;
   return FEMTO_AMD_OK;
   API_END
 }

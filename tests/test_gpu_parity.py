@@ -337,7 +337,14 @@ def test_keys_device_path_equals_symbol_path(fixtures, gpu_ok, name):
     import torch
     fx = fixtures(name)
     g = fx.gold
-    ix = femto_amd.Index(fx.index, device=0)
+    # ... on the default handle and on handles that walk to marks (no suffix array: on small alphabets the marked rank units hand
+    # plan_rows_kernel a marked row the key search stood on, as count_direct_kernel does)
+    for kw in (None, dict(dense_arrays=0, text=0, level_table_syms=2), dict(text=0, mark_every=3, level_table=0)):
+        _keys_device_path(fx, g, femto_amd.Index(fx.index, device=0, options=kw) if kw else femto_amd.Index(fx.index, device=0))
+
+
+def _keys_device_path(fx, g, ix):
+    import torch
     bits, max_syms, table = ix.key_format()
     assert 63 // bits == max_syms and table.max() < (1 << bits)
     plen, flat, starts = fx.patterns
