@@ -341,22 +341,52 @@ int derived_mark_every(const femto_amd_index* ix) {
   return every;
 }
 
-// Will build_text keep the suffix array of every row, with `free_b` bytes to spend?  (Its rules, evaluated ahead of time:
-// build_pack chooses between the plain rank units and the marked ones with it -- marks only matter to handles that walk.)
-bool sa_will_be_resident(const femto_amd_index* ix, size_t free_b) {
-  if (knob(ix->opt.text, "FEMTO_AMD_TEXT", 1) == 0 || knob(ix->opt.dense_arrays, "FEMTO_AMD_DENSE", 1) == 0) return false;
+// What build_text will keep with `free_b` bytes to spend: the text always; the inverse suffix array of every position
+// (*isa_shift = 0) or of every 8th; the suffix array of every row (*want_sa).  False: nothing (no text tail).
+//   * no budget: the dense pair when it takes at most 55 % of the free HBM (the level table, built next, takes at most a quarter
+//     of what is left): 17 GB of 288 at 1 GiB of text, 137 GB at 8 GiB (BASELINE configs[4]: a located row is then one read instead
+//     of up to four LF steps); failing that the suffix array alone when it fits 30 %, the ISA sampled.
+//   * a handle with a budget: the richest of {dense pair, suffix array + sampled ISA, sampled ISA} that fits its SHARE of what is
+//     free -- a fifth on small alphabets (the level table and the rank units, which every pattern uses, are the better buy there),
+//     three quarters on byte alphabets, where nothing else competes under a budget: the level table is 0.7 GB, the per-character
+//     rank lines and the context tables do not fit, and without the text every one of a pattern's ~36 symbols is a search step of
+//     two dependent lines (profiles/r05_budget_sweep_eng.txt).  (Until round 5 the suffix-array variant was chosen first and the
+//     whole text dropped when it missed the share: a 32 x budget held less than a 16 x one.)
+bool plan_text(const femto_amd_index* ix, size_t free_b, bool small_alphabet, int* isa_shift, bool* want_sa) {
+  *isa_shift = kIsaShift;
+  *want_sa = false;
+  if (knob(ix->opt.text, "FEMTO_AMD_TEXT", 1) == 0) return false;
+  const bool dense = knob(ix->opt.dense_arrays, "FEMTO_AMD_DENSE", 1) != 0;
   const int64_t n = ix->host.total_length;
-  int isa_shift = kIsaShift;
-  bool want_sa = false;
-  if (double(n + 2) * 16.0 <= 0.55 * double(free_b)) {
-    isa_shift = 0;
-    want_sa = true;
-  } else if (double(n) * 8.0 <= 0.30 * double(free_b)) {
-    want_sa = true;
+  const size_t tb = size_t(n) + 64, ib8 = (size_t(n >> kIsaShift) + 2) * 8, ib1 = (size_t(n) + 2) * 8, sb = size_t(n) * 8 + 64;
+  if (ix->opt.hbm_budget_bytes < 0) {
+    if (dense && double(n + 2) * 16.0 <= 0.55 * double(free_b)) {
+      *isa_shift = 0;
+      *want_sa = true;
+    } else if (dense && double(n) * 8.0 <= 0.30 * double(free_b)) {
+      *want_sa = true;
+    }
+    return true;
   }
-  const size_t tb = size_t(n) + 64, ib = (size_t(n >> isa_shift) + 2) * 8, sb = want_sa ? size_t(n) * 8 + 64 : 0;
-  if (ix->opt.hbm_budget_bytes >= 0 && tb + ib + sb > free_b / 5) return false;
-  return want_sa;
+  const size_t share = small_alphabet ? free_b / 5 : free_b / 4 * 3;
+  if (dense && tb + ib1 + sb <= share) {
+    *isa_shift = 0;
+    *want_sa = true;
+    return true;
+  }
+  if (dense && tb + ib8 + sb <= share) {
+    *want_sa = true;
+    return true;
+  }
+  return tb + ib8 <= share;
+}
+
+// Will build_text keep the suffix array of every row?  (build_pack chooses between the plain rank units and the marked ones
+// with it -- marks only matter to handles that walk.)
+bool sa_will_be_resident(const femto_amd_index* ix, size_t free_b) {
+  int isa_shift;
+  bool want_sa;
+  return plan_text(ix, free_b, true, &isa_shift, &want_sa) && want_sa;
 }
 
 // Derives the packed lines of pack_kernels.hip.hpp on the GPU from the uploaded index (needs the lane tables).
@@ -713,27 +743,12 @@ int build_pack2(femto_amd_index* ix) {
 // 8-byte read instead of a walk of LF steps, the row of a text position one read instead of up to 7 LF steps.  This is
 // femto's own space/time knob -- mark_period (src/main/index.c:122-142) -- turned to 1 in HBM; the files stay as they are.
 int build_text(femto_amd_index* ix) {
-  if (knob(ix->opt.text, "FEMTO_AMD_TEXT", 1) == 0) return 0;
   const int64_t n = ix->host.total_length;
-  const bool dense = knob(ix->opt.dense_arrays, "FEMTO_AMD_DENSE", 1) != 0;
   const size_t free_b = hbm_free(ix);
-  // (sa_will_be_resident above repeats the rules below for build_pack's choice of rank units)
-  // Dense arrays -- SA of every row and ISA of every position, 8 B each per row -- when the pair takes at most 55 % of
-  // the free HBM (the level table, built next, takes at most a quarter of what is left): 17 GB of 288 at 1 GiB of text,
-  // 137 GB at 8 GiB (BASELINE configs[4]: a located row is then one read instead of up to four LF steps).  Failing that
-  // the suffix array alone when it fits 30 %; the ISA is then sampled.
   int isa_shift = kIsaShift;
   bool want_sa = false;
-  if (dense && double(n + 2) * 16.0 <= 0.55 * double(free_b)) {
-    isa_shift = 0;
-    want_sa = true;
-  } else if (dense && double(n) * 8.0 <= 0.30 * double(free_b)) {
-    want_sa = true;
-  }
+  if (!plan_text(ix, free_b, ix->dev.pack != nullptr, &isa_shift, &want_sa)) return 0;
   const size_t tb = size_t(n) + 64, ib = (size_t(n >> isa_shift) + 2) * 8, sb = want_sa ? size_t(n) * 8 + 64 : 0;
-  // a handle with an HBM budget: the text + sampled inverse suffix array (the tail of LONG patterns) only from what the
-  // structures every pattern uses -- lines, rank units, level table -- would leave: at most a fifth of what is free
-  if (ix->opt.hbm_budget_bytes >= 0 && tb + ib + sb > free_b / 5) return 0;
   if (big_malloc(ix, reinterpret_cast<void**>(&ix->d_txt), tb) != hipSuccess || big_malloc(ix, reinterpret_cast<void**>(&ix->d_isa8), ib) != hipSuccess ||
       (sb && big_malloc(ix, reinterpret_cast<void**>(&ix->d_sa_full), sb) != hipSuccess)) {
     (void)hipGetLastError();
