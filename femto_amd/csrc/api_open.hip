@@ -575,15 +575,31 @@ int build_pack2(femto_amd_index* ix) {
   std::vector<int64_t> pc(512, 0);
   int sigma = 0;
   uint32_t stop_below = 0;
-  for (int ch = 0; ch < kAlphaSize; ch++)
-    if (h.C[size_t(ch) + 1] > h.C[size_t(ch)]) {
-      if (sigma == 256) return 0;  // more than 256 distinct characters: the wavelet path stays
+  {
+    // dense codes: the characters <= SEOF first, then -- on a byte alphabet (no packed lines: their codes are the sort digits and
+    // the keys' fields, and those follow the two-level lines' codes below) -- the others by FALLING frequency, so that the
+    // most frequent ones get a level-1 class of their own (pack2_kernels.hip.hpp: p2_hl); ascending where the packed lines exist
+    std::vector<int> chars;
+    for (int ch = 0; ch < kAlphaSize; ch++)
+      if (h.C[size_t(ch) + 1] > h.C[size_t(ch)]) chars.push_back(ch);
+    if (chars.size() > 256) return 0;  // more than 256 distinct characters: the wavelet path stays
+    if (!ix->dev.pack && knob(-1, "FEMTO_AMD_P2_BY_FREQUENCY", 1) != 0)
+      std::stable_sort(chars.begin(), chars.end(), [&](int a, int b) {
+        const bool sa = a <= kSEOF, sb = b <= kSEOF;
+        if (sa != sb) return sa;
+        if (sa) return a < b;
+        const int64_t ca = h.C[size_t(a) + 1] - h.C[size_t(a)], cb = h.C[size_t(b) + 1] - h.C[size_t(b)];
+        return ca != cb ? ca > cb : a < b;
+      });
+    for (int ch : chars) {
       alpha[size_t(sigma)] = uint16_t(ch);
       pc[size_t(sigma)] = h.C[size_t(ch)];
       pc[256 + size_t(sigma)] = h.C[size_t(ch) + 1] - 1;
       if (ch <= kSEOF) stop_below = uint32_t(sigma) + 1;
       code[size_t(ch)] = uint16_t(sigma++);
     }
+  }
+  const uint32_t singles = knob(-1, "FEMTO_AMD_P2_SINGLES", 1) != 0 ? p2_singles_for(uint32_t(sigma), stop_below) : 0u;
   EventPair ev;
   hipEvent_t &e0 = ev.e0, &e1 = ev.e1;
   HIP_TRY(hipEventCreate(&e0));
@@ -600,6 +616,7 @@ int build_pack2(femto_amd_index* ix) {
   d.p2_c = ix->d_p2_c;
   d.p2_sigma = sigma;
   d.p2_stop_below = stop_below;
+  d.p2_single = singles;
   const int64_t n = h.total_length;
   const int64_t nl1 = (n + kP2Rows1 - 1) / kP2Rows1, stride1 = nl1 + 1;
   DeviceBuffer sym, counts, scans, lo2;
@@ -615,11 +632,12 @@ int build_pack2(femto_amd_index* ix) {
       hipLaunchKernelGGL(p2_extract_kernel, dim3(uint32_t((cn + 255) / 256)), dim3(256), 0, nullptr, ix->dev, r0, cn, sym.as<uint16_t>());
     }
     hipLaunchKernelGGL(p2_l1_planes_kernel, dim3(uint32_t((nl1 + 255) / 256)), dim3(256), 0, nullptr, nl1, n, sym.as<uint16_t>(), ix->d_p2_l1,
-                       counts.as<int64_t>(), stride1);
+                       counts.as<int64_t>(), stride1, singles, stop_below);
     HIP_TRY(hipGetLastError());
     for (int c = 0; c < 17; c++)
       if ((rc = device_scan(ix->open_scan, nl1, counts.as<int64_t>() + c * stride1, scans.as<int64_t>() + c * stride1, 0, nullptr))) return rc;
-    hipLaunchKernelGGL(p2_l1_counts_kernel, dim3(uint32_t((nl1 + 255) / 256)), dim3(256), 0, nullptr, nl1, ix->d_p2_l1, scans.as<int64_t>(), stride1);
+    hipLaunchKernelGGL(p2_l1_counts_kernel, dim3(uint32_t((nl1 + 255) / 256)), dim3(256), 0, nullptr, nl1, ix->d_p2_l1, scans.as<int64_t>(), stride1,
+                       static_cast<const int64_t*>(ix->d_p2_c), singles, stop_below);
     HIP_TRY(hipGetLastError());
     d.p2_l1 = ix->d_p2_l1;
     // level 2: every h starts on a line boundary
@@ -628,7 +646,7 @@ int build_pack2(femto_amd_index* ix) {
     int64_t nl2 = 0;
     for (int k = 0; k < 16; k++) {
       base[size_t(k)] = nl2;
-      nl2 += (tot[size_t(k)] + kP2Rows2 - 1) / kP2Rows2;
+      if (uint32_t(k) >= singles) nl2 += (tot[size_t(k)] + kP2Rows2 - 1) / kP2Rows2;      // (a class of its own has no level 2)
     }
     if (nl2 == 0) nl2 = 1;
     if ((rc = upload(&ix->d_p2_base, base, &ix->table_bytes))) return rc;
@@ -716,6 +734,14 @@ int build_pack2(femto_amd_index* ix) {
     HIP_TRY(hipDeviceSynchronize());
     ix->p2_lines1 = nl1;
     ix->p2_lines2 = nl2;
+    if (!ix->dev.pack && ix->d_dense) {      // the sort digits / key fields of a byte alphabet ARE these codes + 1 (count_keys_kernel steps with field - 1)
+      std::vector<uint8_t> dense(512, 0);
+      for (int ch = 0; ch < kAlphaSize; ch++)
+        if (code[size_t(ch)] != 0xffff) dense[size_t(ch)] = uint8_t(code[size_t(ch)] < 255 ? code[size_t(ch)] + 1 : 0);
+      HIP_TRY(hipMemcpy(ix->d_dense, dense.data(), dense.size(), hipMemcpyHostToDevice));
+      if (sigma <= 255) ix->h_dense = dense;
+      ix->h_dense16.clear();
+    }
     if (sa_bytes) ix->n_marks = nmarks;
     ix->table_bytes += (nl1 + nl2) * 128 + sa_bytes;
     return 0;

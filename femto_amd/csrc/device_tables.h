@@ -161,6 +161,7 @@ struct DevIndex {           // passed by value to kernels
   const uint16_t* p2_alpha; // [256] dense code -> alpha code
   int32_t p2_sigma;
   uint32_t p2_stop_below;   // dense codes below this are <= SEOF (a locate walk stops there)
+  uint32_t p2_single;       // S: the dense codes p2_stop_below .. p2_stop_below + S - 1 have a level-1 class of their own (pack2_kernels.hip.hpp: p2_hl)
   // long-pattern tail (text_kernels.hip.hpp); null when not derived
   const uint8_t* txt;       // dense character code of every text position
   const int64_t* isa8;      // row of the suffix at every (1 << isa_shift)-th text position

@@ -714,7 +714,7 @@ __device__ __forceinline__ int64_t walk_row(const DevIndex& ix, int64_t row) {
 // footprint-bounded handle: 1.116 -> ... ms, profiles/r04_*).  kMode 0: the rows (two-call API; femto_amd_locate_walk_device walks them).
 constexpr int kRowsOnly = 0, kRowsSa = 1, kRowsWalk = 2;
 template <int kMode, class P>
-inline __global__ __launch_bounds__(256) void plan_rows_kernel(const int64_t npats, const int32_t* __restrict__ noccs, const int64_t* __restrict__ first,
+inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kPlanWaves, 8))) void plan_rows_kernel(const int64_t npats, const int32_t* __restrict__ noccs, const int64_t* __restrict__ first,
                                                         const int2* __restrict__ first32 /* or NULL: (first,last) pairs instead of first[] */,
                                                         const PlanSums ps, int64_t* __restrict__ out_starts,
                                                         int64_t* __restrict__ offsets, const int64_t capacity, int* __restrict__ big_flag,

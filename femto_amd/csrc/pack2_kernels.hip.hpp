@@ -16,6 +16,13 @@
 //     dword 12..27  low 32 bits of  C[ch(16h+k)] + #earlier positions of this h whose l == k   k = 0..15
 //     dword 28..31  bits 32..39 of those
 //
+// Round 5, a FREQUENCY-SHAPED first level: the split is not c = 16 h + l for every code.  The S codes behind the stop characters
+// -- the text's most frequent characters: open assigns the dense codes of a byte alphabet by falling frequency -- get a level-1
+// class of their own (h = code - nstop, no level 2 at all: C[c] + the class's rank IS C + Occ), the others share the remaining
+// 16 - S classes sixteen to a class (p2_hl).  S is the largest number for which all characters still fit: 10 for 96 characters,
+// 0 for 256 (then this is the plain 16 x 16 split).  On an English-like text three quarters of all search steps and LF steps are
+// then ONE memory line instead of two dependent ones, and level 2 shrinks to the rare characters' share (3.4 -> 2.5 GB at 1 GiB).
+//
 // Occ(c,row): rank of h among rows <= row from ONE level-1 line, then the l-count from ONE level-2 line -- two
 // memory lines instead of ~4.5 wavelet levels of one or two lines each plus Elias-gamma decoding; an LF step of
 // locate (character of the row, its Occ, the mark test) is the same two lines.  Derived at open on the GPU from the
@@ -26,6 +33,30 @@ namespace femto_amd {
 
 constexpr int kP2Rows1 = 64;
 constexpr int kP2Rows2 = 96;
+
+// dense code -> (level-1 class, digit inside it); S = DevIndex::p2_single, nstop = p2_stop_below
+__host__ __device__ inline void p2_hl(uint32_t code, uint32_t S, uint32_t nstop, uint32_t* h, uint32_t* l) {
+  if (code - nstop < S) {      // (unsigned: false for code < nstop)
+    *h = code - nstop;
+    *l = 0;
+    return;
+  }
+  const uint32_t q = code < nstop ? code : code - S;
+  *h = S + (q >> 4);
+  *l = q & 15u;
+}
+__host__ __device__ inline uint32_t p2_code_of_hl(uint32_t h, uint32_t l, uint32_t S, uint32_t nstop) {
+  if (h < S) return nstop + h;
+  const uint32_t q = ((h - S) << 4) | l;
+  return q < nstop ? q : q + S;
+}
+// the largest S with S + ceil((sigma - S) / 16) <= 16 and S <= table characters
+__host__ __device__ inline uint32_t p2_singles_for(uint32_t sigma, uint32_t nstop) {
+  uint32_t best = 0;
+  for (uint32_t S = 0; S <= 15 && S + nstop <= sigma; S++)
+    if (S + (sigma - S + 15) / 16 <= 16) best = S;
+  return best;
+}
 
 __device__ __forceinline__ uint64_t p2_below_incl(uint32_t r) {  // bits 0..r
   return r >= 63u ? ~0ull : ((1ull << (r + 1)) - 1ull);
@@ -78,8 +109,10 @@ __device__ __forceinline__ void p2_split2(int64_t p, uint64_t* line_in_h, uint32
 
 // C[ch] + Occ(code, row) (row included), row >= 0
 __device__ __forceinline__ int64_t p2_c_plus_occ(const DevIndex& ix, uint32_t code, int64_t row) {
-  const uint32_t h = code >> 4, l = code & 15u;
+  uint32_t h, l;
+  p2_hl(code, ix.p2_single, ix.p2_stop_below, &h, &l);
   const int64_t rank = p2_rank_h(ix.p2_l1, uint64_t(row) >> 6, uint32_t(row) & 63u, h);
+  if (h < ix.p2_single) return rank;      // a class of its own: its level-1 counts start at C[ch], level 1 is the whole answer
   if (rank == 0) return ix.p2_c[code];
   uint64_t lh;
   uint32_t r2;
@@ -100,7 +133,8 @@ __device__ __forceinline__ void p2_search_step(const DevIndex& ix, int j, uint32
     last = ix.p2_c[256 + code];
     return;
   }
-  const uint32_t h = code >> 4, l = code & 15u;
+  uint32_t h, l;
+  p2_hl(code, ix.p2_single, ix.p2_stop_below, &h, &l);
   const uint32_t* __restrict__ l1 = ix.p2_l1;
   const uint32_t* __restrict__ l2 = ix.p2_l2;
   const int64_t base = ix.p2_base[h];
@@ -127,6 +161,11 @@ __device__ __forceinline__ void p2_search_step(const DevIndex& ix, int j, uint32
   }
   trace_touch(ix, kTraceL1, l1L);
   const int64_t c0 = ix.p2_c[code];
+  if (h < ix.p2_single) {      // a class of its own: the level-1 ranks are C + Occ
+    first = haveF ? rkF : c0;
+    last = rkL - 1;
+    return;
+  }
   int64_t nl = c0, nf = c0;
   uint64_t lineL = 0, lineF = 0;
   uint32_t rL = 0, rF = 0;
@@ -201,6 +240,12 @@ __device__ __forceinline__ P2Step p2_step(const DevIndex& ix, int64_t row) {
   const uint64_t eq = (p0 ^ ((h & 1u) ? 0ull : ~0ull)) & (p1 ^ ((h & 2u) ? 0ull : ~0ull)) & (p2 ^ ((h & 4u) ? 0ull : ~0ull)) &
                       (p3 ^ ((h & 8u) ? 0ull : ~0ull));
   const int64_t rank = int64_t((uint64_t(hb) << 32) | lo) + int64_t(__popcll(eq & p2_below_incl(r)));  // >= 1: the row itself
+  if (h < ix.p2_single) {      // a class of its own: no level 2
+    trace_touch(ix, kTraceL1, line1);
+    s.code = ix.p2_stop_below + h;
+    s.c_plus_occ = rank;      // (its counts start at C[ch])
+    return s;
+  }
   uint64_t lh;
   uint32_t r2;
   p2_split2(rank - 1, &lh, &r2);
@@ -222,7 +267,7 @@ __device__ __forceinline__ P2Step p2_step(const DevIndex& ix, int64_t row) {
     x0 |= v[k] & hot; x1 |= v[3 + k] & hot; x2 |= v[6 + k] & hot; x3 |= v[9 + k] & hot;
   }
   const uint32_t l = (x0 ? 1u : 0u) | (x1 ? 2u : 0u) | (x2 ? 4u : 0u) | (x3 ? 8u : 0u);
-  s.code = (h << 4) | l;
+  s.code = p2_code_of_hl(h, l, ix.p2_single, ix.p2_stop_below);
   P2Planes2 P;
 #pragma unroll
   for (int k = 0; k < 12; k++) P.w[k] = v[k];
@@ -292,7 +337,8 @@ inline __global__ __launch_bounds__(256) void p2_extract_kernel(const DevIndex i
 
 // phase B1: level-1 planes of one line (64 rows) + its 16 h-counts and mark count (SoA counts[k*stride + line], k=16: marks)
 inline __global__ __launch_bounds__(256) void p2_l1_planes_kernel(const int64_t nlines, const int64_t nrows, const uint16_t* __restrict__ sym,
-                                                           uint32_t* __restrict__ l1, int64_t* __restrict__ counts, const int64_t stride) {
+                                                           uint32_t* __restrict__ l1, int64_t* __restrict__ counts, const int64_t stride,
+                                                           const uint32_t singles, const uint32_t nstop) {
   const int64_t line = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (line >= nlines) return;
   uint64_t pl[5] = {0, 0, 0, 0, 0};
@@ -303,7 +349,8 @@ inline __global__ __launch_bounds__(256) void p2_l1_planes_kernel(const int64_t 
   for (int i = 0; i < kP2Rows1; i++) {
     if (r0 + i >= nrows) break;
     const uint32_t s = sym[r0 + i];
-    const uint32_t h = (s >> 4) & 15u;
+    uint32_t h, l;
+    p2_hl(s & 0x7fffu, singles, nstop, &h, &l);
     pl[0] |= uint64_t(h & 1u) << i;
     pl[1] |= uint64_t((h >> 1) & 1u) << i;
     pl[2] |= uint64_t((h >> 2) & 1u) << i;
@@ -330,15 +377,17 @@ inline __global__ __launch_bounds__(256) void p2_l1_planes_kernel(const int64_t 
 }
 
 // phase B3: counts before every line -> dwords 10..31
+// (a class of its own stores C[ch] + the rows before the line: its level-1 rank IS C + Occ, as a level-2 count is for the others)
 inline __global__ __launch_bounds__(256) void p2_l1_counts_kernel(const int64_t nlines, uint32_t* __restrict__ l1, const int64_t* __restrict__ scans,
-                                                           const int64_t stride) {
+                                                           const int64_t stride, const int64_t* __restrict__ p2_c, const uint32_t singles,
+                                                           const uint32_t nstop) {
   const int64_t line = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (line >= nlines) return;
   uint32_t* lp = l1 + line * 32;
   uint32_t hi[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    const uint64_t v = uint64_t(scans[int64_t(k) * stride + line]);
+    const uint64_t v = uint64_t(scans[int64_t(k) * stride + line] + (uint32_t(k) < singles ? p2_c[nstop + uint32_t(k)] : 0));
     lp[10 + k] = uint32_t(v);
     hi[k >> 2] |= (uint32_t(v >> 32) & 0xffu) << (8 * (k & 3));
   }
@@ -355,9 +404,11 @@ inline __global__ __launch_bounds__(256) void p2_scatter_kernel(const DevIndex i
   const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (row >= row0 + n) return;
   const uint32_t s = sym[row];
-  const uint32_t h = (s >> 4) & 15u;
+  uint32_t h, l;
+  p2_hl(s & 0x7fffu, ix.p2_single, ix.p2_stop_below, &h, &l);
+  if (h < ix.p2_single) return;      // (a class of its own has no level 2)
   const int64_t rank = p2_rank_h(ix.p2_l1, uint64_t(row) >> 6, uint32_t(row) & 63u, h);
-  lo2[ix.p2_base[h] * kP2Rows2 + rank - 1] = uint8_t(s & 15u);
+  lo2[ix.p2_base[h] * kP2Rows2 + rank - 1] = uint8_t(l);
 }
 
 // phase D1: level-2 planes of one line (96 positions) + its 16 l-counts
@@ -420,7 +471,7 @@ inline __global__ __launch_bounds__(256) void p2_l2_counts_kernel(const DevIndex
   uint32_t hi[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    const uint32_t code = uint32_t(h) * 16u + uint32_t(k);
+    const uint32_t code = p2_code_of_hl(uint32_t(h), uint32_t(k), ix.p2_single, ix.p2_stop_below);
     int64_t v = scans[int64_t(k) * stride + line] - scans[int64_t(k) * stride + first_line];
     if (int(code) < ix.p2_sigma) v += ix.p2_c[code];
     lp[12 + k] = uint32_t(uint64_t(v));

@@ -42,6 +42,7 @@ struct PackPolicy : NoSpec {
     return ix.pack[line * kPackLineWords];
   }
   static constexpr int kWaves = 8;     // waves per SIMD the count kernel is built for (64 VGPRs)
+  static constexpr int kPlanWaves = 7; // ... plan_rows_kernel at least (the walk inside it: 66 VGPRs)
   static constexpr int kNfaWaves = 4;  // ... nfa_search_kernel (regexp_search.hip): what it reaches without scratch
   static constexpr int kDirectWaves = 7;   // ... count_direct_kernel: 72 VGPRs (at 64 it spills 20 bytes per lane)
   static constexpr int kTailRows = 1;  // ranges of up to this many rows take the text tail (direct_kernels.hip.hpp)
@@ -157,6 +158,7 @@ struct RumPolicy : PackPolicy {
 struct Pack2Policy : NoSpec {
   static __device__ __forceinline__ uint32_t touch(const DevIndex&, uint32_t, int64_t) { return 0; }     // (two dependent lines: not worth a guess)
   static constexpr int kNfaWaves = 3;
+  static constexpr int kPlanWaves = 6; // (the walk's LF step on the two-level lines: 79 VGPRs without scratch; left alone the compiler takes 82 and five waves)
   static constexpr bool kSpotMarks = false;
   static __device__ __forceinline__ int64_t marked_offset(const DevIndex&, int64_t) { return -1; }
   static constexpr int kWaves = 8;
