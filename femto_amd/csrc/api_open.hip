@@ -161,7 +161,9 @@ int build_ctx(femto_amd_index* ix, int nstop) {
   if (const int64_t hs = knob(ix->opt.context_syms, "FEMTO_AMD_CTX_SYMS", -1); hs >= 0) hmax = hmin = std::max(1, std::min(hmax, int(hs)));
   if (hmin > hmax) return 0;
   const size_t free_b = hbm_free(ix);
-  const int64_t budget = int64_t(free_b / 4);
+  // (a handle with a budget: half of what is left -- by now the lines, the text and the arrays are in place and only the wide
+  // table, which needs an order of magnitude more, comes after this one)
+  const int64_t budget = int64_t(free_b / (ix->opt.hbm_budget_bytes >= 0 ? 2 : 4));
   DeviceBuffer cnt;
   int rc = cnt.reserve(8);
   if (rc) return rc;
