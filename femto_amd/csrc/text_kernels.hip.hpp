@@ -162,7 +162,7 @@ struct Pack2Policy : NoSpec {
   static constexpr bool kSpotMarks = false;
   static __device__ __forceinline__ int64_t marked_offset(const DevIndex&, int64_t) { return -1; }
   static constexpr int kWaves = 8;
-  static constexpr int kDirectWaves = 8;
+  static constexpr int kDirectWaves = 7;   // (72 VGPRs: at 64 the search step's second exit -- a character with a level-1 class of its own -- spills 20 bytes)
   static constexpr int kTailRows = 4;  // repeated phrases of a byte text: a few rows with tens of symbols to go
   static __device__ __forceinline__ void search_step(const DevIndex& ix, int j, uint32_t code, int64_t& f, int64_t& l) {
     p2_search_step(ix, j, code, f, l);
@@ -187,6 +187,7 @@ struct Pack2Policy : NoSpec {
 // byte alphabets with the per-character rank lines resident (ind_kernels.hip.hpp): search steps read one line per range
 // end; everything that does not know its character in advance (LF steps) stays on the two-level lines
 struct IndPolicy : Pack2Policy {
+  static constexpr int kDirectWaves = 8;
   static constexpr int kNfaWaves = 4;
   static __device__ __forceinline__ uint32_t touch(const DevIndex& ix, uint32_t code, int64_t row) {
     uint64_t line;
