@@ -346,8 +346,9 @@ int femto_amd_multi_child(femto_amd_index_t* ix, int i, femto_amd_index_t** chil
 
 /* ---- patterns as keys (device pointers) ---------------------------------------------------------------------------------
  * A pattern of at most max_syms symbols whose characters all occur in the text fits ONE 64-bit word: `bits`-bit fields, the
- * pattern's LAST symbol in the top field, field = field_of_alpha[alpha code] (1 + the character's rank among the text's
- * characters), 0 = end of pattern.  femto_amd_key_format reports bits / max_syms (3 bits, 21 symbols for DNA; 7 bits, 9
+ * pattern's LAST symbol in the top field, field = field_of_alpha[alpha code] (1 + the character's dense code: its rank among the
+ * text's characters -- by character value on small alphabets, by falling frequency behind the characters <= SEOF on byte
+ * alphabets: take the table, do not derive it), 0 = end of pattern.  femto_amd_key_format reports bits / max_syms (3 bits, 21 symbols for DNA; 7 bits, 9
  * symbols for a 96-character text) and the field table; femto_amd_pack_keys_device packs a (plen, pats, starts) batch that
  * is already in HBM (*d_bad = patterns no key describes: they get key 0 = the empty pattern; such a batch belongs to the
  * symbol entry points).  femto_amd_locate_keys_device is femto_amd_count_device / femto_amd_locate_device on keys: the
