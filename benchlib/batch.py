@@ -36,6 +36,7 @@ class Batch:
         self.d_total = torch.zeros(2, dtype=torch.int64, device=dev)
         self.total, self.max_total = 0, 0
         self.torch, self.dev = torch, dev
+        self.row_free = False     # True: the steps use the row-free form of femto_amd_locate_device (no row arrays: parallel_locate's own results)
 
     def add_inputs(self, plen, flat):
         """one more input set of the same size: the timed steps rotate through DISTINCT batches, so that no step finds the
@@ -56,7 +57,7 @@ class Batch:
         if self.offsets is None:
             self.offsets = self.torch.empty(max(1 << 20, self.n // 4), dtype=self.torch.int64, device=self.dev)
         ix.locate_device(self.n, self.d_plen.data_ptr(), self.d_flat.data_ptr(), self.d_starts.data_ptr(), max_occs,
-                         self.d_res[0].data_ptr(), self.d_res[1].data_ptr(), self.d_noccs.data_ptr(),
+                         0 if self.row_free else self.d_res[0].data_ptr(), 0 if self.row_free else self.d_res[1].data_ptr(), self.d_noccs.data_ptr(),
                          self.d_ostarts.data_ptr(), self.offsets.data_ptr(), self.offsets.numel(), self.d_total.data_ptr(), stream)
 
     def settle(self, ix, max_occs, stream):
@@ -142,6 +143,25 @@ class Batch:
         cnt[pairs[:, 0]] = pairs[:, 1]
         off = raw[o_off:o_cnt].view(np.int32 if esz == 4 else np.int64)[:min(tot, cap)].astype(np.int64)
         return tot, cnt, off
+
+
+def row_free_steps(torch, ix, b, max_occs, stream, steps, warm=2):
+    """the same batch through the ROW-FREE form of the chain (femto_amd_locate_device without row arrays -- what parallel_locate
+    returns, src/main/femto.c:331-400), its noccs / out_starts / offsets checked against the form with rows (run first by the
+    caller: b holds its results).  Returns a dict for an `extra` block."""
+    import numpy as np
+    want = (b.d_noccs.cpu().numpy(), b.d_ostarts.cpu().numpy(), b.offsets[:b.total].cpu().numpy(), b.total)
+    b.row_free = True
+    try:
+        el, (c_ms, _), (l_ms, _) = timed_steps(torch, ix, b, max_occs, stream, steps, warm)
+        same = bool(b.total == want[3] and np.array_equal(b.d_noccs.cpu().numpy(), want[0]) and np.array_equal(b.d_ostarts.cpu().numpy(), want[1])
+                    and np.array_equal(b.offsets[:b.total].cpu().numpy(), want[2]))
+    finally:
+        b.row_free = False
+    assert same, "row-free locate: noccs / out_starts / offsets differ from the form with rows"
+    return {"what": "femto_amd_locate_device with d_first = d_last = NULL: noccs + offsets as parallel_locate returns them (femto.c:331-400), no rows",
+            "value": b.n * steps / el, "unit": "patterns/s", "ms_per_step": 1e3 * el / steps, "count_kernel_ms": c_ms, "locate_kernel_ms": l_ms,
+            "equal_to_form_with_rows": same}
 
 
 def timed_steps(torch, ix, b, max_occs, stream, steps, warm=2):

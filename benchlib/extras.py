@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-from .batch import Batch, timed_steps
+from .batch import Batch, row_free_steps, timed_steps
 from .common import HBM_PEAK_GBS, cpu_quota, log
 from .roofline import add_traffic, pmc_traffic, reference_format_block, roofline_block
 
@@ -174,10 +174,26 @@ def shim_locate_sampled_extra(args, index_path, plen, flat, located_rows):
 def p_hit_extra(c, ix, hb):
     """every pattern occurs and is located (same index, P_hit 20-mers)"""
     args, torch, stream = c.args, c.torch, c.stream
-    el, (c_ms, _), (l_ms, _) = timed_steps(torch, ix, hb, args.max_occs, stream, 3)
-    return {"workload": f"{hb.n} 20-mers sampled from the text, count()+locate(max_occs={args.max_occs})",
-            "value": hb.n * 3 / el, "unit": "patterns/s", "ms_per_step": 1e3 * el / 3,
-            "located_rows": hb.total, "count_kernel_ms": c_ms, "locate_kernel_ms": l_ms}
+    steps = max(3, min(args.steps, 50))
+    el, (c_ms, c_n), (l_ms, _) = timed_steps(torch, ix, hb, args.max_occs, stream, steps)
+    out = {"workload": f"{hb.n} 20-mers sampled from the text, count()+locate(max_occs={args.max_occs})",
+           "value": hb.n * steps / el, "unit": "patterns/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
+           "located_rows": hb.total, "count_kernel_ms": c_ms, "locate_kernel_ms": l_ms}
+    try:
+        roof, _, _, _, _ = roofline_block(ix, True, hb, hb.n, hb.plen, args.max_occs, c_ms, l_ms, c_n)
+        out["roofline"] = {k: roof[k] for k in ("achieved", "frac", "kernel", "kernel_ms", "compulsory_bytes_per_launch", "line_reads")}
+    except Exception as ex:      # noqa: BLE001
+        out["roofline"] = {"error": repr(ex)}
+    out["row_free"] = row_free_steps(torch, ix, hb, args.max_occs, stream, steps)
+    try:
+        ix.set_option("trace_row_free", 1)
+        rr, _, _, _, _ = roofline_block(ix, True, hb, hb.n, hb.plen, args.max_occs, out["row_free"]["count_kernel_ms"], out["row_free"]["locate_kernel_ms"], c_n)
+        out["row_free"]["roofline"] = {k: rr[k] for k in ("achieved", "frac", "kernel", "kernel_ms", "compulsory_bytes_per_launch", "line_reads")}
+    except Exception as ex:      # noqa: BLE001
+        out["row_free"]["roofline"] = {"error": repr(ex)}
+    finally:
+        ix.set_option("trace_row_free", 0)
+    return out
 
 
 def keys_extra(c, ix, batch, ref_results):
@@ -421,9 +437,44 @@ def cfg3_extra(c, world):
         e_roof, e_kname, e_kms, e_comp, _ = roofline_block(eix, eix.rank_mode in (3, 4), eb, npats, ep, args.max_occs, e_cnt, e_loc, e_n)
         e_info = eix.pack_info()
         out["structures"] = eix.structures()
+        # ---- the same batch through the row-free form (what parallel_locate returns: noccs + offsets), results compared
+        try:
+            eb.step(eix, args.max_occs, stream)
+            torch.cuda.synchronize()
+            eb.total = int(eb.d_total[0].item())
+            rf = row_free_steps(torch, eix, eb, args.max_occs, stream, 3)
+            eix.set_option("trace_row_free", 1)
+            try:
+                rr, _, _, rcomp, _ = roofline_block(eix, eix.rank_mode in (3, 4), eb, npats, ep, args.max_occs, rf["count_kernel_ms"], rf["locate_kernel_ms"], e_n)
+            finally:
+                eix.set_option("trace_row_free", 0)
+            rf["roofline"] = {k: rr[k] for k in ("achieved", "frac", "kernel", "kernel_ms", "compulsory_bytes_per_launch", "line_reads")}
+            out["row_free"] = rf
+        except AssertionError:
+            raise
+        except Exception as ex:      # noqa: BLE001
+            out["row_free"] = {"error": repr(ex)}
+        eix.close()
+        eix = None
+        # ---- the same index as a drop-in opens it (plain femto_amd_open: the library's default bound), with rows and row-free
+        try:
+            dix = femto_amd.Index(e_path, device=local_rank)
+            try:
+                de, (d_cnt, _), (d_loc, _) = timed_steps(torch, dix, eb, args.max_occs, stream, 3)
+                d = {"what": "the same index and batch on a handle opened with plain femto_amd_open (the default bound)", "value": npats * 3 / de, "unit": "patterns/s",
+                     "ms_per_step": 1e3 * de / 3, "count_kernel_ms": d_cnt, "locate_kernel_ms": d_loc, "structures": dix.structures(), "index": dix.pack_info()}
+                d["row_free"] = row_free_steps(torch, dix, eb, args.max_occs, stream, 3)
+                out["default_open"] = d
+            finally:
+                dix.close()
+        except AssertionError:
+            raise
+        except Exception as ex:      # noqa: BLE001
+            out["default_open"] = {"error": repr(ex)}
         del eb
     finally:
-        eix.close()
+        if eix is not None:
+            eix.close()
     if args.pmc != "off" and world == 1:
         try:
             import argparse

@@ -207,6 +207,8 @@ def lib():
         L.femto_amd_regexp_free.argtypes = [vp]
         L.femto_amd_regexp_free.restype = None
         L.femto_amd_nfa_search_batch.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]
+        L.femto_amd_nfa_stats.argtypes = [vp, vp]
+        L.femto_amd_key_table_id.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.femto_amd_set_option.argtypes = [vp, C.c_char_p, i32]
         L.femto_amd_block_requests.argtypes = [vp, i64, vp, vp, vp, vp, vp]
         L.femto_amd_kernel_time_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]
@@ -432,12 +434,14 @@ class Index:
         _check(lib().femto_amd_document_info(self._h, int(doc), C.cast(C.byref(pv), C.POINTER(C.c_char_p)), C.byref(n)))
         return C.string_at(pv.value, n.value) if n.value else b""
 
-    def block_requests(self, rows, ch_in=None):
+    def block_requests(self, rows, ch_in=None, location=True):
+        """block_request CHAR / OCCS / LOCATION per row: (L[row], occs in block, mark offset or -1); location=False asks for CHAR and
+        OCCS only (off comes back None) -- in modes 3 / 4 such a call reads the derived lines alone"""
         rows = np.ascontiguousarray(rows, dtype=np.int64)
         n = len(rows)
         ch = np.zeros(n, dtype=np.uint16)
         occ = np.zeros(n, dtype=np.int32)
-        off = np.zeros(n, dtype=np.int64)
+        off = np.zeros(n, dtype=np.int64) if location else None
         chin = np.ascontiguousarray(ch_in, dtype=np.uint16) if ch_in is not None else None
         _check(lib().femto_amd_block_requests(self._h, n, _ptr(rows), _ptr(chin), _ptr(ch), _ptr(occ), _ptr(off)))
         return ch, occ, off
@@ -538,6 +542,12 @@ class Index:
         _check(lib().femto_amd_key_format(self._h, C.byref(bits), C.byref(syms), _ptr(table)))
         return bits.value, syms.value, table
 
+    def key_table_id(self):
+        """identity of the key fields (femto_amd_key_table_id): keys built for one id are meaningless to a handle reporting another"""
+        v = C.c_uint64(0)
+        _check(lib().femto_amd_key_table_id(self._h, C.byref(v)))
+        return v.value
+
     def pack_keys_device(self, npats, d_plen, d_pats, d_starts, d_keys, d_bad, stream=0):
         _check(lib().femto_amd_pack_keys_device(self._h, int(npats), d_plen, d_pats, d_starts, d_keys, d_bad, stream or None))
 
@@ -592,6 +602,13 @@ class Index:
         if approx is None:
             return first[:n.value], last[:n.value], mlen[:n.value]
         return first[:n.value], last[:n.value], mlen[:n.value], cost[:n.value]
+
+    def nfa_stats(self, thread=False):
+        """the last automaton batch (thread=True: of the calling thread): pops, span, workgroup occupancy (femto_amd_nfa_stats)"""
+        out = (C.c_double * 8)()
+        _check(lib().femto_amd_nfa_stats(None if thread else self._h, out))
+        keys = ("automata", "workgroups", "pops", "pops_longest", "busy_cycles", "span_cycles", "occupancy", "longest_waited_cycles")
+        return dict(zip(keys, [float(v) for v in out]))
 
     def set_option(self, name, value):
         """'sort' (suffix-order batches of the wavelet-path kernels), 'regexp_max_iterations', 'regexp_stack_cap'"""

@@ -125,6 +125,10 @@ struct Scratch {
   DeviceBuffer plen, pats, starts, first, last, noccs, noccs64, out_starts, offsets, scan[3];
   DeviceBuffer rows, ch, occ, off;
   DeviceBuffer keys, keys2, idx, idx2, sorttmp, pairs, tail, bsums;
+  // automaton batches (regexp_search.hip): the flattened automata, the workgroups' arenas, the raw results -- kept with the scratch,
+  // so that a caller issuing batch after batch (or several callers at once, one scratch each) allocates and frees nothing per call
+  // (hipFree waits for the whole device: a caller's return would wait for every other caller's search kernel)
+  DeviceBuffer nfa_q, nfa_flags, nfa_sd, nfa_ch, nfa_bychar, nfa_arena, nfa_results, nfa_misc, nfa_order;
   int* d_flags = nullptr;       // [0] error flag, [1] "long ranges" flag of the row expansion, [2] tail item count, [3] see err
   int* err = nullptr;           // where kernels raise "symbol >= ALPHA_SIZE": d_flags (host-pointer calls check and clear it) or,
                                 // for enqueue-only calls, d_flags + 3 (nobody reads it: such a pattern just has the empty range)
@@ -155,7 +159,8 @@ struct Scratch {
   }
   void release() {
     for (DeviceBuffer* b : {&plen, &pats, &starts, &first, &last, &noccs, &noccs64, &out_starts, &offsets, &scan[0], &scan[1], &scan[2],
-                            &rows, &ch, &occ, &off, &keys, &keys2, &idx, &idx2, &sorttmp, &pairs, &tail, &bsums})
+                            &rows, &ch, &occ, &off, &keys, &keys2, &idx, &idx2, &sorttmp, &pairs, &tail, &bsums,
+                            &nfa_q, &nfa_flags, &nfa_sd, &nfa_ch, &nfa_bychar, &nfa_arena, &nfa_results, &nfa_misc, &nfa_order})
       b->release();
     for (int b = 0; b < kPipeDepth; b++) {
       if (pipe.h_in[b]) (void)hipHostFree(pipe.h_in[b]);
@@ -192,6 +197,9 @@ struct femto_amd_index {
   int64_t hbm_free_at_open = -1; // free HBM when this handle started allocating
   bool budget_is_default = false; // opt.hbm_budget_bytes was left on auto: the default bound is in force
   bool segs_released = false;    // d_segs was dropped after the derivations (release_wavelet_lines); the host copy is the source
+  bool segs_drop_ok = false;     // this handle's open released them (a handle with a budget): calls that bring them back give them up
+                                 // again when they leave the handle over its budget (WaveletLinesUse)
+  int segs_users = 0;            // calls in flight that read them (under mu)
   int64_t hbm_held = 0;          // bytes of the handle's PERSISTENT device allocations (big arrays + uploaded tables): what
                                  // hbm_budget_bytes is counted against -- the scratch of the derivations at open comes and goes
   std::vector<std::pair<void*, size_t>> big_allocs;   // big_malloc()ed arrays and their sizes
@@ -266,12 +274,14 @@ struct femto_amd_index {
   int dense_bits = 8;
   double dense_sigma = 256;    // distinct characters of the indexed text
   int64_t sort_min = 4096;
+  bool trace_row_free = false;   // femto_amd_trace_lines follows the row-free form of the chain (option "trace_row_free")
   int64_t regexp_max_iterations = 1000000;   // MAX_REGEXP_ITERATIONS (src/main/server.c:40); option "regexp_max_iterations"
   int64_t regexp_stack_cap = int64_t(1) << 18; // pending ranges one search may hold (option "regexp_stack_cap", <= 2^22); the reference
                                                // has no bound: it runs on to ERR_OVERWORKED
   bool timing = false;
   KernelTimer t_count, t_locate, t_resolve, t_regexp;
   int64_t* d_doc_ends = nullptr;   // the header block's doc_ends[] on the device (resolve.hip; uploaded on first use)
+  double nfa_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // the last automaton batch (femto_amd_nfa_stats)
   double pipe_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the last staged host-pointer call (femto_amd_host_pipeline_stats)
   // range-split index (femto_amd_open_split): this handle holds the segment lines and the block images of
   // data blocks [split_blo[part], split_blo[part+1]); the other parts' slices are mapped from their owners
@@ -352,6 +362,20 @@ size_t hbm_free(const femto_amd_index* ix);
 void ensure_workers(femto_amd_index* ix);         // creates ix->workers (api_host.hip) if it does not exist yet
 int release_wavelet_lines(femto_amd_index* ix);   // a handle with a budget drops femto's segment lines once the derived layouts stand ...
 int ensure_wavelet_lines(femto_amd_index* ix);    // ... and calls that need them (modes 0/1, forward steps) bring them back (caller holds ix->mu or is the only user)
+int64_t hbm_held_all(const femto_amd_index* ix);  // big arrays + uploaded small tables: what hbm_budget_bytes is counted against
+// A call that reads femto's own segment lines on a handle in modes 3 / 4 (LOCATION leaf requests, forward steps): brings them back
+// under ix->mu for the duration of the call and -- when the upload left a bounded handle OVER its budget ("bytes this handle may
+// HOLD in all", include/femto_amd.h) -- gives them up again once the last such call has ended.  Handles whose rank mode is 0 / 1
+// keep them (their kernels read nothing else); femto_amd_set_rank_mode drops them on the way back to modes 3 / 4 by the same rule.
+struct WaveletLinesUse {
+  femto_amd_index* ix;
+  bool held = false;
+  explicit WaveletLinesUse(femto_amd_index* i) : ix(i) {}
+  int acquire();
+  ~WaveletLinesUse();
+  WaveletLinesUse(const WaveletLinesUse&) = delete;
+  WaveletLinesUse& operator=(const WaveletLinesUse&) = delete;
+};
 hipError_t big_malloc(femto_amd_index* ix, void** out, size_t bytes);
 void big_free(femto_amd_index* ix, void* p);
 hipError_t big_memset(femto_amd_index* ix, void* p, int v, size_t bytes);
@@ -374,6 +398,7 @@ struct Plan {
   bool done;
   int64_t* total_user = nullptr;   // device, 2 words: the caller's copy of S.d_total, written by plan_rows_kernel itself
   const int64_t* sa_known = nullptr;   // set by the count: text positions of one-row patterns it already knows (count_direct_kernel's sa_out)
+  bool row_free = false;               // the caller takes no rows (parallel_locate's contract): DevIndex::row_free for this launch
 };
 // modes 3 / 4: the caller-order pipeline of direct_kernels.hip.hpp (with or without a level table)
 inline bool use_direct(const femto_amd_index* ix) { return ix->mode == 3 || ix->mode == 4; }

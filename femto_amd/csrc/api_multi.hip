@@ -216,7 +216,11 @@ struct SharedFacts {       // what make_view copies from the builder, as plain d
   uint64_t d_dense;
   uint64_t dev_bytes, n_dense, n_ranges, n_small, n_fds;
 };
-constexpr uint64_t kSharedMagic = 0x66656d746f534852ull;    // "femtoSHR"
+// ("femtoSHR" + the version of the derived layouts a description describes: a client of another build -- other dense codes, other
+// line formats behind the same DevIndex size -- is refused instead of searching with the wrong tables.  Bump with every change of
+// a derived layout or of the key fields; round 6: 2 -- frequency-ordered dense codes of byte alphabets, one-row level-table entries)
+constexpr uint64_t kDerivedLayoutVersion = 2;
+constexpr uint64_t kSharedMagic = 0x66656d746f534852ull + kDerivedLayoutVersion;
 
 void put(std::string& b, const void* p, size_t n) { b.append(static_cast<const char*>(p), n); }
 template <class T> void put(std::string& b, const T& v) { put(b, &v, sizeof v); }

@@ -6,7 +6,10 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <climits>
+#include <cstdio>
+#include <strings.h>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -112,6 +115,9 @@ int build_ktab2(femto_amd_index* ix, int sigma, int nstop) {
   d.kt2_nstop = nstop;
   d.kt2_deep_big = 0xffffff;
   if (const char* e = getenv("FEMTO_AMD_KTAB_DEEP_BIG")) d.kt2_deep_big = std::max(1, std::min(0xffffff, atoi(e)));    // test hook
+  // one-row entries with their text position (direct_kernels.hip.hpp): the suffix array is at hand and rows / positions fit 31 bits
+  d.kt2_sa1 = (d.sa_full && d.txt && d.isa8 && d.isa_shift == 0 && ix->host.total_length <= (int64_t(1) << 31) && knob(-1, "FEMTO_AMD_KTAB_SA1", 1) != 0) ? 1 : 0;
+  if (d.kt2_sa1) d.kt2_deep_big = std::min(d.kt2_deep_big, 0x800000);
   d.ktab2 = ix->d_ktab2;
   d.kt2_deep = reinterpret_cast<const uint64_t*>(ix->d_ktab2_deep);
   d.kt2_deep_off = upper;
@@ -140,6 +146,7 @@ int build_ktab2(femto_amd_index* ix, int sigma, int nstop) {
   ix->dev.kt2_base = int32_t(t);
   ix->dev.kt2_nstop = nstop;
   ix->dev.kt2_deep_big = d.kt2_deep_big;
+  ix->dev.kt2_sa1 = d.kt2_sa1;
   ix->ktab2_bytes = upper * 16 + compact * 8;
   ix->table_bytes += ix->ktab2_bytes;
   return 0;
@@ -318,6 +325,35 @@ int build_ctx_wide(femto_amd_index* ix, int nstop, bool mid) {
     return 0;
   }
   return 0;
+}
+
+// FEMTO_AMD_HBM_BUDGET: bytes, with an optional k / M / G / T suffix (powers of 1024), or "all" (any case).  Anything else --
+// a typo, a negative number, trailing junk -- is NOT a budget: -1, the default bound, with a line on stderr (atoll() read "8G"
+// as 8 bytes and "ALL" as 0, and every optional structure was then silently declined).
+int64_t parse_budget_env(const char* e) {
+  while (*e == ' ') e++;
+  if (!strcasecmp(e, "all")) return FEMTO_AMD_BUDGET_ALL;
+  char* end = nullptr;
+  errno = 0;
+  const long long v = strtoll(e, &end, 10);
+  int shift = 0;
+  if (end && end != e) {
+    switch (*end) {
+      case 'k': case 'K': shift = 10; end++; break;
+      case 'm': case 'M': shift = 20; end++; break;
+      case 'g': case 'G': shift = 30; end++; break;
+      case 't': case 'T': shift = 40; end++; break;
+      default: break;
+    }
+    if (shift && (*end == 'i' || *end == 'I')) end++;      // "8G", "8GB", "8GiB"
+    if (shift && (*end == 'b' || *end == 'B')) end++;
+    while (*end == ' ') end++;
+  }
+  if (!end || end == e || *end != '\0' || errno || v < 0 || (shift && v > (LLONG_MAX >> shift))) {
+    fprintf(stderr, "[femto_amd] FEMTO_AMD_HBM_BUDGET=\"%s\" is not a byte count (digits with an optional k/M/G/T suffix, or \"all\"): the default bound applies\n", e);
+    return -1;
+  }
+  return int64_t(v) << shift;
 }
 
 // distance between marks in the derived lines (see "denser marks" in pack_kernels.hip.hpp); 0: keep femto's own.
@@ -859,15 +895,19 @@ int femto_amd::open_impl(const char* index_path, int device, int part, int npart
         // the benchmark's setting.  From here on `hbm_budget_bytes >= 0` means "bounded", -1 "unbounded".
         int64_t b = ix->opt.hbm_budget_bytes;
         if (b == -1)
-          if (const char* e = getenv("FEMTO_AMD_HBM_BUDGET")) b = !strcmp(e, "all") ? FEMTO_AMD_BUDGET_ALL : atoll(e);
+          if (const char* e = getenv("FEMTO_AMD_HBM_BUDGET")) b = parse_budget_env(e);
         if (b == -1) {
           const int64_t by_text = std::max<int64_t>(8 * ix->host.total_length, int64_t(2) << 30);
-          b = std::min<int64_t>(int64_t(free_b / 4), by_text);
+          // (a device that cannot say what is free: the text's share alone bounds the handle)
+          b = free_b ? std::min<int64_t>(int64_t(free_b / 4), by_text) : by_text;
           ix->budget_is_default = true;
         } else if (b <= FEMTO_AMD_BUDGET_ALL) {
           b = -1;
         }
         ix->opt.hbm_budget_bytes = b;
+        if (getenv("FEMTO_AMD_VERBOSE"))
+          fprintf(stderr, "[femto_amd] %s: HBM budget %s%lld bytes (%lld free on device %d)\n", index_path, ix->budget_is_default ? "(default bound) " : "",
+                  (long long)b, (long long)free_b, device);
       }
       HostIndex& h = ix->host;
       int r;

@@ -145,7 +145,8 @@ struct DevIndex {           // passed by value to kernels
   const uint64_t* kt2_deep; // the levels from kt2_cfrom on, compact: first (40 bits) | rows in the range (24 bits; 0xffffff: see ktab2_lookup)
   int64_t kt2_deep_off;     // heap position of level kt2_cfrom's first entry (= number of 16-byte entries of the levels above)
   int32_t kt2_cfrom;        // first compact level (K - 1, or K when K == 1)
-  int32_t kt2_pad;
+  int32_t kt2_sa1;          // 1: a ONE-ROW entry of the compact levels also carries SA[first] (bit 63 | SA << 31 | first: indexes of at most
+                            // 2^31 rows whose suffix array is resident when the table is built; direct_kernels.hip.hpp)
   uint32_t* trace;          // NULL, or the line bitmaps of femto_amd_trace_lines: bit trace_off[region] + line index
   unsigned long long* trace_reads;   // NULL, or [kTraceRegions] counters: every traced line READ (not only the distinct ones)
   int64_t trace_off[kTraceRegions];   // first bit of every traced region (kTrace* above)
@@ -184,7 +185,8 @@ struct DevIndex {           // passed by value to kernels
   int32_t ctxm_pad;
   const int64_t* sa_full;   // SA[row] of EVERY row when HBM allows (8 B/row), else NULL: locate is then one read, no walk
   int32_t isa_shift;        // 0: full inverse suffix array (8 B/row), 3: every 8th position
-  int32_t dense_pad;
+  int32_t row_free;        // 1: this launch is a locate that returns no rows (parallel_locate's contract, src/main/femto.c:331-400): a one-row range
+                            // whose text tail consumes the pattern is located by the compare itself -- no inverse-suffix-array read, no (first, last)
   void* tail_items;         // TailItem work list of the current count launch
   int* tail_count;
   int32_t tail_min;         // hand a one-row range over when at least this many symbols remain

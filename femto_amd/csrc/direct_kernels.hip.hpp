@@ -61,12 +61,22 @@ inline __global__ void ktab2_root_kernel(const DevIndex ix, longlong2* __restric
 // runs on every fixture.)  Heap positions of consecutive levels are adjacent, so the compact array is indexed by
 // pos - kt2_deep_off across both levels.  (Round 3 kept only the deepest level compact: 16 instead of 8 bytes for a quarter
 // as many entries again -- 0.13 GB of a K = 13 table, 8.6 GB of the K = 16 one.)
+//
+// ONE-ROW entries with their position (DevIndex::kt2_sa1; round 6).  An entry that holds one row spends 24 bits on the number 1.
+// On an index of at most 2^31 rows whose suffix array is resident when the table is built such an entry is stored as
+// bit 63 | SA[first] << 31 | first instead: a pattern that leaves the table on one row -- four in five of the 20-mers sampled
+// from a 2^30-row DNA text leave a K = 16 table that way -- then knows its row's text position and goes from the table line
+// straight to the text (count_direct_kernel's sa_hint), without the suffix-array read in between; a row-free locate is then two
+// requests per pattern, table and text.  Bit 63 is free for this: the "recompute" bound is capped at 2^23 rows with kt2_sa1
+// (0x800000 .. 0xfffffe never appear as row counts), and 0xffffff itself has bits 40 .. 62 all set, which SA < 2^31 never has.
 constexpr uint64_t kDeepBig = 0xffffffu;
 constexpr uint64_t kDeepFirstMask = (uint64_t(1) << 40) - 1;
+constexpr uint64_t kDeepOneRow = uint64_t(1) << 63;
 
-// the table entry of heap position `pos` at level m: the (first,last) after searching those m symbols
+// the table entry of heap position `pos` at level m: the (first,last) after searching those m symbols; *sa1 = SA[first] where the
+// entry carries it (else untouched)
 template <class P>
-__device__ __forceinline__ void ktab2_lookup(const DevIndex& ix, int64_t pos, int m, int64_t& first, int64_t& last) {
+__device__ __forceinline__ void ktab2_lookup(const DevIndex& ix, int64_t pos, int m, int64_t& first, int64_t& last, int64_t* sa1 = nullptr) {
   const int64_t t = ix.kt2_base;
   uint32_t digit[2];
   int up = 0;               // compact entries that said "recompute": their digits, to be stepped again from the ancestor
@@ -75,6 +85,11 @@ __device__ __forceinline__ void ktab2_lookup(const DevIndex& ix, int64_t pos, in
     const uint64_t e = ix.kt2_deep[i];
     trace_touch(ix, kTraceKtab, uint64_t(ix.kt2_deep_off >> 3) + 1 + (uint64_t(i) >> 4));
     const uint64_t rows = e >> 40;
+    if (ix.kt2_sa1 && (e & kDeepOneRow) && rows != kDeepBig) {
+      first = last = int64_t(e & 0x7fffffffu);
+      if (sa1 && up == 0) *sa1 = int64_t((e >> 31) & 0xffffffffu);
+      break;
+    }
     if (rows != kDeepBig) {
       first = int64_t(e & kDeepFirstMask);
       last = first + int64_t(rows) - 1;
@@ -111,7 +126,12 @@ inline __global__ __launch_bounds__(256) void ktab2_deep_kernel(const DevIndex i
   ktab2_lookup<P>(ix, parent, level - 1, first, last);      // (the parent's level is complete: one launch per level)
   if (first <= last) P::search_step(ix, level - 1, digit + uint32_t(ix.kt2_nstop), first, last);
   const uint64_t rows = first <= last ? uint64_t(last - first + 1) : 0;
-  deep[pos - ix.kt2_deep_off] = (uint64_t(first) & kDeepFirstMask) | ((rows < uint64_t(ix.kt2_deep_big) ? rows : kDeepBig) << 40);
+  uint64_t e = (uint64_t(first) & kDeepFirstMask) | ((rows < uint64_t(ix.kt2_deep_big) ? rows : kDeepBig) << 40);
+  if (ix.kt2_sa1 && rows == 1) {
+    const int64_t p = ix.sa_full[first];
+    if (p >= 0 && p < (int64_t(1) << 31)) e = kDeepOneRow | (uint64_t(p) << 31) | uint64_t(first);      // (-1: a row a damaged index could not locate)
+  }
+  deep[pos - ix.kt2_deep_off] = e;
 }
 
 // sum of `v` over the 256-thread block (all threads must call); valid in thread 0
@@ -304,7 +324,8 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
         if (code == 0xFFu) break;            // not a table character: the ordinary step below deals with it
         pos = pos * t + 1 + int64_t(code - nstop);
       }
-      ktab2_lookup<P>(ix, pos, j, first, last);
+      if (kDense) ktab2_lookup<P>(ix, pos, j, first, last, &sa_hint);
+      else ktab2_lookup<P>(ix, pos, j, first, last);
       if (first > last) j = len;
     }
     bool handed = false;
@@ -314,6 +335,13 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
     // of 5.7 + 2.8 ms handed over, measured on the sigma~96 workload).
     bool tried = false, finished = false;
     int ones = 0;      // consecutive steps that left exactly one row
+    // ROW-FREE locate (ix.row_free: the caller wants parallel_locate's results -- noccs and offsets, src/main/femto.c:331-400 -- and
+    // no rows).  A one-row range whose text tail consumes the pattern is then LOCATED by the compare itself (offset = where the
+    // compared text starts): the inverse-suffix-array read that would turn that position back into a row is skipped; and a tail
+    // that meets a text character other than the pattern's (an ordinary character, not one the step below has to look at) is an
+    // empty range whose (first, last) nobody asked for: no read, no further step.  rf: 1 located, 2 empty.
+    const bool row_free = kPlan && kDense && ix.row_free != 0;
+    int rf = 0;
     // ... unless the wavefront says the batch is made of patterns that occur: when at least three quarters of its patterns
     // still have rows after the table, waiting for two more steps only costs lines (10 M sampled DNA 20-mers: 1.61 ms per step
     // waiting, 1.45 ms jumping at once; random 20-mers leave the table with 22 % alive and keep waiting).
@@ -332,6 +360,9 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
           // jumping at once, 0.65 ms stepping on).
           if (!tried && last - first < int64_t(P::kTailRows) && last - first < int64_t(ix.tail_rows) && j > 0 && ones >= need_ones &&
               len - j >= ix.tail_min + ix.tail_row_cost * int(last - first)) break;
+          // (row-free, one row whose position a table delivered: the compare is ONE request and ends the pattern either way --
+          // never more than the step it replaces, and the row expansion gets the position for nothing)
+          if (row_free && !tried && sa_hint >= 0 && first == last) break;
         } else if (ix.txt && first == last && j > 0 && len - j >= ix.tail_min) {
           tail_append(ix, q, j, first);   // one row left, a long tail to go: count_tail_kernel compares it with the text
           handed = true;
@@ -461,6 +492,20 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
             trace_touch(ix, kTraceTxt, uint64_t(tp - m - ix.txt) >> 7);
             if (uint32_t(tp[-m]) != code) break;
           }
+        if (row_free && first == last) {
+          if (m == remaining) {              // (lim == remaining: the text holds all of them)
+            rf = 1;
+            pbest = p - m;
+            break;
+          }
+          if (m < lim) {                     // stopped at symbol j + m: a mismatch for good unless the step has to look at the symbol itself
+            const uint32_t code = wcode(j + m);
+            if (code != 0xFFu && uint32_t(tp[-m]) != code) {
+              rf = 2;
+              break;
+            }
+          }
+        }
         if (m > 0 && m >= best) {
           const int64_t q2 = ix.isa8[p - m];   // isa_shift == 0: the row of every text position
           trace_touch(ix, kTraceIsa, uint64_t(p - m) >> 4);
@@ -475,6 +520,15 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
         }
       }
       sa_hint = -1;        // (it described the range this tail started from)
+      if (rf == 1) {       // located: first == last stays the row the tail started from (not the pattern's row: nobody reads it)
+        sa_hint = pbest;
+        break;
+      }
+      if (rf == 2) {
+        first = 0;
+        last = -1;
+        break;
+      }
       if (best > 0) {      // the rows whose text goes on with `best` more pattern symbols: one contiguous range again
         first = qmin;
         last = qmax;
@@ -484,7 +538,9 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
       if (j >= len) break;
     }
     if (!handed) {
-      if (last_out) {
+      if (kPlan && ix.row_free) {
+        // (rows are not returned; first_out is the launch layer's own array, and only what plan_rows_kernel will read of it is written)
+      } else if (last_out) {
         first_out[q] = first;
         last_out[q] = last;
       } else {
@@ -495,6 +551,7 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
         else if (last - first > int64_t(max_occs)) nocc = max_occs;
         else nocc = last - first + 1;
         noccs[q] = int32_t(nocc);
+        if (ix.row_free && nocc > 0 && rf != 1) first_out[q] = first;
         // kDense: a search that ended in the text tail (or in the wide context table) on ONE row knows that row's text
         // position already -- it is where the compared text starts.  Handing it to plan_rows_kernel saves that pattern's
         // suffix-array read there: one scattered request less per located pattern.  Written by the wavefronts that hold
@@ -503,13 +560,14 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
           if (__ballot(nocc == 1)) sa_out[q] = first == last ? sa_hint : -1;
         }
         // ... or, without the suffix array, a marked row the search stood on: <= -2 encodes the hint (see "MARK SPOTTING")
-        if (!kDense && P::kSpotMarks && sa_out) {
-          if (__ballot(nocc == 1)) sa_out[q] = (first == last && spot >= 0) ? -2 - spot : -1;
+        // (a row-free launch on the sampled arrays hands count_tail_kernel's positions over the same way: -1 where there is nothing to say)
+        if (!kDense && sa_out) {
+          if (__ballot(nocc == 1)) sa_out[q] = (P::kSpotMarks && first == last && spot >= 0) ? -2 - spot : -1;
         }
       }
     } else if (kPlan) {
       noccs[q] = 0;    // count_tail_kernel stores the real value and adds it to the block's sum
-      if (!kDense && P::kSpotMarks && sa_out) sa_out[q] = -1;
+      if (!kDense && sa_out) sa_out[q] = -1;      // (mark spotting, or a row-free launch: count_tail_kernel may know better)
     }
   }
   if (kPlan) {
@@ -713,6 +771,7 @@ __device__ __forceinline__ int64_t walk_row(const DevIndex& ix, int64_t row) {
 // here: the rows are never written and read back and no walk kernel is launched behind this one (a step of the
 // footprint-bounded handle: 1.116 -> ... ms, profiles/r04_*).  kMode 0: the rows (two-call API; femto_amd_locate_walk_device walks them).
 constexpr int kRowsOnly = 0, kRowsSa = 1, kRowsWalk = 2;
+constexpr int64_t kKnownPos = INT64_MIN;      // kRowsWalk: kKnownPos + position (< -3 x 2^61) in place of a row; spotted rows are -2 - (row | to go << 40) >= -2^62 - 1
 template <int kMode, class P>
 inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::kPlanWaves, 8))) void plan_rows_kernel(const int64_t npats, const int32_t* __restrict__ noccs, const int64_t* __restrict__ first,
                                                         const int2* __restrict__ first32 /* or NULL: (first,last) pairs instead of first[] */,
@@ -778,15 +837,26 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
       if (lane >= d) inc += y;
     }
     s_incl[wave][lane] = inc;
-    int64_t f0 = mine ? (first32 ? int64_t(first32[q].x) : first[q]) : 0;      // (only ranges with rows: most lines of first[] are never touched on a random batch)
+    int64_t f0 = 0;
+    bool have = false;
     if (kMode == kRowsSa && sa_known && mine == 1u) {      // the count kernel may know this row's position: ~position < 0 in place of the row
       const int64_t known = sa_known[q];
-      if (known >= 0) f0 = ~known;
+      if (known >= 0) {
+        f0 = ~known;
+        have = true;
+      }
     }
-    if (kMode == kRowsWalk && sa_known && mine == 1u) {    // ... or a MARKED row its search stood on (<= -2: marked row | symbols to go << 40)
-      const int64_t known = sa_known[q];
-      if (known <= -2) f0 = known;
+    if (kMode == kRowsWalk && sa_known && mine == 1u) {    // ... or a MARKED row its search stood on (<= -2: marked row | symbols to go << 40),
+      const int64_t known = sa_known[q];                  // or the position itself (a row-free launch's text tail): kKnownPos + position
+      if (known <= -2) {
+        f0 = known;
+        have = true;
+      } else if (known >= 0) {
+        f0 = kKnownPos + known;
+        have = true;
+      }
     }
+    if (mine && !have) f0 = first32 ? int64_t(first32[q].x) : first[q];      // (only ranges with rows: most lines of first[] are never touched on a random batch)
     s_first[wave][lane] = f0;
     s_lbase[wave][lane] = base;      // slots are addressed per lane: a long range keeps its slots but is not written here
     const uint32_t total = uint32_t(__shfl(int(inc), 63, 64));
@@ -811,6 +881,8 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
               offsets[slot] = ix.sa_full[row];
               trace_touch(ix, kTraceSa, uint64_t(row) >> 4);
             }
+          } else if (f < -(int64_t(3) << 61)) {      // the position itself (kKnownPos + position)
+            offsets[slot] = f - kKnownPos;
           } else if (f <= -2) {      // spotted during the search: the marked row's offset minus the symbols searched after it
             const int64_t h = -2 - f;
             const int64_t off = P::marked_offset(ix, h & ((int64_t(1) << 40) - 1));

@@ -133,8 +133,7 @@ size_t hbm_free(const femto_amd_index* ix) {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
   if (ix->opt.hbm_budget_bytes >= 0) {
-    int64_t held = ix->hbm_held;
-    for (const auto& t : ix->small_tables) held += int64_t(t.second);
+    const int64_t held = hbm_held_all(ix);
     const int64_t left = ix->opt.hbm_budget_bytes - held;
     if (left <= 0) return 0;
     if (size_t(left) < free_b) free_b = size_t(left);
@@ -263,6 +262,7 @@ int release_wavelet_lines(femto_amd_index* ix) {
   ix->dev.segs = nullptr;
   ix->table_bytes -= int64_t(ix->host.segs.size() * 8);
   ix->segs_released = true;
+  ix->segs_drop_ok = true;
   return 0;
 }
 int ensure_wavelet_lines(femto_amd_index* ix) {
@@ -280,6 +280,27 @@ int ensure_wavelet_lines(femto_amd_index* ix) {
   ix->table_bytes += int64_t(sb);
   ix->segs_released = false;
   return 0;
+}
+
+int64_t hbm_held_all(const femto_amd_index* ix) {
+  int64_t held = ix->hbm_held;
+  for (const auto& t : ix->small_tables) held += int64_t(t.second);
+  return held;
+}
+
+int WaveletLinesUse::acquire() {
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (int rc = ensure_wavelet_lines(ix)) return rc;
+  ix->segs_users++;
+  held = true;
+  return 0;
+}
+WaveletLinesUse::~WaveletLinesUse() {
+  if (!held) return;
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (--ix->segs_users > 0) return;
+  if (ix->segs_drop_ok && ix->mode >= 3 && ix->d_segs && ix->opt.hbm_budget_bytes >= 0 && hbm_held_all(ix) > ix->opt.hbm_budget_bytes)
+    (void)release_wavelet_lines(ix);      // (waits for the device: every kernel that read them has ended)
 }
 
 int ensure_device(femto_amd_index* ix) {
@@ -435,8 +456,11 @@ int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const in
   // ... or, on a handle WITHOUT the suffix array whose rank units carry the rows' mark bits (ru_kernels.hip.hpp), a marked
   // row the search stood on: plan_rows_kernel starts from it instead of walking from the final row ("mark spotting")
   const bool spot = plan && !dense && ix->mode == 3 && d.ru && d.ru_marks && d.pack && d.pack_sa;
+  // ... or, on a row-free launch (Plan::row_free), the position a text tail found the pattern at (count_tail_kernel on handles with
+  // the sampled arrays): plan_rows_kernel then has nothing to walk for that pattern
+  d.row_free = (plan && plan->row_free) ? 1 : 0;
   int64_t* sa_out = nullptr;
-  if (plan && (dense || spot)) {
+  if (plan && (dense || spot || (d.row_free && tail))) {
     if ((rc = S.noccs64.reserve(size_t(npats + 1) * 8))) return rc;
     sa_out = S.noccs64.as<int64_t>();
     plan->sa_known = sa_out;
@@ -456,7 +480,7 @@ int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const in
 #undef LAUNCH_COUNT_DIRECT
   HIP_TRY(hipGetLastError());
   if (tail) {   // persistent grid: the number of handed-over patterns is only known on the device
-    const TailOut out{nullptr, d_first, d_last, noccs, bsums, mo};
+    const TailOut out{nullptr, d_first, d_last, noccs, bsums, mo, sa_out, d.row_free};
     const dim3 tgrid{uint32_t(std::min<int64_t>(nblocks, int64_t(ix->num_cus) * 8))};
     launch_tail(ix, d, tgrid, stream, static_cast<const TailItem*>(S.tail.p), d_plen, d_pats, d_starts, nullptr, nullptr, 1, 0, out, S.err);
     HIP_TRY(hipGetLastError());
@@ -995,7 +1019,9 @@ int femto_amd_locate_device(femto_amd_index_t* ix, int64_t npats, const int32_t*
   if (!ix) return set_err(FEMTO_AMD_ERR_PARAM, "null index");
   if (reinterpret_cast<uintptr_t>(d_pats) & 1u) return set_err(FEMTO_AMD_ERR_PARAM, "d_pats must be 2-byte aligned (uint16 symbols; the kernels read them in aligned 16-byte pieces)");
   if (max_occs_each < 0 || offsets_capacity < 0) return set_err(FEMTO_AMD_ERR_PARAM, "negative max_occs_each / capacity");
-  if (npats && (!d_first || !d_last || !d_noccs || !d_out_starts || !d_total)) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  // d_first == d_last == NULL: the ROW-FREE form -- what parallel_locate itself returns (noccs and offsets, src/main/femto.c:331-400)
+  const bool row_free = !d_first && !d_last;
+  if (npats && ((!row_free && (!d_first || !d_last)) || !d_noccs || !d_out_starts || !d_total)) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
   int rc = ensure_device(ix);
   if (rc) return rc;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -1003,6 +1029,16 @@ int femto_amd_locate_device(femto_amd_index_t* ix, int64_t npats, const int32_t*
   if (!L.s) return L.rc;
   Scratch& S = *L.s;
   Plan plan{max_occs_each, d_noccs, d_out_starts, offsets_capacity, false, d_total};
+  if (row_free && npats) {      // the rows the row expansion still needs live in the call's scratch
+    if ((rc = S.first.reserve(size_t(npats + 1) * 8))) return rc;
+    d_first = S.first.as<int64_t>();
+    if (use_direct(ix)) {
+      plan.row_free = true;
+    } else {                    // femto's own wavelet tree (modes 0 / 1): the search is the same either way
+      if ((rc = S.last.reserve(size_t(npats + 1) * 8))) return rc;
+      d_last = S.last.as<int64_t>();
+    }
+  }
   if ((rc = launch_count_plan(ix, S, npats, d_plen, d_pats, d_starts, d_first, d_last, &plan, stream))) return rc;
   if (plan.done) {   // direct pipeline: one stream-ordered chain, nothing returns to the host (d_total: plan_rows_kernel's last block)
     if ((rc = launch_plan_rows(ix, S, npats, d_noccs, d_first, d_out_starts, d_offsets, offsets_capacity, stream, nullptr, /*fuse_walk=*/true, plan.sa_known))) return rc;
@@ -1026,6 +1062,17 @@ int femto_amd_key_format(const femto_amd_index_t* ix, int* bits, int* max_syms, 
   if (bits) *bits = ix->dense_bits;
   if (max_syms) *max_syms = 63 / ix->dense_bits;
   if (field_of_alpha) memcpy(field_of_alpha, ix->h_dense.data(), std::min<size_t>(ix->h_dense.size(), size_t(kAlphaSize)));
+  return FEMTO_AMD_OK;
+}
+
+int femto_amd_key_table_id(const femto_amd_index_t* ix, uint64_t* id) {
+  if (!ix || !id) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  if (!ix->children.empty()) return femto_amd_key_table_id(ix->children[0], id);
+  if (!use_direct(ix) || ix->h_dense.empty())
+    return set_err(FEMTO_AMD_ERR_INVALID, "keys need the packed layouts (modes 3 / 4) and at most 255 distinct characters");
+  uint64_t h = 0xcbf29ce484222325ull ^ uint64_t(ix->dense_bits);      // FNV-1a over bits and the 261 fields
+  for (size_t c = 0; c < size_t(kAlphaSize) && c < ix->h_dense.size(); c++) h = (h ^ ix->h_dense[c]) * 0x100000001b3ull;
+  *id = h;
   return FEMTO_AMD_OK;
 }
 
@@ -1113,10 +1160,10 @@ int femto_amd_block_requests(femto_amd_index_t* ix, int64_t n, const int64_t* ro
     if (ch_in && ch_in[i] >= kAlphaSize) return set_err(FEMTO_AMD_ERR_PARAM, "character out of range");
   }
   if (n == 0) return FEMTO_AMD_OK;
-  {      // LOCATION requests are answered from femto's own mark tables, whatever the mode (lane_mark_offset)
-    std::lock_guard<std::mutex> lk(ix->mu);
-    if ((rc = ensure_wavelet_lines(ix))) return rc;
-  }
+  // LOCATION requests are answered from femto's own mark tables, whatever the mode (lane_mark_offset); CHAR / OCCS requests in
+  // modes 3 / 4 read the derived lines only and leave femto's segment lines where they are
+  WaveletLinesUse wl(ix);
+  if ((off_out || ix->mode <= 1) && (rc = wl.acquire())) return rc;
   Lease L(ix);
   if (!L.s) return L.rc;
   Scratch& S = *L.s;
@@ -1133,18 +1180,19 @@ int femto_amd_block_requests(femto_amd_index_t* ix, int64_t n, const int64_t* ro
     HIP_TRY(hipMemcpyAsync(d_chin, ch_in, size_t(n) * 2, hipMemcpyHostToDevice, st));
   }
   const int64_t blocks = (n * kGroupW + kBlockThreads - 1) / kBlockThreads;
+  int64_t* const d_off = off_out ? S.off.as<int64_t>() : nullptr;      // (the kernels look a row's offset up only when asked)
   if (ix->mode == 4)
     hipLaunchKernelGGL(block_request_kernel_pack2, dim3(uint32_t((n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads),
-                       0, st, ix->dev, n, S.rows.as<int64_t>(), d_chin, d_chout, S.occ.as<int64_t>(), S.off.as<int64_t>());
+                       0, st, ix->dev, n, S.rows.as<int64_t>(), d_chin, d_chout, S.occ.as<int64_t>(), d_off);
   else if (ix->mode == 3)
     hipLaunchKernelGGL(block_request_kernel_pack, dim3(uint32_t((n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads),
-                       0, st, ix->dev, n, S.rows.as<int64_t>(), d_chin, d_chout, S.occ.as<int64_t>(), S.off.as<int64_t>());
+                       0, st, ix->dev, n, S.rows.as<int64_t>(), d_chin, d_chout, S.occ.as<int64_t>(), d_off);
   else if (ix->mode >= 1)
     hipLaunchKernelGGL(block_request_kernel_lane, dim3(uint32_t((n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads),
-                       0, st, ix->dev, n, S.rows.as<int64_t>(), d_chin, d_chout, S.occ.as<int64_t>(), S.off.as<int64_t>());
+                       0, st, ix->dev, n, S.rows.as<int64_t>(), d_chin, d_chout, S.occ.as<int64_t>(), d_off);
   else
     hipLaunchKernelGGL((block_request_kernel<kGroupW>), dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, st, ix->dev, n,
-                       S.rows.as<int64_t>(), d_chin, d_chout, S.occ.as<int64_t>(), S.off.as<int64_t>());
+                       S.rows.as<int64_t>(), d_chin, d_chout, S.occ.as<int64_t>(), d_off);
   HIP_TRY(hipGetLastError());
   std::vector<uint16_t> chs((size_t(n)));
   std::vector<int64_t> occ((size_t(n)));
@@ -1181,10 +1229,8 @@ int femto_amd_forward_steps(femto_amd_index_t* ix, int64_t n, const int64_t* row
   for (int64_t i = 0; i < n; i++)
     if (rows[i] < 0 || rows[i] >= ix->host.total_length) return set_err(FEMTO_AMD_ERR_PARAM, "row out of range");
   if (n == 0) return FEMTO_AMD_OK;
-  {
-    std::lock_guard<std::mutex> lk(ix->mu);      // femto's own tables answer this: bring the segment lines back if the handle released them
-    if ((rc = ensure_wavelet_lines(ix))) return rc;
-  }
+  WaveletLinesUse wl(ix);      // femto's own tables answer this: bring the segment lines back if the handle released them
+  if ((rc = wl.acquire())) return rc;
   Lease L(ix);
   if (!L.s) return L.rc;
   Scratch& S = *L.s;
@@ -1271,6 +1317,7 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
     a.parity = S.bsums_parity;
     S.bsums_clean = false;    // (the traced twins run plan_rows twice: simply clear before the next real launch)
     a.tail_items = nullptr;
+    a.row_free = ix->trace_row_free ? 1 : 0;
     inline_tail_setup(ix, d);     // as launch_count_direct does (the hand-over case takes tail_setup's below)
     a.tail_min = d.tail_min;
     if (d.txt && !(d.sa_full && d.isa8 && d.isa_shift == 0)) {
@@ -1350,6 +1397,12 @@ int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode) {
     if (int rc = ensure_wavelet_lines(ix)) return rc;
   }
   ix->mode = mode;
+  // ... and back on the derived layouts a bounded handle gives them up again when they put it over its budget
+  if (mode >= 3 && ix->device >= 0 && ix->segs_drop_ok && ix->d_segs && ix->segs_users == 0 && ix->opt.hbm_budget_bytes >= 0 &&
+      hbm_held_all(ix) > ix->opt.hbm_budget_bytes) {
+    HIP_TRY(hipSetDevice(ix->device));
+    if (int rc = release_wavelet_lines(ix)) return rc;
+  }
   return FEMTO_AMD_OK;
 }
 
@@ -1363,6 +1416,7 @@ int femto_amd_set_option(femto_amd_index_t* ix, const char* name, int value) {
   for (femto_amd_index* c : ix->children) { int rc = femto_amd_set_option(c, name, value); if (rc) return rc; }
   std::lock_guard<std::mutex> lk(ix->mu);
   if (!strcmp(name, "sort")) ix->sort_queries = value != 0;
+  else if (!strcmp(name, "trace_row_free")) ix->trace_row_free = value != 0;
   else if (!strcmp(name, "regexp_max_iterations")) ix->regexp_max_iterations = value;
   else if (!strcmp(name, "regexp_stack_cap")) ix->regexp_stack_cap = std::min(1 << 22, std::max(16, value));
   else return set_err(FEMTO_AMD_ERR_PARAM, "unknown option");
@@ -1421,7 +1475,6 @@ void femto_amd_kernel_time_enable(femto_amd_index_t* ix, int on) {
 void femto_amd_kernel_time_reset(femto_amd_index_t* ix) {
   if (!ix) return;
   std::lock_guard<std::mutex> lk(ix->mu);
-  ix->t_count.drain();
   for (KernelTimer* t : {&ix->t_count, &ix->t_locate, &ix->t_resolve, &ix->t_regexp}) {
     t->drain();
     t->total_ms = 0;

@@ -50,6 +50,7 @@ struct QSequence { std::vector<QAtom> atoms; };
 struct QRegexp {
   std::vector<QSequence> choices;
   int cost_bound = 1, subst_cost = 1, delete_cost = 1, insert_cost = 1;   // regexp_settings_t (set_default_regexp_settings)
+  bool has_approx = false;           // the text itself began with APPROX (an explicit "APPROX 0" is a setting too: cost_bound 1)
 };
 
 inline bool q_is_space(int c) { return c == ' ' || (c >= '\t' && c <= '\r'); }                       // [[:space:]], C locale
@@ -298,6 +299,7 @@ class QueryParser {
     if (!regexp(out)) { *err = err_; return false; }
     if (cur().kind != QTok::END) { *err = "syntax error at byte " + std::to_string(cur().at); return false; }
     if (approx) {
+      out->has_approx = true;
       out->cost_bound = ap.approx[0];
       out->subst_cost = ap.approx[1];
       out->delete_cost = ap.approx[2];

@@ -829,6 +829,22 @@ static size_t sort_results(NfaHostResult* r, size_t count) {
   return i;
 }
 
+namespace {
+thread_local double g_nfa_stats_thread[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+}
+
+int femto_amd_nfa_stats(femto_amd_index_t* ix, double* out8) {
+  if (!out8) return set_err(FEMTO_AMD_ERR_PARAM, "null argument");
+  if (!ix) {      // the calling thread's own last batch (concurrent callers on one handle)
+    for (int k = 0; k < 8; k++) out8[k] = g_nfa_stats_thread[k];
+    return FEMTO_AMD_OK;
+  }
+  if (!ix->children.empty()) return femto_amd_nfa_stats(ix->children[0], out8);
+  std::lock_guard<std::mutex> lk(ix->mu);
+  for (int k = 0; k < 8; k++) out8[k] = ix->nfa_stats[k];
+  return FEMTO_AMD_OK;
+}
+
 int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_amd_nfa_t* nfas, int64_t max_results,
                                int64_t* result_start, int64_t* first_out, int64_t* last_out, int32_t* len_out, int32_t* cost_out,
                                int32_t* status_out, int64_t* n_out) {
@@ -891,11 +907,16 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   Lease L(ix);
   if (!L.s) return L.rc;
   hipStream_t st = L.s->stream;
-  DeviceBuffer d_q, d_flags, d_sd, d_ch, d_bychar, d_arena, d_results, d_misc, d_order;
-  struct Free {
-    std::vector<DeviceBuffer*> b;
-    ~Free() { for (DeviceBuffer* x : b) x->release(); }
-  } guard{{&d_q, &d_flags, &d_sd, &d_ch, &d_bychar, &d_arena, &d_results, &d_misc, &d_order}};
+  Scratch& S = *L.s;
+  DeviceBuffer &d_q = S.nfa_q, &d_flags = S.nfa_flags, &d_sd = S.nfa_sd, &d_ch = S.nfa_ch, &d_bychar = S.nfa_bychar, &d_arena = S.nfa_arena,
+               &d_results = S.nfa_results, &d_misc = S.nfa_misc, &d_order = S.nfa_order;
+  struct Trim {      // (the buffers stay with the scratch; an arena or a result buffer that a rare retry blew up does not)
+    Scratch& S;
+    ~Trim() {
+      if (S.nfa_arena.cap > (size_t(2) << 30)) S.nfa_arena.release();
+      if (S.nfa_results.cap > (size_t(1) << 30)) S.nfa_results.release();
+    }
+  } trim{S};
   // Raw results (before the per-automaton sort drops ranges inside other results, and including the attempts of searches
   // that are run again in a larger arena) land in a buffer of the library's own, which grows and the batch runs again
   // when it is too small: max_results bounds what the CALLER's arrays receive, nothing else (max_results == 0: count only).
@@ -927,7 +948,7 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   B.result_count = d_count;
   B.status = d_status;
   const bool want_stats = getenv("FEMTO_AMD_NFA_STATS") != nullptr;
-  B.iters_out = want_stats ? d_status + nq : nullptr;
+  B.iters_out = d_status + nq;      // pops, cycles and start of every search: femto_amd_nfa_stats (three words per automaton, written once)
   B.nq_all = int32_t(nq);
   B.warm = knob(-1, "FEMTO_AMD_NFA_WARM", 1) != 0;
   B.max_iterations = ix->regexp_max_iterations;
@@ -966,6 +987,7 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   const size_t budget = std::min<size_t>(free_b / 2, size_t(16) << 30);
   std::vector<int32_t> todo, status(static_cast<size_t>(nq), 0), last_pass(static_cast<size_t>(nq), 0);
   unsigned long long count = 0;
+  double st_pops = 0, st_max = 0, st_busy = 0, st_span = 0, st_blocks = 0, st_late = 0;      // femto_amd_nfa_stats (of the last attempt)
   for (int attempt = 0;; attempt++) {
   if ((rc = d_results.reserve(size_t(result_cap) * sizeof(NfaResultDev)))) return rc;
   B.results = d_results.as<NfaResultDev>();
@@ -973,6 +995,16 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   HIP_TRY(hipMemsetAsync(d_misc.p, 0, 64 + size_t(nq) * 16 + 128, st));
   todo.resize(static_cast<size_t>(nq));
   for (int64_t i = 0; i < nq; i++) todo[size_t(i)] = int32_t(i);
+  // LONGEST-PREDICTED-FIRST.  The workgroups take automata off one counter, and the kernel lasts as long as its longest search
+  // (profiles/r05_regexp_final.txt: 156 k pops of a mean of 6.3 k) -- plus however long that search waited to be taken.  The
+  // order of the result lists is per automaton, not per batch, so the batch is handed out by falling predicted work: errors
+  // allowed x transitions (an automaton that accepts more strings branches more) x nodes.  A search taken at t = 0 ends the
+  // kernel at its own length; concurrent callers' kernels fill the workgroups the short searches leave.
+  if (knob(-1, "FEMTO_AMD_NFA_LPT", 1) != 0) {
+    auto weight = [&](int32_t q) { const NfaQueryDev& Q = hq[size_t(q)]; return int64_t(Q.cost_bound) * int64_t(Q.num_ents) * int64_t(Q.num_nodes); };
+    std::stable_sort(todo.begin(), todo.end(), [&](int32_t a, int32_t b) { return weight(a) > weight(b); });
+  }
+  st_pops = st_max = st_busy = st_span = st_blocks = st_late = 0;
   int64_t cap = std::min<int64_t>(1024, ix->regexp_stack_cap);
   for (int pass = 0;; pass++) {
     int blocks = int(std::min<int64_t>(int64_t(todo.size()), int64_t(ix->num_cus) * per_cu));
@@ -1002,10 +1034,28 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
     if (timed) timer_end(ix, ix->t_regexp, st, te0, te1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(status.data(), d_status, size_t(nq) * 4, hipMemcpyDeviceToHost, st));
+    std::vector<int32_t> it(static_cast<size_t>(nq) * 3);
+    HIP_TRY(hipMemcpyAsync(it.data(), d_status + nq, size_t(nq) * 12, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    {      // what femto_amd_nfa_stats reports: pops, the span of the pass on the shader clock, how busy its workgroups were
+      uint32_t t0 = UINT32_MAX, tend = 0, late = 0;
+      double busy = 0, pops = 0, pmax = 0;
+      for (int32_t q : todo) t0 = std::min(t0, uint32_t(it[size_t(2 * nq + q)]));
+      for (int32_t q : todo) {
+        const uint32_t s0 = uint32_t(it[size_t(2 * nq + q)]) - t0, run = uint32_t(it[size_t(nq + q)]);
+        busy += double(run);
+        pops += double(it[size_t(q)]);
+        if (double(it[size_t(q)]) > pmax) { pmax = double(it[size_t(q)]); late = s0; }
+        tend = std::max(tend, s0 + run);
+      }
+      st_pops += pops;
+      st_max = std::max(st_max, pmax);
+      st_busy += busy * 1024.0;
+      st_span += double(tend) * 1024.0;
+      st_blocks = std::max(st_blocks, double(blocks));
+      if (pass == 0) st_late = double(late) * 1024.0;
+    }
     if (want_stats) {      // entries popped per automaton: the kernel ends with its longest search (profiles/r05_regexp_*)
-      std::vector<int32_t> it(static_cast<size_t>(nq) * 3);
-      HIP_TRY(hipMemcpy(it.data(), d_status + nq, size_t(nq) * 12, hipMemcpyDeviceToHost));
       std::vector<int32_t> v;
       for (int32_t q : todo) v.push_back(it[size_t(q)]);
       std::sort(v.begin(), v.end());
@@ -1067,6 +1117,11 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   }
   }
   t_search = ms_since(t_call) - t_flat;
+  {
+    std::lock_guard<std::mutex> lk(ix->mu);
+    const double v[8] = {double(nq), st_blocks, st_pops, st_max, st_busy, st_span, (st_span > 0 && st_blocks > 0) ? st_busy / (st_span * st_blocks) : 0.0, st_late};
+    for (int k = 0; k < 8; k++) ix->nfa_stats[k] = g_nfa_stats_thread[k] = v[k];
+  }
   std::vector<NfaResultDev> raw(static_cast<size_t>(count));
   if (count) HIP_TRY(hipMemcpy(raw.data(), d_results.p, size_t(count) * sizeof(NfaResultDev), hipMemcpyDeviceToHost));
   t_copy = ms_since(t_call) - t_flat - t_search;
@@ -1187,7 +1242,7 @@ int femto_amd_regexp_compile(const uint8_t* regex, int64_t regex_len, int max_co
   QRegexp q;
   std::string perr;
   if (!parse_query(regex, regex_len, &q, &perr)) return set_err(FEMTO_AMD_ERR_PARAM, "regular expression: " + perr);
-  if (q.cost_bound == 1) {               // no APPROX in the text: the arguments decide
+  if (!q.has_approx) {                   // no APPROX in the text: the arguments decide (an explicit "APPROX 0 ..." keeps exact matching)
     q.cost_bound = max_cost + 1;
     q.subst_cost = subst_cost;
     q.delete_cost = delete_cost;

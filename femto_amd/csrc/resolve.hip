@@ -71,6 +71,9 @@ __global__ __launch_bounds__(256) void resolve_kernel(const ResolveArgs A) {
 
 // the handle's device copy of doc_ends (made on first use)
 static int ensure_doc_ends(femto_amd_index* ix) {
+  // (the fast path takes no lock: femto_amd_resolve_device is an enqueue-only call issued every step; the pointer is published
+  // with release order once the table is complete)
+  if (__atomic_load_n(&ix->d_doc_ends, __ATOMIC_ACQUIRE)) return 0;
   std::lock_guard<std::mutex> lk(ix->mu);
   if (ix->d_doc_ends) return 0;
   const size_t n = ix->host.doc_ends.size();
@@ -83,7 +86,7 @@ static int ensure_doc_ends(femto_amd_index* ix) {
       return set_err(FEMTO_AMD_ERR_INVALID, std::string("hipMemcpy(doc_ends): ") + hipGetErrorString(e));
     }
   }
-  ix->d_doc_ends = p;
+  __atomic_store_n(&ix->d_doc_ends, p, __ATOMIC_RELEASE);
   ix->table_bytes += int64_t(n * 8);
   ix->hbm_held += int64_t(n * 8);
   return 0;
@@ -91,6 +94,8 @@ static int ensure_doc_ends(femto_amd_index* ix) {
 
 static int launch_resolve(femto_amd_index* ix, const int64_t* d_offsets, int64_t n, const int64_t* d_n, int64_t* d_doc, int32_t* d_doc32,
                           int64_t* d_doc_offset, hipStream_t st) {
+  if (d_doc32 && ix->host.doc_ends.size() >= (size_t(1) << 31))
+    return set_err(FEMTO_AMD_ERR_PARAM, "32-bit document numbers need an index of fewer than 2^31 documents: pass d_doc");
   int rc = ensure_doc_ends(ix);
   if (rc) return rc;
   ResolveArgs A{};

@@ -313,6 +313,10 @@ struct TailOut {
   int32_t* noccs;           // locate plan, or NULL
   int64_t* block_sums;
   int max_occs;
+  int64_t* sa_out;          // or NULL: count_direct_kernel's sa_out (text positions of one-row patterns the search already knows)
+  int row_free;             // 1: no rows are returned (DevIndex::row_free): a tail that consumes the pattern leaves its POSITION in sa_out
+                            // and skips the way back to a row (the sampled inverse suffix array + up to 7 LF steps); first_out gets the
+                            // rows plan_rows_kernel still needs, last_out nothing
 };
 
 template <class P, bool kSaFull>
@@ -345,6 +349,7 @@ inline __global__ __launch_bounds__(256) void count_tail_kernel(const DevIndex i
     int m = 0;                       // symbols matched
     uint64_t tw = 0;                 // aligned 8-byte word of txt holding the byte being compared
     uintptr_t tw_addr = 0;
+    bool differs = false;            // the compare ended on a text character other than the pattern's (an ordinary one)
     for (; m < remaining; m++) {
       uint32_t code = 0, ch = 0;
       if (tail_symbol<P>(ix, R, j + m, &code, &ch) != 0) break;   // leave anything unusual to the ordinary step below
@@ -357,7 +362,20 @@ inline __global__ __launch_bounds__(256) void count_tail_kernel(const DevIndex i
         trace_touch(ix, kTraceTxt, uint64_t(wa - reinterpret_cast<uintptr_t>(ix.txt)) >> 7);
       }
       const uint32_t tc = uint32_t(tw >> (8 * (ta - wa))) & 0xffu;
-      if (tc != code) break;
+      if (tc != code) {
+        differs = true;
+        break;
+      }
+    }
+    if (out.row_free && out.noccs && (m == remaining || differs)) {
+      // row-free locate (direct_kernels.hip.hpp): located by the compare itself, or empty -- no way back to a row
+      const int64_t c = m == remaining ? 1 : 0;
+      out.noccs[q] = int32_t(c);
+      if (c) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(out.block_sums + (q >> 8)), static_cast<unsigned long long>(c));
+        out.sa_out[q] = p - m;
+      }
+      continue;
     }
     if (m > 0) {
       int64_t row;
@@ -389,7 +407,9 @@ inline __global__ __launch_bounds__(256) void count_tail_kernel(const DevIndex i
   if (out.pair_out) {
     out.pair_out[q] = make_longlong2(first, last);
   } else {
-    if (out.last_out) {
+    if (out.row_free && out.noccs) {
+      if (first <= last) out.first_out[q] = first;
+    } else if (out.last_out) {
       out.first_out[q] = first;
       out.last_out[q] = last;
     } else {

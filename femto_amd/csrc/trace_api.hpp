@@ -20,6 +20,7 @@ struct TraceArgs {
   int parity;               // which set of group sums of bsums this launch uses (PlanSums)
   void* tail_items;         // NULL: no text tail
   int tail_min;
+  int row_free;             // 1: the row-free form of the chain (DevIndex::row_free)
   int* flags;               // [0] error, [1] long ranges, [2] tail item count
   int64_t* total;
   uint32_t* bitmap;

@@ -39,6 +39,7 @@ static DevIndex make_dev(const TraceArgs& a) {
   d.tail_items = a.tail_items;
   d.tail_count = a.flags + 2;
   d.tail_min = a.tail_min;
+  d.row_free = a.row_free;
   if (!a.tail_items && !(d.sa_full && d.isa8 && d.isa_shift == 0)) d.txt = nullptr;
   return d;
 }
@@ -57,7 +58,7 @@ hipError_t traced_count_plan(const TraceArgs& a) {
 #define LAUNCH_COUNT_DIRECT(POLICY)                                                                                                     \
   do {                                                                                                                                  \
     if (dense) hipLaunchKernelGGL((count_direct_kernel<POLICY, true, true>), grid, block, 0, a.stream, d, a.npats, a.plen, a.pats, a.starts, a.first, a.last, a.flags, a.max_occs, a.noccs, ps, big_flag, a.sa_known); \
-    else hipLaunchKernelGGL((count_direct_kernel<POLICY, true, false>), grid, block, 0, a.stream, d, a.npats, a.plen, a.pats, a.starts, a.first, a.last, a.flags, a.max_occs, a.noccs, ps, big_flag, spot ? a.sa_known : static_cast<int64_t*>(nullptr));     \
+    else hipLaunchKernelGGL((count_direct_kernel<POLICY, true, false>), grid, block, 0, a.stream, d, a.npats, a.plen, a.pats, a.starts, a.first, a.last, a.flags, a.max_occs, a.noccs, ps, big_flag, (spot || (a.row_free && tail)) ? a.sa_known : static_cast<int64_t*>(nullptr));     \
   } while (0)
   const bool spot = a.mode == 3 && d.ru && d.ru_marks && d.pack && d.pack_sa && !dense;    // as launch_count_direct decides
   if (a.mode == 3 && d.ru && d.ru_marks) LAUNCH_COUNT_DIRECT(RumPolicy);
@@ -67,7 +68,7 @@ hipError_t traced_count_plan(const TraceArgs& a) {
   else LAUNCH_COUNT_DIRECT(Pack2Policy);
 #undef LAUNCH_COUNT_DIRECT
   if (tail) {
-    const TailOut out{nullptr, a.first, a.last, a.noccs, a.bsums, a.max_occs};
+    const TailOut out{nullptr, a.first, a.last, a.noccs, a.bsums, a.max_occs, a.sa_known, a.row_free};
     const dim3 tgrid{uint32_t(std::min<int64_t>(nblocks, int64_t(a.num_cus) * 8))};
     const TailItem* items = static_cast<const TailItem*>(a.tail_items);
     const int* n_items = d.tail_count;
@@ -112,11 +113,11 @@ hipError_t traced_walk(const TraceArgs& a, int64_t* offsets, int64_t capacity) {
   }
   // sampled marks: the walk runs inside the row expansion, as femto_amd_locate_device launches it
   if (a.mode == 3) {
-    const bool spot = d.ru && d.ru_marks && d.pack && d.pack_sa;      // the count twin left its hints in a.sa_known
+    const bool spot = (d.ru && d.ru_marks && d.pack && d.pack_sa) || (a.row_free && a.tail_items);      // the count twin left its hints in a.sa_known
     hipLaunchKernelGGL((plan_rows_kernel<kRowsWalk, PackPolicy>), grid, block, 0, a.stream, a.npats, noccs, first, static_cast<const int2*>(nullptr), boffs, a.out_starts, offsets, capacity, a.flags + 1, d, a.total, static_cast<int64_t*>(nullptr), spot ? static_cast<const int64_t*>(a.sa_known) : static_cast<const int64_t*>(nullptr));
     hipLaunchKernelGGL((plan_big_rows_kernel<kRowsWalk, PackPolicy>), wgrid, block, 0, a.stream, a.npats, first, static_cast<const int2*>(nullptr), ostarts, total, capacity, offsets, big, d);
   } else {
-    hipLaunchKernelGGL((plan_rows_kernel<kRowsWalk, Pack2Policy>), grid, block, 0, a.stream, a.npats, noccs, first, static_cast<const int2*>(nullptr), boffs, a.out_starts, offsets, capacity, a.flags + 1, d, a.total, static_cast<int64_t*>(nullptr), static_cast<const int64_t*>(nullptr));
+    hipLaunchKernelGGL((plan_rows_kernel<kRowsWalk, Pack2Policy>), grid, block, 0, a.stream, a.npats, noccs, first, static_cast<const int2*>(nullptr), boffs, a.out_starts, offsets, capacity, a.flags + 1, d, a.total, static_cast<int64_t*>(nullptr), (a.row_free && a.tail_items) ? static_cast<const int64_t*>(a.sa_known) : static_cast<const int64_t*>(nullptr));
     hipLaunchKernelGGL((plan_big_rows_kernel<kRowsWalk, Pack2Policy>), wgrid, block, 0, a.stream, a.npats, first, static_cast<const int2*>(nullptr), ostarts, total, capacity, offsets, big, d);
   }
   return hipGetLastError();

@@ -158,7 +158,14 @@ int femto_amd_locate_walk_device(femto_amd_index_t* ix, int64_t npats, const int
 /* The whole of parallel_locate (src/main/femto.c:331) as ONE enqueue-only call: count, the reference's clamp, prefix
  * sum and the locate walk run as one stream-ordered chain; nothing returns to the host in between.  d_offsets has room
  * for offsets_capacity rows; d_total[0] receives the number of rows (= d_out_starts[npats]) and d_total[1] is 1 when
- * that exceeds offsets_capacity (the offsets are then incomplete: call again with a larger buffer). */
+ * that exceeds offsets_capacity (the offsets are then incomplete: call again with a larger buffer).
+ * ROW-FREE FORM: d_first == d_last == NULL.  parallel_locate itself returns `noccs` and `offsets` and never a row
+ * (src/main/femto.c:331-400); a caller that passes no row arrays gets exactly that -- d_noccs, d_out_starts, d_offsets,
+ * d_total, bit-identical to the form with rows -- and the search is spared what only the rows need: on handles holding
+ * the text, a pattern whose remaining symbols are compared against the text on ONE row is located by that compare (its
+ * offset is where the compared text starts) without the inverse-suffix-array read (and, with sampled arrays, the LF steps)
+ * that would turn the position back into a row; a compare that meets another character ends the pattern at once, where the
+ * form with rows runs one more step for the (first, last) of the emptied range. */
 int femto_amd_locate_device(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen,
                             const uint16_t* d_pats, const int64_t* d_starts, int max_occs_each,
                             int64_t* d_first, int64_t* d_last, int32_t* d_noccs, int64_t* d_out_starts,
@@ -249,6 +256,12 @@ typedef struct femto_amd_nfa {
 int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_amd_nfa_t* nfas, int64_t max_results,
                                int64_t* result_start /* nq + 1 */, int64_t* first_out, int64_t* last_out, int32_t* len_out,
                                int32_t* cost_out, int32_t* status_out, int64_t* n_out);
+/* What the handle's last automaton batch did (the reference keeps many do_regexp_query state machines in flight,
+ * src/main/server.c:3969-4001; here concurrent callers' batches share the GPU's workgroups): out8 = { automata, workgroups
+ * launched, entries popped in all, ... by the longest search, busy workgroup-cycles (shader clock), the span of the search
+ * passes in cycles, occupancy = busy / (span x workgroups), cycles the longest search waited before a workgroup took it }.
+ * ix == NULL: the calling thread's own last batch. */
+int femto_amd_nfa_stats(femto_amd_index_t* ix, double* out8);
 /* Pattern text -> automaton.  Pattern language: femto's own (src/main/QUERY_FORMAT.txt), restated token rule by token rule
  * and production by production from src/main/posix.flex.l and src/main/posix.bison.y (femto_amd/csrc/query_parser.hpp names
  * the corners): literal bytes, `.`, `[a-z]` / `[^...]`, `( )`, `|`, one of `*` `+` `?` `{m}` `{m,}` `{m,n}` per term, backslash
@@ -357,6 +370,11 @@ int femto_amd_multi_child(femto_amd_index_t* ix, int i, femto_amd_index_t** chil
  * int32 (first, last) pairs instead of two int64 arrays.  d_noccs == NULL: count only (d_out_starts / d_offsets / d_total
  * unused).  Enqueue-only, like the calls it mirrors. */
 int femto_amd_key_format(const femto_amd_index_t* ix, int* bits, int* max_syms, uint8_t* field_of_alpha /* [261] or NULL */);
+/* An identity of the key fields of this handle (a hash of `bits` and field_of_alpha): keys are only meaningful to a handle -- and a
+ * library build -- that reports the SAME id.  A caller that packs keys itself, caches them, or ships them to another process
+ * compares ids first: the fields follow the handle's dense codes, which differ between indexes and have changed between library
+ * versions (byte alphabets: by falling frequency since round 5); a key of another table searches for another string, silently. */
+int femto_amd_key_table_id(const femto_amd_index_t* ix, uint64_t* id);
 int femto_amd_pack_keys_device(femto_amd_index_t* ix, int64_t npats, const int32_t* d_plen, const uint16_t* d_pats,
                                const int64_t* d_starts, uint64_t* d_keys, int64_t* d_bad, void* stream);
 int femto_amd_locate_keys_device(femto_amd_index_t* ix, int64_t npats, const uint64_t* d_keys, int max_occs_each,

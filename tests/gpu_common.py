@@ -56,9 +56,10 @@ def _set_mode(ix, mode):
     assert ix.rank_mode == mode
 
 
-def device_locate(ix, plen, flat, starts, max_occs, capacity):
+def device_locate(ix, plen, flat, starts, max_occs, capacity, row_free=False):
     """femto_amd_locate_device (the one-call device chain: count -> plan_rows with the walk inside) on host arrays:
-    (first, last, noccs, out_starts, offsets[:min(total, capacity)], total)."""
+    (first, last, noccs, out_starts, offsets[:min(total, capacity)], total).  row_free: the form without row arrays
+    (d_first = d_last = NULL: parallel_locate's own results); first / last come back as None."""
     import numpy as np
     import torch
     dev = "cuda:0"
@@ -69,8 +70,23 @@ def device_locate(ix, plen, flat, starts, max_occs, capacity):
     ostarts = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     offs = torch.full((capacity,), -7, dtype=torch.int64, device=dev)
     total = torch.zeros(2, dtype=torch.int64, device=dev)
-    ix.locate_device(n, d_plen.data_ptr(), d_flat.data_ptr(), d_starts.data_ptr(), max_occs, f.data_ptr(), l.data_ptr(), noccs.data_ptr(),
-                     ostarts.data_ptr(), offs.data_ptr(), capacity, total.data_ptr())
+    ix.locate_device(n, d_plen.data_ptr(), d_flat.data_ptr(), d_starts.data_ptr(), max_occs, 0 if row_free else f.data_ptr(), 0 if row_free else l.data_ptr(),
+                     noccs.data_ptr(), ostarts.data_ptr(), offs.data_ptr(), capacity, total.data_ptr())
     torch.cuda.synchronize()
     tot = int(total[0])
+    if row_free:
+        assert not f.any() and not l.any()
+        return (None, None, noccs.cpu().numpy(), ostarts.cpu().numpy(), offs[:min(tot, capacity)].cpu().numpy(), tot)
     return (f.cpu().numpy(), l.cpu().numpy(), noccs.cpu().numpy(), ostarts.cpu().numpy(), offs[:min(tot, capacity)].cpu().numpy(), tot)
+
+
+def assert_row_free_equals(ix, plen, flat, starts, max_occs, noccs, offs, what=""):
+    """the row-free form of the device chain returns the same noccs / out_starts / offsets / total as the form with rows"""
+    import numpy as np
+    _, _, dn, dst, do, dtot = device_locate(ix, plen, flat, starts, max_occs, len(offs) + 16, row_free=True)
+    want_st = np.zeros(len(plen) + 1, dtype=np.int64)
+    want_st[1:] = np.cumsum(noccs.astype(np.int64))
+    assert dtot == len(offs), (what, dtot, len(offs))
+    assert np.array_equal(dn, noccs), what
+    assert np.array_equal(dst, want_st), what
+    assert np.array_equal(do, offs), what

@@ -9,7 +9,7 @@ import pytest
 import femto_amd
 from conftest import INDEX_FIXTURES
 from femto_amd import textgen as tg
-from gpu_common import MODES, _open, _set_mode, _torchrun
+from gpu_common import MODES, _open, _set_mode, _torchrun, assert_row_free_equals, device_locate
 from oracle import pyoracle as po
 
 pytestmark = pytest.mark.gpu
@@ -163,6 +163,16 @@ def test_long_patterns_text_tail(tmp_path, gpu_ok, mode, sigma):
     on, oo = o.locate_flat(plen, flat, starts, 4, threads=16)
     assert np.array_equal(noccs, on) and np.array_equal(offs, oo)
     assert on[3000] == 2
+    # the row-free form of the device chain (parallel_locate's own results): the text tail locates by its compare, a mismatch ends
+    # the pattern at once -- unless the symbol is one the step itself must look at (SEOF, absent characters) or the text starts
+    assert_row_free_equals(ix, plen, flat, starts, 4, on, oo, (mode, sigma))
+    if mode == (3 if sigma == 4 else 4):      # ... and on the sampled arrays (count_tail_kernel hands plan_rows_kernel the position)
+        ix.close()
+        ix = femto_amd.Index(path, device=0, options=dict(dense_arrays=0))
+        assert not ix.pack_info()["sa_full"] and ix.rank_mode == mode
+        assert_row_free_equals(ix, plen, flat, starts, 4, on, oo, (mode, sigma, "sampled"))
+        f2, l2 = ix.count_flat(plen, flat, starts)
+        assert np.array_equal(f2, of) and np.array_equal(l2, ol)
 
 
 @pytest.mark.parametrize("mode", MODES)

@@ -10,7 +10,7 @@ import pytest
 import femto_amd
 from conftest import INDEX_FIXTURES
 from femto_amd import textgen as tg
-from gpu_common import MODES, _open, _set_mode, _torchrun, device_locate
+from gpu_common import MODES, _open, _set_mode, _torchrun, assert_row_free_equals, device_locate
 from oracle import pyoracle as po
 
 pytestmark = pytest.mark.gpu
@@ -94,6 +94,9 @@ def test_full_size_1gib_properties(tmp_path, gpu_ok):
     assert 0.99 < dead.mean() < 1.0 and (rl3[dead] == rf3[dead] - 1).all()
     assert np.array_equal(rf3[dead], rf1[dead]) and np.array_equal(rl3[dead], rl1[dead])        # the emptying step's values
     assert np.array_equal(rf3, rf1) and np.array_equal(rl3, rl1) and np.array_equal(rn3, rn1) and np.array_equal(ro3, ro1)
+    # the row-free form (parallel_locate's own results: no rows, no inverse-suffix-array read) on both batches
+    assert_row_free_equals(ix, rplen, rflat, rstarts, 100, rn3, ro3, "random 20-mers")
+    assert_row_free_equals(ix, plen, flat, starts, 100, noccs, offs, "sampled 20-mers")
     m = 50_000
     of, ol = o.count_flat(rplen[:m], rflat, rstarts[:m], threads=32)
     assert np.array_equal(of, rf3[:m]) and np.array_equal(ol, rl3[:m])
@@ -119,6 +122,7 @@ def test_full_size_1gib_properties(tmp_path, gpu_ok):
     assert bx.pack_info()["rank_units_marked"], bx.pack_info()
     df, dl, dn, dst, do, dtot = device_locate(bx, plen, flat, starts, 100, len(offs) + 16)
     assert dtot == len(offs) and np.array_equal(df, first) and np.array_equal(dl, last) and np.array_equal(dn, noccs) and np.array_equal(do, offs)
+    assert_row_free_equals(bx, plen, flat, starts, 100, noccs, offs, "sampled 20-mers, 4 x text")
     bx.close()
     # the same index with its big arrays striped over "three GPUs" (all stripes on this one): same kernels, same answers
     sx = femto_amd.Index(path, devices=[0, 0, 0], striped=True)      # (the library's default bound: 8 x text over the three stripes)
@@ -210,7 +214,48 @@ def test_full_size_text96_properties(tmp_path, gpu_ok):
     o_starts = np.concatenate([[0], np.cumsum(n4)])
     want = np.concatenate([o4[o_starts[i]:o_starts[i + 1]] for i in pick])
     assert np.array_equal(on, n4[pick]) and np.array_equal(oo, want)
+    # the row-free form of the device chain on both batches (what parallel_locate returns: noccs and offsets)
+    assert_row_free_equals(ix, qlen, qflat, qstarts, 100, n4, o4, "hit / miss batch")
+    assert_row_free_equals(ix, plen, flat, starts, 20, noccs, offs, "sampled batch")
+    # (kept for the bounded handles below: the oracle's answers on the 60 000 picked patterns)
     ix.close()
+    # What a DROP-IN reaches (round-5 verdict, task 1a): the same index opened (a) with the library's defaults -- the default
+    # bound, 8 x text: two-level lines with the frequency-shaped first level, text + a sampled inverse suffix array,
+    # count_direct_kernel<Pack2Policy> + count_tail_kernel + plan_rows_kernel<2, Pack2Policy> -- and (b) under 32 GiB (dense
+    # suffix arrays and a narrow context table, no per-character rank lines).  The 250 k hit / miss batch against the
+    # BUDGET_ALL handle's answers (themselves checked against mode 1 and the oracle above), against the oracle's own answers on
+    # the 60 000 picked patterns incl. the dead ranges' (first, last), and through the one-call device chain (the walk inside
+    # the row expansion, marks and text tails).
+    for opts in (None, dict(hbm_budget_bytes=32 << 30)):
+        bx = femto_amd.Index(path, device=0, options=opts) if opts else femto_amd.Index(path, device=0)
+        st, pi = bx.structures(), bx.pack_info()
+        assert bx.rank_mode == 4 and pi["available2"] and not pi["char_rank_lines"], (st, pi)      # two-level lines, not the rank lines
+        assert st["hbm_allocated"] <= st["hbm_budget"], st
+        if opts is None:
+            assert st["hbm_budget_is_default"] == 1 and st["hbm_allocated"] <= 9 * (1 << 30) and not pi["sa_full"], (st, pi)
+        else:
+            assert st["hbm_budget"] == 32 << 30 and pi["sa_full"], (st, pi)
+        bf, bl = bx.count_flat(qlen, qflat, qstarts)
+        assert np.array_equal(bf[dead], f4[dead]) and np.array_equal(bl[dead], l4[dead])          # the emptying step's values
+        assert np.array_equal(bf, f4) and np.array_equal(bl, l4)
+        bn, bo = bx.locate_flat(qlen, qflat, qstarts, 100)
+        assert np.array_equal(bn, n4) and np.array_equal(bo, o4)
+        assert np.array_equal(of, bf[pick]) and np.array_equal(ol, bl[pick])                       # the oracle's own answers
+        assert np.array_equal(on, bn[pick])
+        b_starts = np.concatenate([[0], np.cumsum(bn)])
+        assert np.array_equal(oo, np.concatenate([bo[b_starts[i]:b_starts[i + 1]] for i in pick]))
+        df, dl, dn, dst, do, dtot = device_locate(bx, qlen, qflat, qstarts, 100, len(o4) + 16)
+        assert dtot == len(o4) and np.array_equal(df, f4) and np.array_equal(dl, l4) and np.array_equal(dn, n4) and np.array_equal(do, o4)
+        # the first batch (every pattern occurs; max_occs 20: another clamp) through the host path and the device chain
+        bf, bl = bx.count_flat(plen, flat, starts)
+        assert np.array_equal(bf, first) and np.array_equal(bl, last)
+        bn, bo = bx.locate_flat(plen, flat, starts, 20)
+        assert np.array_equal(bn, noccs) and np.array_equal(bo, offs)
+        df, dl, dn, dst, do, dtot = device_locate(bx, plen, flat, starts, 20, len(offs) + 16)
+        assert dtot == len(offs) and np.array_equal(df, first) and np.array_equal(dl, last) and np.array_equal(dn, noccs) and np.array_equal(do, offs)
+        assert_row_free_equals(bx, qlen, qflat, qstarts, 100, n4, o4, ("hit / miss batch", opts))
+        assert_row_free_equals(bx, plen, flat, starts, 20, noccs, offs, ("sampled batch", opts))
+        bx.close()
 
 
 def test_full_size_8gib_properties(tmp_path, gpu_ok):

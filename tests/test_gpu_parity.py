@@ -12,7 +12,7 @@ import pytest
 import femto_amd
 from conftest import INDEX_FIXTURES
 from femto_amd import textgen as tg
-from gpu_common import MODES, _open, _set_mode, _torchrun
+from gpu_common import MODES, _open, _set_mode, _torchrun, assert_row_free_equals, device_locate
 from oracle import pyoracle as po
 
 pytestmark = pytest.mark.gpu
@@ -329,6 +329,27 @@ def test_device_chain_walks_inside_the_row_expansion(fixtures, gpu_ok, name):
         ix.close()
 
 
+@pytest.mark.parametrize("name", INDEX_FIXTURES)
+def test_row_free_locate_device(fixtures, gpu_ok, name):
+    """femto_amd_locate_device with d_first == d_last == NULL -- parallel_locate's own results, noccs and offsets and no rows
+    (src/main/femto.c:331-400): the reference's golden noccs / offsets for every clamp, under option sets that take every path
+    the form differs on -- the inline text tail of dense handles (located by the compare, no inverse-suffix-array read; a
+    mismatch ends the pattern without the emptying step), count_tail_kernel on the sampled arrays (the position instead of the
+    way back to a row; plan_rows_kernel does not walk), handles without the text, mark spotting, and femto's own wavelet tree."""
+    fx = fixtures(name)
+    plen, flat, starts = fx.patterns
+    sets = [dict(), dict(tail_min=2, tail_ones=0), dict(tail_min=2, tail_ones=0, level_table=0, context_table=0), dict(tail_min=2, tail_rows=4, tail_row_cost=0),
+            dict(dense_arrays=0), dict(dense_arrays=0, tail_min=2), dict(dense_arrays=0, tail_min=2, mark_every=3, level_table_syms=1),
+            dict(dense_arrays=0, text=0), dict(dense_arrays=0, text=0, rank_units=3, level_table_syms=2), dict(hbm_budget_bytes=600_000)]
+    for kw in sets:
+        ix = femto_amd.Index(fx.index, device=0, options=kw)
+        for mode in ([ix.rank_mode] if kw else [ix.rank_mode, 1, 0]):
+            ix.set_rank_mode(mode)
+            for mo, g_noccs, g_offs in fx.locate_cases():
+                assert_row_free_equals(ix, plen, flat, starts, mo, g_noccs, g_offs, (name, kw, mode, mo))
+        ix.close()
+
+
 @pytest.mark.parametrize("name", ["acgt48k", "eng2doc", "runs3doc"])
 def test_keys_device_path_equals_symbol_path(fixtures, gpu_ok, name):
     """femto_amd_pack_keys_device + femto_amd_locate_keys_device: patterns as 64-bit keys, ranges as int32 pairs -- the same
@@ -483,7 +504,69 @@ def test_released_wavelet_lines_come_back(fixtures, gpu_ok, name):
     ix = femto_amd.Index(fx.index, device=0, options=dict(hbm_budget_bytes=femto_amd.BUDGET_ALL))
     assert ix.structures()["image"] == kept.structures()["image"]          # no budget: nothing released
     ix.close()
+    # "bytes this handle may HOLD in all" stays true (round-5 advisor): a budget the segment lines do not fit next to what the handle
+    # holds -- CHAR / OCCS requests in modes 3 / 4 never bring them back; LOCATION requests, forward steps and a stay in mode 1 do,
+    # and give them up again when the call (the stay) ends
+    kch, krow, koff = kept.forward_steps(rows[:64])
+    released_seen = 0
+    for budget in (held0 + (held_kept - held0) // 2, held0, held0 - (held_kept - held0) // 2, 600_000, 150_000):
+        tight = femto_amd.Index(fx.index, device=0, options=dict(hbm_budget_bytes=int(budget)))
+        t0 = tight.structures()["hbm_allocated"]
+        if tight.rank_mode not in (3, 4) or t0 > budget:      # (a budget below the block images themselves: nothing to give up)
+            tight.close()
+            continue
+        ch, occ, off = tight.block_requests(rows, location=False)
+        assert off is None and np.array_equal(ch, g["L"]) and np.array_equal(occ, g["occ"]) and tight.structures()["hbm_allocated"] == t0, budget
+        ch, occ, off = tight.block_requests(rows)
+        assert np.array_equal(off, g["off"]) and tight.structures()["hbm_allocated"] <= budget, budget
+        fch, frow, foff = tight.forward_steps(rows[:64])
+        assert np.array_equal(fch, kch) and np.array_equal(frow, krow) and np.array_equal(foff, koff) and tight.structures()["hbm_allocated"] <= budget
+        mode34 = tight.rank_mode
+        tight.set_rank_mode(1)
+        in_mode1 = tight.structures()["hbm_allocated"]
+        assert in_mode1 > t0
+        f2, l2 = tight.count_flat(plen, flat, starts)
+        assert np.array_equal(f2, g["count_first"]) and np.array_equal(l2, g["count_last"])
+        tight.set_rank_mode(mode34)
+        back = tight.structures()["hbm_allocated"]
+        assert back <= budget and back in (t0, in_mode1), (budget, t0, in_mode1, back)
+        released_seen += int(in_mode1 > budget and back == t0)
+        f2, l2 = tight.count_flat(plen, flat, starts)
+        assert np.array_equal(f2, g["count_first"]) and np.array_equal(l2, g["count_last"])
+        tight.close()
+    assert released_seen >= 1
     kept.close()
+
+
+def test_budget_environment_variable_is_validated(fixtures, gpu_ok, monkeypatch):
+    """FEMTO_AMD_HBM_BUDGET: bytes with an optional k / M / G / T suffix, or "all" in any case; anything else is not a budget and the
+    default bound applies (atoll() used to read "8G" as 8 bytes and "ALL" as 0: every optional structure silently declined)."""
+    fx = fixtures("acgt48k")
+    for text, want in (("8G", 8 << 30), ("8GiB", 8 << 30), ("512M", 512 << 20), ("3000000", 3_000_000), ("ALL", -1), ("all", -1)):
+        monkeypatch.setenv("FEMTO_AMD_HBM_BUDGET", text)
+        ix = femto_amd.Index(fx.index, device=0)
+        st = ix.structures()
+        assert st["hbm_budget"] == want and st["hbm_budget_is_default"] == 0, (text, st)
+        ix.close()
+    monkeypatch.delenv("FEMTO_AMD_HBM_BUDGET")
+    ix = femto_amd.Index(fx.index, device=0)
+    dflt = ix.structures()["hbm_budget"]
+    ix.close()
+    for text in ("8X", "G", "-5", "12 34", ""):
+        monkeypatch.setenv("FEMTO_AMD_HBM_BUDGET", text)
+        ix = femto_amd.Index(fx.index, device=0)
+        st = ix.structures()
+        assert st["hbm_budget_is_default"] == 1 and st["hbm_budget"] == dflt and st["level_table_syms"] > 0, (text, st)
+        ix.close()
+
+
+def test_key_table_id(fixtures, gpu_ok):
+    """femto_amd_key_table_id: the same for two handles of one index, different for indexes whose characters differ"""
+    a, b = femto_amd.Index(fixtures("acgt48k").index, device=0), femto_amd.Index(fixtures("acgt48k").index, device=0, options=dict(hbm_budget_bytes=600_000))
+    c = femto_amd.Index(fixtures("eng2doc").index, device=0)
+    assert a.key_table_id() == b.key_table_id() != c.key_table_id()
+    for ix in (a, b, c):
+        ix.close()
 
 
 @pytest.mark.parametrize("name", ["acgt48k", "runs3doc", "eng2doc"])
