@@ -64,7 +64,8 @@ def main():
     ap.add_argument("--ref-sample", type=int, default=100_000, help="patterns per timed pass of the genuine reference (3 passes + warm-up)")
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"], help="auto: roofline.traffic from live rocprofv3 --pmc passes (N=1)")
     ap.add_argument("--pmc-child", action="store_true", help="internal: the short run the PMC passes profile")
-    ap.add_argument("--row-free", action="store_true", help="with --pmc-child (profile rounds): the steps use the row-free form of femto_amd_locate_device")
+    ap.add_argument("--row-free", action="store_true", help="experiments / profile rounds (never the headline): the timed steps use the row-free form of "
+                                                             "femto_amd_locate_device (noccs + offsets as parallel_locate returns them, no row arrays)")
     ap.add_argument("--gather", default="torch", choices=["torch", "native"],
                     help="N > 1: torch = torch.distributed.gather (RCCL); native = the library's own grouped ncclSend/ncclRecv "
                          "(femto_amd_comm_gather), its id broadcast through torch.distributed")
@@ -265,6 +266,7 @@ def main():
                 pending[b] = None
 
     batch.settle(ix, args.max_occs, stream)      # untimed: sizes the offsets buffer (the timed steps never read the total back)
+    batch.row_free = args.row_free
     for _ in range(args.warmup):
         step()
     drain()
@@ -284,6 +286,11 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ix.kernel_time_enable(False)
+    if args.row_free:      # everything below reads (first, last) of the last step: once more with rows, untimed
+        batch.row_free = False
+        batch.use(counter["k"] - 1)
+        batch.step(ix, args.max_occs, stream, (counter["k"] - 1) & 1)
+        torch.cuda.synchronize()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -416,6 +423,8 @@ def main():
     roof = None
     if cnt_n > 0:
         try:
+            if args.row_free:
+                ix.set_option("trace_row_free", 1)      # the traced twins follow the form the steps were timed in
             roof, kname, k_ms, comp, step_bytes = roofline_block(ix, direct, batch, npats, plen, args.max_occs, cnt_ms, loc_ms, cnt_n)
         except femto_amd.FemtoAmdError as ex:      # the line trace follows the packed modes' pipeline: modes 0 / 1 report times only
             roof = None
@@ -518,7 +527,7 @@ def main():
         "value": value, "unit": "patterns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-        "config": {"workload": wl, "batches_rotated": nsets, "replay_same_batch": replay, "text_bytes": n_text, "patterns_per_gpu": npats, "pattern_len": args.plen, "seed": args.seed,
+        "config": {"workload": wl + (" [ROW-FREE form: noccs + offsets, no rows]" if args.row_free else ""), "row_free": bool(args.row_free), "batches_rotated": nsets, "replay_same_batch": replay, "text_bytes": n_text, "patterns_per_gpu": npats, "pattern_len": args.plen, "seed": args.seed,
                    "located_rows_per_gpu": located_rows, "gathered_results_verified": gathered_ok, "per_rank": per_rank, "matched_patterns_frac": float(np.mean(last >= first)),
                    "rank_mode": {4: "pack2", 3: "pack", 1: "lane", 0: "raw"}[main_rank_mode], "index": {"rows": int(info.total_length), "blocks": int(info.number_of_blocks), "buckets": int(info.total_buckets),
                              "image_bytes": int(info.image_bytes), "table_bytes": int(info.table_bytes),

@@ -43,7 +43,8 @@ def pmc_traffic(args, kname, pack_info, open_opts="", child_env=None):
         return None, None
     base = [sys.executable, BENCH_PY, "--pmc-child", "--steps", "2", "--warmup", "1", "--text-log2", str(args.text_log2),
             "--npats", str(args.npats), "--plen", str(args.plen), "--seed", str(args.seed), "--max-occs", str(args.max_occs),
-            "--workload", args.workload, "--workdir", args.workdir] + (["--len-range", args.len_range] if args.len_range else [])
+            "--workload", args.workload, "--workdir", args.workdir] + (["--len-range", args.len_range] if args.len_range else []) + (
+            ["--row-free"] if getattr(args, "row_free", False) else [])
     if open_opts or args.open_opts:
         base += ["--open-opts", open_opts or args.open_opts]
     means = {}

@@ -208,6 +208,8 @@ def lib():
         L.femto_amd_regexp_free.restype = None
         L.femto_amd_nfa_search_batch.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]
         L.femto_amd_nfa_stats.argtypes = [vp, vp]
+        if hasattr(L, "femto_amd_lf_steps_device"):      # (absent from the older builds tools/ab_bench.sh loads beside this one)
+            L.femto_amd_lf_steps_device.argtypes = [vp, i64, vp, vp, vp, vp]
         L.femto_amd_key_table_id.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.femto_amd_set_option.argtypes = [vp, C.c_char_p, i32]
         L.femto_amd_block_requests.argtypes = [vp, i64, vp, vp, vp, vp, vp]
@@ -416,7 +418,7 @@ class Index:
         _check(lib().femto_amd_pack_info(self._h, C.byref(a), C.byref(b), C.byref(ms), C.byref(k)))
         return {"available": bool(a.value & 1), "available2": bool(a.value & 2), "level_table": bool(a.value & 4),
                 "sa_full": bool(a.value & 8), "isa_full": bool(a.value & 16), "char_rank_lines": bool(a.value & 32), "context_table": bool(a.value & 64),
-                "context_syms": (a.value >> 8) & 15, "context2_syms": (a.value >> 12) & 31, "context_mid_syms": (a.value >> 24) & 31, "rank_units": bool(a.value & (1 << 20)), "rank_units_marked": bool(a.value & (1 << 21)),
+                "context_syms": (a.value >> 8) & 15, "context2_syms": (a.value >> 12) & 31, "context_mid_syms": (a.value >> 24) & 31, "rank_units": bool(a.value & (1 << 20)), "rank_units_marked": bool(a.value & (1 << 21)), "sa_32bit": bool(a.value & (1 << 22)),
                 "bytes": b.value, "build_ms": ms.value, "ktab_syms": k.value}
 
     def structures(self):
@@ -542,6 +544,10 @@ class Index:
         _check(lib().femto_amd_key_format(self._h, C.byref(bits), C.byref(syms), _ptr(table)))
         return bits.value, syms.value, table
 
+    def lf_steps_device(self, n, d_rows, d_next, d_off, stream=0):
+        """femto_amd_lf_steps_device on raw device addresses: one step of the locate walk per row (offset if marked, else LF(row))"""
+        _check(lib().femto_amd_lf_steps_device(self._h, int(n), d_rows, d_next, d_off, stream or None))
+
     def key_table_id(self):
         """identity of the key fields (femto_amd_key_table_id): keys built for one id are meaningless to a handle reporting another"""
         v = C.c_uint64(0)
@@ -607,7 +613,7 @@ class Index:
         """the last automaton batch (thread=True: of the calling thread): pops, span, workgroup occupancy (femto_amd_nfa_stats)"""
         out = (C.c_double * 8)()
         _check(lib().femto_amd_nfa_stats(None if thread else self._h, out))
-        keys = ("automata", "workgroups", "pops", "pops_longest", "busy_cycles", "span_cycles", "occupancy", "longest_waited_cycles")
+        keys = ("automata", "workgroups", "pops", "pops_longest", "busy_s", "span_s", "occupancy", "longest_waited_s")
         return dict(zip(keys, [float(v) for v in out]))
 
     def set_option(self, name, value):

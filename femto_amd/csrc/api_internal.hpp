@@ -282,6 +282,8 @@ struct femto_amd_index {
   KernelTimer t_count, t_locate, t_resolve, t_regexp;
   int64_t* d_doc_ends = nullptr;   // the header block's doc_ends[] on the device (resolve.hip; uploaded on first use)
   double nfa_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // the last automaton batch (femto_amd_nfa_stats)
+  int32_t* nfa_active = nullptr;       // pinned host word: automaton batches in flight on this handle (regexp_search.hip "FAIR SHARE") ...
+  int32_t* nfa_active_dev = nullptr;   // ... as the kernels address it
   double pipe_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the last staged host-pointer call (femto_amd_host_pipeline_stats)
   // range-split index (femto_amd_open_split): this handle holds the segment lines and the block images of
   // data blocks [split_blo[part], split_blo[part+1]); the other parts' slices are mapped from their owners

@@ -116,7 +116,7 @@ int build_ktab2(femto_amd_index* ix, int sigma, int nstop) {
   d.kt2_deep_big = 0xffffff;
   if (const char* e = getenv("FEMTO_AMD_KTAB_DEEP_BIG")) d.kt2_deep_big = std::max(1, std::min(0xffffff, atoi(e)));    // test hook
   // one-row entries with their text position (direct_kernels.hip.hpp): the suffix array is at hand and rows / positions fit 31 bits
-  d.kt2_sa1 = (d.sa_full && d.txt && d.isa8 && d.isa_shift == 0 && ix->host.total_length <= (int64_t(1) << 31) && knob(-1, "FEMTO_AMD_KTAB_SA1", 1) != 0) ? 1 : 0;
+  d.kt2_sa1 = (d.sa_full && d.txt && ix->host.total_length <= (int64_t(1) << 31) && knob(-1, "FEMTO_AMD_KTAB_SA1", 1) != 0) ? 1 : 0;
   if (d.kt2_sa1) d.kt2_deep_big = std::min(d.kt2_deep_big, 0x800000);
   d.ktab2 = ix->d_ktab2;
   d.kt2_deep = reinterpret_cast<const uint64_t*>(ix->d_ktab2_deep);
@@ -390,22 +390,36 @@ int derived_mark_every(const femto_amd_index* ix) {
 //     rank lines and the context tables do not fit, and without the text every one of a pattern's ~36 symbols is a search step of
 //     two dependent lines (profiles/r05_budget_sweep_eng.txt).  (Until round 5 the suffix-array variant was chosen first and the
 //     whole text dropped when it missed the share: a 32 x budget held less than a 16 x one.)
+// what release_wavelet_lines gives back: femto's own tables (block images, segment lines, the sequences' directories)
+size_t own_tables_bytes(const HostIndex& h) {
+  return h.segs.size() * 8 + h.image.size() + h.cum.size() * sizeof(CumEntry) + h.hint.size() * 4 + h.bdir.size() * sizeof(BlockDir);
+}
+
+// bytes per entry of the dense suffix array / inverse suffix array: 4 on indexes of fewer than 2^32 - 1 rows (text_kernels.hip.hpp sa_at)
+size_t sa_entry_bytes(const femto_amd_index* ix) {
+  return (ix->host.total_length < int64_t(0xffffffffll) && knob(-1, "FEMTO_AMD_SA32_DENSE", 1) != 0) ? 4 : 8;
+}
+
 bool plan_text(const femto_amd_index* ix, size_t free_b, bool small_alphabet, int* isa_shift, bool* want_sa) {
   *isa_shift = kIsaShift;
   *want_sa = false;
   if (knob(ix->opt.text, "FEMTO_AMD_TEXT", 1) == 0) return false;
   const bool dense = knob(ix->opt.dense_arrays, "FEMTO_AMD_DENSE", 1) != 0;
   const int64_t n = ix->host.total_length;
-  const size_t tb = size_t(n) + 64, ib8 = (size_t(n >> kIsaShift) + 2) * 8, ib1 = (size_t(n) + 2) * 8, sb = size_t(n) * 8 + 64;
+  const size_t eb = sa_entry_bytes(ix);
+  const size_t tb = size_t(n) + 64, ib8 = (size_t(n >> kIsaShift) + 2) * eb, ib1 = (size_t(n) + 2) * eb, sb = size_t(n) * eb + 64;
   if (ix->opt.hbm_budget_bytes < 0) {
-    if (dense && double(n + 2) * 16.0 <= 0.55 * double(free_b)) {
+    if (dense && double(n + 2) * double(2 * eb) <= 0.55 * double(free_b)) {
       *isa_shift = 0;
       *want_sa = true;
-    } else if (dense && double(n) * 8.0 <= 0.30 * double(free_b)) {
+    } else if (dense && double(n) * double(eb) <= 0.30 * double(free_b)) {
       *want_sa = true;
     }
     return true;
   }
+  // (byte alphabets: ALL of what is free may go here when that is what it takes to keep the suffix array -- with it a located row
+  // is one read of consecutive entries instead of a walk, and a 1 GiB text's 56 M located rows per 10 M patterns were a third of
+  // the step under the default bound; profiles/r06_budget_sweep_eng.txt)
   const size_t share = small_alphabet ? free_b / 5 : free_b / 4 * 3;
   if (dense && tb + ib1 + sb <= share) {
     *isa_shift = 0;
@@ -413,6 +427,18 @@ bool plan_text(const femto_amd_index* ix, size_t free_b, bool small_alphabet, in
     return true;
   }
   if (dense && tb + ib8 + sb <= share) {
+    *want_sa = true;
+    return true;
+  }
+  if (dense && !small_alphabet && tb + ib8 + sb + (size_t(64) << 20) <= free_b) {
+    *want_sa = true;
+    return true;
+  }
+  // ... and with the inverse suffix array of every 16th position when that is what fits: the way back from a position to a row
+  // (calls that return rows) is then up to 15 LF steps instead of 7, and the row-free locate -- which never goes back -- loses nothing
+  const size_t ib16 = (size_t(n >> (kIsaShift + 1)) + 2) * eb;
+  if (dense && !small_alphabet && tb + ib16 + sb + (size_t(64) << 20) <= free_b) {
+    *isa_shift = kIsaShift + 1;
     *want_sa = true;
     return true;
   }
@@ -494,7 +520,7 @@ int build_pack(femto_amd_index* ix) {
       // (what the budget has left counts the wavelet segment lines as gone where open releases them after the derivations)
       const bool segs_go = ix->d_segs && ix->stripe_devices.empty() &&
                            knob(ix->opt.wavelet_lines, "FEMTO_AMD_WAVELET_LINES", ix->opt.hbm_budget_bytes >= 0 ? 0 : 1) == 0;
-      const size_t free_now = hbm_free(ix) + (segs_go && ix->opt.hbm_budget_bytes >= 0 ? h.segs.size() * 8 : 0);
+      const size_t free_now = hbm_free(ix) + (segs_go && ix->opt.hbm_budget_bytes >= 0 ? own_tables_bytes(h) : 0);
       ru_marked = ru_knob == 3 || (ru_knob == 1 && !sa_will_be_resident(ix, free_now > ru_est ? free_now - ru_est : 0));
       const bool want = ru_knob != 0;
       // the rows of the stop characters (one per document and character <= SEOF): 8 bytes each, listed for ru_stop_step
@@ -732,7 +758,20 @@ int build_pack2(femto_amd_index* ix) {
       }
     }
     int64_t sa_bytes = 0;
-    const int every = derived_mark_every(ix);
+    int every = derived_mark_every(ix);
+    if (every && !ix->d_pack_sa && ix->opt.hbm_budget_bytes >= 0 && ix->opt.mark_every == -1 && !getenv("FEMTO_AMD_MARK_EVERY")) {
+      // A bounded handle that will keep the suffix array of every row locates by reading it, and marks then only serve the derivation
+      // of the text and the leaf-level calls: femto's own (every mark_period-th position) instead of every 5th -- 0.2 instead of
+      // 0.86 GB at 1 GiB of text, which is what lets the suffix array fit a budget of 8 x the text at all.  What the handle will
+      // have free when the text is planned: what is free now, femto's own tables gone (released after the derivations), femto's
+      // marks taken.
+      const bool tables_go = ix->d_segs && ix->stripe_devices.empty() && knob(ix->opt.wavelet_lines, "FEMTO_AMD_WAVELET_LINES", 0) == 0;
+      const size_t own_marks = size_t(tot[16] > 0 ? tot[16] : 1) * size_t(mark_entry_bytes(ix));
+      const size_t free_then = hbm_free(ix) + (tables_go ? own_tables_bytes(h) : 0);
+      int shift;
+      bool sa = false;
+      if (free_then > own_marks && plan_text(ix, free_then - own_marks, false, &shift, &sa) && sa) every = 0;
+    }
     int64_t nmarks = tot[16];
     if (every) {  // denser marks (the same rows the 3-bit lines mark, so the offsets array can be shared)
       for (int64_t r0 = 0; r0 < n; r0 += chunk) {
@@ -812,7 +851,9 @@ int build_text(femto_amd_index* ix) {
   int isa_shift = kIsaShift;
   bool want_sa = false;
   if (!plan_text(ix, free_b, ix->dev.pack != nullptr, &isa_shift, &want_sa)) return 0;
-  const size_t tb = size_t(n) + 64, ib = (size_t(n >> isa_shift) + 2) * 8, sb = want_sa ? size_t(n) * 8 + 64 : 0;
+  const size_t eb = sa_entry_bytes(ix);
+  const int w32 = eb == 4 ? 1 : 0;
+  const size_t tb = size_t(n) + 64, ib = (size_t(n >> isa_shift) + 2) * eb, sb = want_sa ? size_t(n) * eb + 64 : 0;
   if (big_malloc(ix, reinterpret_cast<void**>(&ix->d_txt), tb) != hipSuccess || big_malloc(ix, reinterpret_cast<void**>(&ix->d_isa8), ib) != hipSuccess ||
       (sb && big_malloc(ix, reinterpret_cast<void**>(&ix->d_sa_full), sb) != hipSuccess)) {
     (void)hipGetLastError();
@@ -828,11 +869,11 @@ int build_text(femto_amd_index* ix) {
     const int64_t cn = std::min(chunk, n - r0);
     const dim3 grid{uint32_t((cn + 255) / 256)}, block{256};
     if (ix->dev.pack) {
-      if (sb) hipLaunchKernelGGL((text_isa_build_kernel<PackPolicy, true>), grid, block, 0, nullptr, ix->dev, r0, cn, ix->d_txt, ix->d_isa8, isa_shift, ix->d_sa_full);
-      else hipLaunchKernelGGL((text_isa_build_kernel<PackPolicy, false>), grid, block, 0, nullptr, ix->dev, r0, cn, ix->d_txt, ix->d_isa8, isa_shift, ix->d_sa_full);
+      if (sb) hipLaunchKernelGGL((text_isa_build_kernel<PackPolicy, true>), grid, block, 0, nullptr, ix->dev, r0, cn, ix->d_txt, ix->d_isa8, isa_shift, ix->d_sa_full, w32);
+      else hipLaunchKernelGGL((text_isa_build_kernel<PackPolicy, false>), grid, block, 0, nullptr, ix->dev, r0, cn, ix->d_txt, ix->d_isa8, isa_shift, ix->d_sa_full, w32);
     } else {
-      if (sb) hipLaunchKernelGGL((text_isa_build_kernel<Pack2Policy, true>), grid, block, 0, nullptr, ix->dev, r0, cn, ix->d_txt, ix->d_isa8, isa_shift, ix->d_sa_full);
-      else hipLaunchKernelGGL((text_isa_build_kernel<Pack2Policy, false>), grid, block, 0, nullptr, ix->dev, r0, cn, ix->d_txt, ix->d_isa8, isa_shift, ix->d_sa_full);
+      if (sb) hipLaunchKernelGGL((text_isa_build_kernel<Pack2Policy, true>), grid, block, 0, nullptr, ix->dev, r0, cn, ix->d_txt, ix->d_isa8, isa_shift, ix->d_sa_full, w32);
+      else hipLaunchKernelGGL((text_isa_build_kernel<Pack2Policy, false>), grid, block, 0, nullptr, ix->dev, r0, cn, ix->d_txt, ix->d_isa8, isa_shift, ix->d_sa_full, w32);
     }
   }
   HIP_TRY(hipGetLastError());
@@ -841,6 +882,7 @@ int build_text(femto_amd_index* ix) {
   ix->dev.isa8 = ix->d_isa8;
   ix->dev.isa_shift = isa_shift;
   ix->dev.sa_full = ix->d_sa_full;
+  ix->dev.sa32 = w32;
   ix->text_bytes = int64_t(tb + ib + sb);
   ix->table_bytes += ix->text_bytes;
   return 0;

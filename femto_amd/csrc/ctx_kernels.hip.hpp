@@ -56,7 +56,7 @@ __device__ __forceinline__ uint64_t ctx_gram(const DevIndex& ix, int64_t p, int 
 
 __device__ __forceinline__ uint64_t ctx_gram_of_row(const DevIndex& ix, int64_t row, int H, uint32_t nstop) {
   if (row < 0 || row >= ix.total_length) return 0;
-  return ctx_gram(ix, ix.sa_full[row], H, nstop);
+  return ctx_gram(ix, sa_at(ix, row), H, nstop);
 }
 
 // number of rows that start a group of equal keys (= distinct H-grams), added to *count
@@ -201,7 +201,7 @@ __device__ __forceinline__ CtxKey2 ctx_gram2(const DevIndex& ix, int64_t p, int 
 
 __device__ __forceinline__ CtxKey2 ctx_gram2_of_row(const DevIndex& ix, int64_t row, int H, uint32_t nstop) {
   if (row < 0 || row >= ix.total_length) return CtxKey2{0, 0};
-  return ctx_gram2(ix, ix.sa_full[row], H, nstop);
+  return ctx_gram2(ix, sa_at(ix, row), H, nstop);
 }
 
 __device__ __forceinline__ CtxKey2 ctx_shfl2(const CtxKey2& g, int delta, bool up) {
@@ -243,7 +243,7 @@ inline __global__ __launch_bounds__(256) void ctx2_build_kernel(const DevIndex i
       if (atomicCAS(slots + 4 * s, 0ull, static_cast<unsigned long long>(g.lo)) == 0ull) {
         slots[4 * s + 1] = g.hi;
         slots[4 * s + 2] = uint64_t(row) & kCtxFirstMask;
-        slots[4 * s + 3] = uint64_t(ix.sa_full[row]);      // the text position of the range's FIRST row (ctx2_lookup's sa_first)
+        slots[4 * s + 3] = uint64_t(sa_at(ix, row));      // the text position of the range's FIRST row (ctx2_lookup's sa_first)
         return;
       }
     }

@@ -174,7 +174,7 @@ struct DevIndex {           // passed by value to kernels
   int32_t ctx_nstop;        // dense codes below this are characters <= SEOF
   int32_t ctx_bits;         // bits per key field
   const uint64_t* ctx2;     // wide context table: {key lo, key hi, value, 0} slots, or NULL
-  int32_t ctx2_pad;
+  int32_t sa32;             // 1: sa_full and isa8 hold 4-byte entries (indexes of fewer than 2^32 - 1 rows: half the bytes; 0xffffffff = -1): sa_at / isa_at
   int32_t ctx2_syms;        // H2 > ctx_syms
   int64_t ctx2_trace_off;   // its lines follow the narrow table's in the trace region
   uint64_t ctx2_slots;      // slots of the wide table (any number: slot = high half of hash x slots)

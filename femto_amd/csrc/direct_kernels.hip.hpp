@@ -128,7 +128,7 @@ inline __global__ __launch_bounds__(256) void ktab2_deep_kernel(const DevIndex i
   const uint64_t rows = first <= last ? uint64_t(last - first + 1) : 0;
   uint64_t e = (uint64_t(first) & kDeepFirstMask) | ((rows < uint64_t(ix.kt2_deep_big) ? rows : kDeepBig) << 40);
   if (ix.kt2_sa1 && rows == 1) {
-    const int64_t p = ix.sa_full[first];
+    const int64_t p = sa_at(ix, first);
     if (p >= 0 && p < (int64_t(1) << 31)) e = kDeepOneRow | (uint64_t(p) << 31) | uint64_t(first);      // (-1: a row a damaged index could not locate)
   }
   deep[pos - ix.kt2_deep_off] = e;
@@ -190,6 +190,13 @@ __host__ __device__ inline PlanSums plan_sums_at(void* base, int64_t nblocks, bo
   int64_t* sets = sums + ((nblocks + 63) & ~int64_t(63));
   int64_t* mine = sets + (parity & 1) * w;
   return PlanSums{sums, mine, mine + ns, sets + ((parity & 1) ^ 1) * w, w, nblocks, fold ? 1 : 0};
+}
+
+// Does count_direct_kernel compare text tails inline (kDense)?  With the suffix array of every row, the text and the inverse suffix
+// array of every position -- or, on a ROW-FREE launch, without the latter: such a launch never turns a position back into a row
+// (a tail that would have to -- the text's first positions, a symbol the step itself must look at -- is not taken: the steps go on).
+__host__ __device__ inline bool inline_tail_applies(const DevIndex& d, bool row_free) {
+  return d.txt && d.sa_full && ((d.isa8 && d.isa_shift == 0) || row_free);
 }
 
 // do_string_query (src/main/server.c:713-946), one lane per pattern in the caller's order.
@@ -417,8 +424,8 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
       for (int64_t row = first; row <= last; row++) {
         int64_t p = sa_hint;
         if (!(kDense && row == first && sa_hint >= 0)) {
-          p = ix.sa_full[row];
-          trace_touch(ix, kTraceSa, uint64_t(row) >> 4);
+          p = sa_at(ix, row);
+          trace_touch(ix, kTraceSa, sa_line_of(ix, row));
         }
         if (p <= 0 || p >= ix.total_length) continue;   // (p = -1: the row could not be located, see text_isa_build_kernel)
         const int lim = p < int64_t(remaining) ? int(p) : remaining;
@@ -506,9 +513,9 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
             }
           }
         }
-        if (m > 0 && m >= best) {
-          const int64_t q2 = ix.isa8[p - m];   // isa_shift == 0: the row of every text position
-          trace_touch(ix, kTraceIsa, uint64_t(p - m) >> 4);
+        if (m > 0 && m >= best && ix.isa_shift == 0) {      // (a row-free launch on the sampled inverse suffix array: no way back to a row, the steps go on)
+          const int64_t q2 = isa_at(ix, p - m);   // isa_shift == 0: the row of every text position
+          trace_touch(ix, kTraceIsa, sa_line_of(ix, p - m));
           if (m > best) {
             best = m;
             qmin = qmax = q2;
@@ -878,8 +885,8 @@ inline __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P::k
             if (f < 0) {
               offsets[slot] = ~f;
             } else {
-              offsets[slot] = ix.sa_full[row];
-              trace_touch(ix, kTraceSa, uint64_t(row) >> 4);
+              offsets[slot] = sa_at(ix, row);
+              trace_touch(ix, kTraceSa, sa_line_of(ix, row));
             }
           } else if (f < -(int64_t(3) << 61)) {      // the position itself (kKnownPos + position)
             offsets[slot] = f - kKnownPos;
@@ -923,8 +930,8 @@ inline __global__ __launch_bounds__(256) void plan_big_rows_kernel(const int64_t
     if (end - out_starts[lo] > kExpandSerialMax) {
       const int64_t row = (first32 ? int64_t(first32[lo].x) : first[lo]) + (item - out_starts[lo]);
       if (kMode == kRowsSa) {
-        offsets[item] = ix.sa_full[row];
-        trace_touch(ix, kTraceSa, uint64_t(row) >> 4);
+        offsets[item] = sa_at(ix, row);
+        trace_touch(ix, kTraceSa, sa_line_of(ix, row));
       } else if (kMode == kRowsWalk) {
         offsets[item] = walk_row<P>(ix, row);
       } else {
@@ -939,8 +946,38 @@ inline __global__ __launch_bounds__(256) void gather_sa_kernel(const DevIndex ix
   const int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (item >= total) return;
   const int64_t row = offsets[item];
-  offsets[item] = ix.sa_full[row];
-  trace_touch(ix, kTraceSa, uint64_t(row) >> 4);
+  offsets[item] = sa_at(ix, row);
+  trace_touch(ix, kTraceSa, sa_line_of(ix, row));
+}
+
+// ONE step of the locate walk for a batch of rows (femto_amd_lf_steps_device): the unit of work a range-split index exchanges
+// walkers in (every round a GPU advances the walkers it owns by one LF step and sends each to the owner of its
+// next row, src/main/index.c:1613-1617).  off[i] = the row's text offset when it is marked (the walk ends), else -1 and
+// next[i] = LF(row) -- -1 when L[row] is a stop character (the walk cannot cross a document start, server.c:2336-2342).
+template <class P>
+inline __global__ __launch_bounds__(256) void lf_steps_kernel(const DevIndex ix, const int64_t n, const int64_t* __restrict__ rows,
+                                                       int64_t* __restrict__ next, int64_t* __restrict__ off) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t row = rows[i];
+  if (row < 0 || row >= ix.total_length) {
+    next[i] = -1;
+    off[i] = -1;
+    return;
+  }
+  uint32_t code;
+  bool marked;
+  int64_t sa_index, nx;
+  P::lf(ix, row, code, marked, sa_index, nx);
+  off[i] = marked ? mark_offset_at(ix, sa_index) : int64_t(-1);
+  next[i] = (marked || P::is_stop(ix, code)) ? int64_t(-1) : nx;
+}
+// ... from the leaf answers of femto's own tables (modes 0 / 1: block_request_kernel_lane's character, C + Occ and mark offset)
+inline __global__ __launch_bounds__(256) void lf_from_leaf_kernel(const int64_t n, const uint16_t* __restrict__ ch, const int64_t* __restrict__ occ,
+                                                           int64_t* __restrict__ next, int64_t* __restrict__ off) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  next[i] = (off[i] >= 0 || ch[i] <= uint16_t(kSEOF)) ? int64_t(-1) : occ[i] - 1;      // LF (server.c:2279-2282)
 }
 
 // locate walk (do_back_query / do_context_query, src/main/server.c:2228-2359, :2627-2795), persistent grid: the number

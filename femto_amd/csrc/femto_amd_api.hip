@@ -51,6 +51,13 @@ hipError_t query_sort(int64_t npats, const int32_t* d_plen, const uint16_t* d_pa
 
 namespace {
 thread_local std::string g_last_error;
+
+// Concurrent callers lease one scratch -- one stream -- each (api_internal.hpp), and streams that share a hardware queue run their
+// kernels one after the other: with the runtime's default of four queues, four callers' automaton batches ran as two lanes of two
+// (2.2 s for what the longest search needs 1.45 s for; with 16 queues 1.6 s, eight callers 91 k automata/s --
+// profiles/r06_regexp_concurrent.txt).  The HIP runtime reads GPU_MAX_HW_QUEUES when it initialises, so the library asks for 16
+// when it is loaded -- unless the variable is set already, and with no effect if the process has initialised HIP before.
+__attribute__((constructor)) void femto_amd_ask_for_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 }  // namespace
 
 namespace femto_amd {
@@ -254,30 +261,85 @@ hipError_t big_h2d(femto_amd_index* ix, void* p, const void* src, size_t bytes) 
 // femto's wavelet tree as segment lines (HostIndex::segs -> d_segs): the source of every derivation and the data of modes 0/1,
 // not read by the derived layouts' kernels.  A handle with a budget releases them after open (0.76 GB of a 1 GiB DNA index)
 // and uploads them again -- counted in hbm_held -- when a call needs them.
+// (round 6: the block images go and come with them -- in modes 3 / 4 only the same callers read them: LOCATION leaf requests and
+// forward steps through femto's own mark arrays; 0.55 GB of a 1 GiB DNA index, 0.6 GB of a sigma~96 one)
 int release_wavelet_lines(femto_amd_index* ix) {
-  if (!ix->d_segs || ix->split_parts > 0 || !ix->stripe_devices.empty()) return 0;
+  if ((!ix->d_segs && !ix->d_image && !ix->d_cum) || ix->split_parts > 0 || !ix->stripe_devices.empty() || ix->borrowed) return 0;
   HIP_TRY(hipDeviceSynchronize());
-  big_free(ix, ix->d_segs);
+  if (ix->d_segs) {
+    big_free(ix, ix->d_segs);
+    ix->table_bytes -= int64_t(ix->host.segs.size() * 8);
+  }
+  big_free(ix, ix->d_image);
   ix->d_segs = nullptr;
   ix->dev.segs = nullptr;
-  ix->table_bytes -= int64_t(ix->host.segs.size() * 8);
+  ix->d_image = nullptr;
+  ix->dev.image = nullptr;
+  // ... and the per-segment / per-block directories of femto's sequences (the lane kernels' cum / hint / block directory: 0.4 GB of a
+  // 1 GiB sigma~96 index), which only those same kernels read
+  auto drop_small = [&](void* p, size_t counted) {
+    if (!p) return;
+    for (size_t k = 0; k < ix->small_tables.size(); k++)
+      if (ix->small_tables[k].first == p) {
+        ix->small_tables.erase(ix->small_tables.begin() + long(k));
+        break;
+      }
+    (void)hipFree(p);
+    ix->table_bytes -= int64_t(counted);
+  };
+  drop_small(ix->d_cum, ix->host.cum.size() * sizeof(CumEntry));
+  drop_small(ix->d_hint, ix->host.hint.size() * 4);
+  drop_small(ix->d_bdir, ix->host.bdir.size() * sizeof(BlockDir));
+  ix->d_cum = nullptr;
+  ix->d_hint = nullptr;
+  ix->d_bdir = nullptr;
+  ix->dev.cum = nullptr;
+  ix->dev.hint = nullptr;
+  ix->dev.bdir = nullptr;
   ix->segs_released = true;
   ix->segs_drop_ok = true;
   return 0;
 }
 int ensure_wavelet_lines(femto_amd_index* ix) {
-  if (!ix->segs_released || ix->d_segs) return 0;
+  if (!ix->segs_released || (ix->d_segs && ix->d_image && ix->d_cum && ix->d_hint && ix->d_bdir)) return 0;
   HostIndex& h = ix->host;
-  const size_t sb = h.segs.size() * 8, slack = (size_t(h.b_size) / 511 + 4) * 128;
-  if (big_malloc(ix, reinterpret_cast<void**>(&ix->d_segs), sb + slack) != hipSuccess) {
-    (void)hipGetLastError();
-    ix->d_segs = nullptr;
-    return set_err(FEMTO_AMD_ERR_MEM, "no HBM for femto's wavelet segment lines (modes 0/1)");
+  if (!ix->d_segs) {
+    const size_t sb = h.segs.size() * 8, slack = (size_t(h.b_size) / 511 + 4) * 128;
+    if (big_malloc(ix, reinterpret_cast<void**>(&ix->d_segs), sb + slack) != hipSuccess) {
+      (void)hipGetLastError();
+      ix->d_segs = nullptr;
+      return set_err(FEMTO_AMD_ERR_MEM, "no HBM for femto's wavelet segment lines (modes 0/1)");
+    }
+    if (sb) HIP_TRY(big_h2d(ix, ix->d_segs, h.segs.data(), sb));
+    HIP_TRY(big_memset(ix, reinterpret_cast<char*>(ix->d_segs) + sb, 0, slack));
+    ix->table_bytes += int64_t(sb);
   }
-  if (sb) HIP_TRY(big_h2d(ix, ix->d_segs, h.segs.data(), sb));
-  HIP_TRY(big_memset(ix, reinterpret_cast<char*>(ix->d_segs) + sb, 0, slack));
+  if (!ix->d_image) {
+    const size_t image_slack = size_t(h.b_size) * size_t(h.text_size_bits) / 8 + 64;      // (as at open: a mark array read one bucket too far)
+    if (big_malloc(ix, reinterpret_cast<void**>(&ix->d_image), h.image.size() + image_slack) != hipSuccess) {
+      (void)hipGetLastError();
+      ix->d_image = nullptr;
+      return set_err(FEMTO_AMD_ERR_MEM, "no HBM for femto's block images (modes 0/1, LOCATION requests, forward steps)");
+    }
+    HIP_TRY(big_h2d(ix, ix->d_image, h.image.data(), h.image.size()));
+    HIP_TRY(big_memset(ix, ix->d_image + h.image.size(), 0, image_slack));
+  }
+  {      // the sequences' directories, registered with the handle's small tables like their first upload (they count against the budget)
+    struct Registry {
+      std::vector<std::pair<void*, size_t>>* old;
+      explicit Registry(std::vector<std::pair<void*, size_t>>* mine) : old(g_small_registry) { g_small_registry = mine; }
+      ~Registry() { g_small_registry = old; }
+    } reg(&ix->small_tables);
+    int r;
+    if (!ix->d_cum && (r = upload(&ix->d_cum, h.cum, &ix->table_bytes))) return r;
+    if (!ix->d_hint && (r = upload(&ix->d_hint, h.hint, &ix->table_bytes))) return r;
+    if (!ix->d_bdir && (r = upload(&ix->d_bdir, h.bdir, &ix->table_bytes, (size_t(h.b_size) / 512 + 4) * sizeof(BlockDir)))) return r;
+  }
   ix->dev.segs = ix->d_segs;
-  ix->table_bytes += int64_t(sb);
+  ix->dev.image = ix->d_image;
+  ix->dev.cum = ix->d_cum;
+  ix->dev.hint = ix->d_hint;
+  ix->dev.bdir = ix->d_bdir;
   ix->segs_released = false;
   return 0;
 }
@@ -299,7 +361,7 @@ WaveletLinesUse::~WaveletLinesUse() {
   if (!held) return;
   std::lock_guard<std::mutex> lk(ix->mu);
   if (--ix->segs_users > 0) return;
-  if (ix->segs_drop_ok && ix->mode >= 3 && ix->d_segs && ix->opt.hbm_budget_bytes >= 0 && hbm_held_all(ix) > ix->opt.hbm_budget_bytes)
+  if (ix->segs_drop_ok && ix->mode >= 3 && (ix->d_segs || ix->d_image) && ix->opt.hbm_budget_bytes >= 0 && hbm_held_all(ix) > ix->opt.hbm_budget_bytes)
     (void)release_wavelet_lines(ix);      // (waits for the device: every kernel that read them has ended)
 }
 
@@ -433,7 +495,8 @@ int launch_count_direct(femto_amd_index* ix, Scratch& S, int64_t npats, const in
   int rc;
   // full suffix array + inverse suffix array resident: the text tail is compared inline, after the wavefront's stepping
   // loop (direct_kernels.hip.hpp); with the sampled arrays the pattern is handed over to count_tail_kernel instead
-  const bool inline_tail = d.txt && d.sa_full && d.isa8 && d.isa_shift == 0;
+  // (a row-free launch needs no way back from a position to a row: the suffix array and the text are enough, inline_tail_applies)
+  const bool inline_tail = inline_tail_applies(d, plan && plan->row_free);
   const bool tail = d.txt != nullptr && !inline_tail;
   if (tail && (rc = tail_setup(ix, S, d, npats, stream))) return rc;
   if (d.txt && !tail) inline_tail_setup(ix, d);
@@ -900,6 +963,7 @@ void femto_amd_close(femto_amd_index_t* ix) {
     ix->t_resolve.destroy();
     ix->t_regexp.destroy();
     if (ix->d_doc_ends) (void)hipFree(ix->d_doc_ends);
+    if (ix->nfa_active) (void)hipHostFree(ix->nfa_active);
     (void)hipDeviceSynchronize();   // enqueue-only calls may still be running on the caller's streams
     for (auto& s : ix->pool) s->release();
     ix->pool.clear();
@@ -943,7 +1007,7 @@ int femto_amd_info(const femto_amd_index_t* ix, femto_amd_info_t* out) {
   out->chunk_size = h.chunk_size;
   out->text_size_bits = h.text_size_bits;
   out->total_buckets = h.total_buckets;
-  out->image_bytes = int64_t(h.image.size());
+  out->image_bytes = (ix->device >= 0 && !ix->d_image && ix->split_parts == 0 && ix->children.empty() && !ix->borrowed) ? 0 : int64_t(h.image.size());      // (released with the wavelet lines on a bounded handle)
   out->table_bytes = int64_t(h.nodes.size() * sizeof(DevNode) + h.buckets.size() * sizeof(DevBucket) +
                              h.seqs.size() * sizeof(DevSeq) + h.occ_base.size() * 8 + h.leaf_code.size() * 4 +
                              h.C.size() * 8 + h.segs.size() * 8 + h.cum.size() * sizeof(CumEntry) + h.hint.size() * 4 + h.bdir.size() * sizeof(BlockDir) +
@@ -1063,6 +1127,35 @@ int femto_amd_key_format(const femto_amd_index_t* ix, int* bits, int* max_syms, 
   if (max_syms) *max_syms = 63 / ix->dense_bits;
   if (field_of_alpha) memcpy(field_of_alpha, ix->h_dense.data(), std::min<size_t>(ix->h_dense.size(), size_t(kAlphaSize)));
   return FEMTO_AMD_OK;
+}
+
+int femto_amd_lf_steps_device(femto_amd_index_t* ix, int64_t n, const int64_t* d_rows, int64_t* d_next, int64_t* d_off, void* stream_) {
+  API_BEGIN
+  if (!ix || n < 0 || (n && (!d_rows || !d_next || !d_off))) return set_err(FEMTO_AMD_ERR_PARAM, "bad arguments");
+  if (n >= (int64_t(1) << 31)) return set_err(FEMTO_AMD_ERR_PARAM, "at most 2^31 - 1 rows per call");
+  int rc = ensure_device(ix);
+  if (rc) return rc;
+  if (n == 0) return FEMTO_AMD_OK;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const dim3 grid{uint32_t((n + kBlockThreads - 1) / kBlockThreads)}, block{uint32_t(kBlockThreads)};
+  if (ix->mode == 3) {
+    hipLaunchKernelGGL(lf_steps_kernel<PackPolicy>, grid, block, 0, stream, ix->dev, n, d_rows, d_next, d_off);
+  } else if (ix->mode == 4) {
+    hipLaunchKernelGGL(lf_steps_kernel<Pack2Policy>, grid, block, 0, stream, ix->dev, n, d_rows, d_next, d_off);
+  } else {      // femto's own tables (and their own marks): the leaf kernel's answers, then LF from them
+    if (!ix->host.dir_regular) return set_err(FEMTO_AMD_ERR_INVALID, "LF steps need the derived segment lines");
+    Lease L(ix, stream);
+    if (!L.s) return L.rc;
+    Scratch& S = *L.s;
+    if ((rc = S.ch.reserve(size_t(n) * 2))) return rc;
+    if ((rc = S.occ.reserve(size_t(n) * 8))) return rc;
+    hipLaunchKernelGGL(block_request_kernel_lane, grid, block, 0, stream, ix->dev, n, d_rows, static_cast<const uint16_t*>(nullptr), S.ch.as<uint16_t>(),
+                       S.occ.as<int64_t>(), d_off);
+    hipLaunchKernelGGL(lf_from_leaf_kernel, grid, block, 0, stream, n, static_cast<const uint16_t*>(S.ch.as<uint16_t>()), static_cast<const int64_t*>(S.occ.as<int64_t>()), d_next, d_off);
+  }
+  HIP_TRY(hipGetLastError());
+  return FEMTO_AMD_OK;
+  API_END
 }
 
 int femto_amd_key_table_id(const femto_amd_index_t* ix, uint64_t* id) {
@@ -1274,11 +1367,11 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
   region_lines[kTraceInd] = ix->ind_bytes / 128;
   region_lines[kTracePack] = ix->dev.pack ? (n + kPackRows - 1) / kPackRows : 0;
   region_lines[kTraceKtab] = ix->ktab2_bytes / 128 + 4;
-  region_lines[kTraceSa] = (ix->dev.sa_full ? n : ix->n_marks) / 16 + 1;
+  region_lines[kTraceSa] = ix->dev.sa_full ? n / (ix->dev.sa32 ? 32 : 16) + 1 : ix->n_marks / 16 + 1;
   region_lines[kTraceL1] = ix->p2_lines1;
   region_lines[kTraceL2] = ix->p2_lines2;
   region_lines[kTraceTxt] = ix->dev.txt ? (n + 64) / 128 + 1 : 0;
-  region_lines[kTraceIsa] = ix->dev.isa8 ? ((n >> ix->dev.isa_shift) + 2) / 16 + 1 : 0;
+  region_lines[kTraceIsa] = ix->dev.isa8 ? ((n >> ix->dev.isa_shift) + 2) / (ix->dev.sa32 ? 32 : 16) + 1 : 0;
   region_lines[kTraceCtx] = ix->ctx_bytes / 128 + ix->ctx2_bytes / 128 + ix->ctxm_bytes / 128;
   region_lines[kTraceRu] = ix->ru_bytes / 128 + 1;
   int64_t off[kTraceRegions + 1];
@@ -1320,7 +1413,7 @@ int femto_amd_trace_lines(femto_amd_index_t* ix, int64_t npats, const int32_t* d
     a.row_free = ix->trace_row_free ? 1 : 0;
     inline_tail_setup(ix, d);     // as launch_count_direct does (the hand-over case takes tail_setup's below)
     a.tail_min = d.tail_min;
-    if (d.txt && !(d.sa_full && d.isa8 && d.isa_shift == 0)) {
+    if (d.txt && !inline_tail_applies(d, a.row_free != 0)) {
       if ((r2 = tail_setup(ix, S, d, npats, st))) return r2;
       a.tail_items = d.tail_items;
       a.tail_min = d.tail_min;
@@ -1398,7 +1491,7 @@ int femto_amd_set_rank_mode(femto_amd_index_t* ix, int mode) {
   }
   ix->mode = mode;
   // ... and back on the derived layouts a bounded handle gives them up again when they put it over its budget
-  if (mode >= 3 && ix->device >= 0 && ix->segs_drop_ok && ix->d_segs && ix->segs_users == 0 && ix->opt.hbm_budget_bytes >= 0 &&
+  if (mode >= 3 && ix->device >= 0 && ix->segs_drop_ok && (ix->d_segs || ix->d_image) && ix->segs_users == 0 && ix->opt.hbm_budget_bytes >= 0 &&
       hbm_held_all(ix) > ix->opt.hbm_budget_bytes) {
     HIP_TRY(hipSetDevice(ix->device));
     if (int rc = release_wavelet_lines(ix)) return rc;
@@ -1436,6 +1529,7 @@ int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* by
   if (available && ix->dev.ctxm) *available |= ix->dev.ctxm_syms << 24;        // bits 24-28: HM of the table in between
   if (available && ix->dev.ru) *available |= 1 << 20;   // bit 20: rank units (small alphabets)
   if (available && ix->dev.ru && ix->dev.ru_marks) *available |= 1 << 21;   // bit 21: ... the marked ones (64 rows + mark bits)
+  if (available && (ix->dev.sa_full || ix->dev.isa8) && ix->dev.sa32) *available |= 1 << 22;   // bit 22: the suffix / inverse suffix arrays hold 4-byte entries
   if (available && ix->dev.sa_full) *available |= 8;  // bit 3: the full suffix array is resident
   if (available && ix->dev.isa8 && ix->dev.isa_shift == 0) *available |= 16;   // bit 4: the full inverse suffix array
   if (bytes) *bytes = ix->pack_bytes + ix->pack2_bytes;
@@ -1447,7 +1541,7 @@ int femto_amd_structures(const femto_amd_index_t* ix, int64_t* out, int n) {
   if (!ix || !out || n < 0 || n > 16) return set_err(FEMTO_AMD_ERR_PARAM, "bad argument");
   if (!ix->children.empty()) return femto_amd_structures(ix->children[0], out, n);
   int64_t v[16] = {0};
-  v[0] = int64_t(ix->host.image.size());
+  v[0] = (ix->device >= 0 && !ix->d_image && ix->split_parts == 0 && !ix->borrowed) ? 0 : int64_t(ix->host.image.size());
   v[1] = ix->dev.pack ? ix->pack_bytes - ix->marks_bytes : 0;      // (byte alphabets: the marks belong to the two-level lines)
   v[2] = ix->marks_bytes;
   v[3] = ix->ru_bytes;

@@ -75,7 +75,11 @@ struct NfaBatchDev {
   int64_t result_cap;
   unsigned long long* result_count;
   int32_t* status;           // per query
-  int32_t* iters_out;        // NULL, or per query: entries popped | cycles / 1024 | start / 1024 (FEMTO_AMD_NFA_STATS=1 prints their distribution)
+  int32_t* iters_out;        // NULL, or per query: entries popped | shader cycles / 1024 | start | duration, the last two on the device's
+                             // WALL clock in units of 16 ticks (wall_clock64: one constant-rate counter for the whole device -- the shader
+                             // clocks of the eight XCDs are not synchronised with each other) (femto_amd_nfa_stats; FEMTO_AMD_NFA_STATS=1 prints)
+  const int32_t* active;     // NULL, or a word in pinned host memory: automaton batches in flight on this handle (see "FAIR SHARE")
+  int32_t slots;             // workgroups the GPU holds of this kernel at once (what one batch alone is launched with)
   int32_t nq_all;
   int32_t warm;              // 0: do not request the next pop's rank lines ahead (FEMTO_AMD_NFA_WARM=0: experiments)
   int64_t max_iterations;    // MAX_REGEXP_ITERATIONS (src/main/server.c:40)
@@ -249,13 +253,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
   if (ntext > 64) ntext = 0;        // ("warm": byte alphabets of more than 64 characters: no guessing ahead)
   __syncthreads();
   for (;;) {
-    if (t == 0) s_q = atomicAdd(B.next, 1);
+    // FAIR SHARE.  A batch's kernel is launched with a workgroup for every slot of the GPU, and a workgroup lives until the
+    // batch's counter runs out -- which, with one search 25 x longer than the mean, is most of the kernel's time: a second
+    // caller's kernel would find no slot until then (measured, four callers: each batch started when its predecessor's short
+    // searches were done, 2.1 s for what the longest search needs 1.35 s for).  So before it takes its next automaton a
+    // workgroup looks at the number of batches in flight on the handle (one word of pinned host memory, a few hundred
+    // nanoseconds per automaton of milliseconds): with `a` of them, the workgroups beyond the first 1/a of the grid leave.
+    if (t == 0) {
+      int act = 1;
+      if (B.active) act = __builtin_nontemporal_load(B.active);
+      const bool stay = act <= 1 || int(blockIdx.x) < (B.slots + act - 1) / act;
+      s_q = stay ? atomicAdd(B.next, 1) : INT_MAX;
+    }
     __syncthreads();
     const int qi = uni(s_q);
     __syncthreads();
     if (qi >= B.nq) break;
     const int q = B.order ? B.order[qi] : qi;
     const long long t_begin = B.iters_out ? clock64() : 0;
+    const long long w_begin = B.iters_out ? wall_clock64() : 0;
     const NfaQueryDev Q = B.queries[q];
     const int N = Q.num_nodes, T = Q.num_ents, bound = Q.cost_bound;
     const bool approx = bound > 1;
@@ -749,10 +765,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P::kNfaWaves
         B.iters_out[q] = int32_t(iters < INT_MAX ? iters : INT_MAX);
         const long long now = clock64();
         B.iters_out[B.nq_all + q] = int32_t((now - t_begin) >> 10);
-        B.iters_out[2 * B.nq_all + q] = int32_t(uint32_t(uint64_t(t_begin) >> 10));
+        B.iters_out[2 * B.nq_all + q] = int32_t(uint32_t(uint64_t(w_begin) >> 4));
+        B.iters_out[3 * B.nq_all + q] = int32_t(uint32_t(uint64_t(wall_clock64() - w_begin) >> 4));
 #ifdef FEMTO_AMD_NFA_PROF
         prof_acc[prof_k] += now - prof_t;
-        for (int k = 0; k < 9; k++) atomicAdd(reinterpret_cast<unsigned long long*>(B.iters_out + 3 * B.nq_all) + k, static_cast<unsigned long long>(prof_acc[k]));
+        for (int k = 0; k < 9; k++) atomicAdd(reinterpret_cast<unsigned long long*>(B.iters_out + 4 * B.nq_all) + k, static_cast<unsigned long long>(prof_acc[k]));
 #endif
       }
     }
@@ -904,6 +921,28 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
       }
   }
   t_flat = ms_since(t_call);
+  {      // the handle's count of batches in flight: one word of pinned host memory the kernels read ("FAIR SHARE")
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (!ix->nfa_active) {
+      HIP_TRY(hipSetDevice(ix->device));
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ix->nfa_active), 64, hipHostMallocMapped));
+      *ix->nfa_active = 0;
+      void* dp = nullptr;
+      HIP_TRY(hipHostGetDevicePointer(&dp, ix->nfa_active, 0));
+      ix->nfa_active_dev = static_cast<int32_t*>(dp);
+    }
+  }
+  struct InFlight {
+    int32_t* w;
+    explicit InFlight(int32_t* p) : w(p) { __atomic_add_fetch(w, 1, __ATOMIC_RELAXED); }
+    ~InFlight() { __atomic_sub_fetch(w, 1, __ATOMIC_RELAXED); }
+  } in_flight{ix->nfa_active};
+  double wall_hz = 1e8;
+  {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ix->device) == hipSuccess && khz > 0) wall_hz = double(khz) * 1e3;
+    else (void)hipGetLastError();
+  }
   Lease L(ix);
   if (!L.s) return L.rc;
   hipStream_t st = L.s->stream;
@@ -924,7 +963,7 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   int64_t result_cap = std::max<int64_t>(std::min<int64_t>(2 * max_results, int64_t(1) << 22), 1 << 12);
   if ((rc = d_q.reserve(hq.size() * sizeof(NfaQueryDev))) || (rc = d_flags.reserve(h_flags.size() + 16)) ||
       (rc = d_sd.reserve(h_sd.size() * 4 + 16)) || (rc = d_ch.reserve(h_ch.size() * 2 + 16)) || (rc = d_bychar.reserve(h_bychar.size() * 4)) ||
-      (rc = d_misc.reserve(64 + size_t(nq) * 16 + 128)) ||
+      (rc = d_misc.reserve(64 + size_t(nq) * 20 + 128)) ||
       (rc = d_order.reserve(size_t(nq) * 4)))
     return rc;
   HIP_TRY(hipMemcpyAsync(d_q.p, hq.data(), hq.size() * sizeof(NfaQueryDev), hipMemcpyHostToDevice, st));
@@ -948,8 +987,9 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   B.result_count = d_count;
   B.status = d_status;
   const bool want_stats = getenv("FEMTO_AMD_NFA_STATS") != nullptr;
-  B.iters_out = d_status + nq;      // pops, cycles and start of every search: femto_amd_nfa_stats (three words per automaton, written once)
+  B.iters_out = d_status + nq;      // pops, cycles, start and duration of every search: femto_amd_nfa_stats (four words per automaton, written once)
   B.nq_all = int32_t(nq);
+  B.active = knob(-1, "FEMTO_AMD_NFA_FAIR", 1) != 0 ? ix->nfa_active_dev : nullptr;
   B.warm = knob(-1, "FEMTO_AMD_NFA_WARM", 1) != 0;
   B.max_iterations = ix->regexp_max_iterations;
   B.cost_stride = (max_nodes + 3) & ~3;
@@ -992,7 +1032,7 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   if ((rc = d_results.reserve(size_t(result_cap) * sizeof(NfaResultDev)))) return rc;
   B.results = d_results.as<NfaResultDev>();
   B.result_cap = result_cap;
-  HIP_TRY(hipMemsetAsync(d_misc.p, 0, 64 + size_t(nq) * 16 + 128, st));
+  HIP_TRY(hipMemsetAsync(d_misc.p, 0, 64 + size_t(nq) * 20 + 128, st));
   todo.resize(static_cast<size_t>(nq));
   for (int64_t i = 0; i < nq; i++) todo[size_t(i)] = int32_t(i);
   // LONGEST-PREDICTED-FIRST.  The workgroups take automata off one counter, and the kernel lasts as long as its longest search
@@ -1007,7 +1047,10 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
   st_pops = st_max = st_busy = st_span = st_blocks = st_late = 0;
   int64_t cap = std::min<int64_t>(1024, ix->regexp_stack_cap);
   for (int pass = 0;; pass++) {
-    int blocks = int(std::min<int64_t>(int64_t(todo.size()), int64_t(ix->num_cus) * per_cu));
+    // (a fair share of the GPU's workgroup slots when other batches are in flight on the handle: see "FAIR SHARE" in the kernel)
+    const int active_now = std::max(1, int(__atomic_load_n(ix->nfa_active, __ATOMIC_RELAXED)));
+    B.slots = int32_t(std::min<int64_t>(INT32_MAX, int64_t(ix->num_cus) * per_cu));
+    int blocks = int(std::min<int64_t>(int64_t(todo.size()), (int64_t(B.slots) + active_now - 1) / active_now));
     int64_t hsize = 64;
     while (hsize < 2 * cap) hsize <<= 1;
     const size_t per_block = (size_t(cap) * entry_bytes + size_t(hsize) * 4 + 255) & ~size_t(255);
@@ -1034,26 +1077,29 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
     if (timed) timer_end(ix, ix->t_regexp, st, te0, te1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(status.data(), d_status, size_t(nq) * 4, hipMemcpyDeviceToHost, st));
-    std::vector<int32_t> it(static_cast<size_t>(nq) * 3);
-    HIP_TRY(hipMemcpyAsync(it.data(), d_status + nq, size_t(nq) * 12, hipMemcpyDeviceToHost, st));
+    std::vector<int32_t> it(static_cast<size_t>(nq) * 4);
+    HIP_TRY(hipMemcpyAsync(it.data(), d_status + nq, size_t(nq) * 16, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    {      // what femto_amd_nfa_stats reports: pops, the span of the pass on the shader clock, how busy its workgroups were
-      uint32_t t0 = UINT32_MAX, tend = 0, late = 0;
-      double busy = 0, pops = 0, pmax = 0;
-      for (int32_t q : todo) t0 = std::min(t0, uint32_t(it[size_t(2 * nq + q)]));
+    {      // what femto_amd_nfa_stats reports: pops, the span of the pass and how busy its workgroups were, on the device's wall clock
+      // (starts are 32-bit counts of 16 ticks: differences to one of them, as signed numbers, survive the wrap)
+      const uint32_t ref = todo.empty() ? 0u : uint32_t(it[size_t(2 * nq + todo[0])]);
+      int64_t t0 = INT64_MAX, tend = INT64_MIN, late = 0;
+      double busy = 0, pops = 0, pmax = -1;
+      for (int32_t q : todo) t0 = std::min<int64_t>(t0, int32_t(uint32_t(it[size_t(2 * nq + q)]) - ref));
       for (int32_t q : todo) {
-        const uint32_t s0 = uint32_t(it[size_t(2 * nq + q)]) - t0, run = uint32_t(it[size_t(nq + q)]);
+        const int64_t s0 = int64_t(int32_t(uint32_t(it[size_t(2 * nq + q)]) - ref)) - t0, run = int64_t(uint32_t(it[size_t(3 * nq + q)]));
         busy += double(run);
         pops += double(it[size_t(q)]);
         if (double(it[size_t(q)]) > pmax) { pmax = double(it[size_t(q)]); late = s0; }
         tend = std::max(tend, s0 + run);
       }
+      const double tick_s = 16.0 / wall_hz;
       st_pops += pops;
       st_max = std::max(st_max, pmax);
-      st_busy += busy * 1024.0;
-      st_span += double(tend) * 1024.0;
+      st_busy += busy * tick_s;
+      st_span += todo.empty() ? 0.0 : double(tend) * tick_s;
       st_blocks = std::max(st_blocks, double(blocks));
-      if (pass == 0) st_late = double(late) * 1024.0;
+      if (pass == 0) st_late = double(late) * tick_s;
     }
     if (want_stats) {      // entries popped per automaton: the kernel ends with its longest search (profiles/r05_regexp_*)
       std::vector<int32_t> v;
@@ -1066,37 +1112,39 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
               pass, v.size(), blocks, v.empty() ? 0.0 : sum / double(v.size()), pct(0.5), pct(0.9), pct(0.99), pct(0.999), v.empty() ? 0 : v.back(), sum,
               sum > 0 ? double(v.empty() ? 0 : v.back()) / (sum / double(blocks)) : 0.0);
       {      // the clock: which search ended last, when it started, what a pop of it cost; how busy the workgroups were
-        uint32_t t0 = UINT32_MAX;
-        for (int32_t q : todo) t0 = std::min(t0, uint32_t(it[size_t(2 * nq + q)]));
+        const uint32_t ref = todo.empty() ? 0u : uint32_t(it[size_t(2 * nq + todo[0])]);
+        auto start_of = [&](int32_t q) { return int64_t(int32_t(uint32_t(it[size_t(2 * nq + q)]) - ref)); };
+        int64_t t0 = INT64_MAX, tend = INT64_MIN;
+        for (int32_t q : todo) t0 = std::min(t0, start_of(q));
         int32_t qlast = todo.empty() ? 0 : todo[0], qmax = qlast;
         double busy = 0;
-        uint32_t tend = 0;
         for (int32_t q : todo) {
-          const uint32_t st_ = uint32_t(it[size_t(2 * nq + q)]) - t0, en = st_ + uint32_t(it[size_t(nq + q)]);
-          busy += double(uint32_t(it[size_t(nq + q)]));
+          const int64_t en = start_of(q) - t0 + int64_t(uint32_t(it[size_t(3 * nq + q)]));
+          busy += double(uint32_t(it[size_t(3 * nq + q)]));
           if (en > tend) { tend = en; qlast = q; }
           if (it[size_t(q)] > it[size_t(qmax)]) qmax = q;
         }
+        const double tick_ms = 16e3 / wall_hz;
         auto line = [&](const char* what, int32_t q) {
-          fprintf(stderr, "[femto_amd]   %s: automaton %d, %d pops, started at %.3g Mcycles, ran %.3g Mcycles = %.0f cycles per pop\n", what, q, it[size_t(q)],
-                  double(uint32_t(it[size_t(2 * nq + q)]) - t0) * 1024e-6, double(uint32_t(it[size_t(nq + q)])) * 1024e-6,
+          fprintf(stderr, "[femto_amd]   %s: automaton %d, %d pops, started at %.2f ms, ran %.2f ms = %.0f shader cycles per pop\n", what, q, it[size_t(q)],
+                  double(start_of(q) - t0) * tick_ms, double(uint32_t(it[size_t(3 * nq + q)])) * tick_ms,
                   it[size_t(q)] ? double(uint32_t(it[size_t(nq + q)])) * 1024.0 / double(it[size_t(q)]) : 0.0);
         };
         line("ended last", qlast);
         line("most pops ", qmax);
         {
           unsigned long long ph[9];
-          HIP_TRY(hipMemcpy(ph, d_status + 4 * nq, sizeof ph, hipMemcpyDeviceToHost));
+          HIP_TRY(hipMemcpy(ph, d_status + 5 * nq, sizeof ph, hipMemcpyDeviceToHost));
           static const char* const names[9] = {"pop + final test", "deletions", "min cost + reachable characters + child list", "fan-out: rank step + pending lookup", "slots + warm",
                                                "substitutions", "children's states (groups)", "entries: link / top", "between pops (results, loop)"};
           double tot = 0;
           for (int k = 0; k < 9; k++) tot += double(ph[k]);
           for (int k = 0; k < 9 && tot > 0; k++)
             fprintf(stderr, "[femto_amd]     phase %d  %-46s %6.0f cycles per pop  %5.1f %%\n", k, names[k], sum > 0 ? double(ph[k]) / sum : 0.0, tot > 0 ? 100.0 * double(ph[k]) / tot : 0.0);
-          HIP_TRY(hipMemset(d_status + 4 * nq, 0, sizeof ph));
+          HIP_TRY(hipMemset(d_status + 5 * nq, 0, sizeof ph));
         }
-        fprintf(stderr, "[femto_amd]   all searches: %.3g Mcycles on the shader clock; busy workgroup-cycles %.3g M = %.2f of workgroups x span; mean cycles per pop %.0f\n",
-                double(tend) * 1024e-6, busy * 1024e-6, tend ? busy / (double(tend) * double(blocks)) : 0.0, sum > 0 ? busy * 1024.0 / sum : 0.0);
+        fprintf(stderr, "[femto_amd]   all searches: %.2f ms on the device's wall clock; busy workgroup-time %.1f ms = %.2f of workgroups x span; mean time per pop %.2f us\n",
+                double(tend) * tick_ms, busy * tick_ms, tend > 0 ? busy / (double(tend) * double(blocks)) : 0.0, sum > 0 ? busy * tick_ms * 1e3 / sum : 0.0);
       }
     }
     std::vector<int32_t> again;

@@ -17,6 +17,24 @@ namespace femto_amd {
 
 constexpr int kIsaShift = 3;          // sampled isa8: every 8th text position (DevIndex::isa_shift; 0 = every position)
 
+// The suffix array of every row and the inverse suffix array hold 4-BYTE entries on an index of fewer than 2^32 - 1 rows
+// (DevIndex::sa32; round 6): 4.3 + 4.3 GB instead of 8.6 + 8.6 GB at 1 GiB of text -- what lets a handle under the default
+// bound (8 x text) keep the suffix array at all, and twice the rows per line where a range's rows are read together.
+// 0xffffffff = -1 ("this row could not be located": text_isa_build_kernel on a damaged index).
+__device__ __forceinline__ int64_t sa_at(const DevIndex& ix, int64_t row) {
+  if (ix.sa32) {
+    const uint32_t v = reinterpret_cast<const uint32_t*>(ix.sa_full)[row];
+    return v == 0xffffffffu ? int64_t(-1) : int64_t(v);
+  }
+  return ix.sa_full[row];
+}
+__device__ __forceinline__ int64_t isa_at(const DevIndex& ix, int64_t i) {
+  if (ix.sa32) return int64_t(reinterpret_cast<const uint32_t*>(ix.isa8)[i]);
+  return ix.isa8[i];
+}
+// 128-byte line of entry i of either array (trace regions)
+__device__ __forceinline__ uint64_t sa_line_of(const DevIndex& ix, int64_t i) { return uint64_t(i) >> (ix.sa32 ? 5 : 4); }
+
 struct TailItem {
   uint32_t slot;      // position in the sorted batch
   int32_t done;       // symbols already searched (j)
@@ -206,8 +224,8 @@ struct IndPolicy : Pack2Policy {
 template <class P, bool kSaFull = false>
 __device__ __forceinline__ bool tail_locate(const DevIndex& ix, int64_t row, int64_t* pos, uint32_t* first_code) {
   if (kSaFull) {
-    *pos = ix.sa_full[row];
-    trace_touch(ix, kTraceSa, uint64_t(row) >> 4);
+    *pos = sa_at(ix, row);
+    trace_touch(ix, kTraceSa, sa_line_of(ix, row));
     return true;
   }
   int64_t steps = 0;
@@ -231,7 +249,8 @@ __device__ __forceinline__ bool tail_locate(const DevIndex& ix, int64_t row, int
 // positions (shift 0: all of them) and, kSa, sa_full[row] = SA[row]
 template <class P, bool kSa>
 inline __global__ __launch_bounds__(256) void text_isa_build_kernel(const DevIndex ix, const int64_t row0, const int64_t n, uint8_t* __restrict__ txt,
-                                                             int64_t* __restrict__ isa, const int isa_shift, int64_t* __restrict__ sa_full) {
+                                                             int64_t* __restrict__ isa, const int isa_shift, int64_t* __restrict__ sa_full,
+                                                             const int w32 /* 1: both arrays hold 4-byte entries */) {
   const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (row >= row0 + n) return;
   int64_t pos;
@@ -239,12 +258,21 @@ inline __global__ __launch_bounds__(256) void text_isa_build_kernel(const DevInd
   if (!tail_locate<P>(ix, row, &pos, &code) || pos < 0 || pos >= ix.total_length) {
     // an inconsistent index (an LF cycle without marks, a damaged mark array holding an offset outside the text): the row
     // reports -1 as the walk does, and nothing is written outside the arrays
-    if (kSa) sa_full[row] = -1;
+    if (kSa) {
+      if (w32) reinterpret_cast<uint32_t*>(sa_full)[row] = 0xffffffffu;
+      else sa_full[row] = -1;
+    }
     return;
   }
   txt[pos == 0 ? ix.total_length - 1 : pos - 1] = uint8_t(code);
-  if ((pos & ((int64_t(1) << isa_shift) - 1)) == 0) isa[pos >> isa_shift] = row;
-  if (kSa) sa_full[row] = pos;
+  if ((pos & ((int64_t(1) << isa_shift) - 1)) == 0) {
+    if (w32) reinterpret_cast<uint32_t*>(isa)[pos >> isa_shift] = uint32_t(row);
+    else isa[pos >> isa_shift] = row;
+  }
+  if (kSa) {
+    if (w32) reinterpret_cast<uint32_t*>(sa_full)[row] = uint32_t(pos);
+    else sa_full[row] = pos;
+  }
 }
 
 // row of the suffix starting at text position x (sampled ISA + LF walk); false near the text end or a document end
@@ -253,8 +281,8 @@ __device__ __forceinline__ bool tail_row_of(const DevIndex& ix, int64_t x, int64
   const int64_t K = int64_t(1) << ix.isa_shift;
   const int64_t s = (x + K - 1) & ~(K - 1);
   if (s >= ix.total_length) return false;
-  int64_t row = ix.isa8[s >> ix.isa_shift];
-  trace_touch(ix, kTraceIsa, uint64_t(s >> ix.isa_shift) >> 4);
+  int64_t row = isa_at(ix, s >> ix.isa_shift);
+  trace_touch(ix, kTraceIsa, sa_line_of(ix, s >> ix.isa_shift));
   for (int64_t k = s; k > x; k--) {
     uint32_t code;
     bool marked;

@@ -40,7 +40,7 @@ static DevIndex make_dev(const TraceArgs& a) {
   d.tail_count = a.flags + 2;
   d.tail_min = a.tail_min;
   d.row_free = a.row_free;
-  if (!a.tail_items && !(d.sa_full && d.isa8 && d.isa_shift == 0)) d.txt = nullptr;
+  if (!a.tail_items && !inline_tail_applies(d, a.row_free != 0)) d.txt = nullptr;
   return d;
 }
 
@@ -51,7 +51,7 @@ hipError_t traced_count_plan(const TraceArgs& a) {
   const dim3 grid{uint32_t(nblocks)}, block{256};
   hipError_t e = hipMemsetAsync(a.flags, 0, 4 * sizeof(int), a.stream);
   if (e != hipSuccess) return e;
-  const bool dense = d.txt && d.sa_full && d.isa8 && d.isa_shift == 0;   // as launch_count_direct decides
+  const bool dense = inline_tail_applies(d, a.row_free != 0);   // as launch_count_direct decides
   const bool tail = d.txt && !dense;
   const PlanSums ps = plan_sums_at(a.bsums, nblocks, !tail, a.parity);
   int* big_flag = a.flags + 1;

@@ -144,3 +144,90 @@ def open_striped_shared(path, device, socket_path, group=None, devices=None):
     dist.barrier(group=group)
     return ix, keep
 
+
+
+# ---- range-split locate by WALKER EXCHANGE -----------------------------------------------------------------
+# The other way to serve an index that is split over the GPUs by block range: instead of loading remote lines over xGMI
+# (open_range_split / open_striped_shared above), every GPU only ever touches the rows it OWNS (owner of a row =
+# row / block_size -> part, exactly bsearch_block_rows, src/main/index.c:1613-1617) and the locate walk travels: each round a
+# GPU advances its resident walkers by one LF step (femto_amd_lf_steps_device), buckets them by the owner of their next row and
+# all ranks exchange the buckets -- (query id, row, steps) records of 24 bytes, one all-to-all per round, at most mark distance
+# + 2 rounds.  A walker that reaches a marked row travels home as a result record in the same exchange.  PROTOTYPE: which of
+# the two wins on xGMI is decided by the first multi-GPU run (tools/first_multigpu.sh), not here; nothing below has run on
+# more than one physical GPU.
+
+def split_bounds(nblocks, world):
+    """block boundaries of the parts, as femto_amd_open_split draws them: part p owns blocks [b[p], b[p + 1])"""
+    return [nblocks * p // world for p in range(world + 1)]
+
+
+def owner_of_rows(rows, block_size, bounds):
+    """part owning each row: row / block_size -> the part whose block range holds it (src/main/index.c:1613-1617)"""
+    blk = torch.div(rows, block_size, rounding_mode="floor")
+    inner = torch.tensor(bounds[1:-1], dtype=torch.int64, device=rows.device)
+    return torch.bucketize(blk, inner, right=True)
+
+
+def _all_to_all_records(rec, dest, world, group=None):
+    """rec: int64 [n, 3]; dest: int64 [n] in 0 .. world-1.  Every rank receives the records addressed to it (order: by sender)."""
+    order = torch.argsort(dest, stable=True)
+    rec = rec[order].contiguous()
+    counts = torch.bincount(dest, minlength=world).to(torch.int64)
+    got = torch.empty_like(counts)
+    dist.all_to_all_single(got, counts, group=group)
+    send_split = [int(c) for c in counts.cpu()]
+    recv_split = [int(c) for c in got.cpu()]
+    out = torch.empty((sum(recv_split), 3), dtype=torch.int64, device=rec.device)
+    dist.all_to_all_single(out, rec, output_split_sizes=recv_split, input_split_sizes=send_split, group=group)
+    return out, int(sum(send_split)) * 24
+
+
+def exchange_locate(lf_step, rows, block_size, nblocks, group=None, max_rounds=4096, stats=None):
+    """Text offsets of `rows` (int64 tensor: the rows THIS rank wants located, any rows of the index) by walker exchange.
+    lf_step(rows_tensor) -> (next_rows, offsets): one step of the locate walk per row on rows this rank OWNS (offset >= 0: the
+    row is marked and its walk ends; next < 0 and offset < 0: the walk cannot go on).  Returns an int64 tensor like `rows`
+    (-1 where a walk could not finish).  stats (a dict) receives rounds, records and bytes sent by this rank."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    bounds = split_bounds(nblocks, world)
+    dev = rows.device
+    n = rows.numel()
+    result = torch.full((n,), -1, dtype=torch.int64, device=dev)
+    # records: [qid = home rank << 40 | slot, row (or the result's value), steps (or -1: this is a result travelling home)]
+    rec = torch.stack([(rank << 40) + torch.arange(n, dtype=torch.int64, device=dev), rows.to(torch.int64),
+                       torch.zeros(n, dtype=torch.int64, device=dev)], dim=1)
+    dest = owner_of_rows(rec[:, 1], block_size, bounds)
+    rounds, sent_records, sent_bytes = 0, 0, 0
+    while True:
+        live = torch.tensor([rec.shape[0]], dtype=torch.int64, device=dev)
+        dist.all_reduce(live, group=group)
+        if int(live.item()) == 0:
+            break
+        if rounds >= max_rounds:
+            raise RuntimeError("walker exchange did not end (an LF cycle without marks?)")
+        sent_records += rec.shape[0]
+        got, nbytes = _all_to_all_records(rec, dest, world, group)
+        sent_bytes += nbytes
+        rounds += 1
+        home = got[:, 2] < 0                                   # results that came home
+        if bool(home.any()):
+            r = got[home]
+            assert bool(((r[:, 0] >> 40) == rank).all())
+            result[r[:, 0] & ((1 << 40) - 1)] = r[:, 1]
+        w = got[~home]
+        if w.shape[0] == 0:
+            rec, dest = w, torch.zeros(0, dtype=torch.int64, device=dev)
+            continue
+        assert bool((owner_of_rows(w[:, 1], block_size, bounds) == rank).all()), "a walker arrived at a rank that does not own its row"
+        nxt, off = lf_step(w[:, 1].contiguous())
+        done = off >= 0
+        dead = (~done) & (nxt < 0)
+        fin = done | dead
+        res = torch.stack([w[fin, 0], torch.where(done[fin], off[fin] + w[fin, 2], torch.full_like(off[fin], -1)),
+                           torch.full((int(fin.sum()),), -1, dtype=torch.int64, device=dev)], dim=1)
+        go = torch.stack([w[~fin, 0], nxt[~fin], w[~fin, 2] + 1], dim=1)
+        rec = torch.cat([res, go], dim=0)
+        dest = torch.cat([res[:, 0] >> 40, owner_of_rows(go[:, 1], block_size, bounds)])
+    if stats is not None:
+        stats.update({"rounds": rounds, "records_sent": sent_records, "bytes_sent": sent_bytes, "world": world})
+    return result

@@ -171,6 +171,14 @@ int femto_amd_locate_device(femto_amd_index_t* ix, int64_t npats, const int32_t*
                             int64_t* d_first, int64_t* d_last, int32_t* d_noccs, int64_t* d_out_starts,
                             int64_t* d_offsets, int64_t offsets_capacity, int64_t* d_total, void* stream);
 
+/* ONE step of the locate walk (do_back_query, src/main/server.c:2228-2359) for n rows, enqueue-only: d_off[i] = the text offset of
+ * d_rows[i] when the row is marked (its walk ends here), else -1 and d_next[i] = LF(row) -- -1 when L[row] is a character <= SEOF
+ * (a walk does not cross a document start) or the row is out of range.  The unit a RANGE-SPLIT index exchanges walkers in
+ * (each round every GPU advances the walkers whose rows it owns -- owner = row / block_size,
+ * src/main/index.c:1613-1617 -- and sends each to the owner of its next row): femto_amd/parallel.py exchange_locate.  Marks are the
+ * handle's own (the derived, denser ones in modes 3 / 4; femto's in modes 0 / 1): offsets are the same either way. */
+int femto_amd_lf_steps_device(femto_amd_index_t* ix, int64_t n, const int64_t* d_rows, int64_t* d_next, int64_t* d_off, void* stream);
+
 /* resolve_location (src/main/index.c:1587) on the device, one lane per offset: d_doc[i] (int64) and / or d_doc32[i] (int32:
  * indexes of fewer than 2^31 documents) = the document holding text offset d_offsets[i], d_doc_offset[i] = the offset inside
  * it; any of the three outputs may be NULL, and d_doc_offset may be d_offsets itself (in place).  d_n != NULL: only
@@ -257,9 +265,10 @@ int femto_amd_nfa_search_batch(femto_amd_index_t* ix, int64_t nq, const femto_am
                                int64_t* result_start /* nq + 1 */, int64_t* first_out, int64_t* last_out, int32_t* len_out,
                                int32_t* cost_out, int32_t* status_out, int64_t* n_out);
 /* What the handle's last automaton batch did (the reference keeps many do_regexp_query state machines in flight,
- * src/main/server.c:3969-4001; here concurrent callers' batches share the GPU's workgroups): out8 = { automata, workgroups
- * launched, entries popped in all, ... by the longest search, busy workgroup-cycles (shader clock), the span of the search
- * passes in cycles, occupancy = busy / (span x workgroups), cycles the longest search waited before a workgroup took it }.
+ * src/main/server.c:3969-4001; here concurrent callers' batches share the GPU's workgroups, each kernel giving up its
+ * workgroups beyond a fair share between automata): out8 = { automata, workgroups launched, entries popped in all, ... by the
+ * longest search, busy workgroup-seconds, the span of the search passes in seconds (both on the device's wall clock),
+ * occupancy = busy / (span x workgroups), seconds the longest search waited before a workgroup took it }.
  * ix == NULL: the calling thread's own last batch. */
 int femto_amd_nfa_stats(femto_amd_index_t* ix, double* out8);
 /* Pattern text -> automaton.  Pattern language: femto's own (src/main/QUERY_FORMAT.txt), restated token rule by token rule
@@ -430,10 +439,12 @@ typedef struct femto_amd_options {
   int32_t rank_units;            /* the 16-byte rank units of small alphabets (ru_kernels.hip.hpp): 0 none, 1 auto, 2 plain (88 rows), 3 marked (64 rows + mark bits; auto picks them when the handle will not hold the suffix array) [FEMTO_AMD_RU] */
   int32_t marks_32bit;           /* 0: derived mark offsets stay 8 bytes; auto: 4 bytes when the index has < 2^32 rows [FEMTO_AMD_SA32] */
   int32_t context_mid_table;     /* 1: a third context table of the length half way between the other two; auto: none [FEMTO_AMD_CTXM] */
-  int32_t wavelet_lines;         /* femto's own wavelet tree as segment lines (modes 0/1; every derivation reads them): 1 keep them in HBM |
-                                  * 0 release them once the derived layouts stand (they come back, counted, when a call needs them:
-                                  * femto_amd_set_rank_mode(0/1), femto_amd_forward_steps) | auto: released on handles with a budget,
-                                  * 0.76 GB of a 1 GiB DNA index that then pays for rank units and marks  [FEMTO_AMD_WAVELET_LINES] */
+  int32_t wavelet_lines;         /* femto's OWN tables -- the block files as uploaded and its wavelet tree as segment lines (modes 0/1;
+                                  * every derivation reads them, the derived layouts' kernels do not): 1 keep them in HBM | 0 release them
+                                  * once the derived layouts stand; they come back, counted, for the calls that read them
+                                  * (femto_amd_set_rank_mode(0/1), LOCATION leaf requests, femto_amd_forward_steps) and leave again when
+                                  * they put the handle over its budget | auto: released on handles with a budget -- 1.3 GB of a 1 GiB DNA
+                                  * index that then pays for rank units, marks, the suffix array  [FEMTO_AMD_WAVELET_LINES] */
 } femto_amd_options_t;
 void femto_amd_options_init(femto_amd_options_t* opts);
 /* femto_amd_open with options (NULL = all auto = femto_amd_open) */

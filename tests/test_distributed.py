@@ -133,3 +133,85 @@ def test_bench_wire_format_world2_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _exchange_worker(rank, world, port, index_path, q):
+    """range-split locate by WALKER EXCHANGE (femto_amd/parallel.py exchange_locate) on gloo ranks: every rank
+    steps only rows it owns (the oracle's do_back_query step per row; on the GPU box femto_amd_lf_steps_device), walkers and
+    results travel in one all-to-all per round"""
+    import torch
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from femto_amd import parallel as par
+    from oracle import pyoracle as po
+    o = po.Oracle(index_path)
+    n, bs, nb = o.total_length, o.block_size, o.num_blocks
+    bounds = par.split_bounds(nb, world)
+    stepped = {"rows": 0}
+
+    def lf_step(rows):
+        nxt, off = torch.empty_like(rows), torch.empty_like(rows)
+        for i, r in enumerate(rows.tolist()):
+            assert bounds[rank] <= r // bs < bounds[rank + 1], "stepped a row this rank does not own"
+            ch, nr, of = o.back_step(r)
+            off[i] = of
+            nxt[i] = -1 if (of >= 0 or ch <= 2) else nr
+        stepped["rows"] += len(rows)
+        return nxt, off
+
+    # this rank wants a strided third of ALL rows located (most of them owned by other ranks)
+    want = torch.arange(rank, n, world * 3, dtype=torch.int64)
+    stats = {}
+    got = par.exchange_locate(lf_step, want, bs, nb, stats=stats)
+    # expected: the plain walk on one process
+    exp = []
+    for r in want.tolist():
+        steps, res = 0, -1
+        while True:
+            ch, nr, of = o.back_step(r)
+            if of >= 0:
+                res = of + steps
+                break
+            if ch <= 2 or steps > 4 * o.mark_period + 8:
+                break
+            r = nr
+            steps += 1
+        exp.append(res)
+    ok = bool(torch.equal(got, torch.tensor(exp, dtype=torch.int64))) and stats["rounds"] <= o.mark_period + 3 and stats["records_sent"] >= len(want)
+    allok = [None] * world
+    dist.all_gather_object(allok, (ok, stats, stepped["rows"]))
+    if rank == 0:
+        q.put(allok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("acgt48k", 2), ("runs3doc", 3), ("counter400_small", 2)])
+def test_walker_exchange_locate_gloo(fixtures, name, world):
+    fx = fixtures(name)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, fx.index, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(r[0] for r in res), res
+    assert all(r[2] > 0 for r in res)            # every rank stepped rows (the walkers really travelled)
+
+
+def test_owner_of_rows_matches_block_ranges():
+    """owner of a row = the part whose block range holds row / block_size (src/main/index.c:1613-1617; femto_amd_open_split's bounds)"""
+    import torch
+    from femto_amd import parallel as par
+    for nb, world, bs in ((65, 8, 1 << 27), (9, 8, 1 << 27), (3, 3, 8192), (4, 2, 16384), (1, 2, 100)):
+        b = par.split_bounds(nb, world)
+        rows = torch.arange(0, nb * bs, max(1, bs // 3), dtype=torch.int64)
+        own = par.owner_of_rows(rows, bs, b)
+        for r, p in zip(rows.tolist(), own.tolist()):
+            assert b[p] <= r // bs < b[p + 1], (nb, world, r, p, b)

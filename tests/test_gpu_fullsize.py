@@ -231,8 +231,9 @@ def test_full_size_text96_properties(tmp_path, gpu_ok):
         st, pi = bx.structures(), bx.pack_info()
         assert bx.rank_mode == 4 and pi["available2"] and not pi["char_rank_lines"], (st, pi)      # two-level lines, not the rank lines
         assert st["hbm_allocated"] <= st["hbm_budget"], st
-        if opts is None:
-            assert st["hbm_budget_is_default"] == 1 and st["hbm_allocated"] <= 9 * (1 << 30) and not pi["sa_full"], (st, pi)
+        if opts is None:      # 8 x text: femto's own tables released, femto's own marks, the 4-byte suffix array of every row and a sampled inverse
+            assert st["hbm_budget_is_default"] == 1 and st["hbm_allocated"] <= 8 * ((1 << 30) + 1) and pi["sa_full"] and pi["sa_32bit"] and not pi["isa_full"], (st, pi)
+            assert st["image"] == 0 and st["mark_every"] == 0, st
         else:
             assert st["hbm_budget"] == 32 << 30 and pi["sa_full"], (st, pi)
         bf, bl = bx.count_flat(qlen, qflat, qstarts)

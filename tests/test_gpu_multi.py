@@ -277,3 +277,82 @@ def test_bench_eight_ranks_dry_run(tmp_path, gpu_ok):
     assert len(pr) == 8 and sorted(r["rank"] for r in pr) == list(range(8)) and all(r["world_size_seen"] == 8 for r in pr)
     assert line["config"]["gathered_results_verified"] is True and line["cpu_baseline"]["bit_exact_vs_gpu"] is True
     assert all("extra" in ln for ln in lines[:-1])          # whatever precedes the headline is an `extra` line
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", ["acgt48k", "eng2doc", "runs3doc", "chunks2doc"])
+def test_lf_steps_device_walks_to_every_offset(fixtures, gpu_ok, name, mode):
+    """femto_amd_lf_steps_device (one step of do_back_query per row, the unit the walker exchange of SURVEY.md 8(e) moves): stepping
+    every row of the index until its walk ends -- offset + steps at a marked row -- gives SA[row] for every row
+    (parallel_locate_range's answer), and a first step's (offset | next row) agrees with the reference's leaf goldens: a row femto
+    marks reports femto's offset; an unmarked row's next row is C + Occ(L[row], row) - 1 unless L[row] is a stop character."""
+    import torch
+    fx = fixtures(name)
+    g = fx.gold
+    ix = _open(fx.index, mode)
+    n = ix.info.total_length
+    dev = "cuda:0"
+    rows = torch.arange(n, dtype=torch.int64, device=dev)
+    nxt, off = torch.empty_like(rows), torch.empty_like(rows)
+    ix.lf_steps_device(n, rows.data_ptr(), nxt.data_ptr(), off.data_ptr())
+    torch.cuda.synchronize()
+    n0, o0 = nxt.cpu().numpy(), off.cpu().numpy()
+    marked = g["off"] >= 0
+    assert np.array_equal(o0[marked], g["off"][marked])                       # femto's marks are marks of every mode's
+    if mode in (0, 1):
+        assert (o0[~marked] == -1).all()                                       # ... and the only ones on femto's own tables
+    want_sa = ix.locate_range(0, n - 1)
+    assert np.array_equal(o0[o0 >= 0], want_sa[o0 >= 0])
+    # the whole walk, all rows at once
+    cur, steps, res = rows.clone(), torch.zeros_like(rows), torch.full_like(rows, -1)
+    alive = torch.ones(n, dtype=torch.bool, device=dev)
+    for _ in range(4 * int(ix.info.mark_period) + 16):
+        idx = torch.nonzero(alive).flatten()
+        if idx.numel() == 0:
+            break
+        r = cur[idx].contiguous()
+        a, b = torch.empty_like(r), torch.empty_like(r)
+        ix.lf_steps_device(r.numel(), r.data_ptr(), a.data_ptr(), b.data_ptr())
+        torch.cuda.synchronize()
+        done = b >= 0
+        res[idx[done]] = b[done] + steps[idx[done]]
+        dead = (~done) & (a < 0)
+        alive[idx[done | dead]] = False
+        go = idx[~(done | dead)]
+        cur[go] = a[~(done | dead)]
+        steps[go] += 1
+    assert not bool(alive.any())
+    assert np.array_equal(res.cpu().numpy(), want_sa)
+    ix.close()
+
+
+def test_walker_exchange_one_rank_on_the_gpu(fixtures, gpu_ok):
+    """femto_amd/parallel.py exchange_locate with femto_amd_lf_steps_device as its step, one rank (every row is owned, the records of
+    every round pass through all_to_all_single): the offsets of parallel_locate_range"""
+    import torch
+    import torch.distributed as dist
+    from femto_amd import parallel as par
+    fx = fixtures("acgt48k")
+    ix = femto_amd.Index(fx.index, device=0, options=dict(dense_arrays=0))
+    own = not dist.is_initialized()
+    if own:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["MASTER_PORT"] = str(29000 + os.getpid() % 2000)
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        n = ix.info.total_length
+        rows = torch.arange(0, n, 3, dtype=torch.int64)
+
+        def lf_step(r):
+            d = r.to("cuda:0")
+            a, b = torch.empty_like(d), torch.empty_like(d)
+            ix.lf_steps_device(d.numel(), d.data_ptr(), a.data_ptr(), b.data_ptr())
+            torch.cuda.synchronize()
+            return a.cpu(), b.cpu()
+        stats = {}
+        got = par.exchange_locate(lf_step, rows, ix.info.block_size, ix.info.number_of_blocks, stats=stats)
+        assert np.array_equal(got.numpy(), ix.locate_range(0, n - 1)[::3]) and 1 <= stats["rounds"] <= ix.info.mark_period + 3
+    finally:
+        if own:
+            dist.destroy_process_group()
+        ix.close()

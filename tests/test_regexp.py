@@ -212,6 +212,41 @@ def test_nfa_search_batch_equals_reference_goldens(fixtures, name):
         ix.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["acgt48k", "eng2doc"])
+def test_concurrent_callers_share_the_workgroups(fixtures, name):
+    """Several threads call femto_amd_nfa_search_batch on ONE handle at once (the reference keeps many do_regexp_query state
+    machines in flight, src/main/server.c:3969-4001): every caller's lists equal the reference's goldens -- the batch is handed
+    out longest-predicted-first and a kernel gives up workgroups beyond its fair share between automata, and neither may change a
+    result list; femto_amd_nfa_stats reports what the calling thread's batch did."""
+    import threading
+    fx = fixtures(name)
+    cases = load_regexp_golden(name)
+    ix = femto_amd.Index(fx.index, device=0)
+    errors, stats = [], {}
+
+    def caller(t):
+        try:
+            mine = cases[t::3] + cases[:5]
+            for rep in range(3):
+                _check_batch(ix, mine, (name, "thread", t, rep))
+            stats[t] = ix.nfa_stats(thread=True)
+        except Exception as ex:      # noqa: BLE001
+            errors.append((t, repr(ex)))
+
+    th = [threading.Thread(target=caller, args=(t,)) for t in range(3)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(600)
+    assert not errors, errors
+    for t in range(3):
+        st = stats[t]
+        assert st["automata"] == len(cases[t::3]) + 5 and st["pops"] >= st["pops_longest"] > 0 and st["workgroups"] >= 1, st
+        assert 0 < st["busy_s"] and 0 < st["span_s"] < 60 and 0 < st["occupancy"] <= 1.0 + 1e-6, st
+    ix.close()
+
+
 def _random_acyclic(rng, alpha, approx):
     n = int(rng.integers(2, 12))
     ts, tc, td = [0], [], []

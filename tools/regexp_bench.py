@@ -66,7 +66,7 @@ def concurrent(args, ix, femto_amd):
     from benchlib.extras import regexp_workloads
     T = args.concurrent
     batches = [femto_amd.NfaBatch(regexp_workloads(femto_amd, args.seed + 1000 * (t + 1), 1, args.n)["approx1_motifs_16_20"]) for t in range(T)]
-    alone, clock_hz, slots = [], None, None
+    alone, slots = [], None
     for b in batches:      # each batch alone: the answers, and the shader clock (cycles of the span / the kernel's milliseconds)
         ix.kernel_time_reset()
         ix.kernel_time_enable(True)
@@ -77,8 +77,6 @@ def concurrent(args, ix, femto_amd):
         k_ms, k_n = ix.kernel_time("regexp")
         st = ix.nfa_stats()
         alone.append((r, dt, st))
-        if k_n == 1 and k_ms > 0:
-            clock_hz = st["span_cycles"] / (k_ms * 1e-3)
         slots = st["workgroups"]
         print(json.dumps({"batch": "approx1 alone", "automata": b.n, "wall_ms": 1e3 * dt, "kernel_ms": k_ms * k_n, "automata_per_s": b.n / dt, "stats": st}), flush=True)
     for rep in range(args.reps):
@@ -99,13 +97,13 @@ def concurrent(args, ix, femto_amd):
         dt = time.perf_counter() - t0
         same = all(all(np.array_equal(a, b) for a, b in zip(out[t], alone[t][0])) for t in range(T))
         assert same, "concurrent callers: result lists differ from the lists of the same batches run alone"
-        busy = sum(s["busy_cycles"] for s in stats)
-        occ = busy / (slots * dt * clock_hz) if clock_hz and slots else None
+        busy = sum(s["busy_s"] for s in stats)
+        occ = busy / (slots * dt) if slots else None      # busy workgroup-seconds of all T batches over (slots of the GPU x wall time of the T calls)
         print(json.dumps({"batch": f"approx1 x {T} concurrent callers", "rep": rep, "automata": sum(b.n for b in batches), "wall_ms": 1e3 * dt,
                           "automata_per_s": sum(b.n for b in batches) / dt, "sum_of_alone_ms": 1e3 * sum(a[1] for a in alone),
-                          "workgroup_occupancy": occ, "workgroup_slots": slots, "shader_clock_hz": clock_hz,
-                          "per_call_occupancy": [s["occupancy"] for s in stats], "longest_pops": [s["pops_longest"] for s in stats],
-                          "longest_waited_ms": [1e3 * s["longest_waited_cycles"] / clock_hz if clock_hz else None for s in stats],
+                          "longest_alone_ms": 1e3 * max(a[1] for a in alone), "workgroup_occupancy": occ, "workgroup_slots": slots,
+                          "per_call_search_span_ms": [1e3 * s["span_s"] for s in stats], "longest_pops": [s["pops_longest"] for s in stats],
+                          "longest_waited_ms": [1e3 * s["longest_waited_s"] for s in stats],
                           "equal_to_alone": same}), flush=True)
 
 
