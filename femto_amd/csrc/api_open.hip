@@ -170,7 +170,10 @@ int build_ctx(femto_amd_index* ix, int nstop) {
   const size_t free_b = hbm_free(ix);
   // (a handle with a budget: half of what is left -- by now the lines, the text and the arrays are in place and only the wide
   // table, which needs an order of magnitude more, comes after this one)
-  const int64_t budget = int64_t(free_b / (ix->opt.hbm_budget_bytes >= 0 ? 2 : 4));
+  // ... unless less than 2 GB is left: no wide table fits behind this one then, and the narrow table -- even of 5-grams -- is what
+  // the rest buys most with (cfg 3 under the default bound: K = 3 level table + two search steps -> one hashed read)
+  int64_t budget = int64_t(free_b / (ix->opt.hbm_budget_bytes >= 0 ? 2 : 4));
+  if (ix->opt.hbm_budget_bytes >= 0 && free_b < (size_t(2) << 30)) budget = int64_t(free_b) - std::min<int64_t>(int64_t(32) << 20, int64_t(free_b) / 8);
   DeviceBuffer cnt;
   int rc = cnt.reserve(8);
   if (rc) return rc;
