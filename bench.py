@@ -12,7 +12,7 @@ every pattern (count) followed by the locate walk of every matching row (max_occ
 random 20-mers on 1 GiB only ~0.1 % of the patterns occur, so the step is count-dominated, exactly
 as configs[1] describes.  `--workload acgt_hit` / `eng` run the locate-heavy configurations.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 200 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: one process per GPU, index replicated, each rank owns its own 10 M-pattern shard (weak
@@ -44,8 +44,8 @@ from benchlib.roofline import add_traffic, committed_traffic, pmc_traffic, refer
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (200 x 0.54 ms: a timed region of ~0.1 s; a 20-step window is two orders below scheduler noise)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--text-log2", type=int, default=30, help="text size = 2^k bytes (30 = BASELINE configs[1])")
     ap.add_argument("--npats", type=int, default=10_000_000, help="patterns per GPU per step")
     ap.add_argument("--plen", type=int, default=20)

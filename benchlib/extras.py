@@ -43,7 +43,7 @@ def budget_extra(c, batch, plen, ref_results, budget="4x"):
                        "no dense suffix arrays, no text tail", "structures": bix.structures(), "index": bix.pack_info()}
         pmc_opts = f"hbm_budget_bytes={budget_bytes}"
     try:
-        steps = max(5, args.steps)
+        steps = max(5, min(args.steps, 100))
         el, (c_ms, c_n), (l_ms, _) = timed_steps(torch, bix, batch, args.max_occs, stream, steps)
         first, last, noccs, ost, offs = ref_results
         same = bool(np.array_equal(batch.d_res[0].cpu().numpy(), first) and np.array_equal(batch.d_res[1].cpu().numpy(), last)
@@ -224,7 +224,7 @@ def keys_extra(c, ix, batch, ref_results):
     torch.cuda.synchronize()
     ix.kernel_time_reset()
     ix.kernel_time_enable(True)
-    ksteps = max(3, args.steps)
+    ksteps = max(3, min(args.steps, 100))
     t0 = time.perf_counter()
     for _ in range(ksteps):
         kstep()
@@ -370,10 +370,11 @@ def cfg3_extra(c, world):
         ep, ef = tg.p_hit(8, 64, npats, args.seed + 3000, e_text)
         del e_text
         eb = Batch(torch, dev, ep, ef)
-        ee, (e_cnt, e_n), (e_loc, _) = timed_steps(torch, eix, eb, args.max_occs, stream, 3)
+        e_steps = max(3, min(args.steps, 20))
+        ee, (e_cnt, e_n), (e_loc, _) = timed_steps(torch, eix, eb, args.max_occs, stream, e_steps)
         out = {"workload": f"T_eng(2^{args.text_log2}) sigma~96 index, {npats} sampled patterns of length 8..64, count()+locate(max_occs={args.max_occs})",
                "rank_mode": {4: "pack2", 3: "pack", 1: "lane", 0: "raw"}[eix.rank_mode],
-               "value": npats * 3 / ee, "unit": "patterns/s", "ms_per_step": 1e3 * ee / 3, "located_rows": eb.total,
+               "value": npats * e_steps / ee, "unit": "patterns/s", "ms_per_step": 1e3 * ee / e_steps, "steps": e_steps, "located_rows": eb.total,
                "count_kernel_ms": e_cnt, "locate_kernel_ms": e_loc}
         # ---- bit-check inside the bench, like the headline's: the first 100 k patterns of the timed batch
         try:
@@ -442,7 +443,7 @@ def cfg3_extra(c, world):
             eb.step(eix, args.max_occs, stream)
             torch.cuda.synchronize()
             eb.total = int(eb.d_total[0].item())
-            rf = row_free_steps(torch, eix, eb, args.max_occs, stream, 3)
+            rf = row_free_steps(torch, eix, eb, args.max_occs, stream, e_steps)
             eix.set_option("trace_row_free", 1)
             try:
                 rr, _, _, rcomp, _ = roofline_block(eix, eix.rank_mode in (3, 4), eb, npats, ep, args.max_occs, rf["count_kernel_ms"], rf["locate_kernel_ms"], e_n)
@@ -460,10 +461,11 @@ def cfg3_extra(c, world):
         try:
             dix = femto_amd.Index(e_path, device=local_rank)
             try:
-                de, (d_cnt, _), (d_loc, _) = timed_steps(torch, dix, eb, args.max_occs, stream, 3)
-                d = {"what": "the same index and batch on a handle opened with plain femto_amd_open (the default bound)", "value": npats * 3 / de, "unit": "patterns/s",
-                     "ms_per_step": 1e3 * de / 3, "count_kernel_ms": d_cnt, "locate_kernel_ms": d_loc, "structures": dix.structures(), "index": dix.pack_info()}
-                d["row_free"] = row_free_steps(torch, dix, eb, args.max_occs, stream, 3)
+                d_steps = max(3, min(args.steps, 5))
+                de, (d_cnt, _), (d_loc, _) = timed_steps(torch, dix, eb, args.max_occs, stream, d_steps)
+                d = {"what": "the same index and batch on a handle opened with plain femto_amd_open (the default bound)", "value": npats * d_steps / de, "unit": "patterns/s",
+                     "ms_per_step": 1e3 * de / d_steps, "count_kernel_ms": d_cnt, "locate_kernel_ms": d_loc, "structures": dix.structures(), "index": dix.pack_info()}
+                d["row_free"] = row_free_steps(torch, dix, eb, args.max_occs, stream, d_steps)
                 out["default_open"] = d
             finally:
                 dix.close()

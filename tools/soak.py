@@ -12,6 +12,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import femto_amd  # noqa: E402
 from femto_amd import textgen as tg  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+import gpu_common as gc  # noqa: E402  (device_locate, assert_row_free_equals)
 
 
 def one(seed, root):
@@ -74,7 +76,20 @@ def one(seed, root):
         assert np.array_equal(nn, on) and np.array_equal(offs, oo), (seed, mode, params, "locate")
         ch, occ, off = ix.block_requests(rows)
         assert [(int(a), int(b), int(c)) for a, b, c in zip(ch, occ, off)] == want, (seed, mode, "leaf")
+        # the one-call device chain, with rows and row-free (noccs + offsets as parallel_locate returns them)
+        df, dl, dn, dst, do, dtot = gc.device_locate(ix, plen, flat, starts, mo, len(oo) + 16)
+        assert dtot == len(oo) and np.array_equal(df, of) and np.array_equal(dl, ol) and np.array_equal(dn, on) and np.array_equal(do, oo), (seed, mode, "device chain")
+        gc.assert_row_free_equals(ix, plen, flat, starts, mo, on, oo, (seed, mode, "row-free"))
     ix.close()
+    for kw in (dict(dense_arrays=0), dict(hbm_budget_bytes=int(3 * n)), dict(hbm_budget_bytes=int(8 * n)), dict(tail_min=2, tail_ones=0)):      # sampled arrays, budgets, eager tails
+        bx = femto_amd.Index(path, device=0, options=kw)
+        if bx.rank_mode in (3, 4):
+            f, l_ = bx.count_flat(plen, flat, starts)
+            assert np.array_equal(f, of) and np.array_equal(l_, ol), (seed, kw, "count")
+            gc.assert_row_free_equals(bx, plen, flat, starts, mo, on, oo, (seed, kw, "row-free"))
+            df, dl, dn, dst, do, dtot = gc.device_locate(bx, plen, flat, starts, mo, len(oo) + 16)
+            assert dtot == len(oo) and np.array_equal(df, of) and np.array_equal(dl, ol) and np.array_equal(do, oo), (seed, kw, "device chain")
+        bx.close()
     if seed % 4 == 0:     # range-split three ways in this process: every part answers like the whole index
         parts = [femto_amd.Index(path, device=0, part=p_, nparts=3) for p_ in range(3)]
         for a in parts:
