@@ -39,7 +39,7 @@ if has regexp; then
   python tools/summarize_regexp.py $O > $O/summary.txt 2>&1
   cat $O/summary.txt | cut -c1-220
   for T in 4 8; do
-    python tools/regexp_bench.py --which approx --reps 2 --concurrent $T 2>/dev/null | grep -v '"rep"' > $O/concurrent_$T.json
+    python tools/regexp_bench.py --which approx --reps 2 --concurrent $T 2>/dev/null | grep -v nodes_avg > $O/concurrent_$T.json
     GPU_MAX_HW_QUEUES=4 python tools/regexp_bench.py --which approx --reps 1 --concurrent $T 2>/dev/null | grep concurrent > $O/concurrent_${T}_4queues.json
     FEMTO_AMD_NFA_FAIR=0 python tools/regexp_bench.py --which approx --reps 1 --concurrent $T 2>/dev/null | grep concurrent > $O/concurrent_${T}_nofair.json
   done

@@ -42,7 +42,7 @@ def main():
             if keep:
                 out.append(ln)
         open(os.path.join(ROOT, "profiles", f"{tag}_stats.txt"), "w").write("\n".join(out) + "\n")
-        if tag.endswith("_default"):
+        if tag.split("_", 1)[-1] == "default":      # (rNN_default only: not rNN_eng_default)
             pmc = json.load(open(os.path.join(src, "pmc_summary.json")))
             d = json.loads(line)
             kname = d["roofline"]["kernel"]
