@@ -1,15 +1,10 @@
 set -u
 SECONDS=0
 export TMPDIR=/tmp
-O=gpurun_out/r06_regexp; mkdir -p $O
-for T in 4 8; do
-  python tools/regexp_bench.py --which approx --reps 2 --concurrent $T 2>/dev/null | grep -v nodes_avg > $O/concurrent_$T.json
-  grep concurrent $O/concurrent_$T.json | cut -c1-400
+for i in 1 2; do
+  echo "fair"; python tools/regexp_bench.py --which approx --reps 1 --concurrent 8 2>/dev/null | grep concurrent | cut -c1-330
+  echo "nofair"; FEMTO_AMD_NFA_FAIR=0 python tools/regexp_bench.py --which approx --reps 1 --concurrent 8 2>/dev/null | grep concurrent | cut -c1-330
 done
-echo "regexp $SECONDS s"
-bash tools/budget_sweep_eng.sh > gpurun_out/r06_budget_sweep_eng.log 2>&1
-cat gpurun_out/r06_budget_sweep_eng.log | cut -c1-260
-echo "eng sweep $SECONDS s"
-bash tools/budget_sweep.sh > gpurun_out/r06_budget_sweep.log 2>&1
-cat gpurun_out/r06_budget_sweep.log | cut -c1-260
+echo "ab $SECONDS s"
+bash tools/final_round_r06.sh cfg5
 echo "all $SECONDS s"
