@@ -10,8 +10,8 @@
  * Conventions kept from the reference:
  *   - patterns are arrays of alpha_t (uint16_t) = byte + 5 (src/main/index_types.h:61-69);
  *   - every function returns an err_code_t value (src/utils/error.h:25-39), 0 = OK;
- *   - calls are blocking; a handle may be used from several host threads (calls on one handle are
- *     serialised internally);
+ *   - calls are blocking; a handle may be used from several host threads at once (every call leases a
+ *     scratch and a stream of its own from the handle: concurrent calls overlap on the GPU);
  *   - results are bit-exact with parallel_count / parallel_locate on the same index files.
  *
  * All compute runs in hand-written HIP kernels on the GPU; there is NO CPU fallback: if no HIP
@@ -478,7 +478,7 @@ int femto_amd_set_option(femto_amd_index_t* ix, const char* name, int value);
 /* What was derived (diagnostics; femto_amd/__init__.py pack_info() names every bit): *available bit 0 packed lines, 1 two-level lines,
  * 2 level table, 3 suffix array of every row, 4 inverse suffix array of every position, 5 per-character rank lines, 6 context table,
  * bits 8..11 / 12..16 / 24..28 the context tables' symbol counts, bit 20 rank units, bit 21 the MARKED rank units (64 rows + mark
- * bits: handles that walk to marks). */
+ * bits: handles that walk to marks), bit 22 the suffix / inverse suffix arrays hold 4-byte entries (indexes of fewer than 2^32 - 1 rows). */
 int femto_amd_pack_info(const femto_amd_index_t* ix, int* available, int64_t* bytes, double* build_ms, int* ktab_syms);
 /* What the handle holds in HBM, in bytes -- the server's "what may a handle spend" made visible (the counterpart of
  * server_settings_t's cache sizes, src/main/server.c:3484-3602): out[0] the femto block files as uploaded, [1] packed lines,
