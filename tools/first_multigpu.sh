@@ -50,7 +50,8 @@ for N in (1, 2, 4, 8):
             continue
         if N == 1 and g == "replicated":
             t1 = d["ms_per_step"]
-        eff = (t1 / d["ms_per_step"]) if t1 else None      # weak scaling: per-GPU work fixed, so T1 / TN
+        dry = "16 MiB" in json.dumps(d["config"].get("index", {})) or d["config"].get("text_bytes", 1 << 30) < (1 << 30)
+        eff = (t1 / d["ms_per_step"]) if (t1 and not dry) else None      # weak scaling: per-GPU work fixed, so T1 / TN (dry runs on a shared GPU: no figure)
         pr = d["config"].get("per_rank") or []
         print(N, g, round(d["value"] / 1e9, 2), round(d["ms_per_step"], 3), None if eff is None else round(eff, 3), d["config"].get("gathered_results_verified"),
               [(round(r["search_ms_per_step"], 3), round(r["gather_stall_ms_per_step"], 3), round(r["gather_payload_bytes"] / 1e6, 1)) for r in pr])
@@ -58,10 +59,10 @@ PY
 if [ "$NG" -ge 2 ]; then
   for N in 2 4 8; do [ "$N" -le "$NG" ] || continue
     python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29700 + N)) tools/exchange_bench.py > $O/exchange_n$N.json 2> $O/exchange_n$N.err
-    tail -1 $O/exchange_n$N.json | cut -c1-600
+    grep '^{' $O/exchange_n$N.json | tail -1 | cut -c1-600
   done
 else
-  python tools/exchange_bench.py --npats 500000 > $O/exchange_n1.json 2> $O/exchange_n1.err; tail -1 $O/exchange_n1.json | cut -c1-600
+  python tools/exchange_bench.py --npats 500000 > $O/exchange_n1.json 2> $O/exchange_n1.err; grep '^{' $O/exchange_n1.json | tail -1 | cut -c1-600
 fi
 if [ "$CFG5" = 1 ]; then
   for L in replicated split striped; do
