@@ -313,6 +313,11 @@ def test_full_size_8gib_properties(tmp_path, gpu_ok):
     gn, go = ix.locate_flat(p2, f2, s2, 100)
     on, oo = o.locate_flat(p2, f2, s2, 100, threads=16)
     assert np.array_equal(gn, on) and np.array_equal(go, oo)
+    # the row-free form (femto_amd_locate_device without row arrays) where suffix-array entries are 8 bytes and positions pass 2^32:
+    # located by the text compare itself, a mismatching tail ends its pattern without a row
+    assert not ix.pack_info()["sa_32bit"] and ix.pack_info()["sa_full"]
+    assert_row_free_equals(ix, plen, flat, starts, 100, noccs, offs, "8 GiB, sampled 20-mers")
+    assert_row_free_equals(ix, p2, f2, s2, 100, gn, go, "8 GiB, random + sampled 20-mers")
     # wavelet path on the same handle
     m = 50_000
     ix.set_rank_mode(1)
@@ -332,6 +337,8 @@ def test_full_size_8gib_properties(tmp_path, gpu_ok):
     assert dtot == len(offs) and np.array_equal(df, first) and np.array_equal(dl, last) and np.array_equal(dn, noccs) and np.array_equal(do, offs)
     bn, bo = bx.locate_flat(plen[:m], flat, starts[:m], 100)
     assert np.array_equal(bn, noccs[:m]) and np.array_equal(bo, offs[:int(noccs[:m].sum())])
+    assert_row_free_equals(bx, plen, flat, starts, 100, noccs, offs, "8 GiB default handle, sampled 20-mers")
+    assert_row_free_equals(bx, p2, f2, s2, 100, gn, go, "8 GiB default handle, random + sampled 20-mers")
     bx.close()
     # range-split in two parts (both on this GPU): part p keeps blocks [65p/2, 65(p+1)/2) and reads the rest from its peer
     parts = [femto_amd.Index(path, device=0, part=p, nparts=2) for p in range(2)]
@@ -346,5 +353,6 @@ def test_full_size_8gib_properties(tmp_path, gpu_ok):
         assert np.array_equal(fs, first[:m]) and np.array_equal(ls, last[:m])
         ns, os_ = a.locate_flat(plen[:m], flat, starts[:m], 100)
         assert np.array_equal(ns, noccs[:m]) and np.array_equal(os_, offs[:int(noccs[:m].sum())])
+        assert_row_free_equals(a, plen[:m], flat, starts[:m], 100, noccs[:m], offs[:int(noccs[:m].sum())], "8 GiB range-split part")
     for a in parts:
         a.close()
