@@ -1,4 +1,4 @@
-"""`-m gpu`: BASELINE.json's configurations at FULL size (1 GiB ACGT, 1 GiB sigma~96, 8 GiB ACGT): size-independent
+"""`-m gpu`: BASELINE.json's configurations at FULL size (1 GiB ACGT, 1 GiB sigma~96, 8 GiB ACGT) and three sizes between them: size-independent
 properties, the table paths against femto's own wavelet tree on whole batches and against the oracle on tens of thousands of
 patterns -- hits, misses and dead ranges' (first, last)."""
 import ctypes as C
@@ -256,6 +256,99 @@ def test_full_size_text96_properties(tmp_path, gpu_ok):
         assert dtot == len(offs) and np.array_equal(df, first) and np.array_equal(dl, last) and np.array_equal(dn, noccs) and np.array_equal(do, offs)
         assert_row_free_equals(bx, qlen, qflat, qstarts, 100, n4, o4, ("hit / miss batch", opts))
         assert_row_free_equals(bx, plen, flat, starts, 20, noccs, offs, ("sampled batch", opts))
+        bx.close()
+
+
+@pytest.mark.parametrize("kind,n", [("acgt", (1 << 31) - 1), ("acgt", (3 << 30) - 7), ("eng", (5 << 29) + 3)])
+def test_four_byte_suffix_arrays_between_2_and_4_gib(tmp_path, gpu_ok, kind, n):
+    """Round 6 keeps suffix-array / inverse entries in 4 bytes below 2^32 - 1 rows (`sa_at` / `isa_at`, 0xffffffff = none) and lets
+    one-row level-table entries carry `SA[first]` in 31-bit fields up to 2^31 rows.  The 1 GiB tests above only see positions below
+    2^30 and the 8 GiB test runs on 8-byte entries, so: (a) a text of 2^31 - 1 bytes = 2^31 rows exactly, the largest index whose table
+    entries carry positions; (b) 3 GiB of DNA and (c) 2.5 GiB of the sigma~96 text (sizes that are no power of two: a ragged last bucket),
+    where half of the located positions need bit 31 of a 4-byte entry.  Size-independent properties, femto's own wavelet tree (mode 1:
+    no derived array, offsets from femto's marks) on every pattern, the oracle on 10 000, the row-free form, bounded handles."""
+    eng = kind == "eng"
+    text = tg.t_eng_torch(n, 616, "cuda:0") if eng else tg.t_acgt(n, 616 + (n & 1))
+    assert len(text) == n
+    path = str(tmp_path / f"{kind}_{n}")
+    femto_amd.build_index(path, [text], params=None, infos=["mid"], device=0)
+    ix = femto_amd.Index(path, device=0, options=dict(hbm_budget_bytes=femto_amd.BUDGET_ALL))
+    pi = ix.pack_info()
+    assert ix.info.total_length == n + 1 and ix.rank_mode == (4 if eng else 3) and pi["sa_full"] and pi["isa_full"] and pi["sa_32bit"], pi
+    npat, mo = 300_000, (20 if eng else 100)
+    plen, flat = tg.p_hit(8, 64, npat, 31, text) if eng else tg.p_hit(20, 20, npat, 31, text)
+    starts = tg.starts_of(plen)
+    first, last = ix.count_flat(plen, flat, starts)
+    cnt = last - first + 1
+    assert (cnt >= 1).all()
+    noccs, offs = ix.locate_flat(plen, flat, starts, mo)
+    assert np.array_equal(noccs, np.minimum(cnt, np.where(cnt - 1 > mo, mo, cnt)))
+    if n > (1 << 31):
+        assert (offs >= (1 << 31)).mean() > 0.2 and offs.max() < n       # bit 31 of a 4-byte entry really is in play
+    owner = np.repeat(np.arange(npat), noccs)
+    for k in range(8):                                   # the first 8 symbols of every located occurrence, and the last one
+        assert np.array_equal(text[offs + k].astype(np.uint16) + 5, flat[starts[owner] + k]), k
+    tail = plen[owner] - 1
+    assert np.array_equal(text[offs + tail].astype(np.uint16) + 5, flat[starts[owner] + tail])
+    # patterns that mostly do not occur: random ones, and sampled ones with one symbol substituted (they die in the table, the rank
+    # steps or the text tail)
+    rng = np.random.Generator(np.random.PCG64(5))
+    alphabet = np.flatnonzero(np.bincount(text[:1 << 26], minlength=256)).astype(np.uint16) + 5
+    nmiss = 100_000
+    rlen = rng.integers(8, 65, nmiss).astype(np.int32) if eng else np.full(nmiss, 20, dtype=np.int32)
+    rflat = alphabet[rng.integers(0, len(alphabet), int(rlen.sum()))].astype(np.uint16)
+    mlen, mflat = tg.p_hit(8, 64, nmiss, 32, text) if eng else tg.p_hit(20, 20, nmiss, 32, text)
+    mstarts = tg.starts_of(mlen)
+    mflat = mflat.copy()
+    mflat[mstarts + rng.integers(0, 1 << 30, nmiss) % mlen] = alphabet[rng.integers(0, len(alphabet), nmiss)]
+    qlen = np.concatenate([rlen, mlen])
+    qflat = np.concatenate([rflat, mflat])
+    qstarts = tg.starts_of(qlen)
+    qf, ql = ix.count_flat(qlen, qflat, qstarts)
+    qn, qo = ix.locate_flat(qlen, qflat, qstarts, 100)
+    assert (ql < qf).mean() > 0.5
+    # femto's own wavelet tree on the same handle: every pattern of both batches, dead ranges' (first, last) included
+    ix.set_rank_mode(1)
+    f1, l1 = ix.count_flat(plen, flat, starts)
+    n1, o1 = ix.locate_flat(plen, flat, starts, mo)
+    assert np.array_equal(f1, first) and np.array_equal(l1, last) and np.array_equal(n1, noccs) and np.array_equal(o1, offs)
+    f1, l1 = ix.count_flat(qlen, qflat, qstarts)
+    n1, o1 = ix.locate_flat(qlen, qflat, qstarts, 100)
+    assert np.array_equal(f1, qf) and np.array_equal(l1, ql) and np.array_equal(n1, qn) and np.array_equal(o1, qo)
+    ix.set_rank_mode(4 if eng else 3)
+    # the oracle on 5 000 + 5 000
+    o = po.Oracle(path)
+    m = 5000
+    of, ol = o.count_flat(plen[:m], flat, starts[:m], threads=16)
+    on, oo = o.locate_flat(plen[:m], flat, starts[:m], mo, threads=16)
+    assert np.array_equal(of, first[:m]) and np.array_equal(ol, last[:m]) and np.array_equal(on, noccs[:m]) and np.array_equal(oo, offs[:int(noccs[:m].sum())])
+    pick = np.concatenate([np.arange(0, m // 2), np.arange(nmiss, nmiss + m // 2)])
+    sub_len = qlen[pick]
+    sub_flat = np.concatenate([qflat[qstarts[i]:qstarts[i] + qlen[i]] for i in pick])
+    sub_starts = tg.starts_of(sub_len)
+    of, ol = o.count_flat(sub_len, sub_flat, sub_starts, threads=16)
+    on, oo = o.locate_flat(sub_len, sub_flat, sub_starts, 100, threads=16)
+    q_st = np.concatenate([[0], np.cumsum(qn)])
+    assert np.array_equal(of, qf[pick]) and np.array_equal(ol, ql[pick]) and np.array_equal(on, qn[pick])
+    assert np.array_equal(oo, np.concatenate([qo[q_st[i]:q_st[i + 1]] for i in pick]))
+    # the one-call device chain with rows and row-free (positions from table entries / the text compare itself)
+    df, dl, dn, dst, do, dtot = device_locate(ix, plen, flat, starts, mo, len(offs) + 16)
+    assert dtot == len(offs) and np.array_equal(df, first) and np.array_equal(dl, last) and np.array_equal(dn, noccs) and np.array_equal(do, offs)
+    assert_row_free_equals(ix, plen, flat, starts, mo, noccs, offs, (kind, n, "sampled"))
+    assert_row_free_equals(ix, qlen, qflat, qstarts, 100, qn, qo, (kind, n, "miss"))
+    ix.close()
+    # bounded handles: the library's default (8 x text), 16 x text, and sampled arrays on everything else
+    for opts in (None, dict(hbm_budget_bytes=16 * n), dict(hbm_budget_bytes=femto_amd.BUDGET_ALL, dense_arrays=0)):
+        bx = femto_amd.Index(path, device=0, options=opts) if opts else femto_amd.Index(path, device=0)
+        st = bx.structures()
+        assert st["hbm_budget"] < 0 or st["hbm_allocated"] <= st["hbm_budget"], (opts, st)      # (-1: everything free)
+        bf, bl = bx.count_flat(qlen, qflat, qstarts)
+        bn, bo = bx.locate_flat(qlen, qflat, qstarts, 100)
+        assert np.array_equal(bf, qf) and np.array_equal(bl, ql) and np.array_equal(bn, qn) and np.array_equal(bo, qo), opts
+        df, dl, dn, dst, do, dtot = device_locate(bx, plen, flat, starts, mo, len(offs) + 16)
+        assert dtot == len(offs) and np.array_equal(df, first) and np.array_equal(dl, last) and np.array_equal(dn, noccs) and np.array_equal(do, offs), opts
+        assert_row_free_equals(bx, plen, flat, starts, mo, noccs, offs, (kind, n, "sampled", opts))
+        assert_row_free_equals(bx, qlen, qflat, qstarts, 100, qn, qo, (kind, n, "miss", opts))
         bx.close()
 
 
