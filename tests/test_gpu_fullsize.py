@@ -432,6 +432,29 @@ def test_full_size_8gib_properties(tmp_path, gpu_ok):
     assert np.array_equal(bn, noccs[:m]) and np.array_equal(bo, offs[:int(noccs[:m].sum())])
     assert_row_free_equals(bx, plen, flat, starts, 100, noccs, offs, "8 GiB default handle, sampled 20-mers")
     assert_row_free_equals(bx, p2, f2, s2, 100, gn, go, "8 GiB default handle, random + sampled 20-mers")
+    # femto_amd_lf_steps_device (the walker exchange's unit) where rows and offsets pass 2^32: 50 000 rows stepped until each
+    # walk ends at a mark give SA[row] -- the first offset of their patterns
+    import torch
+    cur = torch.from_numpy(first[:m].copy()).to("cuda:0")
+    assert int(cur.max()) > (1 << 32)
+    res, steps = torch.full_like(cur, -1), torch.zeros_like(cur)
+    idx = torch.arange(m, device="cuda:0")
+    for _ in range(4 * int(bx.info.mark_period) + 64):
+        if idx.numel() == 0:
+            break
+        r = cur[idx].contiguous()
+        a, b = torch.empty_like(r), torch.empty_like(r)
+        bx.lf_steps_device(r.numel(), r.data_ptr(), a.data_ptr(), b.data_ptr())
+        torch.cuda.synchronize()
+        done = b >= 0
+        res[idx[done]] = b[done] + steps[idx[done]]
+        assert bool((a[~done] >= 0).all())              # (a walk from a pattern's row never meets the text's start before a mark here)
+        cur[idx[~done]] = a[~done]
+        steps[idx[~done]] += 1
+        idx = idx[~done]
+    assert idx.numel() == 0
+    o_st = np.concatenate([[0], np.cumsum(noccs[:m].astype(np.int64))])[:-1]
+    assert np.array_equal(res.cpu().numpy(), offs[o_st])
     bx.close()
     # range-split in two parts (both on this GPU): part p keeps blocks [65p/2, 65(p+1)/2) and reads the rest from its peer
     parts = [femto_amd.Index(path, device=0, part=p, nparts=2) for p in range(2)]

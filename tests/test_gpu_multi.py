@@ -10,7 +10,7 @@ import pytest
 import femto_amd
 from conftest import INDEX_FIXTURES
 from femto_amd import textgen as tg
-from gpu_common import MODES, _open, _set_mode, _torchrun
+from gpu_common import MODES, _open, _set_mode, _torchrun, assert_row_free_equals, device_locate
 from oracle import pyoracle as po
 
 pytestmark = pytest.mark.gpu
@@ -96,6 +96,26 @@ def test_striped_index_over_devices(fixtures, gpu_ok, name):
     ch, occ, off = ix.block_requests(np.arange(rows, dtype=np.int64))
     assert np.array_equal(ch, g["L"]) and np.array_equal(occ, g["occ"]) and np.array_equal(off, g["off"])
     single.close()
+    ix.close()
+
+
+@pytest.mark.parametrize("striped", [False, True])
+@pytest.mark.parametrize("name", ["acgt48k", "eng2doc", "runs3doc"])
+def test_device_chain_through_replicas_and_views(fixtures, gpu_ok, name, striped):
+    """What `bench.py --gpus N` calls on every rank: femto_amd_locate_device on replica / view i of a multi-device handle
+    (femto_amd_multi_child) -- with rows and in the row-free form (noccs + offsets, as parallel_locate returns them) -- for a replicated
+    handle and for one whose big arrays are striped over the devices' HBM.  Goldens for every clamp."""
+    fx = fixtures(name)
+    g = fx.gold
+    ix = femto_amd.Index(fx.index, devices=[0, 0, 0], striped=striped)
+    plen, flat, starts = fx.patterns
+    for i in range(3):
+        v = ix.child(i)
+        for mo, g_noccs, g_offs in fx.locate_cases():
+            df, dl, dn, dst, do, dtot = device_locate(v, plen, flat, starts, mo, len(g_offs) + 16)
+            assert dtot == len(g_offs) and np.array_equal(dn, g_noccs) and np.array_equal(do, g_offs), (i, mo)
+            assert np.array_equal(df, g["count_first"]) and np.array_equal(dl, g["count_last"]), (i, mo)
+            assert_row_free_equals(v, plen, flat, starts, mo, g_noccs, g_offs, (name, striped, i, mo))
     ix.close()
 
 
