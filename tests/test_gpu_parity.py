@@ -547,6 +547,77 @@ def test_released_wavelet_lines_come_back(fixtures, gpu_ok, name):
     kept.close()
 
 
+@pytest.mark.parametrize("name", ["acgt48k", "eng2doc"])
+def test_released_lines_under_concurrent_callers(fixtures, gpu_ok, name):
+    """The round-5 advisor's race: femto's own tables come back (an upload under the handle's lock) and go again (over budget) while
+    other threads search on the derived layouts and copy the device descriptor for their launches.  Six threads on ONE handle whose
+    budget sits between what it holds and that + the lines: two search (count + locate, host and device forms), two ask LOCATION
+    leaves (lines up, then released again), one takes forward steps, one count-only leaves (never needs the lines) -- every answer
+    equals the goldens, nothing hangs, and the handle ends where it started."""
+    import threading
+    fx = fixtures(name)
+    g = fx.gold
+    plen, flat, starts = fx.patterns
+    kept = femto_amd.Index(fx.index, device=0, options=dict(wavelet_lines=1))
+    rows = np.arange(kept.info.total_length, dtype=np.int64)
+    kch, krow, koff = kept.forward_steps(rows[:256])
+    fixed = dict(level_table=0, text=0, rank_units=0, mark_every=5, char_rank_lines=0, context_table=0)
+    probe = femto_amd.Index(fx.index, device=0, options=dict(fixed, hbm_budget_bytes=1 << 30))
+    t_probe = probe.structures()["hbm_allocated"]
+    probe.close()
+    kept.close()
+    for budget in (t_probe + 64, 1 << 30):                   # the lines never fit / always fit
+        ix = femto_amd.Index(fx.index, device=0, options=dict(fixed, hbm_budget_bytes=int(budget)))
+        t0 = ix.structures()["hbm_allocated"]
+        assert t0 == t_probe and ix.rank_mode in (3, 4)
+        errors = []
+
+        def guard(fn):
+            def run():
+                try:
+                    for _ in range(12):
+                        fn()
+                except Exception as ex:      # noqa: BLE001
+                    errors.append(repr(ex))
+            return run
+
+        def search():
+            f, l = ix.count_flat(plen, flat, starts)
+            assert np.array_equal(f, g["count_first"]) and np.array_equal(l, g["count_last"])
+            for mo, g_noccs, g_offs in fx.locate_cases():
+                n_, o_ = ix.locate_flat(plen, flat, starts, mo)
+                assert np.array_equal(n_, g_noccs) and np.array_equal(o_, g_offs), mo
+
+        def chain():
+            for mo, g_noccs, g_offs in fx.locate_cases():
+                df, dl, dn, dst, do, dtot = device_locate(ix, plen, flat, starts, mo, len(g_offs) + 16)
+                assert dtot == len(g_offs) and np.array_equal(df, g["count_first"]) and np.array_equal(dn, g_noccs) and np.array_equal(do, g_offs), mo
+
+        def leaves():
+            ch, occ, off = ix.block_requests(rows)
+            assert np.array_equal(ch, g["L"]) and np.array_equal(occ, g["occ"]) and np.array_equal(off, g["off"])
+
+        def forward():
+            fch, frow, foff = ix.forward_steps(rows[:256])
+            assert np.array_equal(fch, kch) and np.array_equal(frow, krow) and np.array_equal(foff, koff)
+
+        def count_leaves():
+            ch, occ, off = ix.block_requests(rows, location=False)
+            assert off is None and np.array_equal(ch, g["L"]) and np.array_equal(occ, g["occ"])
+
+        threads = [threading.Thread(target=guard(fn)) for fn in (search, chain, leaves, leaves, forward, count_leaves)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(timeout=300)
+        assert not any(th.is_alive() for th in threads), "a caller hangs"
+        assert not errors, errors[:3]
+        held = ix.structures()["hbm_allocated"]
+        assert held <= budget and (held == t0 if budget < (1 << 30) else held >= t0), (budget, t0, held)
+        search()
+        ix.close()
+
+
 def test_budget_environment_variable_is_validated(fixtures, gpu_ok, monkeypatch):
     """FEMTO_AMD_HBM_BUDGET: bytes with an optional k / M / G / T suffix, or "all" in any case; anything else is not a budget and the
     default bound applies (atoll() used to read "8G" as 8 bytes and "ALL" as 0: every optional structure silently declined)."""
