@@ -352,6 +352,34 @@ def test_row_free_locate_device(fixtures, gpu_ok, name):
         ix.close()
 
 
+@pytest.mark.parametrize("env", [dict(FEMTO_AMD_SA32_DENSE="0"), dict(FEMTO_AMD_KTAB_SA1="0"), dict(FEMTO_AMD_SA32_DENSE="0", FEMTO_AMD_KTAB_SA1="0")])
+@pytest.mark.parametrize("name", INDEX_FIXTURES)
+def test_big_index_forms_on_the_fixtures(fixtures, gpu_ok, monkeypatch, name, env):
+    """What only indexes above 2^31 / 2^32 rows take by themselves -- 8-byte suffix-array / inverse entries, level-table entries
+    without a text position -- forced on the fixtures (the knobs the A/B runs of profiles/tuning_history.md used): goldens for every
+    clamp through the host path, the device chain and its row-free form, dense and sampled arrays."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    fx = fixtures(name)
+    g = fx.gold
+    plen, flat, starts = fx.patterns
+    for kw in (dict(hbm_budget_bytes=femto_amd.BUDGET_ALL), dict(hbm_budget_bytes=femto_amd.BUDGET_ALL, tail_min=2, tail_ones=0), dict(dense_arrays=0, tail_min=2)):
+        ix = femto_amd.Index(fx.index, device=0, options=kw)
+        pi = ix.pack_info()
+        if "FEMTO_AMD_SA32_DENSE" in env and ix.rank_mode in (3, 4):
+            assert not pi["sa_32bit"], pi
+        f, l = ix.count_flat(plen, flat, starts)
+        assert np.array_equal(f, g["count_first"]) and np.array_equal(l, g["count_last"]), (kw, env)
+        for mo, g_noccs, g_offs in fx.locate_cases():
+            n_, o_ = ix.locate_flat(plen, flat, starts, mo)
+            assert np.array_equal(n_, g_noccs) and np.array_equal(o_, g_offs), (kw, env, mo)
+            df, dl, dn, dst, do, dtot = device_locate(ix, plen, flat, starts, mo, len(g_offs) + 16)
+            assert dtot == len(g_offs) and np.array_equal(df, g["count_first"]) and np.array_equal(dl, g["count_last"]), (kw, env, mo)
+            assert np.array_equal(dn, g_noccs) and np.array_equal(do, g_offs), (kw, env, mo)
+            assert_row_free_equals(ix, plen, flat, starts, mo, g_noccs, g_offs, (name, kw, env, mo))
+        ix.close()
+
+
 @pytest.mark.parametrize("name", ["acgt48k", "eng2doc", "runs3doc"])
 def test_keys_device_path_equals_symbol_path(fixtures, gpu_ok, name):
     """femto_amd_pack_keys_device + femto_amd_locate_keys_device: patterns as 64-bit keys, ranges as int32 pairs -- the same

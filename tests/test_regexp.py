@@ -213,6 +213,21 @@ def test_nfa_search_batch_equals_reference_goldens(fixtures, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env", [dict(FEMTO_AMD_NFA_LPT="0"), dict(FEMTO_AMD_NFA_FAIR="0"), dict(FEMTO_AMD_NFA_LPT="0", FEMTO_AMD_NFA_FAIR="0", FEMTO_AMD_NFA_STATS="1")])
+@pytest.mark.parametrize("name", ["acgt48k", "eng2doc"])
+def test_nfa_batch_order_and_fair_share_do_not_change_results(fixtures, monkeypatch, name, env):
+    """the batch handed out in the caller's order instead of longest-predicted-first, and without the fair share between concurrent
+    kernels (the A/B knobs of profiles/r06_regexp_concurrent.txt): the same golden result lists"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    fx = fixtures(name)
+    cases = load_regexp_golden(name)
+    ix = femto_amd.Index(fx.index, device=0)
+    _check_batch(ix, cases, (name, env))
+    ix.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["acgt48k", "eng2doc"])
 def test_concurrent_callers_share_the_workgroups(fixtures, name):
     """Several threads call femto_amd_nfa_search_batch on ONE handle at once (the reference keeps many do_regexp_query state
