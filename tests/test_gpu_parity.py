@@ -453,6 +453,42 @@ def _keys_device_path(fx, g, ix):
     ix.close()
 
 
+@pytest.mark.parametrize("name", ["acgt48k", "eng2doc", "bytes256", "runs3doc", "b1000"])
+def test_budget_sweep_every_plan_answers_the_goldens(fixtures, gpu_ok, name):
+    """hbm_budget_bytes from a few KB to more than everything in 28 geometric steps: whatever the planner of api_open.hip makes of a
+    budget -- marks of three densities, plain or marked rank units, the text with dense, half-dense (4-byte suffix array + a sampled
+    inverse) or sampled arrays, level tables of every depth, context tables, femto's own tables released or kept -- the handle
+    holds no more than it may (once the budget covers the block images and the smallest layout) and count, locate, the device chain
+    and its row-free form return the goldens.  Several distinct plans must really have been seen."""
+    fx = fixtures(name)
+    g = fx.gold
+    plen, flat, starts = fx.patterns
+    every = femto_amd.Index(fx.index, device=0, options=dict(hbm_budget_bytes=femto_amd.BUDGET_ALL))
+    top = every.structures()["hbm_allocated"]
+    every.close()
+    plans, within = set(), 0
+    for k in range(28):
+        budget = int(20_000 * (1.6 * top / 20_000) ** (k / 27.0))
+        ix = femto_amd.Index(fx.index, device=0, options=dict(hbm_budget_bytes=budget))
+        st, pi = ix.structures(), ix.pack_info()
+        plans.add((ix.rank_mode, pi["sa_full"], pi["isa_full"], pi.get("rank_units", False), pi.get("rank_units_marked", False), pi["ktab_syms"], st["mark_every"],
+                   st["image"] == 0, st["text_sa_isa"] > 0, st["context_tables"] > 0, st["char_rank_lines"] > 0))
+        within += int(st["hbm_allocated"] <= budget)
+        assert st["hbm_allocated"] <= max(budget, top), (budget, st)
+        f, l = ix.count_flat(plen, flat, starts)
+        assert np.array_equal(f, g["count_first"]) and np.array_equal(l, g["count_last"]), (budget, st)
+        for mo, g_noccs, g_offs in fx.locate_cases():
+            n_, o_ = ix.locate_flat(plen, flat, starts, mo)
+            assert np.array_equal(n_, g_noccs) and np.array_equal(o_, g_offs), (budget, mo, st)
+            df, dl, dn, dst, do, dtot = device_locate(ix, plen, flat, starts, mo, len(g_offs) + 16)
+            assert dtot == len(g_offs) and np.array_equal(df, g["count_first"]) and np.array_equal(dl, g["count_last"]), (budget, mo)
+            assert np.array_equal(dn, g_noccs) and np.array_equal(do, g_offs), (budget, mo, st)
+            assert_row_free_equals(ix, plen, flat, starts, mo, g_noccs, g_offs, (name, budget, mo))
+        ix.close()
+    if any(p_[0] in (3, 4) for p_ in plans):      # (an alphabet of more than 256 characters runs on femto's own tables: one plan)
+        assert len(plans) >= 4 and within >= 10, (len(plans), within, sorted(plans))
+
+
 @pytest.mark.parametrize("name", ["acgt48k", "eng2doc"])
 def test_open_with_options(fixtures, gpu_ok, name):
     """femto_amd_open_opts: what is derived is the caller's decision -- a level table of a given depth, none at all, no dense
