@@ -16,6 +16,12 @@ from oracle import pyoracle as po
 pytestmark = pytest.mark.gpu
 
 
+def _drop(path):
+    """the index files of a finished test (pytest keeps tmp_path until the session ends: the 8 GiB test below needs the scratch disk)"""
+    import shutil
+    shutil.rmtree(path, ignore_errors=True)
+
+
 def test_full_size_1gib_properties(tmp_path, gpu_ok):
     """BASELINE configs[1] at FULL size (1 GiB random-ACGT text, reference default parameters), checked through
     size-independent properties plus an oracle spot check:
@@ -131,6 +137,7 @@ def test_full_size_1gib_properties(tmp_path, gpu_ok):
     ns, os_ = sx.locate_flat(plen, flat, starts, 100)
     assert np.array_equal(ns, noccs) and np.array_equal(os_, offs)
     sx.close()
+    _drop(path)
 
 
 def test_full_size_text96_properties(tmp_path, gpu_ok):
@@ -257,6 +264,7 @@ def test_full_size_text96_properties(tmp_path, gpu_ok):
         assert_row_free_equals(bx, qlen, qflat, qstarts, 100, n4, o4, ("hit / miss batch", opts))
         assert_row_free_equals(bx, plen, flat, starts, 20, noccs, offs, ("sampled batch", opts))
         bx.close()
+    _drop(path)
 
 
 @pytest.mark.parametrize("kind,n", [("acgt", (1 << 31) - 1), ("acgt", (3 << 30) - 7), ("eng", (5 << 29) + 3)])
@@ -350,6 +358,7 @@ def test_four_byte_suffix_arrays_between_2_and_4_gib(tmp_path, gpu_ok, kind, n):
         assert_row_free_equals(bx, plen, flat, starts, mo, noccs, offs, (kind, n, "sampled", opts))
         assert_row_free_equals(bx, qlen, qflat, qstarts, 100, qn, qo, (kind, n, "miss", opts))
         bx.close()
+    _drop(path)
 
 
 def test_full_size_8gib_properties(tmp_path, gpu_ok):
