@@ -32,6 +32,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this pool's hosts: the driver only supports dmabuf IPC (RCCL between ranks, stripes shared between processes)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 from benchlib import extras as bx  # noqa: E402
 from benchlib.batch import Batch, _EventWork  # noqa: E402
